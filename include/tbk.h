@@ -1,0 +1,176 @@
+/*
+ * tbk.h — C-ABI of libtbk_hip.so: the MI355X-native classify-by-kmers hot path.
+ *
+ * This is the drop-in boundary.  The reference crosses from Python into native code
+ * through ctypes (src/trio_binning/kmers.py:30-86) into the symbols of c/kmers.c; every
+ * entry point below names the reference interface it replaces.  Plain C types only:
+ * pointers, sizes, opaque handles.  No torch types, no C++ in the signatures.
+ *
+ * Conventions
+ *   - Functions returning int return TBK_OK (0) or a negative tbk_status; the message for
+ *     the calling thread's last failure is tbk_last_error().
+ *   - Handles are opaque, created/destroyed explicitly (the reference leaks its tables:
+ *     c/kmers.c:164-172 has no destroy).
+ *   - "Host" pointers are ordinary process memory; "device" pointers are HIP device
+ *     memory on the handle's device.  The library never keeps a caller pointer after the
+ *     call returns, except between tbk_stream_submit and the matching tbk_stream_wait.
+ *   - A read batch is `bases` = the reads' ASCII bytes back to back, and
+ *     `offsets[n_reads+1]`: read i is bases[offsets[i] .. offsets[i+1]).  No separators,
+ *     no terminators.  Counts come back as int32 counts[n_reads][2] = {hapA, hapB}.
+ *   - Any byte outside {A,C,G,T} (upper case) invalidates every window that contains it:
+ *     such a window scores no hit (the reference is undefined there — c/kmers.c:78-91,279;
+ *     its docstring restricts reads to [ACGT], kmers.py:134-135).
+ *   - Everything that computes on the GPU fails with TBK_ERR_NO_DEVICE when no MI355X is
+ *     visible.  There is no CPU fallback in this library.
+ */
+#ifndef TBK_H
+#define TBK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBK_ABI_VERSION 1
+
+typedef enum tbk_status {
+    TBK_OK = 0,
+    TBK_ERR_INVALID = -1,   /* bad argument (k out of 1..32, NULL, mismatched k, ...)       */
+    TBK_ERR_IO = -2,        /* file missing / unreadable (Python side raises IOError,       */
+                            /*   as kmers.py:117-118 does)                                  */
+    TBK_ERR_FORMAT = -3,    /* malformed k-mer list (empty file, line shorter than k)       */
+    TBK_ERR_NO_DEVICE = -4, /* no usable HIP device                                         */
+    TBK_ERR_HIP = -5,       /* a HIP runtime call failed                                    */
+    TBK_ERR_NOMEM = -6,
+    TBK_ERR_STATE = -7      /* call sequence error (wait without submit, ...)               */
+} tbk_status;
+
+typedef struct tbk_table tbk_table;           /* one k-mer list resident in HBM           */
+typedef struct tbk_classifier tbk_classifier; /* (hapA, hapB) + streams + staging buffers */
+
+/* ---- library ---------------------------------------------------------------------- */
+int tbk_abi_version(void);
+const char *tbk_last_error(void);
+int tbk_device_count(int *count);
+/* Short description of device `device` ("gfx950 AMD Instinct MI355X, 256 CUs, 288 GB"). */
+int tbk_device_name(int device, char *buf, size_t buflen);
+
+/* ---- unit-level API kept for parity with the reference's ctypes surface ------------ */
+/* Replaces kmer_to_int (c/kmers.c:50-72; bound kmers.py:75-82): base i -> bits 2i..2i+1,
+ * A=0 C=1 G=2 T=3, any other byte contributes 0.  Host code. */
+uint64_t tbk_kmer_to_int(const char *kmer, unsigned char k);
+/* Replaces reverse_complement (c/kmers.c:74-93; bound kmers.py:85-93): out[k-1-i] =
+ * complement(in[i]); a non-ACGT byte leaves out[k-1-i] untouched.  Host code. */
+void tbk_reverse_complement(const char *kmer_in, char *kmer_out, unsigned char k);
+
+/* ---- k-mer tables ------------------------------------------------------------------- */
+/* Replaces create_kmer_hash_set (c/kmers.c:185-229; bound kmers.py:62-64,104-122) with
+ * peek_at_file's rules (c/kmers.c:124-146): k = length of the first line as getline()
+ * returns it, minus one; every line is one k-mer (duplicates counted, a last line without
+ * '\n' counted); each line contributes its first k bytes, verbatim (no canonicalisation).
+ * The keys are inserted into an open-addressing table of 64-bit slots in HBM on `device`. */
+int tbk_table_create_from_file(const char *path, int device, tbk_table **out);
+/* Same table from already-packed keys in host memory.  `num_lines` is what
+ * tbk_table_num_kmers will report (pass n when the keys are one-per-line). */
+int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, uint64_t num_lines,
+                               int device, tbk_table **out);
+/* Same, keys already in device memory on `device` (bench generator, N3 GPU parser). */
+int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, uint64_t num_lines,
+                                      int device, tbk_table **out);
+void tbk_table_destroy(tbk_table *t);
+/* Replaces the field read hash_set->num_kmers (kmers.py:157-159): number of list LINES. */
+uint64_t tbk_table_num_kmers(const tbk_table *t);
+int tbk_table_k(const tbk_table *t);
+int tbk_table_device(const tbk_table *t);
+/* Distinct keys stored, bytes of HBM held, number of 64-byte bucket lines. */
+uint64_t tbk_table_distinct(const tbk_table *t);
+uint64_t tbk_table_bytes(const tbk_table *t);
+uint64_t tbk_table_buckets(const tbk_table *t);
+/* Membership of raw packed keys (no canonicalisation): out[i] = 1/0.  Host pointers. */
+int tbk_table_contains(const tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+/* Replaces count_kmers_in_read (c/kmers.c:270-299; bound kmers.py:66-73,125-154) for one
+ * read: `read` is `len` bytes (len < 0: NUL-terminated).  Uses hap_a's k for both tables,
+ * hapA wins when a k-mer is in both lists. */
+int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *hap_a,
+                            const tbk_table *hap_b, int *count_a, int *count_b);
+
+/* Batch path (what the per-read Python loop classify_by_kmers.py:99-102 becomes). */
+int tbk_classifier_create(const tbk_table *hap_a, const tbk_table *hap_b, tbk_classifier **out);
+void tbk_classifier_destroy(tbk_classifier *c);
+
+/* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
+int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
+                       uint64_t n_reads, int32_t *counts);
+
+/* Streaming: up to tbk_stream_depth() batches in flight; H2D of batch i+1 runs on a side
+ * stream while the kernel of batch i runs.  submit returns a ticket; wait blocks until
+ * that batch's counts are in `counts` (the pointer given at submit).  Tickets complete in
+ * submission order.  `bases`/`offsets`/`counts` must stay valid until wait returns; buffers
+ * from tbk_host_alloc are pinned and are copied without an intermediate staging copy. */
+int tbk_stream_depth(const tbk_classifier *c);
+int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
+                      uint64_t n_reads, int32_t *counts, uint64_t *ticket);
+int tbk_stream_wait(tbk_classifier *c, uint64_t ticket);
+void *tbk_host_alloc(size_t bytes);  /* pinned host memory (hipHostMalloc) */
+void tbk_host_free(void *p);
+
+/* Device-resident form (inputs already in HBM: bench.py's timed region, and callers that
+ * produce reads on the GPU).  Asynchronous on the classifier's compute stream;
+ * tbk_classifier_sync waits for it. */
+int tbk_classify_device(tbk_classifier *c, const void *d_bases, const void *d_offsets,
+                        uint64_t n_reads, uint64_t total_bases, void *d_counts);
+int tbk_classifier_sync(tbk_classifier *c);
+
+/* HIP-event timing of the probe kernel on the stream it is launched on.  While enabled,
+ * every probe-kernel launch of this classifier is bracketed by an event pair; read
+ * returns the number of launches and their summed duration since enable, and resets. */
+int tbk_kernel_timing_enable(tbk_classifier *c, int on);
+int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms);
+
+/* Replaces calculate_scaling_factors (classify_by_kmers.py:57-77) and the binning rule
+ * (classify_by_kmers.py:104-115): float64, same operation order (1.0*max/n, count*factor,
+ * strict > both ways, else 'U').  Host code; bins[i] in {'A','B','U'}. */
+int tbk_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64_t num_kmers_a,
+                      uint64_t num_kmers_b, double *score_a, double *score_b, char *bins);
+
+/* ---- device memory helpers for callers without a HIP binding (bench.py, tests) ------- */
+int tbk_device_alloc(int device, size_t bytes, void **d_ptr);
+int tbk_device_free(int device, void *d_ptr);
+int tbk_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes);
+int tbk_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes);
+int tbk_device_sync(int device);
+int tbk_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
+/* ---- synthetic workload generators (BASELINE.json's bench inputs) -------- */
+/* Writes keys i in [first, first+n) of the deterministic k-mer sequence for `seed`: each
+ * is a distinct canonical k-mer (distinct i -> distinct k-mer), packed as above. */
+int tbk_synth_keys_device(int device, uint64_t seed, uint64_t first, uint64_t n, int k, void *d_keys);
+/* Host restatement of the same sequence (tests, small sizes). */
+int tbk_synth_keys_host(uint64_t seed, uint64_t first, uint64_t n, int k, uint64_t *keys);
+/* Fills d_bases with n_reads reads of read_len uniform random ACGT and plants list k-mers
+ * (random strand, non-overlapping slots): a read's origin is A/B/none with p .45/.45/.10;
+ * origin reads get `plant_major` k-mers of their list and `plant_minor` of the other,
+ * origin-less reads get plant_minor+plant_minor.  d_offsets gets n_reads+1 uint64.
+ * Keys [0,n_a) of `key_seed` are list A, [n_a, n_a+n_b) list B. */
+int tbk_synth_reads_device(int device, uint64_t read_seed, uint64_t first_read, uint64_t n_reads,
+                           uint32_t read_len, uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k,
+                           int plant_major, int plant_minor, void *d_bases, void *d_offsets);
+
+/* ---- roofline calibration (SURVEY §8d "random-read roofline") -------------------------- */
+/* Independent uniformly random line-aligned loads over a `footprint_bytes` buffer:
+ * `line_bytes` in {64,128}, `lanes_per_line` in {1,4,8} (16 B per lane when >1, the whole
+ * line per lane when 1), `loads_in_flight` per lane in 1..8.  Reports lines/s. */
+int tbk_calib_gather(int device, uint64_t footprint_bytes, int line_bytes, int lanes_per_line,
+                     int loads_in_flight, uint64_t n_lines, int reps, double *lines_per_sec,
+                     double *ms_per_rep);
+/* Streaming read of the same buffer (the 6.3 TB/s figure on this box). */
+int tbk_calib_stream(int device, uint64_t footprint_bytes, int reps, double *bytes_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBK_H */

@@ -1,0 +1,315 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the oracle on the
+same inputs — bit-exact (integer counts).  Marked gpu: they need a real MI355X."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, load_golden
+
+pytestmark = pytest.mark.gpu
+
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+def _rc(s):
+    return s.translate(COMP)[::-1]
+
+
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def _pack(reads):
+    from trio_binning_amd import kmers
+
+    return kmers.pack_reads(reads)
+
+
+def _rand_reads(rng, n_reads, max_len, plants, k, p_plant=0.7):
+    reads = []
+    for _ in range(n_reads):
+        n = int(rng.integers(0, max_len + 1))
+        s = list("".join("ACGT"[c] for c in rng.integers(0, 4, n)))
+        if plants and n >= k and rng.random() < p_plant:
+            for _ in range(int(rng.integers(1, 8))):
+                km = plants[int(rng.integers(0, len(plants)))]
+                if rng.random() < 0.5:
+                    km = _rc(km)
+                p = int(rng.integers(0, n - k + 1))
+                s[p:p + k] = km
+        reads.append("".join(s))
+    return reads
+
+
+# ---- reference KATs through the product API -------------------------------------------------
+def test_reference_kats(gpu, capfd):
+    # reference tests/test_kmers.py:8-25
+    from trio_binning_amd import kmers
+
+    a = kmers.create_kmer_hash_set(os.path.join(DATA, "hapA.txt"))
+    b = kmers.create_kmer_hash_set(os.path.join(DATA, "hapB.txt"))
+    assert kmers.get_number_kmers_in_set(a) == 4
+    assert kmers.get_number_kmers_in_set(b) == 3
+    assert a.k == 21 and a.contents.num_kmers == 4
+    read = "CTTATCATGTCTTTGTTTTCAAAGCTTCTTAGAGGTTTTTTTTTTTGGTGTTAATTGGCATAAATTATGGCT"
+    assert kmers.count_kmers_in_read(read, a, b) == (2, 1)
+    g = load_golden("kat.json")
+    for case in g["count_kmers_in_read"]:
+        assert list(kmers.count_kmers_in_read(case["read"], a, b)) == case["counts"]
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_golden_differential_vectors(gpu, tmp_path, idx):
+    """Counts recorded from the real reference, k in {5,13,21,27,31,32}, with duplicate,
+    in-both-lists and non-canonical list lines."""
+    from trio_binning_amd import kmers
+
+    v = load_golden("diff_vectors.json")[idx]
+    a = kmers.HashSet.from_file(_write(tmp_path, "a.txt", "".join(x + "\n" for x in v["list_a"])))
+    b = kmers.HashSet.from_file(_write(tmp_path, "b.txt", "".join(x + "\n" for x in v["list_b"])))
+    assert [a.num_kmers, b.num_kmers] == v["num_kmers"] and a.k == v["k"]
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_reads(v["reads"])
+    assert got.tolist() == v["counts"]
+    # the single-read entry point too (first 25 reads)
+    for r, c in list(zip(v["reads"], v["counts"]))[:25]:
+        assert list(kmers.count_kmers_in_read(r, a, b)) == c
+
+
+def test_golden_edge_vectors(gpu, tmp_path):
+    from trio_binning_amd import kmers
+
+    for case in load_golden("edge_vectors.json"):
+        a = kmers.HashSet.from_file(_write(tmp_path, "a.txt", case["text_a"]))
+        b = kmers.HashSet.from_file(_write(tmp_path, "b.txt", case["text_b"]))
+        assert [a.num_kmers, b.num_kmers] == case["num_kmers"], case["name"]
+        assert a.k == case["k"], case["name"]
+        with kmers.Classifier(a, b) as cls:
+            got = cls.classify_reads(case["reads"])
+        assert got.tolist() == case["counts"], case["name"]
+
+
+# ---- seeded random inputs against the oracle ----------------------------------------------------
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 15, 16, 17, 21, 27, 31, 32])
+def test_random_vs_oracle(gpu, orc, tmp_path, k):
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(1000 + k)
+    n_list = min(200, 4 ** k // 2 + 2)
+    la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(n_list)]
+    lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(n_list)] + la[:2]
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "\n".join(lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    assert (a.num_kmers, b.num_kmers, a.k) == (oa.num_kmers, ob.num_kmers, oa.k)
+    reads = _rand_reads(rng, 300, 3000, la + lb, k)
+    reads += ["", "A", "ACGT" * 300, la[0], _rc(la[0]), la[0] * 3]
+    bases, offs = _pack(reads)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+    want = orc.count_batch(bases, offs, oa, ob)
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:10]
+    assert want.sum() > 0
+
+
+def test_ragged_batch_shapes(gpu, orc, tmp_path):
+    """Empty batch, empty reads, many tiny reads, reads around the 1024-window pass size and
+    the 16-base chunk size, one long read: per-read attribution at every boundary."""
+    from trio_binning_amd import kmers
+
+    k = 21
+    rng = np.random.default_rng(5)
+    la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(50)]
+    lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(50)]
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+
+    def dense(n):  # a read made of list k-mers back to back, both strands
+        s = ""
+        while len(s) < n:
+            km = (la + lb)[int(rng.integers(0, 100))]
+            s += km if rng.random() < 0.5 else _rc(km)
+        return s[:n]
+
+    shapes = {
+        "empty_batch": [],
+        "only_empty_reads": ["", "", ""],
+        "tiny_reads": [dense(int(n)) for n in rng.integers(0, 60, 2000)],
+        "around_pass": [dense(n) for n in (1003, 1004, 1023, 1024, 1025, 1044, 1045, 2047, 2048, 2049, 15, 16, 17, 31, 32, 33)],
+        "one_long": [dense(300_000)],
+        "mixed": [dense(int(n)) for n in rng.integers(0, 5000, 300)] + [""] * 5 + [dense(70_000)] + [dense(20), dense(21)],
+    }
+    with kmers.Classifier(a, b) as cls:
+        for name, reads in shapes.items():
+            bases, offs = _pack(reads)
+            got = cls.classify_batch(bases, offs)
+            want = orc.count_batch(bases, offs, oa, ob)
+            assert got.shape == want.shape, name
+            assert np.array_equal(got, want), (name, np.nonzero((got != want).any(axis=1))[0][:10])
+
+
+def test_non_acgt_policy(gpu, orc, tmp_path):
+    """Documented deviation (reference is undefined there): a window containing a byte
+    outside ACGT scores no hit; the oracle implements the same policy."""
+    from trio_binning_amd import kmers
+
+    fa, fb = os.path.join(DATA, "hapA.txt"), os.path.join(DATA, "hapB.txt")
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    km_a, km_b = "ACCTCTAAGAAGCTTTGAAAA", "AACACCAAAAAAAAAAACCTC"
+    rng = np.random.default_rng(9)
+    reads = [km_a, "N" + km_a + "N", km_a[:10] + "N" + km_a[11:], km_a.lower(), km_a + "n" + km_b,
+             km_a + "\n" + km_b, "*" * 50, km_b + "-" + km_b[::-1]]
+    for _ in range(200):
+        n = int(rng.integers(30, 500))
+        s = list("".join("ACGTNacgt*-"[c] for c in rng.choice(11, n, p=[.22, .22, .22, .22, .04, .02, .02, .01, .01, .01, .01])))
+        p = int(rng.integers(0, n - 21))
+        s[p:p + 21] = km_a if rng.random() < 0.5 else _rc(km_b)
+        reads.append("".join(s))
+    bases, offs = _pack(reads)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+    want = orc.count_batch(bases, offs, oa, ob, strict=True)
+    assert np.array_equal(got, want)
+    assert got[0].tolist() == [1, 0] and got[2].tolist() == [0, 0] and got[3].tolist() == [0, 0]
+
+
+def test_list_parser_rules(gpu, orc, tmp_path):
+    """peek_at_file / getline rules (c/kmers.c:124-146): k from the first line, duplicates
+    counted, last line without newline counted, over-long lines use their first k bytes,
+    bytes outside ACGT pack as 0 ('A'), CRLF lists get k+1."""
+    from trio_binning_amd import kmers
+
+    cases = {
+        "dups": "ACGTACGTAC\nACGTACGTAC\nTTTTTTTTTT\nGGGGGGGGGG\n",
+        "no_final_newline": "ACGTACGTAC\nCCCCCCCCCC\nGGGTGGGTGG\nAAAAAAAAAC",
+        "long_lines": "ACGTACGTAC\nACGTACGTACGGGG\nTTTTTTTTTTA\nCCCCCCCCCC\n",
+        "non_acgt_in_list": "ACGTACGTAC\nACGNACGTAC\nacgtacgtac\nCCCCCCCCCC\n",
+        "crlf": "ACGTACGTAC\r\nCCCCCCCCCC\r\nGGGGGGGGGG\r\nTTTTTTTTTA\r\n",
+        "k_equals_line_with_newline": "ACGT\nACG\nCCCC\nGGGG\n",
+    }
+    rng = np.random.default_rng(3)
+    reads = ["".join("ACGT"[c] for c in rng.integers(0, 4, 200)) for _ in range(50)]
+    reads += ["ACGTACGTAC", "ACGAACGTAC", "AAAAAAAAAA", "ACGTACGTACA", "GGGGGGGGGGA", "ACGA", "CCCCA", "TTTTTTTTTAA"]
+    bases, offs = _pack(reads)
+    other = _write(tmp_path, "other.txt", "GATTACAGAT\nGATTACAGAA\nGATTACAGAC\nGATTACAGAG\n")
+    for name, text in cases.items():
+        f = _write(tmp_path, name + ".txt", text)
+        oa, a = orc.table_from_file(f), kmers.HashSet.from_file(f)
+        assert (a.k, a.num_kmers) == (oa.k, oa.num_kmers), name
+        ob, b = orc.table_from_file(other), kmers.HashSet.from_file(other)
+        with kmers.Classifier(a, b) as cls:
+            got = cls.classify_batch(bases, offs)
+        assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob)), name
+    for bad in ("", "ACGTACGT\nACG\nACGTACGT\n", "A" * 33 + "\n"):
+        with pytest.raises(ValueError):
+            kmers.HashSet.from_file(_write(tmp_path, "bad.txt", bad))
+    with pytest.raises(IOError):
+        kmers.HashSet.from_file(str(tmp_path / "missing.txt"))
+
+
+def test_mismatched_k_uses_hap_a_k(gpu, orc, tmp_path):
+    """The reference uses haplotype_A->k for both sets (c/kmers.c:278-290)."""
+    from trio_binning_amd import kmers
+
+    fa = _write(tmp_path, "a.txt", "ACGTACGTACGT\nTTTTTTTTTTTT\nCCCCCCCCCCCA\nGGGGGGGGGGGA\n")
+    fb = _write(tmp_path, "b.txt", "ACGTACGTAC\nAAAAAAAAAA\nCCCCCCCCCA\nGGGGGGGGGA\n")  # k=10
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    reads = ["ACGTACGTACGTAAAAAAAAAAAAAAAAAAAA", "AAAAAAAAAAAA", "ACGTACGTACAA", "CCCCCCCCCAAAG"]
+    bases, offs = _pack(reads)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+    assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
+
+
+def test_table_membership_and_dedupe(gpu):
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 2**42, 200_000, dtype=np.uint64)
+    keys[1000:2000] = keys[:1000]  # duplicates
+    t = kmers.HashSet.from_keys(keys, 21)
+    assert t.num_kmers == keys.size
+    assert t.distinct == np.unique(keys).size
+    assert t.contains(keys).all()
+    absent = rng.integers(2**42, 2**43, 50_000, dtype=np.uint64)
+    assert not t.contains(absent).any()
+    # a crowded table: every line near full, lookups must walk
+    os.environ["TBK_TABLE_LOAD"] = "0.85"
+    try:
+        t2 = kmers.HashSet.from_keys(keys, 21)
+    finally:
+        del os.environ["TBK_TABLE_LOAD"]
+    assert t2.distinct == t.distinct and t2.contains(keys).all() and not t2.contains(absent).any()
+    assert t2.nbytes < t.nbytes
+
+
+def test_crowded_tables_walk_path(gpu, orc, tmp_path):
+    """Force the 'home line is full' continuation in the probe kernel (load 0.85)."""
+    from trio_binning_amd import kmers
+
+    k = 21
+    rng = np.random.default_rng(21)
+    la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(3000)]
+    lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(3000)]
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    os.environ["TBK_TABLE_LOAD"] = "0.9"
+    try:
+        a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    finally:
+        del os.environ["TBK_TABLE_LOAD"]
+    reads = _rand_reads(rng, 400, 4000, la + lb, k, p_plant=1.0)
+    bases, offs = _pack(reads)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+    want = orc.count_batch(bases, offs, oa, ob)
+    assert np.array_equal(got, want)
+    assert want.sum() > 1000
+
+
+def test_streaming_order_and_overlap(gpu, orc, tmp_path):
+    """submit/wait with several batches in flight returns each batch's own counts."""
+    from trio_binning_amd import _lib, kmers
+
+    fa, fb = os.path.join(DATA, "hapA.txt"), os.path.join(DATA, "hapB.txt")
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    lists = [l.strip() for l in open(fa)] + [l.strip() for l in open(fb)]
+    rng = np.random.default_rng(4)
+    batches = [_rand_reads(rng, int(rng.integers(1, 400)), 2500, lists, 21) for _ in range(7)]
+    with kmers.Classifier(a, b) as cls:
+        assert cls.depth >= 2
+        pending, results = [], []
+        for reads in batches:
+            if len(pending) == cls.depth:
+                results.append(cls.wait(pending.pop(0)))
+            pending.append(cls.submit(*_pack(reads)))
+        with pytest.raises(_lib.TbkError):  # ring full
+            for _ in range(cls.depth + 1):
+                pending.append(cls.submit(*_pack(batches[0])))
+        pending = pending[:cls.depth]
+        while pending:
+            results.append(cls.wait(pending.pop(0)))
+    for reads, got in zip(batches, results[:len(batches)]):
+        bases, offs = _pack(reads)
+        assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
+
+
+def test_score_and_bin_on_gpu_counts(gpu, orc):
+    from trio_binning_amd import kmers
+
+    counts = np.array([[4, 1], [0, 2], [0, 0], [3, 4], [7, 7]], dtype=np.int32)
+    sa, sb, bins = kmers.score_and_bin(counts, 4, 3)
+    osa, osb, obins = orc.score_and_bin(counts, 4, 3)
+    assert sa.tolist() == osa.tolist() and sb.tolist() == osb.tolist() and bins.decode() == obins
+    assert bins == b"ABUBB"

@@ -1,0 +1,124 @@
+"""Host logic of the CLI driver without a GPU: argument surface, help text, output-name
+rule, scaling factors, score formatting — against golden values from the reference."""
+import ctypes as C
+import os
+import re
+from unittest.mock import patch
+
+import numpy as np
+import pytest
+
+from conftest import DATA, ROOT, load_golden
+
+
+def test_help_text(built, capsys):
+    # reference tests/test_classify_by_kmers.py:10-16
+    from trio_binning_amd.classify_by_kmers import main
+
+    with patch("sys.argv", ["classify-by-kmers", "--help"]):
+        with pytest.raises(SystemExit):
+            main()
+    out, _ = capsys.readouterr()
+    assert "Classify reads into bins" in out
+    out = " ".join(out.split())  # argparse wraps lines
+    for flag, default in (("--haplotype-a-out-prefix", "hapA"), ("--haplotype-b-out-prefix", "hapB"),
+                          ("--unclassified-out-prefix", "unclassified"), ("--no-gzip-output", "False")):
+        assert flag in out
+        assert f"default: {default}" in out
+    for positional in ("reads", "haplotype_a_kmers", "haplotype_b_kmers"):
+        assert positional in out
+
+
+def test_alias_modules(built):
+    import trio_binning.classify_by_kmers as drop_in
+    import trio_binning_amd.classify as alias
+    import trio_binning_amd.classify_by_kmers as impl
+    from trio_binning import kmers as k1, seq as s1
+    from trio_binning_amd import kmers as k2, seq as s2
+
+    assert drop_in is impl and alias.main is impl.main and k1 is k2 and s1 is s2
+
+
+def test_missing_list_is_ioerror(built):
+    # reference kmers.py:117-118 raises IOError before touching native code
+    from trio_binning_amd import kmers
+
+    with pytest.raises(IOError):
+        kmers.create_kmer_hash_set("/nonexistent/hapA.txt")
+
+
+def test_output_extension_rule(built):
+    from trio_binning_amd.classify_by_kmers import output_extension
+
+    for name, ext in load_golden("cli_misc.json")["ext_rule"]:
+        assert output_extension(name) == ext, name
+
+
+def test_score_and_bin_matches_reference_floats(built):
+    from trio_binning_amd import kmers
+
+    for c in load_golden("cli_misc.json")["float_str"]:
+        sa, sb, bins = kmers.score_and_bin(np.array([[c["count_a"], c["count_b"]]], dtype=np.int32), c["num_a"], c["num_b"])
+        assert float(sa[0]).hex() == c["score_a_hex"] and float(sb[0]).hex() == c["score_b_hex"]
+        assert f"{float(sa[0])!s}" == c["score_a"] and f"{float(sb[0])!s}" == c["score_b"]
+        assert bins.decode() == c["bin"]
+
+
+def test_unit_level_host_functions(built):
+    """kmer_to_int / reverse_complement are host code in the C-ABI (no GPU needed)."""
+    from trio_binning_amd import kmers
+
+    g = load_golden("kat.json")
+    for s, v in g["kmer_to_int"]:
+        assert kmers.kmer_to_int(s) == v, s
+    for s, r in g["reverse_complement"]:
+        assert kmers.reverse_complement(s) == r, s
+    assert kmers.reverse_complement("ACNGT") == "ACxGT"
+
+
+def test_pack_reads(built):
+    from trio_binning_amd import kmers
+
+    bases, offs = kmers.pack_reads(["ACGT", "", "GG"])
+    assert bytes(bases) == b"ACGTGG" and offs.tolist() == [0, 4, 4, 6]
+    bases, offs = kmers.pack_reads([])
+    assert bases.size == 0 and offs.tolist() == [0]
+
+
+def test_abi_exports_every_declared_symbol(built):
+    """The C-ABI library loads without a GPU and exports every function include/tbk.h
+    declares (no compute calls here)."""
+    hdr = open(os.path.join(ROOT, "include", "tbk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tbk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 35
+    lib = C.CDLL(os.path.join(ROOT, "trio_binning_amd", "libtbk_hip.so"))
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    lib.tbk_abi_version.restype = C.c_int
+    assert lib.tbk_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(built):
+    """Without a device every compute entry point fails with an error — never a silent CPU
+    path.  (On a GPU box this test checks the opposite: a device is found.)"""
+    from trio_binning_amd import _lib, kmers
+
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    with pytest.raises(_lib.TbkError) as ei:
+        kmers.HashSet.from_file(os.path.join(DATA, "hapA.txt"))
+    assert ei.value.code == _lib.TBK_ERR_NO_DEVICE
+    with pytest.raises(_lib.TbkError):
+        kmers.HashSet.from_keys(np.arange(10, dtype=np.uint64), 21)
+
+
+def test_product_never_imports_oracle():
+    """The product tree must not reference oracle/ in any way."""
+    pkg = os.path.join(ROOT, "trio_binning_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle[/.]", r"kmers_oracle", r"\borc_\w+\("):
+                    assert not re.search(pat, text), (os.path.join(dirpath, f), pat)

@@ -1,0 +1,136 @@
+"""ctypes loader for libtbk_hip.so (the C-ABI in include/tbk.h).
+
+Mirrors the reference's loader (src/trio_binning/kmers.py:30-38: find the native library
+beside the module, ``ImportError`` when it is missing) with one difference that matters:
+there is exactly one backend.  If the HIP library is absent this module raises; nothing
+in this package falls back to a CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_NAME = "libtbk_hip.so"
+
+TBK_OK = 0
+TBK_ERR_INVALID = -1
+TBK_ERR_IO = -2
+TBK_ERR_FORMAT = -3
+TBK_ERR_NO_DEVICE = -4
+TBK_ERR_HIP = -5
+TBK_ERR_NOMEM = -6
+TBK_ERR_STATE = -7
+
+
+class TbkError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libtbk_hip: {message} (status {code})")
+        self.code = code
+        self.message = message
+
+
+def _find():
+    override = os.environ.get("TBK_LIBRARY")
+    if override:
+        return override
+    return os.path.join(_HERE, _NAME)
+
+
+_path = _find()
+if not os.path.isfile(_path):
+    raise ImportError(
+        f"Cannot load {_NAME}: {_path} does not exist. Build it with "
+        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C trio_binning_amd/csrc`. "
+        "This package has no CPU fallback."
+    )
+lib = C.CDLL(_path)
+
+_vp = C.c_void_p
+_u64 = C.c_uint64
+_u64p = C.POINTER(C.c_uint64)
+_i32p = C.POINTER(C.c_int32)
+_dp = C.POINTER(C.c_double)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("tbk_abi_version", C.c_int)
+_sig("tbk_last_error", C.c_char_p)
+_sig("tbk_device_count", C.c_int, C.POINTER(C.c_int))
+_sig("tbk_device_name", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
+_sig("tbk_kmer_to_int", _u64, C.c_char_p, C.c_ubyte)
+_sig("tbk_reverse_complement", None, C.c_char_p, C.c_char_p, C.c_ubyte)
+_sig("tbk_table_create_from_file", C.c_int, C.c_char_p, C.c_int, C.POINTER(_vp))
+_sig("tbk_table_create_from_keys", C.c_int, _vp, _u64, C.c_int, _u64, C.c_int, C.POINTER(_vp))
+_sig("tbk_table_create_from_device_keys", C.c_int, _vp, _u64, C.c_int, _u64, C.c_int, C.POINTER(_vp))
+_sig("tbk_table_destroy", None, _vp)
+_sig("tbk_table_num_kmers", _u64, _vp)
+_sig("tbk_table_k", C.c_int, _vp)
+_sig("tbk_table_device", C.c_int, _vp)
+_sig("tbk_table_distinct", _u64, _vp)
+_sig("tbk_table_bytes", _u64, _vp)
+_sig("tbk_table_buckets", _u64, _vp)
+_sig("tbk_table_contains", C.c_int, _vp, _vp, _u64, _vp)
+_sig("tbk_count_kmers_in_read", C.c_int, C.c_char_p, C.c_int64, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
+_sig("tbk_classifier_create", C.c_int, _vp, _vp, C.POINTER(_vp))
+_sig("tbk_classifier_destroy", None, _vp)
+_sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
+_sig("tbk_stream_depth", C.c_int, _vp)
+_sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)
+_sig("tbk_stream_wait", C.c_int, _vp, _u64)
+_sig("tbk_host_alloc", _vp, C.c_size_t)
+_sig("tbk_host_free", None, _vp)
+_sig("tbk_classify_device", C.c_int, _vp, _vp, _vp, _u64, _u64, _vp)
+_sig("tbk_classifier_sync", C.c_int, _vp)
+_sig("tbk_kernel_timing_enable", C.c_int, _vp, C.c_int)
+_sig("tbk_kernel_timing_read", C.c_int, _vp, _u64p, _dp)
+_sig("tbk_score_and_bin", C.c_int, _vp, _u64, _u64, _u64, _vp, _vp, _vp)
+_sig("tbk_device_alloc", C.c_int, C.c_int, C.c_size_t, C.POINTER(_vp))
+_sig("tbk_device_free", C.c_int, C.c_int, _vp)
+_sig("tbk_memcpy_h2d", C.c_int, C.c_int, _vp, _vp, C.c_size_t)
+_sig("tbk_memcpy_d2h", C.c_int, C.c_int, _vp, _vp, C.c_size_t)
+_sig("tbk_device_sync", C.c_int, C.c_int)
+_sig("tbk_device_mem_info", C.c_int, C.c_int, _u64p, _u64p)
+_sig("tbk_synth_keys_device", C.c_int, C.c_int, _u64, _u64, _u64, C.c_int, _vp)
+_sig("tbk_synth_keys_host", C.c_int, _u64, _u64, _u64, C.c_int, _vp)
+_sig("tbk_synth_reads_device", C.c_int, C.c_int, _u64, _u64, _u64, C.c_uint32, _u64, _u64, _u64, C.c_int,
+     C.c_int, C.c_int, _vp, _vp)
+_sig("tbk_calib_gather", C.c_int, C.c_int, _u64, C.c_int, C.c_int, C.c_int, _u64, C.c_int, _dp, _dp)
+_sig("tbk_calib_stream", C.c_int, C.c_int, _u64, C.c_int, _dp)
+
+
+def last_error() -> str:
+    msg = lib.tbk_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int) -> None:
+    """Raise for a non-zero tbk_status.  File problems surface as IOError (the type the
+    reference raises for a missing list, kmers.py:117-118), malformed input as ValueError."""
+    if status == TBK_OK:
+        return
+    msg = last_error()
+    if status == TBK_ERR_IO:
+        raise IOError(msg)
+    if status in (TBK_ERR_FORMAT, TBK_ERR_INVALID):
+        raise ValueError(msg)
+    if status == TBK_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise TbkError(status, msg)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    if lib.tbk_device_count(C.byref(n)) != TBK_OK:
+        return 0
+    return n.value
+
+
+def device_name(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    check(lib.tbk_device_name(device, buf, 256))
+    return buf.value.decode()

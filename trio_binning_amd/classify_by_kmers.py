@@ -1,0 +1,139 @@
+"""Classify reads into bins based on kmers.
+
+This is a script for classifying sequence reads into parental bins
+based on the presence of k-mers.
+"""
+# The module docstring above is the CLI description the reference prints for --help
+# (classify_by_kmers.py:1-5,17; asserted by its tests/test_classify_by_kmers.py:16) and is
+# kept word for word because it is user-visible output.
+#
+# Host driver of the MI355X path.  Same command line, defaults, stdout TSV and bin files
+# as the reference driver (src/trio_binning/classify_by_kmers.py:14-117); what changes is
+# the loop: instead of one ctypes call per read (:99-102) reads are packed into batches,
+# streamed through the HIP classifier with the next batch's copy overlapping the current
+# batch's kernel, and scored/binned/written per batch in input order.
+
+import argparse
+import os
+import sys
+from os import path
+from typing import List, Tuple
+
+from . import kmers, seq
+
+# bases per batch handed to the GPU; 3 batches may be in flight
+_BATCH_BASES = int(os.environ.get("TBK_BATCH_BASES", str(256 << 20)))
+_BATCH_READS = int(os.environ.get("TBK_BATCH_READS", str(1 << 20)))
+
+
+def parse_args():
+    """Parse arguments (same positionals, options, defaults and help as the reference,
+    classify_by_kmers.py:14-54; the k-mer tables are built by the ``type=`` callbacks)."""
+    parser = argparse.ArgumentParser(
+        description=__doc__, formatter_class=argparse.ArgumentDefaultsHelpFormatter
+    )
+    parser.add_argument(
+        "reads",
+        help="reads to classify into bins, in fasta/q format. Can be gzipped.",
+    )
+    parser.add_argument(
+        "haplotype_a_kmers",
+        type=kmers.create_kmer_hash_set,
+        help="a list of k-mers unique to haplotype A, one per line",
+    )
+    parser.add_argument(
+        "haplotype_b_kmers",
+        type=kmers.create_kmer_hash_set,
+        help="a list of k-mers unique to haplotype B, one per line",
+    )
+    parser.add_argument("--haplotype-a-out-prefix", default="hapA", help="prefix for haplotype A output file")
+    parser.add_argument("--haplotype-b-out-prefix", default="hapB", help="prefix for haplotype B output file")
+    parser.add_argument("--unclassified-out-prefix", default="unclassified", help="prefix for unclassified output file")
+    parser.add_argument("--no-gzip-output", action="store_true", default=False, help="don't gzip the output")
+    return parser.parse_args()
+
+
+def calculate_scaling_factors(haplotype_a_kmers: kmers.HashSet, haplotype_b_kmers: kmers.HashSet) -> Tuple[float, float]:
+    """Scaling factors for the k-mer scores (reference classify_by_kmers.py:57-77):
+    each count is multiplied by max(nA, nB) / n of its own list, in float64."""
+    num_kmers_a = kmers.get_number_kmers_in_set(haplotype_a_kmers)
+    num_kmers_b = kmers.get_number_kmers_in_set(haplotype_b_kmers)
+    max_num_kmers = max(num_kmers_a, num_kmers_b)
+    return 1.0 * max_num_kmers / num_kmers_a, 1.0 * max_num_kmers / num_kmers_b
+
+
+def output_extension(reads_path: str) -> str:
+    """Extension of the bin files.  The reference computes
+    ``splitext(reads.rstrip(".gz"))[1]`` (classify_by_kmers.py:90): ``rstrip`` strips the
+    character set {'.', 'g', 'z'}, not the suffix, and that quirk decides file names."""
+    return path.splitext(reads_path.rstrip(".gz"))[1]
+
+
+def _emit(batch: List[seq.Read], counts, num_a: int, num_b: int, outs, stdout) -> None:
+    """Score, bin and write one batch in input order (classify_by_kmers.py:104-117)."""
+    score_a, score_b, bins = kmers.score_and_bin(counts, num_a, num_b)
+    out_a, out_b, out_u = outs
+    lines = []
+    for i, read in enumerate(batch):
+        b = bins[i]
+        if b == 65:  # 'A'
+            read.print(file=out_a)
+            tag = "A"
+        elif b == 66:  # 'B'
+            read.print(file=out_b)
+            tag = "B"
+        else:
+            read.print(file=out_u)
+            tag = "U"
+        # the reference prints str(float): shortest round-trip repr ('4.0', '1.3333333333333333')
+        lines.append(f"{read.name}\t{tag}\t{float(score_a[i])!s}\t{float(score_b[i])!s}\n")
+    stdout.write("".join(lines))
+
+
+def main():
+    """Main method of program"""
+    args = parse_args()
+
+    reads = seq.open_fastx_read(args.reads)
+    outs = seq.open_outfiles(
+        args.haplotype_a_out_prefix,
+        args.haplotype_b_out_prefix,
+        args.unclassified_out_prefix,
+        output_extension(args.reads),
+        not args.no_gzip_output,
+    )
+    num_a = kmers.get_number_kmers_in_set(args.haplotype_a_kmers)
+    num_b = kmers.get_number_kmers_in_set(args.haplotype_b_kmers)
+
+    classifier = kmers.Classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
+    in_flight: List[Tuple[int, List[seq.Read]]] = []  # (ticket, reads) in submission order
+    stdout = sys.stdout
+
+    def drain(keep: int) -> None:
+        while len(in_flight) > keep:
+            ticket, batch = in_flight.pop(0)
+            _emit(batch, classifier.wait(ticket), num_a, num_b, outs, stdout)
+
+    batch: List[seq.Read] = []
+    batch_bases = 0
+    for read in reads:
+        batch.append(read)
+        batch_bases += len(read.seq)
+        if batch_bases >= _BATCH_BASES or len(batch) >= _BATCH_READS:
+            drain(classifier.depth - 1)
+            in_flight.append((classifier.submit(*kmers.pack_reads([r.seq for r in batch])), batch))
+            batch, batch_bases = [], 0
+    if batch:
+        drain(classifier.depth - 1)
+        in_flight.append((classifier.submit(*kmers.pack_reads([r.seq for r in batch])), batch))
+    drain(0)
+
+    # The reference never closes its outputs (interpreter shutdown does); closing here
+    # finalises the gzip members at the same point in the byte stream.
+    for fh in outs:
+        fh.close()
+    classifier.close()
+
+
+if __name__ == "__main__":
+    main()

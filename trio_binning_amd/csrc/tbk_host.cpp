@@ -1,0 +1,780 @@
+// tbk_host.cpp — host side of libtbk_hip.so: the C-ABI declared in include/tbk.h.
+//
+// Owns device memory, streams and events directly through the HIP runtime (no PyTorch):
+// k-mer tables resident in HBM, a ring of pinned/device staging slots so the H2D copy of
+// batch i+1 (side stream) overlaps the probe kernel of batch i (compute stream), and the
+// text-list parser that mirrors the reference's getline() rules.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tbk.h"
+#include "tbk_common.h"
+
+// ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, const uint64_t *, uint64_t, unsigned long long *,
+                                        int *, hipStream_t);
+extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkTableView,
+                                       TbkTableView, int, int32_t *, int, hipStream_t);
+extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
+                                             int, int, int, uint8_t *, uint64_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_fill(void *, uint64_t, uint64_t, hipStream_t);
+extern "C" hipError_t tbk_launch_stream(const void *, uint64_t, uint32_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_gather(const void *, uint64_t, int, int, int, uint64_t, uint64_t, uint32_t *,
+                                        uint64_t *, hipStream_t);
+
+// ---- errors ----------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                               \
+    } while (0)
+
+static int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(TBK_ERR_NO_DEVICE, "no HIP device visible (%s); libtbk_hip has no CPU fallback",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(TBK_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    return TBK_OK;
+}
+
+static double env_double(const char *name, double dflt) {
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    double d = strtod(v, &end);
+    return end == v ? dflt : d;
+}
+
+// ---- handles ---------------------------------------------------------------------------
+struct tbk_table {
+    int device = 0;
+    int k = 0;
+    uint64_t num_lines = 0;  // what the reference calls num_kmers (c/kmers.c:37)
+    uint64_t distinct = 0;
+    uint32_t n_buckets = 0;
+    uint64_t *d_slots = nullptr;
+    TbkTableView view() const { return TbkTableView{d_slots, n_buckets}; }
+};
+
+static constexpr int RING = 3;
+static constexpr int TIMING_POOL = 1024;
+
+struct Slot {
+    uint8_t *d_bases = nullptr; size_t cap_bases = 0;
+    uint64_t *d_offsets = nullptr; size_t cap_reads = 0;  // capacity in reads (offsets has +1)
+    int32_t *d_counts = nullptr;
+    uint8_t *h_bases = nullptr; size_t hcap_bases = 0;    // pinned staging for unpinned callers
+    uint64_t *h_offsets = nullptr; int32_t *h_counts = nullptr; size_t hcap_reads = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+    uint64_t ticket = 0, n_reads = 0;
+    int32_t *user_counts = nullptr;
+    bool counts_staged = false;
+};
+
+struct tbk_classifier {
+    int device = 0;
+    int k = 0;
+    TbkTableView a{}, b{};
+    hipStream_t compute = nullptr, copy = nullptr;
+    Slot ring[RING];
+    uint64_t next_ticket = 1;
+    int max_blocks = 0;
+    // kernel timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t ev_used = 0;
+    uint64_t timed_launches = 0;
+    double timed_ms = 0.0;
+};
+
+// ---- library ---------------------------------------------------------------------------
+extern "C" int tbk_abi_version(void) { return TBK_ABI_VERSION; }
+extern "C" const char *tbk_last_error(void) { return g_err.c_str(); }
+
+extern "C" int tbk_device_count(int *count) {
+    if (!count) return fail(TBK_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(TBK_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return TBK_OK;
+}
+
+extern "C" int tbk_device_name(int device, char *buf, size_t buflen) {
+    if (!buf || !buflen) return fail(TBK_ERR_INVALID, "buf is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s %s, %d CUs, %.0f GB", p.gcnArchName, p.name, p.multiProcessorCount,
+             (double)p.totalGlobalMem / 1e9);
+    return TBK_OK;
+}
+
+// ---- unit-level host utilities -----------------------------------------------------------
+static inline unsigned code_of(unsigned char c) {  // c/kmers.c:54-68: anything else -> 0
+    return c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+}
+
+extern "C" uint64_t tbk_kmer_to_int(const char *kmer, unsigned char k) {
+    uint64_t v = 0;
+    for (unsigned i = 0; i < k && i < 32; i++) v |= (uint64_t)code_of((unsigned char)kmer[i]) << (2 * i);
+    return v;
+}
+
+extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char k) {
+    for (unsigned i = 0; i < k; i++) {
+        char c = 0;
+        switch (in[i]) { case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break; }
+        if (c) out[k - 1 - i] = c;  // c/kmers.c:78-91: other bytes leave the slot untouched
+    }
+}
+
+// ---- tables ----------------------------------------------------------------------------
+static uint32_t buckets_for(uint64_t n_keys) {
+    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe must be one line:
+    // at 2 keys per 8-slot line fewer than 0.2% of lines are full, so a miss is decided by
+    // the home line alone.  TBK_TABLE_LOAD overrides.
+    double load = env_double("TBK_TABLE_LOAD", 0.25);
+    if (load < 0.02) load = 0.02;
+    if (load > 0.9) load = 0.9;
+    double want = (double)n_keys / (TBK_SLOTS_PER_BUCKET * load);
+    uint64_t nb = (uint64_t)want + 1;
+    if (nb < 16) nb = 16;
+    if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
+    return (uint32_t)nb;
+}
+
+static int table_build(const uint64_t *d_keys, uint64_t n, int k, uint64_t num_lines, int device, tbk_table **out) {
+    tbk_table *t = new tbk_table();
+    t->device = device; t->k = k; t->num_lines = num_lines;
+    t->n_buckets = buckets_for(n);
+    const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
+    unsigned long long *d_distinct = nullptr;
+    int *d_failed = nullptr;
+    auto cleanup = [&]() {
+        if (d_distinct) (void)hipFree(d_distinct);
+        if (d_failed) (void)hipFree(d_failed);
+    };
+#define TB_TRY(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            cleanup(); if (t->d_slots) (void)hipFree(t->d_slots); delete t;                   \
+            return fail(e_ == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                               \
+        }                                                                                     \
+    } while (0)
+    TB_TRY(hipMalloc((void **)&t->d_slots, bytes));
+    TB_TRY(hipMemset(t->d_slots, 0xFF, bytes));
+    TB_TRY(hipMalloc((void **)&d_distinct, sizeof(unsigned long long)));
+    TB_TRY(hipMalloc((void **)&d_failed, sizeof(int)));
+    TB_TRY(hipMemset(d_distinct, 0, sizeof(unsigned long long)));
+    TB_TRY(hipMemset(d_failed, 0, sizeof(int)));
+    TB_TRY(tbk_launch_insert(t->d_slots, t->n_buckets, d_keys, n, d_distinct, d_failed, nullptr));
+    unsigned long long distinct = 0;
+    int failed = 0;
+    TB_TRY(hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost));
+    TB_TRY(hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost));
+#undef TB_TRY
+    cleanup();
+    if (failed) { (void)hipFree(t->d_slots); delete t; return fail(TBK_ERR_HIP, "table insert overflowed (table full)"); }
+    t->distinct = distinct;
+    *out = t;
+    return TBK_OK;
+}
+
+extern "C" int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, uint64_t num_lines,
+                                                 int device, tbk_table **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 32) return fail(TBK_ERR_INVALID, "k = %d outside 1..32", k);
+    if (n && !d_keys) return fail(TBK_ERR_INVALID, "keys is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    return table_build((const uint64_t *)d_keys, n, k, num_lines, device, out);
+}
+
+extern "C" int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, uint64_t num_lines, int device,
+                                          tbk_table **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (k < 1 || k > 32) return fail(TBK_ERR_INVALID, "k = %d outside 1..32", k);
+    if (n && !keys) return fail(TBK_ERR_INVALID, "keys is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    uint64_t *d_keys = nullptr;
+    if (n) {
+        HIP_TRY(hipMalloc((void **)&d_keys, n * sizeof(uint64_t)));
+        hipError_t e = hipMemcpy(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_keys); return fail(TBK_ERR_HIP, "hipMemcpy keys: %s", hipGetErrorString(e)); }
+    }
+    rc = table_build(d_keys, n, k, num_lines, device, out);
+    if (d_keys) (void)hipFree(d_keys);
+    return rc;
+}
+
+// Text list -> packed keys with the reference's getline() rules (c/kmers.c:124-146,204-221):
+// k = bytes of the first line as getline returns them (newline included) minus one; each
+// getline success is one k-mer; a line contributes its first k bytes (a byte outside ACGT,
+// the newline included, packs as 0).  A line with fewer than k bytes would make the
+// reference pack stale buffer contents: refused as TBK_ERR_FORMAT.
+static int parse_list(const char *path, std::vector<uint64_t> &keys, int &k_out) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(TBK_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return fail(TBK_ERR_IO, "%s is not a regular file", path); }
+    const size_t size = (size_t)st.st_size;
+    if (size == 0) { close(fd); return fail(TBK_ERR_FORMAT, "%s is empty: no k-mers", path); }
+    const char *data = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (data == MAP_FAILED) return fail(TBK_ERR_IO, "mmap %s: %s", path, strerror(errno));
+    (void)madvise((void *)data, size, MADV_SEQUENTIAL);
+    const char *end = data + size;
+    const char *nl = (const char *)memchr(data, '\n', size);
+    const size_t first_len = nl ? (size_t)(nl - data) + 1 : size;  // as getline counts it
+    const long k = (long)first_len - 1;
+    if (k < 1 || k > 32) {
+        munmap((void *)data, size);
+        return fail(TBK_ERR_FORMAT, "%s: first line gives k = %ld (supported: 1..32)", path, k);
+    }
+    keys.clear();
+    keys.reserve(size / (size_t)(k + 1) + 1);
+    const char *p = data;
+    uint64_t line_no = 0;
+    while (p < end) {
+        const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const size_t got = e ? (size_t)(e - p) + 1 : (size_t)(end - p);
+        line_no++;
+        if (got < (size_t)k) {
+            munmap((void *)data, size);
+            return fail(TBK_ERR_FORMAT, "%s: line %llu has %zu bytes, fewer than k = %ld", path,
+                        (unsigned long long)line_no, got, k);
+        }
+        uint64_t v = 0;
+        for (long i = 0; i < k; i++) v |= (uint64_t)code_of((unsigned char)p[i]) << (2 * i);
+        keys.push_back(v);
+        p += got;
+    }
+    munmap((void *)data, size);
+    k_out = (int)k;
+    return TBK_OK;
+}
+
+extern "C" int tbk_table_create_from_file(const char *path, int device, tbk_table **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!path) return fail(TBK_ERR_INVALID, "path is NULL");
+    std::vector<uint64_t> keys;
+    int k = 0;
+    int rc = parse_list(path, keys, k);
+    if (rc) return rc;
+    return tbk_table_create_from_keys(keys.data(), keys.size(), k, keys.size(), device, out);
+}
+
+static void drop_cached_classifier(const tbk_table *t);
+
+extern "C" void tbk_table_destroy(tbk_table *t) {
+    if (!t) return;
+    drop_cached_classifier(t);
+    if (hipSetDevice(t->device) == hipSuccess && t->d_slots) (void)hipFree(t->d_slots);
+    delete t;
+}
+
+extern "C" uint64_t tbk_table_num_kmers(const tbk_table *t) { return t ? t->num_lines : 0; }
+extern "C" int tbk_table_k(const tbk_table *t) { return t ? t->k : 0; }
+extern "C" int tbk_table_device(const tbk_table *t) { return t ? t->device : -1; }
+extern "C" uint64_t tbk_table_distinct(const tbk_table *t) { return t ? t->distinct : 0; }
+extern "C" uint64_t tbk_table_bytes(const tbk_table *t) { return t ? (uint64_t)t->n_buckets * TBK_BUCKET_BYTES : 0; }
+extern "C" uint64_t tbk_table_buckets(const tbk_table *t) { return t ? t->n_buckets : 0; }
+
+extern "C" int tbk_table_contains(const tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out) {
+    if (!t || (n && (!keys || !out))) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = use_device(t->device);
+    if (rc) return rc;
+    if (!n) return TBK_OK;
+    uint64_t *d_keys = nullptr;
+    uint8_t *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_keys, n * sizeof(uint64_t)));
+    hipError_t e = hipMalloc((void **)&d_out, n);
+    if (e == hipSuccess) e = hipMemcpy(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = tbk_launch_contains(t->view(), d_keys, n, d_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_keys);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "tbk_table_contains: %s", hipGetErrorString(e));
+    return TBK_OK;
+}
+
+// ---- classifier ------------------------------------------------------------------------
+extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!a || !b) return fail(TBK_ERR_INVALID, "table is NULL");
+    if (a->device != b->device) return fail(TBK_ERR_INVALID, "tables live on different devices (%d, %d)", a->device, b->device);
+    int rc = use_device(a->device);
+    if (rc) return rc;
+    tbk_classifier *c = new tbk_classifier();
+    c->device = a->device;
+    c->k = a->k;  // the reference uses haplotype_A->k for both sets (c/kmers.c:278-290)
+    c->a = a->view();
+    c->b = b->view();
+    c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
+    hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+    for (int i = 0; i < RING && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        tbk_classifier_destroy(c);
+        return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return TBK_OK;
+}
+
+extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->compute) (void)hipStreamSynchronize(c->compute);
+        if (c->copy) (void)hipStreamSynchronize(c->copy);
+        for (Slot &s : c->ring) {
+            if (s.d_bases) (void)hipFree(s.d_bases);
+            if (s.d_offsets) (void)hipFree(s.d_offsets);
+            if (s.d_counts) (void)hipFree(s.d_counts);
+            if (s.h_bases) (void)hipHostFree(s.h_bases);
+            if (s.h_offsets) (void)hipHostFree(s.h_offsets);
+            if (s.h_counts) (void)hipHostFree(s.h_counts);
+            if (s.copied) (void)hipEventDestroy(s.copied);
+            if (s.done) (void)hipEventDestroy(s.done);
+        }
+        for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+        if (c->compute) (void)hipStreamDestroy(c->compute);
+        if (c->copy) (void)hipStreamDestroy(c->copy);
+    }
+    delete c;
+}
+
+static bool is_pinned(const void *p) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
+static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const uint64_t *d_offsets,
+                              uint64_t n_reads, uint64_t total, int32_t *d_counts) {
+    HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        if (c->ev_used + 2 > c->ev.size()) {
+            if (c->ev.size() >= 2 * TIMING_POOL) {  // fold what we have, then reuse the pool
+                HIP_TRY(hipStreamSynchronize(c->compute));
+                for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+                    float ms = 0;
+                    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+                    c->timed_ms += ms;
+                }
+                c->ev_used = 0;
+            } else {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a));
+                HIP_TRY(hipEventCreate(&b));
+                c->ev.push_back(a);
+                c->ev.push_back(b);
+            }
+        }
+        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+        c->timed_launches++;
+        HIP_TRY(hipEventRecord(e0, c->compute));
+    }
+    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->a, c->b, c->k, d_counts, c->max_blocks, c->compute));
+    if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
+    return TBK_OK;
+}
+
+extern "C" int tbk_stream_depth(const tbk_classifier *) { return RING; }
+
+static int slot_reserve(Slot &s, uint64_t total, uint64_t n_reads, bool stage_in, bool stage_out) {
+    const size_t need_b = ((size_t)total + 15) & ~(size_t)15;
+    if (need_b > s.cap_bases) {
+        if (s.d_bases) HIP_TRY(hipFree(s.d_bases));
+        s.d_bases = nullptr; s.cap_bases = 0;
+        const size_t cap = std::max(need_b + need_b / 8, (size_t)1 << 20);
+        HIP_TRY(hipMalloc((void **)&s.d_bases, cap));
+        s.cap_bases = cap;
+    }
+    if (n_reads > s.cap_reads) {
+        if (s.d_offsets) HIP_TRY(hipFree(s.d_offsets));
+        if (s.d_counts) HIP_TRY(hipFree(s.d_counts));
+        s.d_offsets = nullptr; s.d_counts = nullptr; s.cap_reads = 0;
+        const size_t cap = std::max((size_t)n_reads + (size_t)n_reads / 8, (size_t)1024);
+        HIP_TRY(hipMalloc((void **)&s.d_offsets, (cap + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_counts, cap * 2 * sizeof(int32_t)));
+        s.cap_reads = cap;
+    }
+    if (stage_in && need_b > s.hcap_bases) {
+        if (s.h_bases) HIP_TRY(hipHostFree(s.h_bases));
+        s.h_bases = nullptr; s.hcap_bases = 0;
+        const size_t cap = std::max(need_b + need_b / 8, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocDefault));
+        s.hcap_bases = cap;
+    }
+    if ((stage_in || stage_out) && n_reads > s.hcap_reads) {
+        if (s.h_offsets) HIP_TRY(hipHostFree(s.h_offsets));
+        if (s.h_counts) HIP_TRY(hipHostFree(s.h_counts));
+        s.h_offsets = nullptr; s.h_counts = nullptr; s.hcap_reads = 0;
+        const size_t cap = std::max((size_t)n_reads + (size_t)n_reads / 8, (size_t)1024);
+        HIP_TRY(hipHostMalloc((void **)&s.h_offsets, (cap + 1) * sizeof(uint64_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s.h_counts, cap * 2 * sizeof(int32_t), hipHostMallocDefault));
+        s.hcap_reads = cap;
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                 int32_t *counts, uint64_t *ticket) {
+    if (!c || !offsets || !ticket || (n_reads && !counts)) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (offsets[0] != 0) return fail(TBK_ERR_INVALID, "offsets[0] must be 0");
+    const uint64_t total = offsets[n_reads];
+    if (total && !bases) return fail(TBK_ERR_INVALID, "bases is NULL");
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(TBK_ERR_INVALID, "offsets not non-decreasing at read %llu", (unsigned long long)i);
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    const uint64_t tk = c->next_ticket;
+    Slot &s = c->ring[tk % RING];
+    if (s.busy) return fail(TBK_ERR_STATE, "all %d stream slots are in flight; call tbk_stream_wait(%llu) first", RING,
+                            (unsigned long long)s.ticket);
+    const bool in_pinned = total == 0 || (is_pinned(bases) && is_pinned(offsets));
+    const bool out_pinned = n_reads == 0 || is_pinned(counts);
+    rc = slot_reserve(s, total, n_reads, !in_pinned, !out_pinned);
+    if (rc) return rc;
+    s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
+    if (n_reads && total) {
+        const uint8_t *src_b = bases;
+        const uint64_t *src_o = offsets;
+        if (!in_pinned) {
+            memcpy(s.h_bases, bases, total);
+            memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t));
+            src_b = s.h_bases; src_o = s.h_offsets;
+        }
+        // side stream: H2D of this batch overlaps the previous batch's kernel
+        HIP_TRY(hipMemcpyAsync(s.d_bases, src_b, total, hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
+        HIP_TRY(hipEventRecord(s.copied, c->copy));
+        HIP_TRY(hipStreamWaitEvent(c->compute, s.copied, 0));
+        rc = launch_probe_timed(c, s.d_bases, s.d_offsets, n_reads, total, s.d_counts);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, c->compute));
+    } else if (n_reads) {
+        memset(counts, 0, n_reads * 2 * sizeof(int32_t));
+        s.counts_staged = false;
+    }
+    HIP_TRY(hipEventRecord(s.done, c->compute));
+    s.busy = true;
+    c->next_ticket++;
+    *ticket = tk;
+    return TBK_OK;
+}
+
+extern "C" int tbk_stream_wait(tbk_classifier *c, uint64_t ticket) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    Slot &s = c->ring[ticket % RING];
+    if (!s.busy || s.ticket != ticket) return fail(TBK_ERR_STATE, "ticket %llu is not in flight", (unsigned long long)ticket);
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    HIP_TRY(hipEventSynchronize(s.done));
+    if (s.counts_staged && s.n_reads) memcpy(s.user_counts, s.h_counts, s.n_reads * 2 * sizeof(int32_t));
+    s.busy = false;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                  int32_t *counts) {
+    uint64_t tk = 0;
+    int rc = tbk_stream_submit(c, bases, offsets, n_reads, counts, &tk);
+    if (rc) return rc;
+    return tbk_stream_wait(c, tk);
+}
+
+extern "C" void *tbk_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        fail(TBK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        return nullptr;
+    }
+    return p;
+}
+extern "C" void tbk_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int tbk_classify_device(tbk_classifier *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                   uint64_t total_bases, void *d_counts) {
+    if (!c || (n_reads && (!d_offsets || !d_counts)) || (total_bases && !d_bases)) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(TBK_ERR_INVALID, "d_bases must be 16-byte aligned");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    if (!n_reads) return TBK_OK;
+    return launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases,
+                              (int32_t *)d_counts);
+}
+
+extern "C" int tbk_classifier_sync(tbk_classifier *c) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->copy));
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    return TBK_OK;
+}
+
+extern "C" int tbk_kernel_timing_enable(tbk_classifier *c, int on) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    c->timing = on != 0;
+    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0;
+    return TBK_OK;
+}
+
+extern "C" int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms) {
+    if (!c || !launches || !total_ms) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->timed_ms += ms;
+    }
+    *launches = c->timed_launches;
+    *total_ms = c->timed_ms;
+    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0;
+    return TBK_OK;
+}
+
+// ---- single read (compat with kmers.count_kmers_in_read) ----------------------------------
+static std::mutex g_cache_mu;
+static tbk_classifier *g_cached = nullptr;
+static const tbk_table *g_cached_a = nullptr, *g_cached_b = nullptr;
+
+static void drop_cached_classifier(const tbk_table *t) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (g_cached && (g_cached_a == t || g_cached_b == t)) {
+        tbk_classifier_destroy(g_cached);
+        g_cached = nullptr; g_cached_a = g_cached_b = nullptr;
+    }
+}
+
+extern "C" int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *a, const tbk_table *b,
+                                       int *count_a, int *count_b) {
+    if (!read || !a || !b || !count_a || !count_b) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (len < 0) len = (int64_t)strlen(read);
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (!g_cached || g_cached_a != a || g_cached_b != b) {
+        if (g_cached) { tbk_classifier_destroy(g_cached); g_cached = nullptr; }
+        int rc = tbk_classifier_create(a, b, &g_cached);
+        if (rc) return rc;
+        g_cached_a = a; g_cached_b = b;
+    }
+    uint64_t offsets[2] = {0, (uint64_t)len};
+    int32_t counts[2] = {0, 0};
+    int rc = tbk_classify_batch(g_cached, (const uint8_t *)read, offsets, 1, counts);
+    if (rc) return rc;
+    *count_a = counts[0];
+    *count_b = counts[1];
+    return TBK_OK;
+}
+
+// ---- scoring (host) ------------------------------------------------------------------------
+extern "C" int tbk_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64_t num_a, uint64_t num_b,
+                                 double *score_a, double *score_b, char *bins) {
+    if (n_reads && (!counts || !score_a || !score_b || !bins)) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (!num_a || !num_b) return fail(TBK_ERR_INVALID, "a k-mer list is empty (the reference divides by zero here)");
+    // classify_by_kmers.py:72-76: 1.0 * max / n ; :104-105 count * factor ; :107-115 strict >
+    const uint64_t mx = num_a > num_b ? num_a : num_b;
+    const double fa = 1.0 * (double)mx / (double)num_a;
+    const double fb = 1.0 * (double)mx / (double)num_b;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const double sa = (double)counts[2 * r] * fa, sb = (double)counts[2 * r + 1] * fb;
+        score_a[r] = sa;
+        score_b[r] = sb;
+        bins[r] = sa > sb ? 'A' : (sb > sa ? 'B' : 'U');
+    }
+    return TBK_OK;
+}
+
+// ---- device memory helpers ------------------------------------------------------------------
+extern "C" int tbk_device_alloc(int device, size_t bytes, void **d_ptr) {
+    if (!d_ptr) return fail(TBK_ERR_INVALID, "d_ptr is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return TBK_OK;
+}
+extern "C" int tbk_device_free(int device, void *d_ptr) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (d_ptr) HIP_TRY(hipFree(d_ptr));
+    return TBK_OK;
+}
+extern "C" int tbk_memcpy_h2d(int device, void *d_dst, const void *h_src, size_t bytes) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return TBK_OK;
+}
+extern "C" int tbk_memcpy_d2h(int device, void *h_dst, const void *d_src, size_t bytes) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return TBK_OK;
+}
+extern "C" int tbk_device_sync(int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return TBK_OK;
+}
+extern "C" int tbk_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return TBK_OK;
+}
+
+// ---- synthetic workload -----------------------------------------------------------------------
+extern "C" int tbk_synth_keys_device(int device, uint64_t seed, uint64_t first, uint64_t n, int k, void *d_keys) {
+    if (k < 3 || k > 32) return fail(TBK_ERR_INVALID, "synthetic keys need 3 <= k <= 32");
+    if (k < 32 && first + n > (1ull << (2 * (k - 2)))) return fail(TBK_ERR_INVALID, "key index exceeds 4^(k-2)");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(tbk_launch_synth_keys(seed, first, n, k, (uint64_t *)d_keys, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return TBK_OK;
+}
+
+extern "C" int tbk_synth_keys_host(uint64_t seed, uint64_t first, uint64_t n, int k, uint64_t *keys) {
+    if (k < 3 || k > 32) return fail(TBK_ERR_INVALID, "synthetic keys need 3 <= k <= 32");
+    if (n && !keys) return fail(TBK_ERR_INVALID, "keys is NULL");
+    for (uint64_t i = 0; i < n; i++) keys[i] = tbk_synth_key(seed, first + i, k);
+    return TBK_OK;
+}
+
+extern "C" int tbk_synth_reads_device(int device, uint64_t read_seed, uint64_t first_read, uint64_t n_reads,
+                                      uint32_t read_len, uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k,
+                                      int plant_major, int plant_minor, void *d_bases, void *d_offsets) {
+    if (k < 3 || k > 32 || plant_major < 0 || plant_minor < 0) return fail(TBK_ERR_INVALID, "bad synth parameters");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(TBK_ERR_INVALID, "d_bases must be 16-byte aligned");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(tbk_launch_synth_reads(read_seed, first_read, n_reads, read_len, key_seed, n_a, n_b, k, plant_major,
+                                   plant_minor, (uint8_t *)d_bases, (uint64_t *)d_offsets, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return TBK_OK;
+}
+
+// ---- calibration --------------------------------------------------------------------------------
+extern "C" int tbk_calib_gather(int device, uint64_t footprint, int line_bytes, int lanes_per_line, int inflight,
+                                uint64_t n_lines, int reps, double *lines_per_sec, double *ms_per_rep) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    footprint &= ~(uint64_t)255;
+    if (footprint < (1u << 20)) return fail(TBK_ERR_INVALID, "footprint too small");
+    void *buf = nullptr;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, footprint));
+    hipError_t e = hipMalloc((void **)&sink, 16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t done = 0;
+    float ms = 0;
+    if (e == hipSuccess) e = tbk_launch_fill(buf, footprint, 1, nullptr);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_gather(buf, footprint, line_bytes, lanes_per_line, inflight, n_lines, 7, sink, &done, nullptr);  // warm-up
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++)
+        e = tbk_launch_gather(buf, footprint, line_bytes, lanes_per_line, inflight, n_lines, 11 + r, sink, &done, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TBK_ERR_INVALID : TBK_ERR_HIP, "calib_gather: %s", hipGetErrorString(e));
+    if (ms_per_rep) *ms_per_rep = ms / reps;
+    if (lines_per_sec) *lines_per_sec = (double)done * reps / (ms * 1e-3);
+    return TBK_OK;
+}
+
+extern "C" int tbk_calib_stream(int device, uint64_t footprint, int reps, double *bytes_per_sec) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    footprint &= ~(uint64_t)255;
+    void *buf = nullptr;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, footprint));
+    hipError_t e = hipMalloc((void **)&sink, 16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (e == hipSuccess) e = tbk_launch_fill(buf, footprint, 1, nullptr);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_stream(buf, footprint, sink, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = tbk_launch_stream(buf, footprint, sink, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "calib_stream: %s", hipGetErrorString(e));
+    if (bytes_per_sec) *bytes_per_sec = (double)footprint * reps / (ms * 1e-3);
+    return TBK_OK;
+}

@@ -1,0 +1,238 @@
+// tbk_synth.hip — synthetic workload generators and roofline-calibration kernels.
+//
+// These produce BASELINE.json's bench inputs on the GPU: deterministic
+// distinct canonical k-mer lists and random reads with planted list k-mers, so that the
+// timed region of bench.py starts with its inputs already resident in HBM.  They are
+// workload generators, not part of the reference's path; the tests copy what they generate
+// back to the host and check the probe kernel's counts on it against the CPU checker.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tbk_common.h"
+
+// ---------------------------------------------------------------------------------------
+// keys
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+tbk_synth_keys_kernel(uint64_t seed, uint64_t first, uint64_t n, int k, uint64_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = tbk_synth_key(seed, first + i, k);
+}
+
+// ---------------------------------------------------------------------------------------
+// reads: background
+// ---------------------------------------------------------------------------------------
+// One thread writes 16 bases (one 16-byte store): 32 random bits from a counter-based
+// generator keyed on (seed, absolute chunk index), so any sub-range can be regenerated.
+__global__ void __launch_bounds__(256)
+tbk_synth_background_kernel(uint64_t seed, uint64_t first_chunk, uint64_t n_chunks, uint4 *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_chunks; i += stride) {
+        const uint64_t r = tbk_splitmix(seed ^ ((first_chunk + i) * 0xD6E8FEB86659FD93ull));
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t code = (uint32_t)(r >> (2 * (4 * q + b))) & 3u;
+                // "ACGT"[code]
+                const uint32_t ch = (0x54474341u >> (8 * code)) & 0xFFu;
+                word |= ch << (8 * b);
+            }
+            w[q] = word;
+        }
+        out[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tbk_synth_offsets_kernel(uint64_t n_reads, uint32_t read_len, uint64_t *__restrict__ offsets) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_reads) offsets[i] = i * (uint64_t)read_len;
+}
+
+// ---------------------------------------------------------------------------------------
+// reads: planting
+// ---------------------------------------------------------------------------------------
+// One thread per (read, plant slot).  The read is cut into n_slots equal slots; plant j
+// goes at a random offset inside slot j (never crossing into the next slot), so plants
+// never overlap.  Read origin: A / B / none with p = .45 / .45 / .10.  Origin reads carry
+// `major` k-mers of their own list in the first `major` slots and `minor` of the other;
+// origin-less reads carry `minor` of each.  Each planted k-mer is written forward or
+// reverse-complemented with p = .5.
+__global__ void __launch_bounds__(256)
+tbk_synth_plant_kernel(uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                       uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k, int major, int minor,
+                       uint8_t *__restrict__ bases) {
+    const int n_slots = major + minor;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_reads * (uint64_t)n_slots) return;
+    const uint64_t r = t / n_slots;
+    const int j = (int)(t % n_slots);
+    const uint32_t slot_len = read_len / n_slots;
+    if (slot_len < (uint32_t)k) return;
+    const uint64_t rr = tbk_splitmix(read_seed ^ ((first_read + r) * 0xA0761D6478BD642Full));
+    const uint32_t u = (uint32_t)(rr % 100u);
+    const int origin = u < 45 ? 0 : (u < 90 ? 1 : 2);  // 0=A 1=B 2=none
+    int which;  // list of this plant
+    if (origin == 2) {
+        if (j >= 2 * minor) return;
+        which = j < minor ? 0 : 1;
+    } else {
+        which = j < major ? origin : 1 - origin;
+    }
+    const uint64_t pr = tbk_splitmix(rr ^ ((uint64_t)(j + 1) * 0xE7037ED1A0B428DBull));
+    const uint64_t n_list = which == 0 ? n_a : n_b;
+    if (n_list == 0) return;
+    const uint64_t idx = (which == 0 ? 0 : n_a) + (pr >> 8) % n_list;
+    uint64_t key = tbk_synth_key(key_seed, idx, k);
+    if (pr & 1) key = tbk_revcomp_packed(key, k);
+    const uint32_t off = (uint32_t)((pr >> 40) % (slot_len - (uint32_t)k + 1u));
+    uint8_t *dst = bases + r * (uint64_t)read_len + (uint64_t)j * slot_len + off;
+    for (int i = 0; i < k; i++) {
+        const uint32_t code = (uint32_t)(key >> (2 * i)) & 3u;
+        dst[i] = (uint8_t)((0x54474341u >> (8 * code)) & 0xFFu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// calibration: random line gather and streaming read
+// ---------------------------------------------------------------------------------------
+// LPL lanes share one line (16 B per lane when LPL > 1; the whole line per lane when
+// LPL == 1, as LINE/16 consecutive 16-byte loads).  Each lane group draws `iters` x INF
+// independent random line indices; INF loads are in flight per lane before any is used.
+template <int LINE, int LPL, int INF>
+__global__ void __launch_bounds__(256)
+tbk_calib_gather_kernel(const uint4 *__restrict__ buf, uint64_t n_lines_buf, uint32_t iters, uint64_t seed,
+                        uint32_t *__restrict__ sink) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t group = gid / LPL;
+    const uint32_t sub = (uint32_t)(gid % LPL);
+    constexpr int PER_LINE = LINE / 16;           // 16-byte pieces per line
+    constexpr int PIECES = LPL == 1 ? PER_LINE : 1;  // pieces each lane loads per line
+    uint32_t acc = 0;
+    uint64_t state = seed ^ (group * 0x9E3779B97F4A7C15ull);
+    for (uint32_t it = 0; it < iters; it++) {
+        uint4 v[INF][PIECES];
+#pragma unroll
+        for (int f = 0; f < INF; f++) {
+            state = tbk_splitmix(state);
+            const uint64_t line = (uint64_t)(((unsigned __int128)state * n_lines_buf) >> 64);
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) {
+                const uint64_t piece = LPL == 1 ? (uint64_t)pc : (uint64_t)(sub % PER_LINE);
+                v[f][pc] = buf[line * PER_LINE + piece];
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < INF; f++)
+#pragma unroll
+            for (int pc = 0; pc < PIECES; pc++) acc += v[f][pc].x ^ v[f][pc].y ^ v[f][pc].z ^ v[f][pc].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;  // keep the loads alive
+}
+
+__global__ void __launch_bounds__(256)
+tbk_calib_stream_kernel(const uint4 *__restrict__ buf, uint64_t n_vec, uint32_t *__restrict__ sink) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n_vec; i += 4 * stride) {
+        const uint4 a = buf[i], b = buf[i + stride], c = buf[i + 2 * stride], d = buf[i + 3 * stride];
+        acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n_vec; i += stride) { const uint4 a = buf[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+tbk_fill_kernel(uint4 *__restrict__ buf, uint64_t n_vec, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_vec; i += stride) {
+        const uint64_t r = tbk_splitmix(seed + i);
+        buf[i] = make_uint4((uint32_t)r, (uint32_t)(r >> 32), (uint32_t)i, (uint32_t)(i >> 32));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+static inline unsigned grid_for(uint64_t n, unsigned cap = 1u << 16) {
+    uint64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+extern "C" hipError_t tbk_launch_synth_keys(uint64_t seed, uint64_t first, uint64_t n, int k, uint64_t *d_out,
+                                            hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tbk_synth_keys_kernel, dim3(grid_for(n)), dim3(256), 0, s, seed, first, n, k, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_synth_reads(uint64_t read_seed, uint64_t first_read, uint64_t n_reads,
+                                             uint32_t read_len, uint64_t key_seed, uint64_t n_a, uint64_t n_b,
+                                             int k, int major, int minor, uint8_t *d_bases, uint64_t *d_offsets,
+                                             hipStream_t s) {
+    if (!n_reads) return hipSuccess;
+    const uint64_t total = n_reads * (uint64_t)read_len;
+    const uint64_t n_chunks = (total + 15) / 16;  // buffer is allocated to a multiple of 16
+    const uint64_t first_chunk = first_read * (((uint64_t)read_len + 15) / 16);
+    hipLaunchKernelGGL(tbk_synth_background_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, s,
+                       read_seed, first_chunk, n_chunks, (uint4 *)d_bases);
+    hipLaunchKernelGGL(tbk_synth_offsets_kernel, dim3((unsigned)((n_reads + 256) / 256)), dim3(256), 0, s,
+                       n_reads, read_len, d_offsets);
+    const uint64_t n_plant = n_reads * (uint64_t)(major + minor);
+    if (n_plant)
+        hipLaunchKernelGGL(tbk_synth_plant_kernel, dim3((unsigned)((n_plant + 255) / 256)), dim3(256), 0, s,
+                           read_seed, first_read, n_reads, read_len, key_seed, n_a, n_b, k, major, minor,
+                           d_bases);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_fill(void *d_buf, uint64_t bytes, uint64_t seed, hipStream_t s) {
+    const uint64_t n_vec = bytes / 16;
+    hipLaunchKernelGGL(tbk_fill_kernel, dim3(grid_for(n_vec, 8192)), dim3(256), 0, s, (uint4 *)d_buf, n_vec, seed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_stream(const void *d_buf, uint64_t bytes, uint32_t *d_sink, hipStream_t s) {
+    const uint64_t n_vec = bytes / 16;
+    hipLaunchKernelGGL(tbk_calib_stream_kernel, dim3(256 * 16), dim3(256), 0, s, (const uint4 *)d_buf, n_vec, d_sink);
+    return hipGetLastError();
+}
+
+template <int LINE, int LPL, int INF>
+static hipError_t launch_gather_t(const void *d_buf, uint64_t bytes, uint64_t n_lines, uint64_t seed,
+                                  uint32_t *d_sink, hipStream_t s) {
+    const uint64_t n_lines_buf = bytes / LINE;
+    // groups = lines in flight at once; each group does iters*INF lines
+    const unsigned blocks = 256 * 8;  // 8 blocks of 256 threads per CU
+    const uint64_t groups = (uint64_t)blocks * 256 / LPL;
+    uint64_t iters = n_lines / (groups * INF);
+    if (iters < 1) iters = 1;
+    hipLaunchKernelGGL((tbk_calib_gather_kernel<LINE, LPL, INF>), dim3(blocks), dim3(256), 0, s,
+                       (const uint4 *)d_buf, n_lines_buf, (uint32_t)iters, seed, d_sink);
+    return hipGetLastError();
+}
+
+// returns the number of lines one launch actually gathers through *lines_done
+extern "C" hipError_t tbk_launch_gather(const void *d_buf, uint64_t bytes, int line, int lpl, int inf,
+                                        uint64_t n_lines, uint64_t seed, uint32_t *d_sink, uint64_t *lines_done,
+                                        hipStream_t s) {
+    const uint64_t groups = (uint64_t)256 * 8 * 256 / (uint64_t)lpl;
+    uint64_t iters = n_lines / (groups * (uint64_t)inf);
+    if (iters < 1) iters = 1;
+    *lines_done = iters * groups * (uint64_t)inf;
+#define TBK_G(L, P, F) \
+    if (line == L && lpl == P && inf == F) return launch_gather_t<L, P, F>(d_buf, bytes, n_lines, seed, d_sink, s);
+#define TBK_GF(L, P) TBK_G(L, P, 1) TBK_G(L, P, 2) TBK_G(L, P, 4) TBK_G(L, P, 8)
+    TBK_GF(64, 1) TBK_GF(64, 4) TBK_GF(128, 1) TBK_GF(128, 8)
+#undef TBK_GF
+#undef TBK_G
+    return hipErrorInvalidValue;
+}

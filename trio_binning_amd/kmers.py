@@ -1,0 +1,303 @@
+"""Counting parental k-mers in reads on an MI355X.
+
+Host-side mirror of the reference's ``trio_binning.kmers`` (src/trio_binning/kmers.py):
+the same five functions with the same argument meaning and error behaviour, bound to the
+HIP library's C-ABI (include/tbk.h) instead of the reference's c/kmers.c, plus the batch
+interface the GPU needs (``Classifier``).
+
+>>> hapA = kmers.create_kmer_hash_set("tests/data/hapA.txt")
+>>> hapB = kmers.create_kmer_hash_set("tests/data/hapB.txt")
+>>> kmers.count_kmers_in_read("CTTATCATGTCTTTGTTTTCAAAGCTTC...", hapA, hapB)
+(2, 1)
+
+Every function that computes needs a visible MI355X; there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import sys
+from os.path import isfile
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+def default_device() -> int:
+    """Device index used when none is given: TBK_DEVICE, else LOCAL_RANK, else 0."""
+    for var in ("TBK_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+class _Contents:
+    """Stand-in for ``POINTER(_HashSet).contents`` (reference kmers.py:41-59,159)."""
+
+    def __init__(self, hs):
+        self._hs = hs
+
+    @property
+    def num_kmers(self) -> int:
+        return self._hs.num_kmers
+
+    @property
+    def k(self) -> int:
+        return self._hs.k
+
+
+class HashSet:
+    """A k-mer list resident in HBM as an open-addressing 64-bit hash table.
+
+    Plays the role of the reference's ``HashSet`` pointer type (kmers.py:96-101): what
+    ``create_kmer_hash_set`` returns and ``count_kmers_in_read`` accepts.
+    """
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+
+    # -- construction ---------------------------------------------------------------------
+    @classmethod
+    def from_file(cls, path: str, device: Optional[int] = None) -> "HashSet":
+        h = C.c_void_p()
+        check(lib.tbk_table_create_from_file(os.fsencode(path), default_device() if device is None else device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_keys(cls, keys, k: int, num_lines: Optional[int] = None, device: Optional[int] = None) -> "HashSet":
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        h = C.c_void_p()
+        check(lib.tbk_table_create_from_keys(
+            keys.ctypes.data, keys.size, k, keys.size if num_lines is None else num_lines,
+            default_device() if device is None else device, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_device_keys(cls, d_keys: int, n: int, k: int, num_lines: Optional[int] = None,
+                         device: Optional[int] = None) -> "HashSet":
+        h = C.c_void_p()
+        check(lib.tbk_table_create_from_device_keys(
+            C.c_void_p(d_keys), n, k, n if num_lines is None else num_lines,
+            default_device() if device is None else device, C.byref(h)))
+        return cls(h.value)
+
+    # -- facts ----------------------------------------------------------------------------
+    @property
+    def num_kmers(self) -> int:
+        """Number of list lines, duplicates included (reference: hash_set.num_kmers)."""
+        return lib.tbk_table_num_kmers(self._h)
+
+    @property
+    def k(self) -> int:
+        return lib.tbk_table_k(self._h)
+
+    @property
+    def device(self) -> int:
+        return lib.tbk_table_device(self._h)
+
+    @property
+    def distinct(self) -> int:
+        return lib.tbk_table_distinct(self._h)
+
+    @property
+    def nbytes(self) -> int:
+        return lib.tbk_table_bytes(self._h)
+
+    @property
+    def n_buckets(self) -> int:
+        return lib.tbk_table_buckets(self._h)
+
+    @property
+    def contents(self) -> _Contents:
+        return _Contents(self)
+
+    def contains(self, keys) -> np.ndarray:
+        """Membership of raw packed keys (no canonicalisation)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(keys.size, dtype=np.uint8)
+        check(lib.tbk_table_contains(self._h, keys.ctypes.data, keys.size, out.ctypes.data))
+        return out.astype(bool)
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            lib.tbk_table_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+# ---- the reference's five functions ------------------------------------------------------
+def kmer_to_int(kmer: str) -> int:
+    """Convert a kmer to integer format (reference kmers.py:80-82 -> c/kmers.c:50-72)."""
+    raw = bytes(kmer, "utf-8")
+    return lib.tbk_kmer_to_int(raw, C.c_ubyte(len(kmer)))
+
+
+def reverse_complement(kmer: str) -> str:
+    """Reverse complement a k-mer (reference kmers.py:89-93 -> c/kmers.c:74-93).
+
+    As in the reference, the output starts as ``"x" * k`` and positions whose source
+    base is not one of ACGT keep the ``x``.
+    """
+    k = len(kmer)
+    out = C.create_string_buffer(b"x" * k, k + 1)
+    lib.tbk_reverse_complement(bytes(kmer, "utf-8"), out, k)
+    return out.raw[:k].decode("utf-8")
+
+
+def create_kmer_hash_set(kmer_file_path: str) -> HashSet:
+    """Read a list of k-mers (one per line) into a searchable set in HBM.
+
+    Same contract as the reference (kmers.py:104-122): ``IOError`` when the path is not
+    a file, a progress line on stderr, a handle for ``count_kmers_in_read``.
+    """
+    if not isfile(kmer_file_path):
+        raise IOError(f"Specified file {kmer_file_path} does not exist or is not file.")
+    print(f"Reading k-mers in {kmer_file_path}...", file=sys.stderr)
+    hs = HashSet.from_file(kmer_file_path)
+    print(
+        f"Found {hs.num_kmers} {hs.k}-mers in {kmer_file_path}; "
+        f"{hs.distinct} distinct keys in {hs.nbytes / 2**20:.1f} MiB of HBM on device {hs.device}.",
+        file=sys.stderr,
+    )
+    return hs
+
+
+def count_kmers_in_read(read: str, kmers_hap_a: HashSet, kmers_hap_b: HashSet) -> Tuple[int, int]:
+    """Count the k-mers of one read found in each of two sets (reference kmers.py:125-154).
+
+    Returns ``(count_a, count_b)``; a k-mer present in both sets counts for A only.  One
+    kernel launch per call: use ``Classifier`` for throughput.
+    """
+    raw = read.encode("utf-8")
+    ca, cb = C.c_int(), C.c_int()
+    check(lib.tbk_count_kmers_in_read(raw, len(raw), kmers_hap_a._h, kmers_hap_b._h, C.byref(ca), C.byref(cb)))
+    return ca.value, cb.value
+
+
+def get_number_kmers_in_set(kmer_hash_set: HashSet) -> int:
+    """Look up the number of k-mers in a hash set (reference kmers.py:157-159)."""
+    return kmer_hash_set.contents.num_kmers
+
+
+# ---- batch interface ---------------------------------------------------------------------
+def pack_reads(seqs: Sequence[str]) -> Tuple[np.ndarray, np.ndarray]:
+    """Concatenate read sequences into the batch layout of the C-ABI:
+    ``bases`` (uint8, back to back) and ``offsets`` (uint64, n+1)."""
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=len(seqs))
+    offsets = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    raw = "".join(seqs).encode("utf-8")
+    if len(raw) != int(offsets[-1]):
+        # non-ASCII text: lengths must be byte lengths
+        enc = [s.encode("utf-8") for s in seqs]
+        lens = np.fromiter((len(b) for b in enc), dtype=np.uint64, count=len(enc))
+        np.cumsum(lens, out=offsets[1:])
+        raw = b"".join(enc)
+    bases = np.frombuffer(raw, dtype=np.uint8)
+    return bases, offsets
+
+
+class Classifier:
+    """The batch hot path: per-read (hapA, hapB) k-mer hit counts for many reads at once.
+
+    Replaces the per-read Python loop of the reference driver
+    (classify_by_kmers.py:99-102).  ``submit``/``wait`` keep up to ``depth`` batches in
+    flight so the host-to-device copy of the next batch overlaps the kernel of the
+    current one.
+    """
+
+    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet):
+        h = C.c_void_p()
+        check(lib.tbk_classifier_create(kmers_hap_a._h, kmers_hap_b._h, C.byref(h)))
+        self._h = h
+        self._a, self._b = kmers_hap_a, kmers_hap_b  # keep the tables alive
+        self._keep = {}
+        self.device = kmers_hap_a.device
+
+    @property
+    def depth(self) -> int:
+        return lib.tbk_stream_depth(self._h)
+
+    def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        counts = np.zeros((n, 2), dtype=np.int32)
+        check(lib.tbk_classify_batch(self._h, bases.ctypes.data, offsets.ctypes.data, n, counts.ctypes.data))
+        return counts
+
+    def classify_reads(self, seqs: Sequence[str]) -> np.ndarray:
+        return self.classify_batch(*pack_reads(seqs))
+
+    def submit(self, bases: np.ndarray, offsets: np.ndarray) -> int:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        counts = np.zeros((n, 2), dtype=np.int32)
+        ticket = C.c_uint64()
+        check(lib.tbk_stream_submit(self._h, bases.ctypes.data, offsets.ctypes.data, n, counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (bases, offsets, counts)
+        return ticket.value
+
+    def wait(self, ticket: int) -> np.ndarray:
+        check(lib.tbk_stream_wait(self._h, ticket))
+        return self._keep.pop(ticket)[2]
+
+    # device-resident form (bench.py; inputs already in HBM)
+    def classify_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int, d_counts: int) -> None:
+        check(lib.tbk_classify_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, total_bases,
+                                      C.c_void_p(d_counts)))
+
+    def sync(self) -> None:
+        check(lib.tbk_classifier_sync(self._h))
+
+    def kernel_timing(self, on: bool) -> None:
+        check(lib.tbk_kernel_timing_enable(self._h, int(on)))
+
+    def kernel_timing_read(self) -> Tuple[int, float]:
+        n, ms = C.c_uint64(), C.c_double()
+        check(lib.tbk_kernel_timing_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            lib.tbk_classifier_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def score_and_bin(counts: np.ndarray, num_kmers_a: int, num_kmers_b: int):
+    """Scores and bins for a batch (classify_by_kmers.py:57-77,104-115), float64, in the
+    reference's operation order.  Returns (score_a, score_b, bins) with bins a bytes object
+    over b"ABU"."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n = counts.shape[0]
+    sa = np.zeros(n, dtype=np.float64)
+    sb = np.zeros(n, dtype=np.float64)
+    bins = C.create_string_buffer(n + 1)
+    check(lib.tbk_score_and_bin(counts.ctypes.data, n, num_kmers_a, num_kmers_b, sa.ctypes.data, sb.ctypes.data, bins))
+    return sa, sb, bins.raw[:n]
