@@ -120,8 +120,8 @@ def main():
 
     import __graft_entry__ as entry
 
-    if rank == 0:
-        entry.build()
+    if rank == 0 and os.environ.get("TBK_SKIP_BUILD") != "1":
+        entry.build()  # skipped under rocprofv3 (no child processes from a profiled process)
     dist = Dist(world)
     dist.barrier()
     from trio_binning_amd import _lib, kmers
@@ -144,9 +144,11 @@ def main():
     t0 = time.time()
     hap_a = kmers.HashSet.from_device_keys(d_keys, n_list, k, device=dev)
     hap_b = kmers.HashSet.from_device_keys(d_keys + n_list * 8, n_list, k, device=dev)
+    cls = kmers.Classifier(hap_a, hap_b)  # hashes both lists into the paired table in HBM
     check(lib.tbk_device_sync(dev))
     t_build = time.time() - t0
-    assert hap_a.distinct == n_list and hap_b.distinct == n_list, (hap_a.distinct, hap_b.distinct)
+    stats = cls.stats()
+    assert stats["distinct_a"] == n_list and stats["distinct_b"] == n_list, stats
 
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     h_keys = None
@@ -169,7 +171,6 @@ def main():
         batches.append((d_bases, d_offs, d_counts))
     t_setup = time.time() - t_setup
 
-    cls = kmers.Classifier(hap_a, hap_b)
     counts = np.zeros((R, 2), dtype=np.int32)
     num_a, num_b = hap_a.num_kmers, hap_b.num_kmers
     bins_total = {"A": 0, "B": 0, "U": 0}
@@ -237,7 +238,7 @@ def main():
             "workload": f"BASELINE configs[2] shape: {L} b synthetic reads, 2x{n_list} unique {k}-mers replicated per GPU, "
                         f"{R} reads ({total / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks",
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R, "resident_batches": nb,
-            "table_bytes_per_gpu": hap_a.nbytes + hap_b.nbytes, "table_load": round(n_list / (hap_a.n_buckets * 8), 4),
+            "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(n_list / (stats["n_buckets"] * 8), 4),
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "roofline": roofline,
@@ -246,7 +247,7 @@ def main():
     }
 
     if args.calibrate and rank == 0:
-        out["calibration"] = calibrate(lib, check, dev, hap_a.nbytes + hap_b.nbytes)
+        out["calibration"] = calibrate(lib, check, dev, stats["table_bytes"])
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -----------------------------
     if want_cpu:

@@ -65,42 +65,49 @@ uint64_t tbk_kmer_to_int(const char *kmer, unsigned char k);
  * complement(in[i]); a non-ACGT byte leaves out[k-1-i] untouched.  Host code. */
 void tbk_reverse_complement(const char *kmer_in, char *kmer_out, unsigned char k);
 
-/* ---- k-mer tables ------------------------------------------------------------------- */
+/* ---- k-mer lists ------------------------------------------------------------------- */
 /* Replaces create_kmer_hash_set (c/kmers.c:185-229; bound kmers.py:62-64,104-122) with
  * peek_at_file's rules (c/kmers.c:124-146): k = length of the first line as getline()
  * returns it, minus one; every line is one k-mer (duplicates counted, a last line without
  * '\n' counted); each line contributes its first k bytes, verbatim (no canonicalisation).
- * The keys are inserted into an open-addressing table of 64-bit slots in HBM on `device`. */
+ * The packed keys are placed in HBM on `device`; tbk_classifier_create hashes two such lists
+ * into the paired open-addressing table the probe kernel reads. */
 int tbk_table_create_from_file(const char *path, int device, tbk_table **out);
-/* Same table from already-packed keys in host memory.  `num_lines` is what
- * tbk_table_num_kmers will report (pass n when the keys are one-per-line). */
-int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, uint64_t num_lines,
-                               int device, tbk_table **out);
-/* Same, keys already in device memory on `device` (bench generator, N3 GPU parser). */
-int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, uint64_t num_lines,
-                                      int device, tbk_table **out);
+/* Same from already-packed keys (one per list line) in host memory. */
+int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, int device, tbk_table **out);
+/* Same, keys already in device memory on `device` (bench generator).  The keys are copied. */
+int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, int device, tbk_table **out);
 void tbk_table_destroy(tbk_table *t);
 /* Replaces the field read hash_set->num_kmers (kmers.py:157-159): number of list LINES. */
 uint64_t tbk_table_num_kmers(const tbk_table *t);
 int tbk_table_k(const tbk_table *t);
 int tbk_table_device(const tbk_table *t);
-/* Distinct keys stored, bytes of HBM held, number of 64-byte bucket lines. */
-uint64_t tbk_table_distinct(const tbk_table *t);
+/* Bytes of HBM this list holds (keys + its standalone hashed form once built). */
 uint64_t tbk_table_bytes(const tbk_table *t);
-uint64_t tbk_table_buckets(const tbk_table *t);
-/* Membership of raw packed keys (no canonicalisation): out[i] = 1/0.  Host pointers. */
-int tbk_table_contains(const tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out);
+/* Distinct keys in the list (builds the standalone hashed form on first use). */
+int tbk_table_distinct(tbk_table *t, uint64_t *distinct);
+/* Membership of raw packed keys (no canonicalisation): out[i] = 1/0.  Host pointers.
+ * Builds the standalone hashed form of the list on first use. */
+int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out);
 
 /* ---- the hot path ------------------------------------------------------------------- */
 /* Replaces count_kmers_in_read (c/kmers.c:270-299; bound kmers.py:66-73,125-154) for one
- * read: `read` is `len` bytes (len < 0: NUL-terminated).  Uses hap_a's k for both tables,
- * hapA wins when a k-mer is in both lists. */
+ * read: `read` is `len` bytes (len < 0: NUL-terminated).  hapA wins when a k-mer is in both
+ * lists.  Both lists must have the same k (TBK_ERR_INVALID otherwise; the reference mixes
+ * hapA's window length with hapB's packing there, c/kmers.c:251-253,278-290). */
 int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *hap_a,
                             const tbk_table *hap_b, int *count_a, int *count_b);
 
-/* Batch path (what the per-read Python loop classify_by_kmers.py:99-102 becomes). */
+/* Batch path (what the per-read Python loop classify_by_kmers.py:99-102 becomes).  Creating
+ * the classifier builds the two open-addressing tables in HBM on the lists' device: 64-bit
+ * slots, 8 per bucket per list, hapA's and hapB's bucket i interleaved in one 128-byte line
+ * (initialize_hash_set + add_to_hash, c/kmers.c:112-122,160-180).  The lists may be
+ * destroyed afterwards. */
 int tbk_classifier_create(const tbk_table *hap_a, const tbk_table *hap_b, tbk_classifier **out);
 void tbk_classifier_destroy(tbk_classifier *c);
+/* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
+int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
+                         uint64_t *n_buckets, uint64_t *table_bytes);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

@@ -215,19 +215,17 @@ def test_list_parser_rules(gpu, orc, tmp_path):
         kmers.HashSet.from_file(str(tmp_path / "missing.txt"))
 
 
-def test_mismatched_k_uses_hap_a_k(gpu, orc, tmp_path):
-    """The reference uses haplotype_A->k for both sets (c/kmers.c:278-290)."""
+def test_mismatched_k_is_rejected(gpu, tmp_path):
+    """The reference takes the window length from hapA's k but packs hapB lookups with
+    hapB's k (c/kmers.c:251-253,278-290); pairing lists of different k is refused."""
     from trio_binning_amd import kmers
 
-    fa = _write(tmp_path, "a.txt", "ACGTACGTACGT\nTTTTTTTTTTTT\nCCCCCCCCCCCA\nGGGGGGGGGGGA\n")
-    fb = _write(tmp_path, "b.txt", "ACGTACGTAC\nAAAAAAAAAA\nCCCCCCCCCA\nGGGGGGGGGA\n")  # k=10
-    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
-    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
-    reads = ["ACGTACGTACGTAAAAAAAAAAAAAAAAAAAA", "AAAAAAAAAAAA", "ACGTACGTACAA", "CCCCCCCCCAAAG"]
-    bases, offs = _pack(reads)
-    with kmers.Classifier(a, b) as cls:
-        got = cls.classify_batch(bases, offs)
-    assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
+    a = kmers.HashSet.from_file(_write(tmp_path, "a.txt", "ACGTACGTACGT\nTTTTTTTTTTTT\nCCCCCCCCCCCA\nGGGGGGGGGGGA\n"))
+    b = kmers.HashSet.from_file(_write(tmp_path, "b.txt", "ACGTACGTAC\nAAAAAAAAAA\nCCCCCCCCCA\nGGGGGGGGGA\n"))
+    with pytest.raises(ValueError):
+        kmers.Classifier(a, b)
+    with pytest.raises(ValueError):
+        kmers.count_kmers_in_read("ACGTACGTACGTAAAA", a, b)
 
 
 def test_table_membership_and_dedupe(gpu):
@@ -250,6 +248,9 @@ def test_table_membership_and_dedupe(gpu):
         del os.environ["TBK_TABLE_LOAD"]
     assert t2.distinct == t.distinct and t2.contains(keys).all() and not t2.contains(absent).any()
     assert t2.nbytes < t.nbytes
+    with kmers.Classifier(t, t2) as cls:
+        st = cls.stats()
+    assert st["distinct_a"] == st["distinct_b"] == t.distinct and st["table_bytes"] == st["n_buckets"] * 128
 
 
 def test_crowded_tables_walk_path(gpu, orc, tmp_path):
@@ -263,14 +264,16 @@ def test_crowded_tables_walk_path(gpu, orc, tmp_path):
     fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
     fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
     oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
-    os.environ["TBK_TABLE_LOAD"] = "0.9"
-    try:
-        a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
-    finally:
-        del os.environ["TBK_TABLE_LOAD"]
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
     reads = _rand_reads(rng, 400, 4000, la + lb, k, p_plant=1.0)
     bases, offs = _pack(reads)
-    with kmers.Classifier(a, b) as cls:
+    os.environ["TBK_TABLE_LOAD"] = "0.9"
+    try:
+        cls = kmers.Classifier(a, b)
+    finally:
+        del os.environ["TBK_TABLE_LOAD"]
+    with cls:
+        assert cls.stats()["n_buckets"] < 3000 / 8 / 0.85
         got = cls.classify_batch(bases, offs)
     want = orc.count_batch(bases, offs, oa, ob)
     assert np.array_equal(got, want)

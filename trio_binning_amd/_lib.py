@@ -65,19 +65,19 @@ _sig("tbk_device_name", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
 _sig("tbk_kmer_to_int", _u64, C.c_char_p, C.c_ubyte)
 _sig("tbk_reverse_complement", None, C.c_char_p, C.c_char_p, C.c_ubyte)
 _sig("tbk_table_create_from_file", C.c_int, C.c_char_p, C.c_int, C.POINTER(_vp))
-_sig("tbk_table_create_from_keys", C.c_int, _vp, _u64, C.c_int, _u64, C.c_int, C.POINTER(_vp))
-_sig("tbk_table_create_from_device_keys", C.c_int, _vp, _u64, C.c_int, _u64, C.c_int, C.POINTER(_vp))
+_sig("tbk_table_create_from_keys", C.c_int, _vp, _u64, C.c_int, C.c_int, C.POINTER(_vp))
+_sig("tbk_table_create_from_device_keys", C.c_int, _vp, _u64, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("tbk_table_destroy", None, _vp)
 _sig("tbk_table_num_kmers", _u64, _vp)
 _sig("tbk_table_k", C.c_int, _vp)
 _sig("tbk_table_device", C.c_int, _vp)
-_sig("tbk_table_distinct", _u64, _vp)
+_sig("tbk_table_distinct", C.c_int, _vp, _u64p)
 _sig("tbk_table_bytes", _u64, _vp)
-_sig("tbk_table_buckets", _u64, _vp)
 _sig("tbk_table_contains", C.c_int, _vp, _vp, _u64, _vp)
 _sig("tbk_count_kmers_in_read", C.c_int, C.c_char_p, C.c_int64, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_create", C.c_int, _vp, _vp, C.POINTER(_vp))
 _sig("tbk_classifier_destroy", None, _vp)
+_sig("tbk_classifier_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
 _sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
 _sig("tbk_stream_depth", C.c_int, _vp)
 _sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)

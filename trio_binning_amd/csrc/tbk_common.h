@@ -1,12 +1,19 @@
 // tbk_common.h — layout and arithmetic shared by host and device code of libtbk_hip.so.
 //
-// Table layout in HBM (one per k-mer list, replicated per GPU):
-//   an array of n_buckets bucket lines, each 64 bytes = 8 slots of uint64, 64-byte
-//   aligned so one probe is one aligned line.  A slot holds a packed k-mer (base i at
-//   bits 2i..2i+1, A=0 C=1 G=2 T=3 — the reference's encoding, c/kmers.c:50-72) or
-//   TBK_EMPTY.  A key lives in the first bucket, walking from its home bucket, that had a
-//   free slot when it was inserted (open addressing with linear probing at line
-//   granularity), so a lookup stops at the first line that still has a free slot.
+// Table layout in HBM (replicated per GPU).
+//   The classifier holds the two k-mer lists as two open-addressing tables of uint64 slots
+//   that share one bucket index and are interleaved line by line: bucket i is one 128-byte
+//   aligned line = [8 hapA slots | 8 hapB slots].  Measured on MI355X (profiles/,
+//   DESIGN.md §4): random line reads saturate at ~48 G lines/s whether the line is 64 or
+//   128 bytes, so fetching both tables' buckets as ONE 128-byte line halves the cost of a
+//   window compared with two independent 64-byte lines.  hapA and hapB stay separate tables
+//   (separate slots, separate probes, hapA priority applied afterwards).
+//   A slot holds a packed k-mer (base i at bits 2i..2i+1, A=0 C=1 G=2 T=3 — the reference's
+//   encoding, c/kmers.c:50-72) or TBK_EMPTY.  A key lives in the first bucket, walking from
+//   its home bucket, whose half had a free slot when it was inserted (linear probing at
+//   line granularity), so a lookup stops at the first half-line that still has a free slot.
+//   A standalone list (tbk_table) is just its packed keys in HBM; a single-table form of
+//   the same layout (64-byte lines, 8 slots) is built on demand for tbk_table_contains.
 //   The reference's layout (8-byte slots + a parallel "full" byte array at load 0.75,
 //   c/kmers.c:12-38,160-180) is not observable; only membership is.
 //
@@ -50,9 +57,19 @@ TBK_HD uint32_t tbk_home_bucket(uint64_t key, uint32_t n_buckets) {
     return tbk_reduce(tbk_mix32(key), n_buckets);
 }
 
-// Device view of one table.
+// Device view of a table: bucket b's slots for this list start at
+// slots[b * stride + half] (stride 8, half 0 for a standalone table; stride 16 and half 0 / 8
+// for the hapA / hapB halves of a paired table).
 struct TbkTableView {
-    const uint64_t *slots;  // n_buckets * 8
+    const uint64_t *slots;
+    uint32_t n_buckets;
+    uint32_t stride;  // slots per bucket line (8 or 16)
+    uint32_t half;    // first slot of this list inside the line (0 or 8)
+};
+
+// The paired (hapA | hapB) table the probe kernel reads: bucket b = 16 slots = 128 bytes.
+struct TbkPairView {
+    const uint64_t *slots;  // n_buckets * 16
     uint32_t n_buckets;
 };
 

@@ -25,11 +25,11 @@
 #include "tbk_common.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
-extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, const uint64_t *, uint64_t, unsigned long long *,
-                                        int *, hipStream_t);
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, const uint64_t *, uint64_t,
+                                        unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkTableView,
-                                       TbkTableView, int, int32_t *, int, hipStream_t);
+extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
+                                       int32_t *, int, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
                                              int, int, int, uint8_t *, uint64_t *, hipStream_t);
@@ -79,14 +79,20 @@ static double env_double(const char *name, double dflt) {
 }
 
 // ---- handles ---------------------------------------------------------------------------
+// A k-mer list in HBM: its packed keys, one per list line, verbatim (duplicates and all).
+// The hashed forms are built from these: the paired hapA|hapB table by the classifier, and
+// a standalone table (64-byte lines) on first use of tbk_table_contains / _distinct.
 struct tbk_table {
     int device = 0;
     int k = 0;
     uint64_t num_lines = 0;  // what the reference calls num_kmers (c/kmers.c:37)
-    uint64_t distinct = 0;
-    uint32_t n_buckets = 0;
+    uint64_t *d_keys = nullptr;
+    // lazily built standalone table
     uint64_t *d_slots = nullptr;
-    TbkTableView view() const { return TbkTableView{d_slots, n_buckets}; }
+    uint32_t n_buckets = 0;
+    uint64_t distinct = 0;
+    bool hashed = false;
+    TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0}; }
 };
 
 static constexpr int RING = 3;
@@ -108,7 +114,10 @@ struct Slot {
 struct tbk_classifier {
     int device = 0;
     int k = 0;
-    TbkTableView a{}, b{};
+    uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B: [8 hapA slots | 8 hapB slots]
+    uint32_t n_buckets = 0;
+    uint64_t distinct_a = 0, distinct_b = 0;
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
     uint64_t next_ticket = 1;
@@ -179,73 +188,82 @@ static uint32_t buckets_for(uint64_t n_keys) {
     return (uint32_t)nb;
 }
 
-static int table_build(const uint64_t *d_keys, uint64_t n, int k, uint64_t num_lines, int device, tbk_table **out) {
-    tbk_table *t = new tbk_table();
-    t->device = device; t->k = k; t->num_lines = num_lines;
-    t->n_buckets = buckets_for(n);
-    const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
+// Insert n keys into one list's slots of a table (standalone: stride 8, half 0; paired:
+// stride 16, half 0 / 8).  The slots must already be filled with TBK_EMPTY.
+static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, const uint64_t *d_keys,
+                       uint64_t n, uint64_t *distinct_out) {
     unsigned long long *d_distinct = nullptr;
     int *d_failed = nullptr;
-    auto cleanup = [&]() {
-        if (d_distinct) (void)hipFree(d_distinct);
-        if (d_failed) (void)hipFree(d_failed);
-    };
-#define TB_TRY(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            cleanup(); if (t->d_slots) (void)hipFree(t->d_slots); delete t;                   \
-            return fail(e_ == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "%s: %s", #expr, \
-                        hipGetErrorString(e_));                                               \
-        }                                                                                     \
-    } while (0)
-    TB_TRY(hipMalloc((void **)&t->d_slots, bytes));
-    TB_TRY(hipMemset(t->d_slots, 0xFF, bytes));
-    TB_TRY(hipMalloc((void **)&d_distinct, sizeof(unsigned long long)));
-    TB_TRY(hipMalloc((void **)&d_failed, sizeof(int)));
-    TB_TRY(hipMemset(d_distinct, 0, sizeof(unsigned long long)));
-    TB_TRY(hipMemset(d_failed, 0, sizeof(int)));
-    TB_TRY(tbk_launch_insert(t->d_slots, t->n_buckets, d_keys, n, d_distinct, d_failed, nullptr));
+    hipError_t e = hipMalloc((void **)&d_distinct, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d_distinct, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
+    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, d_keys, n, d_distinct, d_failed, nullptr);
     unsigned long long distinct = 0;
     int failed = 0;
-    TB_TRY(hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost));
-    TB_TRY(hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost));
-#undef TB_TRY
-    cleanup();
-    if (failed) { (void)hipFree(t->d_slots); delete t; return fail(TBK_ERR_HIP, "table insert overflowed (table full)"); }
-    t->distinct = distinct;
+    if (e == hipSuccess) e = hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
+    if (d_distinct) (void)hipFree(d_distinct);
+    if (d_failed) (void)hipFree(d_failed);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "table insert: %s", hipGetErrorString(e));
+    if (failed) return fail(TBK_ERR_HIP, "table insert overflowed (table full)");
+    *distinct_out = distinct;
+    return TBK_OK;
+}
+
+// Build the standalone hashed form of a list on first use.
+static int table_hash(tbk_table *t) {
+    if (t->hashed) return TBK_OK;
+    int rc = use_device(t->device);
+    if (rc) return rc;
+    t->n_buckets = buckets_for(t->num_lines);
+    const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
+    HIP_TRY(hipMalloc((void **)&t->d_slots, bytes));
+    hipError_t e = hipMemset(t->d_slots, 0xFF, bytes);
+    if (e == hipSuccess) rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, t->d_keys, t->num_lines, &t->distinct);
+    else rc = fail(TBK_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+    if (rc) { (void)hipFree(t->d_slots); t->d_slots = nullptr; return rc; }
+    t->hashed = true;
+    return TBK_OK;
+}
+
+static int table_new(const uint64_t *src, bool src_on_device, uint64_t n, int k, uint64_t num_lines, int device,
+                     tbk_table **out) {
+    tbk_table *t = new tbk_table();
+    t->device = device; t->k = k; t->num_lines = n;
+    (void)num_lines;
+    hipError_t e = hipMalloc((void **)&t->d_keys, (n ? n : 1) * sizeof(uint64_t));
+    if (e == hipSuccess && n)
+        e = hipMemcpy(t->d_keys, src, n * sizeof(uint64_t), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (t->d_keys) (void)hipFree(t->d_keys);
+        delete t;
+        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "table keys: %s", hipGetErrorString(e));
+    }
     *out = t;
     return TBK_OK;
 }
 
-extern "C" int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, uint64_t num_lines,
-                                                 int device, tbk_table **out) {
+extern "C" int tbk_table_create_from_device_keys(const void *d_keys, uint64_t n, int k, int device, tbk_table **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (k < 1 || k > 32) return fail(TBK_ERR_INVALID, "k = %d outside 1..32", k);
-    if (n && !d_keys) return fail(TBK_ERR_INVALID, "keys is NULL");
+    if (!n) return fail(TBK_ERR_FORMAT, "empty k-mer list");
+    if (!d_keys) return fail(TBK_ERR_INVALID, "keys is NULL");
     int rc = use_device(device);
     if (rc) return rc;
-    return table_build((const uint64_t *)d_keys, n, k, num_lines, device, out);
+    return table_new((const uint64_t *)d_keys, true, n, k, n, device, out);
 }
 
-extern "C" int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, uint64_t num_lines, int device,
-                                          tbk_table **out) {
+extern "C" int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, int device, tbk_table **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (k < 1 || k > 32) return fail(TBK_ERR_INVALID, "k = %d outside 1..32", k);
-    if (n && !keys) return fail(TBK_ERR_INVALID, "keys is NULL");
+    if (!n) return fail(TBK_ERR_FORMAT, "empty k-mer list");
+    if (!keys) return fail(TBK_ERR_INVALID, "keys is NULL");
     int rc = use_device(device);
     if (rc) return rc;
-    uint64_t *d_keys = nullptr;
-    if (n) {
-        HIP_TRY(hipMalloc((void **)&d_keys, n * sizeof(uint64_t)));
-        hipError_t e = hipMemcpy(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d_keys); return fail(TBK_ERR_HIP, "hipMemcpy keys: %s", hipGetErrorString(e)); }
-    }
-    rc = table_build(d_keys, n, k, num_lines, device, out);
-    if (d_keys) (void)hipFree(d_keys);
-    return rc;
+    return table_new(keys, false, n, k, n, device, out);
 }
 
 // Text list -> packed keys with the reference's getline() rules (c/kmers.c:124-146,204-221):
@@ -303,7 +321,7 @@ extern "C" int tbk_table_create_from_file(const char *path, int device, tbk_tabl
     int k = 0;
     int rc = parse_list(path, keys, k);
     if (rc) return rc;
-    return tbk_table_create_from_keys(keys.data(), keys.size(), k, keys.size(), device, out);
+    return tbk_table_create_from_keys(keys.data(), keys.size(), k, device, out);
 }
 
 static void drop_cached_classifier(const tbk_table *t);
@@ -311,20 +329,32 @@ static void drop_cached_classifier(const tbk_table *t);
 extern "C" void tbk_table_destroy(tbk_table *t) {
     if (!t) return;
     drop_cached_classifier(t);
-    if (hipSetDevice(t->device) == hipSuccess && t->d_slots) (void)hipFree(t->d_slots);
+    if (hipSetDevice(t->device) == hipSuccess) {
+        if (t->d_keys) (void)hipFree(t->d_keys);
+        if (t->d_slots) (void)hipFree(t->d_slots);
+    }
     delete t;
 }
 
 extern "C" uint64_t tbk_table_num_kmers(const tbk_table *t) { return t ? t->num_lines : 0; }
 extern "C" int tbk_table_k(const tbk_table *t) { return t ? t->k : 0; }
 extern "C" int tbk_table_device(const tbk_table *t) { return t ? t->device : -1; }
-extern "C" uint64_t tbk_table_distinct(const tbk_table *t) { return t ? t->distinct : 0; }
-extern "C" uint64_t tbk_table_bytes(const tbk_table *t) { return t ? (uint64_t)t->n_buckets * TBK_BUCKET_BYTES : 0; }
-extern "C" uint64_t tbk_table_buckets(const tbk_table *t) { return t ? t->n_buckets : 0; }
+extern "C" uint64_t tbk_table_bytes(const tbk_table *t) {
+    return t ? t->num_lines * sizeof(uint64_t) + (t->hashed ? (uint64_t)t->n_buckets * TBK_BUCKET_BYTES : 0) : 0;
+}
+extern "C" int tbk_table_distinct(tbk_table *t, uint64_t *distinct) {
+    if (!t || !distinct) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = table_hash(t);
+    if (rc) return rc;
+    *distinct = t->distinct;
+    return TBK_OK;
+}
 
-extern "C" int tbk_table_contains(const tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out) {
+extern "C" int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *out) {
     if (!t || (n && (!keys || !out))) return fail(TBK_ERR_INVALID, "NULL argument");
     int rc = use_device(t->device);
+    if (rc) return rc;
+    rc = table_hash(t);
     if (rc) return rc;
     if (!n) return TBK_OK;
     uint64_t *d_keys = nullptr;
@@ -346,15 +376,29 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     *out = nullptr;
     if (!a || !b) return fail(TBK_ERR_INVALID, "table is NULL");
     if (a->device != b->device) return fail(TBK_ERR_INVALID, "tables live on different devices (%d, %d)", a->device, b->device);
+    // The reference takes the window length from haplotype_A->k but packs hapB lookups with
+    // hapB's own k (c/kmers.c:251-253,278-290) — only meaningful when both are equal.
+    if (a->k != b->k) return fail(TBK_ERR_INVALID, "the two k-mer lists have different k (%d and %d)", a->k, b->k);
     int rc = use_device(a->device);
     if (rc) return rc;
     tbk_classifier *c = new tbk_classifier();
     c->device = a->device;
-    c->k = a->k;  // the reference uses haplotype_A->k for both sets (c/kmers.c:278-290)
-    c->a = a->view();
-    c->b = b->view();
+    c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
-    hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
+    // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines));
+    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
+    if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
+    if (e != hipSuccess) {
+        if (c->d_pair) (void)hipFree(c->d_pair);
+        delete c;
+        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, a->d_keys, a->num_lines, &c->distinct_a);
+    if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, b->d_keys, b->num_lines, &c->distinct_b);
+    if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
+    e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
     for (int i = 0; i < RING && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
@@ -365,6 +409,16 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
     }
     *out = c;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
+                                    uint64_t *n_buckets, uint64_t *table_bytes) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (distinct_a) *distinct_a = c->distinct_a;
+    if (distinct_b) *distinct_b = c->distinct_b;
+    if (n_buckets) *n_buckets = c->n_buckets;
+    if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     return TBK_OK;
 }
 
@@ -384,6 +438,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             if (s.done) (void)hipEventDestroy(s.done);
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+        if (c->d_pair) (void)hipFree(c->d_pair);
         if (c->compute) (void)hipStreamDestroy(c->compute);
         if (c->copy) (void)hipStreamDestroy(c->copy);
     }
@@ -424,7 +479,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         c->timed_launches++;
         HIP_TRY(hipEventRecord(e0, c->compute));
     }
-    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->a, c->b, c->k, d_counts, c->max_blocks, c->compute));
+    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->max_blocks, c->compute));
     if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
     return TBK_OK;
 }

@@ -15,23 +15,25 @@
 // =======================================================================================
 // insert
 // =======================================================================================
-// One key per thread.  Scan the home line; claim the first free slot with a 64-bit CAS;
-// a line without a free slot sends the key to the next line.  Duplicates are detected
-// (the reference stores them twice, c/kmers.c:112-122; membership is the same).
+// One key per thread.  Scan this list's 8 slots of the home bucket; claim the first free
+// slot with a 64-bit CAS; a bucket half without a free slot sends the key to the next
+// bucket.  Duplicates are detected (the reference stores them twice, c/kmers.c:112-122;
+// membership is the same).  `stride`/`half` select a standalone table (8, 0) or the hapA /
+// hapB half of a paired table (16, 0 / 8).
 __global__ void __launch_bounds__(256)
-tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets,
+tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half,
                   const uint64_t *__restrict__ keys, uint64_t n,
                   unsigned long long *__restrict__ n_distinct, int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     unsigned long long mine = 0;
-    for (; i < n; i += stride) {
+    for (; i < n; i += step) {
         const uint64_t key = keys[i];
         if (key == TBK_EMPTY) continue;
         uint32_t b = tbk_home_bucket(key, n_buckets);
         bool done = false;
         for (uint32_t walked = 0; walked < n_buckets && !done; walked++) {
-            unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * TBK_SLOTS_PER_BUCKET);
+            unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
             for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
                 unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == key) { done = true; break; }
@@ -50,7 +52,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets,
 }
 
 // =======================================================================================
-// contains (raw keys; one thread per key, whole-line scan) — test utility, not the hot path
+// contains (raw keys; one thread per key, whole-bucket scan) — test utility, not the hot path
 // =======================================================================================
 __global__ void __launch_bounds__(256)
 tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t n,
@@ -62,7 +64,7 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
     if (key != TBK_EMPTY) {
         uint32_t b = tbk_home_bucket(key, t.n_buckets);
         for (uint32_t walked = 0; walked < t.n_buckets; walked++) {
-            const uint64_t *line = t.slots + (uint64_t)b * TBK_SLOTS_PER_BUCKET;
+            const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
             bool has_free = false;
             for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
                 uint64_t cur = line[s];
@@ -89,14 +91,16 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // forward stream and the 96-bit reverse-complement stream in registers, from which each
 // window's forward and reverse-complement k-mer are bit slices (no per-base loop).
 //
-// Probing is quad-cooperative: a 64-byte bucket line is read by the 4 lanes of a quad,
-// 16 bytes (2 slots) each, so one wave-instruction fetches 16 whole lines with 4 adjacent
-// lanes per line (coalesced bucket-line loads).  In sub-step (j, s) quad q probes window
-// j of its lane s: key and bucket indices are broadcast inside the quad with DPP
-// quad_perm moves, each lane compares its two slots, and the v_cmp results are the wave
-// ballots: a key is stored at most once per table, so popcount(ballot) is the number of
-// windows that hit.  hapA has priority over hapB (c/kmers.c:291-294): both lines are
-// fetched concurrently and the hapB ballot is masked by the quad-expanded hapA ballot.
+// Probing is quad-cooperative: a bucket is one 128-byte line [8 hapA slots | 8 hapB slots]
+// read by the 4 lanes of a quad, each lane taking 16 bytes (2 slots) of the hapA half and
+// 16 bytes of the hapB half, so one wave-instruction touches 16 whole lines with 4 adjacent
+// lanes per line (coalesced bucket-line loads) and a window costs ONE random line for both
+// probes.  In sub-step (j, s) quad q probes window j of its lane s: key and bucket index are
+// broadcast inside the quad with DPP quad_perm moves, each lane compares its slots, and the
+// v_cmp results are the wave ballots: a key is stored at most once per table, so
+// popcount(ballot) is the number of windows that hit.  hapA has priority over hapB
+// (c/kmers.c:291-294): both halves are fetched concurrently and the hapB ballot is masked
+// by the quad-expanded hapA ballot.
 //
 // Per-read attribution.  A pass that lies inside one read (the usual case for long
 // reads) accumulates its two counts in scalar registers and issues one atomicAdd pair.
@@ -114,7 +118,7 @@ struct ProbeArgs {
     uint64_t n_reads;
     uint64_t total;           // offsets[n_reads]
     uint64_t n_passes;
-    TbkTableView a, b;
+    TbkPairView t;            // hapA | hapB interleaved
     int k;
     int32_t *counts;          // [n_reads][2], zeroed by the caller
 };
@@ -184,10 +188,11 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
     return (m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x1111111111111111ull;
 }
 
-// Continue a lookup past lines that had no free slot.  `pending` has a bit at lane 0 of
-// every quad that must keep walking; returns the quads (lane-0 bits) that found the key.
-// Rare: a line is full with probability < 1% at the load factors the library builds.
-__device__ __noinline__ uint64_t probe_walk(const TbkTableView t, uint64_t key, uint32_t bucket,
+// Continue a lookup past buckets whose half (hapA: half = 0, hapB: half = 8) had no free
+// slot.  `pending` has a bit at lane 0 of every quad that must keep walking; returns the
+// quads (lane-0 bits) that found the key.  Rare: a half is full with probability < 1% at
+// the load factors the library builds.
+__device__ __noinline__ uint64_t probe_walk(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket,
                                             uint64_t pending, uint32_t sub) {
     uint64_t found = 0;
     const uint64_t my_quad_bit = 1ull << (__lane_id() & ~3u);
@@ -196,7 +201,7 @@ __device__ __noinline__ uint64_t probe_walk(const TbkTableView t, uint64_t key, 
         const bool act = (pending & my_quad_bit) != 0;
         bucket = bucket + 1 == t.n_buckets ? 0 : bucket + 1;
         ulonglong2 v = make_ulonglong2(0, 0);
-        if (act) v = *reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 8 + sub * 2);
+        if (act) v = *reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half + sub * 2);
         const uint64_t hit = quad_any(__ballot(act && (v.x == key || v.y == key)));
         const uint64_t fre = quad_any(__ballot(act && (v.x == TBK_EMPTY || v.y == TBK_EMPTY)));
         found |= hit;
@@ -204,12 +209,6 @@ __device__ __noinline__ uint64_t probe_walk(const TbkTableView t, uint64_t key, 
     }
     return found;
 }
-
-template <int S>
-struct SubStep {
-    uint32_t klo, khi, ba, bb, ok, rid;
-    ulonglong2 va, vb;
-};
 
 template <bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
@@ -258,9 +257,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             while (rid < p.n_reads && pw >= rend) { rid++; rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total; }
         }
         const bool ok = ((bad48 >> j) & badk) == 0 && pw + (uint64_t)k <= rend && rid < p.n_reads;
-        const uint32_t h = tbk_mix32(key);
-        const uint32_t my_ba = ok ? tbk_reduce(h, p.a.n_buckets) : 0u;
-        const uint32_t my_bb = ok ? tbk_reduce(h, p.b.n_buckets) : 0u;
+        const uint32_t my_bk = ok ? tbk_home_bucket(key, p.t.n_buckets) : 0u;
         const uint32_t my_klo = (uint32_t)key, my_khi = (uint32_t)(key >> 32);
         const uint32_t my_ok = ok ? 1u : 0u;
         const uint32_t my_rid = (uint32_t)rid;
@@ -270,19 +267,19 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
 
         // ---- four quad sub-steps: fetch both lines of each of the quad's 4 windows -----
-        uint32_t klo[4], khi[4], ba[4], bb[4], okq[4], ridq[4];
+        uint32_t klo[4], khi[4], bk[4], okq[4], ridq[4];
         ulonglong2 va[4], vb[4];
 #define TBK_BCAST(S)                                                        \
         klo[S] = quad_bcast<S>(my_klo); khi[S] = quad_bcast<S>(my_khi);     \
-        ba[S] = quad_bcast<S>(my_ba);   bb[S] = quad_bcast<S>(my_bb);       \
-        okq[S] = quad_bcast<S>(my_ok);                                      \
+        bk[S] = quad_bcast<S>(my_bk);   okq[S] = quad_bcast<S>(my_ok);      \
         if (MULTI) ridq[S] = quad_bcast<S>(my_rid);
         TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
 #undef TBK_BCAST
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            va[s] = *reinterpret_cast<const ulonglong2 *>(p.a.slots + (uint64_t)ba[s] * 8 + sub * 2);
-            vb[s] = *reinterpret_cast<const ulonglong2 *>(p.b.slots + (uint64_t)bb[s] * 8 + sub * 2);
+            const uint64_t *line = p.t.slots + (uint64_t)bk[s] * 16 + sub * 2;
+            va[s] = *reinterpret_cast<const ulonglong2 *>(line);
+            vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
         }
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -294,9 +291,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             uint64_t hit_b = quad_any(__ballot(vb[s].x == kk || vb[s].y == kk)) & okm;
             const uint64_t fre_b = quad_any(__ballot(vb[s].x == TBK_EMPTY || vb[s].y == TBK_EMPTY));
             const uint64_t more_a = okm & ~hit_a & ~fre_a;
-            if (more_a) hit_a |= probe_walk(p.a, kk, ba[s], more_a, sub);
+            if (more_a) hit_a |= probe_walk(p.t, 0, kk, bk[s], more_a, sub);
             const uint64_t more_b = okm & ~hit_a & ~hit_b & ~fre_b;
-            if (more_b) hit_b |= probe_walk(p.b, kk, bb[s], more_b, sub);
+            if (more_b) hit_b |= probe_walk(p.t, 8, kk, bk[s], more_b, sub);
             hit_b &= ~hit_a;  // hapA wins (c/kmers.c:291-294)
             if (!MULTI) {
                 acc_a += (uint32_t)__popcll(hit_a);
@@ -349,14 +346,14 @@ tbk_probe_kernel(const ProbeArgs p) {
 // =======================================================================================
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
-extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, const uint64_t *d_keys,
-                                        uint64_t n, unsigned long long *d_distinct, int *d_failed,
-                                        hipStream_t stream) {
+extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half,
+                                        const uint64_t *d_keys, uint64_t n, unsigned long long *d_distinct,
+                                        int *d_failed, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets,
-                       d_keys, n, d_distinct, d_failed);
+    hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
+                       half, d_keys, n, d_distinct, d_failed);
     return hipGetLastError();
 }
 
@@ -369,13 +366,13 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
 }
 
 extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                                       uint64_t total, TbkTableView a, TbkTableView b, int k,
-                                       int32_t *d_counts, int max_blocks, hipStream_t stream) {
+                                       uint64_t total, TbkPairView t, int k, int32_t *d_counts, int max_blocks,
+                                       hipStream_t stream) {
     if (total == 0 || n_reads == 0) return hipSuccess;
     ProbeArgs p;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    p.a = a; p.b = b; p.k = k; p.counts = d_counts;
+    p.t = t; p.k = k; p.counts = d_counts;
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
     hipLaunchKernelGGL(tbk_probe_kernel, dim3((unsigned)blocks), dim3(64 * TBK_WAVES_PER_BLOCK), 0, stream, p);

@@ -49,10 +49,12 @@ class _Contents:
 
 
 class HashSet:
-    """A k-mer list resident in HBM as an open-addressing 64-bit hash table.
+    """A parental k-mer list resident in HBM (packed 64-bit keys).
 
     Plays the role of the reference's ``HashSet`` pointer type (kmers.py:96-101): what
-    ``create_kmer_hash_set`` returns and ``count_kmers_in_read`` accepts.
+    ``create_kmer_hash_set`` returns and ``count_kmers_in_read`` accepts.  Pairing two of
+    them in a ``Classifier`` hashes them into the open-addressing tables the probe kernel
+    reads; ``contains`` hashes this list on its own.
     """
 
     def __init__(self, handle: int):
@@ -66,21 +68,18 @@ class HashSet:
         return cls(h.value)
 
     @classmethod
-    def from_keys(cls, keys, k: int, num_lines: Optional[int] = None, device: Optional[int] = None) -> "HashSet":
+    def from_keys(cls, keys, k: int, device: Optional[int] = None) -> "HashSet":
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         h = C.c_void_p()
         check(lib.tbk_table_create_from_keys(
-            keys.ctypes.data, keys.size, k, keys.size if num_lines is None else num_lines,
-            default_device() if device is None else device, C.byref(h)))
+            keys.ctypes.data, keys.size, k, default_device() if device is None else device, C.byref(h)))
         return cls(h.value)
 
     @classmethod
-    def from_device_keys(cls, d_keys: int, n: int, k: int, num_lines: Optional[int] = None,
-                         device: Optional[int] = None) -> "HashSet":
+    def from_device_keys(cls, d_keys: int, n: int, k: int, device: Optional[int] = None) -> "HashSet":
         h = C.c_void_p()
         check(lib.tbk_table_create_from_device_keys(
-            C.c_void_p(d_keys), n, k, n if num_lines is None else num_lines,
-            default_device() if device is None else device, C.byref(h)))
+            C.c_void_p(d_keys), n, k, default_device() if device is None else device, C.byref(h)))
         return cls(h.value)
 
     # -- facts ----------------------------------------------------------------------------
@@ -99,15 +98,14 @@ class HashSet:
 
     @property
     def distinct(self) -> int:
-        return lib.tbk_table_distinct(self._h)
+        """Distinct keys in the list (hashes the list on its own on first use)."""
+        n = C.c_uint64()
+        check(lib.tbk_table_distinct(self._h, C.byref(n)))
+        return n.value
 
     @property
     def nbytes(self) -> int:
         return lib.tbk_table_bytes(self._h)
-
-    @property
-    def n_buckets(self) -> int:
-        return lib.tbk_table_buckets(self._h)
 
     @property
     def contents(self) -> _Contents:
@@ -167,11 +165,7 @@ def create_kmer_hash_set(kmer_file_path: str) -> HashSet:
         raise IOError(f"Specified file {kmer_file_path} does not exist or is not file.")
     print(f"Reading k-mers in {kmer_file_path}...", file=sys.stderr)
     hs = HashSet.from_file(kmer_file_path)
-    print(
-        f"Found {hs.num_kmers} {hs.k}-mers in {kmer_file_path}; "
-        f"{hs.distinct} distinct keys in {hs.nbytes / 2**20:.1f} MiB of HBM on device {hs.device}.",
-        file=sys.stderr,
-    )
+    print(f"Found {hs.num_kmers} {hs.k}-mers in {kmer_file_path} (in HBM on device {hs.device}).", file=sys.stderr)
     return hs
 
 
@@ -230,6 +224,12 @@ class Classifier:
     @property
     def depth(self) -> int:
         return lib.tbk_stream_depth(self._h)
+
+    def stats(self) -> dict:
+        """Distinct keys per list, bucket lines and bytes of the paired table in HBM."""
+        da, db, nb, by = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.tbk_classifier_stats(self._h, C.byref(da), C.byref(db), C.byref(nb), C.byref(by)))
+        return {"distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value}
 
     def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
