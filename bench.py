@@ -8,7 +8,8 @@ on): k = 21, two 300 M-entry synthetic unique-k-mer tables replicated in each GP
 synthetic 15 kb reads with planted list k-mers.  A *step* is one pass of the
 hot path over one batch of reads that is already resident in HBM when the timed region
 starts: zero the counts, run the probe kernel, copy the per-read counts to the host and
-take the A/B/U binning decision there.  `value` = bases classified by all ranks / wall time
+take the A/B/U binning decision there (the host part of step i-1 overlaps the kernel of
+step i; every step's host part is inside the timed region).  `value` = bases classified by all ranks / wall time
 between two barriers.  Reads are sharded across ranks (each rank draws its own reads from
 the generator), tables are replicated, there is no collective on the data path; the only
 cross-rank traffic is the barrier and the max/sum of the timing (gloo).
@@ -171,28 +172,37 @@ def main():
         batches.append((d_bases, d_offs, d_counts))
     t_setup = time.time() - t_setup
 
-    counts = np.zeros((R, 2), dtype=np.int32)
+    depth = cls.depth
+    counts_ring = [kmers.pinned_empty((R, 2), np.int32) for _ in range(depth)]
     num_a, num_b = hap_a.num_kmers, hap_b.num_kmers
     bins_total = {"A": 0, "B": 0, "U": 0}
 
-    def step(i, tally=False):
-        d_bases, d_offs, d_counts = batches[i % nb]
-        cls.classify_device(d_bases, d_offs, R, total, d_counts)
-        cls.sync()
-        check(lib.tbk_memcpy_d2h(dev, counts.ctypes.data, C.c_void_p(d_counts), counts.nbytes))
-        _, _, bins = kmers.score_and_bin(counts, num_a, num_b)
+    def finish(ticket, slot, tally):
+        """Host side of a step: wait for its counts, take the A/B/U decision."""
+        cls.wait(ticket)
+        _, _, bins = kmers.score_and_bin(counts_ring[slot], num_a, num_b)
         if tally:
             for name, ch in (("A", b"A"), ("B", b"B"), ("U", b"U")):
                 bins_total[name] += bins.count(ch)
 
-    for i in range(args.warmup):
-        step(i)
+    def run(n_steps, tally):
+        """n_steps steps, pipelined: the host finishes step i-1 while the GPU probes step i."""
+        pending = []
+        for i in range(n_steps):
+            d_bases, d_offs, _ = batches[i % nb]
+            slot = i % depth
+            if len(pending) == depth - 1 + (depth == 1):
+                finish(*pending.pop(0), tally)
+            pending.append((cls.submit_device(d_bases, d_offs, R, total, counts_ring[slot]), slot))
+        while pending:
+            finish(*pending.pop(0), tally)
+
+    run(args.warmup, False)
     cls.kernel_timing(True)
     check(lib.tbk_device_sync(dev))
     dist.barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, tally=True)
+    run(args.steps, True)
     check(lib.tbk_device_sync(dev))
     dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -206,7 +216,8 @@ def main():
     # ---- roofline of the probe kernel (rank 0's device) -----------------------------------------
     # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
     # hapB slot when hapA missed.  Per launch: windows = R * (L - k + 1).
-    step(0)
+    counts = counts_ring[0]
+    finish(cls.submit_device(batches[0][0], batches[0][1], R, total, counts), 0, False)
     hits_a = int(counts[:, 0].sum())
     windows = R * max(0, L - k + 1)
     alg_bytes = windows * 9 + (windows - hits_a) * 8
@@ -239,6 +250,7 @@ def main():
                         f"{R} reads ({total / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks",
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R, "resident_batches": nb,
             "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(n_list / (stats["n_buckets"] * 8), 4),
+            "bucket_select": ("minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])) if stats["minimizer_w"] else "plain hash",
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "roofline": roofline,

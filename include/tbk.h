@@ -108,6 +108,10 @@ void tbk_classifier_destroy(tbk_classifier *c);
 /* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
 int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
                          uint64_t *n_buckets, uint64_t *table_bytes);
+/* How a key picks its bucket: the minimizer (w m-mers of length m, starting at base
+ * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
+ * Env TBK_MINIMIZER_W (default 6) and TBK_TABLE_LOAD tune it; neither changes any result. */
+int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
@@ -131,6 +135,12 @@ void tbk_host_free(void *p);
 int tbk_classify_device(tbk_classifier *c, const void *d_bases, const void *d_offsets,
                         uint64_t n_reads, uint64_t total_bases, void *d_counts);
 int tbk_classifier_sync(tbk_classifier *c);
+/* Device-resident batch through the same ticket ring as tbk_stream_submit: the kernel runs
+ * on the compute stream and the counts are copied to `counts` (host; pinned memory from
+ * tbk_host_alloc avoids a staging copy) behind it; tbk_stream_wait(ticket) returns when
+ * they have arrived.  Lets the host bin batch i while the GPU probes batch i+1. */
+int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, const void *d_offsets,
+                             uint64_t n_reads, uint64_t total_bases, int32_t *counts, uint64_t *ticket);
 
 /* HIP-event timing of the probe kernel on the stream it is launched on.  While enabled,
  * every probe-kernel launch of this classifier is bracketed by an event pair; read

@@ -78,6 +78,7 @@ _sig("tbk_count_kmers_in_read", C.c_int, C.c_char_p, C.c_int64, _vp, _vp, C.POIN
 _sig("tbk_classifier_create", C.c_int, _vp, _vp, C.POINTER(_vp))
 _sig("tbk_classifier_destroy", None, _vp)
 _sig("tbk_classifier_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
+_sig("tbk_classifier_layout", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
 _sig("tbk_stream_depth", C.c_int, _vp)
 _sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)
@@ -86,6 +87,7 @@ _sig("tbk_host_alloc", _vp, C.c_size_t)
 _sig("tbk_host_free", None, _vp)
 _sig("tbk_classify_device", C.c_int, _vp, _vp, _vp, _u64, _u64, _vp)
 _sig("tbk_classifier_sync", C.c_int, _vp)
+_sig("tbk_stream_submit_device", C.c_int, _vp, _vp, _vp, _u64, _u64, _vp, _u64p)
 _sig("tbk_kernel_timing_enable", C.c_int, _vp, C.c_int)
 _sig("tbk_kernel_timing_read", C.c_int, _vp, _u64p, _dp)
 _sig("tbk_score_and_bin", C.c_int, _vp, _u64, _u64, _u64, _vp, _vp, _vp)

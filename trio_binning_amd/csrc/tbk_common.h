@@ -12,6 +12,9 @@
 //   encoding, c/kmers.c:50-72) or TBK_EMPTY.  A key lives in the first bucket, walking from
 //   its home bucket, whose half had a free slot when it was inserted (linear probing at
 //   line granularity), so a lookup stops at the first half-line that still has a free slot.
+//   Inserts always take the FIRST free slot of a half and nothing is ever removed, so the
+//   occupied slots of a half form a prefix: a half is full exactly when its last slot is
+//   occupied (the probe kernel tests that one slot).
 //   A standalone list (tbk_table) is just its packed keys in HBM; a single-table form of
 //   the same layout (64-byte lines, 8 slots) is built on demand for tbk_table_contains.
 //   The reference's layout (8-byte slots + a parallel "full" byte array at load 0.75,
@@ -32,13 +35,35 @@
 #endif
 
 #define TBK_EMPTY 0xFFFFFFFFFFFFFFFFull
+// The key an invalid window (non-ACGT byte, read boundary) looks up.  Like TBK_EMPTY it can
+// never be a canonical key (k < 32: >= 4^k; k = 32: "GTTT...T", whose reverse complement
+// "AAA...AC" is smaller), so it is never stored — a list line that packs to it is dead in
+// the reference too — and a window carrying it can never hit.
+#define TBK_NOKEY 0xFFFFFFFFFFFFFFFEull
 #define TBK_SLOTS_PER_BUCKET 8
 #define TBK_BUCKET_BYTES 64
 
-// 64 -> 32-bit mixer for bucket selection.  Not the reference's hash_function
-// (c/kmers.c:98-103): hash values are not observable, so this one is chosen to be cheap on
-// the VALU (three 32-bit multiplies) with good high bits for the multiply-shift range
-// reduction below.
+// ---- bucket selection --------------------------------------------------------------------
+// Not the reference's hash_function (c/kmers.c:98-103): hash values are not observable, so
+// the bucket of a key is chosen for the GPU.
+//
+// Mode "minimizer" (w >= 1): the bucket of a canonical k-mer is chosen by the minimizer of
+// its central span of m + w - 1 bases: H = min over the span's w m-mers of hash(canonical
+// m-mer), bucket = reduce(scramble(H)).  The span is central and the m-mers are
+// canonicalised, so a k-mer and its reverse complement give the same H (the probe kernel
+// computes H from the forward strand alone).  Consecutive windows of a read share their
+// minimizer 1 - 2/(w+1) of the time, so they probe the SAME 128-byte line and the kernel
+// re-uses the line it already holds instead of fetching another random line from HBM.
+// m <= 16 keeps m-mer arithmetic in 32 bits; (m, w) are picked per k by tbk_mz_params so
+// that m + w - 1 has k's parity (the span must be central).
+//
+// Mode "plain" (w = 0): bucket = reduce(mix32(key)), one random line per window.
+struct TbkMz {
+    int w;  // m-mers per span (0 = plain mode)
+    int m;  // m-mer length, <= 16
+    int o;  // first base of the span inside the k-mer: (k - (m + w - 1)) / 2
+};
+
 TBK_HD uint32_t tbk_mix32(uint64_t key) {
     uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
     uint32_t h = lo * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
@@ -53,8 +78,58 @@ TBK_HD uint32_t tbk_reduce(uint32_t h, uint32_t n_buckets) {
     return (uint32_t)(((uint64_t)h * (uint64_t)n_buckets) >> 32);
 }
 
-TBK_HD uint32_t tbk_home_bucket(uint64_t key, uint32_t n_buckets) {
-    return tbk_reduce(tbk_mix32(key), n_buckets);
+// order of canonical m-mers for minimizer selection (a bijection of 32-bit values; the xor
+// keeps poly-A, which packs to 0, from being everybody's minimizer)
+TBK_HD uint32_t tbk_mmer_hash(uint32_t cm) {
+    cm = (cm ^ 0x5BD1E995u) * 0x9E3779B1u;
+    return cm ^ (cm >> 16);
+}
+
+// minimizer hashes are small-biased (a minimum of w values); one odd multiply spreads a
+// dense range of small values over all 32 bits, and tbk_reduce reads the high bits
+TBK_HD uint32_t tbk_scramble(uint32_t h) { return h * 0x9E3779B1u; }
+
+// reverse complement of an m-base packed value, m <= 16
+TBK_HD uint32_t tbk_revcomp32(uint32_t x, int m) {
+    uint32_t y = ~x;
+    y = ((y >> 2) & 0x33333333u) | ((y & 0x33333333u) << 2);
+    y = ((y >> 4) & 0x0F0F0F0Fu) | ((y & 0x0F0F0F0Fu) << 4);
+    y = ((y >> 8) & 0x00FF00FFu) | ((y & 0x00FF00FFu) << 8);
+    y = (y >> 16) | (y << 16);
+    return y >> (32 - 2 * m);
+}
+
+// (m, w, o) for a given k and wanted w.  Largest w' <= w_target with an m in {16, 15} such
+// that the span m + w' - 1 fits in k and has k's parity; plain mode when k < 15.
+TBK_HD TbkMz tbk_mz_params(int k, int w_target) {
+    TbkMz z;
+    z.w = 0; z.m = 0; z.o = 0;
+    if (w_target > 8) w_target = 8;
+    for (int w = w_target; w >= 1; w--) {
+        for (int m = 16; m >= 15; m--) {
+            const int span = m + w - 1;
+            if (span <= k && ((k - span) & 1) == 0) {
+                z.w = w; z.m = m; z.o = (k - span) / 2;
+                return z;
+            }
+        }
+    }
+    return z;
+}
+
+// Bucket of a packed key.  For canonical keys this equals what the probe kernel computes
+// from the read; for the (dead) non-canonical list lines any value is fine.
+TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
+    if (z.w == 0) return tbk_reduce(tbk_mix32(key), n_buckets);
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = 0; i < z.w; i++) {
+        const uint32_t x = (uint32_t)(key >> (2 * (z.o + i))) & mmask;
+        const uint32_t y = tbk_revcomp32(x, z.m);
+        const uint32_t g = tbk_mmer_hash(x < y ? x : y);
+        best = g < best ? g : best;
+    }
+    return tbk_reduce(tbk_scramble(best), n_buckets);
 }
 
 // Device view of a table: bucket b's slots for this list start at
@@ -65,12 +140,14 @@ struct TbkTableView {
     uint32_t n_buckets;
     uint32_t stride;  // slots per bucket line (8 or 16)
     uint32_t half;    // first slot of this list inside the line (0 or 8)
+    TbkMz mz;         // bucket selection
 };
 
 // The paired (hapA | hapB) table the probe kernel reads: bucket b = 16 slots = 128 bytes.
 struct TbkPairView {
     const uint64_t *slots;  // n_buckets * 16
     uint32_t n_buckets;
+    TbkMz mz;               // bucket selection
 };
 
 // ---- synthetic key sequence (bench inputs) ---------------------------------

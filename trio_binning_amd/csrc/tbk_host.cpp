@@ -25,11 +25,12 @@
 #include "tbk_common.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
-extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, const uint64_t *, uint64_t,
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t,
                                         unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
-                                       int32_t *, int, hipStream_t);
+                                       int32_t *, uint32_t *, int, hipStream_t);
+extern "C" uint64_t tbk_probe_passes(uint64_t total);
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
                                              int, int, int, uint8_t *, uint64_t *, hipStream_t);
@@ -92,7 +93,7 @@ struct tbk_table {
     uint32_t n_buckets = 0;
     uint64_t distinct = 0;
     bool hashed = false;
-    TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0}; }
+    TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0, TbkMz{0, 0, 0}}; }
 };
 
 static constexpr int RING = 3;
@@ -117,11 +118,16 @@ struct tbk_classifier {
     uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B: [8 hapA slots | 8 hapB slots]
     uint32_t n_buckets = 0;
     uint64_t distinct_a = 0, distinct_b = 0;
-    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets}; }
+    TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
     uint64_t next_ticket = 1;
     int max_blocks = 0;
+    // scratch for the pass -> read index (launches on `compute` are stream-ordered, so one
+    // buffer serves them all)
+    uint32_t *d_pass_read = nullptr;
+    uint64_t cap_passes = 0;
     // kernel timing
     bool timing = false;
     std::vector<hipEvent_t> ev;  // pairs
@@ -174,11 +180,13 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 }
 
 // ---- tables ----------------------------------------------------------------------------
-static uint32_t buckets_for(uint64_t n_keys) {
-    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe must be one line:
-    // at 2 keys per 8-slot line fewer than 0.2% of lines are full, so a miss is decided by
-    // the home line alone.  TBK_TABLE_LOAD overrides.
-    double load = env_double("TBK_TABLE_LOAD", 0.25);
+static uint32_t buckets_for(uint64_t n_keys, double default_load) {
+    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe must be decided by
+    // one line: a lookup walks to the next bucket only when its half of the home line has no
+    // free slot.  Plain hashing: 2 keys per 8-slot half (load 0.25) leaves ~0.1% of halves
+    // full.  Minimizer bucketing clusters keys that share a minimizer, so it gets 1 key per
+    // half (load 0.125, ~0.07% full).  TBK_TABLE_LOAD overrides.
+    double load = env_double("TBK_TABLE_LOAD", default_load);
     if (load < 0.02) load = 0.02;
     if (load > 0.9) load = 0.9;
     double want = (double)n_keys / (TBK_SLOTS_PER_BUCKET * load);
@@ -190,15 +198,15 @@ static uint32_t buckets_for(uint64_t n_keys) {
 
 // Insert n keys into one list's slots of a table (standalone: stride 8, half 0; paired:
 // stride 16, half 0 / 8).  The slots must already be filled with TBK_EMPTY.
-static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, const uint64_t *d_keys,
-                       uint64_t n, uint64_t *distinct_out) {
+static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
+                       const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out) {
     unsigned long long *d_distinct = nullptr;
     int *d_failed = nullptr;
     hipError_t e = hipMalloc((void **)&d_distinct, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
     if (e == hipSuccess) e = hipMemset(d_distinct, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
-    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, d_keys, n, d_distinct, d_failed, nullptr);
+    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_distinct, d_failed, nullptr);
     unsigned long long distinct = 0;
     int failed = 0;
     if (e == hipSuccess) e = hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost);
@@ -216,11 +224,11 @@ static int table_hash(tbk_table *t) {
     if (t->hashed) return TBK_OK;
     int rc = use_device(t->device);
     if (rc) return rc;
-    t->n_buckets = buckets_for(t->num_lines);
+    t->n_buckets = buckets_for(t->num_lines, 0.25);
     const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
     HIP_TRY(hipMalloc((void **)&t->d_slots, bytes));
     hipError_t e = hipMemset(t->d_slots, 0xFF, bytes);
-    if (e == hipSuccess) rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, t->d_keys, t->num_lines, &t->distinct);
+    if (e == hipSuccess) rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, TbkMz{0, 0, 0}, t->d_keys, t->num_lines, &t->distinct);
     else rc = fail(TBK_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
     if (rc) { (void)hipFree(t->d_slots); t->d_slots = nullptr; return rc; }
     t->hashed = true;
@@ -385,8 +393,11 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->device = a->device;
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
+    // bucket selection: minimizer of the k-mer's central span (TBK_MINIMIZER_W m-mers, default
+    // 6; 0 = plain hashing of the whole key)
+    c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6));
     // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines));
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.125 : 0.25);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
@@ -395,8 +406,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         delete c;
         return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
-    rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, a->d_keys, a->num_lines, &c->distinct_a);
-    if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, b->d_keys, b->num_lines, &c->distinct_b);
+    rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, a->d_keys, a->num_lines, &c->distinct_a);
+    if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, b->d_keys, b->num_lines, &c->distinct_b);
     if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
     e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
@@ -409,6 +420,14 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
     }
     *out = c;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (minimizer_w) *minimizer_w = c->mz.w;
+    if (minimizer_m) *minimizer_m = c->mz.m;
+    if (span_offset) *span_offset = c->mz.o;
     return TBK_OK;
 }
 
@@ -439,6 +458,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         if (c->d_pair) (void)hipFree(c->d_pair);
+        if (c->d_pass_read) (void)hipFree(c->d_pass_read);
         if (c->compute) (void)hipStreamDestroy(c->compute);
         if (c->copy) (void)hipStreamDestroy(c->copy);
     }
@@ -454,6 +474,16 @@ static bool is_pinned(const void *p) {
 
 static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const uint64_t *d_offsets,
                               uint64_t n_reads, uint64_t total, int32_t *d_counts) {
+    if (n_reads >= 0xFFFFFFF0ull) return fail(TBK_ERR_INVALID, "more than 2^32 reads in one batch");
+    const uint64_t passes = tbk_probe_passes(total);
+    if (passes > c->cap_passes) {
+        HIP_TRY(hipStreamSynchronize(c->compute));  // earlier launches may still read the old scratch
+        if (c->d_pass_read) HIP_TRY(hipFree(c->d_pass_read));
+        c->d_pass_read = nullptr; c->cap_passes = 0;
+        const uint64_t cap = passes + passes / 4 + 1024;
+        HIP_TRY(hipMalloc((void **)&c->d_pass_read, cap * sizeof(uint32_t)));
+        c->cap_passes = cap;
+    }
     HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
@@ -479,7 +509,8 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         c->timed_launches++;
         HIP_TRY(hipEventRecord(e0, c->compute));
     }
-    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->max_blocks, c->compute));
+    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->max_blocks,
+                             c->compute));
     if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
     return TBK_OK;
 }
@@ -609,6 +640,38 @@ extern "C" int tbk_classify_device(tbk_classifier *c, const void *d_bases, const
     if (!n_reads) return TBK_OK;
     return launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases,
                               (int32_t *)d_counts);
+}
+
+// Device-resident batch through the ticket ring: kernel on the compute stream, counts copied
+// to the caller's host buffer behind it; tbk_stream_wait(ticket) returns when they are there.
+extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                        uint64_t total_bases, int32_t *counts, uint64_t *ticket) {
+    if (!c || !ticket || (n_reads && (!d_offsets || !counts)) || (total_bases && !d_bases)) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(TBK_ERR_INVALID, "d_bases must be 16-byte aligned");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    const uint64_t tk = c->next_ticket;
+    Slot &s = c->ring[tk % RING];
+    if (s.busy) return fail(TBK_ERR_STATE, "all %d stream slots are in flight; call tbk_stream_wait(%llu) first", RING,
+                            (unsigned long long)s.ticket);
+    const bool out_pinned = n_reads == 0 || is_pinned(counts);
+    rc = slot_reserve(s, 0, n_reads, false, !out_pinned);
+    if (rc) return rc;
+    s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
+    if (n_reads && total_bases) {
+        rc = launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases, s.d_counts);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
+                               hipMemcpyDeviceToHost, c->compute));
+    } else if (n_reads) {
+        memset(counts, 0, n_reads * 2 * sizeof(int32_t));
+        s.counts_staged = false;
+    }
+    HIP_TRY(hipEventRecord(s.done, c->compute));
+    s.busy = true;
+    c->next_ticket++;
+    *ticket = tk;
+    return TBK_OK;
 }
 
 extern "C" int tbk_classifier_sync(tbk_classifier *c) {

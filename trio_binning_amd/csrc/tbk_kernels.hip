@@ -21,7 +21,7 @@
 // membership is the same).  `stride`/`half` select a standalone table (8, 0) or the hapA /
 // hapB half of a paired table (16, 0 / 8).
 __global__ void __launch_bounds__(256)
-tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half,
+tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
                   const uint64_t *__restrict__ keys, uint64_t n,
                   unsigned long long *__restrict__ n_distinct, int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -29,8 +29,8 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     unsigned long long mine = 0;
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
-        if (key == TBK_EMPTY) continue;
-        uint32_t b = tbk_home_bucket(key, n_buckets);
+        if (key >= TBK_NOKEY) continue;  // TBK_EMPTY / TBK_NOKEY: never a canonical key, never stored
+        uint32_t b = tbk_bucket_of(key, mz, n_buckets);
         bool done = false;
         for (uint32_t walked = 0; walked < n_buckets && !done; walked++) {
             unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
@@ -61,8 +61,8 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
     if (i >= n) return;
     const uint64_t key = keys[i];
     uint8_t found = 0;
-    if (key != TBK_EMPTY) {
-        uint32_t b = tbk_home_bucket(key, t.n_buckets);
+    if (key < TBK_NOKEY) {
+        uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
         for (uint32_t walked = 0; walked < t.n_buckets; walked++) {
             const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
             bool has_free = false;
@@ -121,6 +121,7 @@ struct ProbeArgs {
     TbkPairView t;            // hapA | hapB interleaved
     int k;
     int32_t *counts;          // [n_reads][2], zeroed by the caller
+    const uint32_t *pass_read;  // [n_passes] read that contains each pass's first position
 };
 
 // Pack 16 ASCII bases (4 little-endian words) into 2-bit codes and a not-ACGT mask.
@@ -183,6 +184,9 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S * 0x55, 0xF, 0xF, true);
 }
 
+// wave ballot of a predicate (v_cmp result as a 64-bit lane mask)
+__device__ __forceinline__ uint64_t ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 // per-quad OR of a lane mask, result at each quad's lane 0 bit
 __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
     return (m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x1111111111111111ull;
@@ -190,10 +194,10 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 
 // Continue a lookup past buckets whose half (hapA: half = 0, hapB: half = 8) had no free
 // slot.  `pending` has a bit at lane 0 of every quad that must keep walking; returns the
-// quads (lane-0 bits) that found the key.  Rare: a half is full with probability < 1% at
+// quads (lane-0 bits) that found the key.  Rare: a half is full with probability < 0.1% at
 // the load factors the library builds.
-__device__ __noinline__ uint64_t probe_walk(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket,
-                                            uint64_t pending, uint32_t sub) {
+__device__ __forceinline__ uint64_t probe_walk(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket,
+                                               uint64_t pending, uint32_t sub) {
     uint64_t found = 0;
     const uint64_t my_quad_bit = 1ull << (__lane_id() & ~3u);
     uint32_t guard = 0;
@@ -202,106 +206,205 @@ __device__ __noinline__ uint64_t probe_walk(const TbkPairView t, uint32_t half, 
         bucket = bucket + 1 == t.n_buckets ? 0 : bucket + 1;
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) v = *reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half + sub * 2);
-        const uint64_t hit = quad_any(__ballot(act && (v.x == key || v.y == key)));
-        const uint64_t fre = quad_any(__ballot(act && (v.x == TBK_EMPTY || v.y == TBK_EMPTY)));
+        const uint64_t hit = quad_any(ballot(act && (v.x == key || v.y == key)));
+        const uint64_t fre = quad_any(ballot(act && (v.x == TBK_EMPTY || v.y == TBK_EMPTY)));
         found |= hit;
         pending &= ~(hit | fre);
     }
     return found;
 }
 
-template <bool MULTI>
+// Exact resolution of one sub-step (16 windows, one per quad), taken only when the fast
+// path cannot decide: some window's home half is full (the lookup may have to walk on), or
+// hapA and hapB both report a hit (priority must be applied per window).  Returns per-quad
+// results as bits at each quad's lane 0.
+__device__ __forceinline__ void probe_exact(const TbkPairView t, ulonglong2 va, ulonglong2 vb, uint64_t key,
+                                            uint32_t bucket, uint32_t sub, uint64_t &out_a, uint64_t &out_b) {
+    const uint64_t okm = quad_any(ballot(key != TBK_NOKEY));
+    uint64_t hit_a = quad_any(ballot(va.x == key || va.y == key)) & okm;
+    const uint64_t fre_a = quad_any(ballot(va.x == TBK_EMPTY || va.y == TBK_EMPTY));
+    uint64_t hit_b = quad_any(ballot(vb.x == key || vb.y == key)) & okm;
+    const uint64_t fre_b = quad_any(ballot(vb.x == TBK_EMPTY || vb.y == TBK_EMPTY));
+    const uint64_t more_a = okm & ~hit_a & ~fre_a;
+    if (more_a) hit_a |= probe_walk(t, 0, key, bucket, more_a, sub);
+    const uint64_t more_b = okm & ~hit_a & ~hit_b & ~fre_b;
+    if (more_b) hit_b |= probe_walk(t, 8, key, bucket, more_b, sub);
+    out_a = hit_a;
+    out_b = hit_b & ~hit_a;  // hapA wins (c/kmers.c:291-294)
+}
+
+// One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
+// window).  MULTI = the pass touches more than one read.
+template <int W, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t P0, const uint64_t r_first,
-                                           const uint32_t lane) {
+                                           const uint64_t r_first_end, const uint32_t lane) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
-    // forward stream S = bases 0..47 of this lane, reverse-complement stream R = rc(S)
+    // Forward stream S = bases 0..47 of this lane as 2-bit codes (base i at bits 2i).  Window
+    // j's forward k-mer is the low 2k bits of S >> 2j: S is rolled right by one base per
+    // window.  R = reverse complement of the 48-base stream; window j's reverse-complement
+    // k-mer is bits [96-2k-2j, 96-2j) of R.  R is pre-shifted right by 64-2k once and then
+    // rolled LEFT by one base per window, so that k-mer always sits at bits [32, 32+2k):
+    // words (t1, t2), no per-window shift.
     uint32_t s0 = (uint32_t)e0, s1 = (uint32_t)e1, s2 = (uint32_t)e2;
-    uint32_t t0 = rev_pairs(~s2), t1 = rev_pairs(~s1), t2 = rev_pairs(~s0);
-    // window j's rc k-mer = bits [96-2j-2k, 96-2j) of R; after j left shifts by 2 it sits at
-    // [96-2k, 96): keep R shifted so the slice position is constant.
-    const uint64_t bad48 = (e0 >> 32) | ((e1 >> 32) << 16) | ((e2 >> 32) << 32);
-    const uint64_t badk = k == 32 ? 0xFFFFFFFFull : ((1ull << k) - 1ull);
-    const int rsh = 96 - 2 * k;  // 32..94
+    uint32_t t0, t1, t2;
+    {
+        const unsigned __int128 R = (unsigned __int128)rev_pairs(~s2) | ((unsigned __int128)rev_pairs(~s1) << 32) |
+                                    ((unsigned __int128)rev_pairs(~s0) << 64);
+        const unsigned __int128 Rs = R >> (64 - 2 * k);
+        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64);
+    }
+    // not-ACGT flags of the lane's 48 bases, rolled right by one per window: window j is
+    // clean when the low k bits are zero
+    uint32_t bad_lo = (uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16);
+    uint32_t bad_hi = (uint32_t)(e2 >> 32);
+    const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
 
-    // read bookkeeping
+    // ---- minimizer state -----------------------------------------------------------------
+    // win[i] = hash(canonical m-mer starting at base j + o + i) for the current window j: a
+    // W-deep shift register.  The newest m-mer (i = W-1) is bits [2(o+W-1), +2m) of rolled S;
+    // its reverse complement sits at base o of the reverse-complement k-mer (the span is
+    // central), i.e. bits [32+2o, +2m) of rolled R.
+    constexpr int NW = W > 0 ? W : 1;
+    uint32_t win[NW];
+    uint32_t mmask = 0, fsh_new = 0, bsh_new = 0;
+    if (W > 0) {
+        const int m = p.t.mz.m, o = p.t.mz.o;
+        mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+        const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t2 << 32) | t1;
+        win[0] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i + 1 < W; i++) {  // prologue: the W-1 m-mers window 0 shares with window -1
+            const uint32_t x = (uint32_t)(fs >> (2 * (o + i))) & mmask;
+            const uint32_t y = (uint32_t)(bs >> (2 * (o + W - 1 - i))) & mmask;
+            win[i + 1] = tbk_mmer_hash(x < y ? x : y);
+        }
+        fsh_new = (uint32_t)(2 * (o + W - 1));  // <= 30
+        bsh_new = (uint32_t)(2 * o);            // <= 16
+    }
+
+    // ---- read bookkeeping ------------------------------------------------------------------
     const uint64_t p_lane = P0 + (uint64_t)lane * TBK_WPL;
     uint64_t rid = r_first;
-    uint64_t rend;
+    uint64_t rend = r_first_end;
     if (MULTI) {
         // this lane's first window start may be in a later read than the pass start
-        uint64_t pl = p_lane < p.total ? p_lane : p.total;
+        const uint64_t pl = p_lane < p.total ? p_lane : p.total;
         rid = find_read(p.offsets, p.n_reads, pl);
         rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
-    } else {
-        rend = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
     }
+    // windows j with j + k <= rel_end lie inside the current read
+    uint32_t rel_end = rend > p_lane ? (uint32_t)(rend - p_lane < 0x40000000ull ? rend - p_lane : 0x40000000ull) : 0u;
     uint32_t acc_a = 0, acc_b = 0;  // wave-uniform in the single-read case
+
+    // the line each quad slot holds from the previous window of the same lane
+    uint32_t held[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    ulonglong2 va[4], vb[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
+    uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
 
 #pragma unroll 2
     for (int j = 0; j < TBK_WPL; j++) {
         // ---- this lane's window j ---------------------------------------------------
         const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
-        // bits [rsh, rsh+2k) of (t0,t1,t2)
-        uint64_t rc;
-        {
-            const unsigned __int128 R = (unsigned __int128)t0 | ((unsigned __int128)t1 << 32) |
-                                        ((unsigned __int128)t2 << 64);
-            rc = (uint64_t)(R >> rsh) & kmask;
-        }
+        const uint64_t rc = ((uint64_t)t1 | ((uint64_t)t2 << 32)) & kmask;
         const uint64_t key = fwd < rc ? fwd : rc;
-        const uint64_t pw = p_lane + (uint64_t)j;
         if (MULTI) {
-            while (rid < p.n_reads && pw >= rend) { rid++; rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total; }
+            const uint64_t pw = p_lane + (uint64_t)j;
+            bool moved = false;
+            while (rid < p.n_reads && pw >= rend) { rid++; rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total; moved = true; }
+            if (moved) rel_end = rend > p_lane ? (uint32_t)(rend - p_lane < 0x40000000ull ? rend - p_lane : 0x40000000ull) : 0u;
         }
-        const bool ok = ((bad48 >> j) & badk) == 0 && pw + (uint64_t)k <= rend && rid < p.n_reads;
-        const uint32_t my_bk = ok ? tbk_home_bucket(key, p.t.n_buckets) : 0u;
-        const uint32_t my_klo = (uint32_t)key, my_khi = (uint32_t)(key >> 32);
-        const uint32_t my_ok = ok ? 1u : 0u;
+        bool ok = (bad_lo & badk) == 0 && (uint32_t)(j + k) <= rel_end;
+        if (MULTI) ok = ok && rid < p.n_reads;
+        uint32_t hsel;
+        if (W > 0) {
+            // shift in the newest m-mer of this window's span, take the minimum
+            const uint32_t x = (uint32_t)((((uint64_t)s1 << 32) | s0) >> fsh_new) & mmask;
+            const uint32_t y = (uint32_t)((((uint64_t)t2 << 32) | t1) >> bsh_new) & mmask;
+#pragma unroll
+            for (int i = 0; i + 1 < W; i++) win[i] = win[i + 1];
+            win[W - 1] = tbk_mmer_hash(x < y ? x : y);
+            hsel = win[0];
+#pragma unroll
+            for (int i = 1; i < W; i++) hsel = win[i] < hsel ? win[i] : hsel;
+            hsel = tbk_scramble(hsel);
+        } else {
+            hsel = tbk_mix32(key);
+        }
+        // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
+        // TBK_NOKEY, which is never stored (it can never hit)
+        const uint32_t my_bk = ok ? tbk_reduce(hsel, p.t.n_buckets) : last_bk;
+        last_bk = my_bk;
+        const uint32_t my_klo = ok ? (uint32_t)key : (uint32_t)TBK_NOKEY;
+        const uint32_t my_khi = ok ? (uint32_t)(key >> 32) : (uint32_t)(TBK_NOKEY >> 32);
         const uint32_t my_rid = (uint32_t)rid;
 
-        // advance the streams to window j+1: S >>= 2, R <<= 2
+        // advance to window j+1: S >>= 2, R <<= 2, bad >>= 1
         s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 >>= 2;
         t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
+        bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
 
-        // ---- four quad sub-steps: fetch both lines of each of the quad's 4 windows -----
-        uint32_t klo[4], khi[4], bk[4], okq[4], ridq[4];
-        ulonglong2 va[4], vb[4];
+        // ---- four quad sub-steps: the quad's 4 windows, one 128-byte line each ----------
+        uint32_t klo[4], khi[4], bk[4], ridq[4];
 #define TBK_BCAST(S)                                                        \
         klo[S] = quad_bcast<S>(my_klo); khi[S] = quad_bcast<S>(my_khi);     \
-        bk[S] = quad_bcast<S>(my_bk);   okq[S] = quad_bcast<S>(my_ok);      \
+        bk[S] = quad_bcast<S>(my_bk);                                       \
         if (MULTI) ridq[S] = quad_bcast<S>(my_rid);
         TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
 #undef TBK_BCAST
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const uint64_t *line = p.t.slots + (uint64_t)bk[s] * 16 + sub * 2;
-            va[s] = *reinterpret_cast<const ulonglong2 *>(line);
-            vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
+            // fetch only when this window's line differs from the one the slot already holds
+            // (minimizer mode: consecutive windows mostly share it)
+            if (bk[s] != held[s]) {
+                const uint64_t *line = p.t.slots + (uint64_t)bk[s] * 16 + sub * 2;
+                va[s] = *reinterpret_cast<const ulonglong2 *>(line);
+                vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
+                held[s] = bk[s];
+            }
         }
+        // Fast path.  A key is stored at most once per table, so the raw ballots count
+        // windows.  A half is full exactly when its last slot (held by quad lane 3) is
+        // occupied; only then may a miss have to walk on.  hapA/hapB priority only matters
+        // when both tables report a hit.  Anything else goes to the exact path.
+        uint64_t hit_a[4], hit_b[4], full_any = 0, any_a = 0, any_b = 0;
+        uint64_t kk[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
-            const bool okl = okq[s] != 0;
-            const uint64_t okm = quad_any(__ballot(okl));
-            uint64_t hit_a = quad_any(__ballot(va[s].x == kk || va[s].y == kk)) & okm;
-            const uint64_t fre_a = quad_any(__ballot(va[s].x == TBK_EMPTY || va[s].y == TBK_EMPTY));
-            uint64_t hit_b = quad_any(__ballot(vb[s].x == kk || vb[s].y == kk)) & okm;
-            const uint64_t fre_b = quad_any(__ballot(vb[s].x == TBK_EMPTY || vb[s].y == TBK_EMPTY));
-            const uint64_t more_a = okm & ~hit_a & ~fre_a;
-            if (more_a) hit_a |= probe_walk(p.t, 0, kk, bk[s], more_a, sub);
-            const uint64_t more_b = okm & ~hit_a & ~hit_b & ~fre_b;
-            if (more_b) hit_b |= probe_walk(p.t, 8, kk, bk[s], more_b, sub);
-            hit_b &= ~hit_a;  // hapA wins (c/kmers.c:291-294)
+            kk[s] = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
+            hit_a[s] = ballot(va[s].x == kk[s] || va[s].y == kk[s]);
+            hit_b[s] = ballot(vb[s].x == kk[s] || vb[s].y == kk[s]);
+            full_any |= ballot((va[s].y & vb[s].y) != TBK_EMPTY);
+            any_a |= hit_a[s];
+            any_b |= hit_b[s];
+        }
+        full_any &= 0x8888888888888888ull;
+        if (full_any != 0 || (any_a != 0 && any_b != 0)) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const uint64_t full = ballot((va[s].y & vb[s].y) != TBK_EMPTY) & 0x8888888888888888ull;
+                if (full != 0 || (hit_a[s] != 0 && hit_b[s] != 0))
+                    probe_exact(p.t, va[s], vb[s], kk[s], bk[s], sub, hit_a[s], hit_b[s]);  // results at quad lane 0
+            }
+        }
+        if ((any_a | any_b | full_any) != 0) {
             if (!MULTI) {
-                acc_a += (uint32_t)__popcll(hit_a);
-                acc_b += (uint32_t)__popcll(hit_b);
-            } else if (hit_a | hit_b) {
-                const uint64_t me = 1ull << lane;  // quad lane 0 carries the quad's bit
-                if (hit_a & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s]], 1);
-                if (hit_b & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s] + 1], 1);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    acc_a += (uint32_t)__popcll(hit_a[s]);
+                    acc_b += (uint32_t)__popcll(hit_b[s]);
+                }
+            } else {
+                const uint64_t me = 1ull << lane;  // the matching lane (or quad lane 0) reports
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (hit_a[s] & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s]], 1);
+                    if (hit_b[s] & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s] + 1], 1);
+                }
             }
         }
     }
@@ -313,47 +416,53 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     }
 }
 
-__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK)
+// Which read contains the first position of each pass (one thread per pass): keeps the
+// binary search over the offsets out of the probe kernel's waves.
+__global__ void __launch_bounds__(256)
+tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_passes,
+                      uint32_t *__restrict__ pass_read) {
+    const uint64_t pass = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pass < n_passes) pass_read[pass] = (uint32_t)find_read(offsets, n_reads, pass * TBK_PASS);
+}
+
+template <int W>
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, 4)  // <= 128 VGPRs: 4 waves per SIMD
 tbk_probe_kernel(const ProbeArgs p) {
+    // LDS staging of the read tile, one region per wave: a wave only ever reads what it wrote
+    // itself, so wave-scope ordering is enough and the waves of a block never wait for each
+    // other (no s_barrier in this kernel).
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t passes_per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
-    const uint64_t n_iter = (p.n_passes + passes_per_iter - 1) / passes_per_iter;
 
-    for (uint64_t it = 0; it < n_iter; it++) {
-        const uint64_t pass = it * passes_per_iter + (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave;
-        const bool live = pass < p.n_passes;
+    for (uint64_t pass = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; pass < p.n_passes; pass += passes_per_iter) {
         const uint64_t P0 = pass * TBK_PASS;
-        if (live) {
-            stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
-            if (lane < 2) stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
-        }
-        __syncthreads();
-        if (live) {
-            const uint64_t e0 = stage[wave][lane], e1 = stage[wave][lane + 1], e2 = stage[wave][lane + 2];
-            // which read(s) does this pass touch?  (wave-uniform)
-            const uint64_t r_first = find_read(p.offsets, p.n_reads, P0);
-            const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
-            const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-            if (last_pos < r_end) probe_pass<false>(p, e0, e1, e2, P0, r_first, lane);
-            else probe_pass<true>(p, e0, e1, e2, P0, r_first, lane);
-        }
-        __syncthreads();
+        stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
+        if (lane < 2) stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t e0 = stage[wave][lane], e1 = stage[wave][lane + 1], e2 = stage[wave][lane + 2];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // which read(s) does this pass touch?  (wave-uniform)
+        const uint64_t r_first = p.pass_read[pass];
+        const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
+        const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
+        if (last_pos < r_end) probe_pass<W, false>(p, e0, e1, e2, P0, r_first, r_end, lane);
+        else probe_pass<W, true>(p, e0, e1, e2, P0, r_first, r_end, lane);
     }
 }
 
 // =======================================================================================
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
-extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half,
+extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
                                         const uint64_t *d_keys, uint64_t n, unsigned long long *d_distinct,
                                         int *d_failed, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
-                       half, d_keys, n, d_distinct, d_failed);
+                       half, mz, d_keys, n, d_distinct, d_failed);
     return hipGetLastError();
 }
 
@@ -366,15 +475,26 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
 }
 
 extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                                       uint64_t total, TbkPairView t, int k, int32_t *d_counts, int max_blocks,
-                                       hipStream_t stream) {
+                                       uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_pass_read,
+                                       int max_blocks, hipStream_t stream) {
     if (total == 0 || n_reads == 0) return hipSuccess;
     ProbeArgs p;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    p.t = t; p.k = k; p.counts = d_counts;
+    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_pass_read;
+    hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((p.n_passes + 255) / 256)), dim3(256), 0, stream,
+                       d_offsets, n_reads, p.n_passes, d_pass_read);
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
-    hipLaunchKernelGGL(tbk_probe_kernel, dim3((unsigned)blocks), dim3(64 * TBK_WAVES_PER_BLOCK), 0, stream, p);
+    const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
+    switch (t.mz.w) {
+#define TBK_W(N) case N: hipLaunchKernelGGL(tbk_probe_kernel<N>, grid, block, 0, stream, p); break;
+        TBK_W(0) TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
+#undef TBK_W
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
+
+// number of uint32 entries of pass_read scratch a batch of `total` bases needs
+extern "C" uint64_t tbk_probe_passes(uint64_t total) { return (total + TBK_PASS - 1) / TBK_PASS; }

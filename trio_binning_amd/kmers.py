@@ -229,7 +229,10 @@ class Classifier:
         """Distinct keys per list, bucket lines and bytes of the paired table in HBM."""
         da, db, nb, by = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         check(lib.tbk_classifier_stats(self._h, C.byref(da), C.byref(db), C.byref(nb), C.byref(by)))
-        return {"distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value}
+        w, m, o = C.c_int(), C.c_int(), C.c_int()
+        check(lib.tbk_classifier_layout(self._h, C.byref(w), C.byref(m), C.byref(o)))
+        return {"distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
+                "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value}
 
     def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -256,10 +259,21 @@ class Classifier:
         check(lib.tbk_stream_wait(self._h, ticket))
         return self._keep.pop(ticket)[2]
 
+    wait_ticket = wait
+
     # device-resident form (bench.py; inputs already in HBM)
     def classify_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int, d_counts: int) -> None:
         check(lib.tbk_classify_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, total_bases,
                                       C.c_void_p(d_counts)))
+
+    def submit_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int, counts: np.ndarray) -> int:
+        """Ticketed form of ``classify_device``: ``counts`` (int32 [n_reads, 2], ideally a view
+        of pinned memory from ``pinned_empty``) is filled when ``wait_ticket`` returns."""
+        ticket = C.c_uint64()
+        check(lib.tbk_stream_submit_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, total_bases,
+                                           counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (None, None, counts)
+        return ticket.value
 
     def sync(self) -> None:
         check(lib.tbk_classifier_sync(self._h))
@@ -288,6 +302,33 @@ class Classifier:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class _PinnedOwner:
+    """Frees a tbk_host_alloc block when the array that views it is collected."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            lib.tbk_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """A numpy array backed by pinned host memory (hipHostMalloc through the C-ABI), so that
+    async copies to/from the GPU need no staging copy.  Freed with the array."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    ptr = lib.tbk_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError(_lib.last_error())
+    buf = (C.c_char * nbytes).from_address(ptr)
+    buf._tbk_owner = _PinnedOwner(ptr)  # the array keeps `buf` alive through .base
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def score_and_bin(counts: np.ndarray, num_kmers_a: int, num_kmers_b: int):
