@@ -82,14 +82,15 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // probe
 // =======================================================================================
 // Work decomposition.  The batch is one byte stream of `total` bases; window starts are
-// cut into PASSes of 1024 consecutive positions.  One wave owns one pass: lane l owns the
-// 16 window starts P0+16l .. P0+16l+15 and needs bases P0+16l .. P0+16l+15+k-1 <= 47
-// bases = three 16-base chunks.  Each lane loads one 16-byte chunk of the read stream
-// (coalesced: 1 KiB per wave-instruction), packs it to 32 bits of 2-bit codes + a 16-bit
-// "not ACGT" mask, and stages it in LDS; lanes 0/1 also stage the two halo chunks.  Each
-// lane then reads its three chunks back (conflict-free b64 reads) and holds a 96-bit
-// forward stream and the 96-bit reverse-complement stream in registers, from which each
-// window's forward and reverse-complement k-mer are bit slices (no per-base loop).
+// cut into PASSes of 2048 consecutive positions.  One wave owns one pass: lane l owns the
+// 32 window starts P0+32l .. P0+32l+31 and needs bases P0+32l .. P0+32l+31+k-1 <= 63
+// bases = four 16-base chunks.  Each lane loads two 16-byte chunks of the read stream
+// (coalesced: 1 KiB per wave-instruction), packs each to 32 bits of 2-bit codes + a 16-bit
+// "not ACGT" mask, and stages them in the wave's own LDS region; lanes 0/1 also stage the
+// two halo chunks.  Each lane then reads its four chunks back and holds a 128-bit forward
+// stream and the 128-bit reverse-complement stream in registers, from which each window's
+// forward and reverse-complement k-mer are bit slices (no per-base loop).  A longer run of
+// windows per lane means fewer "first window of the lane" fetches that cannot re-use a line.
 //
 // Probing is quad-cooperative: a bucket is one 128-byte line [8 hapA slots | 8 hapB slots]
 // read by the 4 lanes of a quad, each lane taking 16 bytes (2 slots) of the hapA half and
@@ -107,10 +108,10 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // A pass that touches several reads attributes each hit to the read that contains the
 // window start (per-quad read index, broadcast alongside the key).
 
-constexpr int TBK_WPL = 16;                 // windows per lane per pass
-constexpr int TBK_PASS = 64 * TBK_WPL;      // window starts per wave pass
+constexpr int TBK_WPL = 32;                 // windows per lane per pass
+constexpr int TBK_PASS = 64 * TBK_WPL;      // window starts per wave pass (2048)
 constexpr int TBK_WAVES_PER_BLOCK = 4;
-constexpr int TBK_CHUNKS = 66;              // 64 chunks + 2 halo chunks of 16 bases
+constexpr int TBK_CHUNKS = 130;             // 128 chunks of 16 bases + 2 halo chunks
 
 struct ProbeArgs {
     const uint8_t *bases;
@@ -237,43 +238,43 @@ __device__ __forceinline__ void probe_exact(const TbkPairView t, ulonglong2 va, 
 // window).  MULTI = the pass touches more than one read.
 template <int W, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
-                                           const uint64_t e2, const uint64_t P0, const uint64_t r_first,
-                                           const uint64_t r_first_end, const uint32_t lane) {
+                                           const uint64_t e2, const uint64_t e3, const uint64_t P0,
+                                           const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
-    // Forward stream S = bases 0..47 of this lane as 2-bit codes (base i at bits 2i).  Window
+    // Forward stream S = bases 0..63 of this lane as 2-bit codes (base i at bits 2i).  Window
     // j's forward k-mer is the low 2k bits of S >> 2j: S is rolled right by one base per
-    // window.  R = reverse complement of the 48-base stream; window j's reverse-complement
-    // k-mer is bits [96-2k-2j, 96-2j) of R.  R is pre-shifted right by 64-2k once and then
-    // rolled LEFT by one base per window, so that k-mer always sits at bits [32, 32+2k):
-    // words (t1, t2), no per-window shift.
-    uint32_t s0 = (uint32_t)e0, s1 = (uint32_t)e1, s2 = (uint32_t)e2;
-    uint32_t t0, t1, t2;
+    // window.  R = reverse complement of the 64-base stream; window j's reverse-complement
+    // k-mer is bits [128-2k-2j, 128-2j) of R.  R is pre-shifted right by 64-2k once and then
+    // rolled LEFT by one base per window, so that k-mer always sits at bits [64, 64+2k):
+    // words (t2, t3), no per-window shift.
+    uint32_t s0 = (uint32_t)e0, s1 = (uint32_t)e1, s2 = (uint32_t)e2, s3 = (uint32_t)e3;
+    uint32_t t0, t1, t2, t3;
     {
-        const unsigned __int128 R = (unsigned __int128)rev_pairs(~s2) | ((unsigned __int128)rev_pairs(~s1) << 32) |
-                                    ((unsigned __int128)rev_pairs(~s0) << 64);
+        const unsigned __int128 R = (unsigned __int128)rev_pairs(~s3) | ((unsigned __int128)rev_pairs(~s2) << 32) |
+                                    ((unsigned __int128)rev_pairs(~s1) << 64) | ((unsigned __int128)rev_pairs(~s0) << 96);
         const unsigned __int128 Rs = R >> (64 - 2 * k);
-        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64);
+        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64); t3 = (uint32_t)(Rs >> 96);
     }
-    // not-ACGT flags of the lane's 48 bases, rolled right by one per window: window j is
+    // not-ACGT flags of the lane's 64 bases, rolled right by one per window: window j is
     // clean when the low k bits are zero
     uint32_t bad_lo = (uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16);
-    uint32_t bad_hi = (uint32_t)(e2 >> 32);
+    uint32_t bad_hi = (uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16);
     const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
 
     // ---- minimizer state -----------------------------------------------------------------
     // win[i] = hash(canonical m-mer starting at base j + o + i) for the current window j: a
     // W-deep shift register.  The newest m-mer (i = W-1) is bits [2(o+W-1), +2m) of rolled S;
     // its reverse complement sits at base o of the reverse-complement k-mer (the span is
-    // central), i.e. bits [32+2o, +2m) of rolled R.
+    // central), i.e. bits [64+2o, +2m) of rolled R.
     constexpr int NW = W > 0 ? W : 1;
     uint32_t win[NW];
     uint32_t mmask = 0, fsh_new = 0, bsh_new = 0;
     if (W > 0) {
         const int m = p.t.mz.m, o = p.t.mz.o;
         mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-        const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t2 << 32) | t1;
+        const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
         win[0] = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i + 1 < W; i++) {  // prologue: the W-1 m-mers window 0 shares with window -1
@@ -310,7 +311,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     for (int j = 0; j < TBK_WPL; j++) {
         // ---- this lane's window j ---------------------------------------------------
         const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
-        const uint64_t rc = ((uint64_t)t1 | ((uint64_t)t2 << 32)) & kmask;
+        const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
         const uint64_t key = fwd < rc ? fwd : rc;
         if (MULTI) {
             const uint64_t pw = p_lane + (uint64_t)j;
@@ -324,7 +325,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (W > 0) {
             // shift in the newest m-mer of this window's span, take the minimum
             const uint32_t x = (uint32_t)((((uint64_t)s1 << 32) | s0) >> fsh_new) & mmask;
-            const uint32_t y = (uint32_t)((((uint64_t)t2 << 32) | t1) >> bsh_new) & mmask;
+            const uint32_t y = (uint32_t)((((uint64_t)t3 << 32) | t2) >> bsh_new) & mmask;
 #pragma unroll
             for (int i = 0; i + 1 < W; i++) win[i] = win[i + 1];
             win[W - 1] = tbk_mmer_hash(x < y ? x : y);
@@ -344,8 +345,8 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         const uint32_t my_rid = (uint32_t)rid;
 
         // advance to window j+1: S >>= 2, R <<= 2, bad >>= 1
-        s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 >>= 2;
-        t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
+        s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
+        t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
         bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
 
         // ---- four quad sub-steps: the quad's 4 windows, one 128-byte line each ----------
@@ -439,16 +440,18 @@ tbk_probe_kernel(const ProbeArgs p) {
     for (uint64_t pass = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; pass < p.n_passes; pass += passes_per_iter) {
         const uint64_t P0 = pass * TBK_PASS;
         stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
-        if (lane < 2) stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
+        stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
+        if (lane < 2) stage[wave][128 + lane] = load_chunk(p.bases, P0 + (uint64_t)(128 + lane) * 16, p.total);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint64_t e0 = stage[wave][lane], e1 = stage[wave][lane + 1], e2 = stage[wave][lane + 2];
+        const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
+                       e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // which read(s) does this pass touch?  (wave-uniform)
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, false>(p, e0, e1, e2, P0, r_first, r_end, lane);
-        else probe_pass<W, true>(p, e0, e1, e2, P0, r_first, r_end, lane);
+        if (last_pos < r_end) probe_pass<W, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
+        else probe_pass<W, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
     }
 }
 
