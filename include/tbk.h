@@ -154,6 +154,46 @@ int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_
 int tbk_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64_t num_kmers_a,
                       uint64_t num_kmers_b, double *score_a, double *score_b, char *bins);
 
+/* ---- I/O either side of the path ------------------------------------ */
+typedef struct tbk_fastx_reader tbk_fastx_reader; /* FASTA/FASTQ(.gz) record source            */
+typedef struct tbk_fastx_batch tbk_fastx_batch;   /* one batch of records in C-ABI batch layout */
+typedef struct tbk_bin_writer tbk_bin_writer;     /* the three output bins                      */
+
+/* Replaces open_fastx_read + readfq (seq.py:45-92): gzip chosen by the ".gz" name suffix,
+ * universal newlines, and exactly readfq's record rules (name = header up to the first
+ * space, every line loses its last character, '+' switches to quality, quality is read until
+ * its length reaches the sequence's, a short quality section turns the record into FASTA...). */
+int tbk_fastx_open(const char *path, tbk_fastx_reader **out);
+void tbk_fastx_close(tbk_fastx_reader *r);
+int tbk_fastx_batch_create(tbk_fastx_batch **out);
+void tbk_fastx_batch_destroy(tbk_fastx_batch *b);
+/* Fill `b` with the next records: stops after the record that reaches max_bases or max_reads
+ * (0 = no limit).  An empty batch means end of input.  The sequence bytes of a batch lie back
+ * to back in pinned host memory: pass them straight to tbk_stream_submit. */
+int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads);
+/* Borrow the batch's arrays: offsets have n_reads+1 entries; has_qual[i] = 1 when the record
+ * was read as FASTQ (readfq's qual is not None). */
+int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint8_t **bases,
+                         const uint64_t **base_off, const uint8_t **names, const uint64_t **name_off,
+                         const uint8_t **quals, const uint64_t **qual_off, const uint8_t **has_qual);
+/* Replaces open_outfiles + Read.print (seq.py:27-42,98-136): truncating open of the three
+ * files; a record is written as FASTQ when it has a non-empty quality string, else as FASTA;
+ * gzip output is a sequence of gzip members deflated by `threads` threads (0 = all cores) at
+ * `level` (<0: 6).  Decompressed bytes equal the reference's; the container bytes do not
+ * (they never do: gzip stores a timestamp). */
+int tbk_bin_writer_open(const char *path_a, const char *path_b, const char *path_u, int gzip_output,
+                        int level, int threads, tbk_bin_writer **out);
+/* bins[i] in {'A','B','U'} for every record of the batch; records keep input order per bin. */
+int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins);
+int tbk_bin_writer_close(tbk_bin_writer *w);
+/* Replaces the stdout line of classify_by_kmers.py:117 for a whole batch:
+ * name \t bin \t str(score_a) \t str(score_b) \n with Python's float repr.  Call with out = NULL
+ * to get an upper bound of the size in *len. */
+int tbk_format_tsv(const tbk_fastx_batch *b, const char *bins, const double *score_a, const double *score_b,
+                   char *out, size_t cap, size_t *len);
+/* Python's str(float) of one value (returns the length; cap >= 40). */
+int tbk_format_float(double v, char *out, size_t cap);
+
 /* ---- device memory helpers for callers without a HIP binding (bench.py, tests) ------- */
 int tbk_device_alloc(int device, size_t bytes, void **d_ptr);
 int tbk_device_free(int device, void *d_ptr);

@@ -16,6 +16,7 @@ Fixtures written (see SURVEY.md §8c, F1–F6):
     diff_vectors.json   seeded differential vectors, k in {5,13,21,27,31,32}
     edge_vectors.json   priority / short-read / duplicate / no-trailing-newline cases
     readfq_vectors.json parser quirks of readfq + Read.print formats
+    readfq_fuzz.json    400 random byte strings over the characters that steer the parser
     cli_misc.json       output-extension rule and float formatting
 """
 import gzip
@@ -270,6 +271,23 @@ def main():
         "records": [[r.name, r.seq, r.qual] for r in rs.open_fastx_read(crlf)],
     }
     json.dump(parsed, open(os.path.join(HERE, "readfq_vectors.json"), "w"), indent=1)
+
+    # fuzz corpus for the parser: random small byte strings over the characters that steer
+    # readfq (record markers, newlines of all three kinds, spaces), parsed by the reference
+    # from real files in text mode, exactly as open_fastx_read does
+    frng = random.Random(20240611)
+    alphabet = ["@", ">", "+", "\n", "\n", "\n", "\r\n", "\r", " ", "A", "C", "G", "T", "N", "!", "I", "x", "\t"]
+    fuzz = []
+    for i in range(400):
+        n = frng.randrange(0, 60)
+        text = "".join(frng.choice(alphabet) for _ in range(n))
+        if frng.random() < 0.5:
+            text = frng.choice(["@", ">"]) + "r" + str(i) + " c\n" + text
+        fp = os.path.join(tmp, "fuzz.fx")
+        open(fp, "wb").write(text.encode())
+        recs = [[r.name, r.seq, r.qual] for r in rs.open_fastx_read(fp)]
+        fuzz.append({"bytes_hex": text.encode().hex(), "records": recs})
+    json.dump(fuzz, open(os.path.join(HERE, "readfq_fuzz.json"), "w"))
 
     # ---- CLI odds and ends -------------------------------------------------------------
     names = ["x.fastq.gz", "x.fastq", "x.fa.gz", "x.fa", "x.fastqz.gz", "reads.gz", "zz.g", "a.b.fq.gz",

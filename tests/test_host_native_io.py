@@ -1,0 +1,183 @@
+"""Native I/O either side of the path (tbk_fastx_*, tbk_bin_writer_*, tbk_format_tsv): host
+code of the C-ABI library, testable without a GPU.  The reader must yield exactly the
+records the reference's readfq yields (golden vectors recorded from the real reference),
+the writer exactly the bytes of Read.print, the TSV exactly Python's str(float)."""
+import gzip
+import io
+import os
+import random
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import DATA, load_golden
+
+
+def _native_records(path, max_bases=0, max_reads=0):
+    from trio_binning_amd import seq
+
+    out = []
+    with seq.BatchReader(path) as r:
+        b = seq.Batch()
+        while r.next_batch(b, max_bases, max_reads):
+            out += [[x.name, x.seq, x.qual] for x in b.reads()]
+        b.close()
+    return out
+
+
+@pytest.mark.parametrize("limits", [(0, 0), (1, 0), (0, 1), (0, 3), (7, 2)])
+def test_reader_quirk_vectors(built, tmp_path, limits):
+    g = load_golden("readfq_vectors.json")
+    for name, case in g.items():
+        data = bytes.fromhex(case["bytes_hex"]) if name == "crlf_file" else case["text"].encode()
+        p = tmp_path / "x.fastx"
+        p.write_bytes(data)
+        assert _native_records(str(p), *limits) == case["records"], name
+
+
+def test_reader_fuzz_corpus(built, tmp_path):
+    """400 random byte strings parsed by the real reference (tests/golden/readfq_fuzz.json)."""
+    from trio_binning_amd import seq
+
+    p = tmp_path / "fuzz.fx"
+    gz = tmp_path / "fuzz.fx.gz"
+    for i, case in enumerate(load_golden("readfq_fuzz.json")):
+        data = bytes.fromhex(case["bytes_hex"])
+        p.write_bytes(data)
+        assert _native_records(str(p)) == case["records"], (i, data)
+        assert _native_records(str(p), 0, 1) == case["records"], (i, data)
+        # our Python mirror agrees too
+        assert [[r.name, r.seq, r.qual] for r in seq.open_fastx_read(str(p))] == case["records"], (i, data)
+        if i % 8 == 0:
+            with gzip.open(gz, "wb") as fh:
+                fh.write(data)
+            assert _native_records(str(gz)) == case["records"], (i, data)
+
+
+def test_reader_equals_python_mirror_on_toy_files(built, tmp_path):
+    from trio_binning_amd import seq
+
+    for name in ("test.fa", "test.fastq", "test.ccs.fastq.gz"):
+        path = os.path.join(DATA, name)
+        want = [[r.name, r.seq, r.qual] for r in seq.open_fastx_read(path)]
+        for limits in ((0, 0), (10000, 0), (0, 1)):
+            assert _native_records(path, *limits) == want
+    # multi-member gzip, CR-only newlines, a 3 MB single-line record, long multi-line records
+    rng = random.Random(5)
+    big = "".join(rng.choice("ACGT") for _ in range(3_000_000))
+    text = ">big one\n" + big + "\n>wrapped\n" + "\n".join(big[i:i + 70] for i in range(0, 50_000, 70)) + "\n"
+    text += "@q1 x\n" + big[:100_000] + "\n+\n" + "I" * 100_000 + "\n"
+    plain = tmp_path / "big.fa"
+    plain.write_text(text)
+    want = [[r.name, r.seq, r.qual] for r in seq.open_fastx_read(str(plain))]
+    assert len(want) == 3 and len(want[0][1]) == 3_000_000 and want[2][2] == "I" * 100_000
+    assert _native_records(str(plain)) == want
+    multi = tmp_path / "multi.fa.gz"
+    with open(multi, "wb") as fh:
+        third = len(text) // 3
+        for part in (text[:third], text[third:2 * third], text[2 * third:]):
+            fh.write(gzip.compress(part.encode()))
+    assert _native_records(str(multi)) == want
+    cr = tmp_path / "cr.fa"
+    cr.write_bytes(b">a b\rACGT\rGG\r>c\rTT")
+    assert _native_records(str(cr)) == [[r.name, r.seq, r.qual] for r in seq.open_fastx_read(str(cr))]
+
+
+def test_reader_batch_layout(built, tmp_path):
+    """bases lie back to back, offsets are cumulative, limits cut after whole records."""
+    from trio_binning_amd import seq
+
+    p = tmp_path / "r.fq"
+    p.write_text("".join(f"@r{i}\n{'ACGT' * (i + 1)}\n+\n{'I' * 4 * (i + 1)}\n" for i in range(10)))
+    with seq.BatchReader(str(p)) as r:
+        b = seq.Batch()
+        sizes = []
+        while r.next_batch(b, 30, 0):
+            bases, boff, names, noff, quals, qoff, hq = b.arrays()
+            assert boff[0] == 0 and len(boff) == b.n_reads + 1 and bases.size == boff[-1]
+            assert bytes(bases) == b"".join(x.seq.encode() for x in b.reads())
+            assert hq.tolist() == [1] * b.n_reads
+            sizes.append(int(boff[-1]))
+    assert sum(sizes) == sum(4 * (i + 1) for i in range(10)) and all(s >= 30 for s in sizes[:-1])
+    with pytest.raises(IOError):
+        seq.BatchReader(str(tmp_path / "missing.fq"))
+
+
+@pytest.mark.parametrize("gz", [True, False])
+def test_writer_bytes_equal_read_print(built, tmp_path, gz):
+    from trio_binning_amd import seq
+
+    rng = random.Random(9)
+    recs = []
+    for i in range(300):
+        n = rng.randrange(0, 400)
+        s = "".join(rng.choice("ACGT") for _ in range(n))
+        kind = rng.random()
+        q = None if kind < 0.4 else ("" if kind < 0.5 else "".join(rng.choice("!#5I~") for _ in range(n)))
+        recs.append(seq.Read(f"read{i}/x", s, q))
+    src = tmp_path / "in.fq"
+    with open(src, "w") as fh:
+        for r in recs:
+            r.print(file=fh)
+    bins_all = "".join(rng.choice("ABU") for _ in recs)
+    # expected: the Python mirror's writer
+    outs = seq.open_outfiles(str(tmp_path / "pa"), str(tmp_path / "pb"), str(tmp_path / "pu"), ".fq", gz)
+    parsed = list(seq.open_fastx_read(str(src)))
+    for r, b in zip(parsed, bins_all):
+        r.print(file=outs["ABU".index(b)])
+    for fh in outs:
+        fh.close()
+    w = seq.BinWriter(str(tmp_path / "na"), str(tmp_path / "nb"), str(tmp_path / "nu"), ".fq", gz, threads=3)
+    got_n = 0
+    with seq.BatchReader(str(src)) as r:
+        b = seq.Batch()
+        while r.next_batch(b, 5000, 0):
+            w.write(b, bins_all[got_n:got_n + b.n_reads].encode())
+            got_n += b.n_reads
+    w.close()
+    assert got_n == len(parsed)
+    opener = (lambda p: gzip.open(p, "rb")) if gz else (lambda p: open(p, "rb"))
+    for py_name, nat_name in zip(seq.output_names(str(tmp_path / "pa"), str(tmp_path / "pb"), str(tmp_path / "pu"), ".fq", gz), w.names):
+        assert opener(nat_name).read() == opener(py_name).read()
+
+
+def test_writer_empty_bins_are_valid_files(built, tmp_path):
+    from trio_binning_amd import seq
+
+    w = seq.BinWriter(str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "u"), ".fa", True)
+    w.close()
+    for n in w.names:
+        assert gzip.open(n, "rb").read() == b""
+    w = seq.BinWriter(str(tmp_path / "a"), str(tmp_path / "b"), str(tmp_path / "u"), ".fa", False)
+    w.close()
+    assert all(os.path.getsize(n) == 0 for n in w.names)
+
+
+def test_float_format_is_python_str(built):
+    import ctypes as C
+
+    from trio_binning_amd._lib import lib
+
+    rng = random.Random(3)
+    vals = [0.0, 1.0, 4.0, 1.3333333333333333, 2.6666666666666665, 1e15, 1e16, 9999999999999998.0, 1.5e16, 2e18,
+            123456789.0, 0.1, 1e-4, 9.999e-5, 1e-5, 5e-324, 1.7976931348623157e308, 3.0000000000000004, 100.0, 1e22, 123456.789]
+    vals += [rng.randrange(0, 2**31) * (rng.randrange(1, 10**9) / rng.randrange(1, 10**9)) for _ in range(3000)]
+    vals += [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(62)))[0] for _ in range(3000)]
+    buf = C.create_string_buffer(64)
+    for v in vals:
+        n = lib.tbk_format_float(v, buf, 64)
+        assert buf.raw[:n].decode() == str(v), v
+
+
+def test_format_tsv(built, tmp_path):
+    from trio_binning_amd import kmers, seq
+
+    p = tmp_path / "r.fa"
+    p.write_text(">a desc\nACGT\n>b\tx\nGG\n>\nTT\n")
+    with seq.BatchReader(str(p)) as r:
+        b = seq.Batch()
+        assert r.next_batch(b) == 3
+        counts = np.array([[4, 1], [0, 2], [0, 0]], dtype=np.int32)
+        sa, sb, bins = kmers.score_and_bin(counts, 4, 3)
+        assert seq.format_tsv(b, bins, sa, sb) == "a\tA\t4.0\t1.3333333333333333\nb\tx\tB\t0.0\t2.6666666666666665\n\tU\t0.0\t0.0\n"

@@ -7,7 +7,7 @@ python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 tail -3 gpurun_out/pytest_gpu.log
 export TBK_SKIP_BUILD=1
 : > gpurun_out/sweep.log
-for cfg in "6 0.125" "6 0.1" "4 0.125"; do
+for cfg in "6 0.125"; do
   set -- $cfg
   echo "== W=$1 load=$2" >> gpurun_out/sweep.log
   TBK_MINIMIZER_W=$1 TBK_TABLE_LOAD=$2 timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "

@@ -103,6 +103,18 @@ _sig("tbk_synth_reads_device", C.c_int, C.c_int, _u64, _u64, _u64, C.c_uint32, _
      C.c_int, C.c_int, _vp, _vp)
 _sig("tbk_calib_gather", C.c_int, C.c_int, _u64, C.c_int, C.c_int, C.c_int, _u64, C.c_int, _dp, _dp)
 _sig("tbk_calib_stream", C.c_int, C.c_int, _u64, C.c_int, _dp)
+_sig("tbk_fastx_open", C.c_int, C.c_char_p, C.POINTER(_vp))
+_sig("tbk_fastx_close", None, _vp)
+_sig("tbk_fastx_batch_create", C.c_int, C.POINTER(_vp))
+_sig("tbk_fastx_batch_destroy", None, _vp)
+_sig("tbk_fastx_next", C.c_int, _vp, _vp, _u64, _u64)
+_sig("tbk_fastx_batch_view", C.c_int, _vp, _u64p, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp),
+     C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp))
+_sig("tbk_bin_writer_open", C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp))
+_sig("tbk_bin_writer_write", C.c_int, _vp, _vp, C.c_char_p)
+_sig("tbk_bin_writer_close", C.c_int, _vp)
+_sig("tbk_format_tsv", C.c_int, _vp, C.c_char_p, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t))
+_sig("tbk_format_float", C.c_int, C.c_double, C.c_char_p, C.c_size_t)
 
 
 def last_error() -> str:

@@ -9,9 +9,10 @@ based on the presence of k-mers.
 #
 # Host driver of the MI355X path.  Same command line, defaults, stdout TSV and bin files
 # as the reference driver (src/trio_binning/classify_by_kmers.py:14-117); what changes is
-# the loop: instead of one ctypes call per read (:99-102) reads are packed into batches,
-# streamed through the HIP classifier with the next batch's copy overlapping the current
-# batch's kernel, and scored/binned/written per batch in input order.
+# the loop: instead of one ctypes call per read (:99-102) the native reader fills batches
+# (pinned memory, C-ABI layout), they stream through the HIP classifier with the next batch's
+# copy overlapping the current batch's kernel, and each batch is scored, binned and written by
+# the native writer in input order.
 
 import argparse
 import os
@@ -69,69 +70,57 @@ def output_extension(reads_path: str) -> str:
     return path.splitext(reads_path.rstrip(".gz"))[1]
 
 
-def _emit(batch: List[seq.Read], counts, num_a: int, num_b: int, outs, stdout) -> None:
-    """Score, bin and write one batch in input order (classify_by_kmers.py:104-117)."""
-    score_a, score_b, bins = kmers.score_and_bin(counts, num_a, num_b)
-    out_a, out_b, out_u = outs
-    lines = []
-    for i, read in enumerate(batch):
-        b = bins[i]
-        if b == 65:  # 'A'
-            read.print(file=out_a)
-            tag = "A"
-        elif b == 66:  # 'B'
-            read.print(file=out_b)
-            tag = "B"
-        else:
-            read.print(file=out_u)
-            tag = "U"
-        # the reference prints str(float): shortest round-trip repr ('4.0', '1.3333333333333333')
-        lines.append(f"{read.name}\t{tag}\t{float(score_a[i])!s}\t{float(score_b[i])!s}\n")
-    stdout.write("".join(lines))
-
-
 def main():
     """Main method of program"""
     args = parse_args()
 
-    reads = seq.open_fastx_read(args.reads)
-    outs = seq.open_outfiles(
+    num_a = kmers.get_number_kmers_in_set(args.haplotype_a_kmers)
+    num_b = kmers.get_number_kmers_in_set(args.haplotype_b_kmers)
+    classifier = kmers.Classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
+
+    # native reader / writer (same records as seq.readfq, same bytes as Read.print)
+    reader = seq.BatchReader(args.reads)
+    writer = seq.BinWriter(
         args.haplotype_a_out_prefix,
         args.haplotype_b_out_prefix,
         args.unclassified_out_prefix,
         output_extension(args.reads),
         not args.no_gzip_output,
     )
-    num_a = kmers.get_number_kmers_in_set(args.haplotype_a_kmers)
-    num_b = kmers.get_number_kmers_in_set(args.haplotype_b_kmers)
-
-    classifier = kmers.Classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
-    in_flight: List[Tuple[int, List[seq.Read]]] = []  # (ticket, reads) in submission order
     stdout = sys.stdout
+
+    def emit(batch: seq.Batch, counts) -> None:
+        """Score, bin and write one batch in input order (classify_by_kmers.py:104-117)."""
+        score_a, score_b, bins = kmers.score_and_bin(counts, num_a, num_b)
+        writer.write(batch, bins)
+        stdout.write(seq.format_tsv(batch, bins, score_a, score_b))
+
+    # up to `depth` batches in flight on the GPU while the next one is being parsed
+    depth = classifier.depth
+    free = [seq.Batch() for _ in range(depth + 1)]
+    in_flight: List[Tuple[int, seq.Batch]] = []  # (ticket, batch) in submission order
 
     def drain(keep: int) -> None:
         while len(in_flight) > keep:
             ticket, batch = in_flight.pop(0)
-            _emit(batch, classifier.wait(ticket), num_a, num_b, outs, stdout)
+            emit(batch, classifier.wait(ticket))
+            free.append(batch)
 
-    batch: List[seq.Read] = []
-    batch_bases = 0
-    for read in reads:
-        batch.append(read)
-        batch_bases += len(read.seq)
-        if batch_bases >= _BATCH_BASES or len(batch) >= _BATCH_READS:
-            drain(classifier.depth - 1)
-            in_flight.append((classifier.submit(*kmers.pack_reads([r.seq for r in batch])), batch))
-            batch, batch_bases = [], 0
-    if batch:
-        drain(classifier.depth - 1)
-        in_flight.append((classifier.submit(*kmers.pack_reads([r.seq for r in batch])), batch))
+    while True:
+        batch = free.pop()
+        if reader.next_batch(batch, _BATCH_BASES, _BATCH_READS) == 0:
+            free.append(batch)
+            break
+        drain(depth - 1)
+        in_flight.append((classifier.submit_batch(batch), batch))
     drain(0)
 
     # The reference never closes its outputs (interpreter shutdown does); closing here
-    # finalises the gzip members at the same point in the byte stream.
-    for fh in outs:
-        fh.close()
+    # finalises the files at the same point in the byte stream.
+    writer.close()
+    reader.close()
+    for b in free:
+        b.close()
     classifier.close()
 
 

@@ -1,0 +1,613 @@
+// tbk_fastx.cpp — native I/O either side of the hot path:
+//
+//   tbk_fastx_*      FASTA/FASTQ(.gz) batch reader that reproduces the records of the
+//                    reference's readfq (src/trio_binning/seq.py:45-92) byte for byte,
+//                    quirks included, and lays each batch out exactly as the classifier's
+//                    C-ABI wants it (bases back to back in pinned memory + offsets).
+//   tbk_bin_writer_* ordered writer of the three bins with the byte format of Read.print
+//                    (seq.py:27-42) and the file naming of open_outfiles (seq.py:117-134),
+//                    gzip members deflated in parallel.
+//   tbk_format_tsv   the stdout TSV of classify_by_kmers.py:117 including Python's
+//                    str(float) formatting.
+//
+// Host code only (no kernels).  Text is handled as bytes; for ASCII input this is exactly
+// Python's behaviour in text mode with universal newlines ("\n", "\r\n" and "\r" all end a
+// line).
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <charconv>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tbk.h"
+
+extern "C" void tbk_set_error_(int code, const char *msg);  // tbk_host.cpp
+
+static int ffail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    tbk_set_error_(code, buf);
+    return code;
+}
+
+// =======================================================================================
+// line source: plain or gzip file -> lines with universal-newline semantics
+// =======================================================================================
+struct LineSource {
+    int fd = -1;
+    bool gz = false;
+    z_stream zs;
+    bool zs_live = false;
+    bool raw_eof = false;      // no more bytes from the file
+    bool text_eof = false;     // no more decoded bytes
+    std::vector<uint8_t> zin;  // compressed input window
+    size_t zin_pos = 0, zin_end = 0;
+    std::vector<uint8_t> buf;  // decoded text window
+    size_t pos = 0, end = 0;
+    bool skip_lf = false;      // previous line ended in '\r' at the window edge: swallow a leading '\n'
+    std::string err;
+
+    bool open_path(const char *path, bool gzip) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) { err = std::string("cannot open ") + path + ": " + strerror(errno); return false; }
+        gz = gzip;
+        buf.resize(1 << 22);
+        if (gz) {
+            zin.resize(1 << 20);
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "inflateInit2 failed"; return false; }
+            zs_live = true;
+        }
+        return true;
+    }
+    void close_all() {
+        if (zs_live) { inflateEnd(&zs); zs_live = false; }
+        if (fd >= 0) { ::close(fd); fd = -1; }
+    }
+    // append decoded bytes at buf[end..]; returns false on error; sets text_eof at the end
+    bool refill() {
+        if (text_eof) return true;
+        if (pos > 0 && pos == end) { pos = end = 0; }
+        if (buf.size() - end < (1u << 16)) {
+            if (pos > (buf.size() >> 1)) {  // compact
+                memmove(buf.data(), buf.data() + pos, end - pos);
+                end -= pos; pos = 0;
+            } else {
+                buf.resize(buf.size() * 2);
+            }
+        }
+        if (!gz) {
+            ssize_t n = ::read(fd, buf.data() + end, buf.size() - end);
+            if (n < 0) { err = std::string("read: ") + strerror(errno); return false; }
+            if (n == 0) { text_eof = true; return true; }
+            end += (size_t)n;
+            return true;
+        }
+        for (;;) {
+            if (zin_pos == zin_end && !raw_eof) {
+                ssize_t n = ::read(fd, zin.data(), zin.size());
+                if (n < 0) { err = std::string("read: ") + strerror(errno); return false; }
+                if (n == 0) raw_eof = true;
+                zin_pos = 0; zin_end = (size_t)(n > 0 ? n : 0);
+            }
+            if (zin_pos == zin_end && raw_eof) { text_eof = true; return true; }
+            zs.next_in = zin.data() + zin_pos;
+            zs.avail_in = (uInt)(zin_end - zin_pos);
+            zs.next_out = buf.data() + end;
+            const size_t room = buf.size() - end;
+            zs.avail_out = (uInt)std::min<size_t>(room, 1u << 30);
+            const uInt out_before = zs.avail_out;
+            int rc = inflate(&zs, Z_NO_FLUSH);
+            zin_pos = zin_end - zs.avail_in;
+            const size_t produced = out_before - zs.avail_out;
+            end += produced;
+            if (rc == Z_STREAM_END) {
+                // another gzip member may follow (Python's GzipFile reads them all)
+                if (zin_pos < zin_end || !raw_eof) {
+                    if (zin_pos == zin_end) {
+                        ssize_t n = ::read(fd, zin.data(), zin.size());
+                        if (n < 0) { err = std::string("read: ") + strerror(errno); return false; }
+                        if (n == 0) raw_eof = true;
+                        zin_pos = 0; zin_end = (size_t)(n > 0 ? n : 0);
+                    }
+                    if (zin_pos < zin_end) inflateReset(&zs);
+                    else { text_eof = true; }
+                } else {
+                    text_eof = true;
+                }
+                if (produced || text_eof) return true;
+                continue;
+            }
+            if (rc != Z_OK && rc != Z_BUF_ERROR) { err = std::string("inflate: ") + (zs.msg ? zs.msg : "corrupt gzip data"); return false; }
+            if (produced) return true;
+            if (rc == Z_BUF_ERROR && zin_pos == zin_end && raw_eof) { err = "truncated gzip file"; return false; }
+        }
+    }
+    // next line; `len` excludes the terminator, `term` says whether there was one
+    // returns 1 line, 0 end of text, -1 error
+    int next(const uint8_t *&p, size_t &len, bool &term) {
+        for (;;) {
+            if (skip_lf) {
+                if (pos == end) {
+                    if (text_eof) { skip_lf = false; return 0; }
+                    if (!refill()) return -1;
+                    continue;
+                }
+                if (buf[pos] == '\n') pos++;
+                skip_lf = false;
+            }
+            const uint8_t *base = buf.data();
+            size_t i = pos;
+            // scan for '\n' or '\r'
+            while (i < end) {
+                const uint8_t *nl = (const uint8_t *)memchr(base + i, '\n', end - i);
+                const size_t stop = nl ? (size_t)(nl - base) : end;
+                const uint8_t *cr = (const uint8_t *)memchr(base + i, '\r', stop - i);
+                if (cr) { i = (size_t)(cr - base); break; }
+                i = stop;
+                break;
+            }
+            if (i < end) {
+                p = base + pos; len = i - pos; term = true;
+                if (base[i] == '\r') {
+                    if (i + 1 < end) pos = i + 1 + (base[i + 1] == '\n' ? 1 : 0);
+                    else { pos = i + 1; skip_lf = true; }
+                } else {
+                    pos = i + 1;
+                }
+                return 1;
+            }
+            if (text_eof) {
+                if (pos == end) return 0;
+                p = base + pos; len = end - pos; term = false;
+                pos = end;
+                return 1;
+            }
+            if (!refill()) return -1;
+        }
+    }
+};
+
+// =======================================================================================
+// batch
+// =======================================================================================
+struct tbk_fastx_batch {
+    uint8_t *bases = nullptr;  // pinned (hipHostMalloc) when a device is present, else malloc
+    size_t bases_cap = 0;
+    bool pinned = false;
+    std::vector<uint64_t> base_off{0};
+    std::vector<uint8_t> names;
+    std::vector<uint64_t> name_off{0};
+    std::vector<uint8_t> quals;
+    std::vector<uint64_t> qual_off{0};
+    std::vector<uint8_t> has_qual;
+    uint64_t n_bases = 0;
+    // record under construction
+    uint64_t rec_seq0 = 0, rec_qual0 = 0;
+
+    ~tbk_fastx_batch() { release(); }
+    void release() {
+        if (bases) { if (pinned) (void)hipHostFree(bases); else free(bases); }
+        bases = nullptr; bases_cap = 0;
+    }
+    bool reserve_bases(size_t need) {
+        if (need <= bases_cap) return true;
+        size_t cap = std::max<size_t>(need + need / 2, (size_t)1 << 22);
+        uint8_t *nb = nullptr;
+        bool np = false;
+        if (hipHostMalloc((void **)&nb, cap, hipHostMallocDefault) == hipSuccess) np = true;
+        else { (void)hipGetLastError(); nb = (uint8_t *)malloc(cap); }
+        if (!nb) return false;
+        if (n_bases) memcpy(nb, bases, n_bases);
+        release();
+        bases = nb; bases_cap = cap; pinned = np;
+        return true;
+    }
+    void clear() {
+        base_off.assign(1, 0); names.clear(); name_off.assign(1, 0); quals.clear(); qual_off.assign(1, 0);
+        has_qual.clear(); n_bases = 0; rec_seq0 = rec_qual0 = 0;
+    }
+    void begin(const uint8_t *name, size_t n) {
+        names.insert(names.end(), name, name + n);
+        rec_seq0 = n_bases; rec_qual0 = quals.size();
+    }
+    bool seq(const uint8_t *p, size_t n) {
+        if (!reserve_bases(n_bases + n + 16)) return false;
+        memcpy(bases + n_bases, p, n);
+        n_bases += n;
+        return true;
+    }
+    void qual(const uint8_t *p, size_t n) { quals.insert(quals.end(), p, p + n); }
+    void finish(bool with_qual) {
+        if (!with_qual) quals.resize(rec_qual0);
+        name_off.push_back(names.size());
+        base_off.push_back(n_bases);
+        qual_off.push_back(quals.size());
+        has_qual.push_back(with_qual ? 1 : 0);
+    }
+    uint64_t n_reads() const { return has_qual.size(); }
+};
+
+// =======================================================================================
+// reader: the record state machine of seq.py:45-83
+// =======================================================================================
+struct tbk_fastx_reader {
+    LineSource src;
+    enum { SEEK, SEQ, QUAL, DONE } state = SEEK;
+    std::string pending_name;   // header already consumed for the record whose sequence comes next
+    bool have_pending = false;
+    uint64_t seq_len = 0;       // current record (QUAL state)
+    int64_t qual_have = 0;
+};
+
+static void name_of(const uint8_t *body, size_t n, const uint8_t *&np, size_t &nn) {
+    // header without its first character, cut at the first space (seq.py:61)
+    np = body + (n ? 1 : 0);
+    nn = n ? n - 1 : 0;
+    const uint8_t *sp = (const uint8_t *)memchr(np, ' ', nn);
+    if (sp) nn = (size_t)(sp - np);
+}
+
+extern "C" int tbk_fastx_open(const char *path, tbk_fastx_reader **out) {
+    if (!out || !path) return ffail(TBK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    const size_t n = strlen(path);
+    const bool gz = n >= 3 && strcmp(path + n - 3, ".gz") == 0;  // seq.py:88: by file name
+    tbk_fastx_reader *r = new tbk_fastx_reader();
+    if (!r->src.open_path(path, gz)) {
+        std::string e = r->src.err;
+        r->src.close_all();
+        delete r;
+        return ffail(TBK_ERR_IO, "%s", e.c_str());
+    }
+    *out = r;
+    return TBK_OK;
+}
+
+extern "C" void tbk_fastx_close(tbk_fastx_reader *r) {
+    if (!r) return;
+    r->src.close_all();
+    delete r;
+}
+
+extern "C" int tbk_fastx_batch_create(tbk_fastx_batch **out) {
+    if (!out) return ffail(TBK_ERR_INVALID, "NULL argument");
+    *out = new tbk_fastx_batch();
+    return TBK_OK;
+}
+
+extern "C" void tbk_fastx_batch_destroy(tbk_fastx_batch *b) { delete b; }
+
+extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
+    if (!r || !b) return ffail(TBK_ERR_INVALID, "NULL argument");
+    b->clear();
+    if (r->state == tbk_fastx_reader::DONE) return TBK_OK;
+    if (max_reads == 0) max_reads = ~0ull;
+    if (max_bases == 0) max_bases = ~0ull;
+    if (r->have_pending) {  // a FASTA record whose header closed the previous batch
+        b->begin((const uint8_t *)r->pending_name.data(), r->pending_name.size());
+        r->have_pending = false;
+    }
+    auto full = [&]() { return b->n_reads() >= max_reads || b->n_bases >= max_bases; };
+    const uint8_t *p;
+    size_t len;
+    bool term;
+    for (;;) {
+        int got = r->src.next(p, len, term);
+        if (got < 0) return ffail(TBK_ERR_IO, "%s", r->src.err.c_str());
+        if (got == 0) {  // input exhausted
+            if (r->state == tbk_fastx_reader::SEQ) b->finish(false);
+            else if (r->state == tbk_fastx_reader::QUAL) b->finish(false);  // short quality: FASTA (seq.py:81-83)
+            r->state = tbk_fastx_reader::DONE;
+            return TBK_OK;
+        }
+        const uint8_t head = len ? p[0] : (uint8_t)'\n';
+        const size_t body = term ? len : (len ? len - 1 : 0);  // line[:-1]
+        switch (r->state) {
+            case tbk_fastx_reader::SEEK:
+                if (head == '>' || head == '@') {
+                    if (body == 0) { r->state = tbk_fastx_reader::DONE; return TBK_OK; }
+                    const uint8_t *np; size_t nn;
+                    name_of(p, body, np, nn);
+                    b->begin(np, nn);
+                    r->state = tbk_fastx_reader::SEQ;
+                }
+                break;
+            case tbk_fastx_reader::SEQ:
+                if (head == '@' || head == '+' || head == '>') {
+                    if (body == 0) { b->finish(false); r->state = tbk_fastx_reader::DONE; return TBK_OK; }
+                    if (head == '+') {
+                        r->seq_len = b->n_bases - b->rec_seq0;
+                        r->qual_have = 0;
+                        r->state = tbk_fastx_reader::QUAL;
+                    } else {
+                        b->finish(false);
+                        const uint8_t *np; size_t nn;
+                        name_of(p, body, np, nn);
+                        if (full()) {  // hand the batch over; the new record starts the next one
+                            r->pending_name.assign((const char *)np, nn);
+                            r->have_pending = true;
+                            return TBK_OK;
+                        }
+                        b->begin(np, nn);
+                    }
+                } else {
+                    if (!b->seq(p, body)) return ffail(TBK_ERR_NOMEM, "out of memory growing a read batch");
+                }
+                break;
+            case tbk_fastx_reader::QUAL:
+                b->qual(p, body);
+                r->qual_have += (int64_t)len + (term ? 1 : 0) - 1;  // len(line) - 1
+                if ((uint64_t)r->qual_have >= r->seq_len) {
+                    b->finish(true);
+                    r->state = tbk_fastx_reader::SEEK;
+                    if (full()) return TBK_OK;
+                }
+                break;
+            default:
+                return TBK_OK;
+        }
+    }
+}
+
+extern "C" int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint8_t **bases,
+                                    const uint64_t **base_off, const uint8_t **names, const uint64_t **name_off,
+                                    const uint8_t **quals, const uint64_t **qual_off, const uint8_t **has_qual) {
+    if (!b) return ffail(TBK_ERR_INVALID, "NULL argument");
+    static const uint8_t nothing = 0;
+    if (n_reads) *n_reads = b->n_reads();
+    if (bases) *bases = b->bases ? b->bases : &nothing;
+    if (base_off) *base_off = b->base_off.data();
+    if (names) *names = b->names.empty() ? &nothing : b->names.data();
+    if (name_off) *name_off = b->name_off.data();
+    if (quals) *quals = b->quals.empty() ? &nothing : b->quals.data();
+    if (qual_off) *qual_off = b->qual_off.data();
+    if (has_qual) *has_qual = b->has_qual.empty() ? &nothing : b->has_qual.data();
+    return TBK_OK;
+}
+
+// =======================================================================================
+// Python's str(float) (repr): shortest round-trip digits; exponent form when the decimal
+// point position is <= -4 or > 16; ".0" appended to integers.
+// =======================================================================================
+static size_t py_float_repr(double v, char *out) {
+    char tmp[64];
+    auto r = std::to_chars(tmp, tmp + sizeof tmp, v, std::chars_format::scientific);
+    *r.ptr = 0;
+    // tmp = [-]d[.ddd]e[+-]XX
+    char *q = tmp;
+    size_t o = 0;
+    if (*q == '-') { out[o++] = '-'; q++; }
+    if (*q == 'i' || *q == 'n') { strcpy(out + o, *q == 'i' ? "inf" : "nan"); return o + 3; }
+    char digits[40];
+    int nd = 0;
+    while (*q && *q != 'e') { if (*q != '.') digits[nd++] = *q; q++; }
+    const int e10 = atoi(q + 1);
+    const int decpt = e10 + 1;
+    if (decpt <= -4 || decpt > 16) {
+        out[o++] = digits[0];
+        if (nd > 1) { out[o++] = '.'; memcpy(out + o, digits + 1, nd - 1); o += nd - 1; }
+        o += (size_t)sprintf(out + o, "e%c%02d", e10 < 0 ? '-' : '+', e10 < 0 ? -e10 : e10);
+        return o;
+    }
+    if (decpt <= 0) {
+        out[o++] = '0'; out[o++] = '.';
+        for (int i = 0; i < -decpt; i++) out[o++] = '0';
+        memcpy(out + o, digits, nd); o += nd;
+        return o;
+    }
+    if (nd <= decpt) {
+        memcpy(out + o, digits, nd); o += nd;
+        for (int i = nd; i < decpt; i++) out[o++] = '0';
+        out[o++] = '.'; out[o++] = '0';
+        return o;
+    }
+    memcpy(out + o, digits, decpt); o += decpt;
+    out[o++] = '.';
+    memcpy(out + o, digits + decpt, nd - decpt); o += nd - decpt;
+    return o;
+}
+
+extern "C" int tbk_format_float(double v, char *out, size_t cap) {
+    if (!out || cap < 40) return ffail(TBK_ERR_INVALID, "buffer too small");
+    size_t n = py_float_repr(v, out);
+    out[n] = 0;
+    return (int)n;
+}
+
+// name \t bin \t score_a \t score_b \n for every read of the batch (classify_by_kmers.py:117)
+extern "C" int tbk_format_tsv(const tbk_fastx_batch *b, const char *bins, const double *score_a, const double *score_b,
+                              char *out, size_t cap, size_t *len) {
+    if (!b || !len || (b->n_reads() && (!bins || !score_a || !score_b))) return ffail(TBK_ERR_INVALID, "NULL argument");
+    const uint64_t n = b->n_reads();
+    const size_t need = b->names.size() + n * 72 + 1;
+    *len = need;
+    if (!out || cap < need) return TBK_OK;  // caller asks for the size first
+    size_t o = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const size_t nn = b->name_off[i + 1] - b->name_off[i];
+        memcpy(out + o, b->names.data() + b->name_off[i], nn); o += nn;
+        out[o++] = '\t'; out[o++] = bins[i]; out[o++] = '\t';
+        o += py_float_repr(score_a[i], out + o);
+        out[o++] = '\t';
+        o += py_float_repr(score_b[i], out + o);
+        out[o++] = '\n';
+    }
+    *len = o;
+    return TBK_OK;
+}
+
+// =======================================================================================
+// bin writer
+// =======================================================================================
+struct BinFile {
+    int fd = -1;
+    std::vector<char> text;  // records not yet written
+};
+
+struct tbk_bin_writer {
+    BinFile bin[3];  // A, B, U
+    bool gz = false;
+    int level = 6;
+    int threads = 1;
+    size_t chunk = (size_t)8 << 20;
+    std::string err;
+};
+
+static bool write_all(int fd, const char *p, size_t n, std::string &err) {
+    while (n) {
+        ssize_t w = ::write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; err = std::string("write: ") + strerror(errno); return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+// one gzip member per chunk; concatenated members are a valid gzip file
+static bool deflate_member(const char *src, size_t n, int level, std::vector<char> &dst) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    dst.resize(deflateBound(&zs, n) + 64);
+    zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n;
+    zs.next_out = (Bytef *)dst.data(); zs.avail_out = (uInt)dst.size();
+    int rc = deflate(&zs, Z_FINISH);
+    const size_t out = dst.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END) return false;
+    dst.resize(out);
+    return true;
+}
+
+struct Piece { int bin; const char *src; size_t n; std::vector<char> out; bool ok = true; };
+
+static int flush_bins(tbk_bin_writer *w, bool final) {
+    // cut every bin's pending text into pieces (whole chunks; everything when final)
+    std::vector<Piece> pieces;
+    size_t keep[3] = {0, 0, 0};
+    for (int b = 0; b < 3; b++) {
+        BinFile &f = w->bin[b];
+        size_t off = 0;
+        const size_t n = f.text.size();
+        if (!w->gz) { if (n) pieces.push_back(Piece{b, f.text.data(), n, {}, true}); keep[b] = 0; continue; }
+        while (n - off >= w->chunk) { pieces.push_back(Piece{b, f.text.data() + off, w->chunk, {}, true}); off += w->chunk; }
+        if (final && n > off) { pieces.push_back(Piece{b, f.text.data() + off, n - off, {}, true}); off = n; }
+        keep[b] = n - off;
+    }
+    if (w->gz && !pieces.empty()) {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < pieces.size();) {
+                Piece &pc = pieces[i];
+                // zlib's avail_in is 32-bit; chunks are far below that
+                pc.ok = deflate_member(pc.src, pc.n, w->level, pc.out);
+            }
+        };
+        const int nt = (int)std::min<size_t>((size_t)w->threads, pieces.size());
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+    }
+    for (Piece &pc : pieces) {
+        if (!pc.ok) return ffail(TBK_ERR_IO, "deflate failed");
+        const char *p = w->gz ? pc.out.data() : pc.src;
+        const size_t n = w->gz ? pc.out.size() : pc.n;
+        if (!write_all(w->bin[pc.bin].fd, p, n, w->err)) return ffail(TBK_ERR_IO, "%s", w->err.c_str());
+    }
+    for (int b = 0; b < 3; b++) {
+        BinFile &f = w->bin[b];
+        if (keep[b] && keep[b] != f.text.size()) memmove(f.text.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
+        f.text.resize(keep[b]);
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_bin_writer_open(const char *path_a, const char *path_b, const char *path_u, int gzip_output, int level,
+                                   int threads, tbk_bin_writer **out) {
+    if (!out || !path_a || !path_b || !path_u) return ffail(TBK_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    tbk_bin_writer *w = new tbk_bin_writer();
+    w->gz = gzip_output != 0;
+    w->level = level < 0 ? 6 : std::min(level, 9);
+    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    w->threads = std::min(threads, 64);
+    const char *paths[3] = {path_a, path_b, path_u};
+    for (int b = 0; b < 3; b++) {
+        // truncating open, as open(name, "w") / gzip.open(name, "wt") do (seq.py:128-134); when two
+        // names coincide the later bin re-opens the same file, exactly like the reference
+        w->bin[b].fd = ::open(paths[b], O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (w->bin[b].fd < 0) {
+            int e = errno;
+            for (int c = 0; c < b; c++) ::close(w->bin[c].fd);
+            delete w;
+            return ffail(TBK_ERR_IO, "cannot create %s: %s", paths[b], strerror(e));
+        }
+    }
+    *out = w;
+    return TBK_OK;
+}
+
+// append the batch's records to their bins in input order: FASTQ when the record has a
+// non-empty quality string, else FASTA (seq.py:27-31)
+extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins) {
+    if (!w || !b || (b->n_reads() && !bins)) return ffail(TBK_ERR_INVALID, "NULL argument");
+    const uint64_t n = b->n_reads();
+    for (uint64_t i = 0; i < n; i++) {
+        const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
+        std::vector<char> &t = w->bin[which].text;
+        const size_t nn = b->name_off[i + 1] - b->name_off[i];
+        const size_t ns = b->base_off[i + 1] - b->base_off[i];
+        const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
+        const bool fq = b->has_qual[i] && nq > 0;
+        const size_t o = t.size();
+        t.resize(o + 1 + nn + 1 + ns + 1 + (fq ? 2 + nq + 1 : 0));
+        char *p = t.data() + o;
+        *p++ = fq ? '@' : '>';
+        memcpy(p, b->names.data() + b->name_off[i], nn); p += nn;
+        *p++ = '\n';
+        memcpy(p, b->bases + b->base_off[i], ns); p += ns;
+        *p++ = '\n';
+        if (fq) {
+            *p++ = '+'; *p++ = '\n';
+            memcpy(p, b->quals.data() + b->qual_off[i], nq); p += nq;
+            *p++ = '\n';
+        }
+    }
+    return flush_bins(w, false);
+}
+
+extern "C" int tbk_bin_writer_close(tbk_bin_writer *w) {
+    if (!w) return TBK_OK;
+    int rc = flush_bins(w, true);
+    if (w->gz) {
+        // an empty bin is still a valid (empty) gzip file, as gzip.open(...).close() leaves it
+        for (int b = 0; b < 3; b++) {
+            struct stat st;
+            if (fstat(w->bin[b].fd, &st) == 0 && st.st_size == 0) {
+                std::vector<char> out;
+                if (deflate_member("", 0, w->level, out)) write_all(w->bin[b].fd, out.data(), out.size(), w->err);
+            }
+        }
+    }
+    for (int b = 0; b < 3; b++) if (w->bin[b].fd >= 0) ::close(w->bin[b].fd);
+    delete w;
+    return rc;
+}

@@ -52,6 +52,9 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// lets the other translation units of the library report through tbk_last_error()
+extern "C" void tbk_set_error_(int, const char *msg) { g_err = msg ? msg : ""; }
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -517,7 +520,8 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
 
 extern "C" int tbk_stream_depth(const tbk_classifier *) { return RING; }
 
-static int slot_reserve(Slot &s, uint64_t total, uint64_t n_reads, bool stage_in, bool stage_out) {
+// device buffers of a slot
+static int slot_reserve_device(Slot &s, uint64_t total, uint64_t n_reads) {
     const size_t need_b = ((size_t)total + 15) & ~(size_t)15;
     if (need_b > s.cap_bases) {
         if (s.d_bases) HIP_TRY(hipFree(s.d_bases));
@@ -535,14 +539,21 @@ static int slot_reserve(Slot &s, uint64_t total, uint64_t n_reads, bool stage_in
         HIP_TRY(hipMalloc((void **)&s.d_counts, cap * 2 * sizeof(int32_t)));
         s.cap_reads = cap;
     }
-    if (stage_in && need_b > s.hcap_bases) {
+    return TBK_OK;
+}
+
+// pinned host staging of a slot: `stage_bases` bytes of bases (0 = none), offsets/counts staging
+// when `stage_small` / `stage_out`
+static int slot_reserve(Slot &s, uint64_t stage_bases, uint64_t n_reads, bool stage_small, bool stage_out) {
+    const size_t need_b = ((size_t)stage_bases + 15) & ~(size_t)15;
+    if (need_b > s.hcap_bases) {
         if (s.h_bases) HIP_TRY(hipHostFree(s.h_bases));
         s.h_bases = nullptr; s.hcap_bases = 0;
         const size_t cap = std::max(need_b + need_b / 8, (size_t)1 << 20);
         HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocDefault));
         s.hcap_bases = cap;
     }
-    if ((stage_in || stage_out) && n_reads > s.hcap_reads) {
+    if ((stage_small || stage_out) && n_reads > s.hcap_reads) {
         if (s.h_offsets) HIP_TRY(hipHostFree(s.h_offsets));
         if (s.h_counts) HIP_TRY(hipHostFree(s.h_counts));
         s.h_offsets = nullptr; s.h_counts = nullptr; s.hcap_reads = 0;
@@ -568,19 +579,22 @@ extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const 
     Slot &s = c->ring[tk % RING];
     if (s.busy) return fail(TBK_ERR_STATE, "all %d stream slots are in flight; call tbk_stream_wait(%llu) first", RING,
                             (unsigned long long)s.ticket);
-    const bool in_pinned = total == 0 || (is_pinned(bases) && is_pinned(offsets));
+    // pinned inputs are copied straight from the caller's memory; pageable ones go through the
+    // slot's pinned staging (bases and offsets decided independently: a reader batch has its
+    // bases pinned and its small offsets array in ordinary memory)
+    const bool bases_pinned = total == 0 || is_pinned(bases);
+    const bool offs_pinned = is_pinned(offsets);
     const bool out_pinned = n_reads == 0 || is_pinned(counts);
-    rc = slot_reserve(s, total, n_reads, !in_pinned, !out_pinned);
+    rc = slot_reserve(s, bases_pinned ? 0 : total, n_reads, !bases_pinned || !offs_pinned, !out_pinned);
+    if (rc) return rc;
+    rc = slot_reserve_device(s, total, n_reads);
     if (rc) return rc;
     s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
     if (n_reads && total) {
         const uint8_t *src_b = bases;
         const uint64_t *src_o = offsets;
-        if (!in_pinned) {
-            memcpy(s.h_bases, bases, total);
-            memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t));
-            src_b = s.h_bases; src_o = s.h_offsets;
-        }
+        if (!bases_pinned) { memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
+        if (!offs_pinned) { memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t)); src_o = s.h_offsets; }
         // side stream: H2D of this batch overlaps the previous batch's kernel
         HIP_TRY(hipMemcpyAsync(s.d_bases, src_b, total, hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
@@ -656,6 +670,8 @@ extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, 
                             (unsigned long long)s.ticket);
     const bool out_pinned = n_reads == 0 || is_pinned(counts);
     rc = slot_reserve(s, 0, n_reads, false, !out_pinned);
+    if (rc) return rc;
+    rc = slot_reserve_device(s, 0, n_reads);
     if (rc) return rc;
     s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
     if (n_reads && total_bases) {

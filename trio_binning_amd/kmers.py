@@ -255,6 +255,16 @@ class Classifier:
         self._keep[ticket.value] = (bases, offsets, counts)
         return ticket.value
 
+    def submit_batch(self, batch) -> int:
+        """Submit a ``seq.Batch`` (its bases already lie in pinned memory: no staging copy)."""
+        bases_ptr, off_ptr = batch.pointers()
+        counts = np.zeros((batch.n_reads, 2), dtype=np.int32)
+        ticket = C.c_uint64()
+        check(lib.tbk_stream_submit(self._h, C.c_void_p(bases_ptr), C.c_void_p(off_ptr), batch.n_reads,
+                                    counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (batch, None, counts)
+        return ticket.value
+
     def wait(self, ticket: int) -> np.ndarray:
         check(lib.tbk_stream_wait(self._h, ticket))
         return self._keep.pop(ticket)[2]

@@ -138,3 +138,174 @@ def open_outfiles(
     if gzip_output:
         return tuple(gzip.open(n, "wt") for n in names)  # type: ignore[return-value]
     return tuple(open(n, "w") for n in names)  # type: ignore[return-value]
+
+
+# ---- native batch I/O (C-ABI tbk_fastx_* / tbk_bin_writer_*) --------------------------------
+# The same records and the same output bytes as readfq / Read.print above, produced by the
+# library in the batch layout the classifier consumes; used by the CLI driver.  Imported
+# lazily so that this module stays importable without the built library.
+class Batch:
+    """One batch of records read by ``BatchReader`` (owned by the native library)."""
+
+    def __init__(self):
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        h = C.c_void_p()
+        check(lib.tbk_fastx_batch_create(C.byref(h)))
+        self._h = h
+        self.n_reads = 0
+
+    def _view(self):
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        n = C.c_uint64()
+        ptrs = [C.c_void_p() for _ in range(7)]
+        check(lib.tbk_fastx_batch_view(self._h, C.byref(n), *[C.byref(p) for p in ptrs]))
+        return n.value, [p.value for p in ptrs]
+
+    def arrays(self):
+        """(bases, base_off, names, name_off, quals, qual_off, has_qual) as numpy views that
+        stay valid until the batch is refilled or destroyed."""
+        import ctypes as C
+
+        import numpy as np
+
+        n, (bases, boff, names, noff, quals, qoff, hq) = self._view()
+
+        def arr(ptr, count, dtype):
+            if count == 0:
+                return np.zeros(0, dtype=dtype)
+            ct = {np.uint8: C.c_uint8, np.uint64: C.c_uint64}[dtype]
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,))
+
+        base_off = arr(boff, n + 1, np.uint64)
+        name_off = arr(noff, n + 1, np.uint64)
+        qual_off = arr(qoff, n + 1, np.uint64)
+        return (arr(bases, int(base_off[-1]), np.uint8), base_off, arr(names, int(name_off[-1]), np.uint8), name_off,
+                arr(quals, int(qual_off[-1]), np.uint8), qual_off, arr(hq, n, np.uint8))
+
+    def pointers(self):
+        """(bases_ptr, base_off_ptr) for tbk_stream_submit."""
+        _, p = self._view()
+        return p[0], p[1]
+
+    def reads(self) -> List[Read]:
+        """The batch as ``Read`` objects (tests; the CLI never materialises them)."""
+        bases, boff, names, noff, quals, qoff, hq = self.arrays()
+        out = []
+        for i in range(self.n_reads):
+            name = bytes(names[int(noff[i]):int(noff[i + 1])]).decode()
+            sq = bytes(bases[int(boff[i]):int(boff[i + 1])]).decode()
+            ql = bytes(quals[int(qoff[i]):int(qoff[i + 1])]).decode() if hq[i] else None
+            out.append(Read(name, sq, ql))
+        return out
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            from ._lib import lib
+
+            lib.tbk_fastx_batch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchReader:
+    """Native FASTA/FASTQ(.gz) reader: ``next_batch(batch, max_bases, max_reads)`` fills a
+    ``Batch`` and returns the number of records (0 at end of input)."""
+
+    def __init__(self, filename: str):
+        import ctypes as C
+        import os
+
+        from ._lib import check, lib
+
+        h = C.c_void_p()
+        check(lib.tbk_fastx_open(os.fsencode(filename), C.byref(h)))
+        self._h = h
+
+    def next_batch(self, batch: Batch, max_bases: int = 0, max_reads: int = 0) -> int:
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        check(lib.tbk_fastx_next(self._h, batch._h, max_bases, max_reads))
+        n = C.c_uint64()
+        check(lib.tbk_fastx_batch_view(batch._h, C.byref(n), None, None, None, None, None, None, None))
+        batch.n_reads = n.value
+        return n.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            from ._lib import lib
+
+            lib.tbk_fastx_close(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class BinWriter:
+    """Native writer of the three bins (same names, same decompressed bytes as
+    ``open_outfiles`` + ``Read.print``); gzip members are deflated in parallel."""
+
+    def __init__(self, haplotype_a_prefix: str, haplotype_b_prefix: str, unclassified_prefix: str,
+                 outfile_extension: str, gzip_output: bool, level: int = -1, threads: int = 0):
+        import ctypes as C
+        import os
+
+        from ._lib import check, lib
+
+        self.names = output_names(haplotype_a_prefix, haplotype_b_prefix, unclassified_prefix, outfile_extension, gzip_output)
+        h = C.c_void_p()
+        check(lib.tbk_bin_writer_open(*[os.fsencode(n) for n in self.names], int(gzip_output), level, threads, C.byref(h)))
+        self._h = h
+
+    def write(self, batch: Batch, bins: bytes) -> None:
+        from ._lib import check, lib
+
+        check(lib.tbk_bin_writer_write(self._h, batch._h, bins))
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            from ._lib import check, lib
+
+            h, self._h = self._h, None
+            check(lib.tbk_bin_writer_close(h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_tsv(batch: Batch, bins: bytes, score_a, score_b) -> str:
+    """``name\\tbin\\tscoreA\\tscoreB`` lines for a batch, floats formatted as Python's str()."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    need = C.c_size_t()
+    check(lib.tbk_format_tsv(batch._h, bins, score_a.ctypes.data, score_b.ctypes.data, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value + 1)
+    check(lib.tbk_format_tsv(batch._h, bins, score_a.ctypes.data, score_b.ctypes.data, buf, need.value + 1, C.byref(need)))
+    return buf.raw[: need.value].decode()
