@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--calibrate", action="store_true", help="also run the random-line gather calibration")
+    ap.add_argument("--share-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
     return ap.parse_args()
 
 
@@ -117,20 +119,30 @@ def main():
     if args.gpus > 1 and world == 1:
         sys.exit(spawn_ranks(args))
 
+    import fcntl
+
     import numpy as np
 
     import __graft_entry__ as entry
 
-    if rank == 0 and os.environ.get("TBK_SKIP_BUILD") != "1":
-        entry.build()  # skipped under rocprofv3 (no child processes from a profiled process)
-    dist = Dist(world)
-    dist.barrier()
+    # every rank makes sure the library is built (make is a no-op when it is), one at a time
+    if os.environ.get("TBK_SKIP_BUILD") != "1":  # skipped under rocprofv3 (no child processes there)
+        with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            entry.build()
+            fcntl.flock(lock, fcntl.LOCK_UN)
+    # Load the HIP library and initialise its runtime BEFORE torch is imported: the torch wheel
+    # bundles its own copy of the HIP runtime and whichever copy is loaded first owns the process.
     from trio_binning_amd import _lib, kmers
     from trio_binning_amd._lib import check, lib
 
-    dev = local_rank
-    if _lib.device_count() <= dev:
-        raise SystemExit(f"rank {rank}: HIP device {dev} not visible ({_lib.device_count()} devices)")
+    n_dev = _lib.device_count()
+    dist = Dist(world)
+    dist.barrier()
+
+    dev = 0 if args.share_device else local_rank
+    if n_dev <= dev:
+        raise SystemExit(f"rank {rank}: HIP device {dev} not visible ({n_dev} devices)")
     k, n_list, L, R = args.k, args.kmers_per_list, args.read_len, args.reads_per_step
 
     def dalloc(nbytes):
@@ -213,6 +225,7 @@ def main():
     bases_all = dist.reduce(args.steps * total, "SUM")
     value = bases_all / elapsed_max / 1e9
 
+    bucket_select = ("minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])) if stats["minimizer_w"] else "plain hash"
     # ---- roofline of the probe kernel (rank 0's device) -----------------------------------------
     # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
     # hapB slot when hapA missed.  Per launch: windows = R * (L - k + 1).
@@ -228,7 +241,10 @@ def main():
     if os.path.isfile(tfile):
         try:
             t = json.load(open(tfile))
-            if t.get("reads_per_step") == R and t.get("read_len") == L and t.get("kmers_per_list") == n_list:
+            same = (t.get("reads_per_step") == R and t.get("read_len") == L and t.get("kmers_per_list") == n_list
+                    and t.get("k") == k and t.get("bucket_select") == bucket_select
+                    and abs(t.get("table_load", 0) - n_list / (stats["n_buckets"] * 8)) < 1e-3)
+            if same:  # measured in a separate rocprofv3 --pmc pass on this exact configuration
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
@@ -250,7 +266,7 @@ def main():
                         f"{R} reads ({total / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks",
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R, "resident_batches": nb,
             "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(n_list / (stats["n_buckets"] * 8), 4),
-            "bucket_select": ("minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])) if stats["minimizer_w"] else "plain hash",
+            "bucket_select": bucket_select,
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "roofline": roofline,

@@ -73,6 +73,11 @@ void tbk_reverse_complement(const char *kmer_in, char *kmer_out, unsigned char k
  * The packed keys are placed in HBM on `device`; tbk_classifier_create hashes two such lists
  * into the paired open-addressing table the probe kernel reads. */
 int tbk_table_create_from_file(const char *path, int device, tbk_table **out);
+/* Host-only half of the above: parse the list (all host threads when every line is k bytes +
+ * newline, the sequential general parser otherwise) into malloc'd packed keys; free with
+ * tbk_list_free. */
+int tbk_list_parse_file(const char *path, uint64_t **keys, uint64_t *n, int *k);
+void tbk_list_free(uint64_t *keys);
 /* Same from already-packed keys (one per list line) in host memory. */
 int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int k, int device, tbk_table **out);
 /* Same, keys already in device memory on `device` (bench generator).  The keys are copied. */

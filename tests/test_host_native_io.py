@@ -181,3 +181,49 @@ def test_format_tsv(built, tmp_path):
         counts = np.array([[4, 1], [0, 2], [0, 0]], dtype=np.int32)
         sa, sb, bins = kmers.score_and_bin(counts, 4, 3)
         assert seq.format_tsv(b, bins, sa, sb) == "a\tA\t4.0\t1.3333333333333333\nb\tx\tB\t0.0\t2.6666666666666665\n\tU\t0.0\t0.0\n"
+
+
+def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
+    """tbk_list_parse_file (host code): the all-threads fast path for regular lists and the
+    general getline-rule parser give the keys the oracle packs from the same file."""
+    from trio_binning_amd import kmers
+
+    rng = random.Random(12)
+
+    def want(text, k):
+        keys, pos = [], 0
+        data = text.encode()
+        while pos < len(data):
+            nl = data.find(b"\n", pos)
+            end = len(data) if nl < 0 else nl + 1
+            keys.append(orc.kmer_to_int(data[pos:pos + k].decode("latin1")))
+            pos = end
+        return keys
+
+    k = 21
+    lines = ["".join(rng.choice("ACGT") for _ in range(k)) for _ in range(200_000)]
+    cases = {
+        "regular": "".join(x + "\n" for x in lines),
+        "regular_no_final_newline": "\n".join(lines),
+        "with_N_and_lowercase": "".join(x + "\n" for x in lines[:1000]) + "ACGTNNNNacgtACGTACGTA\n" + lines[5] + "\n",
+        "one_long_line": "".join(x + "\n" for x in lines[:70000]) + lines[3] + "GGGG\n" + "".join(x + "\n" for x in lines[:70000]),
+        "crlf": "".join(x + "\r\n" for x in lines[:70000]),
+        "single_line": lines[0] + "\n",
+        "tiny_k": "ACG\nTTT\nGGA\nCCC\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / (name + ".txt")
+        p.write_bytes(text.encode())
+        keys, kk = kmers.parse_kmer_list(str(p))
+        first = text.split("\n")[0]
+        assert kk == len(first.encode()) + (1 if "\n" in text else 0) - 1, name
+        assert keys.tolist() == want(text, kk), name
+        t = orc.table_from_file(str(p))
+        assert (t.k, t.num_kmers) == (kk, keys.size), name
+    for bad in ("", "ACGTACGT\nACG\nACGTACGT\n", "A" * 33 + "\n", "\n"):
+        p = tmp_path / "bad.txt"
+        p.write_text(bad)
+        with pytest.raises(ValueError):
+            kmers.parse_kmer_list(str(p))
+    with pytest.raises(IOError):
+        kmers.parse_kmer_list(str(tmp_path / "missing.txt"))

@@ -42,7 +42,10 @@ if not os.path.isfile(_path):
         "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C trio_binning_amd/csrc`. "
         "This package has no CPU fallback."
     )
-lib = C.CDLL(_path)
+# RTLD_GLOBAL: if another HIP runtime copy is loaded later into the process (PyTorch wheels
+# bundle one), the system runtime this library was built against stays first in symbol
+# resolution.  Load this library before importing torch.
+lib = C.CDLL(_path, mode=C.RTLD_GLOBAL)
 
 _vp = C.c_void_p
 _u64 = C.c_uint64
@@ -65,6 +68,8 @@ _sig("tbk_device_name", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
 _sig("tbk_kmer_to_int", _u64, C.c_char_p, C.c_ubyte)
 _sig("tbk_reverse_complement", None, C.c_char_p, C.c_char_p, C.c_ubyte)
 _sig("tbk_table_create_from_file", C.c_int, C.c_char_p, C.c_int, C.POINTER(_vp))
+_sig("tbk_list_parse_file", C.c_int, C.c_char_p, C.POINTER(_u64p), _u64p, C.POINTER(C.c_int))
+_sig("tbk_list_free", None, _u64p)
 _sig("tbk_table_create_from_keys", C.c_int, _vp, _u64, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("tbk_table_create_from_device_keys", C.c_int, _vp, _u64, C.c_int, C.c_int, C.POINTER(_vp))
 _sig("tbk_table_destroy", None, _vp)

@@ -169,6 +169,18 @@ def create_kmer_hash_set(kmer_file_path: str) -> HashSet:
     return hs
 
 
+def parse_kmer_list(kmer_file_path: str) -> Tuple[np.ndarray, int]:
+    """Host-only: (packed keys, k) of a k-mer list file, exactly what ``create_kmer_hash_set``
+    places in HBM (the reference's getline rules, c/kmers.c:124-146,204-221)."""
+    keys, n, k = _lib._u64p(), C.c_uint64(), C.c_int()
+    check(lib.tbk_list_parse_file(os.fsencode(kmer_file_path), C.byref(keys), C.byref(n), C.byref(k)))
+    try:
+        out = np.ctypeslib.as_array(keys, shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.uint64)
+    finally:
+        lib.tbk_list_free(keys)
+    return out, k.value
+
+
 def count_kmers_in_read(read: str, kmers_hap_a: HashSet, kmers_hap_b: HashSet) -> Tuple[int, int]:
     """Count the k-mers of one read found in each of two sets (reference kmers.py:125-154).
 
