@@ -1,0 +1,96 @@
+"""BASELINE.json's full table size (2 x 300 M 21-mers, 38 GB paired table) on the GPU, checked
+through size-independent properties instead of the oracle (which needs minutes at this size;
+bench.py does the oracle check on a 4096-read sample of the same configuration):
+
+* strand symmetry: a read and its reverse complement have identical (hapA, hapB) counts,
+  because every window is looked up by its canonical k-mer;
+* splitting: cutting every read into two pieces that overlap by k-1 bases preserves the sum;
+* permutation: shuffling the read order permutes the counts and nothing else;
+* determinism: two launches give identical counts;
+* generator promise: origin reads carry at least their 30 planted k-mers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+K, N_LIST, R, L = 21, 300_000_000, 16384, 15000
+KEY_SEED, READ_SEED = 0x5EED0001, 0x5EED0002
+
+
+@pytest.fixture(scope="module")
+def big(gpu):
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    dev = 0
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    d_keys = dalloc(2 * N_LIST * 8)
+    check(lib.tbk_synth_keys_device(dev, KEY_SEED, 0, 2 * N_LIST, K, C.c_void_p(d_keys)))
+    a = kmers.HashSet.from_device_keys(d_keys, N_LIST, K)
+    b = kmers.HashSet.from_device_keys(d_keys + N_LIST * 8, N_LIST, K)
+    check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
+    cls = kmers.Classifier(a, b)
+    a.close()
+    b.close()  # the classifier owns the hashed tables; the lists may go
+    st = cls.stats()
+    assert st["distinct_a"] == N_LIST and st["distinct_b"] == N_LIST
+    total = R * L
+    d_bases, d_offs = dalloc(total + 64), dalloc((R + 1) * 8)
+    check(lib.tbk_synth_reads_device(dev, READ_SEED, 0, R, L, KEY_SEED, N_LIST, N_LIST, K, 30, 3, C.c_void_p(d_bases), C.c_void_p(d_offs)))
+    bases = np.empty(total, dtype=np.uint8)
+    check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_bases), total))
+    offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
+    base_counts = cls.classify_batch(bases, offs)
+    yield cls, bases, offs, base_counts
+    cls.close()
+    for p in (d_bases, d_offs):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+
+
+def test_planted_kmers_are_found(big):
+    cls, bases, offs, counts = big
+    major = counts.max(axis=1)
+    assert (major >= 30).sum() > 0.85 * R          # origin A or B: p = 0.9
+    # origin-less reads: 3 + 3 planted plus ~2 chance hits per list (600 M keys in a 2.2e12 space)
+    assert ((major >= 30) | (major <= 20)).all()
+    assert counts.sum() > 30 * 0.85 * R
+
+
+def test_deterministic(big):
+    cls, bases, offs, counts = big
+    assert np.array_equal(cls.classify_batch(bases, offs), counts)
+
+
+def test_strand_symmetry(big):
+    cls, bases, offs, counts = big
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    rc = comp[bases.reshape(R, L)[:, ::-1]].reshape(-1)
+    assert np.array_equal(cls.classify_batch(np.ascontiguousarray(rc), offs), counts)
+
+
+def test_split_reads_preserve_the_sum(big):
+    cls, bases, offs, counts = big
+    h = L // 2
+    m = bases.reshape(R, L)
+    left, right = m[:, : h + K - 1], m[:, h:]          # windows 0..h-1 and h..L-K
+    pieces = np.concatenate([np.ascontiguousarray(left).reshape(-1), np.ascontiguousarray(right).reshape(-1)])
+    lens = np.concatenate([np.full(R, h + K - 1, dtype=np.uint64), np.full(R, L - h, dtype=np.uint64)])
+    poffs = np.zeros(2 * R + 1, dtype=np.uint64)
+    np.cumsum(lens, out=poffs[1:])
+    got = cls.classify_batch(pieces, poffs)
+    assert np.array_equal(got[:R] + got[R:], counts)
+
+
+def test_read_order_permutation(big):
+    cls, bases, offs, counts = big
+    perm = np.random.default_rng(1).permutation(R)
+    shuffled = np.ascontiguousarray(bases.reshape(R, L)[perm]).reshape(-1)
+    assert np.array_equal(cls.classify_batch(shuffled, offs), counts[perm])
