@@ -108,6 +108,12 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // A pass that touches several reads attributes each hit to the read that contains the
 // window start (per-quad read index, broadcast alongside the key).
 
+#ifndef TBK_UNROLL
+#define TBK_UNROLL 2      // j-loop unroll of the probe pass
+#endif
+#ifndef TBK_MIN_WAVES
+#define TBK_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#endif
 constexpr int TBK_WPL = 32;                 // windows per lane per pass
 constexpr int TBK_PASS = 64 * TBK_WPL;      // window starts per wave pass (2048)
 constexpr int TBK_WAVES_PER_BLOCK = 4;
@@ -291,13 +297,25 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     uint64_t rid = r_first;
     uint64_t rend = r_first_end;
     if (MULTI) {
-        // this lane's first window start may be in a later read than the pass start
+        // This lane's first window start may be in a later read than the pass start.  Gallop
+        // forward from the pass's first read (a long read ending inside the pass costs one or
+        // two loads per lane; a pass full of tiny reads still takes only O(log) steps).
         const uint64_t pl = p_lane < p.total ? p_lane : p.total;
-        rid = find_read(p.offsets, p.n_reads, pl);
+        uint64_t lo = r_first, step = 1;  // invariant: offsets[lo] <= pl
+        while (lo + step <= p.n_reads && p.offsets[lo + step] <= pl) { lo += step; step <<= 1; }
+        uint64_t hi = lo + step <= p.n_reads ? lo + step : p.n_reads + 1;  // offsets[hi] > pl (virtually +inf)
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (p.offsets[mid] <= pl) lo = mid; else hi = mid;
+        }
+        rid = lo;
         rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
     }
     // windows j with j + k <= rel_end lie inside the current read
-    uint32_t rel_end = rend > p_lane ? (uint32_t)(rend - p_lane < 0x40000000ull ? rend - p_lane : 0x40000000ull) : 0u;
+    auto rel = [&](uint64_t pos) -> uint32_t {  // pos relative to this lane's first window, clamped
+        return pos > p_lane ? (uint32_t)(pos - p_lane < 0x40000000ull ? pos - p_lane : 0x40000000ull) : 0u;
+    };
+    uint32_t rel_end = rel(rend);
     uint32_t acc_a = 0, acc_b = 0;  // wave-uniform in the single-read case
 
     // the line each quad slot holds from the previous window of the same lane
@@ -307,17 +325,19 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
     uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
 
-#pragma unroll 2
+#pragma unroll TBK_UNROLL
     for (int j = 0; j < TBK_WPL; j++) {
         // ---- this lane's window j ---------------------------------------------------
         const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
         const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
         const uint64_t key = fwd < rc ? fwd : rc;
         if (MULTI) {
-            const uint64_t pw = p_lane + (uint64_t)j;
-            bool moved = false;
-            while (rid < p.n_reads && pw >= rend) { rid++; rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total; moved = true; }
-            if (moved) rel_end = rend > p_lane ? (uint32_t)(rend - p_lane < 0x40000000ull ? rend - p_lane : 0x40000000ull) : 0u;
+            // window j starts at or past the current read's end: move to the read that holds it
+            while ((uint32_t)j >= rel_end && rid < p.n_reads) {
+                rid++;
+                rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
+                rel_end = rel(rend);
+            }
         }
         bool ok = (bad_lo & badk) == 0 && (uint32_t)(j + k) <= rel_end;
         if (MULTI) ok = ok && rid < p.n_reads;
@@ -427,7 +447,10 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
 }
 
 template <int W>
-__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, 4)  // <= 128 VGPRs: 4 waves per SIMD
+// 4 waves per SIMD (<= 128 VGPRs).  Measured same-box A/B (tools/gpu_ab.sh): asking for 5 or 6
+// waves makes the allocator spill and loses 12-50 %; a third pass variant specialised for
+// two-read passes bloats the code and loses 8-14 % even on single-read passes.
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, TBK_MIN_WAVES)
 tbk_probe_kernel(const ProbeArgs p) {
     // LDS staging of the read tile, one region per wave: a wave only ever reads what it wrote
     // itself, so wave-scope ordering is enough and the waves of a block never wait for each
