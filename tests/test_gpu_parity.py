@@ -148,6 +148,38 @@ def test_every_bucket_selection_mode(gpu, orc, tmp_path, w, monkeypatch):
         assert want.sum() > 100
 
 
+@pytest.mark.parametrize("m", [17, 18, 20, 23, 26])
+def test_long_mmer_bucket_selection(gpu, orc, tmp_path, m, monkeypatch):
+    """Big tables select buckets by minimizers longer than 16 bases (64-bit m-mer path);
+    force that path at test size.  Counts must not change."""
+    from trio_binning_amd import kmers
+
+    monkeypatch.setenv("TBK_MINIMIZER_M", str(m))
+    rng = np.random.default_rng(300 + m)
+    for k, w in ((27, 6), (31, 6), (32, 5), (31, 3)):
+        if m + 1 > k:
+            continue
+        monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+        la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(300)] + ["A" * k, "AC" * 16]
+        lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(300)]
+        fa = _write(tmp_path, "a.txt", "".join(x[:k] + "\n" for x in la))
+        fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
+        oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+        a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+        reads = _rand_reads(rng, 200, 2500, [x[:k] for x in la] + lb, k, p_plant=0.9) + ["A" * 100, "T" * 100, "AC" * 60]
+        bases, offs = _pack(reads)
+        with kmers.Classifier(a, b) as cls:
+            st = cls.stats()
+            if st["minimizer_w"]:
+                assert st["minimizer_m"] == m
+                span = m + st["minimizer_w"] - 1
+                assert span <= k and (k - span) % 2 == 0
+            got = cls.classify_batch(bases, offs)
+        want = orc.count_batch(bases, offs, oa, ob)
+        assert np.array_equal(got, want), (k, m, st, np.nonzero((got != want).any(axis=1))[0][:10])
+        assert want.sum() > 100
+
+
 def test_ragged_batch_shapes(gpu, orc, tmp_path):
     """Empty batch, empty reads, many tiny reads, reads around the 1024-window pass size and
     the 16-base chunk size, one long read: per-read attribution at every boundary."""

@@ -54,13 +54,16 @@
 // computes H from the forward strand alone).  Consecutive windows of a read share their
 // minimizer 1 - 2/(w+1) of the time, so they probe the SAME 128-byte line and the kernel
 // re-uses the line it already holds instead of fetching another random line from HBM.
-// m <= 16 keeps m-mer arithmetic in 32 bits; (m, w) are picked per k by tbk_mz_params so
-// that m + w - 1 has k's parity (the span must be central).
+// (m, w) are picked per k and per table size by tbk_mz_params so that m + w - 1 has k's parity
+// (the span must be central) and so that there are enough distinct m-mers for the keys: all
+// keys sharing a minimizer land in one bucket, so about n_keys * w / (4^m / 2) keys compete
+// for the most popular minimizers.  m <= 16 keeps m-mer arithmetic in 32 bits; bigger tables
+// (or TBK_MINIMIZER_M) use longer m-mers on a 64-bit path.
 //
 // Mode "plain" (w = 0): bucket = reduce(mix32(key)), one random line per window.
 struct TbkMz {
     int w;  // m-mers per span (0 = plain mode)
-    int m;  // m-mer length, <= 16
+    int m;  // m-mer length (<= 16: 32-bit m-mer arithmetic; 17..32: 64-bit)
     int o;  // first base of the span inside the k-mer: (k - (m + w - 1)) / 2
 };
 
@@ -99,14 +102,59 @@ TBK_HD uint32_t tbk_revcomp32(uint32_t x, int m) {
     return y >> (32 - 2 * m);
 }
 
-// (m, w, o) for a given k and wanted w.  Largest w' <= w_target with an m in {16, 15} such
-// that the span m + w' - 1 fits in k and has k's parity; plain mode when k < 15.
-TBK_HD TbkMz tbk_mz_params(int k, int w_target) {
+// Canonical m-mers longer than 16 bases (big tables).  Returns (order << 32) | place: minimizer
+// selection compares the whole 64-bit value (so `order` decides), and the bucket is chosen by
+// `place`, an independent 32-bit hash of the same m-mer.  A minimum of w order values is
+// confined to the lowest ~1/(w+1) of the 32-bit range; using it as the bucket hash as well
+// (fine for the 3e8-bucket tables of the 32-bit path) would leave a 1e9-bucket table half
+// unused.  `place` of the selected m-mer is uniform over all 32 bits.
+TBK_HD uint64_t tbk_mmer_hash64(uint64_t cm) {
+    const uint32_t lo = (uint32_t)cm, hi = (uint32_t)(cm >> 32);
+    uint32_t order = (lo ^ 0x5BD1E995u) * 0x9E3779B1u ^ (hi + 0x7F4A7C15u) * 0x85EBCA77u;
+    order ^= order >> 15;
+    order *= 0xC2B2AE3Du;
+    order ^= order >> 16;
+    uint32_t place = (lo + 0x165667B1u) * 0x27D4EB2Fu ^ (hi ^ 0x9E3779B9u) * 0xC2B2AE35u;
+    place ^= place >> 15;
+    place *= 0x85EBCA6Bu;
+    return ((uint64_t)order << 32) | place;
+}
+
+// reverse complement of an m-base packed value, m <= 32
+TBK_HD uint64_t tbk_revcomp64(uint64_t x, int m) {
+    uint64_t y = ~x;
+    y = ((y >> 2) & 0x3333333333333333ull) | ((y & 0x3333333333333333ull) << 2);
+    y = ((y >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((y & 0x0F0F0F0F0F0F0F0Full) << 4);
+    y = ((y >> 8) & 0x00FF00FF00FF00FFull) | ((y & 0x00FF00FF00FF00FFull) << 8);
+    y = ((y >> 16) & 0x0000FFFF0000FFFFull) | ((y & 0x0000FFFF0000FFFFull) << 16);
+    y = (y >> 32) | (y << 32);
+    return y >> (64 - 2 * m);
+}
+
+// (m, w, o) for a given k, wanted w and table size.  m_need = shortest m-mer with at most
+// ~0.9 keys per distinct canonical m-mer (the 300 M-key / m = 16 / w = 6 operating point that
+// was measured); the preferred m is max(16, m_need), then one shorter (never below m_need or
+// 15), then one longer — whichever gives a span m + w - 1 <= k with k's parity; w shrinks
+// until something fits.  m_force > 0 pins m (tests).  Plain mode when nothing fits (k < 15).
+TBK_HD TbkMz tbk_mz_params(int k, int w_target, uint64_t n_keys, int m_force) {
     TbkMz z;
     z.w = 0; z.m = 0; z.o = 0;
     if (w_target > 8) w_target = 8;
+    if (w_target < 1) return z;
+    int m_need = 15;
+    while (m_need < 32) {
+        const double distinct = 0.5 * (double)(1ull << (2 * (m_need > 31 ? 31 : m_need))) * (m_need > 31 ? 4.0 : 1.0);
+        if ((double)n_keys * (double)w_target <= 0.9 * distinct) break;
+        m_need++;
+    }
+    const int m0 = m_need > 16 ? m_need : 16;
     for (int w = w_target; w >= 1; w--) {
-        for (int m = 16; m >= 15; m--) {
+        int cand[3] = {m0, m0 - 1, m0 + 1};
+        if (m_force > 0) { cand[0] = m_force; cand[1] = cand[2] = -1; }
+        for (int c = 0; c < 3; c++) {
+            const int m = cand[c];
+            if (m < 1 || m > 32) continue;
+            if (m_force <= 0 && (m < 15 || m < m_need)) continue;
             const int span = m + w - 1;
             if (span <= k && ((k - span) & 1) == 0) {
                 z.w = w; z.m = m; z.o = (k - span) / 2;
@@ -121,13 +169,25 @@ TBK_HD TbkMz tbk_mz_params(int k, int w_target) {
 // from the read; for the (dead) non-canonical list lines any value is fine.
 TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
     if (z.w == 0) return tbk_reduce(tbk_mix32(key), n_buckets);
-    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
     uint32_t best = 0xFFFFFFFFu;
-    for (int i = 0; i < z.w; i++) {
-        const uint32_t x = (uint32_t)(key >> (2 * (z.o + i))) & mmask;
-        const uint32_t y = tbk_revcomp32(x, z.m);
-        const uint32_t g = tbk_mmer_hash(x < y ? x : y);
-        best = g < best ? g : best;
+    if (z.m <= 16) {
+        const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+        for (int i = 0; i < z.w; i++) {
+            const uint32_t x = (uint32_t)(key >> (2 * (z.o + i))) & mmask;
+            const uint32_t y = tbk_revcomp32(x, z.m);
+            const uint32_t g = tbk_mmer_hash(x < y ? x : y);
+            best = g < best ? g : best;
+        }
+    } else {
+        const uint64_t mmask = z.m == 32 ? ~0ull : ((1ull << (2 * z.m)) - 1ull);
+        uint64_t best64 = ~0ull;
+        for (int i = 0; i < z.w; i++) {
+            const uint64_t x = (key >> (2 * (z.o + i))) & mmask;
+            const uint64_t y = tbk_revcomp64(x, z.m);
+            const uint64_t g = tbk_mmer_hash64(x < y ? x : y);
+            best64 = g < best64 ? g : best64;
+        }
+        return tbk_reduce((uint32_t)best64, n_buckets);
     }
     return tbk_reduce(tbk_scramble(best), n_buckets);
 }

@@ -467,7 +467,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     // bucket selection: minimizer of the k-mer's central span (TBK_MINIMIZER_W m-mers, default
     // 6; 0 = plain hashing of the whole key)
-    c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6));
+    c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6), std::max(a->num_lines, b->num_lines),
+                          (int)env_double("TBK_MINIMIZER_M", 0));
     // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
     c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.125 : 0.25);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "tbk_common.h"
 
 // =======================================================================================
@@ -242,7 +244,7 @@ __device__ __forceinline__ void probe_exact(const TbkPairView t, ulonglong2 va, 
 
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
 // window).  MULTI = the pass touches more than one read.
-template <int W, bool MULTI>
+template <int W, bool M64, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane) {
@@ -275,21 +277,32 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     // its reverse complement sits at base o of the reverse-complement k-mer (the span is
     // central), i.e. bits [64+2o, +2m) of rolled R.
     constexpr int NW = W > 0 ? W : 1;
-    uint32_t win[NW];
-    uint32_t mmask = 0, fsh_new = 0, bsh_new = 0;
+    // m-mers are 32-bit values for m <= 16 (M64 = false) and 64-bit ones above; both are slices
+    // of the same two 64-bit words, (s1:s0) forward and (t3:t2) reverse complement, because an
+    // m-mer of the span lies inside the window's k-mer.  The shift register holds the 32-bit
+    // order hash (M64 = false) or (order << 32 | place) (M64 = true, see tbk_mmer_hash64).
+    using win_t = typename std::conditional<M64, uint64_t, uint32_t>::type;
+    win_t win[NW];
+    uint64_t mmask = 0;
+    uint32_t fsh_new = 0, bsh_new = 0;
+    auto mmer_order = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh) -> win_t {
+        if (M64) {
+            const uint64_t x = (fwd64 >> fsh) & mmask, y = (rc64 >> bsh) & mmask;
+            return (win_t)tbk_mmer_hash64(x < y ? x : y);
+        }
+        const uint32_t x = (uint32_t)(fwd64 >> fsh) & (uint32_t)mmask, y = (uint32_t)(rc64 >> bsh) & (uint32_t)mmask;
+        return (win_t)tbk_mmer_hash(x < y ? x : y);
+    };
     if (W > 0) {
         const int m = p.t.mz.m, o = p.t.mz.o;
-        mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+        mmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
         const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
-        win[0] = 0xFFFFFFFFu;
+        win[0] = (win_t)~0ull;
 #pragma unroll
-        for (int i = 0; i + 1 < W; i++) {  // prologue: the W-1 m-mers window 0 shares with window -1
-            const uint32_t x = (uint32_t)(fs >> (2 * (o + i))) & mmask;
-            const uint32_t y = (uint32_t)(bs >> (2 * (o + W - 1 - i))) & mmask;
-            win[i + 1] = tbk_mmer_hash(x < y ? x : y);
-        }
-        fsh_new = (uint32_t)(2 * (o + W - 1));  // <= 30
-        bsh_new = (uint32_t)(2 * o);            // <= 16
+        for (int i = 0; i + 1 < W; i++)  // prologue: the W-1 m-mers window 0 shares with window -1
+            win[i + 1] = mmer_order(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + W - 1 - i)));
+        fsh_new = (uint32_t)(2 * (o + W - 1));
+        bsh_new = (uint32_t)(2 * o);
     }
 
     // ---- read bookkeeping ------------------------------------------------------------------
@@ -344,15 +357,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         uint32_t hsel;
         if (W > 0) {
             // shift in the newest m-mer of this window's span, take the minimum
-            const uint32_t x = (uint32_t)((((uint64_t)s1 << 32) | s0) >> fsh_new) & mmask;
-            const uint32_t y = (uint32_t)((((uint64_t)t3 << 32) | t2) >> bsh_new) & mmask;
 #pragma unroll
             for (int i = 0; i + 1 < W; i++) win[i] = win[i + 1];
-            win[W - 1] = tbk_mmer_hash(x < y ? x : y);
-            hsel = win[0];
+            win[W - 1] = mmer_order(((uint64_t)s1 << 32) | s0, ((uint64_t)t3 << 32) | t2, fsh_new, bsh_new);
+            win_t best = win[0];
 #pragma unroll
-            for (int i = 1; i < W; i++) hsel = win[i] < hsel ? win[i] : hsel;
-            hsel = tbk_scramble(hsel);
+            for (int i = 1; i < W; i++) best = win[i] < best ? win[i] : best;
+            hsel = M64 ? (uint32_t)best : tbk_scramble((uint32_t)best);
         } else {
             hsel = tbk_mix32(key);
         }
@@ -446,7 +457,7 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     if (pass < n_passes) pass_read[pass] = (uint32_t)find_read(offsets, n_reads, pass * TBK_PASS);
 }
 
-template <int W>
+template <int W, bool M64>
 // 4 waves per SIMD (<= 128 VGPRs).  Measured same-box A/B (tools/gpu_ab.sh): asking for 5 or 6
 // waves makes the allocator spill and loses 12-50 %; a third pass variant specialised for
 // two-read passes bloats the code and loses 8-14 % even on single-read passes.
@@ -473,8 +484,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
-        else probe_pass<W, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
+        if (last_pos < r_end) probe_pass<W, M64, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
+        else probe_pass<W, M64, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
     }
 }
 
@@ -513,11 +524,21 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
     const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
-    switch (t.mz.w) {
-#define TBK_W(N) case N: hipLaunchKernelGGL(tbk_probe_kernel<N>, grid, block, 0, stream, p); break;
-        TBK_W(0) TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
+    // 32-bit m-mer path for m <= 16 (every W), 64-bit path for longer m-mers
+    if (t.mz.m <= 16) {
+        switch (t.mz.w) {
+#define TBK_W(N) case N: hipLaunchKernelGGL((tbk_probe_kernel<N, false>), grid, block, 0, stream, p); break;
+            TBK_W(0) TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
 #undef TBK_W
-        default: return hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (t.mz.w) {
+#define TBK_W(N) case N: hipLaunchKernelGGL((tbk_probe_kernel<N, true>), grid, block, 0, stream, p); break;
+            TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
+#undef TBK_W
+            default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }
