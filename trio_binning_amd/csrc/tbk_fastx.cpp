@@ -207,13 +207,19 @@ struct tbk_fastx_batch {
         if (bases) { if (pinned) (void)hipHostFree(bases); else free(bases); }
         bases = nullptr; bases_cap = 0;
     }
+    // Pinned when a device is there (the batch then goes to the GPU without a staging copy).
+    // Pinning is tried once per process: a failing hipHostMalloc (no device) is slow.
     bool reserve_bases(size_t need) {
         if (need <= bases_cap) return true;
-        size_t cap = std::max<size_t>(need + need / 2, (size_t)1 << 22);
+        static std::atomic<int> pin_state{0};  // 0 unknown, 1 works, -1 does not
+        size_t cap = bases_cap ? std::max<size_t>(need + need / 2, (size_t)1 << 22) : std::max<size_t>(need, (size_t)1 << 22);
         uint8_t *nb = nullptr;
         bool np = false;
-        if (hipHostMalloc((void **)&nb, cap, hipHostMallocDefault) == hipSuccess) np = true;
-        else { (void)hipGetLastError(); nb = (uint8_t *)malloc(cap); }
+        if (pin_state.load() >= 0) {
+            if (hipHostMalloc((void **)&nb, cap, hipHostMallocDefault) == hipSuccess) { np = true; pin_state.store(1); }
+            else { (void)hipGetLastError(); nb = nullptr; pin_state.store(-1); }
+        }
+        if (!nb) nb = (uint8_t *)malloc(cap);
         if (!nb) return false;
         if (n_bases) memcpy(nb, bases, n_bases);
         release();
@@ -301,6 +307,10 @@ extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t 
     if (r->state == tbk_fastx_reader::DONE) return TBK_OK;
     if (max_reads == 0) max_reads = ~0ull;
     if (max_bases == 0) max_bases = ~0ull;
+    // size the pinned sequence buffer once, from the batch limit, instead of growing it
+    if (max_bases != ~0ull && max_bases <= ((uint64_t)1 << 34) && b->bases_cap < max_bases)
+        if (!b->reserve_bases((size_t)max_bases + ((size_t)max_bases >> 3) + (1 << 20)))
+            return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     if (r->have_pending) {  // a FASTA record whose header closed the previous batch
         b->begin((const uint8_t *)r->pending_name.data(), r->pending_name.size());
         r->have_pending = false;
