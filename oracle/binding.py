@@ -79,6 +79,7 @@ class Oracle:
             C.c_char_p, C.c_int64, vp, vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.orc_count_batch.argtypes = [
             C.c_void_p, u64p, C.c_uint64, vp, vp, C.c_int, C.c_int, i32p]
+        lib.orc_count_batch_fast.argtypes = [C.c_void_p, u64p, C.c_uint64, vp, vp, C.c_int, i32p]
         lib.orc_score_and_bin.argtypes = [
             i32p, C.c_uint64, C.c_uint64, C.c_uint64,
             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p]
@@ -127,6 +128,16 @@ class Oracle:
         self.lib.orc_count_batch(
             bases.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, a.ptr, b.ptr,
             int(strict), threads, counts.ctypes.data_as(C.POINTER(C.c_int32)))
+        return counts
+
+    def count_batch_fast(self, bases: np.ndarray, offsets: np.ndarray, a: _Table, b: _Table, threads: int = 1) -> np.ndarray:
+        """Fairness datum, not the reference's algorithm: rolling k-mers + threads."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        counts = np.zeros((n, 2), dtype=np.int32)
+        self.lib.orc_count_batch_fast(bases.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, a.ptr, b.ptr,
+                                      threads, counts.ctypes.data_as(C.POINTER(C.c_int32)))
         return counts
 
     def score_and_bin(self, counts: np.ndarray, num_a: int, num_b: int):

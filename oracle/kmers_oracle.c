@@ -291,6 +291,66 @@ void orc_count_batch(const uint8_t *bases, const uint64_t *offsets, uint64_t n_r
         for (int w = 0; w < threads; w++) pthread_join(tid[w], NULL);
 }
 
+/* ---- fairness datum (SURVEY 8d "CPU-opt") --------------------------------------------------
+ * NOT a restatement of the reference: the same two tables and the same A-then-B rule, but the
+ * forward and reverse-complement k-mers are rolled base by base instead of re-encoded per
+ * window, and reads are sharded over threads.  bench.py reports its rate next to the faithful
+ * port so that the GPU is not only compared with the reference's slowest formulation.  Counts
+ * are identical to orc_count_batch with strict_acgt = 1 (tests/test_oracle_golden.py). */
+static int orc_lookup_key(const orc_table *t, uint64_t key) {
+    uint64_t pos = orc_hash(key) % t->n_slots;
+    for (uint64_t walked = 0; t->used[pos] && walked < t->n_slots; walked++) {
+        if (t->slot[pos] == key) return 1;
+        pos = (pos + 1) % t->n_slots;
+    }
+    return 0;
+}
+
+static void *orc_fast_worker(void *arg) {
+    orc_count_job *j = (orc_count_job *)arg;
+    const int k = j->a->k;
+    const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+    for (uint64_t r = j->lo; r < j->hi; r++) {
+        const uint8_t *s = j->bases + j->offsets[r];
+        const uint64_t len = j->offsets[r + 1] - j->offsets[r];
+        uint64_t fwd = 0, rc = 0;
+        int run = 0, ca = 0, cb = 0;  /* run = consecutive ACGT bases ending here */
+        for (uint64_t i = 0; i < len; i++) {
+            const unsigned char c = s[i];
+            if (!g_comp[c]) { run = 0; fwd = rc = 0; continue; }
+            const uint64_t code = g_code[c];
+            fwd = (fwd >> 2) | (code << (2 * (k - 1)));
+            rc = ((rc << 2) | (3 - code)) & mask;
+            if (++run >= k) {
+                const uint64_t key = fwd < rc ? fwd : rc;
+                if (orc_lookup_key(j->a, key)) ca++;
+                else if (orc_lookup_key(j->b, key)) cb++;
+            }
+        }
+        j->counts[2 * r] = ca;
+        j->counts[2 * r + 1] = cb;
+    }
+    return NULL;
+}
+
+void orc_count_batch_fast(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                          const orc_table *a, const orc_table *b, int threads, int32_t *counts) {
+    orc_init_tables();
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    if ((uint64_t)threads > n_reads) threads = n_reads ? (int)n_reads : 1;
+    pthread_t tid[256];
+    orc_count_job job[256];
+    for (int w = 0; w < threads; w++) {
+        job[w] = (orc_count_job){bases, offsets, n_reads * (uint64_t)w / threads,
+                                 n_reads * (uint64_t)(w + 1) / threads, a, b, 1, counts};
+        if (threads == 1) orc_fast_worker(&job[w]);
+        else pthread_create(&tid[w], NULL, orc_fast_worker, &job[w]);
+    }
+    if (threads > 1)
+        for (int w = 0; w < threads; w++) pthread_join(tid[w], NULL);
+}
+
 /* (ref: calculate_scaling_factors classify_by_kmers.py:57-77 and the binning rule
  * classify_by_kmers.py:104-115) float64, same operation order: 1.0*max/n, count*factor,
  * strict '>' both ways, otherwise 'U'. */
