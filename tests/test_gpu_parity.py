@@ -374,6 +374,75 @@ def test_streaming_order_and_overlap(gpu, orc, tmp_path):
         assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
 
 
+def test_realistic_haplotypes(gpu, orc):
+    """Lists shaped like real trio-binning input rather than uniform random keys: two haplotypes
+    of one 2 Mb genome differing by SNPs, each list = the canonical 21-mers found in one
+    haplotype only (so keys come in runs of up to 21 overlapping k-mers that share minimizers),
+    reads sampled from either haplotype on either strand with sequencing errors and a few N.
+    Dense hits, clustered buckets, both lists hit inside one read."""
+    from trio_binning_amd import kmers
+
+    k, glen = 21, 2_000_000
+    rng = np.random.default_rng(2024)
+    genome = rng.integers(0, 4, glen, dtype=np.uint8)
+
+    def mutate(g, rate, seed):
+        r = np.random.default_rng(seed)
+        h = g.copy()
+        pos = np.nonzero(r.random(g.size) < rate)[0]
+        h[pos] = (h[pos] + r.integers(1, 4, pos.size)) % 4
+        return h
+
+    hap = [mutate(genome, 1 / 500, 1), mutate(genome, 1 / 500, 2)]
+
+    def canon_kmers(codes):
+        c = codes.astype(np.uint64)
+        n = c.size - k + 1
+        fwd = np.zeros(n, dtype=np.uint64)
+        rc = np.zeros(n, dtype=np.uint64)
+        for i in range(k):
+            fwd |= c[i:i + n] << np.uint64(2 * i)
+            rc |= (np.uint64(3) - c[i:i + n]) << np.uint64(2 * (k - 1 - i))
+        return np.minimum(fwd, rc)
+
+    ka, kb = np.unique(canon_kmers(hap[0])), np.unique(canon_kmers(hap[1]))
+    only_a, only_b = np.setdiff1d(ka, kb), np.setdiff1d(kb, ka)
+    assert only_a.size > 50_000 and only_b.size > 50_000
+    a, b = kmers.HashSet.from_keys(only_a, k), kmers.HashSet.from_keys(only_b, k)
+    oa, ob = orc.table_from_keys(only_a, k), orc.table_from_keys(only_b, k)
+
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+    reads = []
+    for i in range(600):
+        h = hap[i % 2]
+        n = int(rng.integers(200, 12_000))
+        p = int(rng.integers(0, glen - n))
+        codes = h[p:p + n].copy()
+        if rng.random() < 0.5:
+            codes = comp[codes[::-1]]
+        err = rng.random(n) < 0.005
+        codes[err] = (codes[err] + rng.integers(1, 4, int(err.sum()))) % 4
+        s = lut[codes].copy()
+        if i % 7 == 0:
+            s[rng.integers(0, n, 3)] = ord("N")
+        reads.append(s.tobytes().decode())
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob)
+    for load in ("0.125", "0.5"):  # roomy and crowded layouts of the same clustered keys
+        os.environ["TBK_TABLE_LOAD"] = load
+        try:
+            cls = kmers.Classifier(a, b)
+        finally:
+            del os.environ["TBK_TABLE_LOAD"]
+        with cls:
+            got = cls.classify_batch(bases, offs)
+        assert np.array_equal(got, want), (load, np.nonzero((got != want).any(axis=1))[0][:10])
+    # reads from haplotype A carry mostly hapA k-mers and vice versa
+    assert (want[0::2, 0] > want[0::2, 1]).mean() > 0.95 and (want[1::2, 1] > want[1::2, 0]).mean() > 0.95
+    assert want.sum() > 100_000
+
+
 def test_device_resident_and_synthetic_generators(gpu, orc):
     """The bench path at test size: keys and reads generated on the GPU, classified from HBM
     through the ticket ring into pinned host memory; checked against the oracle on the same
