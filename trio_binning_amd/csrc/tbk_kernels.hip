@@ -201,45 +201,60 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
     return (m | (m >> 1) | (m >> 2) | (m >> 3)) & 0x1111111111111111ull;
 }
 
-// Continue a lookup past buckets whose half (hapA: half = 0, hapB: half = 8) had no free
-// slot.  `pending` has a bit at lane 0 of every quad that must keep walking; returns the
-// quads (lane-0 bits) that found the key.  Rare: a half is full with probability < 0.1% at
-// the load factors the library builds.
-__device__ __forceinline__ uint64_t probe_walk(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket,
-                                               uint64_t pending, uint32_t sub) {
-    uint64_t found = 0;
-    const uint64_t my_quad_bit = 1ull << (__lane_id() & ~3u);
+// ---- deferred walks --------------------------------------------------------------------
+// A lookup whose home half is full and does not hold the key must walk on to the next bucket
+// (linear probing at line granularity).  Doing that inside the window loop would stall the
+// wave on one dependent HBM access per walk, and on lists shaped like real data (keys in runs
+// of overlapping k-mers that share a minimizer) a noticeable share of halves is full.  So
+// the loop only ENQUEUES such lookups in a per-wave LDS queue; drain_walks resolves them 64
+// at a time, one lane per lookup, so that the latency of a walk step is paid once per 64
+// walks.  hapA priority (c/kmers.c:291-294) is applied there: a queued lookup counts for
+// hapA if the hapA walk finds the key, else for hapB if hapB's home half held it or the
+// hapB walk finds it.
+constexpr int TBK_QCAP = 128;  // queue entries per wave; a window-loop step adds at most 64
+
+// entry: x = key low, y = key high, z = home bucket, w = flags | (read - first read of pass) << 3
+enum { WQ_WALK_A = 1, WQ_WALK_B = 2, WQ_HIT_B = 4 };
+
+// walk from `bucket` through half `half` (0 hapA, 8 hapB) until the key or a non-full half
+__device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket, bool pend) {
+    bool found = false;
     uint32_t guard = 0;
-    while (pending && guard++ < t.n_buckets) {
-        const bool act = (pending & my_quad_bit) != 0;
-        bucket = bucket + 1 == t.n_buckets ? 0 : bucket + 1;
-        ulonglong2 v = make_ulonglong2(0, 0);
-        if (act) v = *reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half + sub * 2);
-        const uint64_t hit = quad_any(ballot(act && (v.x == key || v.y == key)));
-        const uint64_t fre = quad_any(ballot(act && (v.x == TBK_EMPTY || v.y == TBK_EMPTY)));
-        found |= hit;
-        pending &= ~(hit | fre);
+    while (ballot(pend) != 0 && guard++ < t.n_buckets) {
+        if (pend) {
+            bucket = bucket + 1 == t.n_buckets ? 0 : bucket + 1;
+            const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
+            const ulonglong2 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3];
+            const bool hit = v0.x == key || v0.y == key || v1.x == key || v1.y == key || v2.x == key || v2.y == key ||
+                             v3.x == key || v3.y == key;
+            found = found || hit;
+            pend = !hit && v3.y != TBK_EMPTY;  // occupied slots form a prefix: last slot free = half not full
+        }
     }
     return found;
 }
 
-// Exact resolution of one sub-step (16 windows, one per quad), taken only when the fast
-// path cannot decide: some window's home half is full (the lookup may have to walk on), or
-// hapA and hapB both report a hit (priority must be applied per window).  Returns per-quad
-// results as bits at each quad's lane 0.
-__device__ __forceinline__ void probe_exact(const TbkPairView t, ulonglong2 va, ulonglong2 vb, uint64_t key,
-                                            uint32_t bucket, uint32_t sub, uint64_t &out_a, uint64_t &out_b) {
-    const uint64_t okm = quad_any(ballot(key != TBK_NOKEY));
-    uint64_t hit_a = quad_any(ballot(va.x == key || va.y == key)) & okm;
-    const uint64_t fre_a = quad_any(ballot(va.x == TBK_EMPTY || va.y == TBK_EMPTY));
-    uint64_t hit_b = quad_any(ballot(vb.x == key || vb.y == key)) & okm;
-    const uint64_t fre_b = quad_any(ballot(vb.x == TBK_EMPTY || vb.y == TBK_EMPTY));
-    const uint64_t more_a = okm & ~hit_a & ~fre_a;
-    if (more_a) hit_a |= probe_walk(t, 0, key, bucket, more_a, sub);
-    const uint64_t more_b = okm & ~hit_a & ~hit_b & ~fre_b;
-    if (more_b) hit_b |= probe_walk(t, 8, key, bucket, more_b, sub);
-    out_a = hit_a;
-    out_b = hit_b & ~hit_a;  // hapA wins (c/kmers.c:291-294)
+template <bool MULTI>
+__device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, uint32_t qn, uint64_t r_first,
+                                            uint32_t lane, uint32_t &acc_a, uint32_t &acc_b) {
+    for (uint32_t base = 0; base < qn; base += 64) {
+        const bool act = base + lane < qn;
+        uint4 it = make_uint4(0, 0, 0, 0);
+        if (act) it = q[base + lane];
+        const uint64_t key = (uint64_t)it.x | ((uint64_t)it.y << 32);
+        const bool in_a = walk_one(p.t, 0, key, it.z, act && (it.w & WQ_WALK_A));
+        const bool walked_b = walk_one(p.t, 8, key, it.z, act && !in_a && !(it.w & WQ_HIT_B) && (it.w & WQ_WALK_B));
+        const bool in_b = (it.w & WQ_HIT_B) || walked_b;
+        const bool count_a = act && in_a, count_b = act && !in_a && in_b;
+        if (!MULTI) {
+            acc_a += (uint32_t)__popcll(ballot(count_a));
+            acc_b += (uint32_t)__popcll(ballot(count_b));
+        } else {
+            const uint64_t rid = r_first + (it.w >> 3);
+            if (count_a) atomicAdd(&p.counts[2 * rid], 1);
+            if (count_b) atomicAdd(&p.counts[2 * rid + 1], 1);
+        }
+    }
 }
 
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
@@ -247,7 +262,8 @@ __device__ __forceinline__ void probe_exact(const TbkPairView t, ulonglong2 va, 
 template <int W, bool M64, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
-                                           const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane) {
+                                           const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
+                                           uint4 *walkq) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
@@ -337,6 +353,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 #pragma unroll
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
     uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
+    uint32_t qn = 0;                 // queued walks (wave-uniform)
 
 #pragma unroll TBK_UNROLL
     for (int j = 0; j < TBK_WPL; j++) {
@@ -416,11 +433,31 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         }
         full_any &= 0x8888888888888888ull;
         if (full_any != 0 || (any_a != 0 && any_b != 0)) {
+            // Careful path: per-window (= per-quad) resolution.  Everything is brought to the
+            // quad's lane-0 bit.  Hits in the home line are final for hapA; a hapB hit is final
+            // unless hapA still has to walk.  Lookups that must walk are queued.
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const uint64_t full = ballot((va[s].y & vb[s].y) != TBK_EMPTY) & 0x8888888888888888ull;
-                if (full != 0 || (hit_a[s] != 0 && hit_b[s] != 0))
-                    probe_exact(p.t, va[s], vb[s], kk[s], bk[s], sub, hit_a[s], hit_b[s]);  // results at quad lane 0
+                const uint64_t full_a = (ballot(va[s].y != TBK_EMPTY) >> 3) & 0x1111111111111111ull;  // lane 3 holds the last slot
+                const uint64_t full_b = (ballot(vb[s].y != TBK_EMPTY) >> 3) & 0x1111111111111111ull;
+                if ((full_a | full_b) == 0 && (hit_a[s] == 0 || hit_b[s] == 0)) continue;  // raw ballots are already exact
+                const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
+                const uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
+                const uint64_t walk_a = valid & full_a & ~ha;
+                const uint64_t walk_b = valid & full_b & ~hb & ~ha;
+                const uint64_t queued = walk_a | walk_b;
+                hit_a[s] = ha;
+                hit_b[s] = hb & ~ha & ~queued;  // a queued window's hapB hit travels with it
+                if (queued) {
+                    const uint64_t me = 1ull << lane;
+                    if (queued & me) {
+                        const uint32_t slot = qn + (uint32_t)__popcll(queued & (me - 1));
+                        const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0) | ((hb & me) ? WQ_HIT_B : 0);
+                        const uint32_t rrel = MULTI ? (uint32_t)(ridq[s] - (uint32_t)r_first) : 0u;
+                        walkq[slot] = make_uint4(klo[s], khi[s], bk[s], flags | (rrel << 3));
+                    }
+                    qn += (uint32_t)__popcll(queued);
+                }
             }
         }
         if ((any_a | any_b | full_any) != 0) {
@@ -439,6 +476,17 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 }
             }
         }
+        if (qn > TBK_QCAP - 64) {  // make room for the next step's worst case
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qn = 0;
+        }
+    }
+    if (qn) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (!MULTI) {
         if (lane == 0) {
@@ -467,6 +515,7 @@ tbk_probe_kernel(const ProbeArgs p) {
     // itself, so wave-scope ordering is enough and the waves of a block never wait for each
     // other (no s_barrier in this kernel).
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
+    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t passes_per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
@@ -484,8 +533,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
-        else probe_pass<W, M64, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane);
+        if (last_pos < r_end) probe_pass<W, M64, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
+        else probe_pass<W, M64, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
     }
 }
 
