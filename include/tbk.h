@@ -22,6 +22,11 @@
  *     its docstring restricts reads to [ACGT], kmers.py:134-135).
  *   - Everything that computes on the GPU fails with TBK_ERR_NO_DEVICE when no MI355X is
  *     visible.  There is no CPU fallback in this library.
+ *   - Threading: a tbk_table is read-only after creation and may be shared by threads; a
+ *     tbk_classifier (its streams, ticket ring and scratch) belongs to one thread at a time,
+ *     like the reference's per-call scratch buffers (c/kmers.c:278-279).  tbk_last_error() is
+ *     per thread.  Calls block the calling thread only where stated; the Python bindings
+ *     release the GIL for the duration of every call (ctypes), as the reference's do.
  */
 #ifndef TBK_H
 #define TBK_H
@@ -135,7 +140,8 @@ void *tbk_host_alloc(size_t bytes);  /* pinned host memory (hipHostMalloc) */
 void tbk_host_free(void *p);
 
 /* Device-resident form (inputs already in HBM: bench.py's timed region, and callers that
- * produce reads on the GPU).  Asynchronous on the classifier's compute stream;
+ * produce reads on the GPU).  d_bases must be 16-byte aligned, d_offsets[0] must be 0 and
+ * d_offsets[n_reads] must equal total_bases.  Asynchronous on the classifier's compute stream;
  * tbk_classifier_sync waits for it. */
 int tbk_classify_device(tbk_classifier *c, const void *d_bases, const void *d_offsets,
                         uint64_t n_reads, uint64_t total_bases, void *d_counts);
