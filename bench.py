@@ -225,7 +225,12 @@ def main():
     bases_all = dist.reduce(args.steps * total, "SUM")
     value = bases_all / elapsed_max / 1e9
 
-    bucket_select = ("minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])) if stats["minimizer_w"] else "plain hash"
+    if not stats["minimizer_w"]:
+        bucket_select = "plain hash"
+    elif stats["sampling_t"]:
+        bucket_select = "mod-sampling w=%d m=%d t=%d" % (stats["minimizer_w"], stats["minimizer_m"], stats["sampling_t"])
+    else:
+        bucket_select = "minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])
     # ---- roofline of the probe kernel (rank 0's device) -----------------------------------------
     # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
     # hapB slot when hapA missed.  Per launch: windows = R * (L - k + 1).

@@ -122,6 +122,10 @@ int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t
  * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
  * Env TBK_MINIMIZER_W (default 6) and TBK_TABLE_LOAD tune it; neither changes any result. */
 int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset);
+/* 0: the span's m-mer with the smallest hash picks the bucket (default); t > 0: mod-sampling
+ * over the span's t-mers (fewer bucket switches between consecutive windows, more arithmetic
+ * per window; env TBK_MOD_SAMPLING=1). */
+int tbk_classifier_sampling_t(const tbk_classifier *c);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

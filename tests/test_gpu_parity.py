@@ -117,14 +117,16 @@ def test_random_vs_oracle(gpu, orc, tmp_path, k):
     assert want.sum() > 0
 
 
+@pytest.mark.parametrize("mod_sampling", [1, 0])
 @pytest.mark.parametrize("w", [0, 1, 2, 3, 4, 5, 6, 7, 8])
-def test_every_bucket_selection_mode(gpu, orc, tmp_path, w, monkeypatch):
-    """Bucket selection (plain hash, minimizer spans of 1..8 m-mers) is a layout choice:
-    counts must not depend on it.  k = 21 / 22 / 31 / 32 exercise both m-mer lengths and
-    non-zero span offsets."""
+def test_every_bucket_selection_mode(gpu, orc, tmp_path, w, mod_sampling, monkeypatch):
+    """Bucket selection (plain hash; spans of 1..8 m-mers sampled by mod-sampling or by the
+    random-minimizer rule) is a layout choice: counts must not depend on it.  k = 21 / 22 /
+    31 / 32 exercise both m-mer lengths and non-zero span offsets."""
     from trio_binning_amd import kmers
 
     monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+    monkeypatch.setenv("TBK_MOD_SAMPLING", str(mod_sampling))
     rng = np.random.default_rng(77 + w)
     for k in (21, 22, 31, 32):
         la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(300)]
@@ -135,6 +137,8 @@ def test_every_bucket_selection_mode(gpu, orc, tmp_path, w, monkeypatch):
         oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
         a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
         reads = _rand_reads(rng, 200, 2500, la + lb, k, p_plant=0.9) + ["A" * 100, "T" * 100, "AC" * 60]
+        # tie-heavy reads: short-period repeats and reverse-complement palindromes of list k-mers
+        reads += [("ACGTTGCA" * 20)[:150], "ATAT" * 30 + la[0] + "ATAT" * 30, la[1] + _rc(la[1]) + lb[1] + _rc(lb[1]), "G" * 50 + lb[0] + "C" * 50]
         bases, offs = _pack(reads)
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
@@ -142,9 +146,14 @@ def test_every_bucket_selection_mode(gpu, orc, tmp_path, w, monkeypatch):
             if st["minimizer_w"]:
                 span = st["minimizer_m"] + st["minimizer_w"] - 1
                 assert span <= k and (k - span) % 2 == 0 and st["span_offset"] == (k - span) // 2
+            t_expect = st["minimizer_m"] - st["minimizer_w"]
+            if not mod_sampling or st["minimizer_w"] < 2 or t_expect < 8:
+                assert st["sampling_t"] == 0
+            else:
+                assert st["sampling_t"] == t_expect
             got = cls.classify_batch(bases, offs)
         want = orc.count_batch(bases, offs, oa, ob)
-        assert np.array_equal(got, want), (k, w, np.nonzero((got != want).any(axis=1))[0][:10])
+        assert np.array_equal(got, want), (k, w, st, np.nonzero((got != want).any(axis=1))[0][:10])
         assert want.sum() > 100
 
 
@@ -155,6 +164,7 @@ def test_long_mmer_bucket_selection(gpu, orc, tmp_path, m, monkeypatch):
     from trio_binning_amd import kmers
 
     monkeypatch.setenv("TBK_MINIMIZER_M", str(m))
+    monkeypatch.setenv("TBK_MOD_SAMPLING", str(m % 2))  # both sampling rules on the 64-bit m-mer path
     rng = np.random.default_rng(300 + m)
     for k, w in ((27, 6), (31, 6), (32, 5), (31, 3)):
         if m + 1 > k:

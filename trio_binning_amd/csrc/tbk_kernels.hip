@@ -32,23 +32,30 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;  // TBK_EMPTY / TBK_NOKEY: never a canonical key, never stored
-        uint32_t b = tbk_bucket_of(key, mz, n_buckets);
-        bool done = false;
-        for (uint32_t walked = 0; walked < n_buckets && !done; walked++) {
-            unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
-            for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
-                unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == key) { done = true; break; }
-                if (cur == TBK_EMPTY) {
-                    unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
-                    if (old == TBK_EMPTY) { mine++; done = true; }
-                    else if (old == key) { done = true; }
-                    // else: somebody else's key took the slot; keep scanning
+        // the buckets a lookup of this key may select: one, except when mod-sampling finds the
+        // smallest t-mer rank at several positions of the key (then one per tied position)
+        uint32_t cand[16];
+        int n_cand = tbk_bucket_candidates(key, mz, n_buckets, cand);
+        if (n_cand < 0) { cand[0] = tbk_bucket_of(key, mz, n_buckets); n_cand = 1; }
+        for (int c = 0; c < n_cand; c++) {
+            uint32_t b = cand[c];
+            bool done = false;
+            for (uint32_t walked = 0; walked < n_buckets && !done; walked++) {
+                unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
+                for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
+                    unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cur == key) { done = true; break; }
+                    if (cur == TBK_EMPTY) {
+                        unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
+                        if (old == TBK_EMPTY) { if (c == 0) mine++; done = true; }
+                        else if (old == key) { done = true; }
+                        // else: somebody else's key took the slot; keep scanning
+                    }
                 }
+                if (!done) { b++; if (b == n_buckets) b = 0; }
             }
-            if (!done) { b++; if (b == n_buckets) b = 0; }
+            if (!done) atomicExch(failed, 1);
         }
-        if (!done) atomicExch(failed, 1);
     }
     if (mine) atomicAdd(n_distinct, mine);
 }
@@ -112,6 +119,9 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 
 #ifndef TBK_UNROLL
 #define TBK_UNROLL 2      // j-loop unroll of the probe pass
+#endif
+#ifndef TBK_SAMP_UNROLL
+#define TBK_SAMP_UNROLL 4 // j-loop unroll of the mod-sampling variants
 #endif
 #ifndef TBK_MIN_WAVES
 #define TBK_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
@@ -259,7 +269,7 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
 
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
 // window).  MULTI = the pass touches more than one read.
-template <int W, bool M64, bool MULTI>
+template <int W, bool M64, bool SAMP, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
@@ -292,15 +302,19 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     // W-deep shift register.  The newest m-mer (i = W-1) is bits [2(o+W-1), +2m) of rolled S;
     // its reverse complement sits at base o of the reverse-complement k-mer (the span is
     // central), i.e. bits [64+2o, +2m) of rolled R.
-    constexpr int NW = W > 0 ? W : 1;
-    // m-mers are 32-bit values for m <= 16 (M64 = false) and 64-bit ones above; both are slices
-    // of the same two 64-bit words, (s1:s0) forward and (t3:t2) reverse complement, because an
-    // m-mer of the span lies inside the window's k-mer.  The shift register holds the 32-bit
-    // order hash (M64 = false) or (order << 32 | place) (M64 = true, see tbk_mmer_hash64).
-    using win_t = typename std::conditional<M64, uint64_t, uint32_t>::type;
+    // Two sampling schemes share the machinery (tbk_common.h "bucket selection"):
+    //   SAMP = false  random minimizer: win[] holds the hashes of the span's W m-mers;
+    //   SAMP = true   mod-sampling: win[] holds (hash & ~15) | position of the span's 2W
+    //                 t-mers (t = m - W, always <= 16 bases), position 0 = first of the span.
+    // m-mers are 32-bit values for m <= 16 (M64 = false) and 64-bit ones above.  All slices
+    // come from the same two 64-bit words, (s1:s0) forward and (t3:t2) reverse complement,
+    // because every m-mer / t-mer of the span lies inside the window's k-mer; the piece at
+    // forward base offset a sits at reverse-complement base offset k - len - a.
+    constexpr int NW = W > 0 ? (SAMP ? 2 * W : W) : 1;
+    using win_t = typename std::conditional<(M64 && !SAMP), uint64_t, uint32_t>::type;
     win_t win[NW];
     uint64_t mmask = 0;
-    uint32_t fsh_new = 0, bsh_new = 0;
+    uint32_t tmask = 0, fsh_new = 0, bsh_new = 0, span_o = 0;
     auto mmer_order = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh) -> win_t {
         if (M64) {
             const uint64_t x = (fwd64 >> fsh) & mmask, y = (rc64 >> bsh) & mmask;
@@ -309,16 +323,32 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         const uint32_t x = (uint32_t)(fwd64 >> fsh) & (uint32_t)mmask, y = (uint32_t)(rc64 >> bsh) & (uint32_t)mmask;
         return (win_t)tbk_mmer_hash(x < y ? x : y);
     };
+    auto tmer_rank = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh, uint32_t pos) -> uint32_t {
+        const uint32_t x = (uint32_t)(fwd64 >> fsh) & tmask, y = (uint32_t)(rc64 >> bsh) & tmask;
+        return (tbk_mmer_hash(x < y ? x : y) & ~15u) | pos;
+    };
     if (W > 0) {
         const int m = p.t.mz.m, o = p.t.mz.o;
+        span_o = (uint32_t)o;
         mmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
         const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
-        win[0] = (win_t)~0ull;
+        if (SAMP) {
+            const int t = p.t.mz.t;
+            tmask = t >= 16 ? 0xFFFFFFFFu : ((1u << (2 * t)) - 1u);
+            win[0] = (win_t)0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i + 1 < W; i++)  // prologue: the W-1 m-mers window 0 shares with window -1
-            win[i + 1] = mmer_order(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + W - 1 - i)));
-        fsh_new = (uint32_t)(2 * (o + W - 1));
-        bsh_new = (uint32_t)(2 * o);
+            for (int i = 0; i + 1 < NW; i++)  // prologue: window 0's first 2W-1 t-mers; tag = index of the t-mer in the lane's stream, mod 16
+                win[i + 1] = (win_t)tmer_rank(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + NW - 1 - i)), (uint32_t)i);
+            fsh_new = (uint32_t)(2 * (o + NW - 1));
+            bsh_new = (uint32_t)(2 * o);
+        } else {
+            win[0] = (win_t)~0ull;
+#pragma unroll
+            for (int i = 0; i + 1 < W; i++)  // prologue: the W-1 m-mers window 0 shares with window -1
+                win[i + 1] = mmer_order(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + W - 1 - i)));
+            fsh_new = (uint32_t)(2 * (o + W - 1));
+            bsh_new = (uint32_t)(2 * o);
+        }
     }
 
     // ---- read bookkeeping ------------------------------------------------------------------
@@ -349,13 +379,16 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 
     // the line each quad slot holds from the previous window of the same lane
     uint32_t held[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint64_t held_full[4] = {0, 0, 0, 0};  // lane-3 bits of the quads whose held line has a full half (wave-uniform)
     ulonglong2 va[4], vb[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
     uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
     uint32_t qn = 0;                 // queued walks (wave-uniform)
 
-#pragma unroll TBK_UNROLL
+    // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
+    constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
+#pragma unroll kUnroll
     for (int j = 0; j < TBK_WPL; j++) {
         // ---- this lane's window j ---------------------------------------------------
         const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
@@ -372,8 +405,30 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         bool ok = (bad_lo & badk) == 0 && (uint32_t)(j + k) <= rel_end;
         if (MULTI) ok = ok && rid < p.n_reads;
         uint32_t hsel;
-        if (W > 0) {
-            // shift in the newest m-mer of this window's span, take the minimum
+        if (W > 0 && SAMP) {
+            // mod-sampling: shift in the span's newest t-mer, find the smallest rank (any of the
+            // tied ones will do: the table holds the key under each, see tbk_common.h), turn its
+            // stream index into a position inside this window's span, sample the m-mer at
+            // position mod W
+            const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
+#pragma unroll
+            for (int i = 0; i + 1 < NW; i++) win[i] = win[i + 1];
+            win[NW - 1] = (win_t)tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(j + NW - 1) & 15u);
+            uint32_t best = (uint32_t)win[0];
+#pragma unroll
+            for (int i = 1; i < NW; i++) best = (uint32_t)win[i] < best ? (uint32_t)win[i] : best;
+            const uint32_t x = (best - (uint32_t)j) & 15u;  // 0 .. 2W-1
+            const uint32_t pos = x >= (uint32_t)W ? x - (uint32_t)W : x;
+            const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
+            if (M64) {
+                const uint64_t mx = (fs >> fsh) & mmask, my = (bs >> bsh) & mmask;
+                hsel = (uint32_t)tbk_mmer_hash64(mx < my ? mx : my);
+            } else {
+                const uint32_t mx = (uint32_t)(fs >> fsh) & (uint32_t)mmask, my = (uint32_t)(bs >> bsh) & (uint32_t)mmask;
+                hsel = tbk_mmer_hash(mx < my ? mx : my);
+            }
+        } else if (W > 0) {
+            // random minimizer: shift in the newest m-mer of this window's span, take the minimum
 #pragma unroll
             for (int i = 0; i + 1 < W; i++) win[i] = win[i + 1];
             win[W - 1] = mmer_order(((uint64_t)s1 << 32) | s0, ((uint64_t)t3 << 32) | t2, fsh_new, bsh_new);
@@ -405,6 +460,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (MULTI) ridq[S] = quad_bcast<S>(my_rid);
         TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
 #undef TBK_BCAST
+        uint32_t held_prev[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) held_prev[s] = held[s];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             // fetch only when this window's line differs from the one the slot already holds
@@ -415,6 +473,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
                 held[s] = bk[s];
             }
+        }
+        // which quads reloaded, and is a half of the new line full?  (a half is full exactly when
+        // its last slot, held by quad lane 3, is occupied); kept per slot until the next reload
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint64_t fresh = ballot(bk[s] != held_prev[s]);
+            if (fresh) held_full[s] = (held_full[s] & ~fresh) | (ballot((va[s].y & vb[s].y) != TBK_EMPTY) & fresh & 0x8888888888888888ull);
         }
         // Fast path.  A key is stored at most once per table, so the raw ballots count
         // windows.  A half is full exactly when its last slot (held by quad lane 3) is
@@ -427,11 +492,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             kk[s] = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
             hit_a[s] = ballot(va[s].x == kk[s] || va[s].y == kk[s]);
             hit_b[s] = ballot(vb[s].x == kk[s] || vb[s].y == kk[s]);
-            full_any |= ballot((va[s].y & vb[s].y) != TBK_EMPTY);
+            full_any |= held_full[s];
             any_a |= hit_a[s];
             any_b |= hit_b[s];
         }
-        full_any &= 0x8888888888888888ull;
         if (full_any != 0 || (any_a != 0 && any_b != 0)) {
             // Careful path: per-window (= per-quad) resolution.  Everything is brought to the
             // quad's lane-0 bit.  Hits in the home line are final for hapA; a hapB hit is final
@@ -505,7 +569,7 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     if (pass < n_passes) pass_read[pass] = (uint32_t)find_read(offsets, n_reads, pass * TBK_PASS);
 }
 
-template <int W, bool M64>
+template <int W, bool M64, bool SAMP>
 // 4 waves per SIMD (<= 128 VGPRs).  Measured same-box A/B (tools/gpu_ab.sh): asking for 5 or 6
 // waves makes the allocator spill and loses 12-50 %; a third pass variant specialised for
 // two-read passes bloats the code and loses 8-14 % even on single-read passes.
@@ -533,8 +597,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
-        else probe_pass<W, M64, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
+        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
+        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
     }
 }
 
@@ -573,22 +637,20 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
     const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
-    // 32-bit m-mer path for m <= 16 (every W), 64-bit path for longer m-mers
-    if (t.mz.m <= 16) {
-        switch (t.mz.w) {
-#define TBK_W(N) case N: hipLaunchKernelGGL((tbk_probe_kernel<N, false>), grid, block, 0, stream, p); break;
-            TBK_W(0) TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
-#undef TBK_W
-            default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (t.mz.w) {
-#define TBK_W(N) case N: hipLaunchKernelGGL((tbk_probe_kernel<N, true>), grid, block, 0, stream, p); break;
-            TBK_W(1) TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
-#undef TBK_W
-            default: return hipErrorInvalidValue;
-        }
+    // kernel variant: W m-mers per span; 32-bit (m <= 16) or 64-bit m-mers; random-minimizer or
+    // mod-sampling selection
+    const bool m64 = t.mz.m > 16, samp = t.mz.t > 0;
+#define TBK_LAUNCH(N, M, S) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S>), grid, block, 0, stream, p)
+#define TBK_W(N) case N: if (samp) { if (m64) TBK_LAUNCH(N, true, true); else TBK_LAUNCH(N, false, true); } \
+                         else { if (m64) TBK_LAUNCH(N, true, false); else TBK_LAUNCH(N, false, false); } break;
+    switch (t.mz.w) {
+        case 0: TBK_LAUNCH(0, false, false); break;
+        case 1: if (m64) TBK_LAUNCH(1, true, false); else TBK_LAUNCH(1, false, false); break;
+        TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
+        default: return hipErrorInvalidValue;
     }
+#undef TBK_W
+#undef TBK_LAUNCH
     return hipGetLastError();
 }
 

@@ -244,7 +244,8 @@ class Classifier:
         w, m, o = C.c_int(), C.c_int(), C.c_int()
         check(lib.tbk_classifier_layout(self._h, C.byref(w), C.byref(m), C.byref(o)))
         return {"distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
-                "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value}
+                "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
+                "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
 
     def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
