@@ -379,7 +379,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 
     // the line each quad slot holds from the previous window of the same lane
     uint32_t held[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    uint64_t held_full[4] = {0, 0, 0, 0};  // lane-3 bits of the quads whose held line has a full half (wave-uniform)
     ulonglong2 va[4], vb[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
@@ -460,9 +459,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (MULTI) ridq[S] = quad_bcast<S>(my_rid);
         TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
 #undef TBK_BCAST
-        uint32_t held_prev[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) held_prev[s] = held[s];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             // fetch only when this window's line differs from the one the slot already holds
@@ -474,13 +470,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 held[s] = bk[s];
             }
         }
-        // which quads reloaded, and is a half of the new line full?  (a half is full exactly when
-        // its last slot, held by quad lane 3, is occupied); kept per slot until the next reload
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const uint64_t fresh = ballot(bk[s] != held_prev[s]);
-            if (fresh) held_full[s] = (held_full[s] & ~fresh) | (ballot((va[s].y & vb[s].y) != TBK_EMPTY) & fresh & 0x8888888888888888ull);
-        }
+
         // Fast path.  A key is stored at most once per table, so the raw ballots count
         // windows.  A half is full exactly when its last slot (held by quad lane 3) is
         // occupied; only then may a miss have to walk on.  hapA/hapB priority only matters
@@ -492,10 +482,11 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             kk[s] = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
             hit_a[s] = ballot(va[s].x == kk[s] || va[s].y == kk[s]);
             hit_b[s] = ballot(vb[s].x == kk[s] || vb[s].y == kk[s]);
-            full_any |= held_full[s];
+            full_any |= ballot((va[s].y & vb[s].y) != TBK_EMPTY);
             any_a |= hit_a[s];
             any_b |= hit_b[s];
         }
+        full_any &= 0x8888888888888888ull;  // a half is full exactly when its last slot (quad lane 3) is occupied
         if (full_any != 0 || (any_a != 0 && any_b != 0)) {
             // Careful path: per-window (= per-quad) resolution.  Everything is brought to the
             // quad's lane-0 bit.  Hits in the home line are final for hapA; a hapB hit is final
