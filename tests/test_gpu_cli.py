@@ -85,3 +85,78 @@ def test_small_batches_keep_input_order(gpu, capsys, tmp_path, monkeypatch):
     monkeypatch.setattr(cbk, "_BATCH_BASES", 300)
     monkeypatch.setattr(cbk, "_BATCH_READS", 7)
     test_differential_cli(gpu, capsys, tmp_path, 21)
+
+
+def test_synthetic_prefix_through_the_file_path(gpu, capsys, tmp_path):
+    """a prefix of the synthetic bench workload goes through files — text k-mer lists,
+    a FASTQ of GPU-generated reads — and the CLI must report exactly the counts that the
+    device-resident path (bench.py's path) gets on the same bytes."""
+    import ctypes as C
+
+    import numpy as np
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    dev, k, n_list, R, L = 0, 21, 20000, 256, 3000
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    d_keys = dalloc(2 * n_list * 8)
+    check(lib.tbk_synth_keys_device(dev, 0x5EED0001, 0, 2 * n_list, k, C.c_void_p(d_keys)))
+    h_keys = np.empty(2 * n_list, dtype=np.uint64)
+    check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data, C.c_void_p(d_keys), h_keys.nbytes))
+    a = kmers.HashSet.from_device_keys(d_keys, n_list, k)
+    b = kmers.HashSet.from_device_keys(d_keys + n_list * 8, n_list, k)
+    total = R * L
+    d_bases, d_offs, d_counts = dalloc(total + 32), dalloc((R + 1) * 8), dalloc(R * 8)
+    check(lib.tbk_synth_reads_device(dev, 0x5EED0002, 0, R, L, 0x5EED0001, n_list, n_list, k, 30, 3, C.c_void_p(d_bases), C.c_void_p(d_offs)))
+    with kmers.Classifier(a, b) as cls:
+        cls.classify_device(d_bases, d_offs, R, total, d_counts)
+        cls.sync()
+    counts = np.zeros((R, 2), dtype=np.int32)
+    check(lib.tbk_memcpy_d2h(dev, counts.ctypes.data, C.c_void_p(d_counts), counts.nbytes))
+    bases = np.empty(total, dtype=np.uint8)
+    check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_bases), total))
+    for p in (d_keys, d_bases, d_offs, d_counts):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+
+    def decode(keys):
+        lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+        out = np.empty((keys.size, k + 1), dtype=np.uint8)
+        for i in range(k):
+            out[:, i] = lut[((keys >> np.uint64(2 * i)) & np.uint64(3)).astype(np.int64)]
+        out[:, k] = 10
+        return out.tobytes()
+
+    (tmp_path / "hapA.txt").write_bytes(decode(h_keys[:n_list]))
+    (tmp_path / "hapB.txt").write_bytes(decode(h_keys[n_list:]))
+    with open(tmp_path / "reads.fastq", "wb") as fh:
+        for r in range(R):
+            fh.write(b"@s%d\n" % r + bases[r * L:(r + 1) * L].tobytes() + b"\n+\n" + b"I" * L + b"\n")
+    od = tmp_path / "out"
+    od.mkdir()
+    out = _run([str(tmp_path / "reads.fastq"), str(tmp_path / "hapA.txt"), str(tmp_path / "hapB.txt"),
+                "--haplotype-a-out-prefix", str(od / "hapA"), "--haplotype-b-out-prefix", str(od / "hapB"),
+                "--unclassified-out-prefix", str(od / "unc")], capsys)
+    lines = out.splitlines()
+    assert len(lines) == R
+    sa, sb, bins = kmers.score_and_bin(counts, n_list, n_list)
+    for r, line in enumerate(lines):
+        name, bin_, x, y = line.split("\t")
+        assert (name, bin_, float(x), float(y)) == (f"s{r}", chr(bins[r]), float(sa[r]), float(sb[r]))
+    n_in_bins = sum(len(list(readfq_names(od / f))) for f in ("hapA.fastq.gz", "hapB.fastq.gz", "unc.fastq.gz"))
+    assert n_in_bins == R and counts.sum() > 20 * R
+
+
+def readfq_names(path):
+    import gzip
+
+    from trio_binning_amd.seq import readfq
+
+    with gzip.open(path, "rt") as fh:
+        for rec in readfq(fh):
+            yield rec.name
