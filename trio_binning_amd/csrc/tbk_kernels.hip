@@ -480,8 +480,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             kk[s] = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
-            hit_a[s] = ballot(va[s].x == kk[s] || va[s].y == kk[s]);
-            hit_b[s] = ballot(vb[s].x == kk[s] || vb[s].y == kk[s]);
+            // one ballot per compare, OR-ed as scalars (a ballot of `a || b` costs two extra VALU
+            // instructions: the i1 is materialised and compared again)
+            hit_a[s] = ballot(va[s].x == kk[s]) | ballot(va[s].y == kk[s]);
+            hit_b[s] = ballot(vb[s].x == kk[s]) | ballot(vb[s].y == kk[s]);
             full_any |= ballot((va[s].y & vb[s].y) != TBK_EMPTY);
             any_a |= hit_a[s];
             any_b |= hit_b[s];
