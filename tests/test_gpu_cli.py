@@ -78,6 +78,24 @@ def test_differential_cli(gpu, capsys, tmp_path, k):
         assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
 
 
+def test_stats_line_goes_to_stderr_only(gpu, capsys, tmp_path, monkeypatch):
+    import json
+
+    monkeypatch.setenv("TBK_STATS", "1")
+    g = load_golden("toy_cli.json")["test.fastq"]
+    from trio_binning_amd.classify_by_kmers import main
+
+    with patch("sys.argv", ["classify-by-kmers", os.path.join(DATA, "test.fastq"), os.path.join(DATA, "hapA.txt"),
+                            os.path.join(DATA, "hapB.txt"), "--haplotype-a-out-prefix", str(tmp_path / "a"),
+                            "--haplotype-b-out-prefix", str(tmp_path / "b"), "--unclassified-out-prefix", str(tmp_path / "u")]):
+        main()
+    out, err = capsys.readouterr()
+    assert out == g["stdout"]
+    line = [l for l in err.splitlines() if l.startswith("tbk-stats ")][-1]
+    st = json.loads(line[len("tbk-stats "):])
+    assert st["reads"] == 4 and st["bases"] == 220 and st["batches"] == 1
+
+
 def test_small_batches_keep_input_order(gpu, capsys, tmp_path, monkeypatch):
     """Force many tiny batches through the streaming ring: outputs identical."""
     import trio_binning_amd.classify_by_kmers as cbk

@@ -529,3 +529,39 @@ def test_score_and_bin_on_gpu_counts(gpu, orc):
     osa, osb, obins = orc.score_and_bin(counts, 4, 3)
     assert sa.tolist() == osa.tolist() and sb.tolist() == osb.tolist() and bins.decode() == obins
     assert bins == b"ABUBB"
+
+
+def test_abi_misuse_is_reported_not_crashed(gpu, tmp_path):
+    """Error convention of the boundary: bad arguments come back as status + message
+    (ValueError / TbkError in Python), never as a crash or a silent wrong answer."""
+    import ctypes as C
+
+    from trio_binning_amd import _lib, kmers
+    from trio_binning_amd._lib import lib
+
+    a = kmers.HashSet.from_file(os.path.join(DATA, "hapA.txt"))
+    b = kmers.HashSet.from_file(os.path.join(DATA, "hapB.txt"))
+    with kmers.Classifier(a, b) as cls:
+        bases = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGT", dtype=np.uint8)
+        counts = np.zeros((1, 2), dtype=np.int32)
+        tk = C.c_uint64()
+        bad_first = np.array([3, 28], dtype=np.uint64)
+        assert lib.tbk_stream_submit(cls._h, bases.ctypes.data, bad_first.ctypes.data, 1, counts.ctypes.data, C.byref(tk)) == _lib.TBK_ERR_INVALID
+        assert "offsets[0]" in _lib.last_error()
+        decreasing = np.array([0, 20, 10], dtype=np.uint64)
+        c2 = np.zeros((2, 2), dtype=np.int32)
+        assert lib.tbk_stream_submit(cls._h, bases.ctypes.data, decreasing.ctypes.data, 2, c2.ctypes.data, C.byref(tk)) == _lib.TBK_ERR_INVALID
+        assert lib.tbk_stream_submit(cls._h, None, None, 1, counts.ctypes.data, C.byref(tk)) == _lib.TBK_ERR_INVALID
+        assert lib.tbk_stream_wait(cls._h, 12345) == _lib.TBK_ERR_STATE
+        assert lib.tbk_classify_device(cls._h, C.c_void_p(8), C.c_void_p(16), 1, 10, C.c_void_p(16)) == _lib.TBK_ERR_INVALID  # misaligned
+        # a good call still works afterwards
+        assert cls.classify_reads(["ACCTCTAAGAAGCTTTGAAAA"]).tolist() == [[1, 0]]
+    h = C.c_void_p()
+    assert lib.tbk_table_create_from_keys(None, 5, 21, 0, C.byref(h)) == _lib.TBK_ERR_INVALID
+    keys = np.arange(4, dtype=np.uint64)
+    assert lib.tbk_table_create_from_keys(keys.ctypes.data, 4, 33, 0, C.byref(h)) == _lib.TBK_ERR_INVALID
+    assert lib.tbk_table_create_from_keys(keys.ctypes.data, 0, 21, 0, C.byref(h)) == _lib.TBK_ERR_FORMAT
+    assert lib.tbk_table_create_from_keys(keys.ctypes.data, 4, 21, 99, C.byref(h)) == _lib.TBK_ERR_INVALID  # no such device
+    assert lib.tbk_classifier_create(None, None, C.byref(h)) == _lib.TBK_ERR_INVALID
+    lib.tbk_table_destroy(None)
+    lib.tbk_classifier_destroy(None)

@@ -76,7 +76,12 @@ def main():
 
     num_a = kmers.get_number_kmers_in_set(args.haplotype_a_kmers)
     num_b = kmers.get_number_kmers_in_set(args.haplotype_b_kmers)
+    import time
+
+    stats = {"reads": 0, "bases": 0, "batches": 0, "read_s": 0.0, "gpu_wait_s": 0.0, "write_s": 0.0}
+    t_start = time.perf_counter()
     classifier = kmers.Classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
+    stats["table_build_s"] = time.perf_counter() - t_start
 
     # native reader / writer (same records as seq.readfq, same bytes as Read.print)
     reader = seq.BatchReader(args.reads)
@@ -91,9 +96,11 @@ def main():
 
     def emit(batch: seq.Batch, counts) -> None:
         """Score, bin and write one batch in input order (classify_by_kmers.py:104-117)."""
+        t = time.perf_counter()
         score_a, score_b, bins = kmers.score_and_bin(counts, num_a, num_b)
         writer.write(batch, bins)
         stdout.write(seq.format_tsv(batch, bins, score_a, score_b))
+        stats["write_s"] += time.perf_counter() - t
 
     # up to `depth` batches in flight on the GPU while the next one is being parsed
     depth = classifier.depth
@@ -103,14 +110,23 @@ def main():
     def drain(keep: int) -> None:
         while len(in_flight) > keep:
             ticket, batch = in_flight.pop(0)
-            emit(batch, classifier.wait(ticket))
+            t = time.perf_counter()
+            counts = classifier.wait(ticket)
+            stats["gpu_wait_s"] += time.perf_counter() - t
+            emit(batch, counts)
             free.append(batch)
 
     while True:
         batch = free.pop()
-        if reader.next_batch(batch, _BATCH_BASES, _BATCH_READS) == 0:
+        t = time.perf_counter()
+        n = reader.next_batch(batch, _BATCH_BASES, _BATCH_READS)
+        stats["read_s"] += time.perf_counter() - t
+        if n == 0:
             free.append(batch)
             break
+        stats["reads"] += n
+        stats["batches"] += 1
+        stats["bases"] += int(batch.arrays()[1][-1])
         drain(depth - 1)
         in_flight.append((classifier.submit_batch(batch), batch))
     drain(0)
@@ -122,6 +138,13 @@ def main():
     for b in free:
         b.close()
     classifier.close()
+    if os.environ.get("TBK_STATS"):
+        # stderr is free-form in the reference too (progress chatter); stdout stays pure TSV
+        import json
+
+        stats["total_s"] = time.perf_counter() - t_start
+        stats["gbases_per_s"] = stats["bases"] / stats["total_s"] / 1e9 if stats["total_s"] > 0 else 0.0
+        print("tbk-stats " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}), file=sys.stderr)
 
 
 if __name__ == "__main__":
