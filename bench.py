@@ -235,7 +235,16 @@ def main():
     # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
     # hapB slot when hapA missed.  Per launch: windows = R * (L - k + 1).
     counts = counts_ring[0]
+    dbg_read = getattr(lib, "tbk_debug_counters", None) if hasattr(lib, "tbk_debug_counters") else None
+    if dbg_read is not None:  # debug build (-DTBK_COUNTERS): event counts of one launch, to stderr
+        buf = (C.c_ulonglong * 8)()
+        dbg_read(buf, 1)
     finish(cls.submit_device(batches[0][0], batches[0][1], R, total, counts), 0, False)
+    if dbg_read is not None:
+        dbg_read(buf, 1)
+        w_ = R * max(1, L - k + 1)
+        print("tbk-counters", json.dumps({"careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
+                                         "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4)}), file=sys.stderr)
     hits_a = int(counts[:, 0].sum())
     windows = R * max(0, L - k + 1)
     alg_bytes = windows * 9 + (windows - hits_a) * 8

@@ -118,6 +118,11 @@ void tbk_classifier_destroy(tbk_classifier *c);
 /* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
 int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
                          uint64_t *n_buckets, uint64_t *table_bytes);
+/* Lines of hapB's list whose key is also in hapA's list (0 for lists made by find-unique-kmers).
+ * Only when it is non-zero can a window hit both tables, and only then does the probe kernel
+ * spend work on hapA-over-hapB priority (c/kmers.c:291-294).  Env TBK_ASSUME_SHARED=1 makes the
+ * kernel take that path regardless (tests). */
+int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared);
 /* How a key picks its bucket: the minimizer (w m-mers of length m, starting at base
  * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
  * Env TBK_MINIMIZER_W (default 6) and TBK_TABLE_LOAD tune it; neither changes any result. */

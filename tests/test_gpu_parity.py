@@ -329,31 +329,105 @@ def test_table_membership_and_dedupe(gpu):
     assert st["distinct_a"] == st["distinct_b"] == t.distinct and st["table_bytes"] == st["n_buckets"] * 128
 
 
-def test_crowded_tables_walk_path(gpu, orc, tmp_path):
-    """Force the 'home line is full' continuation in the probe kernel (load 0.85)."""
+@pytest.mark.parametrize("k", [21, 31, 32])
+def test_crowded_tables_walk_path(gpu, orc, tmp_path, k, monkeypatch):
+    """Crowded layouts (load 0.9 and 0.5): most halves are full, keys go past them to their
+    second-choice bucket and on from there, and lookups follow the same sequence."""
     from trio_binning_amd import kmers
 
-    k = 21
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(21 + k)
     la = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(3000)]
-    lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(3000)]
+    lb = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(1500)]  # uneven: hapA crowds, hapB has room
     fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
     fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
     oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
     a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
     reads = _rand_reads(rng, 400, 4000, la + lb, k, p_plant=1.0)
     bases, offs = _pack(reads)
-    os.environ["TBK_TABLE_LOAD"] = "0.9"
-    try:
-        cls = kmers.Classifier(a, b)
-    finally:
-        del os.environ["TBK_TABLE_LOAD"]
-    with cls:
-        assert cls.stats()["n_buckets"] < 3000 / 8 / 0.85
-        got = cls.classify_batch(bases, offs)
     want = orc.count_batch(bases, offs, oa, ob)
-    assert np.array_equal(got, want)
-    assert want.sum() > 300
+    for load in ("0.9", "0.5"):
+        monkeypatch.setenv("TBK_TABLE_LOAD", load)
+        with kmers.Classifier(a, b) as cls:
+            assert cls.stats()["n_buckets"] <= 3000 / 8 / float(load) + 1
+            got = cls.classify_batch(bases, offs)
+        assert np.array_equal(got, want), (k, load, np.nonzero((got != want).any(axis=1))[0][:10])
+    assert want[:, 0].sum() > 300 and want[:, 1].sum() > 100
+
+
+def test_heavy_minimizer_does_not_pile_up(gpu, orc, tmp_path):
+    """Low-complexity sequence: thousands of distinct k-mers share one minimizer (a poly-A
+    m-mer), far more than a bucket half holds.  The surplus goes to second-choice buckets picked
+    by a hash of the whole key, so lookups stay exact and a poly-A-rich read does not walk
+    through hundreds of lines per window."""
+    import time
+
+    from trio_binning_amd import kmers
+
+    k = 21
+    rng = np.random.default_rng(5)
+    def around_poly_a(n):
+        out = set()
+        while len(out) < n:
+            left = int(rng.integers(0, 6))
+            flank = "".join("ACGT"[c] for c in rng.integers(0, 4, 5))
+            out.add(flank[:left] + "A" * 16 + flank[left:])
+        return sorted(out)
+    pool = around_poly_a(4000)  # 4864 such 21-mers exist
+    rng.shuffle(pool)
+    la, lb = pool[:2500], pool[2500:]
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    reads = []
+    for _ in range(300):  # poly-A stretches with random interruptions, list k-mers planted, both strands
+        parts = []
+        for _ in range(60):
+            r = rng.random()
+            parts.append(pool[int(rng.integers(0, len(pool)))] if r < 0.4 else "A" * int(rng.integers(10, 40)) if r < 0.8
+                         else "".join("ACGT"[c] for c in rng.integers(0, 4, 7)))
+        s = "".join(parts)
+        reads.append(s if rng.random() < 0.5 else _rc(s))
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            cls.classify_batch(bases, offs)
+        dt = (time.perf_counter() - t0) / 5
+    assert np.array_equal(got, want), np.nonzero((got != want).any(axis=1))[0][:10]
+    assert want[:, 0].sum() > 2500 and want[:, 1].sum() > 1500
+    assert dt < 0.5, dt  # ~0.5 Mbases: milliseconds when the surplus is scattered
+
+
+@pytest.mark.parametrize("load", ["0.1", "0.9"])
+def test_shared_keys_and_priority_paths(gpu, orc, tmp_path, load, monkeypatch):
+    """hapA-over-hapB priority (c/kmers.c:291-294) is only worked out when the lists share keys.
+    Three configurations of the same reads: lists that overlap by half (priority decides many
+    windows), disjoint lists (the kernel skips the priority path), and disjoint lists with the
+    priority path forced on (TBK_ASSUME_SHARED) — roomy and crowded tables."""
+    from trio_binning_amd import kmers
+
+    k = 21
+    rng = np.random.default_rng(99)
+    pool = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(4500)]
+    la, lb_shared, lb_disjoint = pool[:3000], pool[1500:4500], pool[3000:4500] + pool[3000:3010]
+    monkeypatch.setenv("TBK_TABLE_LOAD", load)
+    reads = _rand_reads(rng, 300, 4000, pool, k, p_plant=1.0)
+    bases, offs = _pack(reads)
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    oa, a = orc.table_from_file(fa), kmers.HashSet.from_file(fa)
+    for name, lb, assume, want_shared in (("shared", lb_shared, "0", 1500), ("disjoint", lb_disjoint, "0", 0), ("forced", lb_disjoint, "1", 0)):
+        fb = _write(tmp_path, name + ".txt", "".join(x + "\n" for x in lb))
+        ob, b = orc.table_from_file(fb), kmers.HashSet.from_file(fb)
+        monkeypatch.setenv("TBK_ASSUME_SHARED", assume)
+        with kmers.Classifier(a, b) as cls:
+            assert cls.stats()["shared_keys"] == want_shared
+            got = cls.classify_batch(bases, offs)
+        want = orc.count_batch(bases, offs, oa, ob)
+        assert np.array_equal(got, want), (name, load, np.nonzero((got != want).any(axis=1))[0][:10])
+        assert want[:, 0].sum() > 300 and want[:, 1].sum() > 100
 
 
 def test_streaming_order_and_overlap(gpu, orc, tmp_path):
@@ -446,6 +520,7 @@ def test_realistic_haplotypes(gpu, orc):
         finally:
             del os.environ["TBK_TABLE_LOAD"]
         with cls:
+            assert cls.stats()["shared_keys"] == 0
             got = cls.classify_batch(bases, offs)
         assert np.array_equal(got, want), (load, np.nonzero((got != want).any(axis=1))[0][:10])
     # reads from haplotype A carry mostly hapA k-mers and vice versa

@@ -49,15 +49,26 @@ def dalloc(n):
     p = C.c_void_p(); check(lib.tbk_device_alloc(0, n, C.byref(p))); return p.value
 d_b, d_o, d_c = dalloc(flat.size + 64), dalloc(offs.nbytes), dalloc(R * 8)
 check(lib.tbk_memcpy_h2d(0, C.c_void_p(d_b), flat.ctypes.data, flat.size)); check(lib.tbk_memcpy_h2d(0, C.c_void_p(d_o), offs.ctypes.data, offs.nbytes))
-for load in ("0.125", "0.0625", "0.25"):
+for load in ("0.1", "0.0625", "0.25"):
     os.environ["TBK_TABLE_LOAD"] = load
     cls = kmers.Classifier(A, B)
     for _ in range(3): cls.classify_device(d_b, d_o, R, flat.size, d_c)
     cls.sync(); cls.kernel_timing(True)
     for _ in range(10): cls.classify_device(d_b, d_o, R, flat.size, d_c)
     n, ms = cls.kernel_timing_read()
+    dbg = None
+    try:  # debug builds (-DTBK_COUNTERS) count probe-kernel events
+        f = lib.tbk_debug_counters
+        buf = (C.c_ulonglong * 8)()
+        cls.sync(); f(buf, 1)
+        cls.classify_device(d_b, d_o, R, flat.size, d_c); cls.sync(); f(buf, 1)
+        w = R * (L - k + 1)
+        dbg = {"jsteps": buf[0], "careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
+               "walks_per_window": round(buf[3] / w, 5), "lines_per_window": round(buf[4] / 4 / w, 4)}
+    except AttributeError:
+        pass
     counts = np.zeros((R, 2), dtype=np.int32); check(lib.tbk_memcpy_d2h(0, counts.ctypes.data, C.c_void_p(d_c), counts.nbytes))
     res[f"load_{load}"] = {"kernel_ms": round(ms / n, 3), "gbases_per_s": round(R * L / (ms / n) / 1e6, 1), "hits_per_read": float(counts.sum() / R),
-                           "correct_bin_frac": float(((counts[0::2, 0] > counts[0::2, 1]).mean() + (counts[1::2, 1] > counts[1::2, 0]).mean()) / 2), **cls.stats()}
+                           "correct_bin_frac": float(((counts[0::2, 0] > counts[0::2, 1]).mean() + (counts[1::2, 1] > counts[1::2, 0]).mean()) / 2), **cls.stats(), **({"counters": dbg} if dbg else {})}
     cls.close()
 print(json.dumps(res))

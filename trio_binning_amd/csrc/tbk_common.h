@@ -287,11 +287,26 @@ struct TbkTableView {
     TbkMz mz;         // bucket selection
 };
 
+// The probe sequence of a key: its home bucket (chosen by the minimizer, shared with its
+// neighbours in a read), then - if that half is full and keys went past it - a second-choice
+// bucket chosen by a hash of the whole key, then linearly on from there.  A minimizer shared by
+// more keys than a half holds (low-complexity sequence: thousands of distinct k-mers around one
+// poly-A m-mer) therefore scatters its surplus over the table instead of piling it up in the
+// lines next to the home bucket, and a lookup meeting such a bucket pays one more random line,
+// not a walk through all of them.  Plain mode's home bucket already is a hash of the key, so its
+// sequence is purely linear.
+TBK_HD uint32_t tbk_next_bucket(uint64_t key, TbkMz mz, uint32_t n_buckets, uint32_t b, bool leaving_home) {
+    if (leaving_home && mz.w > 0) return tbk_reduce(tbk_mix32(key), n_buckets);
+    return b + 1 == n_buckets ? 0 : b + 1;
+}
+
 // The paired (hapA | hapB) table the probe kernel reads: bucket b = 16 slots = 128 bytes.
 struct TbkPairView {
     const uint64_t *slots;  // n_buckets * 16
     uint32_t n_buckets;
     TbkMz mz;               // bucket selection
+    uint32_t shared;        // 0 when no key sits in both halves (the lists are disjoint): a window then
+                            // cannot hit both tables and hapA-over-hapB priority never has to be applied
 };
 
 // ---- synthetic key sequence (bench inputs) ---------------------------------

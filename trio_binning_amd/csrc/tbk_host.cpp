@@ -27,9 +27,11 @@
 #include "tbk_common.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
-extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t,
+extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *,
                                         unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_count_present(TbkTableView, const uint64_t *, uint64_t, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, int, hipStream_t);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
@@ -123,8 +125,10 @@ struct tbk_classifier {
     uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B: [8 hapA slots | 8 hapB slots]
     uint32_t n_buckets = 0;
     uint64_t distinct_a = 0, distinct_b = 0;
+    uint64_t shared = 0;         // hapB list lines whose key is also in hapA's table
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
-    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz}; }
+    bool assume_shared = false;  // TBK_ASSUME_SHARED=1: take the priority path even for disjoint lists (tests)
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, (shared || assume_shared) ? 1u : 0u}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
     uint64_t next_ticket = 1;
@@ -204,7 +208,7 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load) {
 
 // Insert n keys into one list's slots of a table (standalone: stride 8, half 0; paired:
 // stride 16, half 0 / 8).  The slots must already be filled with TBK_EMPTY.
-static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
+static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz, uint32_t *d_overflowed,
                        const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out) {
     unsigned long long *d_distinct = nullptr;
     int *d_failed = nullptr;
@@ -212,7 +216,7 @@ static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, u
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
     if (e == hipSuccess) e = hipMemset(d_distinct, 0, sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
-    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_distinct, d_failed, nullptr);
+    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_overflowed, d_distinct, d_failed, nullptr);
     unsigned long long distinct = 0;
     int failed = 0;
     if (e == hipSuccess) e = hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost);
@@ -225,6 +229,24 @@ static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, u
     return TBK_OK;
 }
 
+// One bit per half: "a key went past this half" (set by the inserts, turned into the order of
+// the half's last two slots by finish_table, then dropped).
+static int overflow_bitmap(uint64_t n_halves, uint32_t **out) {
+    const size_t bytes = ((size_t)n_halves + 31) / 32 * 4 + 4;
+    hipError_t e = hipMalloc((void **)out, bytes);
+    if (e == hipSuccess) e = hipMemset(*out, 0, bytes);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "overflow bitmap (%zu bytes): %s", bytes, hipGetErrorString(e));
+    return TBK_OK;
+}
+
+static int finish_table(uint64_t *d_slots, uint64_t n_halves, uint32_t *d_overflowed) {
+    hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_overflowed);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "table order pass: %s", hipGetErrorString(e));
+    return TBK_OK;
+}
+
 // Build the standalone hashed form of a list on first use.
 static int table_hash(tbk_table *t) {
     if (t->hashed) return TBK_OK;
@@ -234,8 +256,14 @@ static int table_hash(tbk_table *t) {
     const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
     HIP_TRY(hipMalloc((void **)&t->d_slots, bytes));
     hipError_t e = hipMemset(t->d_slots, 0xFF, bytes);
-    if (e == hipSuccess) rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, TbkMz{0, 0, 0, 0}, t->d_keys, t->num_lines, &t->distinct);
-    else rc = fail(TBK_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+    uint32_t *d_over = nullptr;
+    if (e != hipSuccess) rc = fail(TBK_ERR_HIP, "hipMemset: %s", hipGetErrorString(e));
+    if (!rc) rc = overflow_bitmap(t->n_buckets, &d_over);
+    if (!rc) {
+        rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, TbkMz{0, 0, 0, 0}, d_over, t->d_keys, t->num_lines, &t->distinct);
+        const int rc2 = finish_table(t->d_slots, t->n_buckets, d_over);
+        if (!rc) rc = rc2;
+    }
     if (rc) { (void)hipFree(t->d_slots); t->d_slots = nullptr; return rc; }
     t->hashed = true;
     return TBK_OK;
@@ -466,6 +494,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->device = a->device;
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
+    c->assume_shared = env_double("TBK_ASSUME_SHARED", 0) != 0;
     // bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
     // default 6; 0 = plain hashing of the whole key).  TBK_MOD_SAMPLING=1 samples by mod-sampling
     // instead of the random-minimizer rule: 15 % fewer HBM lines but 23 % more VALU work, a net
@@ -482,8 +511,26 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         delete c;
         return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
-    rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, a->d_keys, a->num_lines, &c->distinct_a);
-    if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, b->d_keys, b->num_lines, &c->distinct_b);
+    uint32_t *d_over = nullptr;
+    rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
+    if (!rc) {
+        rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a);
+        if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b);
+        const int rc2 = finish_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
+        if (!rc) rc = rc2;
+    }
+    // Are the lists disjoint (they are when they come from find-unique-kmers)?  Then no window
+    // can hit both tables and the probe kernel never has to apply hapA-over-hapB priority.
+    if (!rc && b->num_lines) {
+        unsigned long long *d_present = nullptr, present = 0;
+        e = hipMalloc((void **)&d_present, sizeof present);
+        if (e == hipSuccess) e = hipMemset(d_present, 0, sizeof present);
+        if (e == hipSuccess) e = tbk_launch_count_present(TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz}, b->d_keys, b->num_lines, d_present, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(&present, d_present, sizeof present, hipMemcpyDeviceToHost);
+        if (d_present) (void)hipFree(d_present);
+        if (e != hipSuccess) rc = fail(TBK_ERR_HIP, "shared-key scan: %s", hipGetErrorString(e));
+        c->shared = present;
+    }
     if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
     e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
@@ -516,6 +563,12 @@ extern "C" int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_
     if (distinct_b) *distinct_b = c->distinct_b;
     if (n_buckets) *n_buckets = c->n_buckets;
     if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared) {
+    if (!c || !n_shared) return fail(TBK_ERR_INVALID, "NULL argument");
+    *n_shared = c->shared;
     return TBK_OK;
 }
 

@@ -24,10 +24,11 @@
 // hapB half of a paired table (16, 0 / 8).
 __global__ void __launch_bounds__(256)
 tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                  const uint64_t *__restrict__ keys, uint64_t n,
+                  const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed,
                   unsigned long long *__restrict__ n_distinct, int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET, which = half / TBK_SLOTS_PER_BUCKET;
     unsigned long long mine = 0;
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
@@ -40,7 +41,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
         for (int c = 0; c < n_cand; c++) {
             uint32_t b = cand[c];
             bool done = false;
-            for (uint32_t walked = 0; walked < n_buckets && !done; walked++) {
+            for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                 unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
                 for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
                     unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -52,7 +53,14 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
                         // else: somebody else's key took the slot; keep scanning
                     }
                 }
-                if (!done) { b++; if (b == n_buckets) b = 0; }
+                if (!done) {
+                    // this half is full and the key goes past it: remember that (tbk_order_kernel turns
+                    // the note into the order of the half's last two slots), then follow the probe
+                    // sequence: home bucket, second-choice bucket, and linearly on from there
+                    const uint64_t bit = (uint64_t)b * halves + which;
+                    atomicOr(&overflowed[bit >> 5], 1u << (bit & 31));
+                    b = tbk_next_bucket(key, mz, n_buckets, b, walked == 0);
+                }
             }
             if (!done) atomicExch(failed, 1);
         }
@@ -60,31 +68,51 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     if (mine) atomicAdd(n_distinct, mine);
 }
 
-// =======================================================================================
-// contains (raw keys; one thread per key, whole-bucket scan) — test utility, not the hot path
-// =======================================================================================
+// After all inserts: give every full half the order of its last two slots that says whether a key
+// went past it (slot 6 > slot 7) or not (slot 6 < slot 7).  One thread per half.
+__global__ void __launch_bounds__(256)
+tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t *__restrict__ overflowed) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_halves) return;
+    ulonglong2 *last = reinterpret_cast<ulonglong2 *>(slots + h * TBK_SLOTS_PER_BUCKET + 6);
+    ulonglong2 v = *last;
+    if (v.y == TBK_EMPTY) return;  // not full: nothing went past it, and slot 6 <= slot 7 = EMPTY already says so
+    const bool past = (overflowed[h >> 5] >> (h & 31)) & 1u;
+    if ((v.x > v.y) != past) *last = make_ulonglong2(v.y, v.x);
+}
+
+// Membership of one key, one thread, whole lines (build-time scans and tests; not the hot path).
+__device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t key) {
+    if (key >= TBK_NOKEY) return false;
+    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
+    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+        const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
+        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
+            if (line[s] == key) return true;
+        if (!(line[6] > line[7])) return false;  // no key went past this half
+        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
+    }
+    return false;
+}
+
 __global__ void __launch_bounds__(256)
 tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t n,
                     uint8_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t key = keys[i];
-    uint8_t found = 0;
-    if (key < TBK_NOKEY) {
-        uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
-        for (uint32_t walked = 0; walked < t.n_buckets; walked++) {
-            const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
-            bool has_free = false;
-            for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
-                uint64_t cur = line[s];
-                if (cur == key) found = 1;
-                if (cur == TBK_EMPTY) has_free = true;
-            }
-            if (found || has_free) break;
-            b++; if (b == t.n_buckets) b = 0;
-        }
-    }
-    out[i] = found;
+    out[i] = tbk_lookup_slow(t, keys[i]) ? 1 : 0;
+}
+
+// How many of `keys` sit in this table (grid-stride).  The classifier runs it once at build time,
+// hapB's list against the hapA half: zero means no window can ever hit both tables.
+__global__ void __launch_bounds__(256)
+tbk_count_present_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t n,
+                         unsigned long long *__restrict__ n_present) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (; i < n; i += step) mine += tbk_lookup_slow(t, keys[i]) ? 1 : 0;
+    if (mine) atomicAdd(n_present, mine);
 }
 
 // =======================================================================================
@@ -130,6 +158,15 @@ constexpr int TBK_WPL = 32;                 // windows per lane per pass
 constexpr int TBK_PASS = 64 * TBK_WPL;      // window starts per wave pass (2048)
 constexpr int TBK_WAVES_PER_BLOCK = 4;
 constexpr int TBK_CHUNKS = 130;             // 128 chunks of 16 bases + 2 halo chunks
+
+#ifdef TBK_COUNTERS
+// event counters of a debug build (tools/measure_realistic.py prints them): j-steps, j-steps on the
+// careful path, careful sub-steps, walks queued, lane loads of bucket lines (4 per line), walk steps
+__device__ unsigned long long tbk_dbg[8];
+#define TBK_COUNT(i, n) dbg[i] += (n)
+#else
+#define TBK_COUNT(i, n)
+#endif
 
 struct ProbeArgs {
     const uint8_t *bases;
@@ -226,20 +263,22 @@ constexpr int TBK_QCAP = 128;  // queue entries per wave; a window-loop step add
 // entry: x = key low, y = key high, z = home bucket, w = flags | (read - first read of pass) << 3
 enum { WQ_WALK_A = 1, WQ_WALK_B = 2, WQ_HIT_B = 4 };
 
-// walk from `bucket` through half `half` (0 hapA, 8 hapB) until the key or a non-full half
+// follow the probe sequence of a key of list `half` (0 hapA, 8 hapB) past its home bucket, until the
+// key is found or a half that no key went past
 __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket, bool pend) {
-    bool found = false;
+    bool found = false, first = true;
     uint32_t guard = 0;
-    while (ballot(pend) != 0 && guard++ < t.n_buckets) {
+    while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
-            bucket = bucket + 1 == t.n_buckets ? 0 : bucket + 1;
+            bucket = tbk_next_bucket(key, t.mz, t.n_buckets, bucket, first);
             const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
             const ulonglong2 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3];
             const bool hit = v0.x == key || v0.y == key || v1.x == key || v1.y == key || v2.x == key || v2.y == key ||
                              v3.x == key || v3.y == key;
             found = found || hit;
-            pend = !hit && v3.y != TBK_EMPTY;  // occupied slots form a prefix: last slot free = half not full
+            pend = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
         }
+        first = false;
     }
     return found;
 }
@@ -384,6 +423,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
     uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
     uint32_t qn = 0;                 // queued walks (wave-uniform)
+#ifdef TBK_COUNTERS
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
     constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
@@ -463,6 +505,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         for (int s = 0; s < 4; s++) {
             // fetch only when this window's line differs from the one the slot already holds
             // (minimizer mode: consecutive windows mostly share it)
+            TBK_COUNT(4, __popcll(ballot(bk[s] != held[s])));
             if (bk[s] != held[s]) {
                 const uint64_t *line = p.t.slots + (uint64_t)bk[s] * 16 + sub * 2;
                 va[s] = *reinterpret_cast<const ulonglong2 *>(line);
@@ -475,7 +518,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         // windows.  A half is full exactly when its last slot (held by quad lane 3) is
         // occupied; only then may a miss have to walk on.  hapA/hapB priority only matters
         // when both tables report a hit.  Anything else goes to the exact path.
-        uint64_t hit_a[4], hit_b[4], full_any = 0, any_a = 0, any_b = 0;
+        uint64_t hit_a[4], hit_b[4], full_a[4], full_b[4], full_any = 0, any_a = 0, any_b = 0;
         uint64_t kk[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -484,24 +527,29 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             // instructions: the i1 is materialised and compared again)
             hit_a[s] = ballot(va[s].x == kk[s]) | ballot(va[s].y == kk[s]);
             hit_b[s] = ballot(vb[s].x == kk[s]) | ballot(vb[s].y == kk[s]);
-            full_any |= ballot((va[s].y & vb[s].y) != TBK_EMPTY);
+            // quad lane 3 holds slots 6 and 7 of each half: slot 6 > slot 7 says a key went past the half
+            full_a[s] = ballot(va[s].x > va[s].y) & 0x8888888888888888ull;
+            full_b[s] = ballot(vb[s].x > vb[s].y) & 0x8888888888888888ull;
+            full_any |= full_a[s] | full_b[s];
             any_a |= hit_a[s];
             any_b |= hit_b[s];
         }
-        full_any &= 0x8888888888888888ull;  // a half is full exactly when its last slot (quad lane 3) is occupied
-        if (full_any != 0 || (any_a != 0 && any_b != 0)) {
+        TBK_COUNT(0, 1);
+        if (full_any != 0 || (p.t.shared != 0 && any_a != 0 && any_b != 0)) {
+            TBK_COUNT(1, 1);
             // Careful path: per-window (= per-quad) resolution.  Everything is brought to the
             // quad's lane-0 bit.  Hits in the home line are final for hapA; a hapB hit is final
             // unless hapA still has to walk.  Lookups that must walk are queued.
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const uint64_t full_a = (ballot(va[s].y != TBK_EMPTY) >> 3) & 0x1111111111111111ull;  // lane 3 holds the last slot
-                const uint64_t full_b = (ballot(vb[s].y != TBK_EMPTY) >> 3) & 0x1111111111111111ull;
-                if ((full_a | full_b) == 0 && (hit_a[s] == 0 || hit_b[s] == 0)) continue;  // raw ballots are already exact
+                if ((full_a[s] | full_b[s]) == 0 && (p.t.shared == 0 || hit_a[s] == 0 || hit_b[s] == 0)) continue;  // raw ballots are already exact
+                const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
+                TBK_COUNT(2, 1);
                 const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
-                const uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
-                const uint64_t walk_a = valid & full_a & ~ha;
-                const uint64_t walk_b = valid & full_b & ~hb & ~ha;
+                uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
+                uint64_t walk_a = valid & fa, walk_b = valid & fb;
+                walk_a &= ~ha;
+                walk_b &= ~hb & ~ha;
                 const uint64_t queued = walk_a | walk_b;
                 hit_a[s] = ha;
                 hit_b[s] = hb & ~ha & ~queued;  // a queued window's hapB hit travels with it
@@ -514,6 +562,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                         walkq[slot] = make_uint4(klo[s], khi[s], bk[s], flags | (rrel << 3));
                     }
                     qn += (uint32_t)__popcll(queued);
+                    TBK_COUNT(3, __popcll(queued));
                 }
             }
         }
@@ -545,6 +594,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+#ifdef TBK_COUNTERS
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) if (dbg[i]) atomicAdd(&tbk_dbg[i], dbg[i]);
+#endif
     if (!MULTI) {
         if (lane == 0) {
             if (acc_a) atomicAdd(&p.counts[2 * r_first], (int)acc_a);
@@ -599,13 +652,20 @@ tbk_probe_kernel(const ProbeArgs p) {
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                                        const uint64_t *d_keys, uint64_t n, unsigned long long *d_distinct,
-                                        int *d_failed, hipStream_t stream) {
+                                        const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed,
+                                        unsigned long long *d_distinct, int *d_failed, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
-                       half, mz, d_keys, n, d_distinct, d_failed);
+                       half, mz, d_keys, n, d_overflowed, d_distinct, d_failed);
+    return hipGetLastError();
+}
+
+// n_halves = n_buckets * stride / 8; d_overflowed has one bit per half (bit index = bucket * halves + which)
+extern "C" hipError_t tbk_launch_order(uint64_t *slots, uint64_t n_halves, const uint32_t *d_overflowed, hipStream_t stream) {
+    if (n_halves == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbk_order_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, d_overflowed);
     return hipGetLastError();
 }
 
@@ -614,6 +674,15 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(tbk_contains_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t,
                        d_keys, n, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_count_present(TbkTableView t, const uint64_t *d_keys, uint64_t n,
+                                               unsigned long long *d_present, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(tbk_count_present_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, d_keys, n, d_present);
     return hipGetLastError();
 }
 
@@ -646,6 +715,17 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d
 #undef TBK_LAUNCH
     return hipGetLastError();
 }
+
+#ifdef TBK_COUNTERS
+extern "C" int tbk_debug_counters(unsigned long long out[8], int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tbk_dbg), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(tbk_dbg), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -5;
+}
+#endif
 
 // number of uint32 entries of pass_read scratch a batch of `total` bases needs
 extern "C" uint64_t tbk_probe_passes(uint64_t total) { return (total + TBK_PASS - 1) / TBK_PASS; }

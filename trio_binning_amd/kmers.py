@@ -243,7 +243,9 @@ class Classifier:
         check(lib.tbk_classifier_stats(self._h, C.byref(da), C.byref(db), C.byref(nb), C.byref(by)))
         w, m, o = C.c_int(), C.c_int(), C.c_int()
         check(lib.tbk_classifier_layout(self._h, C.byref(w), C.byref(m), C.byref(o)))
-        return {"distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
+        sh = C.c_uint64()
+        check(lib.tbk_classifier_shared_keys(self._h, C.byref(sh)))
+        return {"shared_keys": sh.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
                 "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
                 "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
 
