@@ -48,6 +48,12 @@ def parse():
     ap.add_argument("--read-len", type=int, default=15_000)
     ap.add_argument("--reads-per-step", type=int, default=65_536)
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct read batches kept in HBM and cycled")
+    ap.add_argument("--lists", choices=["uniform", "haplotypes"], default="uniform",
+                    help="uniform: BASELINE.json's synthetic lists (distinct uniform random k-mers, reads with planted list "
+                         "k-mers); haplotypes: lists shaped like real find-unique-kmers output (two haplotypes of a random "
+                         "genome differing by SNPs; reads drawn from them with errors)")
+    ap.add_argument("--snp-rate", type=float, default=1 / 500, help="haplotypes: SNPs per base of each haplotype")
+    ap.add_argument("--error-rate", type=float, default=0.002, help="haplotypes: substitution errors per read base")
     ap.add_argument("--plant-major", type=int, default=30)
     ap.add_argument("--plant-minor", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per cpu_baseline leg")
@@ -152,22 +158,41 @@ def main():
 
     t_setup = time.time()
     # ---- tables: 2 x n_list distinct canonical k-mers, generated and inserted on the GPU ----
-    d_keys = dalloc(2 * n_list * 8)
-    check(lib.tbk_synth_keys_device(dev, KEY_SEED, 0, 2 * n_list, k, C.c_void_p(d_keys)))
+    hap = args.lists == "haplotypes"
+    if hap:
+        # genome long enough for ~n_list windows that cover a position where the haplotypes differ
+        snp24 = max(1, int(round(args.snp_rate * (1 << 24))))
+        err24 = int(round(args.error_rate * (1 << 24)))
+        p_diff = 2 * args.snp_rate - args.snp_rate ** 2 * (1 + 1 / 3)
+        genome_len = int(n_list / (1 - (1 - p_diff) ** k))
+        cap = int(n_list * 1.05) + 1024
+        d_keys = dalloc(2 * cap * 8)
+        n_got = C.c_uint64()
+        check(lib.tbk_synth_hap_keys_device(dev, KEY_SEED, genome_len, snp24, k, C.c_void_p(d_keys), C.c_void_p(d_keys + cap * 8),
+                                            cap, C.byref(n_got)))
+        if n_got.value > cap:
+            raise SystemExit(f"haplotype lists: {n_got.value} keys exceed the capacity {cap}")
+        n_list, key_stride = n_got.value, cap
+    else:
+        d_keys = dalloc(2 * n_list * 8)
+        check(lib.tbk_synth_keys_device(dev, KEY_SEED, 0, 2 * n_list, k, C.c_void_p(d_keys)))
+        key_stride = n_list
     t0 = time.time()
     hap_a = kmers.HashSet.from_device_keys(d_keys, n_list, k, device=dev)
-    hap_b = kmers.HashSet.from_device_keys(d_keys + n_list * 8, n_list, k, device=dev)
+    hap_b = kmers.HashSet.from_device_keys(d_keys + key_stride * 8, n_list, k, device=dev)
     cls = kmers.Classifier(hap_a, hap_b)  # hashes both lists into the paired table in HBM
     check(lib.tbk_device_sync(dev))
     t_build = time.time() - t0
     stats = cls.stats()
-    assert stats["distinct_a"] == n_list and stats["distinct_b"] == n_list, stats
+    if not hap:
+        assert stats["distinct_a"] == n_list and stats["distinct_b"] == n_list, stats
 
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     h_keys = None
     if want_cpu:
         h_keys = np.empty(2 * n_list, dtype=np.uint64)
-        check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data, C.c_void_p(d_keys), h_keys.nbytes))
+        check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data, C.c_void_p(d_keys), n_list * 8))
+        check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data + n_list * 8, C.c_void_p(d_keys + key_stride * 8), n_list * 8))
     check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
 
     # ---- reads: `resident_batches` batches in HBM; each rank draws its own reads --------------
@@ -179,8 +204,12 @@ def main():
         d_bases = dalloc((total + 15) // 16 * 16 + 16)
         d_offs = dalloc((R + 1) * 8)
         d_counts = dalloc(R * 2 * 4)
-        check(lib.tbk_synth_reads_device(dev, READ_SEED, first_read, R, L, KEY_SEED, n_list, n_list, k,
-                                         args.plant_major, args.plant_minor, C.c_void_p(d_bases), C.c_void_p(d_offs)))
+        if hap:
+            check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first_read, R, L, err24,
+                                                 C.c_void_p(d_bases), C.c_void_p(d_offs)))
+        else:
+            check(lib.tbk_synth_reads_device(dev, READ_SEED, first_read, R, L, KEY_SEED, n_list, n_list, k,
+                                             args.plant_major, args.plant_minor, C.c_void_p(d_bases), C.c_void_p(d_offs)))
         batches.append((d_bases, d_offs, d_counts))
     t_setup = time.time() - t_setup
 
@@ -291,13 +320,14 @@ def main():
         "metric": "Gbases/sec classified (k=21, 2x300M k-mer tables)", "value": round(value, 3), "unit": "Gbases/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "vs_baseline": None, "dtype": "u64",
+        "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g})",
         "config": {
             "workload": f"BASELINE configs[2] shape: {L} b synthetic reads, 2x{n_list} unique {k}-mers replicated per GPU, "
                         f"{R} reads ({total / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks",
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R, "resident_batches": nb,
             "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(n_list / (stats["n_buckets"] * 8), 4),
-            "bucket_select": bucket_select,
+            "bucket_select": bucket_select, "lists": args.lists,
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "roofline": roofline,

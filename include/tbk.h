@@ -118,10 +118,10 @@ void tbk_classifier_destroy(tbk_classifier *c);
 /* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
 int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
                          uint64_t *n_buckets, uint64_t *table_bytes);
-/* Lines of hapB's list whose key is also in hapA's list (0 for lists made by find-unique-kmers).
- * Only when it is non-zero can a window hit both tables, and only then does the probe kernel
- * spend work on hapA-over-hapB priority (c/kmers.c:291-294).  Env TBK_ASSUME_SHARED=1 makes the
- * kernel take that path regardless (tests). */
+/* Lines of hapB's list whose key hapA's list holds too (0 for lists made by find-unique-kmers).
+ * hapA is asked first (c/kmers.c:291-294), so such a key can never count for hapB: it is left out
+ * of hapB's half of the table (distinct_b above does not include it), the two halves are disjoint
+ * and the probe kernel never arbitrates between them.  get_number_kmers_in_set is unaffected. */
 int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared);
 /* How a key picks its bucket: the minimizer (w m-mers of length m, starting at base
  * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
@@ -236,6 +236,20 @@ int tbk_synth_keys_host(uint64_t seed, uint64_t first, uint64_t n, int k, uint64
 int tbk_synth_reads_device(int device, uint64_t read_seed, uint64_t first_read, uint64_t n_reads,
                            uint32_t read_len, uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k,
                            int plant_major, int plant_minor, void *d_bases, void *d_offsets);
+
+/* Lists and reads shaped like real trio-binning input instead of uniform keys: an implicit random
+ * genome of `genome_len` bases, two haplotypes that each differ from it by SNPs at
+ * snp_per_2p24 / 2^24 per base; list A / list B = the canonical k-mers of haplotype A / B that
+ * cover a position where the haplotypes differ (runs of up to k overlapping k-mers sharing a few
+ * minimizers, both lists clustered at the same loci).  Both lists get *n_keys entries (order not
+ * deterministic, sets are); at most `capacity` are written to each of d_keys_a / d_keys_b. */
+int tbk_synth_hap_keys_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24, int k,
+                              void *d_keys_a, void *d_keys_b, uint64_t capacity, uint64_t *n_keys);
+/* Read r comes from haplotype (first_read + r) & 1, from a hashed position and strand, with
+ * substitution errors at err_per_2p24 / 2^24 per base. */
+int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24,
+                               uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                               uint32_t err_per_2p24, void *d_bases, void *d_offsets);
 
 /* ---- roofline calibration (SURVEY §8d "random-read roofline") -------------------------- */
 /* Independent uniformly random line-aligned loads over a `footprint_bytes` buffer:

@@ -326,7 +326,9 @@ def test_table_membership_and_dedupe(gpu):
     assert t2.nbytes < t.nbytes
     with kmers.Classifier(t, t2) as cls:
         st = cls.stats()
-    assert st["distinct_a"] == st["distinct_b"] == t.distinct and st["table_bytes"] == st["n_buckets"] * 128
+    # the same list on both sides: hapA holds every key, so none is stored for hapB
+    assert st["distinct_a"] == t.distinct and st["distinct_b"] == 0 and st["shared_keys"] == keys.size
+    assert st["table_bytes"] == st["n_buckets"] * 128
 
 
 @pytest.mark.parametrize("k", [21, 31, 32])
@@ -402,28 +404,28 @@ def test_heavy_minimizer_does_not_pile_up(gpu, orc, tmp_path):
 
 
 @pytest.mark.parametrize("load", ["0.1", "0.9"])
-def test_shared_keys_and_priority_paths(gpu, orc, tmp_path, load, monkeypatch):
-    """hapA-over-hapB priority (c/kmers.c:291-294) is only worked out when the lists share keys.
-    Three configurations of the same reads: lists that overlap by half (priority decides many
-    windows), disjoint lists (the kernel skips the priority path), and disjoint lists with the
-    priority path forced on (TBK_ASSUME_SHARED) — roomy and crowded tables."""
+def test_shared_keys_count_for_hap_a_only(gpu, orc, tmp_path, load, monkeypatch):
+    """hapA is asked first (c/kmers.c:291-294): a key both lists hold counts for hapA only.  The
+    table leaves such keys out of hapB's half; counts must match the reference's on lists that
+    overlap by half and on disjoint ones, in roomy and crowded tables."""
     from trio_binning_amd import kmers
 
     k = 21
     rng = np.random.default_rng(99)
     pool = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(4500)]
-    la, lb_shared, lb_disjoint = pool[:3000], pool[1500:4500], pool[3000:4500] + pool[3000:3010]
+    la, lb_shared, lb_disjoint = pool[:3000], pool[1500:4500] + pool[1500:1510], pool[3000:4500] + pool[3000:3010]
     monkeypatch.setenv("TBK_TABLE_LOAD", load)
     reads = _rand_reads(rng, 300, 4000, pool, k, p_plant=1.0)
     bases, offs = _pack(reads)
     fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
     oa, a = orc.table_from_file(fa), kmers.HashSet.from_file(fa)
-    for name, lb, assume, want_shared in (("shared", lb_shared, "0", 1500), ("disjoint", lb_disjoint, "0", 0), ("forced", lb_disjoint, "1", 0)):
+    for name, lb, want_shared, want_b in (("shared", lb_shared, 1510, 1500), ("disjoint", lb_disjoint, 0, 1500)):
         fb = _write(tmp_path, name + ".txt", "".join(x + "\n" for x in lb))
         ob, b = orc.table_from_file(fb), kmers.HashSet.from_file(fb)
-        monkeypatch.setenv("TBK_ASSUME_SHARED", assume)
+        assert b.num_kmers == len(lb)  # the score's denominator still counts every line
         with kmers.Classifier(a, b) as cls:
-            assert cls.stats()["shared_keys"] == want_shared
+            st = cls.stats()
+            assert (st["shared_keys"], st["distinct_a"], st["distinct_b"]) == (want_shared, 3000, want_b)
             got = cls.classify_batch(bases, offs)
         want = orc.count_batch(bases, offs, oa, ob)
         assert np.array_equal(got, want), (name, load, np.nonzero((got != want).any(axis=1))[0][:10])
@@ -593,6 +595,99 @@ def test_device_resident_and_synthetic_generators(gpu, orc):
     major = want.max(axis=1)
     assert ((major >= 30) | (major <= 6)).all() and (major >= 30).sum() > R // 2
     for p in (d_bases, d_offs, d_counts):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+
+
+def test_haplotype_shaped_generators(gpu, orc):
+    """bench.py --lists haplotypes at test size: the GPU generators against a numpy restatement
+    (same hash, same rules), then the probe kernel on what they made against the oracle."""
+    import ctypes as C
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    dev, k, G, R, L = 0, 21, 300_000, 200, 2500
+    seed, rseed, snp24, err24 = 0x5EED0001, 0x5EED0002, int((1 / 400) * (1 << 24)), int(0.003 * (1 << 24))
+    M = np.uint64
+
+    def splitmix(x):
+        with np.errstate(over="ignore"):
+            x = x + M(0x9E3779B97F4A7C15)
+            x = (x ^ (x >> M(30))) * M(0xBF58476D1CE4E5B9)
+            x = (x ^ (x >> M(27))) * M(0x94D049BB133111EB)
+            return x ^ (x >> M(31))
+
+    with np.errstate(over="ignore"):
+        r = splitmix(M(seed) ^ (np.arange(G, dtype=M) * M(0x9E3779B97F4A7C15)))
+    base = (r & M(3)).astype(np.uint8)
+    alt_a = (base + 1 + (((r >> M(52)) & M(0xFF)) % M(3)).astype(np.uint8)) & 3
+    alt_b = (base + 1 + (((r >> M(56)) & M(0xFF)) % M(3)).astype(np.uint8)) & 3
+    hap_a = np.where(((r >> M(4)) & M(0xFFFFFF)) < snp24, alt_a, base).astype(np.uint8)
+    hap_b = np.where(((r >> M(28)) & M(0xFFFFFF)) < snp24, alt_b, base).astype(np.uint8)
+
+    def canon(codes):
+        c = codes.astype(M)
+        n = c.size - k + 1
+        f, rc = np.zeros(n, dtype=M), np.zeros(n, dtype=M)
+        for i in range(k):
+            f |= c[i:i + n] << M(2 * i)
+            rc |= (M(3) - c[i:i + n]) << M(2 * (k - 1 - i))
+        return np.minimum(f, rc)
+
+    diff = np.concatenate([[0], np.cumsum(hap_a != hap_b)])
+    covers = (diff[k:] - diff[:-k]) > 0  # window q covers a differing position
+    want_a, want_b = canon(hap_a)[covers], canon(hap_b)[covers]
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    cap = int(covers.sum()) + 100
+    d_keys = dalloc(2 * cap * 8)
+    n_got = C.c_uint64()
+    check(lib.tbk_synth_hap_keys_device(dev, seed, G, snp24, k, C.c_void_p(d_keys), C.c_void_p(d_keys + cap * 8), cap, C.byref(n_got)))
+    n = n_got.value
+    assert n == int(covers.sum()) and n > 10_000
+    got = np.empty(2 * cap, dtype=M)
+    check(lib.tbk_memcpy_d2h(dev, got.ctypes.data, C.c_void_p(d_keys), got.nbytes))
+    ga, gb = got[:n], got[cap:cap + n]
+    # order is not deterministic; the multiset of (A key, B key) pairs is
+    assert np.array_equal(np.sort(ga), np.sort(want_a)) and np.array_equal(np.sort(gb), np.sort(want_b))
+    order_g, order_w = np.lexsort((gb, ga)), np.lexsort((want_b, want_a))
+    assert np.array_equal(gb[order_g], want_b[order_w])
+
+    total = R * L
+    d_bases, d_offs = dalloc(total + 32), dalloc((R + 1) * 8)
+    check(lib.tbk_synth_hap_reads_device(dev, seed, G, snp24, rseed, 7, R, L, err24, C.c_void_p(d_bases), C.c_void_p(d_offs)))
+    h_bases, h_offs = np.empty(total, dtype=np.uint8), np.empty(R + 1, dtype=M)
+    check(lib.tbk_memcpy_d2h(dev, h_bases.ctypes.data, C.c_void_p(d_bases), total))
+    check(lib.tbk_memcpy_d2h(dev, h_offs.ctypes.data, C.c_void_p(d_offs), h_offs.nbytes))
+    assert h_offs.tolist() == [i * L for i in range(R + 1)]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with np.errstate(over="ignore"):
+        rr = splitmix(M(rseed) ^ ((M(7) + np.arange(R, dtype=M)) * M(0xA0761D6478BD642F)))
+        e = splitmix(M(rseed) ^ M(0x5851F42D4C957F2D) ^ ((M(7 * L) + np.arange(total, dtype=M)) * M(0xD6E8FEB86659FD93)))
+    want_reads = np.empty((R, L), dtype=np.uint8)
+    for i in range(R):
+        start = int((rr[i] >> M(1)) % M(G - L + 1))
+        codes = (hap_b if (7 + i) & 1 else hap_a)[start:start + L]
+        want_reads[i] = (3 - codes[::-1]) if int(rr[i]) & 1 else codes
+    want_reads = want_reads.reshape(-1)
+    hit = (e & M(0xFFFFFF)) < err24
+    want_reads = np.where(hit, (want_reads + 1 + ((e >> M(32)) % M(3)).astype(np.uint8)) & 3, want_reads).astype(np.uint8)
+    assert np.array_equal(h_bases, lut[want_reads])
+
+    a, b = kmers.HashSet.from_device_keys(d_keys, n, k), kmers.HashSet.from_device_keys(d_keys + cap * 8, n, k)
+    oa, ob = orc.table_from_keys(ga, k), orc.table_from_keys(gb, k)
+    want = orc.count_batch(h_bases, h_offs, oa, ob)
+    with kmers.Classifier(a, b) as cls:
+        got_counts = cls.classify_batch(h_bases, h_offs)
+    assert np.array_equal(got_counts, want)
+    # reads of haplotype A (even read index 7 + i) carry mostly hapA k-mers
+    even = (7 + np.arange(R)) % 2 == 0
+    assert (want[even, 0] > want[even, 1]).mean() > 0.9 and (want[~even, 1] > want[~even, 0]).mean() > 0.9
+    for p in (d_keys, d_bases, d_offs):
         check(lib.tbk_device_free(dev, C.c_void_p(p)))
 
 

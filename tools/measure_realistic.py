@@ -49,7 +49,7 @@ def dalloc(n):
     p = C.c_void_p(); check(lib.tbk_device_alloc(0, n, C.byref(p))); return p.value
 d_b, d_o, d_c = dalloc(flat.size + 64), dalloc(offs.nbytes), dalloc(R * 8)
 check(lib.tbk_memcpy_h2d(0, C.c_void_p(d_b), flat.ctypes.data, flat.size)); check(lib.tbk_memcpy_h2d(0, C.c_void_p(d_o), offs.ctypes.data, offs.nbytes))
-for load in ("0.1", "0.0625", "0.25"):
+for load in os.environ.get("TBK_LOADS", "0.1,0.0625,0.25").split(","):
     os.environ["TBK_TABLE_LOAD"] = load
     cls = kmers.Classifier(A, B)
     for _ in range(3): cls.classify_device(d_b, d_o, R, flat.size, d_c)

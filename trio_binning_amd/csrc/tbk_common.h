@@ -305,8 +305,6 @@ struct TbkPairView {
     const uint64_t *slots;  // n_buckets * 16
     uint32_t n_buckets;
     TbkMz mz;               // bucket selection
-    uint32_t shared;        // 0 when no key sits in both halves (the lists are disjoint): a window then
-                            // cannot hit both tables and hapA-over-hapB priority never has to be applied
 };
 
 // ---- synthetic key sequence (bench inputs) ---------------------------------
@@ -355,3 +353,20 @@ TBK_HD uint64_t tbk_splitmix(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+
+// ---- synthetic haplotypes (bench inputs shaped like real trio-binning lists) -------------
+// An implicit random genome (base at position p = a hash of p) and two haplotypes that each
+// differ from it by SNPs at `snp24 / 2^24` per base.  The k-mers covering a position where the
+// haplotypes differ are the "haplotype-unique" lists: they come in runs of up to k overlapping
+// k-mers that share a handful of minimizers, hapA's and hapB's runs at the same loci - the
+// shape of real find-unique-kmers output, unlike tbk_synth_key's uniform keys.
+TBK_HD void tbk_hap_bases(uint64_t seed, uint64_t p, uint32_t snp24, uint32_t &base_a, uint32_t &base_b) {
+    const uint64_t r = tbk_splitmix(seed ^ (p * 0x9E3779B97F4A7C15ull));
+    const uint32_t base = (uint32_t)r & 3u;
+    const uint32_t draw_a = (uint32_t)(r >> 4) & 0xFFFFFFu, draw_b = (uint32_t)(r >> 28) & 0xFFFFFFu;
+    const uint32_t alt_a = (base + 1u + (uint32_t)((r >> 52) & 0xFFu) % 3u) & 3u;
+    const uint32_t alt_b = (base + 1u + (uint32_t)((r >> 56) & 0xFFu) % 3u) & 3u;
+    base_a = draw_a < snp24 ? alt_a : base;
+    base_b = draw_b < snp24 ? alt_b : base;
+}
+

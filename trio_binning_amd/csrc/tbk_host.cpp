@@ -28,10 +28,9 @@
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
 extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *,
-                                        unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, TbkTableView,
+                                        unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_count_present(TbkTableView, const uint64_t *, uint64_t, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, int, hipStream_t);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
@@ -125,10 +124,9 @@ struct tbk_classifier {
     uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B: [8 hapA slots | 8 hapB slots]
     uint32_t n_buckets = 0;
     uint64_t distinct_a = 0, distinct_b = 0;
-    uint64_t shared = 0;         // hapB list lines whose key is also in hapA's table
+    uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
-    bool assume_shared = false;  // TBK_ASSUME_SHARED=1: take the priority path even for disjoint lists (tests)
-    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, (shared || assume_shared) ? 1u : 0u}; }
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
     uint64_t next_ticket = 1;
@@ -189,17 +187,31 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 }
 
 // ---- tables ----------------------------------------------------------------------------
-static uint32_t buckets_for(uint64_t n_keys, double default_load) {
-    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe must be decided by
-    // one line: a lookup walks to the next bucket only when its half of the home line has no
-    // free slot.  Plain hashing: 2 keys per 8-slot half (load 0.25) leaves ~0.1% of halves
-    // full.  Minimizer bucketing clusters keys that share a minimizer, so it gets 0.8 keys per
-    // half (load 0.1; measured same-box: 137 Gbases/s against 131 at 0.125 and 137 at 0.08, the
-    // difference being windows that meet a full half).  TBK_TABLE_LOAD overrides.
-    double load = env_double("TBK_TABLE_LOAD", default_load);
+static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes) {
+    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe should be decided by
+    // one line: a lookup goes on to another bucket only when keys went past its half of the home
+    // line.  Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing clusters keys
+    // that share a minimizer, and real lists cluster further (the k overlapping k-mers around
+    // one variant share ~6 minimizers), so it gets 0.5 keys per half (load 0.0625): measured on
+    // such lists 117 Gbases/s at 0.1, 123 at 0.0625, no more below that; uniform random keys do
+    // not care (141 Gbases/s from 0.1 down to 0.04).  The table may take up to 60 % of the free
+    // HBM; bigger lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
+    double load = env_double("TBK_TABLE_LOAD", 0);
+    const bool forced = load > 0;
+    if (!forced) load = default_load;
     if (load < 0.02) load = 0.02;
     if (load > 0.9) load = 0.9;
     double want = (double)n_keys / (TBK_SLOTS_PER_BUCKET * load);
+    if (!forced) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double fit = 0.6 * (double)free_b / (double)line_bytes;
+            const double floor_ = (double)n_keys / (TBK_SLOTS_PER_BUCKET * 0.5);  // never denser than load 0.5 on our own account
+            if (want > fit) want = fit > floor_ ? fit : floor_;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     uint64_t nb = (uint64_t)want + 1;
     if (nb < 16) nb = 16;
     if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
@@ -209,23 +221,25 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load) {
 // Insert n keys into one list's slots of a table (standalone: stride 8, half 0; paired:
 // stride 16, half 0 / 8).  The slots must already be filled with TBK_EMPTY.
 static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz, uint32_t *d_overflowed,
-                       const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out) {
-    unsigned long long *d_distinct = nullptr;
+                       const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out,
+                       TbkTableView skip = TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}}, uint64_t *skipped_out = nullptr) {
+    // counters: [0] distinct keys stored, [1] keys dropped because `skip` holds them
+    unsigned long long *d_cnt = nullptr, cnt[2] = {0, 0};
     int *d_failed = nullptr;
-    hipError_t e = hipMalloc((void **)&d_distinct, sizeof(unsigned long long));
+    hipError_t e = hipMalloc((void **)&d_cnt, sizeof cnt);
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(d_distinct, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof cnt);
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
-    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_overflowed, d_distinct, d_failed, nullptr);
-    unsigned long long distinct = 0;
+    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_overflowed, skip, d_cnt, d_cnt + 1, d_failed, nullptr);
     int failed = 0;
-    if (e == hipSuccess) e = hipMemcpy(&distinct, d_distinct, sizeof distinct, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
-    if (d_distinct) (void)hipFree(d_distinct);
+    if (d_cnt) (void)hipFree(d_cnt);
     if (d_failed) (void)hipFree(d_failed);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "table insert: %s", hipGetErrorString(e));
     if (failed) return fail(TBK_ERR_HIP, "table insert overflowed (table full)");
-    *distinct_out = distinct;
+    *distinct_out = cnt[0];
+    if (skipped_out) *skipped_out = cnt[1];
     return TBK_OK;
 }
 
@@ -239,10 +253,9 @@ static int overflow_bitmap(uint64_t n_halves, uint32_t **out) {
     return TBK_OK;
 }
 
-static int finish_table(uint64_t *d_slots, uint64_t n_halves, uint32_t *d_overflowed) {
+static int order_table(uint64_t *d_slots, uint64_t n_halves, const uint32_t *d_overflowed) {
     hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(d_overflowed);
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "table order pass: %s", hipGetErrorString(e));
     return TBK_OK;
 }
@@ -252,7 +265,7 @@ static int table_hash(tbk_table *t) {
     if (t->hashed) return TBK_OK;
     int rc = use_device(t->device);
     if (rc) return rc;
-    t->n_buckets = buckets_for(t->num_lines, 0.25);
+    t->n_buckets = buckets_for(t->num_lines, 0.25, TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
     HIP_TRY(hipMalloc((void **)&t->d_slots, bytes));
     hipError_t e = hipMemset(t->d_slots, 0xFF, bytes);
@@ -261,8 +274,8 @@ static int table_hash(tbk_table *t) {
     if (!rc) rc = overflow_bitmap(t->n_buckets, &d_over);
     if (!rc) {
         rc = insert_keys(t->d_slots, t->n_buckets, 8, 0, TbkMz{0, 0, 0, 0}, d_over, t->d_keys, t->num_lines, &t->distinct);
-        const int rc2 = finish_table(t->d_slots, t->n_buckets, d_over);
-        if (!rc) rc = rc2;
+        if (!rc) rc = order_table(t->d_slots, t->n_buckets, d_over);
+        (void)hipFree(d_over);
     }
     if (rc) { (void)hipFree(t->d_slots); t->d_slots = nullptr; return rc; }
     t->hashed = true;
@@ -494,7 +507,6 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->device = a->device;
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
-    c->assume_shared = env_double("TBK_ASSUME_SHARED", 0) != 0;
     // bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
     // default 6; 0 = plain hashing of the whole key).  TBK_MOD_SAMPLING=1 samples by mod-sampling
     // instead of the random-minimizer rule: 15 % fewer HBM lines but 23 % more VALU work, a net
@@ -502,7 +514,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6), std::max(a->num_lines, b->num_lines),
                           (int)env_double("TBK_MINIMIZER_M", 0), (int)env_double("TBK_MOD_SAMPLING", 0));
     // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.1 : 0.25);
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.0625 : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
@@ -511,25 +523,20 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         delete c;
         return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
+    // hapA's list, then hapB's minus the keys hapA holds: such a key can never count for hapB
+    // (hapA is asked first, c/kmers.c:291-294), and leaving it out keeps the halves disjoint, so
+    // the probe kernel never arbitrates between them.  The order pass after each list turns
+    // "a key went past this half" into the order of the half's last two slots, which is what
+    // lookups (hapB's inserts included) read.
     uint32_t *d_over = nullptr;
     rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
     if (!rc) {
         rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a);
-        if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b);
-        const int rc2 = finish_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
-        if (!rc) rc = rc2;
-    }
-    // Are the lists disjoint (they are when they come from find-unique-kmers)?  Then no window
-    // can hit both tables and the probe kernel never has to apply hapA-over-hapB priority.
-    if (!rc && b->num_lines) {
-        unsigned long long *d_present = nullptr, present = 0;
-        e = hipMalloc((void **)&d_present, sizeof present);
-        if (e == hipSuccess) e = hipMemset(d_present, 0, sizeof present);
-        if (e == hipSuccess) e = tbk_launch_count_present(TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz}, b->d_keys, b->num_lines, d_present, nullptr);
-        if (e == hipSuccess) e = hipMemcpy(&present, d_present, sizeof present, hipMemcpyDeviceToHost);
-        if (d_present) (void)hipFree(d_present);
-        if (e != hipSuccess) rc = fail(TBK_ERR_HIP, "shared-key scan: %s", hipGetErrorString(e));
-        c->shared = present;
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
+        if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
+                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz}, &c->shared);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
+        (void)hipFree(d_over);
     }
     if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
     e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
@@ -973,6 +980,40 @@ extern "C" int tbk_synth_reads_device(int device, uint64_t read_seed, uint64_t f
     if (rc) return rc;
     HIP_TRY(tbk_launch_synth_reads(read_seed, first_read, n_reads, read_len, key_seed, n_a, n_b, k, plant_major,
                                    plant_minor, (uint8_t *)d_bases, (uint64_t *)d_offsets, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return TBK_OK;
+}
+
+extern "C" hipError_t tbk_launch_synth_hap_keys(uint64_t, uint64_t, uint32_t, int, uint64_t *, uint64_t *, uint64_t,
+                                                unsigned long long *, hipStream_t);
+extern "C" hipError_t tbk_launch_synth_hap_reads(uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t, uint32_t, uint32_t,
+                                                 uint8_t *, uint64_t *, hipStream_t);
+
+extern "C" int tbk_synth_hap_keys_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24, int k,
+                                         void *d_keys_a, void *d_keys_b, uint64_t capacity, uint64_t *n_keys) {
+    if (k < 3 || k > 32 || genome_len < (uint64_t)k || !d_keys_a || !d_keys_b || !n_keys) return fail(TBK_ERR_INVALID, "bad synth parameters");
+    int rc = use_device(device);
+    if (rc) return rc;
+    unsigned long long *d_n = nullptr, n = 0;
+    HIP_TRY(hipMalloc((void **)&d_n, sizeof n));
+    hipError_t e = hipMemset(d_n, 0, sizeof n);
+    if (e == hipSuccess) e = tbk_launch_synth_hap_keys(seed, genome_len, snp_per_2p24, k, (uint64_t *)d_keys_a, (uint64_t *)d_keys_b, capacity, d_n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&n, d_n, sizeof n, hipMemcpyDeviceToHost);
+    (void)hipFree(d_n);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "tbk_synth_hap_keys_device: %s", hipGetErrorString(e));
+    *n_keys = n;  // may exceed capacity: only the first `capacity` were written
+    return TBK_OK;
+}
+
+extern "C" int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24,
+                                          uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                          uint32_t err_per_2p24, void *d_bases, void *d_offsets) {
+    if (genome_len < read_len || !read_len) return fail(TBK_ERR_INVALID, "bad synth parameters");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(TBK_ERR_INVALID, "d_bases must be 16-byte aligned");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(tbk_launch_synth_hap_reads(seed, genome_len, snp_per_2p24, read_seed, first_read, n_reads, read_len, err_per_2p24,
+                                       (uint8_t *)d_bases, (uint64_t *)d_offsets, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     return TBK_OK;
 }

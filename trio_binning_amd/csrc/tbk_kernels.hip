@@ -17,6 +17,20 @@
 // =======================================================================================
 // insert
 // =======================================================================================
+// Membership of one key, one thread, whole lines (build-time scans and tests; not the hot path).
+__device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t key) {
+    if (key >= TBK_NOKEY) return false;
+    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
+    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+        const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
+        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
+            if (line[s] == key) return true;
+        if (!(line[6] > line[7])) return false;  // no key went past this half
+        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
+    }
+    return false;
+}
+
 // One key per thread.  Scan this list's 8 slots of the home bucket; claim the first free
 // slot with a 64-bit CAS; a bucket half without a free slot sends the key to the next
 // bucket.  Duplicates are detected (the reference stores them twice, c/kmers.c:112-122;
@@ -24,15 +38,20 @@
 // hapB half of a paired table (16, 0 / 8).
 __global__ void __launch_bounds__(256)
 tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                  const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed,
-                  unsigned long long *__restrict__ n_distinct, int *__restrict__ failed) {
+                  const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed, TbkTableView skip,
+                  unsigned long long *__restrict__ n_distinct, unsigned long long *__restrict__ n_skipped,
+                  int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET, which = half / TBK_SLOTS_PER_BUCKET;
-    unsigned long long mine = 0;
+    unsigned long long mine = 0, skipped = 0;
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;  // TBK_EMPTY / TBK_NOKEY: never a canonical key, never stored
+        // hapB's list going into a paired table: a key that hapA's (finished) half already holds can
+        // never count for hapB (hapA is asked first, c/kmers.c:291-294), so it is not stored and the
+        // two halves stay disjoint - the probe kernel never has to arbitrate between them
+        if (skip.slots != nullptr && tbk_lookup_slow(skip, key)) { skipped++; continue; }
         // the buckets a lookup of this key may select: one, except when mod-sampling finds the
         // smallest t-mer rank at several positions of the key (then one per tied position)
         uint32_t cand[16];
@@ -66,6 +85,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
         }
     }
     if (mine) atomicAdd(n_distinct, mine);
+    if (skipped) atomicAdd(n_skipped, skipped);
 }
 
 // After all inserts: give every full half the order of its last two slots that says whether a key
@@ -81,38 +101,12 @@ tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t
     if ((v.x > v.y) != past) *last = make_ulonglong2(v.y, v.x);
 }
 
-// Membership of one key, one thread, whole lines (build-time scans and tests; not the hot path).
-__device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t key) {
-    if (key >= TBK_NOKEY) return false;
-    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
-    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
-        const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
-        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
-            if (line[s] == key) return true;
-        if (!(line[6] > line[7])) return false;  // no key went past this half
-        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
-    }
-    return false;
-}
-
 __global__ void __launch_bounds__(256)
 tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t n,
                     uint8_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = tbk_lookup_slow(t, keys[i]) ? 1 : 0;
-}
-
-// How many of `keys` sit in this table (grid-stride).  The classifier runs it once at build time,
-// hapB's list against the hapA half: zero means no window can ever hit both tables.
-__global__ void __launch_bounds__(256)
-tbk_count_present_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t n,
-                         unsigned long long *__restrict__ n_present) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long mine = 0;
-    for (; i < n; i += step) mine += tbk_lookup_slow(t, keys[i]) ? 1 : 0;
-    if (mine) atomicAdd(n_present, mine);
 }
 
 // =======================================================================================
@@ -249,19 +243,18 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 }
 
 // ---- deferred walks --------------------------------------------------------------------
-// A lookup whose home half is full and does not hold the key must walk on to the next bucket
-// (linear probing at line granularity).  Doing that inside the window loop would stall the
-// wave on one dependent HBM access per walk, and on lists shaped like real data (keys in runs
-// of overlapping k-mers that share a minimizer) a noticeable share of halves is full.  So
-// the loop only ENQUEUES such lookups in a per-wave LDS queue; drain_walks resolves them 64
-// at a time, one lane per lookup, so that the latency of a walk step is paid once per 64
-// walks.  hapA priority (c/kmers.c:291-294) is applied there: a queued lookup counts for
-// hapA if the hapA walk finds the key, else for hapB if hapB's home half held it or the
-// hapB walk finds it.
+// A lookup that misses in a home half some key went past must follow the key's probe sequence
+// (tbk_next_bucket).  Doing that inside the window loop would stall the wave on one dependent
+// HBM access per walk, and on lists shaped like real data (keys in runs of overlapping k-mers
+// that share a minimizer) a noticeable share of halves overflows.  So the loop only ENQUEUES
+// such lookups in a per-wave LDS queue; drain_walks resolves them 64 at a time, one lane per
+// lookup, so that the latency of a walk step is paid once per 64 walks.  The halves are
+// disjoint, so a queued lookup counts for hapA if the hapA walk finds the key, else for hapB if
+// the hapB walk does.
 constexpr int TBK_QCAP = 128;  // queue entries per wave; a window-loop step adds at most 64
 
 // entry: x = key low, y = key high, z = home bucket, w = flags | (read - first read of pass) << 3
-enum { WQ_WALK_A = 1, WQ_WALK_B = 2, WQ_HIT_B = 4 };
+enum { WQ_WALK_A = 1, WQ_WALK_B = 2 };
 
 // follow the probe sequence of a key of list `half` (0 hapA, 8 hapB) past its home bucket, until the
 // key is found or a half that no key went past
@@ -292,8 +285,7 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
         if (act) it = q[base + lane];
         const uint64_t key = (uint64_t)it.x | ((uint64_t)it.y << 32);
         const bool in_a = walk_one(p.t, 0, key, it.z, act && (it.w & WQ_WALK_A));
-        const bool walked_b = walk_one(p.t, 8, key, it.z, act && !in_a && !(it.w & WQ_HIT_B) && (it.w & WQ_WALK_B));
-        const bool in_b = (it.w & WQ_HIT_B) || walked_b;
+        const bool in_b = walk_one(p.t, 8, key, it.z, act && !in_a && (it.w & WQ_WALK_B));
         const bool count_a = act && in_a, count_b = act && !in_a && in_b;
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(ballot(count_a));
@@ -514,10 +506,11 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             }
         }
 
-        // Fast path.  A key is stored at most once per table, so the raw ballots count
-        // windows.  A half is full exactly when its last slot (held by quad lane 3) is
-        // occupied; only then may a miss have to walk on.  hapA/hapB priority only matters
-        // when both tables report a hit.  Anything else goes to the exact path.
+        // Fast path.  A key is stored at most once, in one of the two halves (hapB keys that hapA
+        // holds are dropped at build time), so the raw ballots count windows and hapA-over-hapB
+        // priority (c/kmers.c:291-294) needs no work here.  Only a window whose home half was left
+        // by some key (slot 6 > slot 7, held by quad lane 3) may have to look further; those go
+        // to the exact path.
         uint64_t hit_a[4], hit_b[4], full_a[4], full_b[4], full_any = 0, any_a = 0, any_b = 0;
         uint64_t kk[4];
 #pragma unroll
@@ -535,29 +528,28 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             any_b |= hit_b[s];
         }
         TBK_COUNT(0, 1);
-        if (full_any != 0 || (p.t.shared != 0 && any_a != 0 && any_b != 0)) {
+        if (full_any != 0) {
             TBK_COUNT(1, 1);
-            // Careful path: per-window (= per-quad) resolution.  Everything is brought to the
-            // quad's lane-0 bit.  Hits in the home line are final for hapA; a hapB hit is final
-            // unless hapA still has to walk.  Lookups that must walk are queued.
+            // Careful path: per-window (= per-quad) resolution, everything brought to the quad's
+            // lane-0 bit.  A hit in the home line is final (the halves are disjoint: the other list
+            // cannot hold the key); a miss in a half that keys went past is queued for a walk.
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if ((full_a[s] | full_b[s]) == 0 && (p.t.shared == 0 || hit_a[s] == 0 || hit_b[s] == 0)) continue;  // raw ballots are already exact
+                if ((full_a[s] | full_b[s]) == 0) continue;  // raw ballots are already exact
                 const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
                 TBK_COUNT(2, 1);
                 const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
-                uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
-                uint64_t walk_a = valid & fa, walk_b = valid & fb;
-                walk_a &= ~ha;
-                walk_b &= ~hb & ~ha;
+                const uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
+                const uint64_t walk_a = valid & fa & ~(ha | hb);
+                const uint64_t walk_b = valid & fb & ~(ha | hb);
                 const uint64_t queued = walk_a | walk_b;
                 hit_a[s] = ha;
-                hit_b[s] = hb & ~ha & ~queued;  // a queued window's hapB hit travels with it
+                hit_b[s] = hb;
                 if (queued) {
                     const uint64_t me = 1ull << lane;
                     if (queued & me) {
                         const uint32_t slot = qn + (uint32_t)__popcll(queued & (me - 1));
-                        const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0) | ((hb & me) ? WQ_HIT_B : 0);
+                        const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0);
                         const uint32_t rrel = MULTI ? (uint32_t)(ridq[s] - (uint32_t)r_first) : 0u;
                         walkq[slot] = make_uint4(klo[s], khi[s], bk[s], flags | (rrel << 3));
                     }
@@ -652,13 +644,14 @@ tbk_probe_kernel(const ProbeArgs p) {
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                                        const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed,
-                                        unsigned long long *d_distinct, int *d_failed, hipStream_t stream) {
+                                        const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, TbkTableView skip,
+                                        unsigned long long *d_distinct, unsigned long long *d_skipped, int *d_failed,
+                                        hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
-                       half, mz, d_keys, n, d_overflowed, d_distinct, d_failed);
+                       half, mz, d_keys, n, d_overflowed, skip, d_distinct, d_skipped, d_failed);
     return hipGetLastError();
 }
 
@@ -674,15 +667,6 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(tbk_contains_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t,
                        d_keys, n, d_out);
-    return hipGetLastError();
-}
-
-extern "C" hipError_t tbk_launch_count_present(TbkTableView t, const uint64_t *d_keys, uint64_t n,
-                                               unsigned long long *d_present, hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    uint64_t blocks = (n + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(tbk_count_present_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, t, d_keys, n, d_present);
     return hipGetLastError();
 }
 

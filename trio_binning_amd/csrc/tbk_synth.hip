@@ -99,6 +99,91 @@ tbk_synth_plant_kernel(uint64_t read_seed, uint64_t first_read, uint64_t n_reads
 }
 
 // ---------------------------------------------------------------------------------------
+// haplotype-shaped lists and reads (tbk_hap_bases)
+// ---------------------------------------------------------------------------------------
+// One thread scans SEG consecutive k-mer start positions of the genome with rolling k-mers of
+// both haplotypes and emits, for every window that covers a position where they differ, hapA's
+// canonical k-mer to list A and hapB's to list B (same index: the lists have equal length).
+// Appends are wave-aggregated (one atomic per wave-iteration).  Order is not deterministic, the
+// sets are.
+constexpr int TBK_HAP_SEG = 64;
+__global__ void __launch_bounds__(256)
+tbk_synth_hap_keys_kernel(uint64_t seed, uint64_t genome_len, uint32_t snp24, int k, uint64_t *__restrict__ out_a,
+                          uint64_t *__restrict__ out_b, uint64_t capacity, unsigned long long *__restrict__ n_out) {
+    const uint64_t n_windows = genome_len - (uint64_t)k + 1;
+    const uint64_t n_seg = (n_windows + TBK_HAP_SEG - 1) / TBK_HAP_SEG;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t lane = threadIdx.x & 63u;
+    // whole waves iterate together (the append is a wave operation): segment index per lane
+    for (uint64_t seg0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x - lane); seg0 < n_seg; seg0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t seg = seg0 + lane;
+        const uint64_t q0 = seg * TBK_HAP_SEG;
+        uint64_t fa = 0, ra = 0, fb = 0, rb = 0;
+        uint32_t since_diff = 0x7FFFFFFFu;  // positions since the haplotypes last differed
+        for (int i = 0; i < TBK_HAP_SEG + k - 1; i++) {
+            const uint64_t p = q0 + (uint64_t)i;
+            uint32_t a = 0, b = 0;
+            const bool in = seg < n_seg && p < genome_len;
+            if (in) tbk_hap_bases(seed, p, snp24, a, b);
+            // base i of a k-mer at bits 2i (LSB first): the window's newest base enters at the top
+            fa = (fa >> 2) | ((uint64_t)a << (2 * (k - 1)));
+            fb = (fb >> 2) | ((uint64_t)b << (2 * (k - 1)));
+            ra = ((ra << 2) | (uint64_t)(3u - a)) & kmask;
+            rb = ((rb << 2) | (uint64_t)(3u - b)) & kmask;
+            since_diff = (in && a != b) ? 0u : (since_diff < 0x7FFFFFFFu ? since_diff + 1u : since_diff);
+            const bool emit = in && i >= k - 1 && since_diff < (uint32_t)k;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
+            if (mask) {
+                unsigned long long base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(n_out, (unsigned long long)__popcll(mask));
+                base = __shfl(base, __builtin_ctzll(mask));
+                if (emit) {
+                    const uint64_t at = base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+                    if (at < capacity) {
+                        out_a[at] = fa < ra ? fa : ra;
+                        out_b[at] = fb < rb ? fb : rb;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Reads drawn from the haplotypes: read r comes from haplotype r & 1, from a hashed start
+// position, on a hashed strand, with substitution errors at err24 / 2^24 per base.  One thread
+// writes 16 bases.
+__global__ void __launch_bounds__(256)
+tbk_synth_hap_reads_kernel(uint64_t seed, uint64_t genome_len, uint32_t snp24, uint64_t read_seed, uint64_t first_read,
+                           uint64_t n_reads, uint32_t read_len, uint32_t err24, uint8_t *__restrict__ bases) {
+    const uint64_t total = n_reads * (uint64_t)read_len;
+    const uint64_t n_chunks = (total + 15) / 16;
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; c < n_chunks; c += stride) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16; j++) {
+            const uint64_t pos = c * 16 + (uint64_t)j;
+            uint32_t code = 0;
+            if (pos < total) {
+                const uint64_t r = pos / read_len, i = pos % read_len;
+                const uint64_t rr = tbk_splitmix(read_seed ^ ((first_read + r) * 0xA0761D6478BD642Full));
+                const uint64_t start = (rr >> 1) % (genome_len - (uint64_t)read_len + 1);
+                const bool rev = rr & 1ull;
+                const uint64_t p = rev ? start + (uint64_t)read_len - 1 - i : start + i;
+                uint32_t a, b;
+                tbk_hap_bases(seed, p, snp24, a, b);
+                code = ((first_read + r) & 1ull) ? b : a;
+                if (rev) code = 3u - code;
+                const uint64_t e = tbk_splitmix(read_seed ^ 0x5851F42D4C957F2Dull ^ ((first_read * read_len + pos) * 0xD6E8FEB86659FD93ull));
+                if (((uint32_t)e & 0xFFFFFFu) < err24) code = (code + 1u + (uint32_t)((e >> 32) % 3u)) & 3u;
+            }
+            w[j >> 2] |= ((0x54474341u >> (8 * code)) & 0xFFu) << (8 * (j & 3));
+        }
+        reinterpret_cast<uint4 *>(bases)[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // calibration: random line gather and streaming read
 // ---------------------------------------------------------------------------------------
 // LPL lanes share one line (16 B per lane when LPL > 1; the whole line per lane when
@@ -191,6 +276,26 @@ extern "C" hipError_t tbk_launch_synth_reads(uint64_t read_seed, uint64_t first_
         hipLaunchKernelGGL(tbk_synth_plant_kernel, dim3((unsigned)((n_plant + 255) / 256)), dim3(256), 0, s,
                            read_seed, first_read, n_reads, read_len, key_seed, n_a, n_b, k, major, minor,
                            d_bases);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_synth_hap_keys(uint64_t seed, uint64_t genome_len, uint32_t snp24, int k, uint64_t *d_a,
+                                                uint64_t *d_b, uint64_t capacity, unsigned long long *d_n, hipStream_t s) {
+    const uint64_t n_seg = (genome_len - (uint64_t)k + 1 + TBK_HAP_SEG - 1) / TBK_HAP_SEG;
+    hipLaunchKernelGGL(tbk_synth_hap_keys_kernel, dim3(grid_for(n_seg)), dim3(256), 0, s, seed, genome_len, snp24, k, d_a, d_b,
+                       capacity, d_n);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_synth_hap_reads(uint64_t seed, uint64_t genome_len, uint32_t snp24, uint64_t read_seed,
+                                                 uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint32_t err24,
+                                                 uint8_t *d_bases, uint64_t *d_offsets, hipStream_t s) {
+    if (!n_reads) return hipSuccess;
+    const uint64_t n_chunks = (n_reads * (uint64_t)read_len + 15) / 16;
+    hipLaunchKernelGGL(tbk_synth_hap_reads_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, s, seed, genome_len, snp24, read_seed,
+                       first_read, n_reads, read_len, err24, d_bases);
+    hipLaunchKernelGGL(tbk_synth_offsets_kernel, dim3((unsigned)((n_reads + 256) / 256)), dim3(256), 0, s,
+                       n_reads, read_len, d_offsets);
     return hipGetLastError();
 }
 
