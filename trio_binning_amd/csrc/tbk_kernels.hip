@@ -276,9 +276,21 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
     return found;
 }
 
+// Hits of a pass that touches several reads: every lane counts the hits of its own windows while
+// they stay in one read and hands the sum to the wave's per-read tallies in LDS (reads r_first ..
+// r_first + TBK_RCNT - 1, flushed with one global atomic per read at the end of the pass; reads
+// beyond that - passes full of tiny reads - go straight to the global counters).  One global
+// atomic per hit would serialise on two addresses per read: on data with dense hits the 14 % of
+// passes that straddle a read end then cost 7 % of the whole run.
+constexpr int TBK_RCNT = 64;
+__device__ __forceinline__ void count_hits(const ProbeArgs &p, uint32_t *rcnt, uint64_t r_first, uint32_t rrel, uint32_t hap, uint32_t n) {
+    if (rrel < (uint32_t)TBK_RCNT) atomicAdd(&rcnt[2 * rrel + hap], n);
+    else atomicAdd(&p.counts[2 * (r_first + rrel) + hap], (int)n);
+}
+
 template <bool MULTI>
 __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, uint32_t qn, uint64_t r_first,
-                                            uint32_t lane, uint32_t &acc_a, uint32_t &acc_b) {
+                                            uint32_t lane, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     for (uint32_t base = 0; base < qn; base += 64) {
         const bool act = base + lane < qn;
         uint4 it = make_uint4(0, 0, 0, 0);
@@ -291,9 +303,8 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
             acc_a += (uint32_t)__popcll(ballot(count_a));
             acc_b += (uint32_t)__popcll(ballot(count_b));
         } else {
-            const uint64_t rid = r_first + (it.w >> 3);
-            if (count_a) atomicAdd(&p.counts[2 * rid], 1);
-            if (count_b) atomicAdd(&p.counts[2 * rid + 1], 1);
+            if (count_a) count_hits(p, rcnt, r_first, it.w >> 3, 0, 1);
+            if (count_b) count_hits(p, rcnt, r_first, it.w >> 3, 1, 1);
         }
     }
 }
@@ -304,7 +315,7 @@ template <int W, bool M64, bool SAMP, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                           uint4 *walkq) {
+                                           uint4 *walkq, uint32_t *rcnt) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
@@ -407,6 +418,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     };
     uint32_t rel_end = rel(rend);
     uint32_t acc_a = 0, acc_b = 0;  // wave-uniform in the single-read case
+    uint32_t lane_a = 0, lane_b = 0;  // multi-read pass: this lane's hits in read `rid`
 
     // the line each quad slot holds from the previous window of the same lane
     uint32_t held[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -430,6 +442,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (MULTI) {
             // window j starts at or past the current read's end: move to the read that holds it
             while ((uint32_t)j >= rel_end && rid < p.n_reads) {
+                // hand the finished read's hits to the wave's per-read tallies
+                if (lane_a) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a); lane_a = 0; }
+                if (lane_b) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b); lane_b = 0; }
                 rid++;
                 rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
                 rel_end = rel(rend);
@@ -486,11 +501,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
 
         // ---- four quad sub-steps: the quad's 4 windows, one 128-byte line each ----------
-        uint32_t klo[4], khi[4], bk[4], ridq[4];
+        uint32_t klo[4], khi[4], bk[4];
 #define TBK_BCAST(S)                                                        \
         klo[S] = quad_bcast<S>(my_klo); khi[S] = quad_bcast<S>(my_khi);     \
-        bk[S] = quad_bcast<S>(my_bk);                                       \
-        if (MULTI) ridq[S] = quad_bcast<S>(my_rid);
+        bk[S] = quad_bcast<S>(my_bk);
         TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
 #undef TBK_BCAST
 #pragma unroll
@@ -547,10 +561,14 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 hit_b[s] = hb;
                 if (queued) {
                     const uint64_t me = 1ull << lane;
+                    // the read of the window: its owner is quad lane s (a constant once unrolled); taken
+                    // here, where the whole wave is active - a DPP move cannot read a masked-off lane
+                    const uint32_t rid_s = !MULTI ? 0u : s == 0 ? quad_bcast<0>(my_rid) : s == 1 ? quad_bcast<1>(my_rid)
+                                                   : s == 2 ? quad_bcast<2>(my_rid) : quad_bcast<3>(my_rid);
                     if (queued & me) {
                         const uint32_t slot = qn + (uint32_t)__popcll(queued & (me - 1));
                         const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0);
-                        const uint32_t rrel = MULTI ? (uint32_t)(ridq[s] - (uint32_t)r_first) : 0u;
+                        const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
                         walkq[slot] = make_uint4(klo[s], khi[s], bk[s], flags | (rrel << 3));
                     }
                     qn += (uint32_t)__popcll(queued);
@@ -566,30 +584,46 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                     acc_b += (uint32_t)__popcll(hit_b[s]);
                 }
             } else {
-                const uint64_t me = 1ull << lane;  // the matching lane (or quad lane 0) reports
+                // Bring each window's verdict to the bit of the lane that owns it (quad q's sub-step s
+                // window belongs to lane 4q + s) and let every lane count its own windows: its 32
+                // windows nearly always lie in one read, so the hits travel to the tallies once per
+                // read and lane, not once per hit.
+                uint64_t wa = 0, wb = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if (hit_a[s] & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s]], 1);
-                    if (hit_b[s] & me) atomicAdd(&p.counts[2 * (uint64_t)ridq[s] + 1], 1);
+                    wa |= quad_any(hit_a[s]) << s;
+                    wb |= quad_any(hit_b[s]) << s;
                 }
+                lane_a += (uint32_t)(wa >> lane) & 1u;
+                lane_b += (uint32_t)(wb >> lane) & 1u;
             }
         }
         if (qn > TBK_QCAP - 64) {  // make room for the next step's worst case
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b);
+            drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qn = 0;
         }
     }
     if (qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b);
+        drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #ifdef TBK_COUNTERS
     if (lane == 0)
         for (int i = 0; i < 8; i++) if (dbg[i]) atomicAdd(&tbk_dbg[i], dbg[i]);
 #endif
+    if (MULTI) {
+        if (lane_a) count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a);
+        if (lane_b) count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b);
+        // flush the per-read tallies: lane l owns read r_first + l
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t ca = rcnt[2 * lane], cb = rcnt[2 * lane + 1];
+        if (ca) { atomicAdd(&p.counts[2 * (r_first + lane)], (int)ca); rcnt[2 * lane] = 0; }
+        if (cb) { atomicAdd(&p.counts[2 * (r_first + lane) + 1], (int)cb); rcnt[2 * lane + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (!MULTI) {
         if (lane == 0) {
             if (acc_a) atomicAdd(&p.counts[2 * r_first], (int)acc_a);
@@ -618,9 +652,11 @@ tbk_probe_kernel(const ProbeArgs p) {
     // other (no s_barrier in this kernel).
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP];
+    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][2 * TBK_RCNT];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t passes_per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
+    rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0;  // per-read tallies of multi-read passes (zero between passes)
 
     for (uint64_t pass = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; pass < p.n_passes; pass += passes_per_iter) {
         const uint64_t P0 = pass * TBK_PASS;
@@ -635,8 +671,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
-        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave]);
+        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave]);
+        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave]);
     }
 }
 
