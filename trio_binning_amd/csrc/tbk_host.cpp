@@ -214,7 +214,7 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
     }
     uint64_t nb = (uint64_t)want + 1;
     if (nb < 16) nb = 16;
-    if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
+    if (nb > 0x7FFFFFF0ull) nb = 0x7FFFFFF0ull;  // bit 31 of a bucket index is a flag inside the probe kernel
     return (uint32_t)nb;
 }
 

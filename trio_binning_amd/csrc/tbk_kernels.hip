@@ -264,10 +264,15 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
             bucket = tbk_next_bucket(key, t.mz, t.n_buckets, bucket, first);
+            // 16 bytes at a time: this rare path must not set the kernel's register high-water mark
             const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
-            const ulonglong2 v0 = h[0], v1 = h[1], v2 = h[2], v3 = h[3];
-            const bool hit = v0.x == key || v0.y == key || v1.x == key || v1.y == key || v2.x == key || v2.y == key ||
-                             v3.x == key || v3.y == key;
+            bool hit = false;
+            ulonglong2 v3 = make_ulonglong2(0, 0);
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                v3 = h[i];
+                hit = hit || v3.x == key || v3.y == key;
+            }
             found = found || hit;
             pend = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
         }
@@ -421,11 +426,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     uint32_t lane_a = 0, lane_b = 0;  // multi-read pass: this lane's hits in read `rid`
 
     // the line each quad slot holds from the previous window of the same lane
-    uint32_t held[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     ulonglong2 va[4], vb[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
-    uint32_t last_bk = 0xFFFFFFFFu;  // bucket of this lane's previous valid window
+    uint32_t last_bk = 0x7FFFFFFFu;  // bucket of this lane's previous valid window (none yet)
     uint32_t qn = 0;                 // queued walks (wave-uniform)
 #ifdef TBK_COUNTERS
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -489,8 +493,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         }
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
         // TBK_NOKEY, which is never stored (it can never hit)
-        const uint32_t my_bk = ok ? tbk_reduce(hsel, p.t.n_buckets) : last_bk;
-        last_bk = my_bk;
+        // Bit 31 of the broadcast bucket says "not the bucket of this lane's previous window": only
+        // then do the quad's lanes fetch the line; otherwise they still hold it.  (Bucket indices stay
+        // below 2^31: 2^31 lines would be a 256 GB table.)
+        const uint32_t bkt = tbk_reduce(hsel, p.t.n_buckets);
+        const bool fresh = ok && bkt != last_bk;
+        const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
+        last_bk = my_bk & 0x7FFFFFFFu;
         const uint32_t my_klo = ok ? (uint32_t)key : (uint32_t)TBK_NOKEY;
         const uint32_t my_khi = ok ? (uint32_t)(key >> 32) : (uint32_t)(TBK_NOKEY >> 32);
         const uint32_t my_rid = (uint32_t)rid;
@@ -502,21 +511,16 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 
         // ---- four quad sub-steps: the quad's 4 windows, one 128-byte line each ----------
         uint32_t klo[4], khi[4], bk[4];
-#define TBK_BCAST(S)                                                        \
-        klo[S] = quad_bcast<S>(my_klo); khi[S] = quad_bcast<S>(my_khi);     \
-        bk[S] = quad_bcast<S>(my_bk);
-        TBK_BCAST(0) TBK_BCAST(1) TBK_BCAST(2) TBK_BCAST(3)
-#undef TBK_BCAST
+        bk[0] = quad_bcast<0>(my_bk); bk[1] = quad_bcast<1>(my_bk); bk[2] = quad_bcast<2>(my_bk); bk[3] = quad_bcast<3>(my_bk);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             // fetch only when this window's line differs from the one the slot already holds
             // (minimizer mode: consecutive windows mostly share it)
-            TBK_COUNT(4, __popcll(ballot(bk[s] != held[s])));
-            if (bk[s] != held[s]) {
-                const uint64_t *line = p.t.slots + (uint64_t)bk[s] * 16 + sub * 2;
+            TBK_COUNT(4, __popcll(ballot((int32_t)bk[s] < 0)));
+            if ((int32_t)bk[s] < 0) {
+                const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
                 va[s] = *reinterpret_cast<const ulonglong2 *>(line);
                 vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
-                held[s] = bk[s];
             }
         }
 
@@ -525,6 +529,8 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         // priority (c/kmers.c:291-294) needs no work here.  Only a window whose home half was left
         // by some key (slot 6 > slot 7, held by quad lane 3) may have to look further; those go
         // to the exact path.
+        klo[0] = quad_bcast<0>(my_klo); khi[0] = quad_bcast<0>(my_khi); klo[1] = quad_bcast<1>(my_klo); khi[1] = quad_bcast<1>(my_khi);
+        klo[2] = quad_bcast<2>(my_klo); khi[2] = quad_bcast<2>(my_khi); klo[3] = quad_bcast<3>(my_klo); khi[3] = quad_bcast<3>(my_khi);
         uint64_t hit_a[4], hit_b[4], full_a[4], full_b[4], full_any = 0, any_a = 0, any_b = 0;
         uint64_t kk[4];
 #pragma unroll
@@ -569,7 +575,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                         const uint32_t slot = qn + (uint32_t)__popcll(queued & (me - 1));
                         const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0);
                         const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
-                        walkq[slot] = make_uint4(klo[s], khi[s], bk[s], flags | (rrel << 3));
+                        walkq[slot] = make_uint4(klo[s], khi[s], bk[s] & 0x7FFFFFFFu, flags | (rrel << 3));
                     }
                     qn += (uint32_t)__popcll(queued);
                     TBK_COUNT(3, __popcll(queued));
