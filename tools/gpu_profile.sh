@@ -6,6 +6,8 @@ export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 ( time timeout 1500 python bench.py ) > gpurun_out/bench_default.log 2>&1
 tail -4 gpurun_out/bench_default.log
+( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1
+tail -4 gpurun_out/bench_haplotypes.log
 export TBK_SKIP_BUILD=1
 R=$GRAFT_REPO_ROOT
 cd /tmp

@@ -251,10 +251,9 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 // lookup, so that the latency of a walk step is paid once per 64 walks.  The halves are
 // disjoint, so a queued lookup counts for hapA if the hapA walk finds the key, else for hapB if
 // the hapB walk does.
-constexpr int TBK_QCAP = 128;  // queue entries per wave; a window-loop step adds at most 64
+constexpr int TBK_QCAP = 256;  // queue entries per wave; a window-loop step adds at most 128
 
-// entry: x = key low, y = key high, z = home bucket, w = flags | (read - first read of pass) << 3
-enum { WQ_WALK_A = 1, WQ_WALK_B = 2 };
+// entry: x = key low, y = key high, z = home bucket, w = list (0 hapA, 1 hapB) | (read - first read of pass) << 1
 
 // follow the probe sequence of a key of list `half` (0 hapA, 8 hapB) past its home bucket, until the
 // key is found or a half that no key went past
@@ -264,14 +263,15 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
             bucket = tbk_next_bucket(key, t.mz, t.n_buckets, bucket, first);
-            // 16 bytes at a time: this rare path must not set the kernel's register high-water mark
+            // 32 bytes at a time: this rare path must not set the kernel's register high-water mark
             const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
             bool hit = false;
             ulonglong2 v3 = make_ulonglong2(0, 0);
 #pragma unroll 1
-            for (int i = 0; i < 4; i++) {
-                v3 = h[i];
-                hit = hit || v3.x == key || v3.y == key;
+            for (int i = 0; i < 4; i += 2) {
+                const ulonglong2 v2 = h[i];
+                v3 = h[i + 1];
+                hit = hit || v2.x == key || v2.y == key || v3.x == key || v3.y == key;
             }
             found = found || hit;
             pend = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
@@ -301,15 +301,14 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
         uint4 it = make_uint4(0, 0, 0, 0);
         if (act) it = q[base + lane];
         const uint64_t key = (uint64_t)it.x | ((uint64_t)it.y << 32);
-        const bool in_a = walk_one(p.t, 0, key, it.z, act && (it.w & WQ_WALK_A));
-        const bool in_b = walk_one(p.t, 8, key, it.z, act && !in_a && (it.w & WQ_WALK_B));
-        const bool count_a = act && in_a, count_b = act && !in_a && in_b;
+        const bool found = walk_one(p.t, (it.w & 1u) * 8u, key, it.z, act);
+        const bool count_a = found && !(it.w & 1u), count_b = found && (it.w & 1u);
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(ballot(count_a));
             acc_b += (uint32_t)__popcll(ballot(count_b));
         } else {
-            if (count_a) count_hits(p, rcnt, r_first, it.w >> 3, 0, 1);
-            if (count_b) count_hits(p, rcnt, r_first, it.w >> 3, 1, 1);
+            if (count_a) count_hits(p, rcnt, r_first, it.w >> 1, 0, 1);
+            if (count_b) count_hits(p, rcnt, r_first, it.w >> 1, 1, 1);
         }
     }
 }
@@ -559,25 +558,24 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
                 TBK_COUNT(2, 1);
                 const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
-                const uint64_t ha = quad_any(hit_a[s]), hb = quad_any(hit_b[s]);
-                const uint64_t walk_a = valid & fa & ~(ha | hb);
-                const uint64_t walk_b = valid & fb & ~(ha | hb);
+                const uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s]);  // a hit in either half is final
+                const uint64_t walk_a = miss & fa, walk_b = miss & fb;
                 const uint64_t queued = walk_a | walk_b;
-                hit_a[s] = ha;
-                hit_b[s] = hb;
                 if (queued) {
                     const uint64_t me = 1ull << lane;
                     // the read of the window: its owner is quad lane s (a constant once unrolled); taken
                     // here, where the whole wave is active - a DPP move cannot read a masked-off lane
                     const uint32_t rid_s = !MULTI ? 0u : s == 0 ? quad_bcast<0>(my_rid) : s == 1 ? quad_bcast<1>(my_rid)
                                                    : s == 2 ? quad_bcast<2>(my_rid) : quad_bcast<3>(my_rid);
+                    // one queue entry per (window, list) so that a window's two walks run side by side
+                    const uint32_t n_a = (uint32_t)__popcll(walk_a);
                     if (queued & me) {
-                        const uint32_t slot = qn + (uint32_t)__popcll(queued & (me - 1));
-                        const uint32_t flags = ((walk_a & me) ? WQ_WALK_A : 0) | ((walk_b & me) ? WQ_WALK_B : 0);
                         const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
-                        walkq[slot] = make_uint4(klo[s], khi[s], bk[s] & 0x7FFFFFFFu, flags | (rrel << 3));
+                        const uint32_t home = bk[s] & 0x7FFFFFFFu;
+                        if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(klo[s], khi[s], home, rrel << 1);
+                        if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(klo[s], khi[s], home, (rrel << 1) | 1u);
                     }
-                    qn += (uint32_t)__popcll(queued);
+                    qn += n_a + (uint32_t)__popcll(walk_b);
                     TBK_COUNT(3, __popcll(queued));
                 }
             }
@@ -604,7 +602,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 lane_b += (uint32_t)(wb >> lane) & 1u;
             }
         }
-        if (qn > TBK_QCAP - 64) {  // make room for the next step's worst case
+        if (qn > TBK_QCAP - 128) {  // make room for the next step's worst case
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
