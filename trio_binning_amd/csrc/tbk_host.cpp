@@ -192,10 +192,11 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
     // one line: a lookup goes on to another bucket only when keys went past its half of the home
     // line.  Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing clusters keys
     // that share a minimizer, and real lists cluster further (the k overlapping k-mers around
-    // one variant share ~6 minimizers), so it gets 0.5 keys per half (load 0.0625): measured on
-    // such lists 117 Gbases/s at 0.1, 123 at 0.0625, no more below that; uniform random keys do
-    // not care (141 Gbases/s from 0.1 down to 0.04).  The table may take up to 60 % of the free
-    // HBM; bigger lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
+    // one variant share ~6 minimizers, in both lists at once), so it gets 0.32 keys per half (load
+    // 0.04; 2 x 3e8 keys = 120 GB): measured on haplotype-shaped lists at that scale 118-125
+    // Gbases/s at 0.0625, 131 at 0.04 and 0.03, 134 at 0.025; uniform random keys do not care
+    // (141 Gbases/s from 0.1 down to 0.03).  The table may take up to 60 % of the free HBM; bigger
+    // lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
     double load = env_double("TBK_TABLE_LOAD", 0);
     const bool forced = load > 0;
     if (!forced) load = default_load;
@@ -514,7 +515,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6), std::max(a->num_lines, b->num_lines),
                           (int)env_double("TBK_MINIMIZER_M", 0), (int)env_double("TBK_MOD_SAMPLING", 0));
     // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.0625 : 0.25, 2 * TBK_BUCKET_BYTES);
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.04 : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
