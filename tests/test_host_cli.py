@@ -64,6 +64,20 @@ def test_score_and_bin_matches_reference_floats(built):
         assert bins.decode() == c["bin"]
 
 
+def test_score_and_bin_large_batch_matches_oracle(built):
+    """Batches of millions of short reads are scored by several host threads: same floats, same bins."""
+    from oracle import binding
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 40, (1_500_000, 2), dtype=np.int32)
+    counts[::7] = counts[::7, :1]  # plenty of ties
+    sa, sb, bins = kmers.score_and_bin(counts, 299_999_993, 300_000_007)
+    osa, osb, obins = binding.load().score_and_bin(counts, 299_999_993, 300_000_007)
+    assert np.array_equal(sa, osa) and np.array_equal(sb, osb) and bins.decode() == obins
+    assert {"A", "B", "U"} == set(obins)
+
+
 def test_unit_level_host_functions(built):
     """kmer_to_int / reverse_complement are host code in the C-ABI (no GPU needed)."""
     from trio_binning_amd import kmers

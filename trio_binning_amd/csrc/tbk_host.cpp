@@ -903,11 +903,23 @@ extern "C" int tbk_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64
     const uint64_t mx = num_a > num_b ? num_a : num_b;
     const double fa = 1.0 * (double)mx / (double)num_a;
     const double fb = 1.0 * (double)mx / (double)num_b;
-    for (uint64_t r = 0; r < n_reads; r++) {
-        const double sa = (double)counts[2 * r] * fa, sb = (double)counts[2 * r + 1] * fb;
-        score_a[r] = sa;
-        score_b[r] = sb;
-        bins[r] = sa > sb ? 'A' : (sb > sa ? 'B' : 'U');
+    auto work = [=](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; r++) {
+            const double sa = (double)counts[2 * r] * fa, sb = (double)counts[2 * r + 1] * fb;
+            score_a[r] = sa;
+            score_b[r] = sb;
+            bins[r] = sa > sb ? 'A' : (sb > sa ? 'B' : 'U');
+        }
+    };
+    // batches of millions of short reads: split over a few host threads (each read is independent)
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint64_t n_thr = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 16), n_reads >> 18);
+    if (n_thr <= 1) {
+        work(0, n_reads);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint64_t t = 0; t < n_thr; t++) pool.emplace_back(work, n_reads * t / n_thr, n_reads * (t + 1) / n_thr);
+        for (std::thread &th : pool) th.join();
     }
     return TBK_OK;
 }
