@@ -7,14 +7,17 @@
 //   DESIGN.md §4): random line reads saturate at ~48 G lines/s whether the line is 64 or
 //   128 bytes, so fetching both tables' buckets as ONE 128-byte line halves the cost of a
 //   window compared with two independent 64-byte lines.  hapA and hapB stay separate tables
-//   (separate slots, separate probes, hapA priority applied afterwards).
+//   (separate slots, separate probes); a key both lists hold is stored for hapA only, because
+//   hapA is asked first (c/kmers.c:291-294), so the two halves are disjoint.
 //   A slot holds a packed k-mer (base i at bits 2i..2i+1, A=0 C=1 G=2 T=3 — the reference's
-//   encoding, c/kmers.c:50-72) or TBK_EMPTY.  A key lives in the first bucket, walking from
-//   its home bucket, whose half had a free slot when it was inserted (linear probing at
-//   line granularity), so a lookup stops at the first half-line that still has a free slot.
-//   Inserts always take the FIRST free slot of a half and nothing is ever removed, so the
-//   occupied slots of a half form a prefix: a half is full exactly when its last slot is
-//   occupied (the probe kernel tests that one slot).
+//   encoding, c/kmers.c:50-72) or TBK_EMPTY.  A key lives in the first half along its probe
+//   sequence (tbk_next_bucket: home bucket, second-choice bucket, then linear) that had a free
+//   slot when it was inserted.  Inserts always take the FIRST free slot of a half and nothing
+//   is ever removed, so the occupied slots of a half form a prefix.  After the inserts the last
+//   two slots of every full half are put in the order that says whether any key went past the
+//   half (slot 6 > slot 7) or not (slot 6 < slot 7; a half with a free slot has slot 7 =
+//   TBK_EMPTY, the largest value): a lookup that misses stops at the first half nothing went
+//   past, and the probe kernel learns that from one compare of two slots it already holds.
 //   A standalone list (tbk_table) is just its packed keys in HBM; a single-table form of
 //   the same layout (64-byte lines, 8 slots) is built on demand for tbk_table_contains.
 //   The reference's layout (8-byte slots + a parallel "full" byte array at load 0.75,

@@ -3,10 +3,10 @@
 //   tbk_probe_kernel   replaces the per-window loop of count_kmers_in_read
 //                      (c/kmers.c:270-299) and both kmer_in_hash_set probes
 //                      (c/kmers.c:245-268) for a whole batch of reads.
-//   tbk_insert_kernel  replaces add_to_hash (c/kmers.c:112-122).
+//   tbk_insert_kernel, tbk_order_kernel  replace add_to_hash (c/kmers.c:112-122).
 //   tbk_contains_kernel  raw-key membership (tests).
 //
-// Integer/hash work: no MFMA.  The bound is HBM random-line throughput (DESIGN.md §4).
+// Integer/hash work: no MFMA.  The bound is HBM random-line throughput (DESIGN.md §3.1, §7).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -129,10 +129,9 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // lanes per line (coalesced bucket-line loads) and a window costs ONE random line for both
 // probes.  In sub-step (j, s) quad q probes window j of its lane s: key and bucket index are
 // broadcast inside the quad with DPP quad_perm moves, each lane compares its slots, and the
-// v_cmp results are the wave ballots: a key is stored at most once per table, so
-// popcount(ballot) is the number of windows that hit.  hapA has priority over hapB
-// (c/kmers.c:291-294): both halves are fetched concurrently and the hapB ballot is masked
-// by the quad-expanded hapA ballot.
+// v_cmp results are the wave ballots: a key is stored at most once, in one of the two halves
+// (hapA has priority over hapB, c/kmers.c:291-294, so a key both lists hold is kept for hapA
+// only when the table is built), hence popcount(ballot) is the number of windows that hit.
 //
 // Per-read attribution.  A pass that lies inside one read (the usual case for long
 // reads) accumulates its two counts in scalar registers and issues one atomicAdd pair.
