@@ -149,7 +149,7 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #endif
 constexpr int TBK_WPL = 32;                 // windows per lane per pass
 constexpr int TBK_PASS = 64 * TBK_WPL;      // window starts per wave pass (2048)
-constexpr int TBK_WAVES_PER_BLOCK = 4;
+constexpr int TBK_WAVES_PER_BLOCK = 1;      // waves of a block share nothing; one-wave blocks schedule best (measured: 1 > 2 > 4 > 8)
 constexpr int TBK_CHUNKS = 130;             // 128 chunks of 16 bases + 2 halo chunks
 
 #ifdef TBK_COUNTERS
