@@ -368,7 +368,10 @@ def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n
     import oracle
 
     orc = oracle.load()
-    cores = os.cpu_count() or 1
+    # CPUs this process may actually use: hardware threads cut down to the affinity mask and the
+    # cgroup CPU quota (the GPU boxes show 256 hardware threads and grant 16 CPUs' worth of time)
+    cores = int(lib.tbk_host_threads())
+    hw_threads = os.cpu_count() or 1
     t0 = time.time()
     oa = orc.table_from_keys(h_keys[:n_list], k, threads=cores)
     ob = orc.table_from_keys(h_keys[n_list:], k, threads=cores)
@@ -409,7 +412,7 @@ def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n
         bad = np.nonzero((g != cn).any(axis=1))[0][:5]
         parity["first_mismatches"] = [[int(i), g[i].tolist(), cn[i].tolist()] for i in bad]
     base = {
-        "value": round(rate1, 6), "unit": "Gbases/s", "cores": 1, "kind": "port",
+        "value": round(rate1, 6), "unit": "Gbases/s", "cores": 1, "kind": "port", "host_hardware_threads": hw_threads, "host_usable_cpus": cores,
         "sample": f"oracle (faithful restatement of c/kmers.c: 2 linear-probe tables at load 0.75, non-rolling encode) "
                   f"on the first {n1} reads ({n1 * L / 1e6:.1f} Mbases) of batch 0, same 2x{n_list} {k}-mer tables, {dt1:.1f} s",
         "all_cores": {"value": round(raten, 6), "unit": "Gbases/s", "cores": cores,

@@ -251,6 +251,11 @@ int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, u
                                uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                                uint32_t err_per_2p24, void *d_bases, void *d_offsets);
 
+/* Host threads the library starts for its own host-side work (list parsing, gzip members,
+ * scoring): hardware threads limited by the CPU affinity mask and the cgroup CPU quota.
+ * Env TBK_HOST_THREADS overrides. */
+int tbk_host_threads(void);
+
 /* ---- roofline calibration (SURVEY §8d "random-read roofline") -------------------------- */
 /* Independent uniformly random line-aligned loads over a `footprint_bytes` buffer:
  * `line_bytes` in {64,128}, `lanes_per_line` in {1,4,8} (16 B per lane when >1, the whole

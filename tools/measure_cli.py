@@ -37,7 +37,7 @@ with open(fq, "wb") as fh:
     for r in range(a.reads):
         fh.write(b"@read%d some comment\n" % r); fh.write(bases[r].tobytes()); fh.write(b"\n+\n"); fh.write(qual); fh.write(b"\n")
 res = {"kmers_per_list": a.kmers, "reads": a.reads, "gbases": a.reads * a.read_len / 1e9, "fastq_GB": os.path.getsize(fq) / 1e9}
-env = dict(os.environ, PYTHONPATH=ROOT)
+env = dict(os.environ, PYTHONPATH=ROOT, TBK_STATS="1")
 for mode, extra in (("gzip", []), ("plain", ["--no-gzip-output"])):
     out = os.path.join(tmp, mode); os.makedirs(out)
     t = time.time()
@@ -48,6 +48,7 @@ for mode, extra in (("gzip", []), ("plain", ["--no-gzip-output"])):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = p.stdout.decode().splitlines()
     bins = {b: sum(1 for l in lines if l.split("\t")[1] == b) for b in "ABU"}
-    res[mode] = {"wall_s": round(dt, 2), "gbases_per_s": round(res["gbases"] / dt, 3), "bins": bins,
+    st = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-stats ")]
+    res[mode] = {"stages": json.loads(st[-1][10:]) if st else None, "wall_s": round(dt, 2), "gbases_per_s": round(res["gbases"] / dt, 3), "bins": bins,
                  "out_bytes": sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))}
 print(json.dumps(res))

@@ -477,7 +477,7 @@ struct tbk_bin_writer {
     bool gz = false;
     int level = 6;
     int threads = 1;
-    size_t chunk = (size_t)8 << 20;
+    size_t chunk = (size_t)1 << 20;  // text per gzip member: small enough that one batch keeps every host thread busy
     std::string err;
 };
 
@@ -557,8 +557,8 @@ extern "C" int tbk_bin_writer_open(const char *path_a, const char *path_b, const
     tbk_bin_writer *w = new tbk_bin_writer();
     w->gz = gzip_output != 0;
     w->level = level < 0 ? 6 : std::min(level, 9);
-    if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
-    w->threads = std::min(threads, 64);
+    if (threads <= 0) threads = tbk_host_threads();
+    w->threads = std::min(threads, 512);
     const char *paths[3] = {path_a, path_b, path_u};
     for (int b = 0; b < 3; b++) {
         // truncating open, as open(name, "w") / gzip.open(name, "wt") do (seq.py:128-134); when two

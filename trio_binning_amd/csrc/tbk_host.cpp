@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #include <atomic>
 #include <mutex>
 #include <string>
@@ -83,6 +84,33 @@ static double env_double(const char *name, double dflt) {
     char *end = nullptr;
     double d = strtod(v, &end);
     return end == v ? dflt : d;
+}
+
+// Host threads worth starting: hardware threads, cut down to the CPU affinity mask and to the
+// cgroup CPU quota (a container may see 256 hardware threads and be allowed 16 CPUs' worth of
+// time; more runnable threads than that only adds throttling stalls).  TBK_HOST_THREADS overrides.
+extern "C" int tbk_host_threads(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    long n = (long)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<long>(n, CPU_COUNT(&set));
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+    }
+    if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (long)((quota + period - 1) / period)));
+    const double forced = env_double("TBK_HOST_THREADS", 0);
+    if (forced >= 1) n = (long)forced;
+    cached = (int)std::max<long>(1, n);
+    return cached;
 }
 
 // ---- handles ---------------------------------------------------------------------------
@@ -352,7 +380,7 @@ static bool parse_regular(const char *data, size_t size, long k, std::vector<uin
     if (n == 0) return false;
     keys.resize(n);
     const uint8_t *lut = g_code_lut();
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = (unsigned)tbk_host_threads();
     size_t nt = std::min<size_t>(std::max(1u, hw), 64);
     nt = std::min(nt, std::max<size_t>(1, n / 65536));
     std::atomic<bool> ok{true};
@@ -912,7 +940,7 @@ extern "C" int tbk_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64
         }
     };
     // batches of millions of short reads: split over a few host threads (each read is independent)
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = (unsigned)tbk_host_threads();
     const uint64_t n_thr = std::min<uint64_t>(std::min<uint64_t>(hw ? hw : 1, 16), n_reads >> 18);
     if (n_thr <= 1) {
         work(0, n_reads);
