@@ -328,18 +328,44 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     // k-mer is bits [128-2k-2j, 128-2j) of R.  R is pre-shifted right by 64-2k once and then
     // rolled LEFT by one base per window, so that k-mer always sits at bits [64, 64+2k):
     // words (t2, t3), no per-window shift.
-    uint32_t s0 = (uint32_t)e0, s1 = (uint32_t)e1, s2 = (uint32_t)e2, s3 = (uint32_t)e3;
-    uint32_t t0, t1, t2, t3;
-    {
-        const unsigned __int128 R = (unsigned __int128)rev_pairs(~s3) | ((unsigned __int128)rev_pairs(~s2) << 32) |
-                                    ((unsigned __int128)rev_pairs(~s1) << 64) | ((unsigned __int128)rev_pairs(~s0) << 96);
-        const unsigned __int128 Rs = R >> (64 - 2 * k);
-        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64); t3 = (uint32_t)(Rs >> 96);
-    }
+    //
+    // In a pass that lies inside one read, ODD LANES WALK THEIR 32 WINDOWS DOWNWARDS.  A lane's first
+    // window can never re-use a line, and 71 % of the time it needs the very line its neighbour
+    // lane holds for the adjacent window; with neighbours walking towards each other (or away from
+    // each other) the two fetches of that line happen in the same step or a few steps apart, so the
+    // second one is served by L2 instead of HBM.  Walking down needs no second code path: the
+    // windows of b[0 .. 30+k] taken downwards are the windows of its reverse complement c[i] =
+    // comp(b[30+k-i]) taken upwards, with forward and reverse-complement k-mer swapped - the
+    // canonical k-mer and the (canonical, central) minimizer do not notice.  So an odd lane starts
+    // from S' = R >> 2(33-k), R' = S << 2(33-k) and the bit-reversed not-ACGT mask, and runs the
+    // same loop.  The read end is folded into that mask first (bases at or past it count as not
+    // ACGT), so window validity is one mask test in either direction.
+    unsigned __int128 S128 = (unsigned __int128)(uint32_t)e0 | ((unsigned __int128)(uint32_t)e1 << 32) |
+                             ((unsigned __int128)(uint32_t)e2 << 64) | ((unsigned __int128)(uint32_t)e3 << 96);
+    unsigned __int128 R128 = (unsigned __int128)rev_pairs(~(uint32_t)e3) | ((unsigned __int128)rev_pairs(~(uint32_t)e2) << 32) |
+                             ((unsigned __int128)rev_pairs(~(uint32_t)e1) << 64) | ((unsigned __int128)rev_pairs(~(uint32_t)e0) << 96);
     // not-ACGT flags of the lane's 64 bases, rolled right by one per window: window j is
     // clean when the low k bits are zero
-    uint32_t bad_lo = (uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16);
-    uint32_t bad_hi = (uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16);
+    uint64_t bad64 = (uint64_t)((uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16)) |
+                     ((uint64_t)((uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16)) << 32);
+    if (!MULTI) {
+        const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
+        const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;  // bases of this lane before the read end
+        if (inside < 64) bad64 |= ~0ull << inside;
+        if (lane & 1u) {
+            const int sh = 33 - k;  // >= 1
+            const unsigned __int128 s_up = R128 >> (2 * sh), r_up = S128 << (2 * sh);
+            S128 = s_up; R128 = r_up;
+            bad64 = __brevll(bad64) >> sh;
+        }
+    }
+    uint32_t s0 = (uint32_t)S128, s1 = (uint32_t)(S128 >> 32), s2 = (uint32_t)(S128 >> 64), s3 = (uint32_t)(S128 >> 96);
+    uint32_t t0, t1, t2, t3;
+    {
+        const unsigned __int128 Rs = R128 >> (64 - 2 * k);
+        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64); t3 = (uint32_t)(Rs >> 96);
+    }
+    uint32_t bad_lo = (uint32_t)bad64, bad_hi = (uint32_t)(bad64 >> 32);
     const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
 
     // ---- minimizer state -----------------------------------------------------------------
@@ -452,8 +478,8 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 rel_end = rel(rend);
             }
         }
-        bool ok = (bad_lo & badk) == 0 && (uint32_t)(j + k) <= rel_end;
-        if (MULTI) ok = ok && rid < p.n_reads;
+        bool ok = (bad_lo & badk) == 0;  // single-read pass: the read end is part of the mask
+        if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
         uint32_t hsel;
         if (W > 0 && SAMP) {
             // mod-sampling: shift in the span's newest t-mer, find the smallest rank (any of the
