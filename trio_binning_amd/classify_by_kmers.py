@@ -105,9 +105,61 @@ def main():
         stdout.write(seq.format_tsv(batch, bins, score_a, score_b))
         stats["write_s"] += time.perf_counter() - t
 
-    # up to `depth` batches in flight on the GPU while the next one is being parsed
+    # Three stages run side by side, one batch apiece (the native calls release the GIL):
+    #   reader thread   parses the next batch into pinned memory,
+    #   this thread     keeps up to `depth` batches in flight on the GPU,
+    #   writer thread   scores, bins and writes finished batches in input order.
+    import queue
+    import threading
+
     depth = classifier.depth
-    free = [seq.Batch() for _ in range(depth + 1)]
+    n_batches = depth + 3
+    free_q: "queue.Queue" = queue.Queue()
+    filled_q: "queue.Queue" = queue.Queue(maxsize=2)
+    done_q: "queue.Queue" = queue.Queue(maxsize=2)
+    batches = [seq.Batch() for _ in range(n_batches)]
+    for b in batches:
+        free_q.put(b)
+    failure: List[BaseException] = []
+
+    def read_loop() -> None:
+        try:
+            while not failure:
+                batch = free_q.get()
+                t = time.perf_counter()
+                n = reader.next_batch(batch, _BATCH_BASES, _BATCH_READS)
+                stats["read_s"] += time.perf_counter() - t
+                if n == 0:
+                    free_q.put(batch)
+                    break
+                stats["reads"] += n
+                stats["batches"] += 1
+                stats["bases"] += int(batch.arrays()[1][-1])
+                filled_q.put(batch)
+        except BaseException as exc:  # handed to the main thread
+            failure.append(exc)
+        finally:
+            filled_q.put(None)
+
+    def write_loop() -> None:
+        try:
+            while True:
+                item = done_q.get()
+                if item is None:
+                    break
+                batch, counts = item
+                if not failure:
+                    emit(batch, counts)
+                free_q.put(batch)
+        except BaseException as exc:
+            failure.append(exc)
+            while done_q.get() is not None:  # keep the main thread from blocking on a full queue
+                pass
+
+    rt = threading.Thread(target=read_loop, name="tbk-reader", daemon=True)
+    wt = threading.Thread(target=write_loop, name="tbk-writer", daemon=True)
+    rt.start()
+    wt.start()
     in_flight: List[Tuple[int, seq.Batch]] = []  # (ticket, batch) in submission order
 
     def drain(keep: int) -> None:
@@ -116,23 +168,26 @@ def main():
             t = time.perf_counter()
             counts = classifier.wait(ticket)
             stats["gpu_wait_s"] += time.perf_counter() - t
-            emit(batch, counts)
-            free.append(batch)
+            done_q.put((batch, counts))
 
-    while True:
-        batch = free.pop()
-        t = time.perf_counter()
-        n = reader.next_batch(batch, _BATCH_BASES, _BATCH_READS)
-        stats["read_s"] += time.perf_counter() - t
-        if n == 0:
-            free.append(batch)
-            break
-        stats["reads"] += n
-        stats["batches"] += 1
-        stats["bases"] += int(batch.arrays()[1][-1])
-        drain(depth - 1)
-        in_flight.append((classifier.submit_batch(batch), batch))
-    drain(0)
+    try:
+        while not failure:
+            batch = filled_q.get()
+            if batch is None:
+                break
+            drain(depth - 1)
+            in_flight.append((classifier.submit_batch(batch), batch))
+        drain(0)
+    finally:
+        done_q.put(None)
+        wt.join()
+        if failure:  # unblock a reader waiting for a free batch, then report
+            for _ in range(n_batches):
+                free_q.put(seq.Batch())
+        rt.join(timeout=5)
+    if failure:
+        raise failure[0]
+    free = batches
 
     # The reference never closes its outputs (interpreter shutdown does); closing here
     # finalises the files at the same point in the byte stream.
