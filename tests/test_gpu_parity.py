@@ -190,6 +190,64 @@ def test_long_mmer_bucket_selection(gpu, orc, tmp_path, m, monkeypatch):
         assert want.sum() > 100
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_seeded_fuzz_of_layout_and_input_shapes(gpu, orc, tmp_path, seed, monkeypatch):
+    """Random small configurations: any k, lists with duplicate / shared / reverse-complement /
+    low-complexity lines, reads with N and lower case, ragged lengths (empty reads, reads shorter
+    than k, reads ending inside and exactly on a 2048-window pass), every bucket-selection mode and
+    table loads from roomy to crowded.  Counts must equal the oracle's in all of them."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(9000 + seed)
+    k = int(rng.choice([1, 2, 4, 7, 11, 14, 15, 16, 17, 19, 21, 22, 23, 25, 27, 29, 31, 32]))
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(int(rng.integers(0, 9))))
+    monkeypatch.setenv("TBK_MOD_SAMPLING", str(int(rng.integers(0, 2))))
+    monkeypatch.setenv("TBK_TABLE_LOAD", str(rng.choice([0.04, 0.2, 0.6, 0.9])))
+    n_a, n_b = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+
+    def rand_kmer():
+        mode = rng.random()
+        if mode < 0.1:   # low complexity: long runs of one base
+            return ("ACGT"[int(rng.integers(0, 4))] * k)[: int(rng.integers(0, k + 1))].ljust(k, "ACGT"[int(rng.integers(0, 4))])
+        if mode < 0.2:   # short-period repeat
+            unit = "".join("ACGT"[c] for c in rng.integers(0, 4, int(rng.integers(1, 4))))
+            return (unit * k)[:k]
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, k))
+
+    la = [rand_kmer() for _ in range(n_a)]
+    lb = [rand_kmer() for _ in range(n_b)]
+    lb += [la[int(i)] for i in rng.integers(0, n_a, min(20, n_a))]          # shared with hapA
+    lb += [_rc(la[int(i)]) for i in rng.integers(0, n_a, min(10, n_a))]     # shared, other strand
+    la += [la[int(i)] for i in rng.integers(0, n_a, 5)]                     # duplicates
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "\n".join(lb))                          # no trailing newline
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    assert (a.num_kmers, b.num_kmers) == (oa.num_kmers, ob.num_kmers)
+
+    reads = _rand_reads(rng, int(rng.integers(1, 120)), int(rng.choice([40, 300, 2500, 9000])), la + lb, k, p_plant=0.9)
+    reads += ["", "A" * max(0, k - 1), la[0], _rc(lb[0]) * 2, "".join(la[:40]), "".join(_rc(x) for x in lb[:40])]
+    body = "".join("ACGT"[c] for c in rng.integers(0, 4, 5000))
+    reads += [body[: 2048 - sum(map(len, reads)) % 2048], body[:2047], body[:2048 + k - 1], body[:4096]]  # pass-boundary shapes
+    noisy = list(body[:3000])
+    for i in rng.integers(0, 3000, 40):
+        noisy[int(i)] = "NnacgtR-"[int(rng.integers(0, 8))]
+    reads.append("".join(noisy))
+    order = rng.permutation(len(reads))
+    reads = [reads[int(i)] for i in order]
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob, strict=True)
+    with kmers.Classifier(a, b) as cls:
+        got = cls.classify_batch(bases, offs)
+        again = cls.classify_batch(bases, offs)
+    assert np.array_equal(got, want), (seed, k, cls_env(), np.nonzero((got != want).any(axis=1))[0][:10])
+    assert np.array_equal(again, want)
+
+
+def cls_env():
+    return {v: os.environ.get(v) for v in ("TBK_MINIMIZER_W", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD")}
+
+
 def test_ragged_batch_shapes(gpu, orc, tmp_path):
     """Empty batch, empty reads, many tiny reads, reads around the 1024-window pass size and
     the 16-base chunk size, one long read: per-read attribution at every boundary."""
