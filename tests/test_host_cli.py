@@ -78,6 +78,27 @@ def test_score_and_bin_large_batch_matches_oracle(built):
     assert {"A", "B", "U"} == set(obins)
 
 
+def test_host_threads_follow_quota_and_override(built):
+    """tbk_host_threads never exceeds the hardware threads / affinity mask, honours a cgroup CPU
+    quota when there is one, and TBK_HOST_THREADS overrides (read once per process)."""
+    import subprocess
+    import sys
+
+    code = "from trio_binning_amd._lib import lib; print(lib.tbk_host_threads())"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "TBK_HOST_THREADS"}
+    n = int(subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, check=True).stdout)
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            assert n <= -(-int(quota) // int(period))
+    except (OSError, ValueError):
+        pass
+    forced = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(env, TBK_HOST_THREADS="3"), capture_output=True, text=True, check=True)
+    assert int(forced.stdout) == 3
+
+
 def test_unit_level_host_functions(built):
     """kmer_to_int / reverse_complement are host code in the C-ABI (no GPU needed)."""
     from trio_binning_amd import kmers

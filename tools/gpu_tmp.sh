@@ -1,14 +1,10 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-for round in 1 2; do
-for samp in 0 1; do
-  for lists in uniform haplotypes; do
-  echo -n "samp=$samp $lists: "
-  TBK_MOD_SAMPLING=$samp timeout 600 python bench.py --lists $lists --steps 15 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms_avg'], d['roofline']['kernel_only_gbases_per_s'])"
-  done
-done
+D=$GRAFT_REPO_ROOT/trio_binning_amd/csrc/dbg/c_dbg.so
+for cfg in "0 0.04" "1 0.04" "1 0.03" "0 0.03"; do
+  set -- $cfg
+  echo -n "samp=$1 load=$2 haplotypes: "
+  TBK_MOD_SAMPLING=$1 TBK_TABLE_LOAD=$2 TBK_LIBRARY=$D timeout 600 python bench.py --lists haplotypes --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | grep tbk-counters
 done
 exit 0
