@@ -251,6 +251,33 @@ int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, u
                                uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                                uint32_t err_per_2p24, void *d_bases, void *d_offsets);
 
+/* ---- k-mer counting: the find-unique-kmers step ---------------------------
+ * Replaces the KMC subprocesses of find_unique_kmers.py:62-233 by a counting table in HBM.
+ * Semantics restated from KMC 3 at the reference's settings (kmc -k<k>, defaults -ci2 -cs255;
+ * kmc_tools transform histogram; kmc_tools simple kmers_subtract; kmc_dump -ci -cx): canonical
+ * k-mers of all reads, both strands, k-mers holding a symbol outside ACGT skipped, lower case
+ * counted as upper case; k-mers seen once are not in the database; counters saturate at 255.
+ * KMC itself is not part of the reference checkout: parity with it is unpinned. */
+typedef struct tbk_counter tbk_counter;
+/* Table for up to `capacity_kmers` distinct k-mers (12 bytes per slot at load <= 0.6).  Adding
+ * reads fails with TBK_ERR_NOMEM once it is full. */
+int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tbk_counter **out);
+void tbk_counter_destroy(tbk_counter *c);
+/* Count the canonical k-mers of a batch of reads (the classifier's batch layout; host memory). */
+int tbk_counter_add_batch(tbk_counter *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
+/* Same for a batch already in HBM (d_bases readable up to total_bases). */
+int tbk_counter_add_device(tbk_counter *c, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t total_bases);
+/* hist[c], c = 1..255: number of distinct k-mers whose counter (capped at 255) is c - the rows
+ * kmc_tools writes, except that KMC's -ci2 database has no row-1 k-mers (callers zero hist[1]);
+ * hist[0]: all distinct k-mers met. */
+int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]);
+int tbk_counter_stats(const tbk_counter *c, uint64_t *n_slots, uint64_t *table_bytes, uint64_t *bases_added, uint64_t *reads_added);
+/* kmers_subtract + kmc_dump: write to out_path, one k-mer per line in lexicographic order, the
+ * k-mers of `a` seen at least twice whose counter lies in [min_count, max_count] and that `b` has
+ * seen at most once. */
+int tbk_counter_unique(tbk_counter *a, tbk_counter *b, uint32_t min_count, uint32_t max_count, const char *out_path,
+                       uint64_t *n_written);
+
 /* Host threads the library starts for its own host-side work (list parsing, gzip members,
  * scoring): hardware threads limited by the CPU affinity mask and the cgroup CPU quota.
  * Env TBK_HOST_THREADS overrides. */

@@ -706,6 +706,168 @@ tbk_probe_kernel(const ProbeArgs p) {
 }
 
 // =======================================================================================
+// k-mer counting (the find-unique-kmers step)
+// =======================================================================================
+// The reference shells out to KMC (find_unique_kmers.py:62-233): count canonical k-mers of a read
+// set, keep those seen at least twice (kmc's default -ci2), cap counters at 255 (-cs255), take a
+// histogram, subtract the other parent's database and dump the k-mers whose counter lies between
+// two cut-offs.  Here the database is a table in HBM: 64-byte lines of 8 keys with a parallel
+// array of 32-bit counters, bucket chosen like the classifier's (minimizer of the k-mer, so the
+// consecutive windows of a read update the same line while it sits in L2), probe sequence
+// tbk_next_bucket.
+
+// Copy reads that lie back to back into a stream where every read is followed by one 'N', upper-
+// casing on the way (KMC counts lower-case bases like upper-case ones): a window can then never
+// span two reads and validity is the not-ACGT mask alone.  One wave per read.
+__global__ void __launch_bounds__(256)
+tbk_separate_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets, uint64_t n_reads,
+                    uint8_t *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    for (uint64_t r = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < n_reads; r += waves) {
+        const uint64_t lo = offsets[r], hi = offsets[r + 1];
+        uint8_t *dst = out + lo + r;
+        for (uint64_t i = lo + lane; i < hi; i += 64) dst[i - lo] = bases[i] & 0xDFu;
+        if (lane == 0) dst[hi - lo] = 'N';
+    }
+}
+
+struct TbkCountView {
+    uint64_t *keys;     // n_buckets * 8, TBK_EMPTY = free
+    uint32_t *counts;   // n_buckets * 8
+    uint32_t n_buckets;
+    TbkMz mz;
+};
+
+// find or claim the key's slot along its probe sequence and count one occurrence
+__device__ __forceinline__ bool count_one(const TbkCountView &t, uint64_t key) {
+    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
+    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+        unsigned long long *line = (unsigned long long *)(t.keys + (uint64_t)b * TBK_SLOTS_PER_BUCKET);
+        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
+            unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == TBK_EMPTY) {
+                cur = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
+                if (cur == TBK_EMPTY) cur = key;
+            }
+            if (cur == key) { atomicAdd(&t.counts[(uint64_t)b * TBK_SLOTS_PER_BUCKET + s], 1u); return true; }
+        }
+        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
+    }
+    return false;
+}
+
+// One wave per pass of 2048 window starts of the separated stream, staged and rolled like the probe
+// kernel's; every clean window counts its canonical k-mer.
+__global__ void __launch_bounds__(64)
+tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_passes, int k, TbkCountView t,
+                 int *__restrict__ failed) {
+    __shared__ uint64_t stage[TBK_CHUNKS + 2];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    for (uint64_t pass = blockIdx.x; pass < n_passes; pass += gridDim.x) {
+        const uint64_t P0 = pass * TBK_PASS;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        stage[lane] = load_chunk(bases, P0 + (uint64_t)lane * 16, total);
+        stage[64 + lane] = load_chunk(bases, P0 + (uint64_t)(64 + lane) * 16, total);
+        if (lane < 2) stage[128 + lane] = load_chunk(bases, P0 + (uint64_t)(128 + lane) * 16, total);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t e0 = stage[2 * lane], e1 = stage[2 * lane + 1], e2 = stage[2 * lane + 2], e3 = stage[2 * lane + 3];
+        uint32_t s0 = (uint32_t)e0, s1 = (uint32_t)e1, s2 = (uint32_t)e2, s3 = (uint32_t)e3;
+        const unsigned __int128 R128 = (unsigned __int128)rev_pairs(~s3) | ((unsigned __int128)rev_pairs(~s2) << 32) |
+                                       ((unsigned __int128)rev_pairs(~s1) << 64) | ((unsigned __int128)rev_pairs(~s0) << 96);
+        const unsigned __int128 Rs = R128 >> (64 - 2 * k);
+        uint32_t t0 = (uint32_t)Rs, t1 = (uint32_t)(Rs >> 32), t2 = (uint32_t)(Rs >> 64), t3 = (uint32_t)(Rs >> 96);
+        uint32_t bad_lo = (uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16);
+        uint32_t bad_hi = (uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16);
+        bool full = false;
+        for (int j = 0; j < TBK_WPL; j++) {
+            const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
+            const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
+            const bool ok = (bad_lo & badk) == 0 && P0 + (uint64_t)lane * TBK_WPL + (uint64_t)j + (uint64_t)k <= total;
+            if (ok && !count_one(t, fwd < rc ? fwd : rc)) full = true;
+            s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
+            t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
+            bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
+        }
+        if (full) atomicExch(failed, 1);
+    }
+}
+
+// hist[c] = k-mers whose counter, capped at 255, equals c (c = 1..255); hist[0] = occupied slots
+__global__ void __launch_bounds__(256)
+tbk_count_histogram_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ counts, uint64_t n_slots,
+                           unsigned long long *__restrict__ hist) {
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += step) {
+        if (keys[i] == TBK_EMPTY) continue;
+        const uint32_t c = counts[i] < 255u ? counts[i] : 255u;
+        atomicAdd(&h[c], 1u);
+        atomicAdd(&h[0], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// counter of `key` in a counting table (0 if absent).  Keys are never removed and take the first
+// free slot along their probe sequence, so a line with a free slot ends the search.
+__device__ __forceinline__ uint32_t count_lookup(const TbkCountView &t, uint64_t key) {
+    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
+    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+        const uint64_t *line = t.keys + (uint64_t)b * TBK_SLOTS_PER_BUCKET;
+        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
+            const uint64_t cur = line[s];
+            if (cur == key) return t.counts[(uint64_t)b * TBK_SLOTS_PER_BUCKET + s];
+            if (cur == TBK_EMPTY) return 0;
+        }
+        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
+    }
+    return 0;
+}
+
+// kmc_tools simple A B kmers_subtract + kmc_dump -ci -cx: the k-mers of database A (counter >= 2)
+// that database B does not hold (its counter < 2) and whose counter, capped at 255, lies in
+// [ci, cx].  Each is appended as its lexicographic rank (base 0 in the top bits), ready to sort.
+__global__ void __launch_bounds__(256)
+tbk_count_unique_kernel(TbkCountView a, TbkCountView b, int k, uint32_t ci, uint32_t cx, uint64_t *__restrict__ out,
+                        uint64_t capacity, unsigned long long *__restrict__ n_out) {
+    const uint64_t n_slots = (uint64_t)a.n_buckets * TBK_SLOTS_PER_BUCKET;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    // whole waves iterate together: the append below is a wave operation
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < n_slots; i0 += step) {
+        const uint64_t i = i0 + lane;
+        bool emit = false;
+        uint64_t key = 0;
+        if (i < n_slots) {
+            key = a.keys[i];
+            if (key != TBK_EMPTY) {
+                const uint32_t raw = a.counts[i], c = raw < 255u ? raw : 255u;
+                emit = raw >= 2u && c >= ci && c <= cx && count_lookup(b, key) < 2u;
+            }
+        }
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(emit);
+        if (mask) {
+            unsigned long long base = 0;
+            const int leader = __builtin_ctzll(mask);
+            if ((int)lane == leader) base = atomicAdd(n_out, (unsigned long long)__popcll(mask));
+            base = __shfl(base, leader);
+            if (emit) {
+                const uint64_t at = base + (uint64_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (at < capacity) {
+                    const uint64_t lex = ((uint64_t)rev_pairs((uint32_t)key) << 32) | (uint64_t)rev_pairs((uint32_t)(key >> 32));
+                    out[at] = lex >> (64 - 2 * k);
+                }
+            }
+        }
+    }
+}
+
+// =======================================================================================
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
@@ -778,3 +940,39 @@ extern "C" int tbk_debug_counters(unsigned long long out[8], int reset) {
 
 // number of uint32 entries of pass_read scratch a batch of `total` bases needs
 extern "C" uint64_t tbk_probe_passes(uint64_t total) { return (total + TBK_PASS - 1) / TBK_PASS; }
+
+// ---- k-mer counting ---------------------------------------------------------------------
+extern "C" hipError_t tbk_launch_separate(const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint8_t *d_out,
+                                          hipStream_t stream) {
+    if (!n_reads) return hipSuccess;
+    uint64_t blocks = (n_reads + 3) / 4;
+    if (blocks > 262144) blocks = 262144;
+    hipLaunchKernelGGL(tbk_separate_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d_bases, d_offsets, n_reads, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_count(const uint8_t *d_sep, uint64_t total, int k, uint64_t *d_keys, uint32_t *d_counts,
+                                       uint32_t n_buckets, TbkMz mz, int *d_failed, hipStream_t stream) {
+    if (total < (uint64_t)k) return hipSuccess;
+    const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
+    const uint64_t blocks = n_passes < (1u << 20) ? n_passes : (1u << 20);
+    hipLaunchKernelGGL(tbk_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, d_sep, total, n_passes, k,
+                       TbkCountView{d_keys, d_counts, n_buckets, mz}, d_failed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_count_histogram(const uint64_t *d_keys, const uint32_t *d_counts, uint64_t n_slots,
+                                                 unsigned long long *d_hist, hipStream_t stream) {
+    hipLaunchKernelGGL(tbk_count_histogram_kernel, dim3(4096), dim3(256), 0, stream, d_keys, d_counts, n_slots, d_hist);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_count_unique(uint64_t *a_keys, uint32_t *a_counts, uint32_t a_buckets, TbkMz a_mz,
+                                              uint64_t *b_keys, uint32_t *b_counts, uint32_t b_buckets, TbkMz b_mz, int k,
+                                              uint32_t ci, uint32_t cx, uint64_t *d_out, uint64_t capacity,
+                                              unsigned long long *d_n, hipStream_t stream) {
+    hipLaunchKernelGGL(tbk_count_unique_kernel, dim3(8192), dim3(256), 0, stream, TbkCountView{a_keys, a_counts, a_buckets, a_mz},
+                       TbkCountView{b_keys, b_counts, b_buckets, b_mz}, k, ci, cx, d_out, capacity, d_n);
+    return hipGetLastError();
+}
+

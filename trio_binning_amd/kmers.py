@@ -342,6 +342,77 @@ class _PinnedOwner:
             pass
 
 
+def device_mem_info(device: Optional[int] = None) -> Tuple[int, int]:
+    """(free, total) bytes of HBM on the device."""
+    free, total = C.c_uint64(), C.c_uint64()
+    check(lib.tbk_device_mem_info(default_device() if device is None else device, C.byref(free), C.byref(total)))
+    return free.value, total.value
+
+
+class Counter:
+    """Counting table of canonical k-mers in HBM: the database `kmc` builds for the reference's
+    find-unique-kmers step (find_unique_kmers.py:62-103), with the histogram, subtraction and dump
+    `kmc_tools` / `kmc_dump` provide (find_unique_kmers.py:123-129,186-194,218-225)."""
+
+    def __init__(self, k: int, capacity: int, device: Optional[int] = None):
+        self._h = C.c_void_p()
+        self.k = k
+        self.device = default_device() if device is None else device
+        check(lib.tbk_counter_create(k, capacity, self.device, C.byref(self._h)))
+
+    def add_reads(self, reads: Sequence[str]) -> None:
+        bases, offsets = pack_reads(reads)
+        self.add(bases, offsets)
+
+    def add(self, bases: np.ndarray, offsets: np.ndarray) -> None:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        check(lib.tbk_counter_add_batch(self._h, bases.ctypes.data, offsets.ctypes.data, offsets.size - 1))
+
+    def add_batch(self, batch) -> None:
+        """Count a ``seq.Batch`` straight from its (pinned) buffers."""
+        bases_ptr, off_ptr = batch.pointers()
+        check(lib.tbk_counter_add_batch(self._h, C.c_void_p(bases_ptr), C.c_void_p(off_ptr), batch.n_reads))
+
+    def add_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int) -> None:
+        check(lib.tbk_counter_add_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, total_bases))
+
+    def histogram(self) -> np.ndarray:
+        """hist[c], c = 1..255: distinct k-mers whose counter (capped at 255) is c; hist[0]: all."""
+        hist = np.zeros(256, dtype=np.uint64)
+        check(lib.tbk_counter_histogram(self._h, hist.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return hist
+
+    def stats(self) -> dict:
+        v = [C.c_uint64() for _ in range(4)]
+        check(lib.tbk_counter_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("n_slots", "table_bytes", "bases_added", "reads_added"), (x.value for x in v)))
+
+    def unique(self, other: "Counter", min_count: int, max_count: int, out_path: str) -> int:
+        """Write the k-mers this library saw at least twice, with a counter in [min_count,
+        max_count], that `other` saw at most once; one per line, sorted.  Returns how many."""
+        n = C.c_uint64()
+        check(lib.tbk_counter_unique(self._h, other._h, min_count, max_count, os.fsencode(out_path), C.byref(n)))
+        return n.value
+
+    def close(self) -> None:
+        if self._h is not None and self._h.value:
+            h, self._h = self._h, None
+            lib.tbk_counter_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def pinned_empty(shape, dtype) -> np.ndarray:
     """A numpy array backed by pinned host memory (hipHostMalloc through the C-ABI), so that
     async copies to/from the GPU need no staging copy.  Freed with the array."""
