@@ -1,5 +1,6 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-timeout 900 python -m pytest tests/test_gpu_unique.py -x -q --timeout 300 2>&1 | tail -25
+timeout 900 python tools/measure_count.py --genome 100000000 --coverage 10 2>&1 | tail -3
+timeout 900 python tools/measure_count.py --genome 200000000 --coverage 20 2>&1 | tail -3
 exit 0
