@@ -259,7 +259,8 @@ int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, u
  * counted as upper case; k-mers seen once are not in the database; counters saturate at 255.
  * KMC itself is not part of the reference checkout: parity with it is unpinned. */
 typedef struct tbk_counter tbk_counter;
-/* Table for up to `capacity_kmers` distinct k-mers (12 bytes per slot at load <= 0.6).  Adding
+/* Table for up to `capacity_kmers` distinct k-mers (16 bytes per slot at load <= 0.6: a bucket
+ * is one 128-byte line holding 8 keys and their 8 counters).  Adding
  * reads fails with TBK_ERR_NOMEM once it is full. */
 int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tbk_counter **out);
 void tbk_counter_destroy(tbk_counter *c);

@@ -18,6 +18,7 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fcntl.h>
 #include <string>
@@ -30,10 +31,10 @@
 
 extern "C" void tbk_set_error_(int code, const char *msg);
 extern "C" hipError_t tbk_launch_separate(const uint8_t *, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_count(const uint8_t *, uint64_t, int, uint64_t *, uint32_t *, uint32_t, TbkMz, int *, hipStream_t);
-extern "C" hipError_t tbk_launch_count_histogram(const uint64_t *, const uint32_t *, uint64_t, unsigned long long *, hipStream_t);
-extern "C" hipError_t tbk_launch_count_unique(uint64_t *, uint32_t *, uint32_t, TbkMz, uint64_t *, uint32_t *, uint32_t, TbkMz, int,
-                                              uint32_t, uint32_t, uint64_t *, uint64_t, unsigned long long *, hipStream_t);
+extern "C" hipError_t tbk_launch_count(const uint8_t *, uint64_t, int, uint64_t *, uint32_t, TbkMz, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_count_histogram(uint64_t *, uint32_t, TbkMz, unsigned long long *, hipStream_t);
+extern "C" hipError_t tbk_launch_count_unique(uint64_t *, uint32_t, TbkMz, uint64_t *, uint32_t, TbkMz, int, uint32_t, uint32_t,
+                                              uint64_t *, uint64_t, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_sort_u64(const uint64_t *, uint64_t *, uint64_t, int, hipStream_t);
 
 static int cfail(int code, const char *fmt, ...) {
@@ -54,8 +55,7 @@ static int cfail(int code, const char *fmt, ...) {
 
 struct tbk_counter {
     int device = 0, k = 0;
-    uint64_t *d_keys = nullptr;
-    uint32_t *d_counts = nullptr;
+    uint64_t *d_lines = nullptr;  // n_buckets lines of 128 B: 8 keys | 8 x 32-bit counters | 32 spare bytes
     uint32_t n_buckets = 0;
     TbkMz mz{0, 0, 0, 0};
     int *d_failed = nullptr;
@@ -84,21 +84,26 @@ extern "C" int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tb
     if (rc) return rc;
     // 8-slot lines at load <= 0.6: a counting table meets every distinct k-mer of the reads,
     // sequencing errors included, so it is sized by the caller's estimate and fails loudly when full
-    uint64_t nb = (uint64_t)((double)capacity_kmers / (TBK_SLOTS_PER_BUCKET * 0.6)) + 16;
+    const char *ev = getenv("TBK_COUNT_LOAD");
+    double load = ev ? atof(ev) : 0.6;
+    if (load < 0.05) load = 0.05;
+    if (load > 0.9) load = 0.9;
+    uint64_t nb = (uint64_t)((double)capacity_kmers / (TBK_SLOTS_PER_BUCKET * load)) + 16;
     if (nb > 0x7FFFFFF0ull) return cfail(TBK_ERR_INVALID, "capacity %llu k-mers is more than one table holds", (unsigned long long)capacity_kmers);
     tbk_counter *c = new tbk_counter();
     c->device = device; c->k = k; c->n_buckets = (uint32_t)nb;
-    c->mz = tbk_mz_params(k, 6, capacity_kmers, 0, 0);
-    const size_t slots = (size_t)nb * TBK_SLOTS_PER_BUCKET;
-    hipError_t e = hipMalloc((void **)&c->d_keys, slots * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_counts, slots * sizeof(uint32_t));
+    const char *ew = getenv("TBK_COUNT_W"), *em = getenv("TBK_COUNT_M");
+    c->mz = tbk_mz_params(k, ew ? atoi(ew) : 6, capacity_kmers, em ? atoi(em) : 0, 0);
+    const size_t slots = (size_t)nb * TBK_SLOTS_PER_BUCKET, bytes = (size_t)nb * 128;
+    hipError_t e = hipMalloc((void **)&c->d_lines, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_failed, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_keys, 0xFF, slots * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemset(c->d_counts, 0, slots * sizeof(uint32_t));
+    // keys = all ones (free), counters = 0: per line 64 bytes of 0xFF then 64 bytes of 0
+    if (e == hipSuccess) e = hipMemset2D(c->d_lines, 128, 0xFF, 64, nb);
+    if (e == hipSuccess) e = hipMemset2D((uint8_t *)c->d_lines + 64, 128, 0, 64, nb);
     if (e == hipSuccess) e = hipMemset(c->d_failed, 0, sizeof(int));
     if (e != hipSuccess) {
         tbk_counter_destroy(c);
-        return cfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "counting table (%zu slots, %zu bytes): %s", slots, slots * 12,
+        return cfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "counting table (%zu slots, %zu bytes): %s", slots, bytes,
                      hipGetErrorString(e));
     }
     *out = c;
@@ -109,7 +114,7 @@ extern "C" void tbk_counter_destroy(tbk_counter *c) {
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         (void)hipDeviceSynchronize();
-        for (void *p : {(void *)c->d_keys, (void *)c->d_counts, (void *)c->d_failed, (void *)c->d_raw, (void *)c->d_sep, (void *)c->d_off})
+        for (void *p : {(void *)c->d_lines, (void *)c->d_failed, (void *)c->d_raw, (void *)c->d_sep, (void *)c->d_off})
             if (p) (void)hipFree(p);
     }
     delete c;
@@ -124,7 +129,7 @@ static int counter_run(tbk_counter *c, const uint8_t *d_bases, const uint64_t *d
         c->cap_sep = need_sep + need_sep / 8;
     }
     CHIP(tbk_launch_separate(d_bases, d_offsets, n_reads, c->d_sep, nullptr));
-    CHIP(tbk_launch_count(c->d_sep, total + n_reads, c->k, c->d_keys, c->d_counts, c->n_buckets, c->mz, c->d_failed, nullptr));
+    CHIP(tbk_launch_count(c->d_sep, total + n_reads, c->k, c->d_lines, c->n_buckets, c->mz, c->d_failed, nullptr));
     int failed = 0;
     CHIP(hipMemcpy(&failed, c->d_failed, sizeof failed, hipMemcpyDeviceToHost));
     if (failed) return cfail(TBK_ERR_NOMEM, "counting table is full (%llu slots): create the counter with a larger capacity",
@@ -173,7 +178,7 @@ extern "C" int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]) {
     unsigned long long *d_hist = nullptr;
     CHIP(hipMalloc((void **)&d_hist, 256 * sizeof(unsigned long long)));
     hipError_t e = hipMemset(d_hist, 0, 256 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = tbk_launch_count_histogram(c->d_keys, c->d_counts, (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET, d_hist, nullptr);
+    if (e == hipSuccess) e = tbk_launch_count_histogram(c->d_lines, c->n_buckets, c->mz, d_hist, nullptr);
     unsigned long long h[256];
     if (e == hipSuccess) e = hipMemcpy(h, d_hist, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d_hist);
@@ -185,7 +190,7 @@ extern "C" int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]) {
 extern "C" int tbk_counter_stats(const tbk_counter *c, uint64_t *n_slots, uint64_t *table_bytes, uint64_t *bases_added, uint64_t *reads_added) {
     if (!c) return cfail(TBK_ERR_INVALID, "counter is NULL");
     if (n_slots) *n_slots = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET;
-    if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET * 12;
+    if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * 128;
     if (bases_added) *bases_added = c->bases_added;
     if (reads_added) *reads_added = c->reads_added;
     return TBK_OK;
@@ -253,8 +258,8 @@ extern "C" int tbk_counter_unique(tbk_counter *a, tbk_counter *b, uint32_t min_c
         if (e == hipSuccess) e = hipMalloc((void **)&d_n, sizeof got);
         if (e == hipSuccess) e = hipMemset(d_n, 0, sizeof got);
         if (e == hipSuccess)
-            e = tbk_launch_count_unique(a->d_keys, a->d_counts, a->n_buckets, a->mz, b->d_keys, b->d_counts, b->n_buckets, b->mz, a->k,
-                                        min_count, max_count, d_out, cap, d_n, nullptr);
+            e = tbk_launch_count_unique(a->d_lines, a->n_buckets, a->mz, b->d_lines, b->n_buckets, b->mz, a->k, min_count, max_count,
+                                        d_out, cap, d_n, nullptr);
         if (e == hipSuccess) e = hipMemcpy(&got, d_n, sizeof got, hipMemcpyDeviceToHost);
         n = std::min<uint64_t>(got, cap);
         if (e == hipSuccess && n) e = tbk_launch_sort_u64(d_out, d_sorted, n, 2 * a->k, nullptr);

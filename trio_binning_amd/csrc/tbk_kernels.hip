@@ -732,33 +732,43 @@ tbk_separate_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restric
     }
 }
 
+// bucket b = one 128-byte line: 8 keys (TBK_EMPTY = free), then their 8 32-bit counters, then 32
+// spare bytes - keys and counters of a bucket arrive with one HBM line and the increments of a run
+// of windows land in a line that already sits in L2
+constexpr int TBK_COUNT_LINE = 16;  // uint64 words per bucket line
 struct TbkCountView {
-    uint64_t *keys;     // n_buckets * 8, TBK_EMPTY = free
-    uint32_t *counts;   // n_buckets * 8
+    uint64_t *lines;    // n_buckets * 16 words
     uint32_t n_buckets;
     TbkMz mz;
+    __device__ __forceinline__ unsigned long long *keys(uint32_t b) const { return (unsigned long long *)(lines + (uint64_t)b * TBK_COUNT_LINE); }
+    __device__ __forceinline__ uint32_t *counts(uint32_t b) const { return (uint32_t *)(lines + (uint64_t)b * TBK_COUNT_LINE + TBK_SLOTS_PER_BUCKET); }
 };
 
-// find or claim the key's slot along its probe sequence and count one occurrence
-__device__ __forceinline__ bool count_one(const TbkCountView &t, uint64_t key) {
-    uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
+// find or claim the key's slot along its probe sequence, from bucket b on, and count one occurrence
+__device__ __forceinline__ bool count_from(const TbkCountView &t, uint64_t key, uint32_t b, bool at_home) {
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
-        unsigned long long *line = (unsigned long long *)(t.keys + (uint64_t)b * TBK_SLOTS_PER_BUCKET);
+        unsigned long long *line = t.keys(b);
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
             unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == TBK_EMPTY) {
                 cur = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
                 if (cur == TBK_EMPTY) cur = key;
             }
-            if (cur == key) { atomicAdd(&t.counts[(uint64_t)b * TBK_SLOTS_PER_BUCKET + s], 1u); return true; }
+            if (cur == key) { atomicAdd(&t.counts(b)[s], 1u); return true; }
         }
-        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
+        b = tbk_next_bucket(key, t.mz, t.n_buckets, b, at_home && walked == 0);
     }
     return false;
 }
 
 // One wave per pass of 2048 window starts of the separated stream, staged and rolled like the probe
-// kernel's; every clean window counts its canonical k-mer.
+// kernel's; every clean window counts its canonical k-mer.  A lane keeps the 8 keys of the bucket
+// of its previous window in registers: consecutive windows mostly share their minimizer, so the
+// line is fetched once per run and a window costs its compares and one fire-and-forget atomic add.
+// The copy may be stale - other lanes insert meanwhile - but only in one direction: a slot seen
+// occupied never changes, and a slot seen free is claimed with a compare-and-swap that returns what
+// is really there.
+template <int W, bool M64>
 __global__ void __launch_bounds__(64)
 tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_passes, int k, TbkCountView t,
                  int *__restrict__ failed) {
@@ -766,6 +776,17 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+    using win_t = typename std::conditional<M64, uint64_t, uint32_t>::type;
+    const int m = t.mz.m, o = t.mz.o;
+    const uint64_t mmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
+    auto mmer_order = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh) -> win_t {
+        if (M64) {
+            const uint64_t x = (fwd64 >> fsh) & mmask, y = (rc64 >> bsh) & mmask;
+            return (win_t)tbk_mmer_hash64(x < y ? x : y);
+        }
+        const uint32_t x = (uint32_t)(fwd64 >> fsh) & (uint32_t)mmask, y = (uint32_t)(rc64 >> bsh) & (uint32_t)mmask;
+        return (win_t)tbk_mmer_hash(x < y ? x : y);
+    };
     for (uint64_t pass = blockIdx.x; pass < n_passes; pass += gridDim.x) {
         const uint64_t P0 = pass * TBK_PASS;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -781,12 +802,63 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
         uint32_t t0 = (uint32_t)Rs, t1 = (uint32_t)(Rs >> 32), t2 = (uint32_t)(Rs >> 64), t3 = (uint32_t)(Rs >> 96);
         uint32_t bad_lo = (uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16);
         uint32_t bad_hi = (uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16);
+        // minimizer state: the hashes of the span's W m-mers (see probe_pass)
+        win_t win[W > 0 ? W : 1];
+        uint32_t fsh_new = 0, bsh_new = 0;
+        if (W > 0) {
+            const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
+            win[0] = (win_t)~0ull;
+#pragma unroll
+            for (int i = 0; i + 1 < W; i++) win[i + 1] = mmer_order(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + W - 1 - i)));
+            fsh_new = (uint32_t)(2 * (o + W - 1));
+            bsh_new = (uint32_t)(2 * o);
+        }
+        uint64_t held[TBK_SLOTS_PER_BUCKET];  // keys of bucket held_bk as last seen
+#pragma unroll
+        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) held[s] = 0;
+        uint32_t held_bk = 0xFFFFFFFFu;
         bool full = false;
+#pragma unroll 2
         for (int j = 0; j < TBK_WPL; j++) {
             const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
             const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
+            const uint64_t key = fwd < rc ? fwd : rc;
             const bool ok = (bad_lo & badk) == 0 && P0 + (uint64_t)lane * TBK_WPL + (uint64_t)j + (uint64_t)k <= total;
-            if (ok && !count_one(t, fwd < rc ? fwd : rc)) full = true;
+            uint32_t hsel;
+            if (W > 0) {
+#pragma unroll
+                for (int i = 0; i + 1 < W; i++) win[i] = win[i + 1];
+                win[W - 1] = mmer_order(((uint64_t)s1 << 32) | s0, ((uint64_t)t3 << 32) | t2, fsh_new, bsh_new);
+                win_t best = win[0];
+#pragma unroll
+                for (int i = 1; i < W; i++) best = win[i] < best ? win[i] : best;
+                hsel = M64 ? (uint32_t)best : tbk_scramble((uint32_t)best);
+            } else {
+                hsel = tbk_mix32(key);
+            }
+            if (ok) {
+                const uint32_t b = tbk_reduce(hsel, t.n_buckets);
+                unsigned long long *line = t.keys(b);
+                if (b != held_bk) {
+                    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(line);
+                    const ulonglong2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+                    held[0] = v0.x; held[1] = v0.y; held[2] = v1.x; held[3] = v1.y;
+                    held[4] = v2.x; held[5] = v2.y; held[6] = v3.x; held[7] = v3.y;
+                    held_bk = b;
+                }
+                bool done = false;
+#pragma unroll
+                for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
+                    if (done) continue;
+                    if (held[s] == TBK_EMPTY) {
+                        const unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
+                        held[s] = old == TBK_EMPTY ? key : old;
+                    }
+                    if (held[s] == key) { atomicAdd(&t.counts(b)[s], 1u); done = true; }
+                }
+                // home bucket full of other keys: follow the probe sequence
+                if (!done && !count_from(t, key, tbk_next_bucket(key, t.mz, t.n_buckets, b, true), false)) full = true;
+            }
             s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
             t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
             bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
@@ -797,15 +869,16 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
 
 // hist[c] = k-mers whose counter, capped at 255, equals c (c = 1..255); hist[0] = occupied slots
 __global__ void __launch_bounds__(256)
-tbk_count_histogram_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ counts, uint64_t n_slots,
-                           unsigned long long *__restrict__ hist) {
+tbk_count_histogram_kernel(TbkCountView t, unsigned long long *__restrict__ hist) {
     __shared__ unsigned int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
+    const uint64_t n_slots = (uint64_t)t.n_buckets * TBK_SLOTS_PER_BUCKET;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += step) {
-        if (keys[i] == TBK_EMPTY) continue;
-        const uint32_t c = counts[i] < 255u ? counts[i] : 255u;
+        const uint32_t b = (uint32_t)(i >> 3), s = (uint32_t)(i & 7);
+        if (t.keys(b)[s] == TBK_EMPTY) continue;
+        const uint32_t raw = t.counts(b)[s], c = raw < 255u ? raw : 255u;
         atomicAdd(&h[c], 1u);
         atomicAdd(&h[0], 1u);
     }
@@ -818,10 +891,10 @@ tbk_count_histogram_kernel(const uint64_t *__restrict__ keys, const uint32_t *__
 __device__ __forceinline__ uint32_t count_lookup(const TbkCountView &t, uint64_t key) {
     uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
-        const uint64_t *line = t.keys + (uint64_t)b * TBK_SLOTS_PER_BUCKET;
+        const unsigned long long *line = t.keys(b);
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
             const uint64_t cur = line[s];
-            if (cur == key) return t.counts[(uint64_t)b * TBK_SLOTS_PER_BUCKET + s];
+            if (cur == key) return t.counts(b)[s];
             if (cur == TBK_EMPTY) return 0;
         }
         b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
@@ -844,9 +917,9 @@ tbk_count_unique_kernel(TbkCountView a, TbkCountView b, int k, uint32_t ci, uint
         bool emit = false;
         uint64_t key = 0;
         if (i < n_slots) {
-            key = a.keys[i];
+            key = a.keys((uint32_t)(i >> 3))[i & 7];
             if (key != TBK_EMPTY) {
-                const uint32_t raw = a.counts[i], c = raw < 255u ? raw : 255u;
+                const uint32_t raw = a.counts((uint32_t)(i >> 3))[i & 7], c = raw < 255u ? raw : 255u;
                 emit = raw >= 2u && c >= ci && c <= cx && count_lookup(b, key) < 2u;
             }
         }
@@ -951,28 +1024,36 @@ extern "C" hipError_t tbk_launch_separate(const uint8_t *d_bases, const uint64_t
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_count(const uint8_t *d_sep, uint64_t total, int k, uint64_t *d_keys, uint32_t *d_counts,
+extern "C" hipError_t tbk_launch_count(const uint8_t *d_sep, uint64_t total, int k, uint64_t *d_lines,
                                        uint32_t n_buckets, TbkMz mz, int *d_failed, hipStream_t stream) {
     if (total < (uint64_t)k) return hipSuccess;
     const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
     const uint64_t blocks = n_passes < (1u << 20) ? n_passes : (1u << 20);
-    hipLaunchKernelGGL(tbk_count_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, d_sep, total, n_passes, k,
-                       TbkCountView{d_keys, d_counts, n_buckets, mz}, d_failed);
+    const TbkCountView view{d_lines, n_buckets, mz};
+    const dim3 grid((unsigned)blocks), block(64);
+    const bool m64 = mz.m > 16;
+#define TBK_COUNT_LAUNCH(N) case N: if (m64) hipLaunchKernelGGL((tbk_count_kernel<N, true>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); \
+                                    else hipLaunchKernelGGL((tbk_count_kernel<N, false>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); break;
+    switch (mz.t > 0 ? -1 : mz.w) {
+        case 0: hipLaunchKernelGGL((tbk_count_kernel<0, false>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); break;
+        TBK_COUNT_LAUNCH(1) TBK_COUNT_LAUNCH(2) TBK_COUNT_LAUNCH(3) TBK_COUNT_LAUNCH(4)
+        TBK_COUNT_LAUNCH(5) TBK_COUNT_LAUNCH(6) TBK_COUNT_LAUNCH(7) TBK_COUNT_LAUNCH(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TBK_COUNT_LAUNCH
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_count_histogram(const uint64_t *d_keys, const uint32_t *d_counts, uint64_t n_slots,
-                                                 unsigned long long *d_hist, hipStream_t stream) {
-    hipLaunchKernelGGL(tbk_count_histogram_kernel, dim3(4096), dim3(256), 0, stream, d_keys, d_counts, n_slots, d_hist);
+extern "C" hipError_t tbk_launch_count_histogram(uint64_t *d_lines, uint32_t n_buckets, TbkMz mz, unsigned long long *d_hist,
+                                                 hipStream_t stream) {
+    hipLaunchKernelGGL(tbk_count_histogram_kernel, dim3(4096), dim3(256), 0, stream, TbkCountView{d_lines, n_buckets, mz}, d_hist);
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_count_unique(uint64_t *a_keys, uint32_t *a_counts, uint32_t a_buckets, TbkMz a_mz,
-                                              uint64_t *b_keys, uint32_t *b_counts, uint32_t b_buckets, TbkMz b_mz, int k,
-                                              uint32_t ci, uint32_t cx, uint64_t *d_out, uint64_t capacity,
+extern "C" hipError_t tbk_launch_count_unique(uint64_t *a_lines, uint32_t a_buckets, TbkMz a_mz, uint64_t *b_lines, uint32_t b_buckets,
+                                              TbkMz b_mz, int k, uint32_t ci, uint32_t cx, uint64_t *d_out, uint64_t capacity,
                                               unsigned long long *d_n, hipStream_t stream) {
-    hipLaunchKernelGGL(tbk_count_unique_kernel, dim3(8192), dim3(256), 0, stream, TbkCountView{a_keys, a_counts, a_buckets, a_mz},
-                       TbkCountView{b_keys, b_counts, b_buckets, b_mz}, k, ci, cx, d_out, capacity, d_n);
+    hipLaunchKernelGGL(tbk_count_unique_kernel, dim3(8192), dim3(256), 0, stream, TbkCountView{a_lines, a_buckets, a_mz},
+                       TbkCountView{b_lines, b_buckets, b_mz}, k, ci, cx, d_out, capacity, d_n);
     return hipGetLastError();
 }
-

@@ -104,14 +104,14 @@ def count_library(paths: List[str], k: int, capacity: int) -> "kmers.Counter":
 
 def estimate_capacity(paths: List[str]) -> int:
     """Distinct k-mers cannot outnumber the bases: uncompressed FASTQ spends two bytes per base,
-    gzip compresses it about fourfold.  Bounded by what two tables (12 bytes per slot at load 0.6)
+    gzip compresses it about fourfold.  Bounded by what two tables (16 bytes per slot at load 0.6)
     may take of the free HBM."""
     bases = 0
     for p in paths:
         size = os.path.getsize(p)
         bases += size * 2 if p.endswith(".gz") else size // 2 + 1
     free, _total = kmers.device_mem_info()
-    fit = int(0.35 * free / 12 * 0.6)
+    fit = int(0.35 * free / 16 * 0.6)
     return max(1 << 16, min(bases, fit))
 
 
