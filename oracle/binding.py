@@ -83,7 +83,20 @@ class Oracle:
         lib.orc_score_and_bin.argtypes = [
             i32p, C.c_uint64, C.c_uint64, C.c_uint64,
             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_char_p]
+        lib.orc_kmer_histogram.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_uint64, u64p]
         self.lib = lib
+
+    def kmer_histogram(self, bases: np.ndarray, offsets: np.ndarray, k: int, expected_distinct: int) -> np.ndarray:
+        """Canonical k-mer count histogram of a batch (find-unique-kmers step), single thread."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        slots = 1 << max(10, int(2 * expected_distinct - 1).bit_length())
+        hist = np.zeros(256, dtype=np.uint64)
+        rc = self.lib.orc_kmer_histogram(bases.ctypes.data, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), offsets.size - 1, k,
+                                         slots, hist.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if rc:
+            raise MemoryError("oracle k-mer table too small")
+        return hist
 
     # -- unit-level API ---------------------------------------------------------------
     def kmer_to_int(self, kmer: str) -> int:

@@ -366,3 +366,51 @@ void orc_score_and_bin(const int32_t *counts, uint64_t n_reads, uint64_t num_a,
         bins[r] = sa > sb ? 'A' : (sb > sa ? 'B' : 'U');
     }
 }
+
+/* ---- find-unique-kmers step: a single-thread canonical k-mer counter -------------------------
+ * Checker and CPU datum for the GPU counter (tbk_counter_*).  Restates the reading of `kmc -k<k>`
+ * documented in oracle/unique_oracle.py (KMC itself is not available: parity with it is
+ * unpinned): canonical k-mers over both strands, windows holding a byte outside ACGT skipped,
+ * lower case counted as upper case.  hist[c], c = 1..255 = distinct k-mers whose count, capped at
+ * 255, is c; hist[0] = distinct k-mers.  Open addressing, linear probing, table of `slots` entries
+ * (a power of two >= 2x the distinct k-mers expected).  Returns 0, or -1 when the table fills up. */
+int orc_kmer_histogram(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k,
+                       uint64_t slots, uint64_t *hist) {
+    uint64_t *keys = malloc(slots * sizeof(uint64_t));
+    uint32_t *cnt = calloc(slots, sizeof(uint32_t));
+    if (!keys || !cnt || (slots & (slots - 1))) { free(keys); free(cnt); return -1; }
+    memset(keys, 0xFF, slots * sizeof(uint64_t));
+    const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t used = 0;
+    int rc = 0;
+    for (uint64_t r = 0; r < n_reads && !rc; r++) {
+        uint64_t fwd = 0, rev = 0;
+        int run = 0;  /* consecutive ACGT bytes seen */
+        for (uint64_t i = offsets[r]; i < offsets[r + 1]; i++) {
+            int c;
+            switch (bases[i] & 0xDF) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break; default: c = -1; }
+            if (c < 0) { run = 0; fwd = rev = 0; continue; }
+            fwd = (fwd >> 2) | ((uint64_t)c << (2 * (k - 1)));
+            rev = ((rev << 2) | (uint64_t)(3 - c)) & mask;
+            if (++run < k) continue;
+            const uint64_t key = fwd < rev ? fwd : rev;
+            uint64_t h = key * 0x9E3779B97F4A7C15ULL;
+            h ^= h >> 29;
+            uint64_t p = h & (slots - 1);
+            while (keys[p] != key && keys[p] != ~0ULL) p = (p + 1) & (slots - 1);
+            if (keys[p] != key) {
+                if (++used > slots - slots / 8) { rc = -1; break; }
+                keys[p] = key;
+            }
+            cnt[p]++;
+        }
+    }
+    if (!rc) {
+        memset(hist, 0, 256 * sizeof(uint64_t));
+        for (uint64_t p = 0; p < slots; p++)
+            if (keys[p] != ~0ULL) { hist[cnt[p] < 255 ? cnt[p] : 255]++; hist[0]++; }
+    }
+    free(keys);
+    free(cnt);
+    return rc;
+}

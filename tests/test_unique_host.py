@@ -64,6 +64,28 @@ def test_oracle_kmc_steps_on_toy_input():
     assert uo.unique_kmers(db, {}, 5, 10) == ["ACG"] and uo.unique_kmers(db, {}, 2, 10) == ["ACG", "GTA"]
 
 
+def test_oracle_c_counter_equals_python_restatement():
+    """The oracle's C counter (checker at scale, CPU datum) against the pure-Python restatement."""
+    from collections import Counter
+
+    import numpy as np
+
+    from oracle import binding
+    from oracle import unique_oracle as uo
+
+    orc = binding.load()
+    rng = np.random.default_rng(1)
+    g = "".join("ACGT"[c] for c in rng.integers(0, 4, 3000))
+    reads = [g[p:p + 100] for p in rng.integers(0, 2900, 400)] + ["acgtNacgtacgtacgtacgtacgtttt", "", g[:20], "N" * 50]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    for k in (1, 5, 21, 31, 32):
+        h = orc.kmer_histogram(bases, offs, k, 100_000)
+        c = uo.count_kmers(reads, k)
+        want = Counter(min(v, 255) for v in c.values())
+        assert int(h[0]) == len(c) and [int(x) for x in h[1:]] == [want.get(i, 0) for i in range(1, 256)], k
+
+
 def test_cli_arguments_mirror_the_reference(built):
     from trio_binning_amd import find_unique_kmers as fu
 

@@ -38,10 +38,24 @@ for b in range(n_batches):
     check(lib.tbk_device_sync(dev))
     count_s += time.time() - t
 t = time.time(); hist = ctr.histogram(); hist_s = time.time() - t
+# parity at scale + CPU datum: the oracle's single-thread C counter on a prefix of the last batch
+# against a GPU counter fed the same prefix
+from oracle import binding
+orc = binding.load()
+n_cpu = min(R, max(1000, int(40e6 // L)))
+h_bases = np.empty(n_cpu * L, dtype=np.uint8); h_offs = np.arange(n_cpu + 1, dtype=np.uint64) * np.uint64(L)
+check(lib.tbk_memcpy_d2h(dev, h_bases.ctypes.data, C.c_void_p(d_bases), h_bases.size))
+t = time.time(); cpu_hist = orc.kmer_histogram(h_bases, h_offs, k, n_cpu * L); cpu_s = time.time() - t
+with kmers.Counter(k, n_cpu * L) as small:
+    small.add(h_bases, h_offs)
+    same = bool(np.array_equal(small.histogram(), cpu_hist))
 st = ctr.stats()
 peak = int(np.argmax(hist[3:]) + 3)
 print(json.dumps({"k": k, "genome": a.genome, "reads": n_batches * R, "read_len": L, "gbases": n_batches * R * L / 1e9,
                   "count_s": round(count_s, 3), "gbases_per_s": round(n_batches * R * L / count_s / 1e9, 2),
                   "gkmers_per_s": round(n_batches * R * (L - k + 1) / count_s / 1e9, 2),
                   "distinct": int(hist[0]), "singletons": int(hist[1]), "coverage_peak_at": peak, "table_load": round(int(hist[0]) / st["n_slots"], 3),
-                  "table_GB": round(st["table_bytes"] / 1e9, 1), "create_s": round(t_create, 2), "histogram_s": round(hist_s, 3)}))
+                  "table_GB": round(st["table_bytes"] / 1e9, 1), "create_s": round(t_create, 2), "histogram_s": round(hist_s, 3),
+                  "cpu_baseline": {"kind": "port", "cores": 1, "mbases_per_s": round(n_cpu * L / cpu_s / 1e6, 1),
+                                   "sample": f"oracle C counter (one open-addressing table, rolling canonical k-mers) on {n_cpu} reads ({n_cpu * L / 1e6:.0f} Mbases)"},
+                  "parity": {"gpu_histogram_equals_cpu": same, "reads_checked": n_cpu}}))
