@@ -259,9 +259,10 @@ int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, u
  * counted as upper case; k-mers seen once are not in the database; counters saturate at 255.
  * KMC itself is not part of the reference checkout: parity with it is unpinned. */
 typedef struct tbk_counter tbk_counter;
-/* Table for up to `capacity_kmers` distinct k-mers (16 bytes per slot at load <= 0.6: a bucket
- * is one 128-byte line holding 8 keys and their 8 counters).  Adding
- * reads fails with TBK_ERR_NOMEM once it is full. */
+/* Table for `capacity_kmers` distinct k-mers to start with (16 bytes per slot at load <= 0.6: a
+ * bucket is one 128-byte line holding 8 keys and their 8 counters).  Before a batch that could
+ * fill it the table is rebuilt twice as large (old and new coexist for the move); TBK_ERR_NOMEM
+ * when HBM cannot hold that. */
 int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tbk_counter **out);
 void tbk_counter_destroy(tbk_counter *c);
 /* Count the canonical k-mers of a batch of reads (the classifier's batch layout; host memory). */
@@ -272,6 +273,8 @@ int tbk_counter_add_device(tbk_counter *c, const void *d_bases, const void *d_of
  * kmc_tools writes, except that KMC's -ci2 database has no row-1 k-mers (callers zero hist[1]);
  * hist[0]: all distinct k-mers met. */
 int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]);
+/* Distinct k-mers met so far (slots taken). */
+int tbk_counter_distinct(const tbk_counter *c, uint64_t *distinct);
 int tbk_counter_stats(const tbk_counter *c, uint64_t *n_slots, uint64_t *table_bytes, uint64_t *bases_added, uint64_t *reads_added);
 /* kmers_subtract + kmc_dump: write to out_path, one k-mer per line in lexicographic order, the
  * k-mers of `a` seen at least twice whose counter lies in [min_count, max_count] and that `b` has

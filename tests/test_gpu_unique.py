@@ -72,15 +72,28 @@ def test_counter_matches_oracle(gpu, tmp_path, k):
         assert st["reads_added"] == len(reads_a) and st["bases_added"] == sum(map(len, reads_a))
 
 
-def test_counter_full_table_is_reported(gpu):
-    from trio_binning_amd import _lib, kmers
+def test_counter_grows_before_a_batch_could_fill_it(gpu, tmp_path):
+    """A counter created far too small is rebuilt larger (several times) as batches arrive; the
+    counters it already holds move with it."""
+    from oracle import unique_oracle as uo
+    from trio_binning_amd import kmers
 
+    k = 21
     rng = np.random.default_rng(1)
-    reads = ["".join("ACGT"[c] for c in rng.integers(0, 4, 2000)) for _ in range(50)]
-    with kmers.Counter(21, 1000) as c:
-        with pytest.raises((_lib.TbkError, MemoryError, ValueError)) as e:
-            c.add_reads(reads)
-        assert "full" in str(e.value)
+    genome = "".join("ACGT"[c] for c in rng.integers(0, 4, 20_000))
+    reads = _library(rng, genome, 3000, 120, err=0.02)
+    with kmers.Counter(k, 1000) as c, kmers.Counter(k, 1000) as empty:
+        slots0 = c.stats()["n_slots"]
+        for i in range(0, len(reads), 500):
+            c.add_reads(reads[i:i + 500])
+        st = c.stats()
+        want = uo.count_kmers(reads, k)
+        assert st["n_slots"] > 50 * slots0 and st["distinct"] == len(want)
+        hist = c.histogram()
+        assert int(hist[0]) == len(want)
+        out = str(tmp_path / "all.txt")
+        n = c.unique(empty, 2, 255, out)
+        assert open(out).read().split() == uo.unique_kmers(uo.database(want), {}, 2, 255) and n > 1000
 
 
 def test_find_unique_kmers_cli(gpu, tmp_path, capsys):

@@ -116,6 +116,7 @@ _sig("tbk_counter_destroy", None, _vp)
 _sig("tbk_counter_add_batch", C.c_int, _vp, _vp, _vp, _u64)
 _sig("tbk_counter_add_device", C.c_int, _vp, _vp, _vp, _u64, _u64)
 _sig("tbk_counter_histogram", C.c_int, _vp, _u64p)
+_sig("tbk_counter_distinct", C.c_int, _vp, _u64p)
 _sig("tbk_counter_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
 _sig("tbk_counter_unique", C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_char_p, _u64p)
 _sig("tbk_calib_gather", C.c_int, C.c_int, _u64, C.c_int, C.c_int, C.c_int, _u64, C.c_int, _dp, _dp)

@@ -31,7 +31,10 @@
 
 extern "C" void tbk_set_error_(int code, const char *msg);
 extern "C" hipError_t tbk_launch_separate(const uint8_t *, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_count(const uint8_t *, uint64_t, int, uint64_t *, uint32_t, TbkMz, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_count(const uint8_t *, uint64_t, uint64_t, uint64_t, int, uint64_t *, uint32_t, TbkMz, int *, unsigned long long *,
+                                       hipStream_t);
+extern "C" uint64_t tbk_probe_passes(uint64_t total);
+extern "C" hipError_t tbk_launch_count_rehash(uint64_t *, uint32_t, TbkMz, uint64_t *, uint32_t, TbkMz, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_count_histogram(uint64_t *, uint32_t, TbkMz, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_count_unique(uint64_t *, uint32_t, TbkMz, uint64_t *, uint32_t, TbkMz, int, uint32_t, uint32_t,
                                               uint64_t *, uint64_t, unsigned long long *, hipStream_t);
@@ -59,6 +62,9 @@ struct tbk_counter {
     uint32_t n_buckets = 0;
     TbkMz mz{0, 0, 0, 0};
     int *d_failed = nullptr;
+    unsigned long long *d_used = nullptr;  // slots taken so far (distinct k-mers met), kept by the kernels
+    uint64_t used = 0;
+    double load = 0.6;
     // staging of one batch: reads back to back, their offsets, and the separated upper-cased copy
     uint8_t *d_raw = nullptr, *d_sep = nullptr;
     uint64_t *d_off = nullptr;
@@ -73,6 +79,27 @@ static int counter_device(const tbk_counter *c) {
     return TBK_OK;
 }
 
+// lines for `capacity` distinct k-mers at the counter's target load; keys = all ones (free), counters = 0
+static int alloc_lines(int k, uint64_t capacity, double load, uint64_t **d_lines, uint32_t *n_buckets, TbkMz *mz) {
+    uint64_t nb = (uint64_t)((double)capacity / (TBK_SLOTS_PER_BUCKET * load)) + 16;
+    if (nb > 0x7FFFFFF0ull) return cfail(TBK_ERR_NOMEM, "%llu distinct k-mers are more than one table holds", (unsigned long long)capacity);
+    const size_t bytes = (size_t)nb * 128;
+    hipError_t e = hipMalloc((void **)d_lines, bytes);
+    if (e == hipSuccess) e = hipMemset2D(*d_lines, 128, 0xFF, 64, nb);
+    if (e == hipSuccess) e = hipMemset2D((uint8_t *)*d_lines + 64, 128, 0, 64, nb);
+    if (e != hipSuccess) {
+        if (*d_lines) (void)hipFree(*d_lines);
+        *d_lines = nullptr;
+        (void)hipGetLastError();
+        return cfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "counting table for %llu k-mers (%zu bytes): %s",
+                     (unsigned long long)capacity, bytes, hipGetErrorString(e));
+    }
+    *n_buckets = (uint32_t)nb;
+    const char *ew = getenv("TBK_COUNT_W"), *em = getenv("TBK_COUNT_M");
+    *mz = tbk_mz_params(k, ew ? atoi(ew) : 6, capacity, em ? atoi(em) : 0, 0);
+    return TBK_OK;
+}
+
 extern "C" int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tbk_counter **out) {
     if (!out) return cfail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -82,31 +109,43 @@ extern "C" int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tb
     tmp.device = device;
     int rc = counter_device(&tmp);
     if (rc) return rc;
-    // 8-slot lines at load <= 0.6: a counting table meets every distinct k-mer of the reads,
-    // sequencing errors included, so it is sized by the caller's estimate and fails loudly when full
-    const char *ev = getenv("TBK_COUNT_LOAD");
-    double load = ev ? atof(ev) : 0.6;
-    if (load < 0.05) load = 0.05;
-    if (load > 0.9) load = 0.9;
-    uint64_t nb = (uint64_t)((double)capacity_kmers / (TBK_SLOTS_PER_BUCKET * load)) + 16;
-    if (nb > 0x7FFFFFF0ull) return cfail(TBK_ERR_INVALID, "capacity %llu k-mers is more than one table holds", (unsigned long long)capacity_kmers);
+    // 8-slot lines at load <= 0.6.  A counting table meets every distinct k-mer of the reads,
+    // sequencing errors included; the capacity is the caller's estimate, and the table is rebuilt
+    // twice as large whenever the next batch could fill it.
     tbk_counter *c = new tbk_counter();
-    c->device = device; c->k = k; c->n_buckets = (uint32_t)nb;
-    const char *ew = getenv("TBK_COUNT_W"), *em = getenv("TBK_COUNT_M");
-    c->mz = tbk_mz_params(k, ew ? atoi(ew) : 6, capacity_kmers, em ? atoi(em) : 0, 0);
-    const size_t slots = (size_t)nb * TBK_SLOTS_PER_BUCKET, bytes = (size_t)nb * 128;
-    hipError_t e = hipMalloc((void **)&c->d_lines, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_failed, sizeof(int));
-    // keys = all ones (free), counters = 0: per line 64 bytes of 0xFF then 64 bytes of 0
-    if (e == hipSuccess) e = hipMemset2D(c->d_lines, 128, 0xFF, 64, nb);
-    if (e == hipSuccess) e = hipMemset2D((uint8_t *)c->d_lines + 64, 128, 0, 64, nb);
-    if (e == hipSuccess) e = hipMemset(c->d_failed, 0, sizeof(int));
-    if (e != hipSuccess) {
-        tbk_counter_destroy(c);
-        return cfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "counting table (%zu slots, %zu bytes): %s", slots, bytes,
-                     hipGetErrorString(e));
-    }
+    c->device = device; c->k = k;
+    const char *ev = getenv("TBK_COUNT_LOAD");
+    c->load = ev ? atof(ev) : 0.6;
+    if (c->load < 0.05) c->load = 0.05;
+    if (c->load > 0.9) c->load = 0.9;
+    rc = alloc_lines(k, capacity_kmers, c->load, &c->d_lines, &c->n_buckets, &c->mz);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMalloc((void **)&c->d_failed, sizeof(int));
+    if (!rc && e == hipSuccess) e = hipMalloc((void **)&c->d_used, sizeof(unsigned long long));
+    if (!rc && e == hipSuccess) e = hipMemset(c->d_failed, 0, sizeof(int));
+    if (!rc && e == hipSuccess) e = hipMemset(c->d_used, 0, sizeof(unsigned long long));
+    if (!rc && e != hipSuccess) rc = cfail(TBK_ERR_HIP, "tbk_counter_create: %s", hipGetErrorString(e));
+    if (rc) { tbk_counter_destroy(c); return rc; }
     *out = c;
+    return TBK_OK;
+}
+
+// Rebuild the table for `capacity` distinct k-mers and move every (key, counter) over.
+static int counter_grow(tbk_counter *c, uint64_t capacity) {
+    uint64_t *d_new = nullptr;
+    uint32_t nb = 0;
+    TbkMz mz{0, 0, 0, 0};
+    int rc = alloc_lines(c->k, capacity, c->load, &d_new, &nb, &mz);
+    if (rc) return rc;
+    hipError_t e = tbk_launch_count_rehash(c->d_lines, c->n_buckets, c->mz, d_new, nb, mz, c->d_failed, nullptr);
+    int failed = 0;
+    if (e == hipSuccess) e = hipMemcpy(&failed, c->d_failed, sizeof failed, hipMemcpyDeviceToHost);
+    if (e != hipSuccess || failed) {
+        (void)hipFree(d_new);
+        return cfail(TBK_ERR_HIP, "counting table rebuild failed: %s", e != hipSuccess ? hipGetErrorString(e) : "new table full");
+    }
+    (void)hipFree(c->d_lines);
+    c->d_lines = d_new; c->n_buckets = nb; c->mz = mz;
     return TBK_OK;
 }
 
@@ -114,7 +153,7 @@ extern "C" void tbk_counter_destroy(tbk_counter *c) {
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         (void)hipDeviceSynchronize();
-        for (void *p : {(void *)c->d_lines, (void *)c->d_failed, (void *)c->d_raw, (void *)c->d_sep, (void *)c->d_off})
+        for (void *p : {(void *)c->d_lines, (void *)c->d_failed, (void *)c->d_used, (void *)c->d_raw, (void *)c->d_sep, (void *)c->d_off})
             if (p) (void)hipFree(p);
     }
     delete c;
@@ -129,11 +168,31 @@ static int counter_run(tbk_counter *c, const uint8_t *d_bases, const uint64_t *d
         c->cap_sep = need_sep + need_sep / 8;
     }
     CHIP(tbk_launch_separate(d_bases, d_offsets, n_reads, c->d_sep, nullptr));
-    CHIP(tbk_launch_count(c->d_sep, total + n_reads, c->k, c->d_lines, c->n_buckets, c->mz, c->d_failed, nullptr));
-    int failed = 0;
-    CHIP(hipMemcpy(&failed, c->d_failed, sizeof failed, hipMemcpyDeviceToHost));
-    if (failed) return cfail(TBK_ERR_NOMEM, "counting table is full (%llu slots): create the counter with a larger capacity",
-                             (unsigned long long)c->n_buckets * TBK_SLOTS_PER_BUCKET);
+    // The stream is counted in pieces of a quarter of the table's slots (at least 64 M window
+    // starts).  Every window of a piece could be a k-mer never seen before, so before a piece that
+    // could fill the table the table is rebuilt twice as large - a piece can then never run out of
+    // room half way, and the table grows once its load passes 0.6.
+    const uint64_t sep_total = total + n_reads, passes = tbk_probe_passes(sep_total);
+    for (uint64_t p0 = 0; p0 < passes;) {
+        uint64_t slots = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET;
+        const uint64_t piece = std::max<uint64_t>(32768, slots / 4 / 2048);
+        const uint64_t np = std::min(piece, passes - p0), windows = np * 2048;
+        if ((double)(c->used + windows) > 0.85 * (double)slots) {
+            uint64_t want = (uint64_t)((double)slots * c->load) * 2;  // twice the present capacity
+            while ((double)(c->used + windows) > 0.85 * ((double)want / c->load)) want *= 2;
+            const int rc = counter_grow(c, want);
+            if (rc) return rc;
+            slots = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET;
+        }
+        CHIP(tbk_launch_count(c->d_sep, sep_total, p0, np, c->k, c->d_lines, c->n_buckets, c->mz, c->d_failed, c->d_used, nullptr));
+        int failed = 0;
+        unsigned long long used = 0;
+        CHIP(hipMemcpy(&failed, c->d_failed, sizeof failed, hipMemcpyDeviceToHost));
+        CHIP(hipMemcpy(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost));
+        c->used = used;
+        if (failed) return cfail(TBK_ERR_NOMEM, "counting table is full (%llu slots, %llu taken)", (unsigned long long)slots, used);
+        p0 += np;
+    }
     c->bases_added += total;
     c->reads_added += n_reads;
     return TBK_OK;
@@ -184,6 +243,12 @@ extern "C" int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]) {
     (void)hipFree(d_hist);
     if (e != hipSuccess) return cfail(TBK_ERR_HIP, "tbk_counter_histogram: %s", hipGetErrorString(e));
     for (int i = 0; i < 256; i++) hist[i] = h[i];
+    return TBK_OK;
+}
+
+extern "C" int tbk_counter_distinct(const tbk_counter *c, uint64_t *distinct) {
+    if (!c || !distinct) return cfail(TBK_ERR_INVALID, "NULL argument");
+    *distinct = c->used;
     return TBK_OK;
 }
 

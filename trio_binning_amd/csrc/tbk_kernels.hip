@@ -744,17 +744,22 @@ struct TbkCountView {
     __device__ __forceinline__ uint32_t *counts(uint32_t b) const { return (uint32_t *)(lines + (uint64_t)b * TBK_COUNT_LINE + TBK_SLOTS_PER_BUCKET); }
 };
 
-// find or claim the key's slot along its probe sequence, from bucket b on, and count one occurrence
-__device__ __forceinline__ bool count_from(const TbkCountView &t, uint64_t key, uint32_t b, bool at_home) {
-    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+// A probe sequence longer than this means the table is as good as full (the host grows the table
+// long before: tbk_count.cpp); giving up keeps a mis-sized table from turning into an endless walk.
+constexpr uint32_t TBK_COUNT_MAX_WALK = 1u << 12;
+
+// find or claim the key's slot along its probe sequence, from bucket b on, and add `n` occurrences;
+// `claimed` counts the slots newly taken
+__device__ __forceinline__ bool count_from(const TbkCountView &t, uint64_t key, uint32_t b, bool at_home, uint32_t n, uint32_t &claimed) {
+    for (uint32_t walked = 0; walked <= t.n_buckets && walked < TBK_COUNT_MAX_WALK; walked++) {
         unsigned long long *line = t.keys(b);
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
             unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == TBK_EMPTY) {
                 cur = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
-                if (cur == TBK_EMPTY) cur = key;
+                if (cur == TBK_EMPTY) { cur = key; claimed++; }
             }
-            if (cur == key) { atomicAdd(&t.counts(b)[s], 1u); return true; }
+            if (cur == key) { atomicAdd(&t.counts(b)[s], n); return true; }
         }
         b = tbk_next_bucket(key, t.mz, t.n_buckets, b, at_home && walked == 0);
     }
@@ -770,8 +775,8 @@ __device__ __forceinline__ bool count_from(const TbkCountView &t, uint64_t key, 
 // is really there.
 template <int W, bool M64>
 __global__ void __launch_bounds__(64)
-tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_passes, int k, TbkCountView t,
-                 int *__restrict__ failed) {
+tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t first_pass, uint64_t n_passes, int k, TbkCountView t,
+                 int *__restrict__ failed, unsigned long long *__restrict__ used) {
     __shared__ uint64_t stage[TBK_CHUNKS + 2];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -787,7 +792,7 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
         const uint32_t x = (uint32_t)(fwd64 >> fsh) & (uint32_t)mmask, y = (uint32_t)(rc64 >> bsh) & (uint32_t)mmask;
         return (win_t)tbk_mmer_hash(x < y ? x : y);
     };
-    for (uint64_t pass = blockIdx.x; pass < n_passes; pass += gridDim.x) {
+    for (uint64_t pass = first_pass + blockIdx.x; pass < first_pass + n_passes; pass += gridDim.x) {
         const uint64_t P0 = pass * TBK_PASS;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         stage[lane] = load_chunk(bases, P0 + (uint64_t)lane * 16, total);
@@ -817,6 +822,7 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
 #pragma unroll
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) held[s] = 0;
         uint32_t held_bk = 0xFFFFFFFFu;
+        uint32_t claimed = 0;  // slots this lane took for new k-mers
         bool full = false;
 #pragma unroll 2
         for (int j = 0; j < TBK_WPL; j++) {
@@ -853,17 +859,37 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t n_p
                     if (held[s] == TBK_EMPTY) {
                         const unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
                         held[s] = old == TBK_EMPTY ? key : old;
+                        claimed += old == TBK_EMPTY ? 1u : 0u;
                     }
                     if (held[s] == key) { atomicAdd(&t.counts(b)[s], 1u); done = true; }
                 }
                 // home bucket full of other keys: follow the probe sequence
-                if (!done && !count_from(t, key, tbk_next_bucket(key, t.mz, t.n_buckets, b, true), false)) full = true;
+                if (!done && !count_from(t, key, tbk_next_bucket(key, t.mz, t.n_buckets, b, true), false, 1u, claimed)) full = true;
             }
             s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
             t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
             bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
         }
         if (full) atomicExch(failed, 1);
+        // slots taken by this wave: one atomic per pass
+        uint32_t sum = claimed;
+        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0 && sum) atomicAdd(used, (unsigned long long)sum);
+    }
+}
+
+// Move every (key, counter) of an old table into a new, larger one (the host grows the table when
+// the next batch could fill it).
+__global__ void __launch_bounds__(256)
+tbk_count_rehash_kernel(TbkCountView from, TbkCountView to, int *__restrict__ failed) {
+    const uint64_t n_slots = (uint64_t)from.n_buckets * TBK_SLOTS_PER_BUCKET;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += step) {
+        const uint32_t b = (uint32_t)(i >> 3), s = (uint32_t)(i & 7);
+        const uint64_t key = from.keys(b)[s];
+        if (key == TBK_EMPTY) continue;
+        uint32_t claimed = 0;
+        if (!count_from(to, key, tbk_bucket_of(key, to.mz, to.n_buckets), true, from.counts(b)[s], claimed)) atomicExch(failed, 1);
     }
 }
 
@@ -890,7 +916,7 @@ tbk_count_histogram_kernel(TbkCountView t, unsigned long long *__restrict__ hist
 // free slot along their probe sequence, so a line with a free slot ends the search.
 __device__ __forceinline__ uint32_t count_lookup(const TbkCountView &t, uint64_t key) {
     uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
-    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+    for (uint32_t walked = 0; walked <= t.n_buckets && walked < TBK_COUNT_MAX_WALK; walked++) {
         const unsigned long long *line = t.keys(b);
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
             const uint64_t cur = line[s];
@@ -1024,18 +1050,26 @@ extern "C" hipError_t tbk_launch_separate(const uint8_t *d_bases, const uint64_t
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_count(const uint8_t *d_sep, uint64_t total, int k, uint64_t *d_lines,
-                                       uint32_t n_buckets, TbkMz mz, int *d_failed, hipStream_t stream) {
-    if (total < (uint64_t)k) return hipSuccess;
-    const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
+extern "C" hipError_t tbk_launch_count_rehash(uint64_t *from_lines, uint32_t from_buckets, TbkMz from_mz, uint64_t *to_lines,
+                                              uint32_t to_buckets, TbkMz to_mz, int *d_failed, hipStream_t stream) {
+    hipLaunchKernelGGL(tbk_count_rehash_kernel, dim3(8192), dim3(256), 0, stream, TbkCountView{from_lines, from_buckets, from_mz},
+                       TbkCountView{to_lines, to_buckets, to_mz}, d_failed);
+    return hipGetLastError();
+}
+
+// passes [first_pass, first_pass + n_passes) of the separated stream (tbk_probe_passes(total) in all)
+extern "C" hipError_t tbk_launch_count(const uint8_t *d_sep, uint64_t total, uint64_t first_pass, uint64_t n_passes, int k,
+                                       uint64_t *d_lines, uint32_t n_buckets, TbkMz mz, int *d_failed, unsigned long long *d_used,
+                                       hipStream_t stream) {
+    if (total < (uint64_t)k || !n_passes) return hipSuccess;
     const uint64_t blocks = n_passes < (1u << 20) ? n_passes : (1u << 20);
     const TbkCountView view{d_lines, n_buckets, mz};
     const dim3 grid((unsigned)blocks), block(64);
     const bool m64 = mz.m > 16;
-#define TBK_COUNT_LAUNCH(N) case N: if (m64) hipLaunchKernelGGL((tbk_count_kernel<N, true>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); \
-                                    else hipLaunchKernelGGL((tbk_count_kernel<N, false>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); break;
+#define TBK_COUNT_LAUNCH(N) case N: if (m64) hipLaunchKernelGGL((tbk_count_kernel<N, true>), grid, block, 0, stream, d_sep, total, first_pass, n_passes, k, view, d_failed, d_used); \
+                                    else hipLaunchKernelGGL((tbk_count_kernel<N, false>), grid, block, 0, stream, d_sep, total, first_pass, n_passes, k, view, d_failed, d_used); break;
     switch (mz.t > 0 ? -1 : mz.w) {
-        case 0: hipLaunchKernelGGL((tbk_count_kernel<0, false>), grid, block, 0, stream, d_sep, total, n_passes, k, view, d_failed); break;
+        case 0: hipLaunchKernelGGL((tbk_count_kernel<0, false>), grid, block, 0, stream, d_sep, total, first_pass, n_passes, k, view, d_failed, d_used); break;
         TBK_COUNT_LAUNCH(1) TBK_COUNT_LAUNCH(2) TBK_COUNT_LAUNCH(3) TBK_COUNT_LAUNCH(4)
         TBK_COUNT_LAUNCH(5) TBK_COUNT_LAUNCH(6) TBK_COUNT_LAUNCH(7) TBK_COUNT_LAUNCH(8)
         default: return hipErrorInvalidValue;

@@ -386,7 +386,9 @@ class Counter:
     def stats(self) -> dict:
         v = [C.c_uint64() for _ in range(4)]
         check(lib.tbk_counter_stats(self._h, *[C.byref(x) for x in v]))
-        return dict(zip(("n_slots", "table_bytes", "bases_added", "reads_added"), (x.value for x in v)))
+        d = C.c_uint64()
+        check(lib.tbk_counter_distinct(self._h, C.byref(d)))
+        return dict(zip(("n_slots", "table_bytes", "bases_added", "reads_added", "distinct"), [x.value for x in v] + [d.value]))
 
     def unique(self, other: "Counter", min_count: int, max_count: int, out_path: str) -> int:
         """Write the k-mers this library saw at least twice, with a counter in [min_count,
