@@ -16,6 +16,7 @@ ap.add_argument("--read-len", type=int, default=150)
 ap.add_argument("--error-rate", type=float, default=0.002)
 ap.add_argument("--batch-bases", type=int, default=1_000_000_000)
 ap.add_argument("-k", type=int, default=21)
+ap.add_argument("--dump", default="", help="also time subtract + sorted dump of the k-mers counted 2..255 times to this path")
 a = ap.parse_args()
 dev, k, L = 0, a.k, a.read_len
 R = a.batch_bases // L
@@ -50,6 +51,11 @@ with kmers.Counter(k, n_cpu * L) as small:
     small.add(h_bases, h_offs)
     same = bool(np.array_equal(small.histogram(), cpu_hist))
 st = ctr.stats()
+dump = None
+if a.dump:
+    with kmers.Counter(k, 1 << 16) as nothing:
+        t = time.time(); n_dumped = ctr.unique(nothing, 2, 255, a.dump); dump = {"kmers": n_dumped, "seconds": round(time.time() - t, 2), "file_GB": round(os.path.getsize(a.dump) / 1e9, 2)}
+    os.remove(a.dump)
 peak = int(np.argmax(hist[3:]) + 3)
 print(json.dumps({"k": k, "genome": a.genome, "reads": n_batches * R, "read_len": L, "gbases": n_batches * R * L / 1e9,
                   "count_s": round(count_s, 3), "gbases_per_s": round(n_batches * R * L / count_s / 1e9, 2),
@@ -58,4 +64,4 @@ print(json.dumps({"k": k, "genome": a.genome, "reads": n_batches * R, "read_len"
                   "table_GB": round(st["table_bytes"] / 1e9, 1), "create_s": round(t_create, 2), "histogram_s": round(hist_s, 3),
                   "cpu_baseline": {"kind": "port", "cores": 1, "mbases_per_s": round(n_cpu * L / cpu_s / 1e6, 1),
                                    "sample": f"oracle C counter (one open-addressing table, rolling canonical k-mers) on {n_cpu} reads ({n_cpu * L / 1e6:.0f} Mbases)"},
-                  "parity": {"gpu_histogram_equals_cpu": same, "reads_checked": n_cpu}}))
+                  "parity": {"gpu_histogram_equals_cpu": same, "reads_checked": n_cpu}, "dump": dump}))
