@@ -84,6 +84,55 @@ def test_reader_equals_python_mirror_on_toy_files(built, tmp_path):
     assert _native_records(str(cr)) == [[r.name, r.seq, r.qual] for r in seq.open_fastx_read(str(cr))]
 
 
+def _bgzf(data: bytes, block=60000, eof_marker=True) -> bytes:
+    """bgzip's container: gzip members of <= 64 KiB, each carrying its size in a BC extra subfield."""
+    import zlib
+
+    out = bytearray()
+    pieces = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for piece in pieces:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(piece) + c.flush()
+        bsize = 18 + len(body) + 8
+        out += struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+
+
+def test_reader_inflates_bgzf_blocks_side_by_side(built, tmp_path):
+    """bgzip'ed input (independent <= 64 KiB members) goes through the block-parallel inflate; the
+    records must be those of the plain file.  Also: BGZF blocks followed by an ordinary gzip member
+    (the sequential path takes over), an ordinary member first, and damaged files."""
+    from trio_binning_amd import _lib
+
+    rng = random.Random(11)
+    seqs = ["".join(rng.choice("ACGTN") for _ in range(rng.randint(1, 3000))) for _ in range(3000)]
+    text = "".join("@r%d c\n%s\n+\n%s\n" % (i, q, "I" * len(q)) for i, q in enumerate(seqs)).encode()
+    plain = tmp_path / "p.fastq"
+    plain.write_bytes(text)
+    want = _native_records(str(plain))
+    assert len(want) == 3000
+    cases = {
+        "bgzf.fastq.gz": _bgzf(text),
+        "bgzf_small_blocks.fastq.gz": _bgzf(text, block=777),
+        "bgzf_no_eof.fastq.gz": _bgzf(text, eof_marker=False),
+        "bgzf_then_gzip.fastq.gz": _bgzf(text[:100_000], eof_marker=False) + gzip.compress(text[100_000:]),
+        "gzip_then_bgzf.fastq.gz": gzip.compress(text[:100_000]) + _bgzf(text[100_000:]),
+    }
+    for name, blob in cases.items():
+        f = tmp_path / name
+        f.write_bytes(blob)
+        assert gzip.decompress(blob) == text, name  # the container is valid gzip
+        assert _native_records(str(f)) == want, name
+        assert _native_records(str(f), max_bases=50_000) == want, name
+    good = _bgzf(text)
+    for name, blob in (("cut.fastq.gz", good[: len(good) // 2]), ("flip.fastq.gz", good[:5000] + bytes([good[5000] ^ 0x55]) + good[5001:])):
+        f = tmp_path / name
+        f.write_bytes(blob)
+        with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
+            _native_records(str(f))
+
+
 def test_reader_batch_layout(built, tmp_path):
     """bases lie back to back, offsets are cumulative, limits cut after whole records."""
     from trio_binning_amd import seq

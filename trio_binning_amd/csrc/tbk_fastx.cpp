@@ -63,6 +63,11 @@ struct LineSource {
     size_t pos = 0, end = 0;
     bool skip_lf = false;      // previous line ended in '\r' at the window edge: swallow a leading '\n'
     std::string err;
+    // BGZF (bgzip) files are gzip files whose members are independent blocks of <= 64 KiB that
+    // carry their own compressed size in a "BC" extra subfield: such members can be inflated side
+    // by side.  Same bytes as the sequential path; taken while every member at hand is such a block.
+    bool bgzf = false;
+    int threads = 1;
 
     bool open_path(const char *path, bool gzip) {
         fd = ::open(path, O_RDONLY);
@@ -74,8 +79,89 @@ struct LineSource {
             memset(&zs, 0, sizeof zs);
             if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "inflateInit2 failed"; return false; }
             zs_live = true;
+            threads = std::max(1, tbk_host_threads());
+            uint8_t head[18];
+            const ssize_t n = ::pread(fd, head, sizeof head, 0);
+            bgzf = threads > 1 && n == (ssize_t)sizeof head && bgzf_block_size(head, sizeof head) > 0;
+            if (bgzf) zin.resize((size_t)8 << 20);
         }
         return true;
+    }
+    // total size of the BGZF block starting at p (0 if p does not start one or n < 18)
+    static size_t bgzf_block_size(const uint8_t *p, size_t n) {
+        if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+        const size_t xlen = p[10] | ((size_t)p[11] << 8);
+        if (xlen < 6 || p[12] != 'B' || p[13] != 'C' || p[14] != 2 || p[15] != 0) return 0;
+        return ((size_t)p[16] | ((size_t)p[17] << 8)) + 1;
+    }
+    // Inflate as many whole BGZF blocks as the compressed window holds, side by side, straight
+    // into buf[end..].  Returns 1 bytes produced (or clean end), 0 fall back to the sequential path
+    // (the window does not start with a BGZF block), -1 error.
+    int refill_bgzf() {
+        for (;;) {
+            // top up the compressed window
+            if (zin_pos > 0 && zin_pos < zin_end) memmove(zin.data(), zin.data() + zin_pos, zin_end - zin_pos);
+            zin_end -= zin_pos; zin_pos = 0;
+            while (!raw_eof && zin_end < zin.size()) {
+                const ssize_t n = ::read(fd, zin.data() + zin_end, zin.size() - zin_end);
+                if (n < 0) { err = std::string("read: ") + strerror(errno); return -1; }
+                if (n == 0) raw_eof = true;
+                zin_end += (size_t)(n > 0 ? n : 0);
+            }
+            if (zin_end == 0) { text_eof = true; return 1; }
+            struct Blk { size_t in, in_len, out, out_len; uint32_t crc; };
+            std::vector<Blk> blks;
+            size_t p = 0, out_total = 0;
+            while (p < zin_end) {
+                const size_t bs = bgzf_block_size(zin.data() + p, zin_end - p);
+                if (bs == 0) break;            // not a BGZF block (or its header is cut off)
+                if (bs < 26 || p + bs > zin_end) { if (bs < 26) { err = "corrupt BGZF block"; return -1; } break; }
+                const uint8_t *b = zin.data() + p;
+                const size_t xlen = b[10] | ((size_t)b[11] << 8), hdr = 12 + xlen;
+                if (hdr + 8 > bs) { err = "corrupt BGZF block"; return -1; }
+                const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
+                const size_t isize = (size_t)b[bs - 4] | ((size_t)b[bs - 3] << 8) | ((size_t)b[bs - 2] << 16) | ((size_t)b[bs - 1] << 24);
+                if (isize > (1u << 16)) { err = "corrupt BGZF block"; return -1; }
+                blks.push_back(Blk{p + hdr, bs - hdr - 8, out_total, isize, crc});
+                out_total += isize;
+                p += bs;
+            }
+            if (blks.empty()) {
+                if (p == 0 && zin_end >= 18 && bgzf_block_size(zin.data(), zin_end) == 0) return 0;  // an ordinary gzip member follows
+                if (raw_eof) { err = "truncated gzip file"; return -1; }
+                if (zin_end == zin.size()) { err = "corrupt BGZF block"; return -1; }
+                continue;  // header or block cut off by the window: read more
+            }
+            if (buf.size() - end < out_total) buf.resize(end + out_total + (1u << 16));
+            uint8_t *out = buf.data() + end;
+            std::atomic<size_t> next{0};
+            std::atomic<bool> ok{true};
+            auto work = [&]() {
+                z_stream z;
+                memset(&z, 0, sizeof z);
+                if (inflateInit2(&z, -15) != Z_OK) { ok.store(false); return; }
+                for (size_t i; (i = next.fetch_add(1)) < blks.size() && ok.load();) {
+                    const Blk &k = blks[i];
+                    inflateReset(&z);
+                    z.next_in = zin.data() + k.in; z.avail_in = (uInt)k.in_len;
+                    z.next_out = out + k.out; z.avail_out = (uInt)k.out_len;
+                    const int rc = k.out_len ? inflate(&z, Z_FINISH) : Z_STREAM_END;  // an empty block (the end-of-file marker) has nothing to inflate
+                    if ((rc != Z_STREAM_END) || z.avail_out != 0 ||
+                        (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + k.out, (uInt)k.out_len) != k.crc) ok.store(false);
+                }
+                inflateEnd(&z);
+            };
+            const int nt = (int)std::min<size_t>((size_t)threads, blks.size());
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(work);
+            work();
+            for (std::thread &t : pool) t.join();
+            if (!ok.load()) { err = "inflate: corrupt BGZF block"; return -1; }
+            zin_pos = p;
+            end += out_total;
+            if (out_total) return 1;
+            // only empty blocks (the BGZF end-of-file marker): go on
+        }
     }
     void close_all() {
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
@@ -99,6 +185,15 @@ struct LineSource {
             if (n == 0) { text_eof = true; return true; }
             end += (size_t)n;
             return true;
+        }
+        if (bgzf) {
+            // a window of blocks inflates to tens of megabytes: keep only the unconsumed tail in front of it
+            if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+            const int r = refill_bgzf();
+            if (r < 0) return false;
+            if (r > 0) return true;
+            bgzf = false;  // an ordinary member: the sequential path takes over from zin[zin_pos..zin_end)
+            inflateReset(&zs);
         }
         for (;;) {
             if (zin_pos == zin_end && !raw_eof) {
