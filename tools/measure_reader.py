@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Native FASTQ reader rate on plain, gzip'ed and bgzip'ed copies of one synthetic file
+(text GB/s): the host-side ceiling of both CLIs."""
+import argparse, gzip, json, os, struct, sys, tempfile, time, zlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trio_binning_amd import seq
+from trio_binning_amd._lib import lib
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=60000)
+ap.add_argument("--read-len", type=int, default=10000)
+a = ap.parse_args()
+rng = np.random.default_rng(0)
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+text = b"".join(b"@r%d\n" % i + lut[rng.integers(0, 4, a.read_len)].tobytes() + b"\n+\n" + b"I" * a.read_len + b"\n" for i in range(a.reads))
+def bgzf(data, block=60000):
+    out = bytearray()
+    for i in range(0, len(data), block):
+        piece = data[i:i + block]; c = zlib.compressobj(1, zlib.DEFLATED, -15); body = c.compress(piece) + c.flush()
+        out += struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+tmp = tempfile.mkdtemp(prefix="tbk_reader_")
+files = {"plain": os.path.join(tmp, "t.fastq"), "gzip": os.path.join(tmp, "t_gz.fastq.gz"), "bgzf": os.path.join(tmp, "t_bgzf.fastq.gz")}
+open(files["plain"], "wb").write(text); open(files["gzip"], "wb").write(gzip.compress(text, 1)); open(files["bgzf"], "wb").write(bgzf(text))
+def run(path):
+    t = time.time(); n = 0
+    with seq.BatchReader(path) as r:
+        b = seq.Batch()
+        while True:
+            k = r.next_batch(b, 256 << 20, 1 << 20)
+            if not k: break
+            n += k
+        b.close()
+    assert n == a.reads
+    return time.time() - t
+res = {"text_GB": round(len(text) / 1e9, 2), "host_threads": int(lib.tbk_host_threads())}
+for name in ("plain", "gzip", "bgzf", "plain", "gzip", "bgzf"):
+    dt = run(files[name]); res[name] = {"seconds": round(dt, 2), "text_GB_per_s": round(len(text) / dt / 1e9, 2)}
+for f in files.values(): os.remove(f)
+os.rmdir(tmp)
+print(json.dumps(res))
