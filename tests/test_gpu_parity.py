@@ -190,7 +190,7 @@ def test_long_mmer_bucket_selection(gpu, orc, tmp_path, m, monkeypatch):
         assert want.sum() > 100
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TBK_FUZZ_SEEDS", "24"))))  # more seeds for a soak run
 def test_seeded_fuzz_of_layout_and_input_shapes(gpu, orc, tmp_path, seed, monkeypatch):
     """Random small configurations: any k, lists with duplicate / shared / reverse-complement /
     low-complexity lines, reads with N and lower case, ragged lengths (empty reads, reads shorter

@@ -1,5 +1,6 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-timeout 900 python tools/measure_reader.py 2>&1 | tail -1
+TBK_FUZZ_SEEDS=600 timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k fuzz --timeout 300 2>&1 | tail -4
+timeout 900 python -m pytest tests -x -q -m gpu --timeout 300 2>&1 | tail -3
 exit 0

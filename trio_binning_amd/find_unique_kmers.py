@@ -60,22 +60,23 @@ def analyze_histogram(rows: Sequence[Tuple[int, int]], histogram_path: str = "")
     rise again (the row of count 2 is only remembered), the maximum the first later row that drops
     below the count at the minimum.  Raises HistogramError when either is not found (0 counts as not
     found, as in the reference); warns on stderr when they are less than 5 apart."""
-    min_coverage, max_coverage = False, False
-    min_coverage_count = None
-    last_count = -1
-    for coverage, count in rows:
-        if coverage != 2:
-            if not min_coverage:
-                if count > last_count:
-                    min_coverage = coverage - 1
-                    min_coverage_count = last_count
-            elif not max_coverage:
-                if count < min_coverage_count:
-                    max_coverage = coverage
-                    break
-        last_count = count
-    if not min_coverage or not max_coverage:
+    low = high = 0        # 0 doubles as "not found yet", which is how the reference treats a cut-off of 0
+    floor = None          # number of k-mers in the row of the minimum
+    previous = -1         # number of k-mers in the row before this one
+    for count, n_kmers in rows:
+        if count == 2:    # the row of count 2 is only remembered
+            previous = n_kmers
+            continue
+        if not low:
+            if n_kmers > previous:       # the histogram starts rising: the row before is the minimum
+                low, floor = count - 1, previous
+        elif n_kmers < floor:            # first row after the peak that falls below the minimum's row
+            high = count
+            break
+        previous = n_kmers
+    if not low or not high:
         raise HistogramError(histogram_path)
+    min_coverage, max_coverage = low, high
     if max_coverage - min_coverage < 5:
         print(
             "WARNING: min and max coverage not very far apart. This may be a result of coverage being too low. "
