@@ -139,7 +139,7 @@ struct Slot {
     int32_t *d_counts = nullptr;
     uint8_t *h_bases = nullptr; size_t hcap_bases = 0;    // pinned staging for unpinned callers
     uint64_t *h_offsets = nullptr; int32_t *h_counts = nullptr; size_t hcap_reads = 0;
-    hipEvent_t copied = nullptr, done = nullptr;
+    hipEvent_t copied = nullptr, probed = nullptr, done = nullptr;
     bool busy = false;
     uint64_t ticket = 0, n_reads = 0;
     int32_t *user_counts = nullptr;
@@ -572,6 +572,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
     for (int i = 0; i < RING && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
     }
     if (e != hipSuccess) {
@@ -621,6 +622,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             if (s.h_offsets) (void)hipHostFree(s.h_offsets);
             if (s.h_counts) (void)hipHostFree(s.h_counts);
             if (s.copied) (void)hipEventDestroy(s.copied);
+            if (s.probed) (void)hipEventDestroy(s.probed);
             if (s.done) (void)hipEventDestroy(s.done);
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -642,6 +644,10 @@ static bool is_pinned(const void *p) {
 static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const uint64_t *d_offsets,
                               uint64_t n_reads, uint64_t total, int32_t *d_counts) {
     if (n_reads >= 0xFFFFFFF0ull) return fail(TBK_ERR_INVALID, "more than 2^32 reads in one batch");
+    if (total == 0) {  // nothing to probe (every read empty): all counts are zero
+        HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
+        return TBK_OK;
+    }
     const uint64_t passes = tbk_probe_passes(total);
     if (passes > c->cap_passes) {
         HIP_TRY(hipStreamSynchronize(c->compute));  // earlier launches may still read the old scratch
@@ -651,7 +657,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         HIP_TRY(hipMalloc((void **)&c->d_pass_read, cap * sizeof(uint32_t)));
         c->cap_passes = cap;
     }
-    HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
+    // (the per-read counters are cleared by the pass-index kernel inside tbk_launch_probe)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         if (c->ev_used + 2 > c->ev.size()) {
@@ -841,13 +847,17 @@ extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, 
     if (n_reads && total_bases) {
         rc = launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases, s.d_counts);
         if (rc) return rc;
+        // the counts travel home on the side stream, beside the next batch's kernels
+        HIP_TRY(hipEventRecord(s.probed, c->compute));
+        HIP_TRY(hipStreamWaitEvent(c->copy, s.probed, 0));
         HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, c->compute));
-    } else if (n_reads) {
-        memset(counts, 0, n_reads * 2 * sizeof(int32_t));
+                               hipMemcpyDeviceToHost, c->copy));
+        HIP_TRY(hipEventRecord(s.done, c->copy));
+    } else {
+        if (n_reads) memset(counts, 0, n_reads * 2 * sizeof(int32_t));
         s.counts_staged = false;
+        HIP_TRY(hipEventRecord(s.done, c->compute));
     }
-    HIP_TRY(hipEventRecord(s.done, c->compute));
     s.busy = true;
     c->next_ticket++;
     *ticket = tk;

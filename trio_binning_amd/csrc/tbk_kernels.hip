@@ -619,9 +619,12 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 // binary search over the offsets out of the probe kernel's waves.
 __global__ void __launch_bounds__(256)
 tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_passes,
-                      uint32_t *__restrict__ pass_read) {
+                      uint32_t *__restrict__ pass_read, int32_t *__restrict__ counts) {
     const uint64_t pass = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pass < n_passes) pass_read[pass] = (uint32_t)find_read(offsets, n_reads, pass * TBK_PASS);
+    // the same launch clears the per-read counters the probe kernel adds to
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
 }
 
 template <int W, bool M64, bool SAMP>
@@ -698,7 +701,7 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
     p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_pass_read;
     hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((p.n_passes + 255) / 256)), dim3(256), 0, stream,
-                       d_offsets, n_reads, p.n_passes, d_pass_read);
+                       d_offsets, n_reads, p.n_passes, d_pass_read, d_counts);
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
     const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
