@@ -135,9 +135,10 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 // only when the table is built), hence popcount(ballot) is the number of windows that hit.
 //
 // Per-read attribution.  A pass that lies inside one read (the usual case for long
-// reads) accumulates its two counts in scalar registers and issues one atomicAdd pair.
-// A pass that touches several reads attributes each hit to the read that contains the
-// window start (per-quad read index, broadcast alongside the key).
+// reads) accumulates its two counts in scalar registers and issues one atomicAdd pair; its odd
+// lanes walk their windows downwards (see probe_pass) so that neighbouring lanes share the
+// line at their boundary.  In a pass that touches several reads every lane counts the hits of
+// its own windows per read and hands them to per-read tallies in LDS (count_hits).
 
 #ifndef TBK_UNROLL
 #define TBK_UNROLL 2      // j-loop unroll of the probe pass
