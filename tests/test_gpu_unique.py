@@ -72,6 +72,43 @@ def test_counter_matches_oracle(gpu, tmp_path, k):
         assert st["reads_added"] == len(reads_a) and st["bases_added"] == sum(map(len, reads_a))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TBK_FUZZ_SEEDS", "8"))))
+def test_counter_seeded_fuzz(gpu, tmp_path, seed):
+    """Random small libraries: any k, read lengths from 0 to a few hundred, N and lower case, batches
+    of random size, counters starting too small or roomy; histogram, distinct count and three dumps
+    against the oracle."""
+    from oracle import unique_oracle as uo
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(5000 + seed)
+    k = int(rng.choice([1, 3, 8, 15, 16, 17, 21, 25, 31, 32]))
+    ga, gb = _two_parents(rng, glen=int(rng.choice([300, 3000, 12000])), snp=1 / 100)
+    def lib(g):
+        n, L = int(rng.integers(1, 400)), int(rng.choice([20, 75, 150, 400]))
+        L = min(L, len(g) - 1)
+        reads = _library(rng, g, n, L, err=float(rng.choice([0.0, 0.01, 0.05])), lower=0.2, n_rate=0.003)
+        return reads + ["", "N" * 30, g[:max(k - 1, 0)], g[:k], g[:k].lower()]
+    reads_a, reads_b = lib(ga), lib(gb)
+    cap_a, cap_b = int(rng.choice([16, 1000, 200_000])), int(rng.choice([16, 200_000]))
+    with kmers.Counter(k, cap_a) as ca, kmers.Counter(k, cap_b) as cb:
+        i = 0
+        while i < len(reads_a):
+            step = int(rng.integers(1, 200))
+            ca.add_reads(reads_a[i:i + step])
+            i += step
+        cb.add_reads(reads_b)
+        oa, ob = uo.count_kmers(reads_a, k), uo.count_kmers(reads_b, k)
+        dba, dbb = uo.database(oa), uo.database(ob)
+        hist = ca.histogram()
+        assert int(hist[0]) == len(oa) == ca.stats()["distinct"]
+        assert [int(hist[c]) for c in range(2, 256)] == [n for c, n in uo.histogram_rows(dba) if c >= 2]
+        for lo, hi in ((2, 255), (3, 9), (int(rng.integers(1, 6)), int(rng.integers(6, 300)))):
+            out = str(tmp_path / f"u_{lo}_{hi}.txt")
+            n = ca.unique(cb, lo, hi, out)
+            got = open(out).read().split("\n")
+            assert got[:-1] == uo.unique_kmers(dba, dbb, lo, min(hi, 255)) and n == len(got) - 1, (k, lo, hi)
+
+
 def test_counter_grows_before_a_batch_could_fill_it(gpu, tmp_path):
     """A counter created far too small is rebuilt larger (several times) as batches arrive; the
     counters it already holds move with it."""

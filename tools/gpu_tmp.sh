@@ -1,6 +1,5 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-timeout 1500 python tools/measure_unique_cli.py 2>&1 | tail -2 | cut -c1-1200
-rm -rf /tmp/tbk_unique_*
+TBK_FUZZ_SEEDS=150 timeout 1500 python -m pytest tests/test_gpu_unique.py -x -q -k fuzz --timeout 300 2>&1 | tail -12
 exit 0
