@@ -52,7 +52,7 @@ def test_counter_matches_oracle(gpu, tmp_path, k):
     ga, gb = _two_parents(rng, glen=8_000 if k > 5 else 600)
     reads_a = _library(rng, ga, 900, 150, lower=0.1) + ["", "ACGT", "N" * 40, ga[:k], ga[:k]]
     reads_b = _library(rng, gb, 700, 150)
-    with kmers.Counter(k, 400_000) as ca, kmers.Counter(k, 400_000) as cb:
+    with kmers.KmerCounter(k, 400_000) as ca, kmers.KmerCounter(k, 400_000) as cb:
         for i in range(0, len(reads_a), 250):  # several batches accumulate
             ca.add_reads(reads_a[i:i + 250])
         cb.add_reads(reads_b)
@@ -90,7 +90,7 @@ def test_counter_seeded_fuzz(gpu, tmp_path, seed):
         return reads + ["", "N" * 30, g[:max(k - 1, 0)], g[:k], g[:k].lower()]
     reads_a, reads_b = lib(ga), lib(gb)
     cap_a, cap_b = int(rng.choice([16, 1000, 200_000])), int(rng.choice([16, 200_000]))
-    with kmers.Counter(k, cap_a) as ca, kmers.Counter(k, cap_b) as cb:
+    with kmers.KmerCounter(k, cap_a) as ca, kmers.KmerCounter(k, cap_b) as cb:
         i = 0
         while i < len(reads_a):
             step = int(rng.integers(1, 200))
@@ -119,7 +119,7 @@ def test_counter_grows_before_a_batch_could_fill_it(gpu, tmp_path):
     rng = np.random.default_rng(1)
     genome = "".join("ACGT"[c] for c in rng.integers(0, 4, 20_000))
     reads = _library(rng, genome, 3000, 120, err=0.02)
-    with kmers.Counter(k, 1000) as c, kmers.Counter(k, 1000) as empty:
+    with kmers.KmerCounter(k, 1000) as c, kmers.KmerCounter(k, 1000) as empty:
         slots0 = c.stats()["n_slots"]
         for i in range(0, len(reads), 500):
             c.add_reads(reads[i:i + 500])

@@ -1,5 +1,5 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-TBK_FUZZ_SEEDS=150 timeout 1500 python -m pytest tests/test_gpu_unique.py -x -q -k fuzz --timeout 300 2>&1 | tail -12
+timeout 900 python -m pytest tests -x -q -m gpu --timeout 300 2>&1 | tail -3
 exit 0

@@ -27,7 +27,7 @@ d_bases, d_offs = dalloc(R * L + 64), dalloc((R + 1) * 8)
 err24 = int(a.error_rate * (1 << 24))
 capacity = int(a.genome * 1.05 + n_batches * R * L * a.error_rate * k * 1.1) + (1 << 20)
 t0 = time.time()
-ctr = kmers.Counter(k, capacity)
+ctr = kmers.KmerCounter(k, capacity)
 t_create = time.time() - t0
 gen_s = count_s = 0.0
 for b in range(n_batches):
@@ -47,13 +47,13 @@ n_cpu = min(R, max(1000, int(40e6 // L)))
 h_bases = np.empty(n_cpu * L, dtype=np.uint8); h_offs = np.arange(n_cpu + 1, dtype=np.uint64) * np.uint64(L)
 check(lib.tbk_memcpy_d2h(dev, h_bases.ctypes.data, C.c_void_p(d_bases), h_bases.size))
 t = time.time(); cpu_hist = orc.kmer_histogram(h_bases, h_offs, k, n_cpu * L); cpu_s = time.time() - t
-with kmers.Counter(k, n_cpu * L) as small:
+with kmers.KmerCounter(k, n_cpu * L) as small:
     small.add(h_bases, h_offs)
     same = bool(np.array_equal(small.histogram(), cpu_hist))
 st = ctr.stats()
 dump = None
 if a.dump:
-    with kmers.Counter(k, 1 << 16) as nothing:
+    with kmers.KmerCounter(k, 1 << 16) as nothing:
         t = time.time(); n_dumped = ctr.unique(nothing, 2, 255, a.dump); dump = {"kmers": n_dumped, "seconds": round(time.time() - t, 2), "file_GB": round(os.path.getsize(a.dump) / 1e9, 2)}
     os.remove(a.dump)
 peak = int(np.argmax(hist[3:]) + 3)

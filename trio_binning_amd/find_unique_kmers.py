@@ -86,9 +86,9 @@ def analyze_histogram(rows: Sequence[Tuple[int, int]], histogram_path: str = "")
     return min_coverage, max_coverage
 
 
-def count_library(paths: List[str], k: int, capacity: int) -> "kmers.Counter":
+def count_library(paths: List[str], k: int, capacity: int) -> "kmers.KmerCounter":
     """Count the canonical k-mers of all files of one library (what `kmc -k<k> @files` does)."""
-    counter = kmers.Counter(k, capacity)
+    counter = kmers.KmerCounter(k, capacity)
     batch = seq.Batch()
     try:
         for path in paths:

@@ -349,7 +349,7 @@ def device_mem_info(device: Optional[int] = None) -> Tuple[int, int]:
     return free.value, total.value
 
 
-class Counter:
+class KmerCounter:
     """Counting table of canonical k-mers in HBM: the database `kmc` builds for the reference's
     find-unique-kmers step (find_unique_kmers.py:62-103), with the histogram, subtraction and dump
     `kmc_tools` / `kmc_dump` provide (find_unique_kmers.py:123-129,186-194,218-225)."""
@@ -390,7 +390,7 @@ class Counter:
         check(lib.tbk_counter_distinct(self._h, C.byref(d)))
         return dict(zip(("n_slots", "table_bytes", "bases_added", "reads_added", "distinct"), [x.value for x in v] + [d.value]))
 
-    def unique(self, other: "Counter", min_count: int, max_count: int, out_path: str) -> int:
+    def unique(self, other: "KmerCounter", min_count: int, max_count: int, out_path: str) -> int:
         """Write the k-mers this library saw at least twice, with a counter in [min_count,
         max_count], that `other` saw at most once; one per line, sorted.  Returns how many."""
         n = C.c_uint64()
