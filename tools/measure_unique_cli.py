@@ -9,6 +9,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--genome", type=int, default=20_000_000)
 ap.add_argument("--coverage", type=float, default=30.0)
 ap.add_argument("--read-len", type=int, default=150)
+ap.add_argument("--split", type=int, default=1, help="files per parent library")
+ap.add_argument("--gzip", action="store_true", help="gzip the parents' FASTQ files")
 a = ap.parse_args()
 k = 21
 rng = np.random.default_rng(5)
@@ -20,11 +22,12 @@ def mutate():
     return h
 haps = [mutate(), mutate()]
 tmp = tempfile.mkdtemp(prefix="tbk_unique_")
+import gzip as _gzip
 def write_fastq(path, codes2d, prefix):
     n, L = codes2d.shape
     text = lut[codes2d]
     qual = b"I" * L
-    with open(path, "wb") as fh:
+    with (_gzip.open(path, "wb", compresslevel=1) if path.endswith(".gz") else open(path, "wb")) as fh:
         for i in range(n):
             fh.write(b"@%s%d\n" % (prefix, i)); fh.write(text[i].tobytes()); fh.write(b"\n+\n"); fh.write(qual); fh.write(b"\n")
 files = []
@@ -34,7 +37,11 @@ for h, name in zip(haps, ("mother", "father")):
     reads = h[starts[:, None] + np.arange(a.read_len)[None, :]]
     err = rng.random(reads.shape) < 0.003
     reads[err] = (reads[err] + rng.integers(1, 4, int(err.sum()))) % 4
-    path = os.path.join(tmp, name + ".fastq"); write_fastq(path, reads, name.encode()); files.append(path)
+    parts = []
+    for j in range(a.split):
+        path = os.path.join(tmp, "%s_%d.fastq%s" % (name, j, ".gz" if a.gzip else ""))
+        write_fastq(path, reads[j * n_reads // a.split:(j + 1) * n_reads // a.split], name.encode()); parts.append(path)
+    files.append(",".join(parts))
     del reads
 env = dict(os.environ, PYTHONPATH=ROOT)
 t = time.time()
@@ -58,7 +65,7 @@ assert p2.returncode == 0, p2.stderr.decode()[-2000:]
 bins = [l.split("\t")[1] for l in p2.stdout.decode().splitlines()]
 right = sum(1 for i, b in enumerate(bins) if b == "AB"[i % 2])
 print(json.dumps({"genome": a.genome, "parent_reads": n_reads, "parent_gbases_each": round(n_reads * a.read_len / 1e9, 3),
-                  "fastq_GB_each": round(os.path.getsize(files[0]) / 1e9, 2), "find_unique_s": round(t_unique, 2),
+                  "files_per_parent": a.split, "gzip": a.gzip, "file_GB_each_parent": round(sum(os.path.getsize(f) for f in files[0].split(",")) / 1e9, 2), "find_unique_s": round(t_unique, 2),
                   "cutoffs": [l for l in err.splitlines() if "Using counts" in l], "list_sizes": n_list,
                   "classify_s": round(t_classify, 2), "child_reads": n_long, "binned_to_the_right_parent": right}))
 for f in os.listdir(tmp): os.remove(os.path.join(tmp, f))

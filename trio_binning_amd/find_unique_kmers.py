@@ -87,19 +87,73 @@ def analyze_histogram(rows: Sequence[Tuple[int, int]], histogram_path: str = "")
 
 
 def count_library(paths: List[str], k: int, capacity: int) -> "kmers.KmerCounter":
-    """Count the canonical k-mers of all files of one library (what `kmc -k<k> @files` does)."""
+    """Count the canonical k-mers of all files of one library (what `kmc -k<k> @files` does).
+    The files are read side by side, one reader thread each (a gzip stream inflates on one core, but
+    a library usually comes as many files); this thread feeds their batches to the GPU."""
+    import queue
+    import threading
+
     counter = kmers.KmerCounter(k, capacity)
-    batch = seq.Batch()
+    n_readers = max(1, min(len(paths), kmers.host_threads()))
+    todo: "queue.Queue" = queue.Queue()
+    for p in paths:
+        todo.put(p)
+    filled: "queue.Queue" = queue.Queue(maxsize=2 * n_readers)
+    failure: List[BaseException] = []
+    batches: List[seq.Batch] = []  # every batch made; closed by this thread at the end
+
+    def read_files() -> None:
+        free: "queue.Queue" = queue.Queue()
+        for _ in range(2):
+            b = seq.Batch()
+            batches.append(b)
+            free.put(b)
+        try:
+            while not failure:
+                try:
+                    path = todo.get_nowait()
+                except queue.Empty:
+                    break
+                reader = seq.BatchReader(path)
+                try:
+                    while not failure:
+                        batch = free.get()
+                        if not reader.next_batch(batch, _BATCH_BASES, _BATCH_READS):
+                            free.put(batch)
+                            break
+                        filled.put((batch, free))
+                finally:
+                    reader.close()
+        except BaseException as exc:  # handed to the counting thread
+            failure.append(exc)
+        finally:
+            filled.put(None)
+
+    threads = [threading.Thread(target=read_files, name="tbk-reader-%d" % i, daemon=True) for i in range(n_readers)]
+    for t in threads:
+        t.start()
+    live = n_readers
     try:
-        for path in paths:
-            reader = seq.BatchReader(path)
-            try:
-                while reader.next_batch(batch, _BATCH_BASES, _BATCH_READS):
+        while live:
+            item = filled.get()
+            if item is None:
+                live -= 1
+                continue
+            batch, free = item
+            if not failure:
+                try:
                     counter.add_batch(batch)
-            finally:
-                reader.close()
+                except BaseException as exc:
+                    failure.append(exc)
+            free.put(batch)
     finally:
-        batch.close()
+        for t in threads:
+            t.join(timeout=5)
+        for b in batches:
+            b.close()
+    if failure:
+        counter.close()
+        raise failure[0]
     return counter
 
 

@@ -342,6 +342,11 @@ class _PinnedOwner:
             pass
 
 
+def host_threads() -> int:
+    """Host threads worth starting (hardware threads within the affinity mask and the cgroup quota)."""
+    return int(lib.tbk_host_threads())
+
+
 def device_mem_info(device: Optional[int] = None) -> Tuple[int, int]:
     """(free, total) bytes of HBM on the device."""
     free, total = C.c_uint64(), C.c_uint64()
