@@ -146,28 +146,32 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
                 hsel = tbk_mix32(key);
             }
             if (ok) {
-                const uint32_t b = tbk_reduce(hsel, t.n_buckets);
-                unsigned long long *line = t.keys(b);
-                if (b != held_bk) {
-                    const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(line);
-                    const ulonglong2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-                    held[0] = v0.x; held[1] = v0.y; held[2] = v1.x; held[3] = v1.y;
-                    held[4] = v2.x; held[5] = v2.y; held[6] = v3.x; held[7] = v3.y;
-                    held_bk = b;
-                }
+                // home bucket first, then along the probe sequence; every bucket visited is fetched with
+                // four 16-byte loads in flight at once and scanned in registers
+                uint32_t b = tbk_reduce(hsel, t.n_buckets);
                 bool done = false;
-#pragma unroll
-                for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
-                    if (done) continue;
-                    if (held[s] == TBK_EMPTY) {
-                        const unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
-                        held[s] = old == TBK_EMPTY ? key : old;
-                        claimed += old == TBK_EMPTY ? 1u : 0u;
+                for (uint32_t walked = 0; !done && walked < TBK_COUNT_MAX_WALK; walked++) {
+                    unsigned long long *line = t.keys(b);
+                    if (b != held_bk) {
+                        const ulonglong2 *v = reinterpret_cast<const ulonglong2 *>(line);
+                        const ulonglong2 v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+                        held[0] = v0.x; held[1] = v0.y; held[2] = v1.x; held[3] = v1.y;
+                        held[4] = v2.x; held[5] = v2.y; held[6] = v3.x; held[7] = v3.y;
+                        held_bk = b;
                     }
-                    if (held[s] == key) { atomicAdd(&t.counts(b)[s], 1u); done = true; }
+#pragma unroll
+                    for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) {
+                        if (done) continue;
+                        if (held[s] == TBK_EMPTY) {
+                            const unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
+                            held[s] = old == TBK_EMPTY ? key : old;
+                            claimed += old == TBK_EMPTY ? 1u : 0u;
+                        }
+                        if (held[s] == key) { atomicAdd(&t.counts(b)[s], 1u); done = true; }
+                    }
+                    if (!done) b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
                 }
-                // home bucket full of other keys: follow the probe sequence
-                if (!done && !count_from(t, key, tbk_next_bucket(key, t.mz, t.n_buckets, b, true), false, 1u, claimed)) full = true;
+                if (!done) full = true;
             }
             s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
             t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
