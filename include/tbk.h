@@ -294,6 +294,10 @@ int tbk_host_threads(void);
 int tbk_calib_gather(int device, uint64_t footprint_bytes, int line_bytes, int lanes_per_line,
                      int loads_in_flight, uint64_t n_lines, int reps, double *lines_per_sec,
                      double *ms_per_rep);
+/* Fire-and-forget 32-bit atomic adds over a `footprint_bytes` buffer: each lane sends `run` (1..32)
+ * consecutive adds to consecutive words of one random 128-byte line, then moves to another line.
+ * The ceiling of the k-mer counting kernel (one add per k-mer occurrence). */
+int tbk_calib_atomics(int device, uint64_t footprint_bytes, int run, int reps, double *atomics_per_sec);
 /* Streaming read of the same buffer (the 6.3 TB/s figure on this box). */
 int tbk_calib_stream(int device, uint64_t footprint_bytes, int reps, double *bytes_per_sec);
 

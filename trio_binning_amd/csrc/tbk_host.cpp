@@ -1104,6 +1104,38 @@ extern "C" int tbk_calib_gather(int device, uint64_t footprint, int line_bytes, 
     return TBK_OK;
 }
 
+extern "C" hipError_t tbk_launch_atomics(void *, uint64_t, uint32_t, uint32_t, uint64_t, unsigned, hipStream_t);
+
+extern "C" int tbk_calib_atomics(int device, uint64_t footprint, int run, int reps, double *atomics_per_sec) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (run < 1 || run > 32) return fail(TBK_ERR_INVALID, "run must be 1..32");
+    footprint &= ~(uint64_t)255;
+    if (footprint < (1u << 20)) return fail(TBK_ERR_INVALID, "footprint too small");
+    void *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, footprint));
+    const unsigned blocks = 16384;
+    const uint32_t iters = 256;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    hipError_t e = hipMemset(buf, 0, footprint);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_atomics(buf, footprint, iters, (uint32_t)run, 1, blocks, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = tbk_launch_atomics(buf, footprint, iters, (uint32_t)run, 2 + r, blocks, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "calib_atomics: %s", hipGetErrorString(e));
+    if (atomics_per_sec) *atomics_per_sec = (double)blocks * 256 * iters * reps / (ms * 1e-3);
+    return TBK_OK;
+}
+
 extern "C" int tbk_calib_stream(int device, uint64_t footprint, int reps, double *bytes_per_sec) {
     int rc = use_device(device);
     if (rc) return rc;

@@ -233,6 +233,20 @@ tbk_calib_stream_kernel(const uint4 *__restrict__ buf, uint64_t n_vec, uint32_t 
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// Fire-and-forget 32-bit atomic adds.  `run` consecutive adds of a lane go to consecutive words of
+// one random 128-byte line (run = 1: every add to its own random line), which is the counting
+// kernel's pattern: the windows of a read that share a minimizer update counters of one line.
+__global__ void __launch_bounds__(256)
+tbk_calib_atomics_kernel(uint32_t *__restrict__ buf, uint64_t n_lines, uint32_t iters, uint32_t run, uint64_t seed) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t state = seed ^ (gid * 0x9E3779B97F4A7C15ull);
+    for (uint32_t it = 0; it < iters; it += run) {
+        state = tbk_splitmix(state);
+        uint32_t *line = buf + (uint64_t)(((unsigned __int128)state * n_lines) >> 64) * 32;
+        for (uint32_t r = 0; r < run && it + r < iters; r++) atomicAdd(&line[(r + (uint32_t)(state >> 60)) & 31u], 1u);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 tbk_fill_kernel(uint4 *__restrict__ buf, uint64_t n_vec, uint64_t seed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,6 +310,12 @@ extern "C" hipError_t tbk_launch_synth_hap_reads(uint64_t seed, uint64_t genome_
                        first_read, n_reads, read_len, err24, d_bases);
     hipLaunchKernelGGL(tbk_synth_offsets_kernel, dim3((unsigned)((n_reads + 256) / 256)), dim3(256), 0, s,
                        n_reads, read_len, d_offsets);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_atomics(void *d_buf, uint64_t bytes, uint32_t iters, uint32_t run, uint64_t seed, unsigned blocks,
+                                         hipStream_t s) {
+    hipLaunchKernelGGL(tbk_calib_atomics_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t *)d_buf, bytes / 128, iters, run, seed);
     return hipGetLastError();
 }
 
