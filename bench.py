@@ -280,17 +280,19 @@ def main():
     avg_kernel_s = kernel_ms / max(1, launches) * 1e-3
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.isfile(tfile):
+    for tname in ("pmc_traffic.json", "pmc_traffic_haplotypes.json"):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if not os.path.isfile(tfile):
+            continue
         try:
             t = json.load(open(tfile))
             same = (t.get("reads_per_step") == R and t.get("read_len") == L and t.get("kmers_per_list") == n_list
-                    and t.get("k") == k and t.get("bucket_select") == bucket_select
+                    and t.get("k") == k and t.get("bucket_select") == bucket_select and t.get("lists", "uniform") == args.lists
                     and abs(t.get("table_load", 0) - n_list / (stats["n_buckets"] * 8)) < 1e-3)
             if same:  # measured in a separate rocprofv3 --pmc pass on this exact configuration
                 traffic = t.get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            pass
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -308,7 +310,11 @@ def main():
         if os.path.isfile(cfile):
             try:
                 cal = json.load(open(cfile))
-                ceiling = cal["random_lines_Glines_per_s"]["38.4GB"]["line128"]
+                # the calibration row whose footprint is closest to this table's
+                rows = cal["random_lines_Glines_per_s"]
+                key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
+                ceiling = rows[key]["line128"]
+                roofline["random_line_ceiling_footprint"] = key
                 roofline["random_lines_Gps"] = round(traffic / 128 / avg_kernel_s / 1e9, 2)
                 roofline["random_line_ceiling_Gps"] = ceiling
                 roofline["random_line_frac"] = round(traffic / 128 / avg_kernel_s / 1e9 / ceiling, 3)

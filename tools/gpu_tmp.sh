@@ -1,7 +1,6 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-timeout 300 python tools/measure_streaming.py --pinned 1 --kmers-per-list 100000000 2>&1 | tail -1
-timeout 300 python tools/measure_streaming.py --pinned 0 --kmers-per-list 100000000 2>&1 | tail -1
-timeout 600 python -m pytest tests -x -q -m gpu --timeout 300 2>&1 | tail -2
+timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1
+timeout 600 python bench.py --lists haplotypes > gpurun_out/bench_haplotypes.log 2>&1
 exit 0
