@@ -94,3 +94,55 @@ def test_read_order_permutation(big):
     perm = np.random.default_rng(1).permutation(R)
     shuffled = np.ascontiguousarray(bases.reshape(R, L)[perm]).reshape(-1)
     assert np.array_equal(cls.classify_batch(shuffled, offs), counts[perm])
+
+
+def test_counter_properties_at_scale(gpu):
+    """The k-mer counter of the find-unique-kmers step on 0.5 Gbases of synthetic short reads
+    (1e8 distinct 21-mers), checked through properties that need no oracle: the histogram adds up
+    to the distinct count; counting the same reads again doubles every counter; the reverse
+    complements of the reads count the same canonical k-mers; a library is 'unique' against an
+    empty one exactly where its own counter window says so, and never against itself."""
+    import os
+    import tempfile
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    dev, k, L = 0, 21, 150
+    Rn = 3_300_000
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    d_bases, d_offs = dalloc(Rn * L + 64), dalloc((Rn + 1) * 8)
+    check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, 50_000_000, 0, READ_SEED, 0, Rn, L, int(0.002 * (1 << 24)),
+                                         C.c_void_p(d_bases), C.c_void_p(d_offs)))
+    with kmers.KmerCounter(k, 200_000_000) as once, kmers.KmerCounter(k, 1 << 16) as twice, kmers.KmerCounter(k, 1 << 20) as rc, \
+            kmers.KmerCounter(k, 1 << 16) as empty:
+        once.add_device(d_bases, d_offs, Rn, Rn * L)
+        h1 = once.histogram().astype(np.int64)
+        assert h1[0] == h1[1:].sum() == once.stats()["distinct"] and h1[0] > 50_000_000
+        assert h1[1] > 1_000_000 and int(np.argmax(h1[3:60])) + 3 in range(7, 13)  # error k-mers; coverage peak near 10 x 130/150
+        for _ in range(2):  # a table that starts tiny and grows many times
+            twice.add_device(d_bases, d_offs, Rn, Rn * L)
+        h2 = twice.histogram().astype(np.int64)
+        assert h2[0] == h1[0] and h2[1] == 0
+        assert np.array_equal(h2[2:255:2], h1[1:128]) and h2[3:255:2].sum() == 0 and h2[255] == h1[128:].sum()
+        # reverse complements: same canonical k-mers
+        host = np.empty(Rn * L, dtype=np.uint8)
+        check(lib.tbk_memcpy_d2h(dev, host.ctypes.data, C.c_void_p(d_bases), host.size))
+        comp = np.zeros(256, dtype=np.uint8)
+        comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+        rev = np.ascontiguousarray(comp[host.reshape(Rn, L)[:, ::-1]].reshape(-1))
+        offs = np.arange(Rn + 1, dtype=np.uint64) * np.uint64(L)
+        rc.add(rev, offs)
+        assert np.array_equal(rc.histogram().astype(np.int64), h1)
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, "u.txt")
+            assert once.unique(empty, 5, 20, out) == h1[5:21].sum() and os.path.getsize(out) == h1[5:21].sum() * (k + 1)
+            assert once.unique(once, 2, 255, out) == 0 and os.path.getsize(out) == 0
+            assert once.unique(rc, 2, 255, out) == 0
+    for p in (d_bases, d_offs):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
