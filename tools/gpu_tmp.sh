@@ -1,9 +1,13 @@
 #!/bin/bash
 # scratch script for one-off gpurun experiments (edited per experiment; every step under `timeout`)
 mkdir -p gpurun_out; export TMPDIR=/tmp TBK_SKIP_BUILD=1
-timeout 600 python -m pytest tests/test_gpu_cli.py -x -q --timeout 300 2>&1 | tail -2
-timeout 900 python tools/measure_cli.py --reads 200000 2>&1 | tail -1 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print({m: (d[m]['wall_s'], d[m]['stages']['read_s'], d[m]['stages']['write_s'], d[m]['out_bytes']) for m in ('gzip','plain')})"
-rm -rf /tmp/tbk_cli_*
+R=$GRAFT_REPO_ROOT
+timeout 600 python $R/tools/measure_count.py --genome 200000000 --coverage 20 --dump /tmp/dump_kmers.txt > $R/gpurun_out/count_kmers.log 2>&1
+cd /tmp
+rm -rf $R/gpurun_out/prof_count
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_count -- python3 $R/tools/measure_count.py --genome 200000000 --coverage 20 > $R/gpurun_out/prof_count.log 2>&1
+cd $R
+cp gpurun_out/prof_count/*/*_kernel_stats.csv gpurun_out/count_kernel_stats.csv
+rm -rf gpurun_out/prof_count
+tail -1 gpurun_out/count_kmers.log | cut -c1-200
 exit 0
