@@ -133,6 +133,73 @@ def test_reader_inflates_bgzf_blocks_side_by_side(built, tmp_path):
             _native_records(str(f))
 
 
+def test_own_inflate_equals_zlib(built, tmp_path, monkeypatch):
+    """Ordinary gzip streams go through the library's own DEFLATE decoder; TBK_INFLATE=zlib keeps
+    zlib's.  Same records from both on stored / fast / default / best compression, fixed-Huffman
+    blocks, header extras (FEXTRA, FNAME, FCOMMENT), several members with zero padding between them,
+    highly repetitive and single-symbol data; damaged streams are refused, never mis-decoded."""
+    import zlib
+
+    from trio_binning_amd import _lib
+
+    rng = random.Random(3)
+
+    def fastq(n, maxlen, alphabet="ACGT", qualalpha="I"):
+        parts = []
+        for i in range(n):
+            L = rng.randint(1, maxlen)
+            parts.append("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice(alphabet) for _ in range(L)), "".join(rng.choice(qualalpha) for _ in range(L))))
+        return "".join(parts).encode()
+
+    cases = {
+        "dna_const": fastq(400, 3000),
+        "dna_qual": fastq(300, 3000, qualalpha="".join(chr(33 + i) for i in range(60))),
+        "repeat": ("@r\n" + "ACGTACGTAA" * 30000 + "\n+\n" + "I" * 300000 + "\n").encode() * 2,
+        "one_symbol": fastq(300, 2000, alphabet="A"),
+        "tiny": b"@a\nACGT\n+\nIIII\n",
+        "empty": b"",
+    }
+
+    def both(path):
+        monkeypatch.setenv("TBK_INFLATE", "zlib")
+        a = _native_records(str(path), max_bases=1 << 18)
+        monkeypatch.setenv("TBK_INFLATE", "own")
+        b = _native_records(str(path), max_bases=1 << 18)
+        assert a == b, path
+        return b
+
+    for name, data in cases.items():
+        want = None
+        for level in (0, 1, 6, 9):
+            f = tmp_path / f"{name}_{level}.fastq.gz"
+            f.write_bytes(gzip.compress(data, level))
+            got = both(f)
+            want = got if want is None else want
+            assert got == want
+        co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+        body = co.compress(data) + co.flush()
+        member = (b"\x1f\x8b\x08\x1c" + b"\0" * 6 + struct.pack("<H", 5) + b"hello" + b"name.fq\0" + b"a comment\0" + body
+                  + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF))
+        f = tmp_path / f"{name}_fixed_multi.fastq.gz"
+        f.write_bytes(member + b"\0" * 7 + gzip.compress(b"", 6))
+        assert both(f) == want, name
+    good = gzip.compress(cases["dna_qual"], 6)
+    monkeypatch.setenv("TBK_INFLATE", "own")
+    for trial in range(30):
+        blob = bytearray(good)
+        if trial % 3 == 0:
+            blob = blob[: rng.randint(20, len(blob) - 1)]
+        elif trial % 3 == 1:
+            for _ in range(3):
+                blob[rng.randint(12, len(blob) - 1)] ^= 1 << rng.randint(0, 7)
+        else:
+            blob[-5] ^= 0x40  # the stored CRC
+        f = tmp_path / "bad.fastq.gz"
+        f.write_bytes(bytes(blob))
+        with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
+            _native_records(str(f))
+
+
 def test_reader_batch_layout(built, tmp_path):
     """bases lie back to back, offsets are cumulative, limits cut after whole records."""
     from trio_binning_amd import seq
