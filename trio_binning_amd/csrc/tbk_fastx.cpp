@@ -29,6 +29,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <deque>
+#include <condition_variable>
 #include <string>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -113,7 +116,7 @@ struct LineSource {
         return true;
     }
     // CRC-32 of buf[lo..hi) folded into the running member CRC, computed by several threads
-    void fold_crc(size_t lo, size_t hi) {
+    void fold_crc(const uint8_t *base, size_t lo, size_t hi) {
         const size_t n = hi - lo;
         if (!n) return;
         const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, n >> 20));
@@ -122,7 +125,7 @@ struct LineSource {
         auto one = [&](int t) {
             const size_t a = lo + n * (size_t)t / nt, b = lo + n * (size_t)(t + 1) / nt;
             uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-            for (size_t p = a; p < b; p += (size_t)1 << 30) c = (uint32_t)crc32(c, buf.data() + p, (uInt)std::min<size_t>(b - p, (size_t)1 << 30));
+            for (size_t p = a; p < b; p += (size_t)1 << 30) c = (uint32_t)crc32(c, base + p, (uInt)std::min<size_t>(b - p, (size_t)1 << 30));
             part[(size_t)t] = c; len[(size_t)t] = b - a;
         };
         std::vector<std::thread> pool;
@@ -132,37 +135,74 @@ struct LineSource {
         for (int t = 0; t < nt; t++) member_crc = (uint32_t)crc32_combine(member_crc, part[(size_t)t], (z_off_t)len[(size_t)t]);
         member_size += n;
     }
-    // own decoder: returns like refill()
-    bool refill_fast() {
-        // the decoder needs the last 32 KiB of output in front of the write position: drop consumed
-        // text only up to there, and make room for a few megabytes of new text
-        const size_t hist = std::min<size_t>(end, 32768);
-        const size_t keep = std::min(pos, end - hist);
-        if (keep > 0 && (keep > (buf.size() >> 1) || buf.size() - end < ((size_t)4 << 20))) {
-            memmove(buf.data(), buf.data() + keep, end - keep);
-            pos -= keep; end -= keep;
-            member_start = member_start > keep ? member_start - keep : 0;
-        }
-        if (buf.size() - end < ((size_t)4 << 20)) buf.resize(end + ((size_t)8 << 20));
+    // The decoder runs on its own thread, in its own window (it needs the last 32 KiB of its
+    // output in front of the write position), and hands the text over in chunks: inflating and
+    // parsing then overlap instead of taking turns.
+    struct Chunk { std::vector<uint8_t> data; bool last = false; std::string err; };
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Chunk> ready;
+    bool stop = false, started = false;
+
+    void push(Chunk &&c) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || ready.size() < 3; });
+        if (stop) return;
+        ready.push_back(std::move(c));
+        cv.notify_all();
+    }
+    void inflate_loop() {
+        std::vector<uint8_t> win((size_t)24 << 20);
+        size_t wend = 0;
         for (;;) {
-            const size_t before = end;
-            const TbkInflate::Status st = inf.run(buf.data(), &end, buf.size(), member_start);
-            if (st == TbkInflate::ERROR) { err = std::string("inflate: ") + inf.error(); return false; }
-            fold_crc(before, end);
+            { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
+            if (win.size() - wend < ((size_t)8 << 20)) {  // keep the last 32 KiB, drop the rest
+                const size_t hist = std::min<size_t>(wend, 32768);
+                memmove(win.data(), win.data() + wend - hist, hist);
+                member_start = member_start > wend - hist ? member_start - (wend - hist) : 0;
+                wend = hist;
+            }
+            const size_t before = wend;
+            const TbkInflate::Status st = inf.run(win.data(), &wend, win.size(), member_start);
+            Chunk c;
+            if (st == TbkInflate::ERROR) { c.err = std::string("inflate: ") + inf.error(); c.last = true; push(std::move(c)); return; }
+            fold_crc(win.data(), before, wend);
             if (st == TbkInflate::MEMBER_DONE) {
-                if (member_crc != inf.trailer_crc() || (uint32_t)member_size != inf.trailer_isize()) { err = "inflate: gzip CRC or size mismatch"; return false; }
+                if (member_crc != inf.trailer_crc() || (uint32_t)member_size != inf.trailer_isize()) {
+                    c.err = "inflate: gzip CRC or size mismatch"; c.last = true; push(std::move(c)); return;
+                }
                 member_crc = (uint32_t)crc32(0L, Z_NULL, 0);
                 member_size = 0;
-                member_start = end;
-                if (end > before) return true;
-                continue;  // an empty member: go on with the next
+                member_start = wend;
             }
-            if (st == TbkInflate::INPUT_DONE) { text_eof = true; return true; }
-            if (end > before) return true;
-            // NEED_OUTPUT without progress cannot happen with megabytes of room
-            err = "inflate: no progress";
-            return false;
+            c.data.assign(win.data() + before, win.data() + wend);
+            c.last = st == TbkInflate::INPUT_DONE;
+            if (!c.data.empty() || c.last) push(std::move(c));
+            if (st == TbkInflate::INPUT_DONE) return;
         }
+    }
+    // own decoder: returns like refill()
+    bool refill_fast() {
+        if (!started) { started = true; worker = std::thread([this] { inflate_loop(); }); }
+        Chunk c;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !ready.empty(); });
+            c = std::move(ready.front());
+            ready.pop_front();
+            cv.notify_all();
+        }
+        if (!c.err.empty()) { err = c.err; return false; }
+        if (pos > 0 && pos == end) { pos = end = 0; }
+        if (buf.size() - end < c.data.size()) {
+            if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+            if (buf.size() - end < c.data.size()) buf.resize(end + c.data.size() + ((size_t)1 << 20));
+        }
+        if (!c.data.empty()) memcpy(buf.data() + end, c.data.data(), c.data.size());  // (an empty last chunk has no storage)
+        end += c.data.size();
+        if (c.last) text_eof = true;
+        return true;
     }
     // total size of the BGZF block starting at p (0 if p does not start one or n < 18)
     static size_t bgzf_block_size(const uint8_t *p, size_t n) {
@@ -240,7 +280,14 @@ struct LineSource {
             // only empty blocks (the BGZF end-of-file marker): go on
         }
     }
+    ~LineSource() { close_all(); }
     void close_all() {
+        if (started) {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            if (worker.joinable()) worker.join();
+            started = false;
+        }
         if (map) { munmap((void *)map, map_size); map = nullptr; }
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
         if (fd >= 0) { ::close(fd); fd = -1; }
