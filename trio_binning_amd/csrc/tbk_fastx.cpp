@@ -138,7 +138,8 @@ struct LineSource {
     // The decoder runs on its own thread, in its own window (it needs the last 32 KiB of its
     // output in front of the write position), and hands the text over in chunks: inflating and
     // parsing then overlap instead of taking turns.
-    struct Chunk { std::vector<uint8_t> data; bool last = false; std::string err; };
+    // A chunk owns the buffer it was inflated into: [ up to 32 KiB of the text before it | new text ].
+    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false; std::string err; };
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -153,33 +154,44 @@ struct LineSource {
         cv.notify_all();
     }
     void inflate_loop() {
-        std::vector<uint8_t> win((size_t)24 << 20);
-        size_t wend = 0;
+        constexpr size_t HIST = 32768, ROOM = (size_t)8 << 20;
+        std::vector<uint8_t> tail;  // the last 32 KiB inflated so far
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
-            if (win.size() - wend < ((size_t)8 << 20)) {  // keep the last 32 KiB, drop the rest
-                const size_t hist = std::min<size_t>(wend, 32768);
-                memmove(win.data(), win.data() + wend - hist, hist);
-                member_start = member_start > wend - hist ? member_start - (wend - hist) : 0;
-                wend = hist;
-            }
-            const size_t before = wend;
-            const TbkInflate::Status st = inf.run(win.data(), &wend, win.size(), member_start);
             Chunk c;
-            if (st == TbkInflate::ERROR) { c.err = std::string("inflate: ") + inf.error(); c.last = true; push(std::move(c)); return; }
-            fold_crc(win.data(), before, wend);
-            if (st == TbkInflate::MEMBER_DONE) {
-                if (member_crc != inf.trailer_crc() || (uint32_t)member_size != inf.trailer_isize()) {
-                    c.err = "inflate: gzip CRC or size mismatch"; c.last = true; push(std::move(c)); return;
+            c.data.resize(HIST + ROOM);
+            if (!tail.empty()) memcpy(c.data.data() + HIST - tail.size(), tail.data(), tail.size());
+            // the member may have begun before this buffer: then matches may reach back through all of `tail`
+            size_t pos = HIST, mstart = member_size >= tail.size() ? HIST - tail.size() : HIST - (size_t)member_size;
+            TbkInflate::Status st = TbkInflate::NEED_OUTPUT;
+            while (c.data.size() - pos >= 4096) {  // a buffer may hold the ends and beginnings of several members
+                const size_t before = pos;
+                st = inf.run(c.data.data(), &pos, c.data.size(), mstart);
+                if (st == TbkInflate::ERROR) break;
+                fold_crc(c.data.data(), before, pos);
+                if (st == TbkInflate::MEMBER_DONE) {
+                    if (member_crc != inf.trailer_crc() || (uint32_t)member_size != inf.trailer_isize()) { st = TbkInflate::ERROR; c.err = "inflate: gzip CRC or size mismatch"; break; }
+                    member_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+                    member_size = 0;
+                    mstart = pos;
+                    continue;
                 }
-                member_crc = (uint32_t)crc32(0L, Z_NULL, 0);
-                member_size = 0;
-                member_start = wend;
+                break;  // NEED_OUTPUT (buffer full) or INPUT_DONE
             }
-            c.data.assign(win.data() + before, win.data() + wend);
+            if (st == TbkInflate::ERROR) {
+                if (c.err.empty()) c.err = std::string("inflate: ") + inf.error();
+                c.last = true;
+                push(std::move(c));
+                return;
+            }
+            c.off = HIST; c.len = pos - HIST;
             c.last = st == TbkInflate::INPUT_DONE;
-            if (!c.data.empty() || c.last) push(std::move(c));
-            if (st == TbkInflate::INPUT_DONE) return;
+            const size_t keep = std::min(HIST, tail.size() + c.len);
+            std::vector<uint8_t> next_tail(c.data.data() + pos - keep, c.data.data() + pos);
+            tail.swap(next_tail);
+            const bool done = c.last;
+            if (c.len || c.last) push(std::move(c));
+            if (done) return;
         }
     }
     // own decoder: returns like refill()
@@ -195,12 +207,12 @@ struct LineSource {
         }
         if (!c.err.empty()) { err = c.err; return false; }
         if (pos > 0 && pos == end) { pos = end = 0; }
-        if (buf.size() - end < c.data.size()) {
+        if (buf.size() - end < c.len) {
             if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
-            if (buf.size() - end < c.data.size()) buf.resize(end + c.data.size() + ((size_t)1 << 20));
+            if (buf.size() - end < c.len) buf.resize(end + c.len + ((size_t)1 << 20));
         }
-        if (!c.data.empty()) memcpy(buf.data() + end, c.data.data(), c.data.size());  // (an empty last chunk has no storage)
-        end += c.data.size();
+        if (c.len) memcpy(buf.data() + end, c.data.data() + c.off, c.len);
+        end += c.len;
         if (c.last) text_eof = true;
         return true;
     }
