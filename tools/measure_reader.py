@@ -10,10 +10,17 @@ from trio_binning_amd._lib import lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--reads", type=int, default=60000)
 ap.add_argument("--read-len", type=int, default=10000)
+ap.add_argument("--qual", choices=["const", "hifi"], default="hifi", help="quality strings: one symbol, or HiFi-like (60 % at the cap, the rest spread)")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 lut = np.frombuffer(b"ACGT", dtype=np.uint8)
-text = b"".join(b"@r%d\n" % i + lut[rng.integers(0, 4, a.read_len)].tobytes() + b"\n+\n" + b"I" * a.read_len + b"\n" for i in range(a.reads))
+def qual():
+    if a.qual == "const":
+        return b"I" * a.read_len
+    qv = np.clip(rng.normal(60, 15, a.read_len), 2, 93).astype(np.uint8)
+    qv[rng.random(a.read_len) < 0.6] = 93
+    return (qv + 33).tobytes()
+text = b"".join(b"@r%d\n" % i + lut[rng.integers(0, 4, a.read_len)].tobytes() + b"\n+\n" + qual() + b"\n" for i in range(a.reads))
 def bgzf(data, block=60000):
     out = bytearray()
     for i in range(0, len(data), block):
@@ -22,7 +29,7 @@ def bgzf(data, block=60000):
     return bytes(out)
 tmp = tempfile.mkdtemp(prefix="tbk_reader_")
 files = {"plain": os.path.join(tmp, "t.fastq"), "gzip": os.path.join(tmp, "t_gz.fastq.gz"), "bgzf": os.path.join(tmp, "t_bgzf.fastq.gz")}
-open(files["plain"], "wb").write(text); open(files["gzip"], "wb").write(gzip.compress(text, 1)); open(files["bgzf"], "wb").write(bgzf(text))
+open(files["plain"], "wb").write(text); open(files["gzip"], "wb").write(gzip.compress(text, 6)); open(files["bgzf"], "wb").write(bgzf(text))
 def run(path):
     t = time.time(); n = 0
     with seq.BatchReader(path) as r:
@@ -34,7 +41,7 @@ def run(path):
         b.close()
     assert n == a.reads
     return time.time() - t
-res = {"text_GB": round(len(text) / 1e9, 2), "host_threads": int(lib.tbk_host_threads())}
+res = {"qualities": a.qual, "inflate": os.environ.get("TBK_INFLATE", "own"), "text_GB": round(len(text) / 1e9, 2), "gzip_GB": round(os.path.getsize(files["gzip"]) / 1e9, 2), "host_threads": int(lib.tbk_host_threads())}
 for name in ("plain", "gzip", "bgzf", "plain", "gzip", "bgzf"):
     dt = run(files[name]); res[name] = {"seconds": round(dt, 2), "text_GB_per_s": round(len(text) / dt / 1e9, 2)}
 for f in files.values(): os.remove(f)

@@ -116,6 +116,23 @@ bool TbkInflate::build(const uint8_t *lens, int n, uint32_t *table, int table_si
     return true;
 }
 
+// Where a primary-table index holds a whole literal code and, behind it, a second whole literal
+// code, let one lookup decode both: FASTQ is mostly literals with short codes (2-3 bits for bases).
+void TbkInflate::pair_literals() {
+    constexpr int N = 1 << LBITS;
+    static thread_local uint32_t single[N];
+    memcpy(single, lit_, sizeof single);
+    for (int i = 0; i < N; i++) {
+        const uint32_t e1 = single[i];
+        if (((e1 >> 12) & 15u) != LIT) continue;
+        const int l1 = (int)(e1 & 0xFF), rem = LBITS - l1;
+        if (rem < 1) continue;
+        const uint32_t e2 = single[i >> l1];  // the bits above `rem` read as zero: right whenever the code fits in `rem`
+        if (((e2 >> 12) & 15u) != LIT || (int)(e2 & 0xFF) > rem) continue;
+        lit_[i] = entry((e1 >> 16) | ((e2 >> 16) << 8), LIT2, 0, (uint32_t)(l1 + (int)(e2 & 0xFF)));
+    }
+}
+
 void TbkInflate::fixed_tables() {
     uint8_t lens[288];
     for (int i = 0; i < 144; i++) lens[i] = 8;
@@ -123,6 +140,7 @@ void TbkInflate::fixed_tables() {
     for (int i = 256; i < 280; i++) lens[i] = 7;
     for (int i = 280; i < 288; i++) lens[i] = 8;
     build(lens, 288, lit_, LSIZE, LBITS, false);
+    pair_literals();
     uint8_t dl[32];
     for (int i = 0; i < 32; i++) dl[i] = 5;
     build(dl, 32, dist_, DSIZE, DBITS, true);
@@ -162,6 +180,7 @@ bool TbkInflate::dynamic_tables() {
     }
     if (lens[256] == 0) { err_ = "no end-of-block code"; return false; }
     if (!build(lens, hlit, lit_, LSIZE, LBITS, false)) return false;
+    pair_literals();
     return build(lens + hlit, hdist, dist_, DSIZE, DBITS, true);
 }
 
@@ -243,21 +262,27 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
                 TBK_REFILL();
                 uint32_t e;
                 TBK_LOOKUP(e);
-                if (((e >> 12) & 15u) == LIT) {
-                    // up to three literals per refill (3 x 15 bits <= 56)
-                    bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                    *op++ = (uint8_t)(e >> 16);
+                if ((e & 0x7000u) == 0) {
+                    // up to three lookups per refill (3 x 15 bits <= 56), each worth one or two literals:
+                    // both bytes are stored (the second is overwritten if there is only one)
+#define TBK_EMIT()                                                                   \
+                    do {                                                              \
+                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);                     \
+                        const uint16_t v_ = (uint16_t)(e >> 16);                      \
+                        memcpy(op, &v_, 2);                                           \
+                        op += 1 + ((e >> 15) & 1u);                                   \
+                    } while (0)
+                    TBK_EMIT();
                     TBK_LOOKUP(e);
-                    if (((e >> 12) & 15u) == LIT) {
-                        bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                        *op++ = (uint8_t)(e >> 16);
+                    if ((e & 0x7000u) == 0) {
+                        TBK_EMIT();
                         TBK_LOOKUP(e);
-                        if (((e >> 12) & 15u) == LIT) {
-                            bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);
-                            *op++ = (uint8_t)(e >> 16);
+                        if ((e & 0x7000u) == 0) {
+                            TBK_EMIT();
                             continue;
                         }
                     }
+#undef TBK_EMIT
                     // a length or end-of-block code follows: top the buffer up again first (the
                     // code's low bits are in the buffer already, so the lookup stands)
                     TBK_REFILL();

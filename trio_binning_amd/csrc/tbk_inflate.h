@@ -38,7 +38,9 @@ private:
     static constexpr int LBITS = 11, DBITS = 8;
     static constexpr int LSIZE = (1 << LBITS) + 1024, DSIZE = (1 << DBITS) + 512;
     // table entry: bits 0-7 code length, 8-11 extra bits (or sub-table bits), 12-15 kind, 16-31 value
-    enum Kind { LIT = 0, LEN = 1, EOB = 2, SUB = 3, DIST = 4, BAD = 15 };
+    // LIT2: two literals decoded by one lookup (value = first | second << 8); the literal kinds are
+    // the ones with bits 12-14 clear
+    enum Kind { LIT = 0, LEN = 1, EOB = 2, SUB = 3, DIST = 4, LIT2 = 8, BAD = 15 };
 
     const uint8_t *in_ = nullptr, *ip_ = nullptr, *in_end_ = nullptr;
     uint64_t bitbuf_ = 0;
@@ -86,4 +88,5 @@ private:
     bool build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist);
     bool dynamic_tables();
     void fixed_tables();
+    void pair_literals();
 };
