@@ -238,7 +238,7 @@ struct LineSource {
                 zin_end += (size_t)(n > 0 ? n : 0);
             }
             if (zin_end == 0) { text_eof = true; return 1; }
-            struct Blk { size_t in, in_len, out, out_len; uint32_t crc; };
+            struct Blk { size_t in, in_len, out, out_len; uint32_t crc; size_t whole, whole_len; };
             std::vector<Blk> blks;
             size_t p = 0, out_total = 0;
             while (p < zin_end) {
@@ -251,7 +251,7 @@ struct LineSource {
                 const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
                 const size_t isize = (size_t)b[bs - 4] | ((size_t)b[bs - 3] << 8) | ((size_t)b[bs - 2] << 16) | ((size_t)b[bs - 1] << 24);
                 if (isize > (1u << 16)) { err = "corrupt BGZF block"; return -1; }
-                blks.push_back(Blk{p + hdr, bs - hdr - 8, out_total, isize, crc});
+                blks.push_back(Blk{p + hdr, bs - hdr - 8, out_total, isize, crc, p, bs});
                 out_total += isize;
                 p += bs;
             }
@@ -265,18 +265,32 @@ struct LineSource {
             uint8_t *out = buf.data() + end;
             std::atomic<size_t> next{0};
             std::atomic<bool> ok{true};
+            const bool own = !(getenv("TBK_INFLATE") && strcmp(getenv("TBK_INFLATE"), "zlib") == 0);
             auto work = [&]() {
                 z_stream z;
                 memset(&z, 0, sizeof z);
                 if (inflateInit2(&z, -15) != Z_OK) { ok.store(false); return; }
+                // own decoder: a block (a whole gzip member) is inflated into a private buffer with the
+                // slack the decoder's wide stores need, then copied to its place beside its neighbours
+                std::vector<uint8_t> scratch(own ? (1u << 16) + 1024 : 0);
+                TbkInflate blk_inf;
                 for (size_t i; (i = next.fetch_add(1)) < blks.size() && ok.load();) {
                     const Blk &k = blks[i];
-                    inflateReset(&z);
-                    z.next_in = zin.data() + k.in; z.avail_in = (uInt)k.in_len;
-                    z.next_out = out + k.out; z.avail_out = (uInt)k.out_len;
-                    const int rc = k.out_len ? inflate(&z, Z_FINISH) : Z_STREAM_END;  // an empty block (the end-of-file marker) has nothing to inflate
-                    if ((rc != Z_STREAM_END) || z.avail_out != 0 ||
-                        (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + k.out, (uInt)k.out_len) != k.crc) ok.store(false);
+                    bool good;
+                    if (own && k.out_len) {
+                        blk_inf.reset(zin.data() + k.whole, k.whole_len);
+                        size_t pos = 0;
+                        const TbkInflate::Status st = blk_inf.run(scratch.data(), &pos, scratch.size(), 0);
+                        good = st == TbkInflate::MEMBER_DONE && pos == k.out_len;
+                        if (good) memcpy(out + k.out, scratch.data(), k.out_len);
+                    } else {
+                        inflateReset(&z);
+                        z.next_in = zin.data() + k.in; z.avail_in = (uInt)k.in_len;
+                        z.next_out = out + k.out; z.avail_out = (uInt)k.out_len;
+                        const int rc = k.out_len ? inflate(&z, Z_FINISH) : Z_STREAM_END;  // an empty block (the end-of-file marker) has nothing to inflate
+                        good = rc == Z_STREAM_END && z.avail_out == 0;
+                    }
+                    if (!good || (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + k.out, (uInt)k.out_len) != k.crc) ok.store(false);
                 }
                 inflateEnd(&z);
             };
