@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--kmers", type=int, default=10_000_000)
 ap.add_argument("--reads", type=int, default=20_000)
 ap.add_argument("--read-len", type=int, default=15_000)
+ap.add_argument("--gz-input", action="store_true", help="gzip the reads file (one ordinary gzip stream)")
 a = ap.parse_args()
 k = 21
 rng = np.random.default_rng(1)
@@ -31,8 +32,8 @@ for r in range(a.reads):  # plant 20 list k-mers per read
     for j in range(20):
         p = j * (a.read_len // 20) + 5
         bases[r, p:p + k] = src[(r * 20 + j) % a.kmers, :k]
-fq = os.path.join(tmp, "reads.fastq")
-with open(fq, "wb") as fh:
+fq = os.path.join(tmp, "reads.fastq" + (".gz" if a.gz_input else ""))
+with (gzip.open(fq, "wb", compresslevel=1) if a.gz_input else open(fq, "wb")) as fh:
     qual = b"I" * a.read_len
     for r in range(a.reads):
         fh.write(b"@read%d some comment\n" % r); fh.write(bases[r].tobytes()); fh.write(b"\n+\n"); fh.write(qual); fh.write(b"\n")
