@@ -78,6 +78,7 @@ struct LineSource {
     // memory-mapped file: about twice zlib's speed on FASTQ, and that stream is what a run on .gz
     // input waits for.  TBK_INFLATE=zlib keeps zlib's inflate.
     bool fast = false;
+    bool threaded = false;     // a worker thread produces the text (own decoder, or BGZF windows)
     TbkInflate inf;
     const uint8_t *map = nullptr;
     size_t map_size = 0;
@@ -112,6 +113,7 @@ struct LineSource {
                     fast = true;
                 }
             }
+            threaded = fast || bgzf;
         }
         return true;
     }
@@ -139,7 +141,7 @@ struct LineSource {
     // output in front of the write position), and hands the text over in chunks: inflating and
     // parsing then overlap instead of taking turns.
     // A chunk owns the buffer it was inflated into: [ up to 32 KiB of the text before it | new text ].
-    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false; std::string err; };
+    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; };
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -152,6 +154,20 @@ struct LineSource {
         if (stop) return;
         ready.push_back(std::move(c));
         cv.notify_all();
+    }
+    // bgzip'ed input on the worker thread: windows of blocks inflated side by side, one chunk each
+    void bgzf_loop() {
+        for (;;) {
+            { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
+            Chunk c;
+            bool at_end = false;
+            const int r = bgzf_window(c.data, &at_end);
+            if (r < 0) { c.err = err; c.last = true; push(std::move(c)); return; }
+            if (r == 0) { c.fallback = true; c.data.clear(); push(std::move(c)); return; }  // an ordinary member: the parser thread takes over
+            c.off = 0; c.len = c.data.size(); c.last = at_end;
+            push(std::move(c));
+            if (at_end) return;
+        }
     }
     void inflate_loop() {
         constexpr size_t HIST = 32768, ROOM = (size_t)8 << 20;
@@ -196,7 +212,7 @@ struct LineSource {
     }
     // own decoder: returns like refill()
     bool refill_fast() {
-        if (!started) { started = true; worker = std::thread([this] { inflate_loop(); }); }
+        if (!started) { started = true; worker = std::thread([this] { if (bgzf) bgzf_loop(); else inflate_loop(); }); }
         Chunk c;
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -206,6 +222,12 @@ struct LineSource {
             cv.notify_all();
         }
         if (!c.err.empty()) { err = c.err; return false; }
+        if (c.fallback) {  // the worker met an ordinary gzip member and has left: zlib goes on from zin[zin_pos..)
+            if (worker.joinable()) worker.join();
+            started = false; bgzf = false; threaded = false;
+            inflateReset(&zs);
+            return refill();
+        }
         if (pos > 0 && pos == end) { pos = end = 0; }
         if (buf.size() - end < c.len) {
             if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
@@ -226,7 +248,9 @@ struct LineSource {
     // Inflate as many whole BGZF blocks as the compressed window holds, side by side, straight
     // into buf[end..].  Returns 1 bytes produced (or clean end), 0 fall back to the sequential path
     // (the window does not start with a BGZF block), -1 error.
-    int refill_bgzf() {
+    // `dst` receives the text of the window (its previous contents are dropped); *at_end is set when
+    // the file is exhausted.
+    int bgzf_window(std::vector<uint8_t> &dst, bool *at_end) {
         for (;;) {
             // top up the compressed window
             if (zin_pos > 0 && zin_pos < zin_end) memmove(zin.data(), zin.data() + zin_pos, zin_end - zin_pos);
@@ -237,7 +261,7 @@ struct LineSource {
                 if (n == 0) raw_eof = true;
                 zin_end += (size_t)(n > 0 ? n : 0);
             }
-            if (zin_end == 0) { text_eof = true; return 1; }
+            if (zin_end == 0) { *at_end = true; dst.clear(); return 1; }
             struct Blk { size_t in, in_len, out, out_len; uint32_t crc; size_t whole, whole_len; };
             std::vector<Blk> blks;
             size_t p = 0, out_total = 0;
@@ -261,8 +285,8 @@ struct LineSource {
                 if (zin_end == zin.size()) { err = "corrupt BGZF block"; return -1; }
                 continue;  // header or block cut off by the window: read more
             }
-            if (buf.size() - end < out_total) buf.resize(end + out_total + (1u << 16));
-            uint8_t *out = buf.data() + end;
+            dst.resize(out_total);
+            uint8_t *out = dst.data();
             std::atomic<size_t> next{0};
             std::atomic<bool> ok{true};
             const bool own = !(getenv("TBK_INFLATE") && strcmp(getenv("TBK_INFLATE"), "zlib") == 0);
@@ -301,7 +325,6 @@ struct LineSource {
             for (std::thread &t : pool) t.join();
             if (!ok.load()) { err = "inflate: corrupt BGZF block"; return -1; }
             zin_pos = p;
-            end += out_total;
             if (out_total) return 1;
             // only empty blocks (the BGZF end-of-file marker): go on
         }
@@ -321,7 +344,7 @@ struct LineSource {
     // append decoded bytes at buf[end..]; returns false on error; sets text_eof at the end
     bool refill() {
         if (text_eof) return true;
-        if (fast) return refill_fast();  // keeps its own 32 KiB of history in the window
+        if (threaded) return refill_fast();  // a worker thread inflates, this one parses
         if (pos > 0 && pos == end) { pos = end = 0; }
         if (buf.size() - end < (1u << 16)) {
             if (pos > (buf.size() >> 1)) {  // compact
@@ -337,15 +360,6 @@ struct LineSource {
             if (n == 0) { text_eof = true; return true; }
             end += (size_t)n;
             return true;
-        }
-        if (bgzf) {
-            // a window of blocks inflates to tens of megabytes: keep only the unconsumed tail in front of it
-            if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
-            const int r = refill_bgzf();
-            if (r < 0) return false;
-            if (r > 0) return true;
-            bgzf = false;  // an ordinary member: the sequential path takes over from zin[zin_pos..zin_end)
-            inflateReset(&zs);
         }
         for (;;) {
             if (zin_pos == zin_end && !raw_eof) {
