@@ -198,6 +198,29 @@ def test_own_inflate_equals_zlib(built, tmp_path, monkeypatch):
         f.write_bytes(bytes(blob))
         with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
             _native_records(str(f))
+    # arbitrary bytes behind a gzip header, spliced streams, trailing garbage: refused, and (this test
+    # also runs under ASan + UBSan) without reading or writing out of bounds
+    for trial in range(120):
+        kind = trial % 4
+        if kind == 0:
+            blob = b"\x1f\x8b\x08\x00" + b"\0" * 6 + bytes(rng.getrandbits(8) for _ in range(rng.randint(0, 3000)))
+        elif kind == 1:
+            blob = good[:10] + bytes(rng.getrandbits(8) for _ in range(rng.randint(1, 2000))) + good[rng.randint(10, len(good) - 1):]
+        elif kind == 2:
+            b = bytearray(good)
+            for _ in range(rng.randint(2, 20)):
+                b[rng.randint(10, len(b) - 9)] = rng.getrandbits(8)
+            blob = bytes(b)
+        else:
+            blob = good + bytes(rng.getrandbits(8) | 1 for _ in range(rng.randint(1, 50)))
+        f = tmp_path / "garbage.fastq.gz"
+        f.write_bytes(blob)
+        try:
+            _native_records(str(f))
+            decoded = True
+        except (_lib.TbkError, ValueError, IOError, OSError):
+            decoded = False
+        assert not decoded or kind == 2  # a few random byte changes can leave a valid stream (CRC collisions aside: text identical)
 
 
 def test_reader_batch_layout(built, tmp_path):
