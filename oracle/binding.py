@@ -47,6 +47,14 @@ class _Table:
     def k(self) -> int:
         return self._lib.orc_table_k(self.ptr)
 
+    def keys(self) -> np.ndarray:
+        """The stored keys (one per list line, duplicates included), sorted."""
+        out = np.empty(max(1, self.hash_size), dtype=np.uint64)
+        self._lib.orc_table_keys.restype = C.c_uint64
+        self._lib.orc_table_keys.argtypes = [C.c_void_p, C.c_void_p]
+        n = self._lib.orc_table_keys(self.ptr, out.ctypes.data)
+        return np.sort(out[:n])
+
     def __del__(self):
         try:
             self._lib.orc_table_free(self.ptr)
@@ -185,6 +193,13 @@ class RefLib:
 
     def create_kmer_hash_set(self, path: str):
         return self.lib.create_kmer_hash_set(path.encode())
+
+    @staticmethod
+    def keys(hs) -> np.ndarray:
+        """The keys a reference hash_set stores (its kmers[] where full[] is set), sorted."""
+        c = hs.contents
+        full = np.ctypeslib.as_array(c.full, shape=(c.hash_size,)).astype(bool)
+        return np.sort(np.ctypeslib.as_array(c.kmers, shape=(c.hash_size,))[full].copy())
 
     def count_kmers_in_read(self, read: str, a, b) -> Tuple[int, int]:
         ca, cb = C.c_int(), C.c_int()

@@ -127,9 +127,8 @@ orc_table *orc_table_from_file(const char *path) {
     rewind(fp);
     if (t) {
         while ((got = getline(&line, &cap, fp)) != -1) {
-            if (got < k) { /* short line: the reference would read stale bytes; refuse */
-                free(t->slot); free(t->used); free(t); t = NULL; break;
-            }
+            /* a line shorter than k packs getline's buffer as the reference does: the line, the NUL,
+             * then the bytes earlier lines of this pass left behind (same buffer, only ever grown) */
             orc_insert_key(t, orc_kmer_to_int(line, k));
         }
     }
@@ -198,6 +197,12 @@ void orc_table_free(orc_table *t) {
 }
 
 uint64_t orc_table_num_kmers(const orc_table *t) { return t->n_lines; }
+/* the stored keys in slot order (tests compare them, sorted, with the real reference's arrays) */
+uint64_t orc_table_keys(const orc_table *t, uint64_t *out) {
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < t->n_slots; i++) if (t->used[i]) out[n++] = t->slot[i];
+    return n;
+}
 uint64_t orc_table_hash_size(const orc_table *t) { return t->n_slots; }
 int orc_table_k(const orc_table *t) { return t->k; }
 

@@ -325,6 +325,9 @@ def test_list_parser_rules(gpu, orc, tmp_path):
         "non_acgt_in_list": "ACGTACGTAC\nACGNACGTAC\nacgtacgtac\nCCCCCCCCCC\n",
         "crlf": "ACGTACGTAC\r\nCCCCCCCCCC\r\nGGGGGGGGGG\r\nTTTTTTTTTA\r\n",
         "k_equals_line_with_newline": "ACGT\nACG\nCCCC\nGGGG\n",
+        # lines shorter than k pack the reference's getline buffer (the line, a NUL, earlier lines' tail)
+        "blank_last_line": "ACGTACGTAC\nCCCCCCCCCC\n\n",
+        "short_lines": "ACGTACGTAC\nACG\nAAAAAAAAAA\nGG\n\nTTTTTTTTTA\nC",
     }
     rng = np.random.default_rng(3)
     reads = ["".join("ACGT"[c] for c in rng.integers(0, 4, 200)) for _ in range(50)]
@@ -341,7 +344,7 @@ def test_list_parser_rules(gpu, orc, tmp_path):
         with kmers.Classifier(a, b) as cls:
             got = cls.classify_batch(bases, offs)
         assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob)), name
-    for bad in ("", "ACGTACGT\nACG\nACGTACGT\n", "A" * 33 + "\n"):
+    for bad in ("", "A" * 33 + "\n"):
         with pytest.raises(ValueError):
             kmers.HashSet.from_file(_write(tmp_path, "bad.txt", bad))
     with pytest.raises(IOError):
@@ -784,6 +787,11 @@ def test_abi_misuse_is_reported_not_crashed(gpu, tmp_path):
         assert lib.tbk_classify_device(cls._h, C.c_void_p(8), C.c_void_p(16), 1, 10, C.c_void_p(16)) == _lib.TBK_ERR_INVALID  # misaligned
         # a good call still works afterwards
         assert cls.classify_reads(["ACCTCTAAGAAGCTTTGAAAA"]).tolist() == [[1, 0]]
+        # the counter takes the same batches and applies the same rule to their offsets
+        with kmers.KmerCounter(5, 1 << 10) as ctr:
+            for bad in (bad_first, decreasing):
+                assert lib.tbk_counter_add_batch(ctr._h, bases.ctypes.data, bad.ctypes.data, bad.size - 1) == _lib.TBK_ERR_INVALID
+            assert ctr.stats()["bases_added"] == 0
     h = C.c_void_p()
     assert lib.tbk_table_create_from_keys(None, 5, 21, 0, C.byref(h)) == _lib.TBK_ERR_INVALID
     keys = np.arange(4, dtype=np.uint64)

@@ -118,6 +118,10 @@ def test_reader_inflates_bgzf_blocks_side_by_side(built, tmp_path):
         "bgzf_no_eof.fastq.gz": _bgzf(text, eof_marker=False),
         "bgzf_then_gzip.fastq.gz": _bgzf(text[:100_000], eof_marker=False) + gzip.compress(text[100_000:]),
         "gzip_then_bgzf.fastq.gz": gzip.compress(text[:100_000]) + _bgzf(text[100_000:]),
+        # zero padding between members, which Python's GzipFile skips: between BGZF blocks, before an
+        # ordinary member that follows them, and at the end of the file
+        "bgzf_padded.fastq.gz": _bgzf(text[:200_000], eof_marker=False) + b"\0" * 11 + _bgzf(text[200_000:]) + b"\0" * 5,
+        "bgzf_pad_gzip.fastq.gz": _bgzf(text[:100_000], eof_marker=False) + b"\0" * 3 + gzip.compress(text[100_000:]),
     }
     for name, blob in cases.items():
         f = tmp_path / name
@@ -198,6 +202,38 @@ def test_own_inflate_equals_zlib(built, tmp_path, monkeypatch):
         f.write_bytes(bytes(blob))
         with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
             _native_records(str(f))
+    # a dynamic block whose literal/length code leaves code space unused (two 2-bit codes: 'A' and
+    # end-of-block) is refused by zlib ("invalid literal/lengths set") and by the library's decoder
+    bits = []
+
+    def put(v, n):
+        bits.extend((v >> i) & 1 for i in range(n))
+
+    put(1, 1); put(2, 2)                    # BFINAL, dynamic Huffman
+    put(0, 5); put(0, 5); put(14, 4)        # HLIT = 257, HDIST = 1, HCLEN = 18
+    cl_order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1]
+    cl_len = {0: 1, 2: 2, 18: 2}            # a complete code-length code: 0 -> '0', 2 -> '10', 18 -> '11'
+    for sym in cl_order:
+        put(cl_len.get(sym, 0), 3)
+
+    def cl(sym):                            # Huffman codes go out most significant bit first
+        code, n = {0: (0, 1), 2: (2, 2), 18: (3, 2)}[sym]
+        bits.extend((code >> (n - 1 - i)) & 1 for i in range(n))
+
+    cl(18); put(65 - 11, 7)                 # 65 zeros
+    cl(2)                                   # 'A': 2 bits
+    cl(18); put(138 - 11, 7); cl(18); put(52 - 11, 7)   # 190 zeros
+    cl(2)                                   # end-of-block: 2 bits
+    cl(0)                                   # no distance code
+    put(0, 2); put(1, 2)                    # 'A', end-of-block
+    raw = bytes(sum(b << i for i, b in enumerate(bits[j:j + 8])) for j in range(0, len(bits), 8))
+    with pytest.raises(zlib.error):
+        zlib.decompress(raw, -15)
+    f = tmp_path / "incomplete.fastq.gz"
+    f.write_bytes(b"\x1f\x8b\x08\x00" + b"\0" * 6 + raw + struct.pack("<II", zlib.crc32(b"A"), 1))
+    with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
+        _native_records(str(f))
+    assert "incomplete" in _lib.last_error() or "inflate" in _lib.last_error()
     # arbitrary bytes behind a gzip header, spliced streams, trailing garbage: refused, and (this test
     # also runs under ASan + UBSan) without reading or writing out of bounds
     for trial in range(120):
@@ -329,14 +365,11 @@ def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
 
     rng = random.Random(12)
 
+    from test_oracle_golden import SHORT_LINE_LISTS, getline_keys
+
     def want(text, k):
-        keys, pos = [], 0
-        data = text.encode()
-        while pos < len(data):
-            nl = data.find(b"\n", pos)
-            end = len(data) if nl < 0 else nl + 1
-            keys.append(orc.kmer_to_int(data[pos:pos + k].decode("latin1")))
-            pos = end
+        kk, keys = getline_keys(text.encode())
+        assert kk == k
         return keys
 
     k = 21
@@ -349,7 +382,9 @@ def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
         "crlf": "".join(x + "\r\n" for x in lines[:70000]),
         "single_line": lines[0] + "\n",
         "tiny_k": "ACG\nTTT\nGGA\nCCC\n",
+        "blank_last_line_after_regular": "".join(x + "\n" for x in lines[:70000]) + "\n",
     }
+    cases.update({name: data.decode() for name, data in SHORT_LINE_LISTS.items()})
     for name, text in cases.items():
         p = tmp_path / (name + ".txt")
         p.write_bytes(text.encode())
@@ -359,7 +394,9 @@ def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
         assert keys.tolist() == want(text, kk), name
         t = orc.table_from_file(str(p))
         assert (t.k, t.num_kmers) == (kk, keys.size), name
-    for bad in ("", "ACGTACGT\nACG\nACGTACGT\n", "A" * 33 + "\n", "\n"):
+        if keys.size < 1000:
+            assert t.keys().tolist() == sorted(keys.tolist()), name
+    for bad in ("", "A" * 33 + "\n", "\n"):
         p = tmp_path / "bad.txt"
         p.write_text(bad)
         with pytest.raises(ValueError):

@@ -198,12 +198,15 @@ static int counter_run(tbk_counter *c, const uint8_t *d_bases, const uint64_t *d
     return TBK_OK;
 }
 
+extern "C" int tbk_check_offsets_(const uint64_t *offsets, uint64_t n_reads);
+
 extern "C" int tbk_counter_add_batch(tbk_counter *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads) {
     if (!c || (n_reads && (!bases || !offsets))) return cfail(TBK_ERR_INVALID, "NULL argument");
     if (!n_reads) return TBK_OK;
-    int rc = counter_device(c);
+    int rc = tbk_check_offsets_(offsets, n_reads);  // same rule as tbk_stream_submit
     if (rc) return rc;
-    if (offsets[0] != 0) return cfail(TBK_ERR_INVALID, "offsets[0] must be 0");
+    rc = counter_device(c);
+    if (rc) return rc;
     const uint64_t total = offsets[n_reads];
     if (total + 16 > c->cap_raw) {
         if (c->d_raw) CHIP(hipFree(c->d_raw));

@@ -73,6 +73,7 @@ struct LineSource {
     // carry their own compressed size in a "BC" extra subfield: such members can be inflated side
     // by side.  Same bytes as the sequential path; taken while every member at hand is such a block.
     bool bgzf = false;
+    bool bgzf_seen = false;  // a BGZF member has been read: zero padding may follow it (Python's GzipFile skips it)
     int threads = 1;
     // Ordinary gzip streams go through the library's own DEFLATE decoder (tbk_inflate.h) on the
     // memory-mapped file: about twice zlib's speed on FASTQ, and that stream is what a run on .gz
@@ -266,6 +267,7 @@ struct LineSource {
             std::vector<Blk> blks;
             size_t p = 0, out_total = 0;
             while (p < zin_end) {
+                if (bgzf_seen && zin[p] == 0) { p++; continue; }  // zero padding between members
                 const size_t bs = bgzf_block_size(zin.data() + p, zin_end - p);
                 if (bs == 0) break;            // not a BGZF block (or its header is cut off)
                 if (bs < 26 || p + bs > zin_end) { if (bs < 26) { err = "corrupt BGZF block"; return -1; } break; }
@@ -278,9 +280,11 @@ struct LineSource {
                 blks.push_back(Blk{p + hdr, bs - hdr - 8, out_total, isize, crc, p, bs});
                 out_total += isize;
                 p += bs;
+                bgzf_seen = true;
             }
             if (blks.empty()) {
-                if (p == 0 && zin_end >= 18 && bgzf_block_size(zin.data(), zin_end) == 0) return 0;  // an ordinary gzip member follows
+                if (p > 0) { zin_pos = p; continue; }  // only padding so far: drop it and look again
+                if (zin_end >= 18 && bgzf_block_size(zin.data(), zin_end) == 0) return 0;  // an ordinary gzip member follows
                 if (raw_eof) { err = "truncated gzip file"; return -1; }
                 if (zin_end == zin.size()) { err = "corrupt BGZF block"; return -1; }
                 continue;  // header or block cut off by the window: read more

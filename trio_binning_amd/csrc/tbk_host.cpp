@@ -353,8 +353,8 @@ extern "C" int tbk_table_create_from_keys(const uint64_t *keys, uint64_t n, int 
 // Text list -> packed keys with the reference's getline() rules (c/kmers.c:124-146,204-221):
 // k = bytes of the first line as getline returns them (newline included) minus one; each
 // getline success is one k-mer; a line contributes its first k bytes (a byte outside ACGT,
-// the newline included, packs as 0).  A line with fewer than k bytes would make the
-// reference pack stale buffer contents: refused as TBK_ERR_FORMAT.
+// the newline included, packs as 0).  A line with fewer than k bytes packs what the reference's
+// getline buffer holds there: the line, a NUL, then the tail earlier lines left (parse_list).
 //
 // Lists are gigabytes (22 B per 21-mer line, 6.6 GB per 300 M-line list; the reference parses
 // them at 2.3-2.5 M lines/s).  The common case — every line exactly k bytes + '\n' — is
@@ -428,19 +428,23 @@ static int parse_list(const char *path, std::vector<uint64_t> &keys, int &k_out)
     (void)madvise((void *)data, size, MADV_SEQUENTIAL);
     keys.clear();
     keys.reserve(size / (size_t)(k + 1) + 1);
+    // The reference packs the first k bytes of getline()'s buffer whatever the line's length
+    // (c/kmers.c:113,204-206).  A line with fewer than k bytes therefore packs its own bytes, the
+    // terminating NUL getline wrote, and behind it whatever EARLIER lines left in the buffer:
+    // getline reuses (and only ever grows, by realloc) one buffer, and the first line has k + 1
+    // bytes, so those bytes are defined.  `sim` is that buffer's first k bytes.  (A blank last line,
+    // which many tools leave, is such a line: it counts in num_kmers and stores a key made of the
+    // previous line's tail - almost never canonical, hence dead, exactly as in the reference.)
+    std::vector<uint8_t> sim((size_t)k, 0);
     const char *p = data;
-    uint64_t line_no = 0;
     while (p < end) {
         const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
         const size_t got = e ? (size_t)(e - p) + 1 : (size_t)(end - p);
-        line_no++;
-        if (got < (size_t)k) {
-            munmap((void *)data, size);
-            return fail(TBK_ERR_FORMAT, "%s: line %llu has %zu bytes, fewer than k = %ld", path,
-                        (unsigned long long)line_no, got, k);
-        }
+        const size_t take = std::min(got, (size_t)k);
+        memcpy(sim.data(), p, take);
+        if (got < (size_t)k) sim[got] = 0;  // getline's terminator
         uint64_t v = 0;
-        for (long i = 0; i < k; i++) v |= (uint64_t)code_of((unsigned char)p[i]) << (2 * i);
+        for (long i = 0; i < k; i++) v |= (uint64_t)code_of(sim[(size_t)i]) << (2 * i);
         keys.push_back(v);
         p += got;
     }
@@ -704,6 +708,16 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
 
 extern "C" int tbk_stream_depth(const tbk_classifier *) { return RING; }
 
+// A host batch's offsets (every entry point that takes one): offsets[0] = 0, non-decreasing.
+// offsets[n_reads] sizes the copies and bounds the kernels, so a malformed array must not get past here.
+extern "C" int tbk_check_offsets_(const uint64_t *offsets, uint64_t n_reads) {
+    if (!offsets) return fail(TBK_ERR_INVALID, "offsets is NULL");
+    if (offsets[0] != 0) return fail(TBK_ERR_INVALID, "offsets[0] must be 0");
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (offsets[i + 1] < offsets[i]) return fail(TBK_ERR_INVALID, "offsets not non-decreasing at read %llu", (unsigned long long)i);
+    return TBK_OK;
+}
+
 // device buffers of a slot
 static int slot_reserve_device(Slot &s, uint64_t total, uint64_t n_reads) {
     const size_t need_b = ((size_t)total + 15) & ~(size_t)15;
@@ -752,12 +766,11 @@ static int slot_reserve(Slot &s, uint64_t stage_bases, uint64_t n_reads, bool st
 extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                                  int32_t *counts, uint64_t *ticket) {
     if (!c || !offsets || !ticket || (n_reads && !counts)) return fail(TBK_ERR_INVALID, "NULL argument");
-    if (offsets[0] != 0) return fail(TBK_ERR_INVALID, "offsets[0] must be 0");
+    int rc = tbk_check_offsets_(offsets, n_reads);
+    if (rc) return rc;
     const uint64_t total = offsets[n_reads];
     if (total && !bases) return fail(TBK_ERR_INVALID, "bases is NULL");
-    for (uint64_t i = 0; i < n_reads; i++)
-        if (offsets[i + 1] < offsets[i]) return fail(TBK_ERR_INVALID, "offsets not non-decreasing at read %llu", (unsigned long long)i);
-    int rc = use_device(c->device);
+    rc = use_device(c->device);
     if (rc) return rc;
     const uint64_t tk = c->next_ticket;
     Slot &s = c->ring[tk % RING];

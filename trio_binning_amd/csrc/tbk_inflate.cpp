@@ -51,7 +51,7 @@ bool TbkInflate::parse_header() {
 
 // Canonical Huffman code -> lookup table.  Codes no longer than `primary_bits` fill the primary
 // table directly (bit-reversed, replicated); longer ones go through a sub-table per primary prefix.
-bool TbkInflate::build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist) {
+bool TbkInflate::build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist, bool is_codes) {
     int count[16] = {0};
     for (int i = 0; i < n; i++) count[lens[i]]++;
     count[0] = 0;
@@ -64,6 +64,14 @@ bool TbkInflate::build(const uint8_t *lens, int n, uint32_t *table, int table_si
         kraft += (long)count[len] << (15 - len);
     }
     if (kraft > (1L << 15)) { err_ = "over-subscribed Huffman code"; return false; }
+    // An incomplete code is refused as zlib refuses it (inftrees.c): only a literal/length or
+    // distance code made of a single 1-bit code may leave part of the code space unused (and a
+    // code with no symbols at all is a table of invalid entries).
+    {
+        int used = 0, longest_len = 0;
+        for (int len = 1; len <= 15; len++) if (count[len]) { used += count[len]; longest_len = len; }
+        if (used > 0 && kraft < (1L << 15) && (is_codes || !(used == 1 && longest_len == 1))) { err_ = "incomplete Huffman code"; return false; }
+    }
     const int primary_size = 1 << primary_bits;
     const uint32_t bad = entry(0, BAD, 0, 1);
     for (int i = 0; i < table_size; i++) table[i] = bad;
@@ -156,7 +164,7 @@ bool TbkInflate::dynamic_tables() {
         cl[kClOrder[i]] = (uint8_t)take(3);
     }
     uint32_t cltab[1 << 7];
-    if (!build(cl, 19, cltab, 1 << 7, 7, false)) return false;  // symbols 0..18 decode as "literals"
+    if (!build(cl, 19, cltab, 1 << 7, 7, false, true)) return false;  // symbols 0..18 decode as "literals"
     uint8_t lens[320];
     int i = 0;
     while (i < hlit + hdist) {

@@ -85,7 +85,7 @@ private:
     Status fail(const char *msg) { err_ = msg; return ERROR; }
     bool parse_header();
     bool read_block_head();
-    bool build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist);
+    bool build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist, bool is_codes = false);
     bool dynamic_tables();
     void fixed_tables();
     void pair_literals();
