@@ -45,7 +45,7 @@ typedef enum tbk_status {
     TBK_ERR_INVALID = -1,   /* bad argument (k out of 1..32, NULL, mismatched k, ...)       */
     TBK_ERR_IO = -2,        /* file missing / unreadable (Python side raises IOError,       */
                             /*   as kmers.py:117-118 does)                                  */
-    TBK_ERR_FORMAT = -3,    /* malformed k-mer list (empty file, line shorter than k)       */
+    TBK_ERR_FORMAT = -3,    /* malformed k-mer list (empty file, first line gives k > 32)    */
     TBK_ERR_NO_DEVICE = -4, /* no usable HIP device                                         */
     TBK_ERR_HIP = -5,       /* a HIP runtime call failed                                    */
     TBK_ERR_NOMEM = -6,
@@ -115,6 +115,19 @@ int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *hap_
  * destroyed afterwards. */
 int tbk_classifier_create(const tbk_table *hap_a, const tbk_table *hap_b, tbk_classifier **out);
 void tbk_classifier_destroy(tbk_classifier *c);
+/* Several devices (the reference's per-read loop, classify_by_kmers.py:99-102, has no
+ * cross-read state, so reads shard over devices and the tables are replicated).  The two lists are
+ * hashed once, on their own device; out[i] is a classifier on devices[i] holding a copy of the
+ * finished paired table (device-to-device copy, xGMI between peers) with its own streams and
+ * ticket ring.  A device may appear more than once (two rings on one GPU).  There is no
+ * collective and no cross-device traffic after this call: the caller deals batches to the
+ * classifiers and writes results in input order (trio_binning_amd.kmers.MultiClassifier does;
+ * tickets of one classifier complete in submission order).  On failure nothing is left behind. */
+int tbk_classifier_create_multi(const tbk_table *hap_a, const tbk_table *hap_b, const int *devices, int n_devices,
+                                tbk_classifier **out /* [n_devices] */);
+/* One more copy of a finished classifier's table, on `device` (which may be src's own). */
+int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out);
+int tbk_classifier_device(const tbk_classifier *c);
 /* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
 int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
                          uint64_t *n_buckets, uint64_t *table_bytes);

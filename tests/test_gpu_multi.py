@@ -1,0 +1,87 @@
+"""The multi-device product path on what a one-GPU lease offers: two classifiers on device 0
+(`TBK_DEVICES=0,0`: the table replicated device-to-device, two stream rings), batches dealt between
+them, results in input order.  Counts, TSV and bins must equal the single-classifier run's and the
+reference's recorded output."""
+import ctypes as C
+import gzip
+import hashlib
+import os
+from unittest.mock import patch
+
+import numpy as np
+import pytest
+
+from conftest import DATA, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(tmp_path, k=21):
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == k)
+    fa, fb = tmp_path / "la.txt", tmp_path / "lb.txt"
+    fa.write_text("".join(x + "\n" for x in v["list_a"]))
+    fb.write_text("".join(x + "\n" for x in v["list_b"]))
+    return v, str(fa), str(fb)
+
+
+def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
+    from trio_binning_amd import _lib, kmers
+    from trio_binning_amd._lib import check, lib
+
+    v, fa, fb = _lists(tmp_path)
+    a, b = kmers.HashSet.from_file(fa, 0), kmers.HashSet.from_file(fb, 0)
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    bases, offs = kmers.pack_reads(v["reads"])
+    want = orc.count_batch(bases, offs, oa, ob)
+    with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
+        assert multi.devices == [0, 0, 0] and multi.depth == 9
+        st = multi.stats()
+        assert st["devices"] == [0, 0, 0] and st["table_bytes_total"] == 3 * st["table_bytes"]
+        for part in multi._parts:       # every replica on its own
+            assert part.stats() == multi._parts[0].stats()
+            assert np.array_equal(part.classify_batch(bases, offs), want)
+        # dealt: nine batches in flight at once, waited for out of order
+        cuts = [0, 10, 11, 40, 41, 41, 90, 120, 149, len(v["reads"])]
+        tickets = []
+        for lo, hi in zip(cuts, cuts[1:]):
+            tickets.append((lo, hi, multi.submit(*kmers.pack_reads(v["reads"][lo:hi]))))
+        assert multi.dealt == [3, 3, 3]
+        for lo, hi, t in reversed(tickets):
+            assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
+    # a replica of a replica, and the error paths of the C entry points
+    with kmers.Classifier(a, b) as one:
+        h = C.c_void_p()
+        check(lib.tbk_classifier_replicate(one._h, 0, C.byref(h)))
+        with kmers.Classifier(a, b, _handle=h.value) as two:
+            assert two.stats() == one.stats() and np.array_equal(two.classify_batch(bases, offs), want)
+        assert lib.tbk_classifier_replicate(one._h, 99, C.byref(h)) == _lib.TBK_ERR_INVALID
+        out = (C.c_void_p * 2)()
+        bad = (C.c_int * 2)(0, 99)
+        assert lib.tbk_classifier_create_multi(a._h, b._h, bad, 2, out) == _lib.TBK_ERR_INVALID
+        assert not out[0] and not out[1]
+        assert lib.tbk_classifier_create_multi(a._h, b._h, bad, 0, out) == _lib.TBK_ERR_INVALID
+
+
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
+def test_cli_on_device_list_writes_the_same_bytes(gpu, capsys, tmp_path, monkeypatch, devices):
+    import trio_binning_amd.classify_by_kmers as cbk
+
+    v, fa, fb = _lists(tmp_path)
+    fq = tmp_path / "reads21.fa"
+    with open(fq, "w") as fh:
+        for i, s in enumerate(v["reads"]):
+            fh.write(f">r{i} some comment\n{s}\n")
+    monkeypatch.setenv("TBK_DEVICES", devices)
+    monkeypatch.setenv("TBK_STATS", "1")
+    monkeypatch.setattr(cbk, "_BATCH_BASES", 300)
+    monkeypatch.setattr(cbk, "_BATCH_READS", 5)
+    od = tmp_path / "out"
+    od.mkdir()
+    with patch("sys.argv", ["classify-by-kmers", str(fq), fa, fb, "--haplotype-a-out-prefix", str(od / "hapA"),
+                            "--haplotype-b-out-prefix", str(od / "hapB"), "--unclassified-out-prefix", str(od / "unclassified")]):
+        cbk.main()
+    out, err = capsys.readouterr()
+    assert out == v["cli_stdout"]
+    for fn, digest in v["cli_bins"].items():
+        assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
+    assert '"devices": [%s]' % devices.replace(",", ", ") in err

@@ -82,6 +82,9 @@ _sig("tbk_table_contains", C.c_int, _vp, _vp, _u64, _vp)
 _sig("tbk_count_kmers_in_read", C.c_int, C.c_char_p, C.c_int64, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_create", C.c_int, _vp, _vp, C.POINTER(_vp))
 _sig("tbk_classifier_destroy", None, _vp)
+_sig("tbk_classifier_create_multi", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(_vp))
+_sig("tbk_classifier_replicate", C.c_int, _vp, C.c_int, C.POINTER(_vp))
+_sig("tbk_classifier_device", C.c_int, _vp)
 _sig("tbk_classifier_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
 _sig("tbk_classifier_shared_keys", C.c_int, _vp, _u64p)
 _sig("tbk_classifier_layout", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))

@@ -70,6 +70,16 @@ def output_extension(reads_path: str) -> str:
     return path.splitext(reads_path.rstrip(".gz"))[1]
 
 
+def make_classifier(haplotype_a_kmers, haplotype_b_kmers):
+    """The batch classifier for this run: one per device of TBK_DEVICES (default: every visible
+    device), tables replicated, batches dealt to them and results taken back in input order; a plain
+    ``Classifier`` when that is a single device."""
+    devices = kmers.visible_devices()
+    if len(devices) > 1:
+        return kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, devices)
+    return kmers.Classifier(haplotype_a_kmers, haplotype_b_kmers)
+
+
 def main():
     """Main method of program"""
     args = parse_args()
@@ -80,8 +90,9 @@ def main():
 
     stats = {"reads": 0, "bases": 0, "batches": 0, "read_s": 0.0, "gpu_wait_s": 0.0, "write_s": 0.0}
     t_start = time.perf_counter()
-    classifier = kmers.Classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
+    classifier = make_classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
     stats["table_build_s"] = time.perf_counter() - t_start
+    stats["devices"] = list(getattr(classifier, "devices", [classifier.device]))
 
     # native reader / writer (same records as seq.readfq, same bytes as Read.print)
     reader = seq.BatchReader(args.reads)
@@ -113,7 +124,7 @@ def main():
     import threading
 
     depth = classifier.depth
-    n_batches = depth + 3
+    n_batches = depth + 3  # in flight on the GPU(s) + one apiece for reader, queues and writer
     free_q: "queue.Queue" = queue.Queue()
     filled_q: "queue.Queue" = queue.Queue(maxsize=2)
     done_q: "queue.Queue" = queue.Queue(maxsize=2)

@@ -482,7 +482,7 @@ struct tbk_fastx_batch {
         uint8_t *nb = nullptr;
         bool np = false;
         if (pin_state.load() >= 0) {
-            if (hipHostMalloc((void **)&nb, cap, hipHostMallocDefault) == hipSuccess) { np = true; pin_state.store(1); }
+            if (hipHostMalloc((void **)&nb, cap, hipHostMallocPortable) == hipSuccess) { np = true; pin_state.store(1); }
             else { (void)hipGetLastError(); nb = nullptr; pin_state.store(-1); }
         }
         if (!nb) nb = (uint8_t *)malloc(cap);

@@ -526,6 +526,19 @@ extern "C" int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n
 }
 
 // ---- classifier ------------------------------------------------------------------------
+// streams and the ticket ring's events (the current device is the classifier's)
+static int classifier_streams(tbk_classifier *c) {
+    hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+    for (int i = 0; i < RING && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
+    return TBK_OK;
+}
+
 extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -572,20 +585,85 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         (void)hipFree(d_over);
     }
     if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
-    e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
-    for (int i = 0; i < RING && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
-    }
-    if (e != hipSuccess) {
-        tbk_classifier_destroy(c);
-        return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
-    }
+    rc = classifier_streams(c);
+    if (rc) { tbk_classifier_destroy(c); return rc; }
     *out = c;
     return TBK_OK;
 }
+
+// ---- one classifier per device (tables replicated, reads sharded, no collective) ----
+extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!src) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    tbk_classifier *c = new tbk_classifier();
+    c->device = device;
+    c->k = src->k;
+    c->n_buckets = src->n_buckets;
+    c->distinct_a = src->distinct_a; c->distinct_b = src->distinct_b; c->shared = src->shared;
+    c->mz = src->mz;
+    c->max_blocks = src->max_blocks;
+    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
+    if (e == hipSuccess) {
+        if (device == src->device) {
+            e = hipMemcpy(c->d_pair, src->d_pair, bytes, hipMemcpyDeviceToDevice);
+        } else {
+            // the finished table travels device to device (xGMI when the two are peers; the runtime
+            // stages through the host otherwise) - once, outside any timed region
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+            (void)hipGetLastError();
+            e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    if (e != hipSuccess) {
+        if (c->d_pair) (void)hipFree(c->d_pair);
+        delete c;
+        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "replicating the paired table (%zu bytes) to device %d: %s", bytes, device,
+                    hipGetErrorString(e));
+    }
+    rc = classifier_streams(c);
+    if (rc) { tbk_classifier_destroy(c); return rc; }
+    *out = c;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_create_multi(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_classifier **out) {
+    if (!out || !devices || n_devices < 1) return fail(TBK_ERR_INVALID, "devices/out is NULL or n_devices < 1");
+    for (int i = 0; i < n_devices; i++) out[i] = nullptr;
+    int n_visible = 0;
+    if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0) return fail(TBK_ERR_NO_DEVICE, "no HIP device visible; libtbk_hip has no CPU fallback");
+    for (int i = 0; i < n_devices; i++)
+        if (devices[i] < 0 || devices[i] >= n_visible) return fail(TBK_ERR_INVALID, "device %d out of range (0..%d)", devices[i], n_visible - 1);
+    // hash the two lists once, on the device that holds them; every other entry gets a copy of the
+    // finished table (identical bytes, hence identical lookups)
+    tbk_classifier *first = nullptr;
+    int rc = tbk_classifier_create(a, b, &first);
+    if (rc) return rc;
+    bool placed = false;
+    for (int i = 0; i < n_devices && !rc; i++) {
+        if (!placed && devices[i] == first->device) { out[i] = first; placed = true; continue; }
+        rc = tbk_classifier_replicate(first, devices[i], &out[i]);
+    }
+    if (rc) {
+        const std::string msg = g_err;
+        for (int i = 0; i < n_devices; i++) { if (out[i] && out[i] != first) tbk_classifier_destroy(out[i]); out[i] = nullptr; }
+        tbk_classifier_destroy(first);
+        g_err = msg;
+        return rc;
+    }
+    if (!placed) tbk_classifier_destroy(first);
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_device(const tbk_classifier *c) { return c ? c->device : -1; }
 
 extern "C" int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
@@ -748,7 +826,7 @@ static int slot_reserve(Slot &s, uint64_t stage_bases, uint64_t n_reads, bool st
         if (s.h_bases) HIP_TRY(hipHostFree(s.h_bases));
         s.h_bases = nullptr; s.hcap_bases = 0;
         const size_t cap = std::max(need_b + need_b / 8, (size_t)1 << 20);
-        HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s.h_bases, cap, hipHostMallocPortable));
         s.hcap_bases = cap;
     }
     if ((stage_small || stage_out) && n_reads > s.hcap_reads) {
@@ -756,8 +834,8 @@ static int slot_reserve(Slot &s, uint64_t stage_bases, uint64_t n_reads, bool st
         if (s.h_counts) HIP_TRY(hipHostFree(s.h_counts));
         s.h_offsets = nullptr; s.h_counts = nullptr; s.hcap_reads = 0;
         const size_t cap = std::max((size_t)n_reads + (size_t)n_reads / 8, (size_t)1024);
-        HIP_TRY(hipHostMalloc((void **)&s.h_offsets, (cap + 1) * sizeof(uint64_t), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&s.h_counts, cap * 2 * sizeof(int32_t), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&s.h_offsets, (cap + 1) * sizeof(uint64_t), hipHostMallocPortable));
+        HIP_TRY(hipHostMalloc((void **)&s.h_counts, cap * 2 * sizeof(int32_t), hipHostMallocPortable));
         s.hcap_reads = cap;
     }
     return TBK_OK;
@@ -834,7 +912,7 @@ extern "C" int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const
 
 extern "C" void *tbk_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
         fail(TBK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
         return nullptr;
     }

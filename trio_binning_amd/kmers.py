@@ -25,11 +25,12 @@ from ._lib import check, lib
 
 
 def default_device() -> int:
-    """Device index used when none is given: TBK_DEVICE, else LOCAL_RANK, else 0."""
-    for var in ("TBK_DEVICE", "LOCAL_RANK"):
+    """Device index used when none is given: TBK_DEVICE, else the first of TBK_DEVICES, else
+    LOCAL_RANK, else 0."""
+    for var in ("TBK_DEVICE", "TBK_DEVICES", "LOCAL_RANK"):
         v = os.environ.get(var)
         if v not in (None, ""):
-            return int(v)
+            return int(v.split(",")[0])
     return 0
 
 
@@ -225,13 +226,16 @@ class Classifier:
     current one.
     """
 
-    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet):
-        h = C.c_void_p()
-        check(lib.tbk_classifier_create(kmers_hap_a._h, kmers_hap_b._h, C.byref(h)))
+    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, _handle: Optional[int] = None):
+        if _handle is None:
+            h = C.c_void_p()
+            check(lib.tbk_classifier_create(kmers_hap_a._h, kmers_hap_b._h, C.byref(h)))
+        else:  # one of tbk_classifier_create_multi's classifiers
+            h = C.c_void_p(_handle)
         self._h = h
         self._a, self._b = kmers_hap_a, kmers_hap_b  # keep the tables alive
         self._keep = {}
-        self.device = kmers_hap_a.device
+        self.device = lib.tbk_classifier_device(h)
 
     @property
     def depth(self) -> int:
@@ -321,6 +325,122 @@ class Classifier:
             self.close()
         except Exception:
             pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def visible_devices() -> list:
+    """Device indices a multi-device run uses: TBK_DEVICES ("0,1,2", a device may repeat), else
+    every visible device."""
+    spec = os.environ.get("TBK_DEVICES", "").strip()
+    if spec:
+        return [int(x) for x in spec.split(",") if x.strip() != ""]
+    return list(range(_lib.device_count()))
+
+
+class MultiClassifier:
+    """Reads sharded over several classifiers, one per device, behind ``Classifier``'s interface
+    (tables replicated, no collective; the reference's loop, classify_by_kmers.py:99-102,
+    has no cross-read state).
+
+    ``submit`` deals a batch to the classifier with the fewest batches in flight (the next one in
+    turn when several tie) and returns a ticket of its own numbering; ``wait(ticket)`` returns that
+    batch's counts whatever device computed them, so a caller that waits in submission order gets its
+    results in input order.  ``depth`` batches may be in flight in total.
+    """
+
+    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, devices: Optional[Sequence[int]] = None):
+        devices = list(visible_devices() if devices is None else devices)
+        if not devices:
+            raise _lib.TbkError(_lib.TBK_ERR_NO_DEVICE, "no HIP device visible; there is no CPU fallback")
+        arr = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        check(lib.tbk_classifier_create_multi(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), out))
+        self._init([Classifier(kmers_hap_a, kmers_hap_b, _handle=h) for h in out])
+
+    @classmethod
+    def from_classifiers(cls, classifiers) -> "MultiClassifier":
+        """Deal over already-built classifier-like objects (tests use stubs here)."""
+        self = cls.__new__(cls)
+        self._init(list(classifiers))
+        return self
+
+    def _init(self, parts) -> None:
+        self._parts = parts
+        self._load = [0] * len(parts)      # batches in flight per part
+        self._turn = 0                     # tie-break: the part after the last one dealt to
+        self._tickets = {}                 # our ticket -> (part index, its ticket)
+        self._next = 1
+        self.devices = [getattr(p, "device", None) for p in parts]
+        self.device = self.devices[0]
+        self.dealt = [0] * len(parts)      # batches each part has been given (for reports and tests)
+
+    @property
+    def depth(self) -> int:
+        return sum(p.depth for p in self._parts)
+
+    def stats(self) -> dict:
+        st = dict(self._parts[0].stats())
+        st["devices"] = list(self.devices)
+        st["table_bytes_total"] = st.get("table_bytes", 0) * len(self._parts)
+        return st
+
+    def _pick(self) -> int:
+        n = len(self._parts)
+        best = None
+        for step in range(n):
+            i = (self._turn + step) % n
+            if self._load[i] < self._parts[i].depth and (best is None or self._load[i] < self._load[best]):
+                best = i
+        if best is None:
+            raise _lib.TbkError(_lib.TBK_ERR_STATE, f"all {self.depth} stream slots are in flight; wait for a ticket first")
+        self._turn = (best + 1) % n
+        return best
+
+    def _deal(self, method: str, *args) -> int:
+        i = self._pick()
+        inner = getattr(self._parts[i], method)(*args)
+        self._load[i] += 1
+        self.dealt[i] += 1
+        ticket = self._next
+        self._next += 1
+        self._tickets[ticket] = (i, inner)
+        return ticket
+
+    def submit(self, bases: np.ndarray, offsets: np.ndarray) -> int:
+        return self._deal("submit", bases, offsets)
+
+    def submit_batch(self, batch) -> int:
+        return self._deal("submit_batch", batch)
+
+    def wait(self, ticket: int) -> np.ndarray:
+        if ticket not in self._tickets:
+            raise _lib.TbkError(_lib.TBK_ERR_STATE, f"ticket {ticket} is not in flight")
+        i, inner = self._tickets.pop(ticket)
+        try:
+            return self._parts[i].wait(inner)
+        finally:
+            self._load[i] -= 1
+
+    wait_ticket = wait
+
+    def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
+        return self.wait(self.submit(bases, offsets))
+
+    def classify_reads(self, seqs: Sequence[str]) -> np.ndarray:
+        return self.classify_batch(*pack_reads(seqs))
+
+    def sync(self) -> None:
+        for p in self._parts:
+            p.sync()
+
+    def close(self) -> None:
+        for p in self._parts:
+            p.close()
 
     def __enter__(self):
         return self
