@@ -9,22 +9,42 @@ synthetic 15 kb reads with planted list k-mers.  A *step* is one p
 hot path over one batch of reads that is already resident in HBM when the timed region
 starts: zero the counts, run the probe kernel, copy the per-read counts to the host and
 take the A/B/U binning decision there (the host part of step i-1 overlaps the kernel of
-step i; every step's host part is inside the timed region).  `value` = bases classified by all ranks / wall time
-between two barriers.  Reads are sharded across ranks (each rank draws its own reads from
-the generator), tables are replicated, there is no collective on the data path; the only
-cross-rank traffic is the barrier and the max/sum of the timing (gloo).
+step i; every step's host part is inside the timed region).  `value` = bases classified by
+all ranks / wall time of K steps between two barriers (max over ranks).  A region of K steps
+that lasts less than --min-timed-s is repeated until that much time has been measured, and the
+median region is reported (`timed_regions` says how many).
+
+Scaling.  Default "weak": every rank classifies its own reads (the generator is indexed by
+read number, ranks take disjoint ranges), tables replicated, no collective on the data path.
+`--scaling strong` is BASELINE configs[3]: ONE fixed read set (--strong-reads reads, default
+the 90 Gbp of configs[3]) split over the ranks by read index; a step is one pass of a rank over
+its whole shard, `value` = the set's bases / the slowest rank's time.
+
+Ranks are started by the driver's launcher (`python -m torch.distributed.run ... bench.py`, which
+only sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT) or, without one, by this script itself.
+Nothing here imports torch: the barrier and the max/sum of the timing scalars go through files in
+a run-private directory (the ranks of one node share /tmp); `TBK_BENCH_DIST=gloo` selects a
+torch.distributed gloo group instead (tests cover both).
 
 The JSON line also carries
   roofline      the probe kernel's algorithmic bytes per launch / its HIP-event-timed
                 average duration, against the 8 TB/s HBM peak;
+  streaming     the north-star pipeline on the same tables in the same run: batches in pinned
+                host memory through tbk_stream_submit (H2D on a side stream overlapped with
+                the kernel), PCIe-inclusive Gbases/s, as ASCII and in the packed transfer format;
   cpu_baseline  the oracle (faithful CPU restatement of c/kmers.c) timed on this box's
                 host cores on a bounded sample of the same reads and tables, with a
                 count-for-count parity check of the GPU result on that sample.
+
+`--path count` benches the k-mer counting kernel of the find-unique-kmers step instead
+(SURVEY §8f N4): Gbases/s counted, atomic adds per second against the chip's measured ceiling,
+a CPU datum and a histogram parity check.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import subprocess
 import sys
 import time
@@ -36,18 +56,23 @@ if ROOT not in sys.path:
 KEY_SEED = 0x5EED0001
 READ_SEED = 0x5EED0002
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured stream)
+BASELINE_K, BASELINE_KEYS = 21, 300_000_000
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--k", type=int, default=21)
-    ap.add_argument("--kmers-per-list", type=int, default=300_000_000)
+    ap.add_argument("--path", choices=["classify", "count"], default="classify")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--strong-reads", type=int, default=6_000_000, help="strong scaling: reads of the fixed set (configs[3]: 6 M x 15 kb = 90 Gbp)")
+    ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step region until this much time has been measured")
+    ap.add_argument("--k", type=int, default=BASELINE_K)
+    ap.add_argument("--kmers-per-list", type=int, default=BASELINE_KEYS)
     ap.add_argument("--read-len", type=int, default=15_000)
-    ap.add_argument("--reads-per-step", type=int, default=65_536)
-    ap.add_argument("--resident-batches", type=int, default=4, help="distinct read batches kept in HBM and cycled")
+    ap.add_argument("--reads-per-step", type=int, default=262_144, help="reads of one batch = one step (3.9 Gbases at 15 kb)")
+    ap.add_argument("--resident-batches", type=int, default=2, help="weak scaling: distinct read batches kept in HBM and cycled")
     ap.add_argument("--lists", choices=["uniform", "haplotypes"], default="uniform",
                     help="uniform: BASELINE.json's synthetic lists (distinct uniform random k-mers, reads with planted list "
                          "k-mers); haplotypes: lists shaped like real find-unique-kmers output (two haplotypes of a random "
@@ -58,55 +83,136 @@ def parse():
     ap.add_argument("--plant-minor", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--stream-batch-reads", type=int, default=65_536, help="reads per host batch of the streaming leg")
+    ap.add_argument("--stream-seconds", type=float, default=2.0)
     ap.add_argument("--calibrate", action="store_true", help="also run the random-line gather calibration")
     ap.add_argument("--share-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
-    return ap.parse_args()
+    # --path count
+    ap.add_argument("--count-genome", type=int, default=200_000_000)
+    ap.add_argument("--count-read-len", type=int, default=150)
+    ap.add_argument("--count-batch-bases", type=int, default=1_000_000_000)
+    return ap.parse_args(argv)
 
 
+# ---- ranks ------------------------------------------------------------------------------------------
 def spawn_ranks(args):
-    """`--gpus N` without a launcher: start N ranks as child processes (never exec)."""
-    import socket
+    """`--gpus N` without a launcher: start N ranks as child processes (never exec) and hand them a
+    private rendezvous directory."""
+    import tempfile
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+    rdv = tempfile.mkdtemp(prefix="tbk_bench_rdv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), TBK_BENCH_RDV=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    try:
+        for f in os.listdir(rdv):
+            os.unlink(os.path.join(rdv, f))
+        os.rmdir(rdv)
+    except OSError:
+        pass
+    return rc
 
 
 class Dist:
-    """Barrier + max/sum over ranks.  gloo on CPU tensors: the data path has no collective,
-    so nothing here touches the GPU."""
+    """Barrier + max/sum over the ranks of one node.  The data path has no collective: ranks only
+    meet to start and stop the clock together and to combine their timing scalars.
 
-    def __init__(self, world):
+    backend "file" (default): every rank drops `<seq>.<rank>` holding its value into a directory
+    the ranks share and polls until all `world` files of that round are there (an all-gather, from
+    which barrier, max and sum follow).  The directory is TBK_BENCH_RDV when this script spawned the
+    ranks, else derived from what a launcher gives all its workers alike (MASTER_PORT, the
+    launcher's pid).  backend "gloo": torch.distributed on CPU tensors, kept for comparison."""
+
+    def __init__(self, world, rank=None, backend=None, rdv=None, timeout_s=1800.0):
         self.world = world
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        self.backend = backend or os.environ.get("TBK_BENCH_DIST", "file")
+        self.seq = 0
+        self.timeout_s = timeout_s
         self.dist = None
-        if world > 1:
+        self.dir = None
+        if world <= 1:
+            return
+        if self.backend == "gloo":
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend="gloo", init_method="env://")
             self.dist = dist
+            return
+        self.dir = rdv or os.environ.get("TBK_BENCH_RDV") or os.path.join(
+            "/tmp", "tbk_bench_rdv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+        os.makedirs(self.dir, exist_ok=True)
+
+    def gather(self, value=0.0):
+        """Every rank's value, in rank order (a barrier as a side effect)."""
+        if self.world <= 1:
+            return [float(value)]
+        if self.dist:
+            import torch
+
+            t = torch.zeros(self.world, dtype=torch.float64)
+            t[self.rank] = float(value)
+            self.dist.all_reduce(t)
+            return [float(x) for x in t]
+        self.seq += 1
+        mine = os.path.join(self.dir, "%d.%d" % (self.seq, self.rank))
+        with open(mine + ".tmp", "w") as fh:
+            fh.write(repr(float(value)))
+        os.rename(mine + ".tmp", mine)  # atomic: a reader sees the whole value or no file
+        out, deadline = [None] * self.world, time.monotonic() + self.timeout_s
+        while True:
+            for r in range(self.world):
+                if out[r] is None:
+                    try:
+                        with open(os.path.join(self.dir, "%d.%d" % (self.seq, r))) as fh:
+                            out[r] = float(fh.read())
+                    except (OSError, ValueError):
+                        pass
+            if all(v is not None for v in out):
+                break
+            if time.monotonic() > deadline:
+                raise TimeoutError("bench rendezvous: ranks %s never reached round %d" % ([r for r, v in enumerate(out) if v is None], self.seq))
+            time.sleep(0.0002)
+        # a rank may remove its own file of the round before last: everyone has passed that round
+        old = os.path.join(self.dir, "%d.%d" % (self.seq - 2, self.rank))
+        if self.seq > 2 and os.path.exists(old):
+            os.unlink(old)
+        return out
 
     def barrier(self):
-        if self.dist:
-            self.dist.barrier()
+        self.gather(0.0)
 
     def reduce(self, value, op):
-        if not self.dist:
-            return value
-        import torch
-
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
-        return float(t[0])
+        vals = self.gather(value)
+        return max(vals) if op == "MAX" else min(vals) if op == "MIN" else sum(vals)
 
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
+        elif self.dir:
+            # A rank's files may only go once nobody can still be polling for them: after the last
+            # round every other rank says "bye" (it has read all it ever will), and rank 0, having
+            # seen every bye, removes the directory.
+            self.barrier()
+            if self.rank != 0:
+                open(os.path.join(self.dir, "bye.%d" % self.rank), "w").close()
+                return
+            deadline = time.monotonic() + 60.0
+            while not all(os.path.exists(os.path.join(self.dir, "bye.%d" % r)) for r in range(1, self.world)) and time.monotonic() < deadline:
+                time.sleep(0.001)
+            try:
+                for f in os.listdir(self.dir):
+                    os.unlink(os.path.join(self.dir, f))
+                os.rmdir(self.dir)
+            except OSError:
+                pass
 
 
 def shard_plan(total_units, rank, world):
@@ -117,6 +223,25 @@ def shard_plan(total_units, rank, world):
     return lo, hi
 
 
+def metric_label(k, n_list):
+    """BASELINE.json's metric string when the configuration is BASELINE's, else one that says what ran."""
+    if k == BASELINE_K and n_list == BASELINE_KEYS:
+        return "Gbases/sec classified (k=21, 2x300M k-mer tables)"
+    return "Gbases/sec classified (k=%d, 2x%s k-mer tables)" % (k, ("%dM" % round(n_list / 1e6)) if n_list >= 1e6 else str(n_list))
+
+
+def timed_regions(run_region, dist, min_timed_s, max_regions=64):
+    """Call run_region() (K steps between two barriers; returns this rank's seconds) until the
+    regions add up to min_timed_s.  Every rank sees the same max-over-ranks times, so all agree when
+    to stop.  Returns the list of max-over-ranks region times."""
+    times = []
+    while True:
+        times.append(dist.reduce(run_region(), "MAX"))
+        if sum(times) >= min_timed_s or len(times) >= max_regions:
+            return times
+
+
+# ---- classify ---------------------------------------------------------------------------------------
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,18 +262,21 @@ def main():
             fcntl.flock(lock, fcntl.LOCK_EX)
             entry.build()
             fcntl.flock(lock, fcntl.LOCK_UN)
-    # Load the HIP library and initialise its runtime BEFORE torch is imported: the torch wheel
-    # bundles its own copy of the HIP runtime and whichever copy is loaded first owns the process.
     from trio_binning_amd import _lib, kmers
     from trio_binning_amd._lib import check, lib
 
     n_dev = _lib.device_count()
-    dist = Dist(world)
+    dist = Dist(world, rank)
     dist.barrier()
-
     dev = 0 if args.share_device else local_rank
     if n_dev <= dev:
         raise SystemExit(f"rank {rank}: HIP device {dev} not visible ({n_dev} devices)")
+    if args.path == "count":
+        out = bench_count(args, np, kmers, lib, check, dev, dist, world, rank)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dist.close()
+        return
     k, n_list, L, R = args.k, args.kmers_per_list, args.read_len, args.reads_per_step
 
     def dalloc(nbytes):
@@ -159,6 +287,7 @@ def main():
     t_setup = time.time()
     # ---- tables: 2 x n_list distinct canonical k-mers, generated and inserted on the GPU ----
     hap = args.lists == "haplotypes"
+    genome_len = snp24 = err24 = 0
     if hap:
         # genome long enough for ~n_list windows that cover a position where the haplotypes differ
         snp24 = max(1, int(round(args.snp_rate * (1 << 24))))
@@ -195,64 +324,84 @@ def main():
         check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data + n_list * 8, C.c_void_p(d_keys + key_stride * 8), n_list * 8))
     check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
 
-    # ---- reads: `resident_batches` batches in HBM; each rank draws its own reads --------------
-    nb = max(1, args.resident_batches)
-    total = R * L
-    batches = []
-    for b in range(nb):
-        first_read = (rank * nb + b) * R  # disjoint read indices per rank: sharded, weak scaling
-        d_bases = dalloc((total + 15) // 16 * 16 + 16)
-        d_offs = dalloc((R + 1) * 8)
-        d_counts = dalloc(R * 2 * 4)
+    # ---- reads resident in HBM ------------------------------------------------------------------
+    # weak: `resident_batches` batches per rank, cycled; read indices disjoint between ranks.
+    # strong: the rank's shard [lo, hi) of ONE fixed set of reads, all of it resident, in batches of
+    # at most R reads; the generator is indexed by absolute read number, so the set does not depend
+    # on how many ranks share it.
+    strong = args.scaling == "strong"
+    if strong:
+        lo, hi = shard_plan(args.strong_reads, rank, world)
+        spans = [(s, min(s + R, hi)) for s in range(lo, hi, R)]
+    else:
+        nb = max(1, args.resident_batches)
+        spans = [((rank * nb + b) * R, (rank * nb + b + 1) * R) for b in range(nb)]
+    batches = []  # (d_bases, d_offsets, n_reads, total_bases)
+    for first, last in spans:
+        n_r = last - first
+        tot = n_r * L
+        d_bases = dalloc((tot + 15) // 16 * 16 + 16)
+        d_offs = dalloc((n_r + 1) * 8)
         if hap:
-            check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first_read, R, L, err24,
+            check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first, n_r, L, err24,
                                                  C.c_void_p(d_bases), C.c_void_p(d_offs)))
         else:
-            check(lib.tbk_synth_reads_device(dev, READ_SEED, first_read, R, L, KEY_SEED, n_list, n_list, k,
+            check(lib.tbk_synth_reads_device(dev, READ_SEED, first, n_r, L, KEY_SEED, n_list, n_list, k,
                                              args.plant_major, args.plant_minor, C.c_void_p(d_bases), C.c_void_p(d_offs)))
-        batches.append((d_bases, d_offs, d_counts))
+        batches.append((d_bases, d_offs, n_r, tot))
     t_setup = time.time() - t_setup
+    if not batches:
+        raise SystemExit(f"rank {rank}: empty shard (more ranks than reads?)")
 
     depth = cls.depth
-    counts_ring = [kmers.pinned_empty((R, 2), np.int32) for _ in range(depth)]
+    r_max = max(b[2] for b in batches)
+    counts_ring = [kmers.pinned_empty((r_max, 2), np.int32) for _ in range(depth)]
     num_a, num_b = hap_a.num_kmers, hap_b.num_kmers
     bins_total = {"A": 0, "B": 0, "U": 0}
 
-    def finish(ticket, slot, tally):
-        """Host side of a step: wait for its counts, take the A/B/U decision."""
+    def finish(ticket, slot, n_r, tally):
+        """Host side of a launch: wait for its counts, take the A/B/U decision."""
         cls.wait(ticket)
-        _, _, bins = kmers.score_and_bin(counts_ring[slot], num_a, num_b)
+        _, _, bins = kmers.score_and_bin(counts_ring[slot][:n_r], num_a, num_b)
         if tally:
             for name, ch in (("A", b"A"), ("B", b"B"), ("U", b"U")):
                 bins_total[name] += bins.count(ch)
 
+    # a step: weak = one batch (cycled); strong = every batch of the shard
+    launches_per_step = len(batches) if strong else 1
+    bases_per_step = sum(b[3] for b in batches) if strong else batches[0][3]
+
     def run(n_steps, tally):
-        """n_steps steps, pipelined: the host finishes step i-1 while the GPU probes step i."""
+        """n_steps steps, pipelined: the host finishes launch i-1 while the GPU probes launch i."""
         pending = []
-        for i in range(n_steps):
-            d_bases, d_offs, _ = batches[i % nb]
+        for i in range(n_steps * launches_per_step):
+            d_bases, d_offs, n_r, tot = batches[i % len(batches)]
             slot = i % depth
             if len(pending) == depth - 1 + (depth == 1):
                 finish(*pending.pop(0), tally)
-            pending.append((cls.submit_device(d_bases, d_offs, R, total, counts_ring[slot]), slot))
+            pending.append((cls.submit_device(d_bases, d_offs, n_r, tot, counts_ring[slot][:n_r]), slot, n_r))
         while pending:
             finish(*pending.pop(0), tally)
 
     run(args.warmup, False)
     cls.kernel_timing(True)
-    check(lib.tbk_device_sync(dev))
-    dist.barrier()
-    t0 = time.perf_counter()
-    run(args.steps, True)
-    check(lib.tbk_device_sync(dev))
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
+
+    def region():
+        check(lib.tbk_device_sync(dev))
+        dist.barrier()
+        t0 = time.perf_counter()
+        run(args.steps, True)
+        check(lib.tbk_device_sync(dev))
+        dist.barrier()
+        return time.perf_counter() - t0
+
+    region_s = timed_regions(region, dist, args.min_timed_s)
     launches, kernel_ms = cls.kernel_timing_read()
     cls.kernel_timing(False)
 
-    elapsed_max = dist.reduce(elapsed, "MAX")
-    bases_all = dist.reduce(args.steps * total, "SUM")
-    value = bases_all / elapsed_max / 1e9
+    elapsed = statistics.median(region_s)
+    bases_all = dist.reduce(args.steps * bases_per_step, "SUM")
+    value = bases_all / elapsed / 1e9
 
     if not stats["minimizer_w"]:
         bucket_select = "plain hash"
@@ -262,23 +411,27 @@ def main():
         bucket_select = "minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])
     # ---- roofline of the probe kernel (rank 0's device) -----------------------------------------
     # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
-    # hapB slot when hapA missed.  Per launch: windows = R * (L - k + 1).
-    counts = counts_ring[0]
+    # hapB slot when hapA missed.  Per launch: windows = reads * (L - k + 1), averaged over the
+    # launches of the timed regions (all batches have the same shape except a shard's last one).
+    d_b0, d_o0, n_r0, tot0 = batches[0]
+    counts = counts_ring[0][:n_r0]
     dbg_read = getattr(lib, "tbk_debug_counters", None) if hasattr(lib, "tbk_debug_counters") else None
     if dbg_read is not None:  # debug build (-DTBK_COUNTERS): event counts of one launch, to stderr
         buf = (C.c_ulonglong * 8)()
         dbg_read(buf, 1)
-    finish(cls.submit_device(batches[0][0], batches[0][1], R, total, counts), 0, False)
+    finish(cls.submit_device(d_b0, d_o0, n_r0, tot0, counts), 0, n_r0, False)
     if dbg_read is not None:
         dbg_read(buf, 1)
-        w_ = R * max(1, L - k + 1)
+        w_ = n_r0 * max(1, L - k + 1)
         print("tbk-counters", json.dumps({"careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
                                          "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4)}), file=sys.stderr)
-    hits_a = int(counts[:, 0].sum())
-    windows = R * max(0, L - k + 1)
-    alg_bytes = windows * 9 + (windows - hits_a) * 8
+    hit_a_frac = float(counts[:, 0].sum()) / max(1, n_r0 * max(0, L - k + 1))
+    reads_per_launch = sum(b[2] for b in batches) / len(batches) if strong else n_r0
+    windows = reads_per_launch * max(0, L - k + 1)
+    alg_bytes = windows * (9 + 8 * (1 - hit_a_frac))
     avg_kernel_s = kernel_ms / max(1, launches) * 1e-3
     achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    table_load = n_list / (stats["n_buckets"] * 8)
     traffic = None
     for tname in ("pmc_traffic.json", "pmc_traffic_haplotypes.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
@@ -286,19 +439,20 @@ def main():
             continue
         try:
             t = json.load(open(tfile))
-            same = (t.get("reads_per_step") == R and t.get("read_len") == L and t.get("kmers_per_list") == n_list
+            same = (t.get("read_len") == L and t.get("kmers_per_list") == n_list
                     and t.get("k") == k and t.get("bucket_select") == bucket_select and t.get("lists", "uniform") == args.lists
-                    and abs(t.get("table_load", 0) - n_list / (stats["n_buckets"] * 8)) < 1e-3)
-            if same:  # measured in a separate rocprofv3 --pmc pass on this exact configuration
-                traffic = t.get("hbm_bytes_per_launch")
+                    and abs(t.get("table_load", 0) - table_load) < 2e-3)
+            if same:  # measured in separate rocprofv3 --pmc passes on this configuration; scaled to this launch's windows
+                traffic = t["hbm_bytes_per_window"] * windows
         except Exception:
             pass
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic),
         "kernel": "tbk_probe_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "launches": int(launches),
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(alg_bytes / max(1, windows), 3),
-        "kernel_only_gbases_per_s": round(total / avg_kernel_s / 1e9, 2) if avg_kernel_s > 0 else None,
+        "windows_per_launch": int(windows),
+        "kernel_only_gbases_per_s": round(reads_per_launch * L / avg_kernel_s / 1e9, 2) if avg_kernel_s > 0 else None,
     }
     if traffic is not None and avg_kernel_s > 0:
         # where the kernel sits against what the memory system can actually deliver: PMC-measured
@@ -306,6 +460,7 @@ def main():
         # random-line ceiling measured by tools/calib_footprint.py (profiles/calibration.json)
         roofline["traffic_GBps"] = round(traffic / avg_kernel_s / 1e9, 1)
         roofline["traffic_frac_of_peak"] = round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBPS, 4)
+        roofline["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
         cfile = os.path.join(ROOT, "profiles", "calibration.json")
         if os.path.isfile(cfile):
             try:
@@ -326,37 +481,116 @@ def main():
         # the CPU sample works in whole reads; one read of this length is minutes of oracle time
         print(f"bench: reads of {L} bases are too long for a bounded CPU sample: cpu_baseline skipped", file=sys.stderr)
         want_cpu = False
+    if strong:
+        workload = (f"BASELINE configs[3]: one fixed set of {args.strong_reads} synthetic {L} b reads ({args.strong_reads * L / 1e9:.1f} Gbp) "
+                    f"split over {world} rank(s) by read index, 2x{n_list} unique {k}-mers replicated per GPU, each rank's shard resident in HBM; "
+                    f"a step = one pass of every rank over its shard")
+    else:
+        workload = (f"BASELINE configs[2] shape: {L} b synthetic reads, 2x{n_list} unique {k}-mers replicated per GPU, "
+                    f"{R} reads ({R * L / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks")
     out = {
-        "metric": "Gbases/sec classified (k=21, 2x300M k-mer tables)", "value": round(value, 3), "unit": "Gbases/s",
+        "metric": metric_label(k, n_list), "value": round(value, 3), "unit": "Gbases/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed_max / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u64",
         "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g})",
         "config": {
-            "workload": f"BASELINE configs[2] shape: {L} b synthetic reads, 2x{n_list} unique {k}-mers replicated per GPU, "
-                        f"{R} reads ({total / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks",
-            "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R, "resident_batches": nb,
-            "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(n_list / (stats["n_buckets"] * 8), 4),
+            "workload": workload,
+            "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R if not strong else None,
+            "resident_batches": len(batches), "launches_per_step": launches_per_step, "bases_per_step_per_rank": bases_per_step,
+            "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
+        "timed_regions": len(region_s), "timed_total_s": round(sum(region_s), 3),
+        "region_s_min_median_max": [round(min(region_s), 4), round(elapsed, 4), round(max(region_s), 4)],
         "roofline": roofline,
         "bins": bins_total, "setup_s": round(t_setup, 2), "table_build_s": round(t_build, 2),
         "device": _lib.device_name(dev),
     }
+
+    # ---- the north-star pipeline: pinned host batches through the stream ring (rank 0, N = 1) -----
+    if rank == 0 and world == 1 and not args.no_streaming:
+        out["streaming"] = streaming_leg(args, np, kmers, lib, check, dev, cls, batches[0], counts, L)
 
     if args.calibrate and rank == 0:
         out["calibration"] = calibrate(lib, check, dev, stats["table_bytes"])
 
     # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -----------------------------
     if want_cpu:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(args, np, lib, check, dev, batches[0], counts, h_keys, n_list, k, L, R)
+        out["cpu_baseline"], out["parity"] = cpu_baseline(args, np, lib, check, dev, batches[0], counts, h_keys, n_list, k, L, n_r0)
 
     cls.close()
     dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.close()
+
+
+def streaming_leg(args, np, kmers, lib, check, dev, cls, batch0, gpu_counts_batch0, L):
+    """Host-fed classify rate: what SURVEY §8d calls the classify stage (pinned batches -> H2D on the
+    side stream, overlapped -> probe kernel -> D2H of the counts).  Three pinned host batches (the
+    first reads of resident batch 0, copied back) are cycled through tbk_stream_submit for
+    ~stream_seconds; the counts must equal those the device-resident path got for the same reads.
+    Reported beside `value`, never as `value`."""
+    d_bases, _, n_r0, _ = batch0
+    Rs = min(args.stream_batch_reads, n_r0 // 3 if n_r0 >= 3 else n_r0)
+    if Rs < 1:
+        return None
+    tot = Rs * L
+    host = []
+    for b in range(min(3, n_r0 // Rs)):
+        hb = kmers.pinned_empty((tot,), np.uint8)
+        ho = kmers.pinned_empty((Rs + 1,), np.uint64)
+        check(lib.tbk_memcpy_d2h(dev, hb.ctypes.data, C.c_void_p(d_bases + b * tot), tot))
+        ho[:] = np.arange(Rs + 1, dtype=np.uint64) * np.uint64(L)
+        host.append((hb, ho, gpu_counts_batch0[b * Rs:(b + 1) * Rs]))
+    res = {"batch_reads": Rs, "batch_gbases": round(tot / 1e9, 4), "pinned_host_batches": len(host),
+           "note": "inputs in pinned host memory, H2D inside the timed loop (PCIe-inclusive); not `value`"}
+
+    def cycle(submit, n_batches, check_counts):
+        pend, same = [], True
+        for i in range(n_batches):
+            if len(pend) == cls.depth:
+                j, t = pend.pop(0)
+                c = cls.wait(t)
+                same = same and (not check_counts or bool(np.array_equal(c, host[j][2])))
+            j = i % len(host)
+            pend.append((j, submit(j)))
+        while pend:
+            j, t = pend.pop(0)
+            c = cls.wait(t)
+            same = same and (not check_counts or bool(np.array_equal(c, host[j][2])))
+        return same
+
+    def leg(submit):
+        cycle(submit, 3, False)
+        t = time.perf_counter()
+        cycle(submit, 6, False)
+        per = (time.perf_counter() - t) / 6
+        n = int(max(6, min(2000, args.stream_seconds / max(per, 1e-6))))
+        t = time.perf_counter()
+        same = cycle(submit, n, True)
+        dt = time.perf_counter() - t
+        return n, dt, same
+
+    n, dt, same = leg(lambda j: cls.submit(host[j][0], host[j][1]))
+    res["ascii"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * (tot + (Rs + 1) * 8) / dt / 1e9, 2),
+                    "bytes_per_base": 1.0, "batches": n, "seconds": round(dt, 3), "counts_equal_resident_path": same}
+    if hasattr(kmers, "pack_bases"):
+        # the packed transfer format: 2-bit codes + the not-ACGT exceptions, packed on the host
+        t = time.perf_counter()
+        packed = [kmers.pack_bases(hb, ho) for hb, ho, _ in host]
+        pack_s = time.perf_counter() - t
+        n, dt, same = leg(lambda j: cls.submit_packed(packed[j]))
+        nbytes = sum(p.nbytes for p in packed) / len(packed)
+        res["packed"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * nbytes / dt / 1e9, 2),
+                         "bytes_per_base": round(nbytes / tot, 4), "batches": n, "seconds": round(dt, 3), "counts_equal_resident_path": same,
+                         "host_pack_gbases_per_s": round(len(host) * tot / pack_s / 1e9, 2), "host_pack_threads": int(lib.tbk_host_threads())}
+    best = max((res[x]["gbases_per_s"] for x in ("ascii", "packed") if x in res), default=None)
+    res["gbases_per_s"] = best
+    res["h2d_GBps"] = res["ascii"]["h2d_GBps"]
+    return res
 
 
 def calibrate(lib, check, dev, footprint):
@@ -433,6 +667,109 @@ def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n
         "table_build_s": round(t_tables, 1),
     }
     return base, parity
+
+
+# ---- count (find-unique-kmers' counting kernel) -----------------------------------------------------
+def bench_count(args, np, kmers, lib, check, dev, dist, world, rank):
+    """`--path count`: k-mers of synthetic short reads (one haplotype of an implicit random genome
+    with substitution errors, generated in HBM) counted into the table in HBM
+    (find_unique_kmers.py:62-103's `kmc` step).  A step is one batch of --count-batch-bases through
+    tbk_counter_add_device; each rank counts its own reads into its own table (weak scaling)."""
+    k, L, genome = args.k, args.count_read_len, args.count_genome
+    R = args.count_batch_bases // L
+    total = R * L
+    err24 = int(args.error_rate * (1 << 24))
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    n_batches = args.warmup + args.steps
+    nres = min(4, n_batches)
+    res = []
+    for b in range(nres):
+        d_bases, d_offs = dalloc(total + 64), dalloc((R + 1) * 8)
+        res.append((d_bases, d_offs))
+    capacity = int(genome * 1.05 + n_batches * total * args.error_rate * k * 1.1) + (1 << 20)
+    ctr = kmers.KmerCounter(k, capacity, device=dev)
+
+    def fill(slot, index):
+        check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome, 0, READ_SEED + 1, (rank * n_batches + index) * R, R, L, err24,
+                                             C.c_void_p(res[slot][0]), C.c_void_p(res[slot][1])))
+
+    # every batch holds new reads (counting the same reads again would only meet known k-mers), so
+    # batches are generated outside the clock, `nres` at a time, and counted inside it
+    def run(first, n):
+        spent = 0.0
+        for base in range(first, first + n, nres):
+            m = min(nres, first + n - base)
+            for s in range(m):
+                fill(s, base + s)
+            check(lib.tbk_device_sync(dev))
+            dist.barrier()
+            t0 = time.perf_counter()
+            for s in range(m):
+                ctr.add_device(res[s][0], res[s][1], R, total)
+            check(lib.tbk_device_sync(dev))
+            dist.barrier()
+            spent += time.perf_counter() - t0
+        return spent
+
+    run(0, args.warmup)
+    ctr.kernel_timing(True)
+    elapsed = dist.reduce(run(args.warmup, args.steps), "MAX")
+    launches, wins, kernel_ms = ctr.kernel_timing(True)
+    bases_all = dist.reduce(args.steps * total, "SUM")
+    value = bases_all / elapsed / 1e9
+    hist = ctr.histogram()
+    st = ctr.stats()
+    # algorithmic bytes per window start: 1 read byte + the 8-byte key it is compared with + the
+    # 32-bit counter read and written back
+    alg = wins * (1 + 8 + 8)
+    k_s = kernel_ms * 1e-3
+    out = {
+        "metric": "Gbases/sec counted (find-unique-kmers counting step, k=%d)" % k, "value": round(value, 3), "unit": "Gbases/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"k-mer counting: {L} b synthetic reads of a {genome / 1e6:.0f} Mb genome with {args.error_rate:g} errors per base, "
+                               f"{R} reads ({total / 1e9:.2f} Gbases) per step per GPU resident in HBM, canonical {k}-mers into a counting table in HBM",
+                   "k": k, "read_len": L, "reads_per_step": R, "genome": genome, "table_bytes_per_gpu": st["table_bytes"],
+                   "table_load": round(int(hist[0]) / st["n_slots"], 3), "distinct_kmers": int(hist[0])},
+        "roofline": {"bound": "hbm", "achieved": round(alg / k_s / 1e9, 1) if k_s > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(alg / k_s / 1e9 / HBM_PEAK_GBPS, 4) if k_s > 0 else 0.0, "traffic": None,
+                     "kernel": "tbk_count_kernel", "kernel_ms_avg": round(kernel_ms / max(1, launches), 4), "launches": int(launches),
+                     "alg_bytes_per_window": 17, "windows": int(wins),
+                     "kernel_only_gbases_per_s": round(args.steps * total / k_s / 1e9, 2) if k_s > 0 else None,
+                     "window_starts_per_s": round(wins / k_s / 1e9, 2) if k_s > 0 else None},
+        "device": __import__("trio_binning_amd")._lib.device_name(dev),
+    }
+    if rank == 0:
+        # the ceiling this kernel is judged against: fire-and-forget 32-bit atomic adds, 3-4 in a row per 128-byte line
+        aps = C.c_double()
+        check(lib.tbk_calib_atomics(dev, min(st["table_bytes"], 40 << 30), 3, 3, C.byref(aps)))
+        out["roofline"]["atomic_adds_ceiling_Gps"] = round(aps.value / 1e9, 2)
+        out["roofline"]["atomic_frac"] = round(wins / k_s / aps.value, 3) if k_s > 0 else None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+
+        orc = oracle.load()
+        n_cpu = min(R, max(1000, int(args.cpu_seconds * 25e6 // L)))
+        h_bases = np.empty(n_cpu * L, dtype=np.uint8)
+        h_offs = np.arange(n_cpu + 1, dtype=np.uint64) * np.uint64(L)
+        check(lib.tbk_memcpy_d2h(dev, h_bases.ctypes.data, C.c_void_p(res[0][0]), h_bases.size))
+        t = time.perf_counter()
+        cpu_hist = orc.kmer_histogram(h_bases, h_offs, k, n_cpu * L)
+        cpu_s = time.perf_counter() - t
+        with kmers.KmerCounter(k, n_cpu * L, device=dev) as small:
+            small.add(h_bases, h_offs)
+            same = bool(np.array_equal(small.histogram(), cpu_hist))
+        out["cpu_baseline"] = {"value": round(n_cpu * L / cpu_s / 1e9, 6), "unit": "Gbases/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle C counter (one open-addressing table, rolling canonical k-mers; KMC itself is not in the reference checkout) "
+                                         f"on {n_cpu} reads ({n_cpu * L / 1e6:.0f} Mbases) of the last batch, {cpu_s:.1f} s"}
+        out["parity"] = {"gpu_histogram_equals_cpu": same, "reads_checked": int(n_cpu), "distinct_kmers_checked": int(cpu_hist[0])}
+    ctr.close()
+    return out
 
 
 if __name__ == "__main__":

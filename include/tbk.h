@@ -282,6 +282,9 @@ void tbk_counter_destroy(tbk_counter *c);
 int tbk_counter_add_batch(tbk_counter *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads);
 /* Same for a batch already in HBM (d_bases readable up to total_bases). */
 int tbk_counter_add_device(tbk_counter *c, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t total_bases);
+/* HIP-event timing of the counting kernel (every launch is bracketed by an event pair on the stream
+ * it runs on): launches, window starts they covered and their summed duration since the last reset. */
+int tbk_counter_kernel_timing(tbk_counter *c, uint64_t *launches, uint64_t *window_starts, double *total_ms, int reset);
 /* hist[c], c = 1..255: number of distinct k-mers whose counter (capped at 255) is c - the rows
  * kmc_tools writes, except that KMC's -ci2 database has no row-1 k-mers (callers zero hist[1]);
  * hist[0]: all distinct k-mers met. */

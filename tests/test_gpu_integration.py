@@ -24,7 +24,7 @@ def snippet(letter):
 
 
 @pytest.mark.parametrize("letter", ["B", "C"])
-def test_integration_snippet_runs_the_reference_kats(gpu, letter, capfd):
+def test_integration_snippet_runs_the_reference_kats(gpu, letter, capfd, tmp_path):
     ns = {"__file__": os.path.join(ROOT, "trio_binning_amd", "kmers.py"), "__name__": "reference_kmers_patched"}
     exec(compile(snippet(letter), f"INTEGRATION.md[{letter}]", "exec"), ns)
     a = ns["create_kmer_hash_set"](os.path.join(DATA, "hapA.txt"))
@@ -46,8 +46,9 @@ def test_integration_snippet_runs_the_reference_kats(gpu, letter, capfd):
         with pytest.raises(IOError):
             ns["create_kmer_hash_set"](os.path.join(DATA, "no_such_list.txt"))
         # a failure inside the library: NULL handle, counts left at -1 (the C signatures have no error channel)
-        bad = os.path.join(DATA, "..", "golden", "kat.json")   # a file, but k = its first line's length > 32
-        h = ns["create_kmer_hash_set"](bad)
+        bad = tmp_path / "k40.txt"                              # a file, but its first line gives k = 40 > 32
+        bad.write_text("A" * 40 + "\n")
+        h = ns["create_kmer_hash_set"](str(bad))
         assert not h
         with pytest.raises(ValueError):
             h.contents

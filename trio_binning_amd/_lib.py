@@ -118,6 +118,7 @@ _sig("tbk_counter_create", C.c_int, C.c_int, _u64, C.c_int, C.POINTER(_vp))
 _sig("tbk_counter_destroy", None, _vp)
 _sig("tbk_counter_add_batch", C.c_int, _vp, _vp, _vp, _u64)
 _sig("tbk_counter_add_device", C.c_int, _vp, _vp, _vp, _u64, _u64)
+_sig("tbk_counter_kernel_timing", C.c_int, _vp, _u64p, _u64p, _dp, C.c_int)
 _sig("tbk_counter_histogram", C.c_int, _vp, _u64p)
 _sig("tbk_counter_distinct", C.c_int, _vp, _u64p)
 _sig("tbk_counter_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)

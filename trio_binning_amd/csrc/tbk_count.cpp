@@ -70,6 +70,10 @@ struct tbk_counter {
     uint64_t *d_off = nullptr;
     size_t cap_raw = 0, cap_sep = 0, cap_reads = 0;
     uint64_t bases_added = 0, reads_added = 0;
+    // HIP-event timing of the counting kernel (every launch; read by tbk_counter_kernel_timing)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t timed_launches = 0, timed_windows = 0;
+    double timed_ms = 0.0;
 };
 
 static int counter_device(const tbk_counter *c) {
@@ -153,6 +157,8 @@ extern "C" void tbk_counter_destroy(tbk_counter *c) {
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         (void)hipDeviceSynchronize();
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
         for (void *p : {(void *)c->d_lines, (void *)c->d_failed, (void *)c->d_used, (void *)c->d_raw, (void *)c->d_sep, (void *)c->d_off})
             if (p) (void)hipFree(p);
     }
@@ -184,10 +190,18 @@ static int counter_run(tbk_counter *c, const uint8_t *d_bases, const uint64_t *d
             if (rc) return rc;
             slots = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET;
         }
+        if (!c->ev0) { CHIP(hipEventCreate(&c->ev0)); CHIP(hipEventCreate(&c->ev1)); }
+        CHIP(hipEventRecord(c->ev0, nullptr));
         CHIP(tbk_launch_count(c->d_sep, sep_total, p0, np, c->k, c->d_lines, c->n_buckets, c->mz, c->d_failed, c->d_used, nullptr));
+        CHIP(hipEventRecord(c->ev1, nullptr));
         int failed = 0;
         unsigned long long used = 0;
         CHIP(hipMemcpy(&failed, c->d_failed, sizeof failed, hipMemcpyDeviceToHost));
+        {
+            float ms = 0;
+            CHIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            c->timed_ms += ms; c->timed_launches++; c->timed_windows += std::min<uint64_t>(windows, sep_total - p0 * 2048);
+        }
         CHIP(hipMemcpy(&used, c->d_used, sizeof used, hipMemcpyDeviceToHost));
         c->used = used;
         if (failed) return cfail(TBK_ERR_NOMEM, "counting table is full (%llu slots, %llu taken)", (unsigned long long)slots, used);
@@ -231,6 +245,15 @@ extern "C" int tbk_counter_add_device(tbk_counter *c, const void *d_bases, const
     int rc = counter_device(c);
     if (rc) return rc;
     return counter_run(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases);
+}
+
+extern "C" int tbk_counter_kernel_timing(tbk_counter *c, uint64_t *launches, uint64_t *window_starts, double *total_ms, int reset) {
+    if (!c) return cfail(TBK_ERR_INVALID, "counter is NULL");
+    if (launches) *launches = c->timed_launches;
+    if (window_starts) *window_starts = c->timed_windows;
+    if (total_ms) *total_ms = c->timed_ms;
+    if (reset) { c->timed_launches = 0; c->timed_windows = 0; c->timed_ms = 0.0; }
+    return TBK_OK;
 }
 
 extern "C" int tbk_counter_histogram(tbk_counter *c, uint64_t hist[256]) {

@@ -502,6 +502,12 @@ class KmerCounter:
     def add_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int) -> None:
         check(lib.tbk_counter_add_device(self._h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, total_bases))
 
+    def kernel_timing(self, reset: bool = True) -> Tuple[int, int, float]:
+        """(launches, window starts, total ms) of the counting kernel since the last reset."""
+        n, w, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        check(lib.tbk_counter_kernel_timing(self._h, C.byref(n), C.byref(w), C.byref(ms), int(reset)))
+        return n.value, w.value, ms.value
+
     def histogram(self) -> np.ndarray:
         """hist[c], c = 1..255: distinct k-mers whose counter (capped at 255) is c; hist[0]: all."""
         hist = np.zeros(256, dtype=np.uint64)
