@@ -158,6 +158,26 @@ int tbk_stream_depth(const tbk_classifier *c);
 int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
                       uint64_t n_reads, int32_t *counts, uint64_t *ticket);
 int tbk_stream_wait(tbk_classifier *c, uint64_t ticket);
+/* The packed transfer format.  ASCII reads cost a byte per base over PCIe (Gen5 x16: ~56 GB/s, a
+ * third of what the probe kernel consumes); the kernel's first step on a 16-base chunk is to turn it
+ * into a 32-bit word of 2-bit codes (c/kmers.c:50-72's encoding) and a 16-bit not-ACGT mask, and that
+ * step can run on the host instead.  A packed batch is
+ *     codes[tbk_packed_chunks(total)]     chunk j = stream positions 16j..16j+15, base i at bits 2i..2i+1
+ *     exc_chunk[n_exc], exc_mask[n_exc]   the chunks holding a byte outside ACGT, or positions at or
+ *                                         past the end of the stream: chunk index and 16-bit mask
+ * = 0.25 bytes per base for clean reads.  Counts are identical to the ASCII path's by construction.
+ * tbk_stream_submit itself packs a host batch this way before the copy (all host threads, straight
+ * from the caller's memory into pinned staging) unless TBK_PACKED_H2D=0 / tbk_classifier_set_transfer
+ * (c, 0); tbk_pack_bases + tbk_stream_submit_packed let a caller pack ahead of time (a reader thread). */
+uint64_t tbk_packed_chunks(uint64_t total_bases);
+/* TBK_ERR_NOMEM with *n_exc set when exc_capacity is too small (tbk_packed_chunks(total) always suffices). */
+int tbk_pack_bases(const uint8_t *bases, uint64_t total_bases, uint32_t *codes, uint32_t *exc_chunk, uint16_t *exc_mask,
+                   uint64_t exc_capacity, uint64_t *n_exc);
+int tbk_stream_submit_packed(tbk_classifier *c, const uint32_t *codes, const uint32_t *exc_chunk, const uint16_t *exc_mask,
+                             uint64_t n_exc, const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket);
+/* packed != 0: tbk_stream_submit / tbk_classify_batch pack on the host before the copy (default). */
+int tbk_classifier_set_transfer(tbk_classifier *c, int packed);
+int tbk_classifier_transfer(const tbk_classifier *c);
 void *tbk_host_alloc(size_t bytes);  /* pinned host memory (hipHostMalloc) */
 void tbk_host_free(void *p);
 

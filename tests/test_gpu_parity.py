@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 COMP = str.maketrans("ACGT", "TGCA")
 
 
+@pytest.fixture(autouse=True, params=["packed-h2d", "ascii-h2d"])
+def transfer(request, monkeypatch):
+    """Every test of this file runs twice: host batches cross PCIe in the packed transfer format
+    (the default: packed on the host, the kernel starts from code words and masks) and as ASCII
+    (TBK_PACKED_H2D=0: the kernel packs).  Same oracle, same expected counts."""
+    monkeypatch.setenv("TBK_PACKED_H2D", "1" if request.param == "packed-h2d" else "0")
+    return request.param
+
+
 def _rc(s):
     return s.translate(COMP)[::-1]
 
@@ -519,6 +528,54 @@ def test_streaming_order_and_overlap(gpu, orc, tmp_path):
     for reads, got in zip(batches, results[:len(batches)]):
         bases, offs = _pack(reads)
         assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
+
+
+def test_prepacked_batches(gpu, orc, transfer):
+    """tbk_pack_bases + tbk_stream_submit_packed: batches packed ahead of time (pinned and pageable
+    arrays), with N runs, lower case, reads ending inside a chunk, an empty batch; counts equal the
+    oracle's and the ASCII path's.  A malformed exception list is refused."""
+    import ctypes as C
+
+    from trio_binning_amd import _lib, kmers
+    from trio_binning_amd._lib import lib
+
+    fa, fb = os.path.join(DATA, "hapA.txt"), os.path.join(DATA, "hapB.txt")
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    lists = [l.strip() for l in open(fa)] + [l.strip() for l in open(fb)]
+    rng = np.random.default_rng(44)
+    with kmers.Classifier(a, b) as cls:
+        assert cls.packed_transfer == (transfer == "packed-h2d")
+        for trial in range(6):
+            reads = _rand_reads(rng, int(rng.integers(1, 300)), 3000, lists, 21)
+            for i in range(0, len(reads), 5):   # damage some reads: N runs, lower case, a planted k-mer broken by an N
+                r = list(reads[i])
+                if len(r) > 60:
+                    p = int(rng.integers(0, len(r) - 40))
+                    r[p:p + int(rng.integers(1, 40))] = "N" * 1
+                    r[-3:] = "acg"
+                reads[i] = "".join(r)
+            if trial == 3:
+                reads = ["", "ACGT", lists[0], lists[0] + "N" + lists[1], "N" * 50, lists[2][:20]]
+            bases, offs = _pack(reads)
+            want = orc.count_batch(bases, offs, oa, ob)
+            for pinned in (True, False):
+                pk = kmers.pack_bases(bases, offs, pinned=pinned)
+                assert np.array_equal(cls.wait(cls.submit_packed(pk)), want), (trial, pinned)
+            assert np.array_equal(cls.classify_batch(bases, offs), want)
+            cls.packed_transfer = not cls.packed_transfer      # and through the other transfer of submit
+            assert np.array_equal(cls.classify_batch(bases, offs), want)
+            cls.packed_transfer = not cls.packed_transfer
+        empty = kmers.pack_bases(np.zeros(0, dtype=np.uint8), np.array([0, 0, 0], dtype=np.uint64))
+        assert cls.wait(cls.submit_packed(empty)).tolist() == [[0, 0], [0, 0]]
+        pk = kmers.pack_bases(*_pack([lists[0] * 3]), pinned=False)
+        bad_chunk = np.array([99], dtype=np.uint32)
+        counts, tk = np.zeros((1, 2), dtype=np.int32), C.c_uint64()
+        assert lib.tbk_stream_submit_packed(cls._h, pk.codes.ctypes.data, bad_chunk.ctypes.data, pk.exc_mask.ctypes.data, 1,
+                                            pk.offsets.ctypes.data, 1, counts.ctypes.data, C.byref(tk)) == _lib.TBK_ERR_INVALID
+        assert lib.tbk_stream_submit_packed(cls._h, pk.codes.ctypes.data, None, None, 1,
+                                            pk.offsets.ctypes.data, 1, counts.ctypes.data, C.byref(tk)) == _lib.TBK_ERR_INVALID
+        assert np.array_equal(cls.wait(cls.submit_packed(pk)), orc.count_batch(*_pack([lists[0] * 3]), oa, ob))
 
 
 def test_realistic_haplotypes(gpu, orc):

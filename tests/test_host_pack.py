@@ -1,0 +1,118 @@
+"""The host packer of the packed transfer format (tbk_pack_bases, host code: no GPU needed) against
+a numpy restatement of the device's pack16 (csrc/tbk_device.h): 2-bit codes per base, and the
+exceptions for chunks holding a byte outside ACGT or positions past the end of the stream."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def want_packed(bases: np.ndarray):
+    total = bases.size
+    n_chunks = (total + 15) // 16
+    padded = np.zeros(n_chunks * 16, dtype=np.uint8)
+    padded[:total] = bases
+    code = ((padded >> 1) ^ (padded >> 2)) & 3
+    good = np.isin(padded, np.frombuffer(b"ACGT", dtype=np.uint8))
+    good[total:] = False
+    shifts = (2 * np.arange(16, dtype=np.uint64))
+    codes = (code.reshape(n_chunks, 16).astype(np.uint64) << shifts).sum(axis=1).astype(np.uint32)
+    mask = ((~good).reshape(n_chunks, 16).astype(np.uint32) << np.arange(16, dtype=np.uint32)).sum(axis=1).astype(np.uint16)
+    if total % 16:
+        codes[-1] &= np.uint32((1 << (2 * (total % 16))) - 1)
+    # where a byte is not ACGT the code bits are free: compare codes under the mask of good bases only
+    return codes, mask
+
+
+def check_pack(kmers, bases):
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offs = np.array([0, bases.size], dtype=np.uint64)
+    p = kmers.pack_bases(bases, offs, pinned=False)
+    codes, mask = want_packed(bases)
+    assert p.codes.size == codes.size
+    dense = np.zeros(codes.size, dtype=np.uint16)
+    assert np.all(np.diff(p.exc_chunk.astype(np.int64)) > 0)         # ordered by chunk, each chunk once
+    dense[p.exc_chunk] = p.exc_mask
+    assert np.array_equal(dense, mask)
+    assert np.all(p.exc_mask != 0)
+    good2 = np.repeat(~((mask[:, None] >> np.arange(16)) & 1).astype(bool), 2, axis=1)       # two code bits per base
+    keep = (good2.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    assert np.array_equal(p.codes & keep, codes & keep)
+    return p
+
+
+def test_packer_matches_the_device_packing(built):
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for n in (0, 1, 15, 16, 17, 31, 32, 33, 100, 1000, 4097):
+        check_pack(kmers, acgt[rng.integers(0, 4, n)])
+    # every byte value, in every position of a chunk
+    allb = np.tile(np.arange(256, dtype=np.uint8), 17)
+    check_pack(kmers, allb)
+    # reads with N runs, lower case, IUPAC; a clean stream has no exceptions but the tail's
+    noisy = acgt[rng.integers(0, 4, 300_001)].copy()
+    noisy[rng.integers(0, noisy.size, 3000)] = np.frombuffer(b"NnacgtRYKM-*", dtype=np.uint8)[rng.integers(0, 12, 3000)]
+    noisy[5000:5400] = ord("N")
+    check_pack(kmers, noisy)
+    clean = check_pack(kmers, acgt[rng.integers(0, 4, 64_000)])
+    assert clean.exc_chunk.size == 0
+    assert clean.nbytes == 64_000 // 4 + 16     # a quarter byte per base + the two offsets
+    tail = check_pack(kmers, acgt[rng.integers(0, 4, 64_005)])
+    assert tail.exc_chunk.tolist() == [4000] and tail.exc_mask.tolist() == [0xFFE0]
+
+
+def test_packer_threads_and_scalar_path_agree(built):
+    """A batch big enough for several packer threads, and the scalar code path (TBK_NO_AVX2=1) in a
+    child process: same words, same exceptions."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(9)
+    n = 40_000_003
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+    bad = rng.integers(0, n, 20_000)
+    bases[bad] = ord("N")
+    p = check_pack(kmers, bases)
+    path = "/tmp/tbk_pack_test_%d.npy" % os.getpid()
+    np.save(path, bases)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from trio_binning_amd import kmers;"
+            "b = np.load(%r); p = kmers.pack_bases(b, np.array([0, b.size], dtype=np.uint64), pinned=False);"
+            "import zlib; print(zlib.crc32(p.codes.tobytes()), zlib.crc32(p.exc_chunk.tobytes()), zlib.crc32(p.exc_mask.tobytes()))" % (ROOT, path))
+    try:
+        outs = []
+        for env in ({"TBK_NO_AVX2": "1", "TBK_HOST_THREADS": "1"}, {"TBK_HOST_THREADS": "5"}):
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-1500:]
+            outs.append(r.stdout.split())
+    finally:
+        os.unlink(path)
+    import zlib
+
+    # code bits of not-ACGT bytes are free, and the scalar and AVX2 paths happen to agree on them too
+    mine = [str(zlib.crc32(p.codes.tobytes())), str(zlib.crc32(p.exc_chunk.tobytes())), str(zlib.crc32(p.exc_mask.tobytes()))]
+    assert outs[0][1:] == outs[1][1:] == mine[1:]
+    assert outs[0][0] == outs[1][0] == mine[0]
+
+
+def test_pack_bases_capacity_protocol(built):
+    import ctypes as C
+
+    from trio_binning_amd import _lib
+    from trio_binning_amd._lib import lib
+
+    bases = np.frombuffer(b"ACGTNACGTACGTACGTNNNNACGTACGTACGTACGTAC", dtype=np.uint8)
+    codes = np.zeros(3, dtype=np.uint32)
+    n = C.c_uint64()
+    ec, em = np.zeros(1, dtype=np.uint32), np.zeros(1, dtype=np.uint16)
+    assert lib.tbk_packed_chunks(bases.size) == 3
+    assert lib.tbk_pack_bases(bases.ctypes.data, bases.size, codes.ctypes.data, ec.ctypes.data, em.ctypes.data, 1, C.byref(n)) == _lib.TBK_ERR_NOMEM
+    assert n.value == 3
+    ec, em = np.zeros(3, dtype=np.uint32), np.zeros(3, dtype=np.uint16)
+    assert lib.tbk_pack_bases(bases.ctypes.data, bases.size, codes.ctypes.data, ec.ctypes.data, em.ctypes.data, 3, C.byref(n)) == 0
+    assert ec.tolist() == [0, 1, 2] and em.tolist() == [1 << 4, 0b11110, 0xFF80]
+    assert lib.tbk_pack_bases(None, 5, codes.ctypes.data, None, None, 0, C.byref(n)) == _lib.TBK_ERR_INVALID

@@ -93,6 +93,11 @@ _sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
 _sig("tbk_stream_depth", C.c_int, _vp)
 _sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)
 _sig("tbk_stream_wait", C.c_int, _vp, _u64)
+_sig("tbk_packed_chunks", _u64, _u64)
+_sig("tbk_pack_bases", C.c_int, _vp, _u64, _vp, _vp, _vp, _u64, _u64p)
+_sig("tbk_stream_submit_packed", C.c_int, _vp, _vp, _vp, _vp, _u64, _vp, _u64, _vp, _u64p)
+_sig("tbk_classifier_set_transfer", C.c_int, _vp, C.c_int)
+_sig("tbk_classifier_transfer", C.c_int, _vp)
 _sig("tbk_host_alloc", _vp, C.c_size_t)
 _sig("tbk_host_free", None, _vp)
 _sig("tbk_classify_device", C.c_int, _vp, _vp, _vp, _u64, _u64, _vp)

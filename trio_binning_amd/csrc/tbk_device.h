@@ -46,6 +46,14 @@ __device__ __forceinline__ uint64_t load_chunk(const uint8_t *bases, uint64_t po
     return pack16(v);
 }
 
+// The same chunk from the packed transfer format: its code word and its dense 16-bit mask; chunks
+// past the end of the stream read as sixteen not-ACGT bases (the last, partial chunk carries the
+// mask bits of the positions past the end already - tbk_pack.cpp).
+__device__ __forceinline__ uint64_t load_packed_chunk(const uint32_t *codes, const uint16_t *bad16, uint64_t chunk, uint64_t n_chunks) {
+    if (chunk >= n_chunks) return 0xFFFFull << 32;
+    return (uint64_t)codes[chunk] | ((uint64_t)bad16[chunk] << 32);
+}
+
 // reverse the order of the sixteen 2-bit groups of a word
 __device__ __forceinline__ uint32_t rev_pairs(uint32_t x) {
     x = __brev(x);

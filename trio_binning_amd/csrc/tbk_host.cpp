@@ -32,8 +32,11 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, h
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
+extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, int, hipStream_t);
+extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, hipStream_t);
+extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
+int tbk_pack_bases_vec(const uint8_t *bases, uint64_t total, uint32_t *codes, std::vector<uint32_t> &exc_chunk, std::vector<uint16_t> &exc_mask, int threads);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
@@ -139,6 +142,12 @@ struct Slot {
     int32_t *d_counts = nullptr;
     uint8_t *h_bases = nullptr; size_t hcap_bases = 0;    // pinned staging for unpinned callers
     uint64_t *h_offsets = nullptr; int32_t *h_counts = nullptr; size_t hcap_reads = 0;
+    // packed transfer format (tbk_pack.cpp): code words, dense masks, exceptions; pinned staging for
+    // batches packed at submit time
+    uint32_t *d_codes = nullptr; uint16_t *d_bad = nullptr; size_t cap_chunks = 0;
+    uint32_t *d_exc_chunk = nullptr; uint16_t *d_exc_mask = nullptr; size_t cap_exc = 0;
+    uint32_t *h_codes = nullptr; size_t hcap_chunks = 0;
+    uint32_t *h_exc_chunk = nullptr; uint16_t *h_exc_mask = nullptr; size_t hcap_exc = 0;
     hipEvent_t copied = nullptr, probed = nullptr, done = nullptr;
     bool busy = false;
     uint64_t ticket = 0, n_reads = 0;
@@ -159,6 +168,11 @@ struct tbk_classifier {
     Slot ring[RING];
     uint64_t next_ticket = 1;
     int max_blocks = 0;
+    // how tbk_stream_submit moves a host batch's bases: 1 = packed on the host first (0.25 B/base over
+    // PCIe), 0 = as ASCII (1 B/base).  TBK_PACKED_H2D, tbk_classifier_set_transfer.
+    int packed_h2d = 1;
+    std::vector<uint32_t> exc_chunk;  // scratch of the packer
+    std::vector<uint16_t> exc_mask;
     // scratch for the pass -> read index (launches on `compute` are stream-ordered, so one
     // buffer serves them all)
     uint32_t *d_pass_read = nullptr;
@@ -553,6 +567,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->device = a->device;
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
+    c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
     // bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
     // default 6; 0 = plain hashing of the whole key).  TBK_MOD_SAMPLING=1 samples by mod-sampling
     // instead of the random-minimizer rule: 15 % fewer HBM lines but 23 % more VALU work, a net
@@ -605,6 +620,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->distinct_a = src->distinct_a; c->distinct_b = src->distinct_b; c->shared = src->shared;
     c->mz = src->mz;
     c->max_blocks = src->max_blocks;
+    c->packed_h2d = src->packed_h2d;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) {
@@ -703,6 +719,13 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             if (s.h_bases) (void)hipHostFree(s.h_bases);
             if (s.h_offsets) (void)hipHostFree(s.h_offsets);
             if (s.h_counts) (void)hipHostFree(s.h_counts);
+            if (s.d_codes) (void)hipFree(s.d_codes);
+            if (s.d_bad) (void)hipFree(s.d_bad);
+            if (s.d_exc_chunk) (void)hipFree(s.d_exc_chunk);
+            if (s.d_exc_mask) (void)hipFree(s.d_exc_mask);
+            if (s.h_codes) (void)hipHostFree(s.h_codes);
+            if (s.h_exc_chunk) (void)hipHostFree(s.h_exc_chunk);
+            if (s.h_exc_mask) (void)hipHostFree(s.h_exc_mask);
             if (s.copied) (void)hipEventDestroy(s.copied);
             if (s.probed) (void)hipEventDestroy(s.probed);
             if (s.done) (void)hipEventDestroy(s.done);
@@ -738,7 +761,8 @@ static bool is_pinned(const void *p) {
 }
 
 static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const uint64_t *d_offsets,
-                              uint64_t n_reads, uint64_t total, int32_t *d_counts) {
+                              uint64_t n_reads, uint64_t total, int32_t *d_counts, const uint32_t *d_codes = nullptr,
+                              const uint16_t *d_bad16 = nullptr) {
     if (n_reads >= 0xFFFFFFF0ull) return fail(TBK_ERR_INVALID, "more than 2^32 reads in one batch");
     if (total == 0) {  // nothing to probe (every read empty): all counts are zero
         HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
@@ -778,7 +802,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         c->timed_launches++;
         HIP_TRY(hipEventRecord(e0, c->compute));
     }
-    HIP_TRY(tbk_launch_probe(d_bases, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->max_blocks,
+    HIP_TRY(tbk_launch_probe(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->max_blocks,
                              c->compute));
     if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
     return TBK_OK;
@@ -841,41 +865,136 @@ static int slot_reserve(Slot &s, uint64_t stage_bases, uint64_t n_reads, bool st
     return TBK_OK;
 }
 
-extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
-                                 int32_t *counts, uint64_t *ticket) {
+// device buffers of a slot for a packed batch
+static int slot_reserve_packed(Slot &s, uint64_t n_chunks, uint64_t n_exc) {
+    if (n_chunks > s.cap_chunks) {
+        if (s.d_codes) HIP_TRY(hipFree(s.d_codes));
+        if (s.d_bad) HIP_TRY(hipFree(s.d_bad));
+        s.d_codes = nullptr; s.d_bad = nullptr; s.cap_chunks = 0;
+        const size_t cap = std::max((size_t)n_chunks + (size_t)n_chunks / 8, (size_t)1 << 16);
+        HIP_TRY(hipMalloc((void **)&s.d_codes, cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_bad, cap * sizeof(uint16_t)));
+        s.cap_chunks = cap;
+    }
+    if (n_exc > s.cap_exc) {
+        if (s.d_exc_chunk) HIP_TRY(hipFree(s.d_exc_chunk));
+        if (s.d_exc_mask) HIP_TRY(hipFree(s.d_exc_mask));
+        s.d_exc_chunk = nullptr; s.d_exc_mask = nullptr; s.cap_exc = 0;
+        const size_t cap = std::max((size_t)n_exc + (size_t)n_exc / 4, (size_t)4096);
+        HIP_TRY(hipMalloc((void **)&s.d_exc_chunk, cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_exc_mask, cap * sizeof(uint16_t)));
+        s.cap_exc = cap;
+    }
+    return TBK_OK;
+}
+
+// pinned staging of a slot for a batch packed at submit time
+static int slot_reserve_packed_host(Slot &s, uint64_t n_chunks, uint64_t n_exc) {
+    if (n_chunks > s.hcap_chunks) {
+        if (s.h_codes) HIP_TRY(hipHostFree(s.h_codes));
+        s.h_codes = nullptr; s.hcap_chunks = 0;
+        const size_t cap = std::max((size_t)n_chunks + (size_t)n_chunks / 8, (size_t)1 << 16);
+        HIP_TRY(hipHostMalloc((void **)&s.h_codes, cap * sizeof(uint32_t), hipHostMallocPortable));
+        s.hcap_chunks = cap;
+    }
+    if (n_exc > s.hcap_exc) {
+        if (s.h_exc_chunk) HIP_TRY(hipHostFree(s.h_exc_chunk));
+        if (s.h_exc_mask) HIP_TRY(hipHostFree(s.h_exc_mask));
+        s.h_exc_chunk = nullptr; s.h_exc_mask = nullptr; s.hcap_exc = 0;
+        const size_t cap = std::max((size_t)n_exc + (size_t)n_exc / 4, (size_t)4096);
+        HIP_TRY(hipHostMalloc((void **)&s.h_exc_chunk, cap * sizeof(uint32_t), hipHostMallocPortable));
+        HIP_TRY(hipHostMalloc((void **)&s.h_exc_mask, cap * sizeof(uint16_t), hipHostMallocPortable));
+        s.hcap_exc = cap;
+    }
+    return TBK_OK;
+}
+
+// The common body of the host-batch submits.  Exactly one of `bases` (ASCII) and `codes` (packed) is
+// given; src pointers must stay valid until the ticket is waited for unless they were staged here.
+static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *codes, const uint32_t *exc_chunk, const uint16_t *exc_mask,
+                       uint64_t n_exc, const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket) {
     if (!c || !offsets || !ticket || (n_reads && !counts)) return fail(TBK_ERR_INVALID, "NULL argument");
     int rc = tbk_check_offsets_(offsets, n_reads);
     if (rc) return rc;
     const uint64_t total = offsets[n_reads];
-    if (total && !bases) return fail(TBK_ERR_INVALID, "bases is NULL");
+    if (total && !bases && !codes) return fail(TBK_ERR_INVALID, "bases is NULL");
+    if (codes && n_exc && (!exc_chunk || !exc_mask)) return fail(TBK_ERR_INVALID, "exception arrays are NULL");
     rc = use_device(c->device);
     if (rc) return rc;
     const uint64_t tk = c->next_ticket;
     Slot &s = c->ring[tk % RING];
     if (s.busy) return fail(TBK_ERR_STATE, "all %d stream slots are in flight; call tbk_stream_wait(%llu) first", RING,
                             (unsigned long long)s.ticket);
+    const uint64_t n_chunks = tbk_packed_chunks(total);
+    bool packed = codes != nullptr;
+    if (!packed && total && c->packed_h2d) {
+        // Pack on the host (all host threads) straight from the caller's memory into the slot's pinned
+        // staging: a quarter of the bytes cross PCIe, and a pageable batch needs no staging copy (the
+        // packer reads it once, where a copy into pinned memory would read and write it).
+        rc = slot_reserve_packed_host(s, n_chunks, 0);
+        if (rc) return rc;
+        rc = tbk_pack_bases_vec(bases, total, s.h_codes, c->exc_chunk, c->exc_mask, 0);
+        if (rc) return fail(rc, "%s", g_err.c_str());
+        n_exc = c->exc_chunk.size();
+        rc = slot_reserve_packed_host(s, n_chunks, n_exc);
+        if (rc) return rc;
+        if (n_exc) {
+            memcpy(s.h_exc_chunk, c->exc_chunk.data(), n_exc * sizeof(uint32_t));
+            memcpy(s.h_exc_mask, c->exc_mask.data(), n_exc * sizeof(uint16_t));
+        }
+        codes = s.h_codes; exc_chunk = s.h_exc_chunk; exc_mask = s.h_exc_mask;
+        packed = true;
+    } else if (packed && total) {
+        // caller-packed arrays: pinned ones are copied from where they lie, pageable ones are staged
+        const bool codes_pinned = is_pinned(codes), exc_pinned = n_exc == 0 || (is_pinned(exc_chunk) && is_pinned(exc_mask));
+        rc = slot_reserve_packed_host(s, codes_pinned ? 0 : n_chunks, exc_pinned ? 0 : n_exc);
+        if (rc) return rc;
+        if (!codes_pinned) { par_memcpy(s.h_codes, codes, n_chunks * sizeof(uint32_t)); codes = s.h_codes; }
+        if (!exc_pinned) {
+            memcpy(s.h_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t));
+            memcpy(s.h_exc_mask, exc_mask, n_exc * sizeof(uint16_t));
+            exc_chunk = s.h_exc_chunk; exc_mask = s.h_exc_mask;
+        }
+        for (uint64_t i = 0; i < n_exc; i++)
+            if (exc_chunk[i] >= n_chunks) return fail(TBK_ERR_INVALID, "exception %llu names chunk %u of %llu", (unsigned long long)i, exc_chunk[i], (unsigned long long)n_chunks);
+    }
     // pinned inputs are copied straight from the caller's memory; pageable ones go through the
     // slot's pinned staging (bases and offsets decided independently: a reader batch has its
     // bases pinned and its small offsets array in ordinary memory)
-    const bool bases_pinned = total == 0 || is_pinned(bases);
+    const bool bases_pinned = packed || total == 0 || is_pinned(bases);
     const bool offs_pinned = is_pinned(offsets);
     const bool out_pinned = n_reads == 0 || is_pinned(counts);
     rc = slot_reserve(s, bases_pinned ? 0 : total, n_reads, !bases_pinned || !offs_pinned, !out_pinned);
     if (rc) return rc;
-    rc = slot_reserve_device(s, total, n_reads);
+    rc = slot_reserve_device(s, packed ? 0 : total, n_reads);
     if (rc) return rc;
+    if (packed) {
+        rc = slot_reserve_packed(s, n_chunks, n_exc);
+        if (rc) return rc;
+    }
     s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
     if (n_reads && total) {
-        const uint8_t *src_b = bases;
         const uint64_t *src_o = offsets;
-        if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
         if (!offs_pinned) { memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t)); src_o = s.h_offsets; }
         // side stream: H2D of this batch overlaps the previous batch's kernel
-        HIP_TRY(hipMemcpyAsync(s.d_bases, src_b, total, hipMemcpyHostToDevice, c->copy));
+        if (packed) {
+            HIP_TRY(hipMemcpyAsync(s.d_codes, codes, n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
+            HIP_TRY(hipMemsetAsync(s.d_bad, 0, n_chunks * sizeof(uint16_t), c->copy));
+            if (n_exc) {
+                HIP_TRY(hipMemcpyAsync(s.d_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
+                HIP_TRY(hipMemcpyAsync(s.d_exc_mask, exc_mask, n_exc * sizeof(uint16_t), hipMemcpyHostToDevice, c->copy));
+                HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, c->copy));
+            }
+        } else {
+            const uint8_t *src_b = bases;
+            if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
+            HIP_TRY(hipMemcpyAsync(s.d_bases, src_b, total, hipMemcpyHostToDevice, c->copy));
+        }
         HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(s.copied, c->copy));
         HIP_TRY(hipStreamWaitEvent(c->compute, s.copied, 0));
-        rc = launch_probe_timed(c, s.d_bases, s.d_offsets, n_reads, total, s.d_counts);
+        rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? s.d_codes : nullptr,
+                                packed ? s.d_bad : nullptr);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
                                hipMemcpyDeviceToHost, c->compute));
@@ -889,6 +1008,26 @@ extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const 
     *ticket = tk;
     return TBK_OK;
 }
+
+extern "C" int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                 int32_t *counts, uint64_t *ticket) {
+    return submit_host(c, bases, nullptr, nullptr, nullptr, 0, offsets, n_reads, counts, ticket);
+}
+
+extern "C" int tbk_stream_submit_packed(tbk_classifier *c, const uint32_t *codes, const uint32_t *exc_chunk, const uint16_t *exc_mask,
+                                        uint64_t n_exc, const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket) {
+    if (!codes && offsets && n_reads && offsets[n_reads]) return fail(TBK_ERR_INVALID, "codes is NULL");
+    static const uint32_t none = 0;
+    return submit_host(c, nullptr, codes ? codes : &none, exc_chunk, exc_mask, n_exc, offsets, n_reads, counts, ticket);
+}
+
+extern "C" int tbk_classifier_set_transfer(tbk_classifier *c, int packed) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    c->packed_h2d = packed != 0;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_transfer(const tbk_classifier *c) { return c ? c->packed_h2d : -1; }
 
 extern "C" int tbk_stream_wait(tbk_classifier *c, uint64_t ticket) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");

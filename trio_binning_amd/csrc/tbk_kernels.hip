@@ -161,6 +161,11 @@ __device__ unsigned long long tbk_dbg[8];
 #endif
 
 struct ProbeArgs {
+    // the read stream: ASCII bytes, or (codes != nullptr) already packed 16 bases to a word with a
+    // dense 16-bit not-ACGT mask per chunk (the packed transfer format, tbk_pack.cpp)
+    const uint32_t *codes;
+    const uint16_t *bad16;
+    uint64_t n_chunks;
     const uint8_t *bases;
     const uint64_t *offsets;  // n_reads + 1
     uint64_t n_reads;
@@ -647,9 +652,16 @@ tbk_probe_kernel(const ProbeArgs p) {
 
     for (uint64_t pass = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; pass < p.n_passes; pass += passes_per_iter) {
         const uint64_t P0 = pass * TBK_PASS;
-        stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
-        stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
-        if (lane < 2) stage[wave][128 + lane] = load_chunk(p.bases, P0 + (uint64_t)(128 + lane) * 16, p.total);
+        if (p.codes != nullptr) {  // packed input (wave-uniform): the chunk words are there already
+            const uint64_t c0 = P0 / 16 + lane;
+            stage[wave][lane] = load_packed_chunk(p.codes, p.bad16, c0, p.n_chunks);
+            stage[wave][64 + lane] = load_packed_chunk(p.codes, p.bad16, c0 + 64, p.n_chunks);
+            if (lane < 2) stage[wave][128 + lane] = load_packed_chunk(p.codes, p.bad16, c0 + 128, p.n_chunks);
+        } else {
+            stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
+            stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
+            if (lane < 2) stage[wave][128 + lane] = load_chunk(p.bases, P0 + (uint64_t)(128 + lane) * 16, p.total);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
@@ -693,11 +705,28 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads,
-                                       uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_pass_read,
+// Scatter the packed format's exceptions into the dense per-chunk mask array (zeroed by the caller).
+__global__ void __launch_bounds__(256)
+tbk_scatter_bad_kernel(const uint32_t *__restrict__ exc_chunk, const uint16_t *__restrict__ exc_mask, uint64_t n,
+                       uint16_t *__restrict__ bad16) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bad16[exc_chunk[i]] = exc_mask[i];
+}
+
+extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *d_exc_chunk, const uint16_t *d_exc_mask, uint64_t n, uint16_t *d_bad16,
+                                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbk_scatter_bad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_exc_chunk, d_exc_mask, n, d_bad16);
+    return hipGetLastError();
+}
+
+// d_codes == nullptr: the read stream is d_bases (ASCII); else it is (d_codes, d_bad16) and d_bases is not read.
+extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
+                                       uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_pass_read,
                                        int max_blocks, hipStream_t stream) {
     if (total == 0 || n_reads == 0) return hipSuccess;
     ProbeArgs p;
+    p.codes = d_codes; p.bad16 = d_bad16; p.n_chunks = (total + 15) / 16;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
     p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_pass_read;
