@@ -403,3 +403,65 @@ def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
             kmers.parse_kmer_list(str(p))
     with pytest.raises(IOError):
         kmers.parse_kmer_list(str(tmp_path / "missing.txt"))
+
+
+def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monkeypatch):
+    """Plain FASTQ is read by the chunk-parallel scan while its records are regular; the sequential
+    state machine (TBK_FASTQ_SCAN=0) is the yardstick.  A file big enough for several pieces per
+    window, several batch limits, and files where a record stops being regular somewhere in the
+    middle (CRLF, wrapped sequence, '>' record, blank line, short or long quality, '+' or '@' first in
+    a sequence line, no final newline): the scan must hand over at that record, not a byte early or late."""
+    rng = random.Random(77)
+
+    def rec(i, lo=200, hi=9000, qual=None):
+        n = rng.randint(lo, hi)
+        s = "".join(rng.choice("ACGTN") for _ in range(n))
+        q = qual if qual is not None else "".join(rng.choice("!#5?@IJ+>") for _ in range(n))
+        return "@r%d extra words %d\n%s\n+%s\n%s\n" % (i, i, s, "" if i % 3 else "r%d" % i, q)
+
+    def both(path, *limits):
+        monkeypatch.setenv("TBK_FASTQ_SCAN", "0")
+        want = _native_records(str(path), *limits)
+        monkeypatch.setenv("TBK_FASTQ_SCAN", "1")
+        assert _native_records(str(path), *limits) == want, (str(path), limits)
+        return want
+
+    monkeypatch.setenv("TBK_HOST_THREADS", "6")   # read once per process; harmless if another test got there first
+    big = "".join(rec(i) for i in range(9000))     # ~80 MB: windows of several 4 MB pieces
+    p = tmp_path / "big.fastq"
+    p.write_text(big)
+    recs = both(p)
+    assert len(recs) == 9000 and recs[0][0] == "r0" and recs[-1][0] == "r8999"
+    for limits in ((3_000_000, 0), (0, 1000), (10_000_000, 777), (1, 0)):
+        assert both(p, *limits) == recs
+    # zero-length reads, '@' and '+' leading quality lines, a header that is just '@'
+    odd = "@\n\n+\n\n" + "@a b\nACGT\n+\n@@@@\n" + "@c\nAC\n+c\n++\n" + "".join(rec(i, 1, 50) for i in range(2000))
+    q = tmp_path / "odd.fastq"
+    q.write_text(odd)
+    assert len(both(q)) == 2003 and both(q, 0, 1) == both(q)
+    # irregular records in the middle: everything before them by the scan, everything after by the machine
+    head = "".join(rec(i, 50, 4000) for i in range(3000))
+    tail = "".join(rec(5000 + i, 50, 4000) for i in range(500))
+    breakers = {
+        "crlf": "@x\r\nACGT\r\n+\r\nIIII\r\n",
+        "cr_in_seq": "@x\nAC\rGT\n+\nIIIII\n",
+        "wrapped": "@x\nACGT\nACGT\n+\nIIII\nIIII\n",
+        "fasta": ">x\nACGTACGT\n",
+        "blank": "\n",
+        "short_qual": "@x\nACGTACGT\n+\nIII\n",
+        "long_qual": "@x\nACGT\n+\nIIIIIIII\n",
+        "plus_in_seq": "@x\n+ACGT\n+\nIIIII\n",
+        "at_in_seq": "@x\n@ACGT\n+\nIIIII\n",
+        "junk": "hello world\n",
+    }
+    for name, mid in breakers.items():
+        f = tmp_path / (name + ".fastq")
+        f.write_text(head + mid + tail)
+        got = both(f)
+        assert len(got) >= 3000 and got[:3000] == [[x[0], x[1], x[2]] for x in both(f)[:3000]], name
+        both(f, 500_000, 0)
+    for name, text in (("no_final_newline", head + "@z\nACGT\n+\nIIII"), ("truncated", head + "@z\nACGTACGT\n+\nII"), ("only_header", head + "@z")):
+        f = tmp_path / (name + ".fastq")
+        f.write_text(text)
+        both(f)
+        both(f, 0, 64)

@@ -19,6 +19,7 @@
 #include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <immintrin.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -520,8 +521,81 @@ struct tbk_fastx_batch {
 // =======================================================================================
 // reader: the record state machine of seq.py:45-83
 // =======================================================================================
+// ---- chunk-parallel scan of regular 4-line FASTQ ------------------------------------------------
+// Plain (uncompressed) FASTQ whose records are "@header / sequence / +... / quality of the same
+// length", every line ended by a single '\n': what sequencers and basecallers write.  For such a
+// record the state machine below has no choices to make, so records can be found by several threads
+// at once and copied into the batch by several threads at once.  The file is mapped; a call takes a
+// window of it, cuts the window into one piece per host thread, lets every thread but the first
+// guess a record start in its piece, index the records that begin in the piece (checking each one
+// for regularity) and report where the last one ended.  The guesses are then checked, not trusted:
+// piece t+1 is accepted only if it began exactly where piece t ended, and piece 0 begins where the
+// previous call stopped, in the state machine's SEEK state - so by induction the accepted records are
+// exactly those the sequential machine would have produced.  The first record that is not regular
+// (CR anywhere, a multi-line sequence, a quality line of another length, a blank line, '>' records,
+// a last line without newline ...) ends this mode for good: the sequential machine takes over at
+// that record's first byte.
+struct FastqRec { uint64_t head, seq, plus, qual, end; uint32_t name_len; };  // line starts; `end` = start of the next record
+
+struct RegularScan {
+    const uint8_t *map = nullptr;
+    size_t size = 0, pos = 0;   // pos: a record starts here (or pos == size)
+    bool active = false;
+    double bytes_per_base = 2.2;  // estimate used to size a call's window
+};
+
+// first '\n' or '\r' at or after p (or end)
+__attribute__((target("avx2"))) static const uint8_t *find_eol_avx2(const uint8_t *p, const uint8_t *end) {
+    const __m256i nl = _mm256_set1_epi8('\n'), cr = _mm256_set1_epi8('\r');
+    while (p + 32 <= end) {
+        const __m256i v = _mm256_loadu_si256((const __m256i *)p);
+        const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_or_si256(_mm256_cmpeq_epi8(v, nl), _mm256_cmpeq_epi8(v, cr)));
+        if (m) return p + __builtin_ctz(m);
+        p += 32;
+    }
+    while (p < end && *p != '\n' && *p != '\r') p++;
+    return p;
+}
+static const uint8_t *find_eol_scalar(const uint8_t *p, const uint8_t *end) {
+    while (p < end && *p != '\n' && *p != '\r') p++;
+    return p;
+}
+static inline const uint8_t *find_eol(const uint8_t *p, const uint8_t *end) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    return avx2 ? find_eol_avx2(p, end) : find_eol_scalar(p, end);
+}
+
+// The record starting at `at`, if it is regular and complete: fills rec and returns true.
+static bool regular_record(const uint8_t *d, size_t size, size_t at, FastqRec &rec) {
+    const uint8_t *end = d + size;
+    if (at >= size || d[at] != '@') return false;
+    const uint8_t *e0 = find_eol(d + at, end);
+    if (e0 == end || *e0 != '\n') return false;
+    const uint8_t *s = e0 + 1;
+    if (s < end && (*s == '@' || *s == '+' || *s == '>')) return false;  // would be taken for a header or the separator
+    const uint8_t *e1 = find_eol(s, end);
+    if (e1 == end || *e1 != '\n') return false;
+    const uint8_t *pl = e1 + 1;
+    if (pl >= end || *pl != '+') return false;
+    const uint8_t *e2 = find_eol(pl, end);
+    if (e2 == end || *e2 != '\n') return false;
+    const uint8_t *q = e2 + 1;
+    const size_t len = (size_t)(e1 - s);
+    if ((size_t)(end - q) < len + 1 || q[len] != '\n') return false;   // quality: same length, then newline
+    if (find_eol(q, q + len) != q + len) return false;                  // no line end inside it
+    rec.head = at; rec.seq = (uint64_t)(s - d); rec.plus = (uint64_t)(pl - d); rec.qual = (uint64_t)(q - d);
+    rec.end = rec.qual + len + 1;
+    // name = header without '@', up to the first space (seq.py:61)
+    const uint8_t *name = d + at + 1;
+    const size_t hl = (size_t)(e0 - name);
+    const uint8_t *sp = (const uint8_t *)memchr(name, ' ', hl);
+    rec.name_len = (uint32_t)(sp ? (size_t)(sp - name) : hl);
+    return true;
+}
+
 struct tbk_fastx_reader {
     LineSource src;
+    RegularScan scan;
     enum { SEEK, SEQ, QUAL, DONE } state = SEEK;
     std::string pending_name;   // header already consumed for the record whose sequence comes next
     bool have_pending = false;
@@ -549,12 +623,24 @@ extern "C" int tbk_fastx_open(const char *path, tbk_fastx_reader **out) {
         delete r;
         return ffail(TBK_ERR_IO, "%s", e.c_str());
     }
+    // plain FASTQ: records are found and copied by several threads while they stay regular
+    const char *scan_env = getenv("TBK_FASTQ_SCAN");
+    struct stat st;
+    if (!gz && !(scan_env && *scan_env == '0') && fstat(r->src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, r->src.fd, 0);
+        if (m != MAP_FAILED) {
+            r->scan.map = (const uint8_t *)m;
+            r->scan.size = (size_t)st.st_size;
+            r->scan.active = r->scan.map[0] == '@';
+        }
+    }
     *out = r;
     return TBK_OK;
 }
 
 extern "C" void tbk_fastx_close(tbk_fastx_reader *r) {
     if (!r) return;
+    if (r->scan.map) munmap((void *)r->scan.map, r->scan.size);
     r->src.close_all();
     delete r;
 }
@@ -567,12 +653,164 @@ extern "C" int tbk_fastx_batch_create(tbk_fastx_batch **out) {
 
 extern "C" void tbk_fastx_batch_destroy(tbk_fastx_batch *b) { delete b; }
 
+// One batch by the chunk-parallel scan (see RegularScan).  Leaves the batch empty when the record at
+// scan.pos is not regular (the mode is then off and the sequential machine goes on from there) or
+// the file is exhausted.
+static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
+    RegularScan &sc = r->scan;
+    const uint8_t *d = sc.map;
+    if (sc.pos >= sc.size) return TBK_OK;
+    const size_t left = sc.size - sc.pos;
+    size_t want = left;
+    if (max_bases != ~0ull) {
+        const double est = (double)max_bases * sc.bytes_per_base * 1.02 + (double)((size_t)2 << 20);
+        if (est < (double)left) want = (size_t)est;
+    }
+    const size_t piece_min = (size_t)4 << 20;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, tbk_host_threads()), want / piece_min));
+    struct Piece { size_t lo = 0, hi = 0, begin = 0, end = 0; bool synced = false, bad = false; std::vector<FastqRec> recs; };
+    std::vector<Piece> pieces((size_t)nt);
+    for (int t = 0; t < nt; t++) {
+        pieces[(size_t)t].lo = sc.pos + want * (size_t)t / (size_t)nt;
+        pieces[(size_t)t].hi = sc.pos + want * (size_t)(t + 1) / (size_t)nt;
+    }
+    auto work = [&](int t) {
+        Piece &pc = pieces[(size_t)t];
+        size_t at = pc.lo;
+        FastqRec rec, nxt;
+        if (t == 0) {
+            pc.synced = true;
+        } else {
+            // guess: the first line start in the piece where two regular records follow one another
+            const uint8_t *e = find_eol(d + pc.lo, d + sc.size);
+            size_t ls = (size_t)(e - d) + 1;
+            for (int tries = 0; tries < 12 && ls < pc.hi && !pc.synced; tries++) {
+                if (e == d + sc.size || *e != '\n') break;  // a CR: not this mode's business
+                if (regular_record(d, sc.size, ls, rec) && (rec.end == sc.size || regular_record(d, sc.size, rec.end, nxt))) {
+                    at = ls;
+                    pc.synced = true;
+                    break;
+                }
+                e = find_eol(d + ls, d + sc.size);
+                ls = (size_t)(e - d) + 1;
+            }
+            if (!pc.synced) return;
+        }
+        pc.begin = at;
+        pc.recs.reserve((pc.hi - pc.lo) / 4096 + 16);
+        while (at < pc.hi) {
+            if (!regular_record(d, sc.size, at, rec)) { pc.bad = true; break; }
+            pc.recs.push_back(rec);
+            at = (size_t)rec.end;
+        }
+        pc.end = at;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+    }
+    // accept the pieces that chain up: each must begin exactly where the one before it ended
+    int n_ok = 1;
+    while (n_ok < nt && !pieces[(size_t)n_ok - 1].bad && pieces[(size_t)n_ok].synced && pieces[(size_t)n_ok].begin == pieces[(size_t)n_ok - 1].end) n_ok++;
+    // records of this batch: up to and including the one that reaches a limit
+    uint64_t n_reads = 0, n_bases = 0, n_name = 0;
+    int last_piece = 0;
+    size_t last_idx = 0;
+    bool full = false;
+    for (int t = 0; t < n_ok && !full; t++) {
+        const std::vector<FastqRec> &rs = pieces[(size_t)t].recs;
+        for (size_t i = 0; i < rs.size(); i++) {
+            n_reads++;
+            n_bases += rs[i].plus - 1 - rs[i].seq;
+            n_name += rs[i].name_len;
+            last_piece = t; last_idx = i + 1;
+            if (n_reads >= max_reads || n_bases >= max_bases) { full = true; break; }
+        }
+    }
+    if (n_reads == 0) {  // the record at scan.pos is not regular: hand over to the sequential machine
+        sc.active = false;
+        return TBK_OK;
+    }
+    // flat view of the chosen records, then parallel copies into the batch's arrays
+    std::vector<const FastqRec *> chosen;
+    chosen.reserve((size_t)n_reads);
+    for (int t = 0; t <= last_piece; t++) {
+        const std::vector<FastqRec> &rs = pieces[(size_t)t].recs;
+        const size_t upto = t == last_piece ? last_idx : rs.size();
+        for (size_t i = 0; i < upto; i++) chosen.push_back(&rs[i]);
+    }
+    if (!b->reserve_bases((size_t)n_bases + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
+    b->base_off.resize((size_t)n_reads + 1);
+    b->name_off.resize((size_t)n_reads + 1);
+    b->qual_off.resize((size_t)n_reads + 1);
+    b->has_qual.assign((size_t)n_reads, 1);
+    b->names.resize((size_t)n_name);
+    b->quals.resize((size_t)n_bases);
+    uint64_t ob = 0, on = 0;
+    for (size_t i = 0; i < chosen.size(); i++) {
+        b->base_off[i] = ob; b->qual_off[i] = ob; b->name_off[i] = on;
+        ob += chosen[i]->plus - 1 - chosen[i]->seq;
+        on += chosen[i]->name_len;
+    }
+    b->base_off[chosen.size()] = ob; b->qual_off[chosen.size()] = ob; b->name_off[chosen.size()] = on;
+    b->n_bases = ob;
+    {
+        const int ct = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, tbk_host_threads()), (size_t)n_bases / ((size_t)8 << 20)));
+        auto copy = [&](int t) {
+            // records [first, last) of thread t: split where the bases split evenly (reads differ in length; empty ones have none)
+            auto cut = [&](int u) -> size_t {
+                if (u <= 0) return 0;
+                if (u >= ct) return chosen.size();
+                const uint64_t at_b = n_bases * (uint64_t)u / (uint64_t)ct;
+                return (size_t)(std::lower_bound(b->base_off.begin(), b->base_off.begin() + (ptrdiff_t)chosen.size(), at_b) - b->base_off.begin());
+            };
+            const size_t last = cut(t + 1);
+            for (size_t i = cut(t); i < last; i++) {
+                const FastqRec &rc = *chosen[i];
+                const size_t len = (size_t)(rc.plus - 1 - rc.seq);
+                memcpy(b->bases + b->base_off[i], d + rc.seq, len);
+                memcpy(b->quals.data() + b->qual_off[i], d + rc.qual, len);
+                memcpy(b->names.data() + b->name_off[i], d + rc.head + 1, rc.name_len);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < ct; t++) pool.emplace_back(copy, t);
+        copy(0);
+        for (std::thread &th : pool) th.join();
+    }
+    const size_t new_pos = (size_t)chosen.back()->end;
+    if (n_bases) sc.bytes_per_base = std::max(1.5, (double)(new_pos - sc.pos) / (double)n_bases);
+    sc.pos = new_pos;
+    // everything that chained up was taken and the last piece stopped at an irregular record: leave the mode there
+    if (!full && pieces[(size_t)n_ok - 1].bad && last_piece == n_ok - 1 && last_idx == pieces[(size_t)n_ok - 1].recs.size()) sc.active = false;
+    return TBK_OK;
+}
+
 extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
     if (!r || !b) return ffail(TBK_ERR_INVALID, "NULL argument");
     b->clear();
     if (r->state == tbk_fastx_reader::DONE) return TBK_OK;
     if (max_reads == 0) max_reads = ~0ull;
     if (max_bases == 0) max_bases = ~0ull;
+    if (r->scan.map && (r->scan.active || r->scan.pos > 0)) {
+        if (r->scan.active) {
+            const int rc = regular_next(r, b, max_bases, max_reads);
+            if (rc) return rc;
+            if (b->n_reads() > 0) return TBK_OK;
+            if (r->scan.pos >= r->scan.size) { r->state = tbk_fastx_reader::DONE; return TBK_OK; }
+        }
+        // the scan has stopped in front of a record that is not regular: the sequential machine reads
+        // on from that byte, in its SEEK state
+        if (!r->scan.active && r->scan.pos != (size_t)-1) {
+            if (lseek(r->src.fd, (off_t)r->scan.pos, SEEK_SET) < 0) return ffail(TBK_ERR_IO, "lseek: %s", strerror(errno));
+            r->src.pos = r->src.end = 0;
+            r->src.text_eof = false; r->src.skip_lf = false;
+            r->state = tbk_fastx_reader::SEEK;
+            r->scan.pos = (size_t)-1;  // handed over
+        }
+    }
     // size the pinned sequence buffer once, from the batch limit, instead of growing it
     if (max_bases != ~0ull && max_bases <= ((uint64_t)1 << 34) && b->bases_cap < max_bases)
         if (!b->reserve_bases((size_t)max_bases + ((size_t)max_bases >> 3) + (1 << 20)))
