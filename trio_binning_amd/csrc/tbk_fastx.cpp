@@ -770,9 +770,11 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
             for (size_t i = cut(t); i < last; i++) {
                 const FastqRec &rc = *chosen[i];
                 const size_t len = (size_t)(rc.plus - 1 - rc.seq);
-                memcpy(b->bases + b->base_off[i], d + rc.seq, len);
-                memcpy(b->quals.data() + b->qual_off[i], d + rc.qual, len);
-                memcpy(b->names.data() + b->name_off[i], d + rc.head + 1, rc.name_len);
+                if (len) {
+                    memcpy(b->bases + b->base_off[i], d + rc.seq, len);
+                    memcpy(b->quals.data() + b->qual_off[i], d + rc.qual, len);
+                }
+                if (rc.name_len) memcpy(b->names.data() + b->name_off[i], d + rc.head + 1, rc.name_len);
             }
         };
         std::vector<std::thread> pool;
