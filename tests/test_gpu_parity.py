@@ -212,6 +212,7 @@ def test_seeded_fuzz_of_layout_and_input_shapes(gpu, orc, tmp_path, seed, monkey
     monkeypatch.setenv("TBK_MINIMIZER_W", str(int(rng.integers(0, 9))))
     monkeypatch.setenv("TBK_MOD_SAMPLING", str(int(rng.integers(0, 2))))
     monkeypatch.setenv("TBK_TABLE_LOAD", str(rng.choice([0.04, 0.2, 0.6, 0.9])))
+    monkeypatch.setenv("TBK_GUESTS", str(seed % 3 and 1))     # a third of the seeds without guests in the other half
     n_a, n_b = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
 
     def rand_kmer():
@@ -419,10 +420,14 @@ def test_crowded_tables_walk_path(gpu, orc, tmp_path, k, monkeypatch):
     want = orc.count_batch(bases, offs, oa, ob)
     for load in ("0.9", "0.5"):
         monkeypatch.setenv("TBK_TABLE_LOAD", load)
-        with kmers.Classifier(a, b) as cls:
-            assert cls.stats()["n_buckets"] <= 3000 / 8 / float(load) + 1
-            got = cls.classify_batch(bases, offs)
-        assert np.array_equal(got, want), (k, load, np.nonzero((got != want).any(axis=1))[0][:10])
+        # with and without guests: a key whose half is full goes, tagged, into the other list's half of its
+        # line before it leaves the line (k < 32; hapB's half has room here), or straight on along its sequence
+        for guests in ("1", "0"):
+            monkeypatch.setenv("TBK_GUESTS", guests)
+            with kmers.Classifier(a, b) as cls:
+                assert cls.stats()["n_buckets"] <= 3000 / 8 / float(load) + 1
+                got = cls.classify_batch(bases, offs)
+            assert np.array_equal(got, want), (k, load, guests, np.nonzero((got != want).any(axis=1))[0][:10])
     assert want[:, 0].sum() > 300 and want[:, 1].sum() > 100
 
 

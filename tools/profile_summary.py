@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condense a tools/gpu_profile.sh run (gpurun_out/) into the small files kept under profiles/rNN_*:
+kernel_stats.csv (rocprofv3 --stats), pmc_summary_<lists>.json (per-launch means of every PMC pass for
+the probe kernel) and pmc_traffic[_haplotypes].json (HBM bytes per window, which bench.py scales to
+its own launch size for `roofline.traffic`).
+
+HBM bytes from the counters as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950:
+FETCH_SIZE is reported in KiB and tallies the L2's 128-byte memory-side requests at 64 bytes, so
+bytes = FETCH_SIZE x 1024 x 2; cross-check: TCC_MISS_sum x 128 B (separate pass).  WRITE_SIZE x 1024."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+
+
+def probe_means(pattern, kernel="probe_kernel"):
+    agg, meta = collections.defaultdict(list), {}
+    for f in sorted(glob.glob(os.path.join(out_dir, pattern, "*", "*_counter_collection.csv"))):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {"VGPR_Count": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
+                        "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80]}
+    return {k: sum(v) / len(v) for k, v in agg.items()}, meta
+
+
+for lists in ("uniform", "haplotypes"):
+    summary = {}
+    for d in sorted(glob.glob(os.path.join(out_dir, f"pmc_{lists}_*"))):
+        if not os.path.isdir(d):
+            continue
+        means, meta = probe_means(os.path.basename(d))
+        summary.update({k: round(v) for k, v in means.items()})
+        summary.update({k: v for k, v in meta.items() if v})
+    if not summary:
+        continue
+    bench = None
+    bfile = os.path.join(out_dir, "bench_default.json" if lists == "uniform" else "bench_haplotypes.json")
+    try:
+        bench = json.loads(open(bfile).read())
+    except Exception:
+        pass
+    # the PMC passes run bench.py with its default batch: windows per launch from the bench line of the same shape
+    if bench and "FETCH_SIZE" in summary:
+        windows = bench["roofline"]["windows_per_launch"]
+        hbm = summary["FETCH_SIZE"] * 1024 * 2
+        summary["hbm_bytes_per_launch_from_FETCH_SIZE"] = hbm
+        summary["hbm_bytes_per_launch_from_TCC_MISS"] = summary.get("TCC_MISS_sum", 0) * 128
+        summary["windows_per_launch"] = windows
+        summary["lines_per_window"] = round(summary.get("TCC_MISS_sum", 0) / windows, 4)
+        cfg = bench["config"]
+        traffic = {
+            "note": "HBM bytes of one tbk_probe_kernel launch, from rocprofv3 PMC passes run separately from the timed bench "
+                    "(tools/gpu_profile.sh): FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM), "
+                    "cross-checked by TCC_MISS_sum x 128 B; divided by the launch's window starts so that bench.py can scale it to its own launch size.",
+            "read_len": cfg["read_len"], "kmers_per_list": cfg["kmers_per_list"], "k": cfg["k"], "bucket_select": cfg["bucket_select"],
+            "table_load": cfg["table_load"], "lists": lists, "windows_per_launch": windows,
+            "hbm_bytes_per_launch": hbm, "hbm_bytes_per_window": hbm / windows,
+            "fetch_size_kib_raw": summary["FETCH_SIZE"], "write_size_kib_raw": summary.get("WRITE_SIZE"),
+            "tcc_miss": summary.get("TCC_MISS_sum"), "tcc_hit": summary.get("TCC_HIT_sum"),
+        }
+        json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json" if lists == "uniform" else "pmc_traffic_haplotypes.json"), "w"), indent=1)
+    json.dump(summary, open(os.path.join(out_dir, f"pmc_summary_{lists}.json"), "w"), indent=1)
+    print(lists, json.dumps(summary))
+
+for name, dst in (("prof_trace", "kernel_stats.csv"), ("prof_trace_count", "count_kernel_stats.csv")):
+    hits = glob.glob(os.path.join(out_dir, name, "*", "*_kernel_stats.csv"))
+    if hits:
+        shutil.copy(hits[0], os.path.join(out_dir, dst))
+        print(dst, open(hits[0]).read()[:900])

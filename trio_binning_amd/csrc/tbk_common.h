@@ -18,6 +18,13 @@
 //   half (slot 6 > slot 7) or not (slot 6 < slot 7; a half with a free slot has slot 7 =
 //   TBK_EMPTY, the largest value): a lookup that misses stops at the first half nothing went
 //   past, and the probe kernel learns that from one compare of two slots it already holds.
+//   Before a key leaves its LINE it tries the other list's half of the same line (k < 32): it is
+//   stored there with TBK_GUEST set, and only if that half is full too does it go on along its probe
+//   sequence.  The order of slots 4 and 5 of a full half that keys went past says which: slot 4 >
+//   slot 5 = "some key of this list left the line".  A lookup holds the whole line in registers, so
+//   a guest costs it two more compares where a key that left the line costs another random line;
+//   lists shaped like real data (the k overlapping k-mers around one variant share ~6 minimizers,
+//   in both lists at once) fill single halves long before they fill lines.
 //   A standalone list (tbk_table) is just its packed keys in HBM; a single-table form of
 //   the same layout (64-byte lines, 8 slots) is built on demand for tbk_table_contains.
 //   The reference's layout (8-byte slots + a parallel "full" byte array at load 0.75,
@@ -45,6 +52,12 @@
 #define TBK_NOKEY 0xFFFFFFFFFFFFFFFEull
 #define TBK_SLOTS_PER_BUCKET 8
 #define TBK_BUCKET_BYTES 64
+// A key of one list stored in a free slot of the OTHER list's half of its line (its own half was
+// full) carries this tag.  Keys of k < 32 leave bit 63 free (they are below 4^31 = 2^62); a tagged
+// key never equals a lookup key, TBK_EMPTY or TBK_NOKEY, so the raw compares of the probe kernel's
+// fast path do not see guests at all: only a lookup that found its own half left by keys looks for
+// them (in slots it already holds in registers).  k = 32 has no free bit: no guests there.
+#define TBK_GUEST 0x8000000000000000ull
 
 // ---- bucket selection --------------------------------------------------------------------
 // Not the reference's hash_function (c/kmers.c:98-103): hash values are not observable, so
@@ -288,6 +301,7 @@ struct TbkTableView {
     uint32_t stride;  // slots per bucket line (8 or 16)
     uint32_t half;    // first slot of this list inside the line (0 or 8)
     TbkMz mz;         // bucket selection
+    uint32_t guests;  // paired table, k < 32: a full half's surplus may sit, tagged, in the other half of the line
 };
 
 // The probe sequence of a key: its home bucket (chosen by the minimizer, shared with its
@@ -308,6 +322,7 @@ struct TbkPairView {
     const uint64_t *slots;  // n_buckets * 16
     uint32_t n_buckets;
     TbkMz mz;               // bucket selection
+    uint32_t guests;        // see TbkTableView
 };
 
 // ---- synthetic key sequence (bench inputs) ---------------------------------

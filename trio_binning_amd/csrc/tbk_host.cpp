@@ -28,8 +28,8 @@
 #include "tbk_common.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
-extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, TbkTableView,
+extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, const uint32_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -130,7 +130,7 @@ struct tbk_table {
     uint32_t n_buckets = 0;
     uint64_t distinct = 0;
     bool hashed = false;
-    TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0, TbkMz{0, 0, 0, 0}}; }
+    TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0, TbkMz{0, 0, 0, 0}, 0}; }
 };
 
 static constexpr int RING = 3;
@@ -163,7 +163,8 @@ struct tbk_classifier {
     uint64_t distinct_a = 0, distinct_b = 0;
     uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
-    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz}; }
+    uint32_t guests = 0;         // k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
     uint64_t next_ticket = 1;
@@ -265,7 +266,8 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
 // stride 16, half 0 / 8).  The slots must already be filled with TBK_EMPTY.
 static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz, uint32_t *d_overflowed,
                        const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out,
-                       TbkTableView skip = TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}}, uint64_t *skipped_out = nullptr) {
+                       TbkTableView skip = TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, uint64_t *skipped_out = nullptr,
+                       uint32_t *d_left_line = nullptr, uint32_t guests = 0) {
     // counters: [0] distinct keys stored, [1] keys dropped because `skip` holds them
     unsigned long long *d_cnt = nullptr, cnt[2] = {0, 0};
     int *d_failed = nullptr;
@@ -273,7 +275,7 @@ static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, u
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
     if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof cnt);
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
-    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_overflowed, skip, d_cnt, d_cnt + 1, d_failed, nullptr);
+    if (e == hipSuccess) e = tbk_launch_insert(d_slots, n_buckets, stride, half, mz, d_keys, n, d_overflowed, d_left_line, guests, skip, d_cnt, d_cnt + 1, d_failed, nullptr);
     int failed = 0;
     if (e == hipSuccess) e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
@@ -296,8 +298,8 @@ static int overflow_bitmap(uint64_t n_halves, uint32_t **out) {
     return TBK_OK;
 }
 
-static int order_table(uint64_t *d_slots, uint64_t n_halves, const uint32_t *d_overflowed) {
-    hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, nullptr);
+static int order_table(uint64_t *d_slots, uint64_t n_halves, const uint32_t *d_overflowed, const uint32_t *d_left_line = nullptr) {
+    hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, d_left_line, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "table order pass: %s", hipGetErrorString(e));
     return TBK_OK;
@@ -590,15 +592,22 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // "a key went past this half" into the order of the half's last two slots, which is what
     // lookups (hapB's inserts included) read.
     uint32_t *d_over = nullptr;
+    // k < 32 leaves bit 63 of a key free: a key whose half is full goes, tagged, into the other list's
+    // half of the same line before it leaves the line (TBK_GUESTS=0 turns that off)
+    c->guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? 1u : 0u;
+    uint32_t *d_left = nullptr;
     rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
+    if (!rc && c->guests) rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_left);
     if (!rc) {
-        rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
+        rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
+                         TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
         if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
-                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz}, &c->shared);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over);
-        (void)hipFree(d_over);
+                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
     }
+    if (d_over) (void)hipFree(d_over);
+    if (d_left) (void)hipFree(d_left);
     if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
     rc = classifier_streams(c);
     if (rc) { tbk_classifier_destroy(c); return rc; }
@@ -621,6 +630,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->mz = src->mz;
     c->max_blocks = src->max_blocks;
     c->packed_h2d = src->packed_h2d;
+    c->guests = src->guests;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) {

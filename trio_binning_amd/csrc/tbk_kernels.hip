@@ -27,6 +27,12 @@ __device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t k
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
             if (line[s] == key) return true;
         if (!(line[6] > line[7])) return false;  // no key went past this half
+        if (t.guests) {
+            const uint64_t *other = t.slots + (uint64_t)b * t.stride + (t.half ^ 8u);
+            for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
+                if (other[s] == (key | TBK_GUEST)) return true;
+            if (!(line[4] > line[5])) return false;  // keys went past the half, none left the line
+        }
         b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
     }
     return false;
@@ -39,7 +45,8 @@ __device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t k
 // hapB half of a paired table (16, 0 / 8).
 __global__ void __launch_bounds__(256)
 tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                  const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed, TbkTableView skip,
+                  const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed,
+                  uint32_t *__restrict__ left_line, uint32_t guests, TbkTableView skip,
                   unsigned long long *__restrict__ n_distinct, unsigned long long *__restrict__ n_skipped,
                   int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -75,11 +82,27 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
                 }
                 if (!done) {
                     // this half is full and the key goes past it: remember that (tbk_order_kernel turns
-                    // the note into the order of the half's last two slots), then follow the probe
-                    // sequence: home bucket, second-choice bucket, and linearly on from there
+                    // the note into the order of the half's last two slots)
                     const uint64_t bit = (uint64_t)b * halves + which;
                     atomicOr(&overflowed[bit >> 5], 1u << (bit & 31));
-                    b = tbk_next_bucket(key, mz, n_buckets, b, walked == 0);
+                    if (guests) {
+                        // ... first into a free slot of the other list's half of the same line, tagged: lookups
+                        // hold the whole line, so a guest costs them two compares, not another random line
+                        unsigned long long *other = (unsigned long long *)(slots + (uint64_t)b * stride + (half ^ 8u));
+                        const unsigned long long tagged = key | TBK_GUEST;
+                        for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
+                            unsigned long long cur = __hip_atomic_load(&other[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (cur == tagged) { done = true; break; }
+                            if (cur == TBK_EMPTY) {
+                                unsigned long long old = atomicCAS(&other[s], (unsigned long long)TBK_EMPTY, tagged);
+                                if (old == TBK_EMPTY) { if (c == 0) mine++; done = true; }
+                                else if (old == tagged) { done = true; }
+                            }
+                        }
+                        if (!done) atomicOr(&left_line[bit >> 5], 1u << (bit & 31));  // ... or out of the line (order of slots 4 and 5)
+                    }
+                    // then along the probe sequence: home bucket, second-choice bucket, and linearly on from there
+                    if (!done) b = tbk_next_bucket(key, mz, n_buckets, b, walked == 0);
                 }
             }
             if (!done) atomicExch(failed, 1);
@@ -90,9 +113,11 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
 }
 
 // After all inserts: give every full half the order of its last two slots that says whether a key
-// went past it (slot 6 > slot 7) or not (slot 6 < slot 7).  One thread per half.
+// went past it (slot 6 > slot 7) or not (slot 6 < slot 7), and - tables with guests - the order of
+// slots 4 and 5 that says whether one of those keys left the line (slot 4 > slot 5).  One thread per half.
 __global__ void __launch_bounds__(256)
-tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t *__restrict__ overflowed) {
+tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t *__restrict__ overflowed,
+                 const uint32_t *__restrict__ left_line) {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_halves) return;
     ulonglong2 *last = reinterpret_cast<ulonglong2 *>(slots + h * TBK_SLOTS_PER_BUCKET + 6);
@@ -100,6 +125,12 @@ tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t
     if (v.y == TBK_EMPTY) return;  // not full: nothing went past it, and slot 6 <= slot 7 = EMPTY already says so
     const bool past = (overflowed[h >> 5] >> (h & 31)) & 1u;
     if ((v.x > v.y) != past) *last = make_ulonglong2(v.y, v.x);
+    if (left_line != nullptr) {
+        ulonglong2 *mid = reinterpret_cast<ulonglong2 *>(slots + h * TBK_SLOTS_PER_BUCKET + 4);
+        const ulonglong2 m = *mid;
+        const bool left = (left_line[h >> 5] >> (h & 31)) & 1u;
+        if ((m.x > m.y) != left) *mid = make_ulonglong2(m.y, m.x);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -225,15 +256,30 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
             // 32 bytes at a time: this rare path must not set the kernel's register high-water mark
             const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
             bool hit = false;
-            ulonglong2 v3 = make_ulonglong2(0, 0);
+            ulonglong2 v2 = make_ulonglong2(0, 0), v3 = make_ulonglong2(0, 0);
 #pragma unroll 1
             for (int i = 0; i < 4; i += 2) {
-                const ulonglong2 v2 = h[i];
+                v2 = h[i];
                 v3 = h[i + 1];
                 hit = hit || v2.x == key || v2.y == key || v3.x == key || v3.y == key;
             }
             found = found || hit;
-            pend = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
+            bool past = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
+            if (past && t.guests) {
+                // ... into the other half of this line (tagged), or - slot 4 > slot 5 - out of the line
+                const bool left = v2.x > v2.y;
+                const ulonglong2 *g = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + (half ^ 8u));
+                const uint64_t tagged = key | TBK_GUEST;
+                bool guest = false;
+#pragma unroll 1
+                for (int i = 0; i < 4; i++) {
+                    const ulonglong2 w = g[i];
+                    guest = guest || w.x == tagged || w.y == tagged;
+                }
+                found = found || guest;
+                past = !guest && left;
+            }
+            pend = past;
         }
         first = false;
     }
@@ -532,6 +578,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             any_b |= hit_b[s];
         }
         TBK_COUNT(0, 1);
+        uint64_t guests_a = 0, guests_b = 0;  // windows whose key was found as a guest in the other half (bit of the owning lane)
         if (full_any != 0) {
             TBK_COUNT(1, 1);
             // Careful path: per-window (= per-quad) resolution, everything brought to the quad's
@@ -543,8 +590,23 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
                 TBK_COUNT(2, 1);
                 const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
-                const uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s]);  // a hit in either half is final
-                const uint64_t walk_a = miss & fa, walk_b = miss & fb;
+                uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s]);  // a hit in either half is final
+                uint64_t walk_a = miss & fa, walk_b = miss & fb;
+                if (p.t.guests && (walk_a | walk_b) != 0) {
+                    // The keys that went past a half went, tagged, into free slots of the line's other half
+                    // first (the quad holds them already), and only then out of the line: quad lane 2 holds
+                    // slots 4 and 5 of each half, whose order says whether any did.
+                    const uint64_t tagged = kk[s] | TBK_GUEST;
+                    const uint64_t guest_a = quad_any(ballot(vb[s].x == tagged) | ballot(vb[s].y == tagged)) & walk_a;  // hapA's guests sit in hapB's half
+                    const uint64_t guest_b = quad_any(ballot(va[s].x == tagged) | ballot(va[s].y == tagged)) & walk_b & ~guest_a;
+                    const uint64_t left_a = (ballot(va[s].x > va[s].y) & 0x4444444444444444ull) >> 2;
+                    const uint64_t left_b = (ballot(vb[s].x > vb[s].y) & 0x4444444444444444ull) >> 2;
+                    guests_a |= guest_a << s;  // brought to the bit of the lane that owns the window (quad lane s)
+                    guests_b |= guest_b << s;
+                    miss &= ~(guest_a | guest_b);
+                    walk_a = miss & fa & left_a;
+                    walk_b = miss & fb & left_b;
+                }
                 const uint64_t queued = walk_a | walk_b;
                 if (queued) {
                     const uint64_t me = 1ull << lane;
@@ -572,12 +634,14 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                     acc_a += (uint32_t)__popcll(hit_a[s]);
                     acc_b += (uint32_t)__popcll(hit_b[s]);
                 }
+                acc_a += (uint32_t)__popcll(guests_a);
+                acc_b += (uint32_t)__popcll(guests_b);
             } else {
                 // Bring each window's verdict to the bit of the lane that owns it (quad q's sub-step s
                 // window belongs to lane 4q + s) and let every lane count its own windows: its 32
                 // windows nearly always lie in one read, so the hits travel to the tallies once per
                 // read and lane, not once per hit.
-                uint64_t wa = 0, wb = 0;
+                uint64_t wa = guests_a, wb = guests_b;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     wa |= quad_any(hit_a[s]) << s;
@@ -679,21 +743,22 @@ tbk_probe_kernel(const ProbeArgs p) {
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
-                                        const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, TbkTableView skip,
+                                        const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, uint32_t *d_left_line, uint32_t guests, TbkTableView skip,
                                         unsigned long long *d_distinct, unsigned long long *d_skipped, int *d_failed,
                                         hipStream_t stream) {
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
-                       half, mz, d_keys, n, d_overflowed, skip, d_distinct, d_skipped, d_failed);
+                       half, mz, d_keys, n, d_overflowed, d_left_line, guests, skip, d_distinct, d_skipped, d_failed);
     return hipGetLastError();
 }
 
 // n_halves = n_buckets * stride / 8; d_overflowed has one bit per half (bit index = bucket * halves + which)
-extern "C" hipError_t tbk_launch_order(uint64_t *slots, uint64_t n_halves, const uint32_t *d_overflowed, hipStream_t stream) {
+extern "C" hipError_t tbk_launch_order(uint64_t *slots, uint64_t n_halves, const uint32_t *d_overflowed, const uint32_t *d_left_line,
+                                       hipStream_t stream) {
     if (n_halves == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_order_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, d_overflowed);
+    hipLaunchKernelGGL(tbk_order_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, d_overflowed, d_left_line);
     return hipGetLastError();
 }
 
