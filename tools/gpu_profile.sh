@@ -6,11 +6,11 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 R=$GRAFT_REPO_ROOT
-( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/bench_default.json
-( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; tail -1 gpurun_out/bench_haplotypes.log > gpurun_out/bench_haplotypes.json
-( time timeout 600 python bench.py --path count ) > gpurun_out/bench_count.log 2>&1; tail -1 gpurun_out/bench_count.log > gpurun_out/bench_count.json
+( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default.log | tail -1 > gpurun_out/bench_default.json
+( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_haplotypes.log | tail -1 > gpurun_out/bench_haplotypes.json
+( time timeout 600 python bench.py --path count ) > gpurun_out/bench_count.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_count.log | tail -1 > gpurun_out/bench_count.json
 export TBK_SKIP_BUILD=1
-( time timeout 900 python bench.py --scaling strong --strong-reads 3000000 --steps 5 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_strong.log 2>&1; tail -1 gpurun_out/bench_strong.log > gpurun_out/bench_strong.json
+( time timeout 900 python bench.py --scaling strong --strong-reads 3000000 --steps 5 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
 FLAGS="--steps 4 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-streaming"
 cd /tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_*
