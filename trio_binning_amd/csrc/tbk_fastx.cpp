@@ -26,6 +26,7 @@
 #include <atomic>
 #include <cerrno>
 #include <charconv>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -682,7 +683,8 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
             pc.synced = true;
         } else {
             // guess: the first line start in the piece where two regular records follow one another
-            const uint8_t *e = find_eol(d + pc.lo, d + sc.size);
+            // (the piece may begin on a line start itself: then that line is the first candidate)
+            const uint8_t *e = d[pc.lo - 1] == '\n' ? d + pc.lo - 1 : find_eol(d + pc.lo, d + sc.size);
             size_t ls = (size_t)(e - d) + 1;
             for (int tries = 0; tries < 12 && ls < pc.hi && !pc.synced; tries++) {
                 if (e == d + sc.size || *e != '\n') break;  // a CR: not this mode's business
@@ -705,12 +707,15 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
         }
         pc.end = at;
     };
+    static const bool timing = getenv("TBK_SCAN_TIMING") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
     {
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
         work(0);
         for (std::thread &th : pool) th.join();
     }
+    const auto t_b = std::chrono::steady_clock::now();
     // accept the pieces that chain up: each must begin exactly where the one before it ended
     int n_ok = 1;
     while (n_ok < nt && !pieces[(size_t)n_ok - 1].bad && pieces[(size_t)n_ok].synced && pieces[(size_t)n_ok].begin == pieces[(size_t)n_ok - 1].end) n_ok++;
@@ -781,6 +786,14 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
         for (int t = 1; t < ct; t++) pool.emplace_back(copy, t);
         copy(0);
         for (std::thread &th : pool) th.join();
+    }
+    if (timing && n_ok < nt)
+        fprintf(stderr, "tbk-scan chain broke at piece %d: prev end %zu bad %d, synced %d begin %zu (lo %zu hi %zu)\n", n_ok, pieces[(size_t)n_ok - 1].end,
+                (int)pieces[(size_t)n_ok - 1].bad, (int)pieces[(size_t)n_ok].synced, pieces[(size_t)n_ok].begin, pieces[(size_t)n_ok].lo, pieces[(size_t)n_ok].hi);
+    if (timing) {
+        const auto t_c = std::chrono::steady_clock::now();
+        fprintf(stderr, "tbk-scan window %.1f MB, %d pieces (%d chained), %llu reads: index %.1f ms, select+copy %.1f ms\n", (double)want / 1e6, nt, n_ok,
+                (unsigned long long)n_reads, std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_c - t_b).count());
     }
     const size_t new_pos = (size_t)chosen.back()->end;
     if (n_bases) sc.bytes_per_base = std::max(1.5, (double)(new_pos - sc.pos) / (double)n_bases);

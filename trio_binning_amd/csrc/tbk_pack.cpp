@@ -67,19 +67,29 @@ __attribute__((target("avx2"))) void pack_range_avx2(const uint8_t *bases, uint6
     const __m256i lut = _mm256_setr_epi8(0x41, 0x43, 0x47, 0x54, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x41, 0x43, 0x47, 0x54, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     const __m256i w1 = _mm256_set1_epi16(0x0401);      // code(byte 0) + 4 * code(byte 1)
     const __m256i w2 = _mm256_set1_epi32(0x00100001);  // pair 0 + 16 * pair 1
-    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m256i order = _mm256_setr_epi32(0, 4, 1, 5, 2, 6, 3, 7);
     uint64_t c = c_lo;
-    for (; c + 2 <= c_hi; c += 2) {
-        const __m256i v = _mm256_loadu_si256((const __m256i *)(bases + c * 16));
-        const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
-        const uint32_t good = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_shuffle_epi8(lut, code)));
-        const __m256i q = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(code, w1), w2), pick);
-        codes[c] = (uint32_t)_mm256_extract_epi32(q, 0);
-        codes[c + 1] = (uint32_t)_mm256_extract_epi32(q, 4);
-        if (good != 0xFFFFFFFFu) {
-            const uint32_t bad = ~good;
-            if (bad & 0xFFFFu) exc.push_back(Exc{(uint32_t)c, (uint16_t)(bad & 0xFFFFu)});
-            if (bad >> 16) exc.push_back(Exc{(uint32_t)(c + 1), (uint16_t)(bad >> 16)});
+    // 128 bases = 8 chunks per step: four 32-byte loads, one 32-byte store of 8 code words
+    for (; c + 8 <= c_hi; c += 8) {
+        __m256i m[4];
+        uint32_t good[4];
+#pragma GCC unroll 4
+        for (int i = 0; i < 4; i++) {
+            const __m256i v = _mm256_loadu_si256((const __m256i *)(bases + (c + 2 * (uint64_t)i) * 16));
+            const __m256i code = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+            good[i] = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_shuffle_epi8(lut, code)));
+            m[i] = _mm256_madd_epi16(_mm256_maddubs_epi16(code, w1), w2);  // 8 dwords, each the 8 code bits of 4 bases
+        }
+        // dwords -> words -> bytes (the packs work per 128-bit lane: lane 0 collects every load's low chunk,
+        // lane 1 its high chunk), then the chunks' dwords back into stream order
+        const __m256i b = _mm256_packus_epi16(_mm256_packus_epi32(m[0], m[1]), _mm256_packus_epi32(m[2], m[3]));
+        _mm256_storeu_si256((__m256i *)(codes + c), _mm256_permutevar8x32_epi32(b, order));
+        if ((good[0] & good[1] & good[2] & good[3]) != 0xFFFFFFFFu) {
+            for (int i = 0; i < 4; i++) {
+                const uint32_t bad = ~good[i];
+                if (bad & 0xFFFFu) exc.push_back(Exc{(uint32_t)(c + 2 * (uint64_t)i), (uint16_t)(bad & 0xFFFFu)});
+                if (bad >> 16) exc.push_back(Exc{(uint32_t)(c + 2 * (uint64_t)i + 1), (uint16_t)(bad >> 16)});
+            }
         }
     }
     if (c < c_hi) pack_range_scalar(bases, c, c_hi, codes, exc);
