@@ -500,6 +500,7 @@ def main():
             "resident_batches": len(batches), "launches_per_step": launches_per_step, "bases_per_step_per_rank": bases_per_step,
             "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
+            "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "timed_regions": len(region_s), "timed_total_s": round(sum(region_s), 3),

@@ -140,10 +140,16 @@ int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared);
  * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
  * Env TBK_MINIMIZER_W (default 6) and TBK_TABLE_LOAD tune it; neither changes any result. */
 int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset);
-/* 0: the span's m-mer with the smallest hash picks the bucket (default); t > 0: mod-sampling
- * over the span's t-mers (fewer bucket switches between consecutive windows, more arithmetic
- * per window; env TBK_MOD_SAMPLING=1). */
+/* 0: the span's m-mer with the smallest hash picks the bucket (random minimizer); t > 0: mod-sampling
+ * over the span's t-mers (15 % fewer bucket switches between consecutive windows, more arithmetic per
+ * window, longer runs of keys per bucket).  The lists decide: the table is built with mod-sampling
+ * and, if more than 0.3 % (TBK_CLUSTERED) of the keys found their own half of their home line full
+ * - lists that cluster, as real find-unique-kmers output does - built again with the random
+ * minimizer.  TBK_MOD_SAMPLING=1 / 0 pins the rule.  No result depends on it. */
 int tbk_classifier_sampling_t(const tbk_classifier *c);
+/* How many times the table was built (1 or 2, see above) and how many keys found their own half of
+ * their home line full in the layout that was kept. */
+int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint64_t *keys_past_half);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

@@ -535,6 +535,65 @@ def test_streaming_order_and_overlap(gpu, orc, tmp_path):
         assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
 
 
+def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
+    """Without TBK_MOD_SAMPLING the lists decide how buckets are selected: keys that fall evenly into
+    buckets keep mod-sampling (one build), lists that cluster the way real find-unique-kmers output
+    does (runs of overlapping k-mers around variants) are rebuilt with the random minimizer.  Either
+    way, and with the rule pinned either way, the counts are the oracle's."""
+    import ctypes as C
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    monkeypatch.delenv("TBK_MOD_SAMPLING", raising=False)
+    dev, k, n = 0, 21, 400_000
+
+    def dalloc(nbytes):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, nbytes, C.byref(p)))
+        return p.value
+
+    # uniform: BASELINE's synthetic lists; clustered: haplotype-shaped lists of a 30 Mb genome
+    uni = np.empty(2 * n, dtype=np.uint64)
+    check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, k, uni.ctypes.data))
+    cap = 2 * n
+    d_a, d_b = dalloc(cap * 8), dalloc(cap * 8)
+    got = C.c_uint64()
+    check(lib.tbk_synth_hap_keys_device(dev, 0x5EED0001, 3_000_000, int(round((1 / 500) * (1 << 24))), k, C.c_void_p(d_a), C.c_void_p(d_b), cap, C.byref(got)))
+    m = got.value
+    assert 100_000 < m <= cap
+    hap = np.empty(2 * m, dtype=np.uint64)
+    check(lib.tbk_memcpy_d2h(dev, hap.ctypes.data, C.c_void_p(d_a), m * 8))
+    check(lib.tbk_memcpy_d2h(dev, hap.ctypes.data + m * 8, C.c_void_p(d_b), m * 8))
+    for p in (d_a, d_b):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+    rng = np.random.default_rng(8)
+
+    def decode(key):
+        return "".join("ACGT"[(int(key) >> (2 * i)) & 3] for i in range(k))
+
+    for name, keys, half, want_t, want_builds in (("uniform", uni, n, True, 1), ("clustered", hap, m, False, 2)):
+        ka, kb = keys[:half], keys[half:]
+        oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
+        plants = [decode(x) for x in np.concatenate([ka[:300], kb[:300]])]
+        reads = _rand_reads(rng, 300, 3000, plants, k, p_plant=0.9)
+        bases, offs = _pack(reads)
+        want = orc.count_batch(bases, offs, oa, ob)
+        assert want.sum() > 300
+        a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
+        with kmers.Classifier(a, b) as cls:
+            st = cls.stats()
+            assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
+            assert np.array_equal(cls.classify_batch(bases, offs), want), name
+        for pin in ("0", "1"):
+            monkeypatch.setenv("TBK_MOD_SAMPLING", pin)
+            with kmers.Classifier(a, b) as cls:
+                st = cls.stats()
+                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == 1, (name, pin, st)
+                assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin)
+        monkeypatch.delenv("TBK_MOD_SAMPLING")
+
+
 def test_prepacked_batches(gpu, orc, transfer):
     """tbk_pack_bases + tbk_stream_submit_packed: batches packed ahead of time (pinned and pageable
     arrays), with N runs, lower case, reads ending inside a chunk, an empty batch; counts equal the

@@ -89,6 +89,7 @@ _sig("tbk_classifier_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
 _sig("tbk_classifier_shared_keys", C.c_int, _vp, _u64p)
 _sig("tbk_classifier_layout", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_sampling_t", C.c_int, _vp)
+_sig("tbk_classifier_build_info", C.c_int, _vp, C.POINTER(C.c_int), _u64p)
 _sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
 _sig("tbk_stream_depth", C.c_int, _vp)
 _sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)

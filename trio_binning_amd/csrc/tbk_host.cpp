@@ -163,6 +163,8 @@ struct tbk_classifier {
     uint64_t distinct_a = 0, distinct_b = 0;
     uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
+    int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
+    uint64_t past_half = 0;      // keys that found their own half of their home line full
     uint32_t guests = 0;         // k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
     hipStream_t compute = nullptr, copy = nullptr;
@@ -267,9 +269,10 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
 static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz, uint32_t *d_overflowed,
                        const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out,
                        TbkTableView skip = TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, uint64_t *skipped_out = nullptr,
-                       uint32_t *d_left_line = nullptr, uint32_t guests = 0) {
-    // counters: [0] distinct keys stored, [1] keys dropped because `skip` holds them
-    unsigned long long *d_cnt = nullptr, cnt[2] = {0, 0};
+                       uint32_t *d_left_line = nullptr, uint32_t guests = 0, uint64_t *past_out = nullptr) {
+    // counters: [0] distinct keys stored, [1] keys dropped because `skip` holds them, [2] keys that found
+    // their own half of their home line full
+    unsigned long long *d_cnt = nullptr, cnt[3] = {0, 0, 0};
     int *d_failed = nullptr;
     hipError_t e = hipMalloc((void **)&d_cnt, sizeof cnt);
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
@@ -285,6 +288,7 @@ static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, u
     if (failed) return fail(TBK_ERR_HIP, "table insert overflowed (table full)");
     *distinct_out = cnt[0];
     if (skipped_out) *skipped_out = cnt[1];
+    if (past_out) *past_out = cnt[2];
     return TBK_OK;
 }
 
@@ -555,6 +559,42 @@ static int classifier_streams(tbk_classifier *c) {
     return TBK_OK;
 }
 
+// The paired table for c->mz: allocate, fill with TBK_EMPTY, insert hapA's list, then hapB's minus the
+// keys hapA holds: such a key can never count for hapB (hapA is asked first, c/kmers.c:291-294), and
+// leaving it out keeps the halves disjoint, so the probe kernel never arbitrates between them.  The
+// order pass after each list turns "a key went past this half" / "left the line" into the order of
+// the half's last slots, which is what lookups (hapB's inserts included) read.  *past = keys that
+// found their own half of their home line full.
+static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint64_t *past) {
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.04 : 0.25, 2 * TBK_BUCKET_BYTES);
+    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
+    if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
+    if (e != hipSuccess) {
+        if (c->d_pair) (void)hipFree(c->d_pair);
+        c->d_pair = nullptr;
+        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    uint32_t *d_over = nullptr, *d_left = nullptr;
+    uint64_t past_a = 0, past_b = 0;
+    int rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
+    if (!rc && c->guests) rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_left);
+    if (!rc) {
+        rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
+                         TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests, &past_a);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
+        if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
+                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests, &past_b);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
+    }
+    if (d_over) (void)hipFree(d_over);
+    if (d_left) (void)hipFree(d_left);
+    if (rc) { (void)hipFree(c->d_pair); c->d_pair = nullptr; return rc; }
+    c->past_half = past_a + past_b;
+    *past = past_a + past_b;
+    return TBK_OK;
+}
+
 extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -570,45 +610,32 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
-    // bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
-    // default 6; 0 = plain hashing of the whole key).  TBK_MOD_SAMPLING=1 samples by mod-sampling
-    // instead of the random-minimizer rule: 15 % fewer HBM lines but 23 % more VALU work, a net
-    // 3 % loss on MI355X as measured in round 1 (the kernel turns issue-bound), so it is opt-in.
-    c->mz = tbk_mz_params(c->k, (int)env_double("TBK_MINIMIZER_W", 6), std::max(a->num_lines, b->num_lines),
-                          (int)env_double("TBK_MINIMIZER_M", 0), (int)env_double("TBK_MOD_SAMPLING", 0));
-    // the two open-addressing tables, interleaved bucket by bucket into 128-byte lines
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.04 : 0.25, 2 * TBK_BUCKET_BYTES);
-    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
-    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
-    if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
-    if (e != hipSuccess) {
-        if (c->d_pair) (void)hipFree(c->d_pair);
-        delete c;
-        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
-    }
-    // hapA's list, then hapB's minus the keys hapA holds: such a key can never count for hapB
-    // (hapA is asked first, c/kmers.c:291-294), and leaving it out keeps the halves disjoint, so
-    // the probe kernel never arbitrates between them.  The order pass after each list turns
-    // "a key went past this half" into the order of the half's last two slots, which is what
-    // lookups (hapB's inserts included) read.
-    uint32_t *d_over = nullptr;
-    // k < 32 leaves bit 63 of a key free: a key whose half is full goes, tagged, into the other list's
-    // half of the same line before it leaves the line (TBK_GUESTS=0 turns that off)
+    // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
+    // default 6; 0 = plain hashing of the whole key).  Which m-mer is sampled: mod-sampling reads
+    // 15 % fewer lines than the random minimizer on lists whose keys fall evenly into buckets
+    // (BASELINE's uniform lists: 158 against 148 Gbases/s) and its longer runs per bucket overflow
+    // more halves on lists that cluster (lists shaped like real find-unique-kmers output: 129 against
+    // 139).  Nothing of that is observable in the results, and building the table takes a fraction
+    // of a second, so the lists decide: the table is built with mod-sampling, and if more than
+    // TBK_CLUSTERED (default 0.3 %) of the keys found their own half of their home line full it is
+    // built again with the random minimizer.  TBK_MOD_SAMPLING=1 / 0 pins the rule.
+    const double pin = env_double("TBK_MOD_SAMPLING", -1);
+    const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
+    const uint64_t n_big = std::max(a->num_lines, b->num_lines);
     c->guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? 1u : 0u;
-    uint32_t *d_left = nullptr;
-    rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
-    if (!rc && c->guests) rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_left);
-    if (!rc) {
-        rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
-                         TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
-        if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
-                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int mod_sampling = pin >= 0 ? (pin != 0) : (attempt == 0);
+        c->mz = tbk_mz_params(c->k, w_target, n_big, m_force, mod_sampling);
+        if (pin < 0 && attempt == 0 && c->mz.t == 0) continue;  // mod-sampling is not available for this k / table size
+        c->layout_builds++;
+        uint64_t past = 0;
+        rc = build_pair_table(c, a, b, &past);
+        if (rc) { delete c; return rc; }
+        const double clustered = (double)past / (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
+        if (pin >= 0 || attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
+        (void)hipFree(c->d_pair);  // the lists cluster: again, with the random minimizer
+        c->d_pair = nullptr;
     }
-    if (d_over) (void)hipFree(d_over);
-    if (d_left) (void)hipFree(d_left);
-    if (rc) { (void)hipFree(c->d_pair); delete c; return rc; }
     rc = classifier_streams(c);
     if (rc) { tbk_classifier_destroy(c); return rc; }
     *out = c;
@@ -631,6 +658,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->max_blocks = src->max_blocks;
     c->packed_h2d = src->packed_h2d;
     c->guests = src->guests;
+    c->layout_builds = src->layout_builds; c->past_half = src->past_half;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) {
@@ -708,6 +736,13 @@ extern "C" int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_
     if (distinct_b) *distinct_b = c->distinct_b;
     if (n_buckets) *n_buckets = c->n_buckets;
     if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint64_t *keys_past_half) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (layout_builds) *layout_builds = c->layout_builds;
+    if (keys_past_half) *keys_past_half = c->past_half;
     return TBK_OK;
 }
 

@@ -48,11 +48,11 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
                   const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ overflowed,
                   uint32_t *__restrict__ left_line, uint32_t guests, TbkTableView skip,
                   unsigned long long *__restrict__ n_distinct, unsigned long long *__restrict__ n_skipped,
-                  int *__restrict__ failed) {
+                  unsigned long long *__restrict__ n_past, int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET, which = half / TBK_SLOTS_PER_BUCKET;
-    unsigned long long mine = 0, skipped = 0;
+    unsigned long long mine = 0, skipped = 0, past = 0;  // past: keys that found their own half of their home line full
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;  // TBK_EMPTY / TBK_NOKEY: never a canonical key, never stored
@@ -85,6 +85,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
                     // the note into the order of the half's last two slots)
                     const uint64_t bit = (uint64_t)b * halves + which;
                     atomicOr(&overflowed[bit >> 5], 1u << (bit & 31));
+                    past += (c == 0 && walked == 0);
                     if (guests) {
                         // ... first into a free slot of the other list's half of the same line, tagged: lookups
                         // hold the whole line, so a guest costs them two compares, not another random line
@@ -110,6 +111,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     }
     if (mine) atomicAdd(n_distinct, mine);
     if (skipped) atomicAdd(n_skipped, skipped);
+    if (past) atomicAdd(n_past, past);
 }
 
 // After all inserts: give every full half the order of its last two slots that says whether a key
@@ -216,6 +218,18 @@ __device__ __forceinline__ uint64_t find_read(const uint64_t *offsets, uint64_t 
         if (offsets[mid] <= pos) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// 16 bytes (two slots) of a bucket line.  -DTBK_NT_LOADS marks the load non-temporal: a line is used by the
+// quad that fetched it and hardly ever again before it has left the caches.
+__device__ __forceinline__ ulonglong2 load_slots(const uint64_t *p) {
+#ifdef TBK_NT_LOADS
+    typedef unsigned long long tbk_v2 __attribute__((ext_vector_type(2)));
+    const tbk_v2 v = __builtin_nontemporal_load(reinterpret_cast<const tbk_v2 *>(p));
+    return make_ulonglong2(v.x, v.y);
+#else
+    return *reinterpret_cast<const ulonglong2 *>(p);
+#endif
 }
 
 template <int S>
@@ -549,8 +563,8 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             TBK_COUNT(4, __popcll(ballot((int32_t)bk[s] < 0)));
             if ((int32_t)bk[s] < 0) {
                 const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
-                va[s] = *reinterpret_cast<const ulonglong2 *>(line);
-                vb[s] = *reinterpret_cast<const ulonglong2 *>(line + 8);
+                va[s] = load_slots(line);
+                vb[s] = load_slots(line + 8);
             }
         }
 
@@ -750,7 +764,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uin
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, stride,
-                       half, mz, d_keys, n, d_overflowed, d_left_line, guests, skip, d_distinct, d_skipped, d_failed);
+                       half, mz, d_keys, n, d_overflowed, d_left_line, guests, skip, d_distinct, d_skipped, d_skipped + 1, d_failed);
     return hipGetLastError();
 }
 
