@@ -61,12 +61,24 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
         // two halves stay disjoint - the probe kernel never has to arbitrate between them
         if (skip.slots != nullptr && tbk_lookup_slow(skip, key)) { skipped++; continue; }
         // the buckets a lookup of this key may select: one, except when mod-sampling finds the
-        // smallest t-mer rank at several positions of the key (then one per tied position)
-        uint32_t cand[16];
-        int n_cand = tbk_bucket_candidates(key, mz, n_buckets, cand);
-        if (n_cand < 0) { cand[0] = tbk_bucket_of(key, mz, n_buckets); n_cand = 1; }
-        for (int c = 0; c < n_cand; c++) {
-            uint32_t b = cand[c];
+        // smallest t-mer rank at several positions of the key - then the key goes into the bucket of
+        // every tied position (two positions naming the same bucket: the second visit finds the key there).
+        // No candidate array: positions are walked twice (arrays indexed at run time live in scratch memory).
+        const bool tied_positions = mz.w > 0 && mz.t > 0;
+        const int n_pos = tied_positions ? 2 * mz.w : 1;
+        uint32_t best = 0xFFFFFFFFu;
+        if (tied_positions)
+            for (int pi = 0; pi < n_pos; pi++) { const uint32_t g = tbk_tmer_rank(key, mz, pi); best = g < best ? g : best; }
+        int c = -1;  // copies placed so far - 1: only the first one counts as a stored key
+        for (int pi = 0; pi < n_pos; pi++) {
+            uint32_t b;
+            if (tied_positions) {
+                if (tbk_tmer_rank(key, mz, pi) != best) continue;
+                b = tbk_bucket_at(key, mz, pi % mz.w, n_buckets);
+            } else {
+                b = tbk_bucket_of(key, mz, n_buckets);
+            }
+            c++;
             bool done = false;
             for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                 unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
