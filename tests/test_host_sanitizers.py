@@ -1,7 +1,7 @@
 """Host code of the library (list parser, FASTX reader, bin writer, TSV formatter, error paths)
 under AddressSanitizer + UndefinedBehaviorSanitizer.  CPU only: the sanitized build is loaded
-through TBK_LIBRARY in a child interpreter with the ASan runtime preloaded, and the native-I/O
-and CLI host tests are re-run against it."""
+through TBK_LIBRARY in a child interpreter with the ASan runtime preloaded, and the native-I/O,
+packer, multi-device dealer and CLI host tests are re-run against it."""
 import glob
 import os
 import subprocess
@@ -28,6 +28,8 @@ def test_host_code_under_asan_ubsan(built):
                TBK_LIBRARY=os.path.join(csrc, "build_asan", "libtbk_hip_asan.so"))
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_host_native_io.py"),
+                        os.path.join(ROOT, "tests", "test_host_pack.py"),
+                        os.path.join(ROOT, "tests", "test_multi_cpu.py"),
                         os.path.join(ROOT, "tests", "test_host_cli.py")],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     out = p.stdout + p.stderr
