@@ -986,9 +986,28 @@ extern "C" int tbk_format_tsv(const tbk_fastx_batch *b, const char *bins, const 
 // =======================================================================================
 // bin writer
 // =======================================================================================
+// bytes not yet written: a plain buffer that grows by realloc (a vector would zero-fill gigabytes
+// that are overwritten the next moment)
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~TextBuf() { free(p); }
+    bool grow_to(size_t need) {
+        if (need <= cap) return true;
+        size_t c = std::max(need + need / 4, (size_t)1 << 20);
+        char *q = (char *)realloc(p, c);
+        if (!q) return false;
+        p = q; cap = c;
+        return true;
+    }
+    char *data() { return p; }
+    size_t size() const { return n; }
+};
+
 struct BinFile {
     int fd = -1;
-    std::vector<char> text;  // records not yet written
+    uint64_t file_off = 0;  // bytes written so far (this descriptor's own offset: plain output is written with pwrite)
+    TextBuf text;           // records not yet written
 };
 
 struct tbk_bin_writer {
@@ -1068,16 +1087,48 @@ static int flush_bins(tbk_bin_writer *w, bool final) {
         work();
         for (auto &t : pool) t.join();
     }
-    for (Piece &pc : pieces) {
-        if (!pc.ok) return ffail(TBK_ERR_IO, "deflate failed");
-        const char *p = w->gz ? pc.out.data() : pc.src;
-        const size_t n = w->gz ? pc.out.size() : pc.n;
-        if (!write_all(w->bin[pc.bin].fd, p, n, w->err)) return ffail(TBK_ERR_IO, "%s", w->err.c_str());
+    if (w->gz) {
+        for (Piece &pc : pieces) {
+            if (!pc.ok) return ffail(TBK_ERR_IO, "deflate failed");
+            if (!write_all(w->bin[pc.bin].fd, pc.out.data(), pc.out.size(), w->err)) return ffail(TBK_ERR_IO, "%s", w->err.c_str());
+            w->bin[pc.bin].file_off += pc.out.size();
+        }
+    } else {
+        // Plain output: the bytes of a bin go to the file at the offset a sequence of write() calls
+        // would have reached (each descriptor counts for itself, as the kernel does), in slices
+        // written by several threads - the copy into the page cache is what writing costs here.
+        struct Slice { int fd; const char *src; size_t n; uint64_t off; };
+        std::vector<Slice> slices;
+        const size_t slice_bytes = (size_t)8 << 20;
+        for (Piece &pc : pieces) {
+            BinFile &f = w->bin[pc.bin];
+            for (size_t o = 0; o < pc.n; o += slice_bytes) slices.push_back(Slice{f.fd, pc.src + o, std::min(slice_bytes, pc.n - o), f.file_off + o});
+            f.file_off += pc.n;
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed_errno{0};
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < slices.size() && !failed_errno.load();) {
+                const Slice &sl = slices[i];
+                size_t done = 0;
+                while (done < sl.n) {
+                    const ssize_t k = ::pwrite(sl.fd, sl.src + done, sl.n - done, (off_t)(sl.off + done));
+                    if (k < 0) { if (errno == EINTR) continue; failed_errno.store(errno); return; }
+                    done += (size_t)k;
+                }
+            }
+        };
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)w->threads, slices.size()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (failed_errno.load()) return ffail(TBK_ERR_IO, "write: %s", strerror(failed_errno.load()));
     }
     for (int b = 0; b < 3; b++) {
         BinFile &f = w->bin[b];
         if (keep[b] && keep[b] != f.text.size()) memmove(f.text.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
-        f.text.resize(keep[b]);
+        f.text.n = keep[b];
     }
     return TBK_OK;
 }
@@ -1112,26 +1163,62 @@ extern "C" int tbk_bin_writer_open(const char *path_a, const char *path_b, const
 extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins) {
     if (!w || !b || (b->n_reads() && !bins)) return ffail(TBK_ERR_INVALID, "NULL argument");
     const uint64_t n = b->n_reads();
+    // where every record goes: its bin and its offset in that bin's pending text (one serial pass
+    // over the records' lengths), then the bytes are put there by several threads
+    std::vector<uint64_t> dst((size_t)n), upto((size_t)n + 1);
+    uint64_t at[3] = {w->bin[0].text.size(), w->bin[1].text.size(), w->bin[2].text.size()};
+    upto[0] = 0;
     for (uint64_t i = 0; i < n; i++) {
         const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
-        std::vector<char> &t = w->bin[which].text;
         const size_t nn = b->name_off[i + 1] - b->name_off[i];
         const size_t ns = b->base_off[i + 1] - b->base_off[i];
         const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
         const bool fq = b->has_qual[i] && nq > 0;
-        const size_t o = t.size();
-        t.resize(o + 1 + nn + 1 + ns + 1 + (fq ? 2 + nq + 1 : 0));
-        char *p = t.data() + o;
-        *p++ = fq ? '@' : '>';
-        memcpy(p, b->names.data() + b->name_off[i], nn); p += nn;
-        *p++ = '\n';
-        memcpy(p, b->bases + b->base_off[i], ns); p += ns;
-        *p++ = '\n';
-        if (fq) {
-            *p++ = '+'; *p++ = '\n';
-            memcpy(p, b->quals.data() + b->qual_off[i], nq); p += nq;
+        const size_t len = 1 + nn + 1 + ns + 1 + (fq ? 2 + nq + 1 : 0);
+        dst[(size_t)i] = at[which];
+        at[which] += len;
+        upto[(size_t)i + 1] = upto[(size_t)i] + len;
+    }
+    for (int k = 0; k < 3; k++) {
+        if (!w->bin[k].text.grow_to((size_t)at[k])) return ffail(TBK_ERR_NOMEM, "out of memory buffering a bin");
+        w->bin[k].text.n = (size_t)at[k];
+    }
+    const uint64_t total = upto[(size_t)n];
+    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)4 << 20)));
+    auto fill = [&](int t) {
+        auto cut = [&](int u) -> size_t {
+            if (u <= 0) return 0;
+            if (u >= nt) return (size_t)n;
+            return (size_t)(std::lower_bound(upto.begin(), upto.begin() + (ptrdiff_t)n, total * (uint64_t)u / (uint64_t)nt) - upto.begin());
+        };
+        const size_t last = cut(t + 1);
+        for (size_t i = cut(t); i < last; i++) {
+            // FASTQ when the record has a non-empty quality string, else FASTA (seq.py:27-31)
+            const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
+            const size_t nn = b->name_off[i + 1] - b->name_off[i];
+            const size_t ns = b->base_off[i + 1] - b->base_off[i];
+            const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
+            const bool fq = b->has_qual[i] && nq > 0;
+            char *p = w->bin[which].text.data() + dst[i];
+            *p++ = fq ? '@' : '>';
+            if (nn) memcpy(p, b->names.data() + b->name_off[i], nn);
+            p += nn;
             *p++ = '\n';
+            if (ns) memcpy(p, b->bases + b->base_off[i], ns);
+            p += ns;
+            *p++ = '\n';
+            if (fq) {
+                *p++ = '+'; *p++ = '\n';
+                memcpy(p, b->quals.data() + b->qual_off[i], nq); p += nq;
+                *p++ = '\n';
+            }
         }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(fill, t);
+        fill(0);
+        for (std::thread &th : pool) th.join();
     }
     return flush_bins(w, false);
 }
