@@ -604,7 +604,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             any_b |= hit_b[s];
         }
         TBK_COUNT(0, 1);
-        uint64_t guests_a = 0, guests_b = 0;  // windows whose key was found as a guest in the other half (bit of the owning lane)
+        uint64_t guests_a = 0, guests_b = 0;  // multi-read passes: windows whose key was found as a guest in the other half (bit of the owning lane)
         if (full_any != 0) {
             TBK_COUNT(1, 1);
             // Careful path: per-window (= per-quad) resolution, everything brought to the quad's
@@ -615,23 +615,36 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 if ((full_a[s] | full_b[s]) == 0) continue;  // raw ballots are already exact
                 const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
                 TBK_COUNT(2, 1);
-                const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
-                uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s]);  // a hit in either half is final
-                uint64_t walk_a = miss & fa, walk_b = miss & fb;
-                if (p.t.guests && (walk_a | walk_b) != 0) {
+                uint64_t walk_a, walk_b;
+                if (p.t.guests) {
                     // The keys that went past a half went, tagged, into free slots of the line's other half
-                    // first (the quad holds them already), and only then out of the line: quad lane 2 holds
-                    // slots 4 and 5 of each half, whose order says whether any did.
+                    // first, and the quad holds that half already.  A tagged slot equal to the window's key
+                    // IS the key (stored once, and only in its home line's other half when its own half was
+                    // full), so these compares count as they stand: no masks, no per-window reduction.
                     const uint64_t tagged = kk[s] | TBK_GUEST;
-                    const uint64_t guest_a = quad_any(ballot(vb[s].x == tagged) | ballot(vb[s].y == tagged)) & walk_a;  // hapA's guests sit in hapB's half
-                    const uint64_t guest_b = quad_any(ballot(va[s].x == tagged) | ballot(va[s].y == tagged)) & walk_b & ~guest_a;
-                    const uint64_t left_a = (ballot(va[s].x > va[s].y) & 0x4444444444444444ull) >> 2;
-                    const uint64_t left_b = (ballot(vb[s].x > vb[s].y) & 0x4444444444444444ull) >> 2;
-                    guests_a |= guest_a << s;  // brought to the bit of the lane that owns the window (quad lane s)
-                    guests_b |= guest_b << s;
-                    miss &= ~(guest_a | guest_b);
-                    walk_a = miss & fa & left_a;
-                    walk_b = miss & fb & left_b;
+                    const uint64_t ga = ballot(vb[s].x == tagged) | ballot(vb[s].y == tagged);  // hapA's guests sit in hapB's half
+                    const uint64_t gb = ballot(va[s].x == tagged) | ballot(va[s].y == tagged);
+                    if (!MULTI) {
+                        acc_a += (uint32_t)__popcll(ga);
+                        acc_b += (uint32_t)__popcll(gb);
+                    } else {
+                        guests_a |= quad_any(ga) << s;  // brought to the bit of the lane that owns the window (quad lane s)
+                        guests_b |= quad_any(gb) << s;
+                    }
+                    // Only keys that LEFT THE LINE need a walk: quad lane 2 holds slots 4 and 5 of each half,
+                    // whose order says whether any did (meaningful where keys went past the half).  Rare.
+                    const uint64_t need_a = fa & ((ballot(va[s].x > va[s].y) & 0x4444444444444444ull) >> 2);
+                    const uint64_t need_b = fb & ((ballot(vb[s].x > vb[s].y) & 0x4444444444444444ull) >> 2);
+                    if ((need_a | need_b) == 0) continue;
+                    const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
+                    const uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s] | ga | gb);  // a hit anywhere in the line is final
+                    walk_a = miss & need_a;
+                    walk_b = miss & need_b;
+                } else {
+                    const uint64_t valid = ballot(kk[s] != TBK_NOKEY) & 0x1111111111111111ull;
+                    const uint64_t miss = valid & ~quad_any(hit_a[s] | hit_b[s]);  // a hit in either half is final
+                    walk_a = miss & fa;
+                    walk_b = miss & fb;
                 }
                 const uint64_t queued = walk_a | walk_b;
                 if (queued) {
@@ -660,8 +673,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                     acc_a += (uint32_t)__popcll(hit_a[s]);
                     acc_b += (uint32_t)__popcll(hit_b[s]);
                 }
-                acc_a += (uint32_t)__popcll(guests_a);
-                acc_b += (uint32_t)__popcll(guests_b);
             } else {
                 // Bring each window's verdict to the bit of the lane that owns it (quad q's sub-step s
                 // window belongs to lane 4q + s) and let every lane count its own windows: its 32
