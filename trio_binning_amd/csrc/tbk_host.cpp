@@ -233,15 +233,15 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 
 // ---- tables ----------------------------------------------------------------------------
 static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes) {
-    // Target load (keys per slot).  HBM is plentiful (288 GB) and a probe should be decided by
-    // one line: a lookup goes on to another bucket only when keys went past its half of the home
-    // line.  Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing clusters keys
-    // that share a minimizer, and real lists cluster further (the k overlapping k-mers around
-    // one variant share ~6 minimizers, in both lists at once), so it gets 0.32 keys per half (load
-    // 0.04; 2 x 3e8 keys = 120 GB): measured on haplotype-shaped lists at that scale 118-125
-    // Gbases/s at 0.0625, 131 at 0.04 and 0.03, 134 at 0.025; uniform random keys do not care
-    // (141 Gbases/s from 0.1 down to 0.03).  The table may take up to 60 % of the free HBM; bigger
-    // lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
+    // Target load (keys per slot).  A probe should be decided by one line: a lookup goes on to another
+    // bucket only when keys left its home line.  Plain hashing: 2 keys per 8-slot half (load 0.25).
+    // Minimizer bucketing clusters keys that share a minimizer, and real lists cluster further (the k
+    // overlapping k-mers around one variant share ~6 minimizers, in both lists at once), so it gets
+    // 0.64 keys per half (load 0.08; 2 x 3e8 keys = 60 GB).  Measured at that scale, uniform /
+    // haplotype-shaped lists (profiles/r02_final/ab_load_lean.log): load 0.04 155-159 / 141 Gbases/s,
+    // 0.08 154 / 133-134, 0.10 148 / 124-128 - guests in the other half of the line carry most of what
+    // twice the memory used to buy.  The table may take up to 60 % of the free HBM; bigger lists get
+    // a proportionally higher load.  TBK_TABLE_LOAD overrides (0.04: the last 2-5 %, for 120 GB).
     double load = env_double("TBK_TABLE_LOAD", 0);
     const bool forced = load > 0;
     if (!forced) load = default_load;
@@ -566,7 +566,7 @@ static int classifier_streams(tbk_classifier *c) {
 // the half's last slots, which is what lookups (hapB's inserts included) read.  *past = keys that
 // found their own half of their home line full.
 static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint64_t *past) {
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.04 : 0.25, 2 * TBK_BUCKET_BYTES);
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.08 : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
