@@ -536,16 +536,18 @@ def test_streaming_order_and_overlap(gpu, orc, tmp_path):
 
 
 def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
-    """Without TBK_MOD_SAMPLING the lists decide how buckets are selected: keys that fall evenly into
-    buckets keep mod-sampling (one build), lists that cluster the way real find-unique-kmers output
-    does (runs of overlapping k-mers around variants) are rebuilt with the random minimizer.  Either
-    way, and with the rule pinned either way, the counts are the oracle's."""
+    """Without TBK_MOD_SAMPLING / TBK_TABLE_LOAD the lists decide how buckets are selected and how roomy
+    the table is: keys that fall evenly into buckets keep mod-sampling at load 0.08 (one build), lists
+    that cluster the way real find-unique-kmers output does (runs of overlapping k-mers around
+    variants) are rebuilt with the random minimizer at load 0.04.  Either way, and with the rule or the
+    load pinned, the counts are the oracle's."""
     import ctypes as C
 
     from trio_binning_amd import kmers
     from trio_binning_amd._lib import check, lib
 
     monkeypatch.delenv("TBK_MOD_SAMPLING", raising=False)
+    monkeypatch.delenv("TBK_TABLE_LOAD", raising=False)
     dev, k, n = 0, 21, 400_000
 
     def dalloc(nbytes):
@@ -584,14 +586,29 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
             assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
+            load = half / (st["n_buckets"] * 8)
+            assert abs(load - (0.08 if want_builds == 1 else 0.04)) < 0.005, (name, load)
             assert np.array_equal(cls.classify_batch(bases, offs), want), name
         for pin in ("0", "1"):
-            monkeypatch.setenv("TBK_MOD_SAMPLING", pin)
+            monkeypatch.setenv("TBK_MOD_SAMPLING", pin)   # the rule is pinned, the load still follows the lists
+            with kmers.Classifier(a, b) as cls:
+                st = cls.stats()
+                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == want_builds, (name, pin, st)
+                assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin)
+            monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")   # both pinned: one build
             with kmers.Classifier(a, b) as cls:
                 st = cls.stats()
                 assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == 1, (name, pin, st)
-                assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin)
+                assert abs(half / (st["n_buckets"] * 8) - 0.1) < 0.005
+                assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin, "load")
+            monkeypatch.delenv("TBK_TABLE_LOAD")
         monkeypatch.delenv("TBK_MOD_SAMPLING")
+        monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")       # the load is pinned, the rule still follows the lists
+        with kmers.Classifier(a, b) as cls:
+            st = cls.stats()
+            assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, "load pinned", st)
+            assert np.array_equal(cls.classify_batch(bases, offs), want), (name, "load pinned")
+        monkeypatch.delenv("TBK_TABLE_LOAD")
 
 
 def test_prepacked_batches(gpu, orc, transfer):

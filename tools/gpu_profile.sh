@@ -24,6 +24,7 @@ done
 done
 cd $R
 python tools/profile_summary.py gpurun_out
+for e in "TBK_MOD_SAMPLING=1" "TBK_MOD_SAMPLING=0" "TBK_TABLE_LOAD=0.04"; do for l in uniform haplotypes; do echo -n "$e $l: "; env $e timeout 600 python bench.py --lists $l --steps 10 --warmup 2 --no-cpu-baseline --no-streaming 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d[\"value\"], d[\"roofline\"][\"kernel_ms_avg\"], d[\"config\"][\"bucket_select\"], d[\"config\"][\"table_load\"])"; done; done > gpurun_out/ab_final_rules.log 2>&1
 # host side of the boundary
 ( timeout 600 python tools/measure_reader.py --qual hifi ) > gpurun_out/reader_hifi.json 2> gpurun_out/reader_hifi.err
 ( timeout 600 python tools/measure_cli.py --reads 200000 ) > gpurun_out/cli_plain_input.json 2> gpurun_out/cli_plain_input.err

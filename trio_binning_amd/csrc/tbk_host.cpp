@@ -565,8 +565,8 @@ static int classifier_streams(tbk_classifier *c) {
 // order pass after each list turns "a key went past this half" / "left the line" into the order of
 // the half's last slots, which is what lookups (hapB's inserts included) read.  *past = keys that
 // found their own half of their home line full.
-static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint64_t *past) {
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? 0.08 : 0.25, 2 * TBK_BUCKET_BYTES);
+static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past) {
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
@@ -611,30 +611,40 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
     // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
-    // default 6; 0 = plain hashing of the whole key).  Which m-mer is sampled: mod-sampling reads
-    // 15 % fewer lines than the random minimizer on lists whose keys fall evenly into buckets
-    // (BASELINE's uniform lists: 158 against 148 Gbases/s) and its longer runs per bucket overflow
-    // more halves on lists that cluster (lists shaped like real find-unique-kmers output: 129 against
-    // 139).  Nothing of that is observable in the results, and building the table takes a fraction
-    // of a second, so the lists decide: the table is built with mod-sampling, and if more than
-    // TBK_CLUSTERED (default 0.3 %) of the keys found their own half of their home line full it is
-    // built again with the random minimizer.  TBK_MOD_SAMPLING=1 / 0 pins the rule.
+    // default 6; 0 = plain hashing of the whole key).  Which m-mer is sampled, and how roomy the table
+    // is, is decided by the lists.  Mod-sampling reads 18 % fewer lines than the random minimizer on
+    // lists whose keys fall evenly into buckets (BASELINE's uniform lists: 154-159 against 143-148
+    // Gbases/s), and such lists do not care about the load (0.64 keys per 8-slot half = load 0.08 =
+    // 60 GB for 2 x 3e8 keys measures the same as half that load).  Lists that cluster the way real
+    // find-unique-kmers output does (the k overlapping k-mers around one variant share ~6 minimizers,
+    // in both lists at once) overflow more halves under mod-sampling's longer runs per bucket (122-129
+    // against 129-140), and they do care: 140 Gbases/s at load 0.04 against 129-134 at 0.08.  Nothing
+    // of that is observable in the results and building the table takes a fraction of a second, so:
+    // build with mod-sampling at load 0.08; if more than TBK_CLUSTERED (default 0.3 %) of the keys
+    // found their own half of their home line full (uniform lists: 1e-5; haplotype-shaped: 2-10 %),
+    // build again with the random minimizer at load 0.04.  TBK_MOD_SAMPLING=1 / 0 pins the rule
+    // (the load still follows the lists), TBK_TABLE_LOAD pins the load.
     const double pin = env_double("TBK_MOD_SAMPLING", -1);
     const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
+    const bool load_pinned = env_double("TBK_TABLE_LOAD", 0) > 0;
     c->guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? 1u : 0u;
+    int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
     for (int attempt = 0; attempt < 2; attempt++) {
         const int mod_sampling = pin >= 0 ? (pin != 0) : (attempt == 0);
         c->mz = tbk_mz_params(c->k, w_target, n_big, m_force, mod_sampling);
-        if (pin < 0 && attempt == 0 && c->mz.t == 0) continue;  // mod-sampling is not available for this k / table size
+        // nothing to decide between: the same rule and (pinned) the same load as the table that stands
+        if (built_t == c->mz.t && load_pinned) break;
+        // mod-sampling is not available for this k / table size and the load is pinned: one build, below
+        if (pin < 0 && attempt == 0 && c->mz.t == 0 && load_pinned) continue;
+        if (c->d_pair) { (void)hipFree(c->d_pair); c->d_pair = nullptr; }
+        built_t = c->mz.t;
         c->layout_builds++;
         uint64_t past = 0;
-        rc = build_pair_table(c, a, b, &past);
+        rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
         if (rc) { delete c; return rc; }
         const double clustered = (double)past / (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
-        if (pin >= 0 || attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
-        (void)hipFree(c->d_pair);  // the lists cluster: again, with the random minimizer
-        c->d_pair = nullptr;
+        if (attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
     }
     rc = classifier_streams(c);
     if (rc) { tbk_classifier_destroy(c); return rc; }
