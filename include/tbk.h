@@ -145,7 +145,9 @@ int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimi
  * window, longer runs of keys per bucket).  The lists decide: the table is built with mod-sampling
  * and, if more than 0.3 % (TBK_CLUSTERED) of the keys found their own half of their home line full
  * - lists that cluster, as real find-unique-kmers output does - built again with the random
- * minimizer.  TBK_MOD_SAMPLING=1 / 0 pins the rule.  No result depends on it. */
+ * minimizer and at half the load (0.04 instead of 0.08 keys per slot: such lists are the ones a
+ * roomier table helps).  TBK_MOD_SAMPLING=1 / 0 pins the rule, TBK_TABLE_LOAD the load.  No result
+ * depends on either. */
 int tbk_classifier_sampling_t(const tbk_classifier *c);
 /* How many times the table was built (1 or 2, see above) and how many keys found their own half of
  * their home line full in the layout that was kept. */
