@@ -1,4 +1,6 @@
-"""Drop-in alias of :mod:`trio_binning_amd.classify` (reference module: src/trio_binning/classify.py)."""
+"""Alias of :mod:`trio_binning_amd.classify`: the entry-point name BASELINE.json's north star uses.
+The reference has no module of this name (its driver is ``trio_binning.classify_by_kmers``,
+src/trio_binning/classify_by_kmers.py); both names resolve to the same driver here."""
 import sys as _sys
 
 import trio_binning_amd.classify as _impl
