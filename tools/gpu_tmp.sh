@@ -1,11 +1,12 @@
 #!/bin/bash
-# one-off: the split-layout branch at 5 waves per SIMD with mod-sampling on uniform lists
-export TMPDIR=/tmp TBK_SKIP_BUILD=1
-cd v2wt
-for e in "TBK_MOD_SAMPLING=1 TBK_TABLE_LOAD=0.08" "TBK_MOD_SAMPLING=0 TBK_TABLE_LOAD=0.08" "TBK_MOD_SAMPLING=1 TBK_TABLE_LOAD=0.04"; do
-  echo -n "v2 5 waves $e uniform: "
-  env $e timeout 600 python bench.py --lists uniform --steps 10 --warmup 2 --no-cpu-baseline --no-streaming 2>&1 | tail -1 | python -c "
-import sys,json
-d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_avg'], d['config']['bucket_select'], d['config']['table_load'])"
-done
+# one-off: packer with a persistent pool against threads per batch, interleaved on one box
+mkdir -p gpurun_out; export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
+export TBK_SKIP_BUILD=1
+for r in 1 2 3; do for p in 1 0; do
+echo -n "pool=$p: "
+( TBK_PACK_POOL=$p timeout 600 python bench.py --no-cpu-baseline --steps 5 --min-timed-s 0 ) 2>&1 | grep '^{"metric"' | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); s=d['streaming']; print(d['value'], 'stream', s['ascii']['gbases_per_s'], s['packed_on_submit']['gbases_per_s'], s['prepacked']['gbases_per_s'], s['prepacked']['host_pack_alone_gbases_per_s'])"
+done; done
+nproc; cat /sys/fs/cgroup/cpu.max; uptime
 exit 0

@@ -16,11 +16,8 @@
 #include <immintrin.h>
 
 #include <algorithm>
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -105,61 +102,6 @@ bool have_avx2() {
 
 }  // namespace
 
-// ---- a small persistent pool for the packer ---------------------------------------------------
-// tbk_stream_submit packs every batch; a batch of 1 Gbase takes the 16 threads of a GPU box ~7 ms,
-// and starting 15 threads per batch is a noticeable part of that.  The workers are started once
-// and sleep between batches; one job at a time (the submitting thread takes part).
-class PackPool {
-  public:
-    static PackPool &get() { static PackPool *p = new PackPool(); return *p; }  // never destroyed: workers may outlive static destructors
-    // run fn(t) for t in [0, n): n <= workers + 1
-    void run(int n, const std::function<void(int)> &fn) {
-        if (n <= 1) { if (n == 1) fn(0); return; }
-        std::unique_lock<std::mutex> job(job_mu_);  // one job at a time
-        ensure(n - 1);
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn; n_tasks_ = n; next_ = 1; pending_ = n - 1; generation_++;
-        }
-        cv_.notify_all();
-        fn(0);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = nullptr;
-    }
-
-  private:
-    void ensure(int n) {
-        while ((int)workers_.size() < n) {
-            workers_.emplace_back([this] { loop(); });
-            workers_.back().detach();
-        }
-    }
-    void loop() {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(int)> *fn = nullptr;
-            int t = -1;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return generation_ != seen && next_ < n_tasks_; });
-                t = next_++;
-                if (next_ >= n_tasks_) seen = generation_;
-                fn = fn_;
-            }
-            (*fn)(t);
-            std::lock_guard<std::mutex> lk(mu_);
-            if (--pending_ == 0) done_.notify_all();
-        }
-    }
-    std::mutex job_mu_, mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> workers_;
-    const std::function<void(int)> *fn_ = nullptr;
-    int n_tasks_ = 0, next_ = 0, pending_ = 0;
-    uint64_t generation_ = 0;
-};
-
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases) { return (total_bases + 15) / 16; }
 
 // Pack `total` ASCII bases.  codes must hold tbk_packed_chunks(total) words.  The exceptions of the
@@ -179,7 +121,17 @@ int tbk_pack_bases_vec(const uint8_t *bases, uint64_t total, uint32_t *codes, st
         if (have_avx2()) pack_range_avx2(bases, lo, hi, codes, found[(size_t)t]);
         else pack_range_scalar(bases, lo, hi, codes, found[(size_t)t]);
     };
-    PackPool::get().run(nt, work);
+    // Threads are started per call on purpose.  A persistent pool woken through a condition variable was
+    // tried and measured on the GPU box (16 CPUs' worth of quota on a 256-thread host): 78-83 Gbases/s
+    // through tbk_stream_submit against 123-138 with fresh threads, three interleaved runs each - woken
+    // workers are placed next to their waker and stack up on a few cores for the 7 ms a batch takes,
+    // fresh threads are placed on idle cores.
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+    }
     size_t n_exc = 0;
     for (const auto &f : found) n_exc += f.size();
     exc_chunk.reserve(n_exc + 1);
