@@ -759,7 +759,9 @@ def bench_count(args, np, kmers, lib, check, dev, dist, world, rank):
         "device": __import__("trio_binning_amd")._lib.device_name(dev),
     }
     if rank == 0:
-        # the ceiling this kernel is judged against: fire-and-forget 32-bit atomic adds, 3-4 in a row per 128-byte line
+        # the yardstick: fire-and-forget 32-bit atomic adds, 3-4 in a row per 128-byte line, as the chip executes
+        # them.  One add per window start would cap the kernel there; it merges the adds of consecutive windows
+        # that fall into one 64-bit word of counters, so window starts per second may exceed it (atomic_frac > 1).
         aps = C.c_double()
         check(lib.tbk_calib_atomics(dev, min(st["table_bytes"], 40 << 30), 3, 3, C.byref(aps)))
         out["roofline"]["atomic_adds_ceiling_Gps"] = round(aps.value / 1e9, 2)

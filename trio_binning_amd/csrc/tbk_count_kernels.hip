@@ -127,6 +127,14 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
         uint32_t held_bk = 0xFFFFFFFFu;
         uint32_t claimed = 0;  // slots this lane took for new k-mers
         bool full = false;
+        // The adds of consecutive windows are merged where they can be: a bucket's eight 32-bit counters
+        // are four 64-bit words, the k-mers of a run of windows were inserted one after the other - so
+        // they mostly sit in neighbouring slots - and one 64-bit add of (1 | 1 << 32) counts both
+        // halves of a word (a counter would have to pass 2^32 to carry into its neighbour; readers cap
+        // at 255).  The lane keeps one add pending and sends it when the next one goes elsewhere: the
+        // kernel runs at the rate the chip executes atomic adds, so fewer adds is the lever.
+        unsigned long long *pend_word = nullptr;
+        unsigned long long pend_add = 0;
 #pragma unroll 2
         for (int j = 0; j < TBK_WPL; j++) {
             const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
@@ -167,7 +175,18 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
                             held[s] = old == TBK_EMPTY ? key : old;
                             claimed += old == TBK_EMPTY ? 1u : 0u;
                         }
-                        if (held[s] == key) { atomicAdd(&t.counts(b)[s], 1u); done = true; }
+                        if (held[s] == key) {
+                            unsigned long long *word = reinterpret_cast<unsigned long long *>(t.counts(b)) + (s >> 1);
+                            const unsigned long long one = 1ull << (32 * (s & 1));
+                            if (word == pend_word) {
+                                pend_add += one;
+                            } else {
+                                if (pend_word != nullptr) atomicAdd(pend_word, pend_add);
+                                pend_word = word;
+                                pend_add = one;
+                            }
+                            done = true;
+                        }
                     }
                     if (!done) b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
                 }
@@ -177,6 +196,7 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
             t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
             bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
         }
+        if (pend_word != nullptr) atomicAdd(pend_word, pend_add);
         if (full) atomicExch(failed, 1);
         // slots taken by this wave: one atomic per pass
         uint32_t sum = claimed;
