@@ -131,10 +131,18 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
         // are four 64-bit words, the k-mers of a run of windows were inserted one after the other - so
         // they mostly sit in neighbouring slots - and one 64-bit add of (1 | 1 << 32) counts both
         // halves of a word (a counter would have to pass 2^32 to carry into its neighbour; readers cap
-        // at 255).  The lane keeps one add pending and sends it when the next one goes elsewhere: the
-        // kernel runs at the rate the chip executes atomic adds, so fewer adds is the lever.
-        unsigned long long *pend_word = nullptr;
-        unsigned long long pend_add = 0;
+        // at 255).  The lane keeps the adds to the four words of ONE bucket pending and sends them when
+        // a window counts in another bucket: the kernel runs at the rate the chip executes atomic adds,
+        // so fewer adds is the lever.
+        uint32_t pend_bk = 0xFFFFFFFFu;
+        unsigned long long pend[4] = {0, 0, 0, 0};
+        auto flush = [&]() {
+            if (pend_bk == 0xFFFFFFFFu) return;
+            unsigned long long *words = reinterpret_cast<unsigned long long *>(t.counts(pend_bk));
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (pend[w]) { atomicAdd(&words[w], pend[w]); pend[w] = 0; }
+        };
 #pragma unroll 2
         for (int j = 0; j < TBK_WPL; j++) {
             const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
@@ -176,15 +184,8 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
                             claimed += old == TBK_EMPTY ? 1u : 0u;
                         }
                         if (held[s] == key) {
-                            unsigned long long *word = reinterpret_cast<unsigned long long *>(t.counts(b)) + (s >> 1);
-                            const unsigned long long one = 1ull << (32 * (s & 1));
-                            if (word == pend_word) {
-                                pend_add += one;
-                            } else {
-                                if (pend_word != nullptr) atomicAdd(pend_word, pend_add);
-                                pend_word = word;
-                                pend_add = one;
-                            }
+                            if (b != pend_bk) { flush(); pend_bk = b; }
+                            pend[s >> 1] += 1ull << (32 * (s & 1));
                             done = true;
                         }
                     }
@@ -196,7 +197,7 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
             t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
             bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
         }
-        if (pend_word != nullptr) atomicAdd(pend_word, pend_add);
+        flush();
         if (full) atomicExch(failed, 1);
         // slots taken by this wave: one atomic per pass
         uint32_t sum = claimed;
