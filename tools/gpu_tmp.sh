@@ -1,5 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
-timeout 900 python tools/measure_multi_cli.py | tee gpurun_out/multi_cli.json | cut -c1-900
+AB_ENVS="X=1" bash tools/gpu_ab.sh 2>&1 | grep haplo | tee gpurun_out/ab_unroll_hap.log
 exit 0

@@ -1028,24 +1028,33 @@ static bool write_all(int fd, const char *p, size_t n, std::string &err) {
     return true;
 }
 
-// FASTQ text is bases (no LZ77 match worth having in a 32 KiB window) and qualities (runs): zlib's
-// run-length strategy compresses it as well as the default one (0.44 against 0.43 of the input on
-// HiFi-like records, better when qualities are constant) at 8-10 times the speed - and the gzip
-// members are what a run with compressed output waits for.  TBK_GZIP_STRATEGY=default restores
-// zlib's default strategy.  Decompressed bytes are the same either way.
-static int deflate_strategy() {
-    static const int strategy = [] {
+// FASTQ text is bases (no LZ77 match worth having in a 32 KiB window) and qualities.  zlib's default
+// strategy spends 8-10 times the time of its match-free ones for nothing (0.43 against 0.43-0.44 of the
+// input on HiFi-like records) - and the gzip members are what a run with compressed output waits
+// for.  Of the match-free strategies Huffman-only is the faster (about 1.3x) and on qualities that
+// vary the smaller (0.429 against 0.442); run-length wins where qualities come in runs (binned or
+// constant qualities: a third of the size).  So each member looks at its first 64 KiB: where more
+// than 45 % of the bytes equal their predecessor it is deflated with Z_RLE, else with Z_HUFFMAN_ONLY.
+// TBK_GZIP_STRATEGY=rle / huffman / default pins one.  Decompressed bytes are the same either way.
+static int deflate_strategy(const char *src, size_t n) {
+    static const int pinned = [] {
         const char *e = getenv("TBK_GZIP_STRATEGY");
-        return e && strcmp(e, "default") == 0 ? Z_DEFAULT_STRATEGY : e && strcmp(e, "huffman") == 0 ? Z_HUFFMAN_ONLY : Z_RLE;
+        if (!e) return -1;
+        return strcmp(e, "default") == 0 ? Z_DEFAULT_STRATEGY : strcmp(e, "huffman") == 0 ? Z_HUFFMAN_ONLY : strcmp(e, "rle") == 0 ? Z_RLE : -1;
     }();
-    return strategy;
+    if (pinned >= 0) return pinned;
+    const size_t look = n < ((size_t)64 << 10) ? n : ((size_t)64 << 10);
+    if (look < 2) return Z_RLE;
+    size_t same = 0;
+    for (size_t i = 1; i < look; i++) same += src[i] == src[i - 1];
+    return same * 100 > (look - 1) * 45 ? Z_RLE : Z_HUFFMAN_ONLY;
 }
 
 // one gzip member per chunk; concatenated members are a valid gzip file
 static bool deflate_member(const char *src, size_t n, int level, std::vector<char> &dst) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, deflate_strategy()) != Z_OK) return false;
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, deflate_strategy(src, n)) != Z_OK) return false;
     dst.resize(deflateBound(&zs, n) + 64);
     zs.next_in = (Bytef *)src; zs.avail_in = (uInt)n;
     zs.next_out = (Bytef *)dst.data(); zs.avail_out = (uInt)dst.size();
