@@ -247,6 +247,13 @@ int tbk_bin_writer_open(const char *path_a, const char *path_b, const char *path
 /* bins[i] in {'A','B','U'} for every record of the batch; records keep input order per bin. */
 int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins);
 int tbk_bin_writer_close(tbk_bin_writer *w);
+/* The writer's own encoder for gzip members whose bytes do not come in runs (FASTQ of long reads:
+ * nothing for LZ77 to match, so entropy coding only - dynamic-Huffman DEFLATE blocks cut at line ends,
+ * so that bases and qualities get codes of their own).  One complete gzip member for src[0..n);
+ * TBK_ERR_NOMEM with *len = the size needed when cap is too small (2n + 1024 always suffices).
+ * Members with runs go through zlib (Z_RLE);
+ * TBK_GZIP_ENCODER=zlib sends everything there. */
+int tbk_gzip_member(const char *src, size_t n, char *dst, size_t cap, size_t *len);
 /* Replaces the stdout line of classify_by_kmers.py:117 for a whole batch:
  * name \t bin \t str(score_a) \t str(score_b) \n with Python's float repr.  Call with out = NULL
  * to get an upper bound of the size in *len. */

@@ -11,7 +11,7 @@ import struct
 import numpy as np
 import pytest
 
-from conftest import DATA, load_golden
+from conftest import DATA, ROOT, load_golden
 
 
 def _native_records(path, max_bases=0, max_reads=0):
@@ -465,3 +465,89 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
         f.write_text(text)
         both(f)
         both(f, 0, 64)
+
+
+def _gzip_member(data: bytes) -> bytes:
+    import ctypes as C
+
+    from trio_binning_amd._lib import lib
+
+    need = C.c_size_t(0)
+    assert lib.tbk_gzip_member(data, len(data), None, 0, C.byref(need)) == -6 and need.value >= 18
+    out = C.create_string_buffer(need.value)
+    assert lib.tbk_gzip_member(data, len(data), out, need.value, C.byref(need)) == 0
+    return out.raw[:need.value]
+
+
+def test_own_gzip_members_are_read_by_zlib_and_by_the_reader(built, tmp_path):
+    """tbk_deflate.cpp: literal-only dynamic-Huffman members.  Any inflater must give the bytes back
+    (zlib here, and the library's own inflater through the reader), CRC and size included; covered:
+    empty input, one symbol, all 256 values, skewed counts that need the 15-bit length limit, blocks
+    with and without line ends, and FASTQ text, where the result must not be larger than zlib's
+    Z_HUFFMAN_ONLY."""
+    import zlib
+
+    from trio_binning_amd import seq
+
+    rng = np.random.default_rng(5)
+    skew = np.concatenate([np.full(1 << k, k, dtype=np.uint8) for k in range(20)])  # Fibonacci-deep tree without a limit
+    rng.shuffle(skew)
+    cases = [b"", b"A", b"\n", b"AA", b"AB" * 5, bytes(range(256)) * 3, rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),
+             b"A" * 200_000 + b"z", skew.tobytes(), b"\n" * 70_000, b"ACGT" * 5000 + b"\n" + b"I" * 20_000 + b"\n"]
+    for data in cases:
+        z = _gzip_member(data)
+        assert zlib.decompress(z, 31) == data and gzip.decompress(z) == data, len(data)
+    n = 1 << 20
+    bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()
+    quals = (33 + np.clip(rng.normal(30, 8, n), 0, 60).astype(np.uint8)).tobytes()
+    for read_len in (150, 15_000):
+        text = b"".join(b"@r%d\n" % i + bases[i:i + read_len] + b"\n+\n" + quals[i:i + read_len] + b"\n" for i in range(0, n, read_len))
+        z = _gzip_member(text)
+        assert zlib.decompress(z, 31) == text
+        co = zlib.compressobj(1, zlib.DEFLATED, 31, 8, zlib.Z_HUFFMAN_ONLY)
+        assert len(z) <= len(co.compress(text) + co.flush()) * 1.01, read_len
+        # two members back to back are one gzip file; the reader (own inflater) parses it
+        path = tmp_path / f"r{read_len}.fq.gz"
+        path.write_bytes(z + z)
+        got = sum(1 for _ in seq.open_fastx_read(str(path)))
+        want = 2 * len(range(0, n, read_len))
+        with seq.BatchReader(str(path)) as r:
+            b, total = seq.Batch(), 0
+            while r.next_batch(b, 1 << 22, 0):
+                total += b.n_reads
+        assert got == want == total
+
+
+def test_writer_gzip_encoders_agree(built, tmp_path):
+    """The same batch through the library's own encoder and through zlib (TBK_GZIP_ENCODER=zlib, read
+    once per process, so in child interpreters): same decompressed files."""
+    import hashlib
+    import subprocess
+    import sys
+
+    rng = random.Random(4)
+    src = tmp_path / "in.fq"
+    with open(src, "w") as fh:
+        for i in range(400):
+            n = rng.randrange(1, 3000)
+            fh.write("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(n)), "".join(rng.choice("!#5I~+,-") for _ in range(n))))
+    prog = (
+        "import sys, gzip, hashlib\n"
+        "from trio_binning_amd import seq\n"
+        "w = seq.BinWriter(sys.argv[2] + 'a', sys.argv[2] + 'b', sys.argv[2] + 'u', '.fq', True, threads=2)\n"
+        "with seq.BatchReader(sys.argv[1]) as r:\n"
+        "    b = seq.Batch()\n"
+        "    i = 0\n"
+        "    while r.next_batch(b, 100000, 0):\n"
+        "        w.write(b, bytes('ABU'[(i + j) % 3].encode()[0] for j in range(b.n_reads)))\n"
+        "        i += b.n_reads\n"
+        "w.close()\n"
+        "print(' '.join(hashlib.sha256(gzip.open(n, 'rb').read()).hexdigest() for n in w.names))\n"
+    )
+    digests = []
+    for enc in ("own", "zlib"):
+        env = dict(os.environ, TBK_GZIP_ENCODER=enc)
+        r = subprocess.run([sys.executable, "-c", prog, str(src), str(tmp_path / enc)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(r.stdout.split())
+    assert digests[0] == digests[1] and len(set(digests[0])) == 3
