@@ -480,11 +480,11 @@ def _gzip_member(data: bytes) -> bytes:
 
 
 def test_own_gzip_members_are_read_by_zlib_and_by_the_reader(built, tmp_path):
-    """tbk_deflate.cpp: literal-only dynamic-Huffman members.  Any inflater must give the bytes back
-    (zlib here, and the library's own inflater through the reader), CRC and size included; covered:
-    empty input, one symbol, all 256 values, skewed counts that need the 15-bit length limit, blocks
-    with and without line ends, and FASTQ text, where the result must not be larger than zlib's
-    Z_HUFFMAN_ONLY."""
+    """tbk_deflate.cpp: dynamic-Huffman members, runs as distance-1 matches.  Any inflater must give the
+    bytes back (zlib here, and the library's own inflater through the reader), CRC and size included;
+    covered: empty input, one symbol, all 256 values, skewed counts that need the 15-bit length limit,
+    blocks with and without line ends, runs of every length, and FASTQ text with noisy / constant /
+    mostly-'~' qualities, where the result must not be larger than zlib's Z_HUFFMAN_ONLY resp. Z_RLE."""
     import zlib
 
     from trio_binning_amd import seq
@@ -493,18 +493,24 @@ def test_own_gzip_members_are_read_by_zlib_and_by_the_reader(built, tmp_path):
     skew = np.concatenate([np.full(1 << k, k, dtype=np.uint8) for k in range(20)])  # Fibonacci-deep tree without a limit
     rng.shuffle(skew)
     cases = [b"", b"A", b"\n", b"AA", b"AB" * 5, bytes(range(256)) * 3, rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),
-             b"A" * 200_000 + b"z", skew.tobytes(), b"\n" * 70_000, b"ACGT" * 5000 + b"\n" + b"I" * 20_000 + b"\n"]
+             b"A" * 200_000 + b"z", skew.tobytes(), b"\n" * 70_000, b"ACGT" * 5000 + b"\n" + b"I" * 20_000 + b"\n",
+             b"".join(bytes([65 + r % 7]) * r for r in range(1, 700)),  # runs of every length: 258-byte matches and their remainders
+             np.repeat(rng.choice(np.frombuffer(b"#-7<FI", dtype=np.uint8), 40_000), rng.integers(1, 12, 40_000)).tobytes()]
     for data in cases:
         z = _gzip_member(data)
         assert zlib.decompress(z, 31) == data and gzip.decompress(z) == data, len(data)
     n = 1 << 20
     bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), n).tobytes()
     quals = (33 + np.clip(rng.normal(30, 8, n), 0, 60).astype(np.uint8)).tobytes()
-    for read_len in (150, 15_000):
+    tilde = np.full(n, ord("~"), dtype=np.uint8)
+    dips = rng.random(n) < 0.08
+    tilde[dips] = 33 + rng.integers(5, 60, int(dips.sum()))
+    for read_len, quals, strategy in ((150, quals, zlib.Z_HUFFMAN_ONLY), (15_000, quals, zlib.Z_HUFFMAN_ONLY),
+                                      (150, b"I" * n, zlib.Z_RLE), (15_000, tilde.tobytes(), zlib.Z_RLE)):
         text = b"".join(b"@r%d\n" % i + bases[i:i + read_len] + b"\n+\n" + quals[i:i + read_len] + b"\n" for i in range(0, n, read_len))
         z = _gzip_member(text)
         assert zlib.decompress(z, 31) == text
-        co = zlib.compressobj(1, zlib.DEFLATED, 31, 8, zlib.Z_HUFFMAN_ONLY)
+        co = zlib.compressobj(1, zlib.DEFLATED, 31, 8, strategy)
         assert len(z) <= len(co.compress(text) + co.flush()) * 1.01, read_len
         # two members back to back are one gzip file; the reader (own inflater) parses it
         path = tmp_path / f"r{read_len}.fq.gz"

@@ -1,4 +1,4 @@
-// tbk_deflate.cpp — a literal-only DEFLATE encoder for the gzip members of the bin writer.
+// tbk_deflate.cpp — the DEFLATE encoder behind the gzip members of the bin writer: entropy coding, and runs.
 //
 // FASTQ text has nothing for LZ77 to find inside a 32 KiB window (bases are four-symbol noise,
 // qualities of long-read data vary from base to base), so what compresses it is entropy coding alone,
@@ -7,8 +7,10 @@
 // byte histogram, a length-limited canonical Huffman code, the dynamic-block header (RFC 1951
 // 3.2.7), then the literals through a 64-bit bit buffer.  Output is an ordinary gzip member (RFC
 // 1952): any inflater reads it, decompressed bytes are what went in, CRC-32 and size in the trailer.
-// The bin writer uses it for members whose bytes do not come in runs (tbk_fastx.cpp: deflate_strategy);
-// TBK_GZIP_ENCODER=zlib keeps zlib for everything.
+// The one redundancy LZ77 does find in FASTQ - runs of one byte (constant or binned qualities, the
+// '~' stretches of HiFi reads) - is kept: a block whose bytes mostly repeat their predecessor is coded
+// as literals + matches at distance 1, what zlib calls Z_RLE.  TBK_GZIP_ENCODER=zlib sends the bin
+// writer's members through zlib instead.
 #include <zlib.h>
 
 #include <algorithm>
@@ -113,30 +115,36 @@ inline void encode_literals(BitWriter &bw, const uint8_t *src, size_t n, const u
     for (; i < n; i++) { const uint32_t e = sym[src[i]]; bw.put(e & 0xFFFFu, (int)(e >> 16)); }
 }
 
-void encode_block(BitWriter &bw, const uint8_t *src, size_t n, bool final) {
-    // four interleaved histograms: FASTQ repeats a handful of byte values, and one counter per value
-    // would serialise on its own store
-    uint32_t h[4][256];
-    memset(h, 0, sizeof(h));
-    size_t i = 0;
-    for (; i + 4 <= n; i += 4) { h[0][src[i]]++; h[1][src[i + 1]]++; h[2][src[i + 2]]++; h[3][src[i + 3]]++; }
-    for (; i < n; i++) h[0][src[i]]++;
-    uint32_t freq[257];
-    for (int v = 0; v < 256; v++) freq[v] = h[0][v] + h[1][v] + h[2][v] + h[3][v];
-    freq[256] = 1;  // end of block
-    uint8_t len[258];
-    huffman_lengths(freq, 257, 15, len);
-    len[257] = 0;  // the one distance code: unused (literals only)
-    uint16_t code[257];
-    canonical_codes(len, 257, code);
-    // the 258 code lengths as code-length symbols: lengths as they are, runs of zeros as 17 (3-10) / 18 (11-138)
+// length symbol (257..285), extra bits and their value for a match length 3..258 (RFC 1951 3.2.5)
+struct LenCode { uint16_t sym; uint8_t extra_bits; uint8_t extra; };
+const LenCode *length_codes() {
+    static LenCode table[259];
+    static const bool once = [] {
+        static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        for (int len = 3; len <= 258; len++) {
+            int c = 28;
+            while (base[c] > len) c--;
+            if (len == 258) c = 28;
+            table[len] = LenCode{(uint16_t)(257 + c), bits[c], (uint8_t)(len - base[c])};
+        }
+        return true;
+    }();
+    (void)once;
+    return table;
+}
+
+// header of a dynamic block for `nlit` literal/length code lengths followed by one distance code length
+void put_block_header(BitWriter &bw, const uint8_t *len, int nlit, bool final) {
+    const int total = nlit + 1;
+    // the code lengths as code-length symbols: lengths as they are, runs of zeros as 17 (3-10) / 18 (11-138)
     struct Cl { uint8_t sym, extra_bits; uint16_t extra; };
-    Cl cl[258];
+    Cl cl[288];
     int ncl = 0;
-    for (int k = 0; k < 258;) {
+    for (int k = 0; k < total;) {
         if (len[k] != 0) { cl[ncl++] = Cl{len[k], 0, 0}; k++; continue; }
         int run = 1;
-        while (k + run < 258 && len[k + run] == 0) run++;
+        while (k + run < total && len[k + run] == 0) run++;
         int left = run;
         while (left >= 11) { const int r = std::min(left, 138); cl[ncl++] = Cl{18, 7, (uint16_t)(r - 11)}; left -= r; }
         if (left >= 3) { cl[ncl++] = Cl{17, 3, (uint16_t)(left - 3)}; left = 0; }
@@ -155,17 +163,91 @@ void encode_block(BitWriter &bw, const uint8_t *src, size_t n, bool final) {
     static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     int hclen = 19;
     while (hclen > 4 && cllen[order[hclen - 1]] == 0) hclen--;
-    bw.ensure(2 * n + 1024);  // literals take at most 15 bits each, the header under 400 bytes
     bw.put(final ? 1u : 0u, 1);
-    bw.put(2u, 2);               // dynamic Huffman codes
-    bw.put(0u, 5);               // HLIT: 257 literal/length codes
-    bw.put(0u, 5);               // HDIST: 1 distance code
+    bw.put(2u, 2);                        // dynamic Huffman codes
+    bw.put((uint32_t)(nlit - 257), 5);    // HLIT
+    bw.put(0u, 5);                        // HDIST: 1 distance code
     bw.put((uint32_t)(hclen - 4), 4);
     for (int k = 0; k < hclen; k++) bw.put(cllen[order[k]], 3);
     for (int k = 0; k < ncl; k++) {
         bw.put(clcode[cl[k].sym], cllen[cl[k].sym]);
         if (cl[k].extra_bits) bw.put(cl[k].extra, cl[k].extra_bits);
     }
+}
+
+// A block whose bytes come in runs (constant or binned qualities, homopolymers): a run is its first
+// byte as a literal, then matches at distance 1 - the only distance this encoder knows, so the
+// distance code is one 1-bit symbol.  Tokens: a literal is its value, a match is 0x8000 | length.
+void encode_block_runs(BitWriter &bw, const uint8_t *src, size_t n, bool final) {
+    static thread_local std::vector<uint16_t> tokens;
+    tokens.clear();
+    tokens.reserve(n);
+    uint32_t freq[286] = {0};
+    const LenCode *lc = length_codes();
+    for (size_t i = 0; i < n;) {
+        const uint8_t v = src[i];
+        size_t run = 1;
+        while (i + run < n && src[i + run] == v) run++;
+        tokens.push_back(v);
+        freq[v]++;
+        size_t left = run - 1;
+        while (left >= 3) {
+            size_t m = std::min<size_t>(left, 258);
+            if (left - m > 0 && left - m < 3) m = left - 3;  // never strand one or two bytes behind a full match
+            tokens.push_back((uint16_t)(0x8000u | m));
+            freq[lc[m].sym]++;
+            left -= m;
+        }
+        for (; left > 0; left--) { tokens.push_back(v); freq[v]++; }
+        i += run;
+    }
+    freq[256] = 1;
+    int nlit = 286;
+    while (nlit > 257 && freq[nlit - 1] == 0) nlit--;
+    uint8_t len[287];
+    huffman_lengths(freq, nlit, 15, len);
+    uint16_t code[286];
+    canonical_codes(len, nlit, code);
+    len[nlit] = 1;  // the distance code: one symbol (distance 1), one bit, value 0
+    bw.ensure(2 * n + 1024);
+    put_block_header(bw, len, nlit, final);
+    for (size_t t = 0; t < tokens.size(); t++) {
+        const uint16_t tok = tokens[t];
+        if (tok < 0x8000u) {
+            bw.add(code[tok], len[tok]);
+        } else {
+            const LenCode &l = lc[tok & 0x7FFFu];
+            bw.add(code[l.sym], len[l.sym]);
+            bw.add(l.extra, l.extra_bits);
+            bw.add(0u, 1);
+        }
+        bw.flush();  // at most 15 + 5 + 1 bits per token on top of 7 waiting
+    }
+    bw.put(code[256], len[256]);
+}
+
+void encode_block(BitWriter &bw, const uint8_t *src, size_t n, bool final) {
+    // four interleaved histograms: FASTQ repeats a handful of byte values, and one counter per value
+    // would serialise on its own store; the same pass counts bytes that repeat their predecessor
+    uint32_t h[4][256];
+    memset(h, 0, sizeof(h));
+    size_t i = 0, same = 0;
+    for (; i + 4 <= n; i += 4) { h[0][src[i]]++; h[1][src[i + 1]]++; h[2][src[i + 2]]++; h[3][src[i + 3]]++; }
+    for (; i < n; i++) h[0][src[i]]++;
+    for (i = 1; i < n; i++) same += src[i] == src[i - 1];
+    // uniform random bases repeat their predecessor a quarter of the time and runs of four or more
+    // cover 1.6 % of them: nothing to gain.  Past 40 % there are real runs.
+    if (same * 5 > n * 2) return encode_block_runs(bw, src, n, final);
+    uint32_t freq[257];
+    for (int v = 0; v < 256; v++) freq[v] = h[0][v] + h[1][v] + h[2][v] + h[3][v];
+    freq[256] = 1;  // end of block
+    uint8_t len[258];
+    huffman_lengths(freq, 257, 15, len);
+    len[257] = 0;  // the one distance code: unused (literals only)
+    uint16_t code[257];
+    canonical_codes(len, 257, code);
+    bw.ensure(2 * n + 1024);  // literals take at most 15 bits each, the header under 400 bytes
+    put_block_header(bw, len, 257, final);
     uint32_t sym[256];
     int longest = 0;
     for (int v = 0; v < 256; v++) { sym[v] = (uint32_t)code[v] | ((uint32_t)len[v] << 16); longest = std::max<int>(longest, len[v]); }
@@ -188,13 +270,22 @@ bool tbk_gzip_member_literal(const char *src, size_t n, std::vector<char> &out) 
         bw.ensure(16);
         bw.put(1u, 1); bw.put(1u, 2); bw.put(0u, 7);  // final block, fixed codes, end of block
     } else {
-        // a block ends at the first line end past 8 KiB (64 KiB at most): the bases of a long read and
-        // its qualities then get codes of their own - 2 bits a base instead of a code stretched over
-        // both alphabets - and short reads are grouped so that the ~60-byte header stays under 1 %
-        static const size_t least = getenv("TBK_GZIP_BLOCK") ? (size_t)atol(getenv("TBK_GZIP_BLOCK")) : (size_t)8 << 10;
-        const size_t most = std::max<size_t>(least, (size_t)64 << 10);
+        // Long lines (the second line of a block - after "@name" or "+" - runs past 2 KiB): a block ends
+        // at the first line end past 8 KiB, 64 KiB at most, so that the bases of a long read and its
+        // qualities get codes of their own - 2 bits a base instead of a code stretched over both
+        // alphabets.  Short lines: bases and qualities alternate too fast to separate, and blocks of
+        // 32 KiB keep the ~70-byte header under 1/4 %.
+        static const size_t pinned = getenv("TBK_GZIP_BLOCK") ? (size_t)atol(getenv("TBK_GZIP_BLOCK")) : 0;
         for (size_t off = 0; off < n;) {
             size_t m = n - off;
+            size_t least = pinned;
+            if (!least) {
+                const char *first = (const char *)memchr(src + off, '\n', std::min<size_t>(m, 2048));
+                const size_t used = first ? (size_t)(first - (src + off)) + 1 : m;
+                const bool short_lines = first && (used == m || memchr(first + 1, '\n', std::min<size_t>(m - used, 2048)) != nullptr);
+                least = short_lines ? (size_t)32 << 10 : (size_t)8 << 10;
+            }
+            const size_t most = std::max<size_t>(least, (size_t)64 << 10);
             if (m > least) {
                 const size_t span = std::min(m, most) - least;
                 const void *nl = memchr(src + off + least, '\n', span);

@@ -1054,10 +1054,10 @@ bool tbk_gzip_member_literal(const char *src, size_t n, std::vector<char> &out);
 
 // one gzip member per chunk; concatenated members are a valid gzip file
 static bool deflate_member(const char *src, size_t n, int level, std::vector<char> &dst) {
-    // bytes that do not come in runs: entropy coding is all there is to gain, and the library's own
-    // literal-only encoder does it several times faster than zlib's Z_HUFFMAN_ONLY
-    static const bool own = !(getenv("TBK_GZIP_ENCODER") && strcmp(getenv("TBK_GZIP_ENCODER"), "zlib") == 0);
-    if (own && level > 0 && deflate_strategy(src, n) == Z_HUFFMAN_ONLY) return tbk_gzip_member_literal(src, n, dst);
+    // the library's own encoder (tbk_deflate.cpp: Huffman coding per line-aligned block, runs as
+    // distance-1 matches) unless zlib is asked for or a zlib strategy is pinned
+    static const bool own = !(getenv("TBK_GZIP_ENCODER") && strcmp(getenv("TBK_GZIP_ENCODER"), "zlib") == 0) && !getenv("TBK_GZIP_STRATEGY");
+    if (own && level > 0) return tbk_gzip_member_literal(src, n, dst);
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, deflate_strategy(src, n)) != Z_OK) return false;
