@@ -1028,6 +1028,8 @@ static bool write_all(int fd, const char *p, size_t n, std::string &err) {
     return true;
 }
 
+// The zlib path of the gzip members (TBK_GZIP_ENCODER=zlib or a pinned TBK_GZIP_STRATEGY; the default
+// is the library's own encoder, tbk_deflate.cpp).
 // FASTQ text is bases (no LZ77 match worth having in a 32 KiB window) and qualities.  zlib's default
 // strategy spends 8-10 times the time of its match-free ones for nothing (0.43 against 0.43-0.44 of the
 // input on HiFi-like records) - and the gzip members are what a run with compressed output waits
