@@ -137,12 +137,21 @@ def test_reader_inflates_bgzf_blocks_side_by_side(built, tmp_path):
             _native_records(str(f))
 
 
-def test_own_inflate_equals_zlib(built, tmp_path, monkeypatch):
+@pytest.mark.parametrize("guessing", [False, True])
+def test_own_inflate_equals_zlib(built, tmp_path, monkeypatch, guessing):
     """Ordinary gzip streams go through the library's own DEFLATE decoder; TBK_INFLATE=zlib keeps
     zlib's.  Same records from both on stored / fast / default / best compression, fixed-Huffman
     blocks, header extras (FEXTRA, FNAME, FCOMMENT), several members with zero padding between them,
-    highly repetitive and single-symbol data; damaged streams are refused, never mis-decoded."""
+    highly repetitive and single-symbol data; damaged streams are refused, never mis-decoded.
+    guessing: the same through the several-thread decoder (LineSource::pinflate_loop), made to cut
+    even these small files into 4 KiB spans."""
     import zlib
+
+    if guessing:
+        monkeypatch.setenv("TBK_PINFLATE_MIN", "0")
+        monkeypatch.setenv("TBK_PINFLATE_SPAN", "4096")
+    else:
+        monkeypatch.setenv("TBK_PINFLATE", "0")
 
     from trio_binning_amd import _lib
 
@@ -557,3 +566,86 @@ def test_writer_gzip_encoders_agree(built, tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append(r.stdout.split())
     assert digests[0] == digests[1] and len(set(digests[0])) == 3
+
+
+def test_guessing_inflate_equals_the_sequential_decoder(built, tmp_path, monkeypatch, capfd):
+    """A gzip stream large enough for the several-thread decoder at realistic span sizes: single member
+    (zlib levels 1, 6, 9: blocks of different sizes, matches reaching back across chunk borders),
+    several members of uneven size (one ends in every other round), a member of stored blocks (no
+    dynamic block to guess at) in front of a compressed one.  Same records, in the same batches, as
+    with TBK_PINFLATE=0; a flipped bit deep in the file, a cut-off file and a wrong CRC are refused."""
+    import zlib
+
+    from trio_binning_amd import _lib, seq
+
+    rng = np.random.default_rng(8)
+    n, length = 1500, 9000
+    bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (n, length))
+    quals = (33 + np.clip(rng.normal(30, 8, (n, length)), 0, 60)).astype(np.uint8)
+    parts = []
+    for i in range(n):
+        if i % 3 == 1:
+            bases[i, : length // 2] = bases[i - 1, length // 4: length // 4 + length // 2]  # something for LZ77 to find
+        parts.append(b"@read%d/ccs np=%d\n" % (i, i % 17) + bases[i].tobytes() + b"\n+\n" + quals[i].tobytes() + b"\n")
+    text = b"".join(parts)
+
+    def member(data, level, strategy=zlib.Z_DEFAULT_STRATEGY):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+        return co.compress(data) + co.flush()
+
+    third = len(text) // 3
+    files = {
+        "l1": member(text, 1), "l6": member(text, 6), "l9": member(text, 9),
+        "members": member(text[:third], 6) + member(text[third:third + 100], 9) + member(text[third + 100:], 1),
+        "stored_first": member(text[:third], 0) + b"\0" * 5 + member(text[third:], 6),
+        "fixed_blocks": member(text[:third], 6, zlib.Z_FIXED) + member(text[third:], 6),
+    }
+
+    def read_all(path):
+        sizes, digest = [], __import__("hashlib").sha256()
+        with seq.BatchReader(str(path)) as r:
+            b = seq.Batch()
+            while r.next_batch(b, 3 << 20, 0):
+                sizes.append(b.n_reads)
+                for a in b.arrays():
+                    digest.update(a.tobytes())
+        return sizes, digest.hexdigest()
+
+    monkeypatch.setenv("TBK_PINFLATE_MIN", "0")
+    want = None
+    for name, blob in files.items():
+        f = tmp_path / f"{name}.fastq.gz"
+        f.write_bytes(blob)
+        monkeypatch.setenv("TBK_PINFLATE", "0")
+        ref = read_all(f)
+        assert sum(ref[0]) == n
+        want = want or ref
+        assert ref == want, name
+        monkeypatch.delenv("TBK_PINFLATE")
+        for span in (300_000, 70_000):
+            monkeypatch.setenv("TBK_PINFLATE_SPAN", str(span))
+            assert read_all(f) == want, (name, span)
+    # the guesses do hold on such a stream: most rounds keep every chunk they decoded
+    monkeypatch.setenv("TBK_PINFLATE_SPAN", "200000")
+    monkeypatch.setenv("TBK_PINFLATE_TIMING", "1")
+    capfd.readouterr()
+    assert read_all(tmp_path / "l6.fastq.gz") == want
+    monkeypatch.delenv("TBK_PINFLATE_TIMING")
+    import re
+    rounds = [(int(g), int(k)) for g, k in re.findall(r"(\d+) guesses, (\d+) chunks kept", capfd.readouterr().err)]
+    assert len(rounds) >= 3 and sum(k for _, k in rounds) >= 0.8 * sum(g + 1 for g, _ in rounds) and max(k for _, k in rounds) >= 4, rounds
+    good = files["l6"]
+    for kind in ("flip", "cut", "crc", "size"):
+        blob = bytearray(good)
+        if kind == "flip":
+            blob[len(blob) * 3 // 4] ^= 0x10
+        elif kind == "cut":
+            blob = blob[: len(blob) * 2 // 3]
+        elif kind == "crc":
+            blob[-6] ^= 1
+        else:
+            blob[-2] ^= 1
+        f = tmp_path / "bad.fastq.gz"
+        f.write_bytes(bytes(blob))
+        with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
+            read_all(f)

@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <deque>
 #include <condition_variable>
@@ -53,6 +54,38 @@ static int ffail(int code, const char *fmt, ...) {
     va_end(ap);
     tbk_set_error_(code, buf);
     return code;
+}
+
+// Second pass of the guessing inflater (LineSource::pinflate_loop): 16-bit symbols -> bytes.  A symbol
+// is a byte value or a marker 0x8000 + i for byte i of the window `w` in front of the chunk.  Returns
+// the OR of everything stored: above 0xFF when a marker pointed before the member's first byte.
+static uint32_t resolve_symbols(const uint16_t *src, size_t n, const uint16_t *w, uint8_t *dst) {
+    uint32_t seen = 0;
+    for (size_t k = 0; k < n; k++) {
+        uint32_t v = src[k];
+        if (v >= 0x8000u) v = w[v - 0x8000u];
+        seen |= v;
+        dst[k] = (uint8_t)v;
+    }
+    return seen;
+}
+__attribute__((target("avx2"))) static uint32_t resolve_symbols_avx2(const uint16_t *src, size_t n, const uint16_t *w, uint8_t *dst) {
+    uint32_t seen = 0;
+    __m256i seen_v = _mm256_setzero_si256();
+    size_t k = 0;
+    for (; k + 32 <= n; k += 32) {  // 32 symbols without a marker among them (the rule, past a chunk's first stretch): narrow and store
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + k)), b = _mm256_loadu_si256((const __m256i *)(src + k + 16));
+        if ((uint32_t)_mm256_movemask_epi8(_mm256_or_si256(a, b)) & 0xAAAAAAAAu) {
+            seen |= resolve_symbols(src + k, 32, w, dst + k);
+            continue;
+        }
+        seen_v = _mm256_or_si256(seen_v, _mm256_or_si256(a, b));
+        _mm256_storeu_si256((__m256i *)(dst + k), _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8));
+    }
+    alignas(32) uint16_t lanes[16];
+    _mm256_store_si256((__m256i *)lanes, seen_v);
+    for (int q = 0; q < 16; q++) seen |= lanes[q];
+    return seen | resolve_symbols(src + k, n - k, w, dst + k);
 }
 
 // =======================================================================================
@@ -150,10 +183,23 @@ struct LineSource {
     std::condition_variable cv;
     std::deque<Chunk> ready;
     bool stop = false, started = false;
+    size_t queue_cap = 3;
 
+    // buffers of chunks the parser is done with, for the next chunks (a fresh 8 MiB vector is a
+    // trip to the kernel, a zero-fill and two thousand page faults)
+    std::vector<std::vector<uint8_t>> spare;
+    std::vector<uint8_t> take_buffer(size_t n) {
+        std::vector<uint8_t> v;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!spare.empty()) { v.swap(spare.back()); spare.pop_back(); }
+        }
+        if (v.size() < n) { std::vector<uint8_t>().swap(v); v.resize(n); }  // a vector that grows copies its old bytes: start anew
+        return v;
+    }
     void push(Chunk &&c) {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return stop || ready.size() < 3; });
+        cv.wait(lk, [&] { return stop || ready.size() < queue_cap; });
         if (stop) return;
         ready.push_back(std::move(c));
         cv.notify_all();
@@ -213,9 +259,187 @@ struct LineSource {
             if (done) return;
         }
     }
+    // ---- an ordinary gzip stream on several threads -------------------------------------------------
+    // DEFLATE is one chain: a block can be found only by decoding the one before it, and a match may
+    // reach 32 KiB back into text that is not there yet.  Both are broken by guessing, and every guess
+    // is checked (the idea of pugz / rapidgzip, restated for this reader's chunks).  A round cuts the
+    // next stretch of the file into one span per thread.  Thread 0 continues the exact decoder.  Every
+    // other thread looks for the first bit of its span where a dynamic-Huffman block can begin
+    // (TbkInflate::open_dynamic_block_at: type bits, code counts, complete codes) and decodes from there
+    // into 16-bit symbols: a byte value, or - where a match reaches back before the thread's own
+    // output - a marker 0x8000 + i for "byte i of the 32 KiB window I do not have".  A thread stops in
+    // front of the first block header at or past the next thread's guess.  Then the guesses are
+    // checked in order: thread i's output counts only if thread i-1's counted and ended EXACTLY on
+    // thread i's starting bit - so by induction every accepted chunk starts on a block boundary of
+    // the real chain, and what it decoded is what the sequential decoder decodes there.  The windows
+    // are then filled in front to back (only the last 32 KiB of each chunk, one after the other), the
+    // markers replaced and the CRCs taken by all threads, and the chunks handed to the parser in order.
+    // A guess that fails, a member that ends, a chunk that outgrows its buffer: the round is cut
+    // there, the exact decoder takes over that state, and the next round goes on from it.
+    // Text, CRC checks and errors are those of inflate_loop().  TBK_PINFLATE=0 turns this off;
+    // TBK_PINFLATE_SPAN / TBK_PINFLATE_MIN set the span and the least file size (tests).
+    static size_t env_size(const char *name, size_t dflt) {
+        const char *e = getenv(name);
+        return e && *e ? (size_t)strtoull(e, nullptr, 10) : dflt;
+    }
+    bool guessing() const {
+        const char *e = getenv("TBK_PINFLATE");
+        if (e && strcmp(e, "0") == 0) return false;
+        return fast && threads >= 3 && map_size >= env_size("TBK_PINFLATE_MIN", (size_t)16 << 20);
+    }
+    struct GuessJob {
+        TbkInflate dec;
+        uint64_t start_bit = 0, stop_bit = 0;
+        std::unique_ptr<uint16_t[]> sym;  // [ 32 Ki window | output ]; never zero-filled: its pages are first touched by the thread that decodes into them
+        size_t sym_cap = 0;
+        size_t n = 0;               // output symbols
+        TbkInflate::Status st = TbkInflate::ERROR;
+        std::vector<uint16_t> window;  // the real window in front of this chunk (filled in when known)
+        Chunk out;
+        uint32_t crc = 0;
+        bool bad_symbol = false;
+    };
+    void pinflate_loop() {
+        constexpr size_t HIST = 32768;
+        constexpr uint16_t NOTHING = 0x7FFF;  // window position before the member's first byte
+        const size_t span = std::max<size_t>(env_size("TBK_PINFLATE_SPAN", (size_t)2 << 20), 4096);
+        size_t cap = std::max<size_t>(span * 5, (size_t)1 << 16);  // symbols per chunk; grows when chunks hit it
+        const int nt = std::min(threads, 32);
+        { std::lock_guard<std::mutex> lk(mu); queue_cap = (size_t)(2 * nt); }
+        std::vector<GuessJob> jobs((size_t)nt);
+        std::vector<uint16_t> tail(HIST, NOTHING);  // window in front of the exact decoder
+        int rest = 0, backoff = 1;                  // rounds without guesses after a round that wasted them
+        auto run_threads = [&](int n, auto &&fn) {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < n; t++) pool.emplace_back([&fn, t] { fn(t); });
+            fn(0);
+            for (std::thread &th : pool) th.join();
+        };
+        const bool timing = getenv("TBK_PINFLATE_TIMING") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (;;) {
+            { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
+            const size_t base = (size_t)(inf.bit_position() >> 3);
+            const double t0 = now();
+            // ---- guesses ----
+            int n_jobs = 1;
+            if (rest > 0) {
+                rest--;
+            } else {
+                std::vector<uint64_t> found((size_t)nt, ~0ull);
+                run_threads(nt, [&](int t) {
+                    if (t == 0) return;
+                    const size_t lo = base + (size_t)t * span, hi = std::min(map_size, lo + span);
+                    if (lo + 64 >= map_size) return;
+                    TbkInflate &d = jobs[(size_t)t].dec;
+                    for (uint64_t bit = (uint64_t)lo * 8; bit < (uint64_t)hi * 8; bit++)
+                        if (d.open_dynamic_block_at(map, map_size, bit)) { found[(size_t)t] = bit; return; }
+                });
+                for (int t = 1; t < nt; t++) {
+                    if (found[(size_t)t] == ~0ull) continue;
+                    if (n_jobs != t) jobs[(size_t)n_jobs].dec = jobs[(size_t)t].dec;
+                    jobs[(size_t)n_jobs].start_bit = found[(size_t)t];
+                    n_jobs++;
+                }
+            }
+            jobs[0].dec = inf;
+            jobs[0].start_bit = inf.bit_position();
+            for (int i = 0; i < n_jobs; i++) {
+                GuessJob &j = jobs[(size_t)i];
+                // the last chunk of a round ends at the first block boundary past its span
+                j.stop_bit = i + 1 < n_jobs ? jobs[(size_t)i + 1].start_bit : ((j.start_bit >> 3) + span) * 8;  // may lie past the end of the file: then the file ends first
+                if (j.sym_cap < HIST + cap + 512) { j.sym_cap = HIST + cap + 512; j.sym.reset(new uint16_t[j.sym_cap]); }
+                if (i == 0) memcpy(j.sym.get(), tail.data(), HIST * 2);
+                else for (size_t w = 0; w < HIST; w++) j.sym[w] = (uint16_t)(0x8000u + w);
+            }
+            const double t1 = now();
+            // ---- first pass: decode ----
+            run_threads(n_jobs, [&](int t) {
+                GuessJob &j = jobs[(size_t)t];
+                size_t pos = HIST;
+                j.st = j.dec.run16(j.sym.get(), &pos, HIST + cap, j.stop_bit);
+                j.n = pos - HIST;
+            });
+            const double t2 = now();
+            // ---- which guesses hold ----
+            int good = 1;
+            while (good < n_jobs) {
+                const GuessJob &prev = jobs[(size_t)good - 1];
+                if (prev.st != TbkInflate::BOUNDARY || prev.dec.bit_position() != jobs[(size_t)good].start_bit) break;
+                if (jobs[(size_t)good].st == TbkInflate::ERROR) break;  // the exact decoder will meet it and say what it is
+                good++;
+            }
+            if (n_jobs > 1 && good * 2 < n_jobs) { rest = backoff; backoff = std::min(backoff * 2, 64); }
+            else if (n_jobs > 1) backoff = 1;
+            for (int i = 0; i < good; i++)
+                if (jobs[(size_t)i].st == TbkInflate::NEED_OUTPUT) cap = std::min(cap * 2, span * 64);
+            // ---- the windows, front to back ----
+            auto window_after = [&](const GuessJob &j, const std::vector<uint16_t> &before) {
+                std::vector<uint16_t> w(HIST);
+                if (j.st == TbkInflate::MEMBER_DONE) { std::fill(w.begin(), w.end(), NOTHING); return w; }
+                const size_t take = std::min(HIST, j.n), keep = HIST - take;
+                memcpy(w.data(), before.data() + (HIST - keep), keep * 2);
+                const uint16_t *src = j.sym.get() + HIST + j.n - take;
+                for (size_t k = 0; k < take; k++) { const uint16_t v = src[k]; w[keep + k] = v >= 0x8000u ? before[v - 0x8000u] : v; }
+                return w;
+            };
+            jobs[0].window = tail;
+            for (int i = 1; i < good; i++) jobs[(size_t)i].window = window_after(jobs[(size_t)i - 1], jobs[(size_t)i - 1].window);
+            std::vector<uint16_t> next_tail = window_after(jobs[(size_t)good - 1], jobs[(size_t)good - 1].window);
+            // ---- second pass: markers -> bytes, CRC ----
+            run_threads(good, [&](int t) {
+                GuessJob &j = jobs[(size_t)t];
+                j.out = Chunk();
+                j.out.data = take_buffer(j.n);
+                static const bool avx2 = __builtin_cpu_supports("avx2");
+                const uint32_t seen = avx2 ? resolve_symbols_avx2(j.sym.get() + HIST, j.n, j.window.data(), j.out.data.data())
+                                           : resolve_symbols(j.sym.get() + HIST, j.n, j.window.data(), j.out.data.data());
+                j.bad_symbol = seen > 0xFFu;
+                uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+                for (size_t p = 0; p < j.n; p += (size_t)1 << 30) c = (uint32_t)crc32(c, j.out.data.data() + p, (uInt)std::min<size_t>(j.n - p, (size_t)1 << 30));
+                j.crc = c;
+                j.out.off = 0; j.out.len = j.n;
+            });
+            const double t3 = now();
+            if (timing) {
+                size_t text = 0;
+                for (int i = 0; i < good; i++) text += jobs[(size_t)i].n;
+                fprintf(stderr, "tbk-pinflate round at byte %zu: %d guesses, %d chunks kept, %.1f MB of text: guess %.1f ms, decode %.1f ms, resolve %.1f ms\n",
+                        base, n_jobs - 1, good, text / 1e6, t1 - t0, t2 - t1, t3 - t2);
+            }
+            // ---- hand over, in order ----
+            for (int i = 0; i < good; i++) {
+                GuessJob &j = jobs[(size_t)i];
+                std::string problem;
+                if (j.bad_symbol) problem = "inflate: distance too far back";
+                else if (j.st == TbkInflate::ERROR) problem = std::string("inflate: ") + j.dec.error();
+                if (problem.empty()) {
+                    member_crc = (uint32_t)crc32_combine(member_crc, j.crc, (z_off_t)j.n);
+                    member_size += j.n;
+                    if (j.st == TbkInflate::MEMBER_DONE) {
+                        if (member_crc != j.dec.trailer_crc() || (uint32_t)member_size != j.dec.trailer_isize()) problem = "inflate: gzip CRC or size mismatch";
+                        member_crc = (uint32_t)crc32(0L, Z_NULL, 0);
+                        member_size = 0;
+                    }
+                }
+                if (!problem.empty()) {
+                    Chunk c;
+                    c.err = problem; c.last = true;
+                    push(std::move(c));
+                    return;
+                }
+                const bool done = j.st == TbkInflate::INPUT_DONE;
+                j.out.last = done;
+                if (j.out.len || done) push(std::move(j.out));
+                if (done) return;
+            }
+            inf = jobs[(size_t)good - 1].dec;
+            tail.swap(next_tail);
+        }
+    }
     // own decoder: returns like refill()
     bool refill_fast() {
-        if (!started) { started = true; worker = std::thread([this] { if (bgzf) bgzf_loop(); else inflate_loop(); }); }
+        if (!started) { started = true; worker = std::thread([this] { if (bgzf) bgzf_loop(); else if (guessing()) pinflate_loop(); else inflate_loop(); }); }
         Chunk c;
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -239,6 +463,10 @@ struct LineSource {
         if (c.len) memcpy(buf.data() + end, c.data.data() + c.off, c.len);
         end += c.len;
         if (c.last) text_eof = true;
+        if (!c.data.empty()) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (spare.size() < 2 * queue_cap) spare.push_back(std::move(c.data));
+        }
         return true;
     }
     // total size of the BGZF block starting at p (0 if p does not start one or n < 18)

@@ -213,9 +213,21 @@ bool TbkInflate::read_block_head() {
 }
 
 TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t member_start) {
-    uint8_t *op = out + *pos;
-    uint8_t *const oend = out + cap;
-    const uint8_t *const floor_ = out + member_start;  // matches may not start before this
+    return run_impl<uint8_t>(out, pos, cap, member_start, ~0ull);
+}
+
+TbkInflate::Status TbkInflate::run16(uint16_t *out, size_t *pos, size_t cap, uint64_t stop_bit) {
+    return run_impl<uint16_t>(out, pos, cap, 0, stop_bit);
+}
+
+// T = uint8_t: the text.  T = uint16_t: one symbol per element - a byte value, or whatever the caller put
+// in front of the write position and a match copied from there (tbk_pinflate.cpp: markers for a
+// window that is not known yet).
+template <class T>
+TbkInflate::Status TbkInflate::run_impl(T *out, size_t *pos, size_t cap, size_t member_start, uint64_t stop_bit) {
+    T *op = out + *pos;
+    T *const oend = out + cap;
+    const T *const floor_ = out + member_start;  // matches may not start before this
     constexpr uint32_t LMASK = (1u << LBITS) - 1, DMASK = (1u << DBITS) - 1;
     for (;;) {
         switch (state_) {
@@ -224,6 +236,7 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
             if (state_ == HEADER) { *pos = (size_t)(op - out); return INPUT_DONE; }  // nothing but padding left
             break;
         case BLOCK_HEAD:
+            if (bit_position() >= stop_bit) { *pos = (size_t)(op - out); return BOUNDARY; }
             if (!read_block_head()) return ERROR;
             if (bits_consumed_past_end()) return fail("truncated gzip file");
             break;
@@ -235,7 +248,8 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
                 size_t n = stored_left_;
                 if (n > room) n = room;
                 if (n > have) n = have;
-                memcpy(op, ip_, n);
+                if (sizeof(T) == 1) memcpy(op, ip_, n);
+                else for (size_t i = 0; i < n; i++) op[i] = (T)ip_[i];
                 op += n; ip_ += n; stored_left_ -= (uint32_t)n;
             }
             state_ = last_block_ ? TRAILER : BLOCK_HEAD;
@@ -243,7 +257,7 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
         }
         case HUFF: {
             if (oend - op < 320) { *pos = (size_t)(op - out); return NEED_OUTPUT; }
-            uint8_t *const olimit = oend - 320;
+            T *const olimit = oend - 320;
             bool block_done = false;
             // the decoder state lives in locals inside the loop: the byte stores to `op` could alias the
             // members, which would force a reload of the bit buffer after every literal
@@ -277,7 +291,8 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
                     do {                                                              \
                         bb >>= (e & 0xFF); bc -= (int)(e & 0xFF);                     \
                         const uint16_t v_ = (uint16_t)(e >> 16);                      \
-                        memcpy(op, &v_, 2);                                           \
+                        if (sizeof(T) == 1) memcpy(op, &v_, 2);                       \
+                        else { op[0] = (T)(v_ & 0xFFu); op[1] = (T)(v_ >> 8); }       \
                         op += 1 + ((e >> 15) & 1u);                                   \
                     } while (0)
                     TBK_EMIT();
@@ -315,13 +330,16 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
                 const uint32_t dist = (d >> 16) + (uint32_t)(bb & ((1ull << de) - 1));
                 bb >>= de; bc -= de;
                 if ((size_t)(op - floor_) < dist) { bad = "distance too far back"; break; }
-                const uint8_t *src = op - dist;
-                uint8_t *const end = op + len;
-                if (dist >= 8) {
-                    do { uint64_t w; memcpy(&w, src, 8); memcpy(op, &w, 8); op += 8; src += 8; } while (op < end);
+                const T *src = op - dist;
+                T *const end = op + len;
+                constexpr uint32_t PER = 8 / sizeof(T);  // elements per 8-byte copy
+                if (dist >= PER) {
+                    do { uint64_t w; memcpy(&w, src, 8); memcpy(op, &w, 8); op += PER; src += PER; } while (op < end);
                     op = end;
                 } else if (dist == 1) {
-                    memset(op, *src, len);
+                    const T v = *src;
+                    if (sizeof(T) == 1) memset(op, (int)v, len);
+                    else for (uint32_t i = 0; i < len; i++) op[i] = v;
                     op = end;
                 } else {
                     while (op < end) *op++ = *src++;
@@ -348,4 +366,36 @@ TbkInflate::Status TbkInflate::run(uint8_t *out, size_t *pos, size_t cap, size_t
         }
         }
     }
+}
+
+template TbkInflate::Status TbkInflate::run_impl<uint8_t>(uint8_t *, size_t *, size_t, size_t, uint64_t);
+template TbkInflate::Status TbkInflate::run_impl<uint16_t>(uint16_t *, size_t *, size_t, size_t, uint64_t);
+
+// Does a dynamic-Huffman, non-final block begin at bit `bitpos`?  A cheap look at the first bits
+// (type, code counts, a complete code-length code) before the tables are built for real; on success
+// the decoder stands behind that block's header.
+bool TbkInflate::open_dynamic_block_at(const uint8_t *data, size_t size, uint64_t bitpos) {
+    const size_t byte = (size_t)(bitpos >> 3);
+    if (byte + 16 > size) return false;
+    uint64_t w0, w1;
+    memcpy(&w0, data + byte, 8);
+    memcpy(&w1, data + byte + 8, 8);
+    const int sh = (int)(bitpos & 7);
+    const unsigned __int128 v = (((unsigned __int128)w1 << 64) | w0) >> sh;  // 121+ bits from bitpos on; the header's fixed part takes 17 + 57 at most
+    const uint32_t lo = (uint32_t)v;
+    if ((lo & 7u) != 4u) return false;                     // BFINAL = 0, BTYPE = 2
+    if (((lo >> 3) & 31u) > 29u || ((lo >> 8) & 31u) > 29u) return false;  // HLIT, HDIST
+    const int n = (int)((lo >> 13) & 15u) + 4;
+    uint32_t kraft = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t len = (uint32_t)(v >> (17 + 3 * i)) & 7u;
+        if (len) kraft += 128u >> len;
+    }
+    if (kraft != 128u) return false;
+    reset(data, size);
+    ip_ = in_ + byte;
+    refill();
+    take(sh);
+    if (!read_block_head()) { err_ = nullptr; return false; }
+    return state_ == HUFF && !last_block_;
 }

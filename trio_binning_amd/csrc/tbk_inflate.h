@@ -1,7 +1,7 @@
 // tbk_inflate.h — a DEFLATE (RFC 1951) decoder for gzip members (RFC 1952), written for the one
 // thing the FASTX reader needs: inflate a memory-mapped .gz file into a text window as fast as one
-// core can.  A single gzip stream cannot be inflated in parallel, and for FASTQ(.gz) input that
-// stream is what both CLIs wait for; zlib 1.2.11 delivers ~0.55 GB/s of text here.  This decoder
+// core can.  A single gzip stream is one chain of dependencies (tbk_pinflate.cpp breaks it by
+// guessing), and for FASTQ(.gz) input that stream is what both CLIs wait for; zlib 1.2.11 delivers ~0.55 GB/s of text here.  This decoder
 // works the way the fast ones do: a 64-bit bit buffer refilled eight bytes at a time, one table
 // lookup per symbol (11-bit primary table for literals/lengths, 8-bit for distances, sub-tables
 // behind them for longer codes), word-wide match copies.
@@ -17,7 +17,7 @@
 
 class TbkInflate {
 public:
-    enum Status { NEED_OUTPUT, MEMBER_DONE, INPUT_DONE, ERROR };
+    enum Status { NEED_OUTPUT, MEMBER_DONE, INPUT_DONE, ERROR, BOUNDARY };
 
     void reset(const uint8_t *data, size_t size) {
         in_ = ip_ = data; in_end_ = data + size;
@@ -27,6 +27,15 @@ public:
     // current member (as far as it exists).  member_start = *pos at which the current member began
     // (matches may not reach before it).
     Status run(uint8_t *out, size_t *pos, size_t cap, size_t member_start);
+    // The same machine with 16-bit output elements: a literal is its byte value; a match copies
+    // elements, whatever they are - out[*pos - 32768 .. *pos) holds the window, as byte values where it
+    // is known and as markers of the caller's choosing where it is not (tbk_pinflate.cpp).  Returns
+    // BOUNDARY in front of the first block header at or past bit `stop_bit` of the input.
+    Status run16(uint16_t *out, size_t *pos, size_t cap, uint64_t stop_bit);
+    // bits of the input consumed so far (exact between blocks and between symbols)
+    uint64_t bit_position() const { return (uint64_t)(ip_ - in_) * 8 - (uint64_t)bitcnt_; }
+    // Start decoding at bit `bitpos` if a non-final dynamic-Huffman block can begin there.
+    bool open_dynamic_block_at(const uint8_t *data, size_t size, uint64_t bitpos);
     const char *error() const { return err_ ? err_ : ""; }
     // CRC-32 and ISIZE from the trailer of the member that just ended (after MEMBER_DONE)
     uint32_t trailer_crc() const { return t_crc_; }
@@ -83,6 +92,7 @@ private:
         bitbuf_ = 0; bitcnt_ = 0;
     }
     Status fail(const char *msg) { err_ = msg; return ERROR; }
+    template <class T> Status run_impl(T *out, size_t *pos, size_t cap, size_t member_start, uint64_t stop_bit);
     bool parse_header();
     bool read_block_head();
     bool build(const uint8_t *lens, int n, uint32_t *table, int table_size, int primary_bits, bool is_dist, bool is_codes = false);
