@@ -649,3 +649,33 @@ def test_guessing_inflate_equals_the_sequential_decoder(built, tmp_path, monkeyp
         f.write_bytes(bytes(blob))
         with pytest.raises((_lib.TbkError, ValueError, IOError, OSError)):
             read_all(f)
+
+
+def test_guessing_inflate_side_by_side(built, tmp_path, monkeypatch):
+    """Several gzip streams read at the same time (find-unique-kmers reads a library's files side by side):
+    each reader gets its share of the host threads, the records are those of a reader alone."""
+    import threading
+
+    rng = np.random.default_rng(12)
+    texts = []
+    for f in range(3):
+        n, length = 300 + 50 * f, 6000
+        bases = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), (n, length))
+        texts.append(b"".join(b"@f%d_%d\n" % (f, i) + bases[i].tobytes() + b"\n+\n" + b"I" * length + b"\n" for i in range(n)))
+        (tmp_path / f"lib{f}.fastq.gz").write_bytes(gzip.compress(texts[-1], 6))
+    monkeypatch.setenv("TBK_PINFLATE_MIN", "0")
+    monkeypatch.setenv("TBK_PINFLATE_SPAN", "100000")
+    got = [None] * 3
+
+    def read(f):
+        got[f] = _native_records(str(tmp_path / f"lib{f}.fastq.gz"), max_bases=1 << 20)
+
+    for rounds in range(2):
+        threads = [threading.Thread(target=read, args=(f,)) for f in range(3)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for f in range(3):
+            lines = texts[f].split(b"\n")
+            assert got[f] == [[lines[4 * i][1:].decode(), lines[4 * i + 1].decode(), lines[4 * i + 3].decode()] for i in range(len(lines) // 4)]

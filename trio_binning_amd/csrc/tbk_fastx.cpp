@@ -299,14 +299,18 @@ struct LineSource {
         uint32_t crc = 0;
         bool bad_symbol = false;
     };
+    // streams being inflated this way right now (find-unique-kmers reads a library's files side by
+    // side): they share the host threads instead of each taking all of them
+    static std::atomic<int> &guessers() { static std::atomic<int> n{0}; return n; }
     void pinflate_loop() {
+        struct Here { Here() { guessers()++; } ~Here() { guessers()--; } } here;
         constexpr size_t HIST = 32768;
         constexpr uint16_t NOTHING = 0x7FFF;  // window position before the member's first byte
         const size_t span = std::max<size_t>(env_size("TBK_PINFLATE_SPAN", (size_t)2 << 20), 4096);
         size_t cap = std::max<size_t>(span * 5, (size_t)1 << 16);  // symbols per chunk; grows when chunks hit it
-        const int nt = std::min(threads, 32);
-        { std::lock_guard<std::mutex> lk(mu); queue_cap = (size_t)(2 * nt); }
-        std::vector<GuessJob> jobs((size_t)nt);
+        const int nt_most = std::min(threads, 32);
+        { std::lock_guard<std::mutex> lk(mu); queue_cap = (size_t)(2 * nt_most); }
+        std::vector<GuessJob> jobs((size_t)nt_most);
         std::vector<uint16_t> tail(HIST, NOTHING);  // window in front of the exact decoder
         int rest = 0, backoff = 1;                  // rounds without guesses after a round that wasted them
         auto run_threads = [&](int n, auto &&fn) {
@@ -321,11 +325,12 @@ struct LineSource {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
             const size_t base = (size_t)(inf.bit_position() >> 3);
             const double t0 = now();
+            const int nt = std::max(1, nt_most / std::max(1, guessers().load()));
             // ---- guesses ----
             int n_jobs = 1;
             if (rest > 0) {
                 rest--;
-            } else {
+            } else if (nt >= 2) {
                 std::vector<uint64_t> found((size_t)nt, ~0ull);
                 run_threads(nt, [&](int t) {
                     if (t == 0) return;
@@ -372,7 +377,7 @@ struct LineSource {
             if (n_jobs > 1 && good * 2 < n_jobs) { rest = backoff; backoff = std::min(backoff * 2, 64); }
             else if (n_jobs > 1) backoff = 1;
             for (int i = 0; i < good; i++)
-                if (jobs[(size_t)i].st == TbkInflate::NEED_OUTPUT) cap = std::min(cap * 2, span * 64);
+                if (jobs[(size_t)i].st == TbkInflate::NEED_OUTPUT) cap = std::min(cap * 2, std::max(cap, span * 16));
             // ---- the windows, front to back ----
             auto window_after = [&](const GuessJob &j, const std::vector<uint16_t> &before) {
                 std::vector<uint16_t> w(HIST);
