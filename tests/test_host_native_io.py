@@ -414,8 +414,10 @@ def test_list_parser_regular_and_general_paths(built, orc, tmp_path):
         kmers.parse_kmer_list(str(tmp_path / "missing.txt"))
 
 
-def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monkeypatch):
-    """Plain FASTQ is read by the chunk-parallel scan while its records are regular; the sequential
+@pytest.mark.parametrize("gz", [False, True])
+def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monkeypatch, gz):
+    """FASTQ is read by the chunk-parallel scan while its records are regular - a plain file from its
+    mapping, gzip input (gz) from the inflated text at hand, window by window; the sequential
     state machine (TBK_FASTQ_SCAN=0) is the yardstick.  A file big enough for several pieces per
     window, several batch limits, and files where a record stops being regular somewhere in the
     middle (CRLF, wrapped sequence, '>' record, blank line, short or long quality, '+' or '@' first in
@@ -428,6 +430,11 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
         q = qual if qual is not None else "".join(rng.choice("!#5?@IJ+>") for _ in range(n))
         return "@r%d extra words %d\n%s\n+%s\n%s\n" % (i, i, s, "" if i % 3 else "r%d" % i, q)
 
+    ext = ".fastq.gz" if gz else ".fastq"
+
+    def write(path, text):
+        path.write_bytes(gzip.compress(text.encode(), 1) if gz else text.encode())
+
     def both(path, *limits):
         monkeypatch.setenv("TBK_FASTQ_SCAN", "0")
         want = _native_records(str(path), *limits)
@@ -437,16 +444,16 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
 
     monkeypatch.setenv("TBK_HOST_THREADS", "6")   # read once per process; harmless if another test got there first
     big = "".join(rec(i) for i in range(9000))     # ~80 MB: windows of several 4 MB pieces
-    p = tmp_path / "big.fastq"
-    p.write_text(big)
+    p = tmp_path / ("big" + ext)
+    write(p, big)
     recs = both(p)
     assert len(recs) == 9000 and recs[0][0] == "r0" and recs[-1][0] == "r8999"
     for limits in ((3_000_000, 0), (0, 1000), (10_000_000, 777), (1, 0)):
         assert both(p, *limits) == recs
     # zero-length reads, '@' and '+' leading quality lines, a header that is just '@'
     odd = "@\n\n+\n\n" + "@a b\nACGT\n+\n@@@@\n" + "@c\nAC\n+c\n++\n" + "".join(rec(i, 1, 50) for i in range(2000))
-    q = tmp_path / "odd.fastq"
-    q.write_text(odd)
+    q = tmp_path / ("odd" + ext)
+    write(q, odd)
     assert len(both(q)) == 2003 and both(q, 0, 1) == both(q)
     # irregular records in the middle: everything before them by the scan, everything after by the machine
     head = "".join(rec(i, 50, 4000) for i in range(3000))
@@ -464,14 +471,14 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
         "junk": "hello world\n",
     }
     for name, mid in breakers.items():
-        f = tmp_path / (name + ".fastq")
-        f.write_text(head + mid + tail)
+        f = tmp_path / (name + ext)
+        write(f, head + mid + tail)
         got = both(f)
         assert len(got) >= 3000 and got[:3000] == [[x[0], x[1], x[2]] for x in both(f)[:3000]], name
         both(f, 500_000, 0)
     for name, text in (("no_final_newline", head + "@z\nACGT\n+\nIIII"), ("truncated", head + "@z\nACGTACGT\n+\nII"), ("only_header", head + "@z")):
-        f = tmp_path / (name + ".fastq")
-        f.write_text(text)
+        f = tmp_path / (name + ext)
+        write(f, text)
         both(f)
         both(f, 0, 64)
 
@@ -617,7 +624,9 @@ def test_guessing_inflate_equals_the_sequential_decoder(built, tmp_path, monkeyp
         f = tmp_path / f"{name}.fastq.gz"
         f.write_bytes(blob)
         monkeypatch.setenv("TBK_PINFLATE", "0")
+        monkeypatch.setenv("TBK_FASTQ_SCAN", "0")   # the yardstick: one inflating thread, the sequential record machine
         ref = read_all(f)
+        monkeypatch.delenv("TBK_FASTQ_SCAN")
         assert sum(ref[0]) == n
         want = want or ref
         assert ref == want, name

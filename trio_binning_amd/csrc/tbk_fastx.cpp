@@ -775,6 +775,7 @@ struct RegularScan {
     const uint8_t *map = nullptr;
     size_t size = 0, pos = 0;   // pos: a record starts here (or pos == size)
     bool active = false;
+    bool inflated = false;        // the same scan over inflated text (gzip input), see regular_next_inflated
     double bytes_per_base = 2.2;  // estimate used to size a call's window
 };
 
@@ -868,6 +869,7 @@ extern "C" int tbk_fastx_open(const char *path, tbk_fastx_reader **out) {
             r->scan.active = r->scan.map[0] == '@';
         }
     }
+    r->scan.inflated = gz && !(scan_env && *scan_env == '0');
     *out = r;
     return TBK_OK;
 }
@@ -887,14 +889,17 @@ extern "C" int tbk_fastx_batch_create(tbk_fastx_batch **out) {
 
 extern "C" void tbk_fastx_batch_destroy(tbk_fastx_batch *b) { delete b; }
 
-// One batch by the chunk-parallel scan (see RegularScan).  Leaves the batch empty when the record at
-// scan.pos is not regular (the mode is then off and the sequential machine goes on from there) or
-// the file is exhausted.
-static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
-    RegularScan &sc = r->scan;
-    const uint8_t *d = sc.map;
-    if (sc.pos >= sc.size) return TBK_OK;
-    const size_t left = sc.size - sc.pos;
+// One batch by the chunk-parallel scan (see RegularScan) of the text d[pos..size): a mapped file
+// (final: nothing follows d[size-1]) or the inflated text at hand (more may follow: a record cut off by
+// the end of the window is not irregular, only incomplete).  Leaves the batch empty when the record
+// at `pos` is not regular and complete.  *new_pos = where the next record starts; *leave = every
+// record that chained up was taken and the one after them is not regular (meaningful when final).
+static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, const size_t pos, tbk_fastx_batch *b,
+                          uint64_t max_bases, uint64_t max_reads, size_t *new_pos_out, bool *leave) {
+    *new_pos_out = pos;
+    *leave = false;
+    if (pos >= size) return TBK_OK;
+    const size_t left = size - pos;
     size_t want = left;
     if (max_bases != ~0ull) {
         const double est = (double)max_bases * sc.bytes_per_base * 1.02 + (double)((size_t)2 << 20);
@@ -905,8 +910,8 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
     struct Piece { size_t lo = 0, hi = 0, begin = 0, end = 0; bool synced = false, bad = false; std::vector<FastqRec> recs; };
     std::vector<Piece> pieces((size_t)nt);
     for (int t = 0; t < nt; t++) {
-        pieces[(size_t)t].lo = sc.pos + want * (size_t)t / (size_t)nt;
-        pieces[(size_t)t].hi = sc.pos + want * (size_t)(t + 1) / (size_t)nt;
+        pieces[(size_t)t].lo = pos + want * (size_t)t / (size_t)nt;
+        pieces[(size_t)t].hi = pos + want * (size_t)(t + 1) / (size_t)nt;
     }
     auto work = [&](int t) {
         Piece &pc = pieces[(size_t)t];
@@ -917,16 +922,16 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
         } else {
             // guess: the first line start in the piece where two regular records follow one another
             // (the piece may begin on a line start itself: then that line is the first candidate)
-            const uint8_t *e = d[pc.lo - 1] == '\n' ? d + pc.lo - 1 : find_eol(d + pc.lo, d + sc.size);
+            const uint8_t *e = d[pc.lo - 1] == '\n' ? d + pc.lo - 1 : find_eol(d + pc.lo, d + size);
             size_t ls = (size_t)(e - d) + 1;
             for (int tries = 0; tries < 12 && ls < pc.hi && !pc.synced; tries++) {
-                if (e == d + sc.size || *e != '\n') break;  // a CR: not this mode's business
-                if (regular_record(d, sc.size, ls, rec) && (rec.end == sc.size || regular_record(d, sc.size, rec.end, nxt))) {
+                if (e == d + size || *e != '\n') break;  // a CR: not this mode's business
+                if (regular_record(d, size, ls, rec) && (rec.end == size || regular_record(d, size, rec.end, nxt))) {
                     at = ls;
                     pc.synced = true;
                     break;
                 }
-                e = find_eol(d + ls, d + sc.size);
+                e = find_eol(d + ls, d + size);
                 ls = (size_t)(e - d) + 1;
             }
             if (!pc.synced) return;
@@ -934,7 +939,7 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
         pc.begin = at;
         pc.recs.reserve((pc.hi - pc.lo) / 4096 + 16);
         while (at < pc.hi) {
-            if (!regular_record(d, sc.size, at, rec)) { pc.bad = true; break; }
+            if (!regular_record(d, size, at, rec)) { pc.bad = true; break; }
             pc.recs.push_back(rec);
             at = (size_t)rec.end;
         }
@@ -967,10 +972,7 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
             if (n_reads >= max_reads || n_bases >= max_bases) { full = true; break; }
         }
     }
-    if (n_reads == 0) {  // the record at scan.pos is not regular: hand over to the sequential machine
-        sc.active = false;
-        return TBK_OK;
-    }
+    if (n_reads == 0) return TBK_OK;  // the record at pos is not regular (or not all there)
     // flat view of the chosen records, then parallel copies into the batch's arrays
     std::vector<const FastqRec *> chosen;
     chosen.reserve((size_t)n_reads);
@@ -979,20 +981,24 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
         const size_t upto = t == last_piece ? last_idx : rs.size();
         for (size_t i = 0; i < upto; i++) chosen.push_back(&rs[i]);
     }
-    if (!b->reserve_bases((size_t)n_bases + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
-    b->base_off.resize((size_t)n_reads + 1);
-    b->name_off.resize((size_t)n_reads + 1);
-    b->qual_off.resize((size_t)n_reads + 1);
-    b->has_qual.assign((size_t)n_reads, 1);
-    b->names.resize((size_t)n_name);
-    b->quals.resize((size_t)n_bases);
-    uint64_t ob = 0, on = 0;
+    // appended behind what the batch holds already (inflated text comes window by window)
+    const size_t n0 = (size_t)b->n_reads(), on0 = b->names.size(), oq0 = b->quals.size();
+    const uint64_t ob0 = b->n_bases;
+    if (!b->reserve_bases((size_t)(ob0 + n_bases) + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
+    b->base_off.resize(n0 + (size_t)n_reads + 1);
+    b->name_off.resize(n0 + (size_t)n_reads + 1);
+    b->qual_off.resize(n0 + (size_t)n_reads + 1);
+    b->has_qual.resize(n0 + (size_t)n_reads, 1);
+    b->names.resize(on0 + (size_t)n_name);
+    b->quals.resize(oq0 + (size_t)n_bases);
+    uint64_t ob = ob0, on = on0, oq = oq0;
     for (size_t i = 0; i < chosen.size(); i++) {
-        b->base_off[i] = ob; b->qual_off[i] = ob; b->name_off[i] = on;
-        ob += chosen[i]->plus - 1 - chosen[i]->seq;
+        b->base_off[n0 + i] = ob; b->qual_off[n0 + i] = oq; b->name_off[n0 + i] = on;
+        const uint64_t len = chosen[i]->plus - 1 - chosen[i]->seq;
+        ob += len; oq += len;
         on += chosen[i]->name_len;
     }
-    b->base_off[chosen.size()] = ob; b->qual_off[chosen.size()] = ob; b->name_off[chosen.size()] = on;
+    b->base_off[n0 + chosen.size()] = ob; b->qual_off[n0 + chosen.size()] = oq; b->name_off[n0 + chosen.size()] = on;
     b->n_bases = ob;
     {
         const int ct = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, tbk_host_threads()), (size_t)n_bases / ((size_t)8 << 20)));
@@ -1001,18 +1007,19 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
             auto cut = [&](int u) -> size_t {
                 if (u <= 0) return 0;
                 if (u >= ct) return chosen.size();
-                const uint64_t at_b = n_bases * (uint64_t)u / (uint64_t)ct;
-                return (size_t)(std::lower_bound(b->base_off.begin(), b->base_off.begin() + (ptrdiff_t)chosen.size(), at_b) - b->base_off.begin());
+                const uint64_t at_b = ob0 + n_bases * (uint64_t)u / (uint64_t)ct;
+                const auto first = b->base_off.begin() + (ptrdiff_t)n0;
+                return (size_t)(std::lower_bound(first, first + (ptrdiff_t)chosen.size(), at_b) - first);
             };
             const size_t last = cut(t + 1);
             for (size_t i = cut(t); i < last; i++) {
                 const FastqRec &rc = *chosen[i];
                 const size_t len = (size_t)(rc.plus - 1 - rc.seq);
                 if (len) {
-                    memcpy(b->bases + b->base_off[i], d + rc.seq, len);
-                    memcpy(b->quals.data() + b->qual_off[i], d + rc.qual, len);
+                    memcpy(b->bases + b->base_off[n0 + i], d + rc.seq, len);
+                    memcpy(b->quals.data() + b->qual_off[n0 + i], d + rc.qual, len);
                 }
-                if (rc.name_len) memcpy(b->names.data() + b->name_off[i], d + rc.head + 1, rc.name_len);
+                if (rc.name_len) memcpy(b->names.data() + b->name_off[n0 + i], d + rc.head + 1, rc.name_len);
             }
         };
         std::vector<std::thread> pool;
@@ -1029,11 +1036,65 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
                 (unsigned long long)n_reads, std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(t_c - t_b).count());
     }
     const size_t new_pos = (size_t)chosen.back()->end;
-    if (n_bases) sc.bytes_per_base = std::max(1.5, (double)(new_pos - sc.pos) / (double)n_bases);
-    sc.pos = new_pos;
-    // everything that chained up was taken and the last piece stopped at an irregular record: leave the mode there
-    if (!full && pieces[(size_t)n_ok - 1].bad && last_piece == n_ok - 1 && last_idx == pieces[(size_t)n_ok - 1].recs.size()) sc.active = false;
+    if (n_bases) sc.bytes_per_base = std::max(1.5, (double)(new_pos - pos) / (double)n_bases);
+    *new_pos_out = new_pos;
+    // everything that chained up was taken and the last piece stopped at an irregular record
+    *leave = !full && pieces[(size_t)n_ok - 1].bad && last_piece == n_ok - 1 && last_idx == pieces[(size_t)n_ok - 1].recs.size();
     return TBK_OK;
+}
+
+// The mapped plain file: leaves the batch empty when the record at scan.pos is not regular (the mode is
+// then off and the sequential machine goes on from there) or the file is exhausted.
+static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
+    RegularScan &sc = r->scan;
+    if (sc.pos >= sc.size) return TBK_OK;
+    size_t new_pos = sc.pos;
+    bool leave = false;
+    const int rc = regular_window(sc, sc.map, sc.size, sc.pos, b, max_bases, max_reads, &new_pos, &leave);
+    if (rc) return rc;
+    if (b->n_reads() == 0 || leave) sc.active = false;
+    sc.pos = new_pos;
+    return TBK_OK;
+}
+
+// Inflated text (gzip / bgzip input): the same scan over the decoded bytes at hand, while the machine
+// stands between records.  The text is taken as it arrives, in windows of up to 64 MiB appended to the
+// batch one after the other (the inflating threads work on the next window meanwhile), until the batch
+// is full.  A record cut off by the end of a window waits for more text; a record that is not regular
+// ends the mode, and the machine reads on from that byte of the same buffer.
+static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
+    LineSource &src = r->src;
+    RegularScan &sc = r->scan;
+    // size the pinned sequence buffer once, from the batch limit, instead of growing it
+    if (max_bases != ~0ull && max_bases <= ((uint64_t)1 << 34) && b->bases_cap < max_bases)
+        if (!b->reserve_bases((size_t)max_bases + ((size_t)max_bases >> 3) + (1 << 20)))
+            return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
+    size_t window = (size_t)64 << 20, at_least = 0;
+    for (;;) {
+        const uint64_t have_reads = b->n_reads(), have_bases = b->n_bases;
+        if (have_reads >= max_reads || have_bases >= max_bases) return TBK_OK;
+        size_t want = window;
+        if (max_bases != ~0ull) want = (size_t)std::min<double>((double)window, (double)(max_bases - have_bases) * sc.bytes_per_base * 1.02 + (double)((size_t)1 << 20));
+        want = std::max(want, at_least);
+        while (!src.text_eof && src.end - src.pos < want)
+            if (!src.refill()) return ffail(TBK_ERR_IO, "%s", src.err.c_str());
+        if (src.pos == src.end) return TBK_OK;  // nothing left: the machine will say so
+        if (src.buf[src.pos] != '@') { sc.inflated = false; return TBK_OK; }
+        size_t new_pos = src.pos;
+        bool leave = false;
+        const int rc = regular_window(sc, src.buf.data(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave);
+        if (rc) return rc;
+        if (b->n_reads() > have_reads) {
+            src.pos = new_pos;
+            at_least = 0;
+            if (leave && src.text_eof) { sc.inflated = false; return TBK_OK; }
+            continue;
+        }
+        // the record at src.pos: cut off by the end of the window (read on), or not regular (the machine's)
+        if (!src.text_eof && src.end - src.pos < ((size_t)64 << 20)) { at_least = src.end - src.pos + ((size_t)8 << 20); continue; }
+        sc.inflated = false;
+        return TBK_OK;
+    }
 }
 
 extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
@@ -1058,6 +1119,11 @@ extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t 
             r->state = tbk_fastx_reader::SEEK;
             r->scan.pos = (size_t)-1;  // handed over
         }
+    }
+    if (r->scan.inflated && r->state == tbk_fastx_reader::SEEK && !r->have_pending && !r->src.skip_lf) {
+        const int rc = regular_next_inflated(r, b, max_bases, max_reads);
+        if (rc) return rc;
+        if (b->n_reads() > 0) return TBK_OK;  // (a batch the scan left unfilled at an irregular record: the machine fills the next one)
     }
     // size the pinned sequence buffer once, from the batch limit, instead of growing it
     if (max_bases != ~0ull && max_bases <= ((uint64_t)1 << 34) && b->bases_cap < max_bases)
