@@ -25,6 +25,7 @@ def test_host_code_under_asan_ubsan(built):
                LD_PRELOAD=_asan_runtime(),
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98",
+               TBK_TEST_LIGHT="1",
                TBK_LIBRARY=os.path.join(csrc, "build_asan", "libtbk_hip_asan.so"))
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_host_native_io.py"),
