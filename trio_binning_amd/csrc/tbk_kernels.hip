@@ -188,6 +188,9 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #ifndef TBK_UNROLL
 #define TBK_UNROLL 2      // j-loop unroll of the probe pass
 #endif
+#ifndef TBK_LOOKAHEAD
+#define TBK_LOOKAHEAD 0   // 1: each step asks for the lines of the next one (see probe_pass)
+#endif
 #ifndef TBK_SAMP_UNROLL
 #define TBK_SAMP_UNROLL 4 // j-loop unroll of the mod-sampling variants
 #endif
@@ -230,6 +233,33 @@ __device__ __forceinline__ uint64_t find_read(const uint64_t *offsets, uint64_t 
         if (offsets[mid] <= pos) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// Look-ahead builds (TBK_LOOKAHEAD): the line loads of the probe loop are issued and waited for by
+// hand.  hipcc drains the VM counter completely (vmcnt(0)) at the first use of a load result while an
+// LDS-DMA is in flight, which would make every step wait for the look-ahead load it has just issued;
+// issued from inline asm the line loads are invisible to that bookkeeping, and tbk_wait_lines() waits
+// with the exact count instead: "all but the youngest one" - the look-ahead load, issued after them.
+// (The counter is in order, so loads the compiler does know about are at worst waited for longer.)
+typedef uint32_t tbk_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_line_async(const uint64_t *line, ulonglong2 &a, ulonglong2 &b) {
+    tbk_v4u x = __builtin_bit_cast(tbk_v4u, a), y = __builtin_bit_cast(tbk_v4u, b);
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "+v"(x), "+v"(y) : "v"(line));
+    a = __builtin_bit_cast(ulonglong2, x);
+    b = __builtin_bit_cast(ulonglong2, y);
+}
+__device__ __forceinline__ void tbk_wait_lines(ulonglong2 (&va)[4], ulonglong2 (&vb)[4]) {
+    tbk_v4u a0 = __builtin_bit_cast(tbk_v4u, va[0]), a1 = __builtin_bit_cast(tbk_v4u, va[1]), a2 = __builtin_bit_cast(tbk_v4u, va[2]),
+            a3 = __builtin_bit_cast(tbk_v4u, va[3]), b0 = __builtin_bit_cast(tbk_v4u, vb[0]), b1 = __builtin_bit_cast(tbk_v4u, vb[1]),
+            b2 = __builtin_bit_cast(tbk_v4u, vb[2]), b3 = __builtin_bit_cast(tbk_v4u, vb[3]);
+#ifdef TBK_LA_NOPF
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+#else
+    asm volatile("s_waitcnt vmcnt(1)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+#endif
+    va[0] = __builtin_bit_cast(ulonglong2, a0); va[1] = __builtin_bit_cast(ulonglong2, a1); va[2] = __builtin_bit_cast(ulonglong2, a2);
+    va[3] = __builtin_bit_cast(ulonglong2, a3); vb[0] = __builtin_bit_cast(ulonglong2, b0); vb[1] = __builtin_bit_cast(ulonglong2, b1);
+    vb[2] = __builtin_bit_cast(ulonglong2, b2); vb[3] = __builtin_bit_cast(ulonglong2, b3);
 }
 
 // 16 bytes (two slots) of a bucket line.  -DTBK_NT_LOADS marks the load non-temporal: a line is used by the
@@ -350,7 +380,7 @@ template <int W, bool M64, bool SAMP, bool MULTI>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                           uint4 *walkq, uint32_t *rcnt) {
+                                           uint4 *walkq, uint32_t *rcnt, uint32_t *sink) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
@@ -491,27 +521,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-    // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
-    constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
-#pragma unroll kUnroll
-    for (int j = 0; j < TBK_WPL; j++) {
-        // ---- this lane's window j ---------------------------------------------------
-        const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
-        const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
-        const uint64_t key = fwd < rc ? fwd : rc;
-        if (MULTI) {
-            // window j starts at or past the current read's end: move to the read that holds it
-            while ((uint32_t)j >= rel_end && rid < p.n_reads) {
-                // hand the finished read's hits to the wave's per-read tallies
-                if (lane_a) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a); lane_a = 0; }
-                if (lane_b) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b); lane_b = 0; }
-                rid++;
-                rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
-                rel_end = rel(rend);
-            }
-        }
-        bool ok = (bad_lo & badk) == 0;  // single-read pass: the read end is part of the mask
-        if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
+    // bucket of the window the rolled streams stand at (window jj of this lane); moves the minimizer
+    // state on by one window, so it is called once per window, in order
+    auto bucket_here = [&](const int jj) -> uint32_t {
         uint32_t hsel;
         if (W > 0 && SAMP) {
             // mod-sampling: shift in the span's newest t-mer, find the smallest rank (any of the
@@ -521,11 +533,11 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
 #pragma unroll
             for (int i = 0; i + 1 < NW; i++) win[i] = win[i + 1];
-            win[NW - 1] = (win_t)tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(j + NW - 1) & 15u);
+            win[NW - 1] = (win_t)tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(jj + NW - 1) & 15u);
             uint32_t best = (uint32_t)win[0];
 #pragma unroll
             for (int i = 1; i < NW; i++) best = (uint32_t)win[i] < best ? (uint32_t)win[i] : best;
-            const uint32_t x = (best - (uint32_t)j) & 15u;  // 0 .. 2W-1
+            const uint32_t x = (best - (uint32_t)jj) & 15u;  // 0 .. 2W-1
             const uint32_t pos = x >= (uint32_t)W ? x - (uint32_t)W : x;
             const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
             if (M64) {
@@ -545,14 +557,51 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             for (int i = 1; i < W; i++) best = win[i] < best ? win[i] : best;
             hsel = M64 ? (uint32_t)best : tbk_scramble((uint32_t)best);
         } else {
-            hsel = tbk_mix32(key);
+            const uint64_t f_ = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask, r_ = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
+            hsel = tbk_mix32(f_ < r_ ? f_ : r_);
         }
+        return tbk_reduce(hsel, p.t.n_buckets);
+    };
+    // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
+    constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
+    constexpr bool LA = TBK_LOOKAHEAD && !MULTI;  // single-read passes only: the multi-read pass has no scalar registers to spare
+    // One window of look-ahead.  A wave that asks for its lines and then needs them at once sits
+    // out the whole HBM latency every step, and four waves per SIMD do not cover it (measured: the
+    // kernel moved 0.79 of the line ceiling).  So the bucket of window j+1 is worked out during step j,
+    // after step j's own loads have been issued, and every lane touches its next line with a 4-byte
+    // load that lands in LDS (global_load_lds: no VGPR, nothing to wait for, and being younger
+    // than the step's real loads it does not hold up the wait for them).  A step later the real
+    // loads find the line in L2 or on its way.  Lanes whose next window stays in the same line touch
+    // bucket 0 instead (one address for all of them).
+    uint32_t bkt_next = 0;
+    if (LA) bkt_next = bucket_here(0);
+#pragma unroll kUnroll
+    for (int j = 0; j < TBK_WPL; j++) {
+        // ---- this lane's window j ---------------------------------------------------
+        const uint64_t fwd = ((uint64_t)s0 | ((uint64_t)s1 << 32)) & kmask;
+        const uint64_t rc = ((uint64_t)t2 | ((uint64_t)t3 << 32)) & kmask;
+        const uint64_t key = fwd < rc ? fwd : rc;
+        if (MULTI) {
+            // window j starts at or past the current read's end: move to the read that holds it
+            while ((uint32_t)j >= rel_end && rid < p.n_reads) {
+                // hand the finished read's hits to the wave's per-read tallies
+                if (lane_a) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a); lane_a = 0; }
+                if (lane_b) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b); lane_b = 0; }
+                rid++;
+                rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
+                rel_end = rel(rend);
+            }
+        }
+        bool ok = (bad_lo & badk) == 0;  // single-read pass: the read end is part of the mask
+        if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
+        uint32_t bkt;
+        if (LA) bkt = bkt_next;   // worked out one window ago, its line asked for then
+        else bkt = bucket_here(j);
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
         // TBK_NOKEY, which is never stored (it can never hit)
         // Bit 31 of the broadcast bucket says "not the bucket of this lane's previous window": only
         // then do the quad's lanes fetch the line; otherwise they still hold it.  (Bucket indices stay
         // below 2^31: 2^31 lines would be a 256 GB table.)
-        const uint32_t bkt = tbk_reduce(hsel, p.t.n_buckets);
         const bool fresh = ok && bkt != last_bk;
         const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
         last_bk = my_bk & 0x7FFFFFFFu;
@@ -575,11 +624,26 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             TBK_COUNT(4, __popcll(ballot((int32_t)bk[s] < 0)));
             if ((int32_t)bk[s] < 0) {
                 const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
-                va[s] = load_slots(line);
-                vb[s] = load_slots(line + 8);
+                if (LA) {
+                    load_line_async(line, va[s], vb[s]);
+                } else {
+                    va[s] = load_slots(line);
+                    vb[s] = load_slots(line + 8);
+                }
             }
         }
 
+        if (LA) {
+            if (j + 1 < TBK_WPL) bkt_next = bucket_here(j + 1);
+            const uint32_t ahead = bkt_next != bkt ? bkt_next : 0u;
+#ifndef TBK_LA_NOPF
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.t.slots + (uint64_t)ahead * 16),
+                                             (__attribute__((address_space(3))) void *)sink, 4, 0, 0);
+#else
+            asm volatile("" :: "v"(ahead));
+#endif
+            tbk_wait_lines(va, vb);  // this step's lines are in; the look-ahead load stays in flight
+        }
         // Fast path.  A key is stored at most once, in one of the two halves (hapB keys that hapA
         // holds are dropped at build time), so the raw ballots count windows and hapA-over-hapB
         // priority (c/kmers.c:291-294) needs no work here.  Only a window whose home half was left
@@ -746,6 +810,7 @@ tbk_probe_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][2 * TBK_RCNT];
+    __shared__ uint32_t sink[TBK_WAVES_PER_BLOCK][64];  // where the look-ahead loads land (never read)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t passes_per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
@@ -771,8 +836,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave]);
-        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave]);
+        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
+        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
     }
 }
 
