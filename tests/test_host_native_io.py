@@ -431,6 +431,8 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
         return "@r%d extra words %d\n%s\n+%s\n%s\n" % (i, i, s, "" if i % 3 else "r%d" % i, q)
 
     ext = ".fastq.gz" if gz else ".fastq"
+    if gz:
+        monkeypatch.setenv("TBK_INFLATED_SCAN", "1")   # the scan over inflated text is opt-in
 
     def write(path, text):
         path.write_bytes(gzip.compress(text.encode(), 1) if gz else text.encode())
@@ -620,6 +622,7 @@ def test_guessing_inflate_equals_the_sequential_decoder(built, tmp_path, monkeyp
         return sizes, digest.hexdigest()
 
     monkeypatch.setenv("TBK_PINFLATE_MIN", "0")
+    monkeypatch.setenv("TBK_INFLATED_SCAN", "1")   # the guessed chunks also feed the window-by-window record scan
     want = None
     for name, blob in files.items():
         f = tmp_path / f"{name}.fastq.gz"

@@ -8,4 +8,11 @@ tail -12 gpurun_out/gpu_tests.log
 ( time timeout 900 python bench.py ) > gpurun_out/bench_final.log 2>&1
 grep '^{"metric"' gpurun_out/bench_final.log | tail -1 | cut -c1-2500
 ( timeout 600 python tools/measure_reader.py --qual hifi ) 2>/dev/null | tail -1
+( timeout 600 python tools/measure_cli.py --reads 60000 --gz-input ) > gpurun_out/cli_gz_input.json 2> gpurun_out/cli_gz_input.err
+python -c "
+import json; d=json.load(open('gpurun_out/cli_gz_input.json')); print({m:(d[m]['wall_s'], d[m]['stages']) for m in ('gzip','plain')})"
+( timeout 600 python tools/measure_cli.py --reads 200000 ) > gpurun_out/cli_plain_input.json 2> gpurun_out/cli_plain_input.err
+python -c "
+import json; d=json.load(open('gpurun_out/cli_plain_input.json')); print({m:(d[m]['wall_s'], d[m]['stages']) for m in ('gzip','plain')})"
+( timeout 900 python tools/measure_unique_cli.py --gzip ) 2>/dev/null | tail -1 | cut -c1-330
 exit 0
