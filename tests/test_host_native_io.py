@@ -692,3 +692,22 @@ def test_guessing_inflate_side_by_side(built, tmp_path, monkeypatch):
         for f in range(3):
             lines = texts[f].split(b"\n")
             assert got[f] == [[lines[4 * i][1:].decode(), lines[4 * i + 1].decode(), lines[4 * i + 3].decode()] for i in range(len(lines) // 4)]
+
+
+def test_crc32_by_carryless_multiplication_equals_zlib(built):
+    """tbk_crc.cpp: every length 0..300 and a few long ones, at three alignments, from two starting
+    values; TBK_CRC=zlib (read once per process) is the fallback the library takes by itself when the CPU
+    lacks PCLMULQDQ or its own known-answer check fails."""
+    import ctypes as C
+    import zlib
+
+    from trio_binning_amd._lib import lib
+
+    f = lib.tbk_crc32_c
+    f.restype, f.argtypes = C.c_uint32, [C.c_uint32, C.c_char_p, C.c_size_t]
+    data = np.random.default_rng(0).integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    for n in list(range(0, 300)) + [1000, 4095, 4096, 4097, 65537, (1 << 20) - 7]:
+        for off in (0, 1, 7):
+            piece = data[off:off + n]
+            for start in (0, 0xDEADBEEF):
+                assert f(start, piece, len(piece)) == zlib.crc32(piece, start), (n, off, start)

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <vector>
 
+uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp
+
 namespace {
 
 // Bits go into a 64-bit accumulator and leave it eight bytes at a time through an unaligned store;
@@ -297,7 +299,7 @@ bool tbk_gzip_member_literal(const char *src, size_t n, std::vector<char> &out) 
     }
     bw.finish();
     uLong crc = crc32(0L, Z_NULL, 0);
-    for (size_t off = 0; off < n; off += (size_t)1 << 30) crc = crc32(crc, (const Bytef *)src + off, (uInt)std::min<size_t>(n - off, (size_t)1 << 30));
+    crc = tbk_crc32((uint32_t)crc, (const uint8_t *)src, n);
     const uint32_t tail[2] = {(uint32_t)crc, (uint32_t)(n & 0xFFFFFFFFu)};
     out.insert(out.end(), (const char *)tail, (const char *)tail + 8);
     return true;

@@ -44,6 +44,8 @@
 #include "../../include/tbk.h"
 #include "tbk_inflate.h"
 
+uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp: zlib's crc32() by carry-less multiplication
+
 extern "C" void tbk_set_error_(int code, const char *msg);  // tbk_host.cpp
 
 static int ffail(int code, const char *fmt, ...) {
@@ -163,7 +165,7 @@ struct LineSource {
         auto one = [&](int t) {
             const size_t a = lo + n * (size_t)t / nt, b = lo + n * (size_t)(t + 1) / nt;
             uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-            for (size_t p = a; p < b; p += (size_t)1 << 30) c = (uint32_t)crc32(c, base + p, (uInt)std::min<size_t>(b - p, (size_t)1 << 30));
+            c = tbk_crc32(c, base + a, b - a);
             part[(size_t)t] = c; len[(size_t)t] = b - a;
         };
         std::vector<std::thread> pool;
@@ -401,7 +403,7 @@ struct LineSource {
                                            : resolve_symbols(j.sym.get() + HIST, j.n, j.window.data(), j.out.data.data());
                 j.bad_symbol = seen > 0xFFu;
                 uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-                for (size_t p = 0; p < j.n; p += (size_t)1 << 30) c = (uint32_t)crc32(c, j.out.data.data() + p, (uInt)std::min<size_t>(j.n - p, (size_t)1 << 30));
+                c = tbk_crc32(c, j.out.data.data(), j.n);
                 j.crc = c;
                 j.out.off = 0; j.out.len = j.n;
             });
@@ -553,7 +555,7 @@ struct LineSource {
                         const int rc = k.out_len ? inflate(&z, Z_FINISH) : Z_STREAM_END;  // an empty block (the end-of-file marker) has nothing to inflate
                         good = rc == Z_STREAM_END && z.avail_out == 0;
                     }
-                    if (!good || (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + k.out, (uInt)k.out_len) != k.crc) ok.store(false);
+                    if (!good || tbk_crc32(0u, out + k.out, k.out_len) != k.crc) ok.store(false);
                 }
                 inflateEnd(&z);
             };
