@@ -174,6 +174,34 @@ def device_count() -> int:
     return n.value
 
 
+def warm_up() -> None:
+    """Start the HIP runtime on the devices this process will use, on a thread of its own: the
+    command-line drivers call this before they import numpy and parse their arguments, so that
+    the runtime's start-up (device discovery, the primary context) runs beside those instead of
+    after them.  Purely a head start - every entry point initialises what it needs anyway; without a
+    device it returns at once."""
+    import threading
+
+    def start():
+        n = C.c_int(0)
+        if lib.tbk_device_count(C.byref(n)) != TBK_OK or n.value <= 0:
+            return
+        spec = os.environ.get("TBK_DEVICES") or os.environ.get("TBK_DEVICE") or os.environ.get("LOCAL_RANK") or ""
+        wanted = [int(x) for x in spec.split(",") if x.strip().lstrip("-").isdigit()] or list(range(n.value))
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        for device in dict.fromkeys(wanted):
+            if 0 <= device < n.value:
+                lib.tbk_device_mem_info(device, C.byref(free), C.byref(total))
+
+    thread = threading.Thread(target=start, name="tbk-warm-up", daemon=True)
+    thread.start()
+    # a process that ends early (--help, a bad argument) lets the runtime finish starting before it
+    # is torn down
+    import atexit
+
+    atexit.register(thread.join)
+
+
 def device_name(device: int = 0) -> str:
     buf = C.create_string_buffer(256)
     check(lib.tbk_device_name(device, buf, 256))

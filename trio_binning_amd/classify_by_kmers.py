@@ -20,7 +20,11 @@ import sys
 from os import path
 from typing import List, Tuple
 
-from . import kmers, seq
+from . import _lib
+
+_lib.warm_up()  # the HIP runtime starts beside the imports and the argument parsing below
+
+from . import kmers, seq  # noqa: E402
 
 # bases per batch handed to the GPU; 3 batches may be in flight
 _BATCH_BASES = int(os.environ.get("TBK_BATCH_BASES", str(64 << 20)))  # small enough that pinning the batch buffers is not what a short run waits for

@@ -13,7 +13,11 @@ import os
 import sys
 from typing import List, Sequence, Tuple
 
-from . import kmers, seq
+from . import _lib
+
+_lib.warm_up()  # the HIP runtime starts beside the imports and the argument parsing below
+
+from . import kmers, seq  # noqa: E402
 
 _BATCH_BASES = int(os.environ.get("TBK_BATCH_BASES", str(256 << 20)))
 _BATCH_READS = int(os.environ.get("TBK_BATCH_READS", str(4 << 20)))
