@@ -635,7 +635,11 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 
         if (LA) {
             if (j + 1 < TBK_WPL) bkt_next = bucket_here(j + 1);
-            const uint32_t ahead = bkt_next != bkt ? bkt_next : 0u;
+#ifdef TBK_LA_COMMON
+            const uint32_t ahead = bkt_next != bkt ? bkt_next : 0u;   // lanes that stay in their line all touch bucket 0
+#else
+            const uint32_t ahead = bkt_next;                          // ... or the line they hold (no address shared by the whole chip)
+#endif
 #ifndef TBK_LA_NOPF
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.t.slots + (uint64_t)ahead * 16),
                                              (__attribute__((address_space(3))) void *)sink, 4, 0, 0);

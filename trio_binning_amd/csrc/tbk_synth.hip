@@ -197,7 +197,7 @@ tbk_calib_gather_kernel(const uint4 *__restrict__ buf, uint64_t n_lines_buf, uin
     const uint64_t group = gid / LPL;
     const uint32_t sub = (uint32_t)(gid % LPL);
     constexpr int PER_LINE = LINE / 16;           // 16-byte pieces per line
-    constexpr int PIECES = LPL == 1 ? PER_LINE : 1;  // pieces each lane loads per line
+    constexpr int PIECES = PER_LINE / LPL;        // pieces each lane loads per line (LPL = 4 on 128-byte lines: the probe kernel's shape, two 64-byte halves)
     uint32_t acc = 0;
     uint64_t state = seed ^ (group * 0x9E3779B97F4A7C15ull);
     for (uint32_t it = 0; it < iters; it++) {
@@ -208,7 +208,7 @@ tbk_calib_gather_kernel(const uint4 *__restrict__ buf, uint64_t n_lines_buf, uin
             const uint64_t line = (uint64_t)(((unsigned __int128)state * n_lines_buf) >> 64);
 #pragma unroll
             for (int pc = 0; pc < PIECES; pc++) {
-                const uint64_t piece = LPL == 1 ? (uint64_t)pc : (uint64_t)(sub % PER_LINE);
+                const uint64_t piece = (uint64_t)sub + (uint64_t)pc * LPL;
                 v[f][pc] = buf[line * PER_LINE + piece];
             }
         }
@@ -356,7 +356,7 @@ extern "C" hipError_t tbk_launch_gather(const void *d_buf, uint64_t bytes, int l
 #define TBK_G(L, P, F) \
     if (line == L && lpl == P && inf == F) return launch_gather_t<L, P, F>(d_buf, bytes, n_lines, seed, d_sink, s);
 #define TBK_GF(L, P) TBK_G(L, P, 1) TBK_G(L, P, 2) TBK_G(L, P, 4) TBK_G(L, P, 8)
-    TBK_GF(64, 1) TBK_GF(64, 4) TBK_GF(128, 1) TBK_GF(128, 8)
+    TBK_GF(64, 1) TBK_GF(64, 4) TBK_GF(128, 1) TBK_GF(128, 8) TBK_GF(128, 4)
 #undef TBK_GF
 #undef TBK_G
     return hipErrorInvalidValue;
