@@ -254,6 +254,10 @@ int tbk_bin_writer_close(tbk_bin_writer *w);
  * Members with runs go through zlib (Z_RLE);
  * TBK_GZIP_ENCODER=zlib sends everything there. */
 int tbk_gzip_member(const char *src, size_t n, char *dst, size_t cap, size_t *len);
+/* zlib's crc32(crc, p, n) - the CRC-32 of gzip members - by carry-less multiplication (PCLMULQDQ folding,
+ * csrc/tbk_crc.cpp; zlib's own where the CPU lacks the instruction or TBK_CRC=zlib): what the reader
+ * and the bin writer sum their members with. */
+uint32_t tbk_crc32_c(uint32_t crc, const uint8_t *p, size_t n);
 /* Replaces the stdout line of classify_by_kmers.py:117 for a whole batch:
  * name \t bin \t str(score_a) \t str(score_b) \n with Python's float repr.  Call with out = NULL
  * to get an upper bound of the size in *len. */

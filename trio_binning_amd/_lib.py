@@ -143,6 +143,7 @@ _sig("tbk_bin_writer_open", C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int
 _sig("tbk_bin_writer_write", C.c_int, _vp, _vp, C.c_char_p)
 _sig("tbk_bin_writer_close", C.c_int, _vp)
 _sig("tbk_gzip_member", C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))
+_sig("tbk_crc32_c", C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t)
 _sig("tbk_format_tsv", C.c_int, _vp, C.c_char_p, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t))
 _sig("tbk_format_float", C.c_int, C.c_double, C.c_char_p, C.c_size_t)
 
