@@ -501,6 +501,7 @@ def main():
             "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
+            "line_layout": "front: 64 of a line's 128 bytes fetched per window" if stats.get("front_layout") else "whole lines", "keys_behind_front": stats.get("keys_behind_front"),
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "timed_regions": len(region_s), "timed_total_s": round(sum(region_s), 3),

@@ -152,6 +152,10 @@ int tbk_classifier_sampling_t(const tbk_classifier *c);
 /* How many times the table was built (1 or 2, see above) and how many keys found their own half of
  * their home line full in the layout that was kept. */
 int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint64_t *keys_past_half);
+/* Layout of the paired table that stands: front = 1 when the probe kernel fetches the first 64 bytes of a
+ * line only (the first four slots of each list; csrc/tbk_common.h "front layout"), and how many keys lie
+ * behind that front (settled by the deferred walk).  TBK_FRONT=1 / 0 pins the layout. */
+int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_behind_front);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

@@ -213,6 +213,7 @@ def test_seeded_fuzz_of_layout_and_input_shapes(gpu, orc, tmp_path, seed, monkey
     monkeypatch.setenv("TBK_MOD_SAMPLING", str(int(rng.integers(0, 2))))
     monkeypatch.setenv("TBK_TABLE_LOAD", str(rng.choice([0.04, 0.2, 0.6, 0.9])))
     monkeypatch.setenv("TBK_GUESTS", str(seed % 3 and 1))     # a third of the seeds without guests in the other half
+    monkeypatch.setenv("TBK_FRONT", str(seed // 3 % 2))       # half of them in the front layout (where mod-sampling is drawn): crowded fronts, walks from the home line
     n_a, n_b = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
 
     def rand_kmer():
@@ -586,6 +587,9 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
             assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
+            # lists that spread, with few keys behind the first four slots of a bucket, are probed front-first
+            # (64 of a line's 128 bytes); clustered ones in whole lines
+            assert st["front_layout"] == want_t and (not want_t or st["keys_behind_front"] <= 0.004 * 2 * half), (name, st)
             load = half / (st["n_buckets"] * 8)
             assert abs(load - (0.08 if want_builds == 1 else 0.04)) < 0.005, (name, load)
             assert np.array_equal(cls.classify_batch(bases, offs), want), name
@@ -603,6 +607,14 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin, "load")
             monkeypatch.delenv("TBK_TABLE_LOAD")
         monkeypatch.delenv("TBK_MOD_SAMPLING")
+        for front in ("0", "1"):                          # the layout pinned either way
+            monkeypatch.setenv("TBK_FRONT", front)
+            monkeypatch.setenv("TBK_MOD_SAMPLING", "1")
+            with kmers.Classifier(a, b) as cls:
+                assert cls.stats()["front_layout"] == (front == "1"), (name, front, cls.stats())
+                assert np.array_equal(cls.classify_batch(bases, offs), want), (name, "front", front)
+            monkeypatch.delenv("TBK_MOD_SAMPLING")
+        monkeypatch.delenv("TBK_FRONT")
         monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")       # the load is pinned, the rule still follows the lists
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()

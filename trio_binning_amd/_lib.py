@@ -90,6 +90,8 @@ _sig("tbk_classifier_shared_keys", C.c_int, _vp, _u64p)
 _sig("tbk_classifier_layout", C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_sampling_t", C.c_int, _vp)
 _sig("tbk_classifier_build_info", C.c_int, _vp, C.POINTER(C.c_int), _u64p)
+if hasattr(lib, "tbk_classifier_front"):  # absent from libraries built before the front layout (tools/gpu_ab.sh compares such builds)
+    _sig("tbk_classifier_front", C.c_int, _vp, C.POINTER(C.c_int), _u64p)
 _sig("tbk_classify_batch", C.c_int, _vp, _vp, _vp, _u64, _vp)
 _sig("tbk_stream_depth", C.c_int, _vp)
 _sig("tbk_stream_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)

@@ -295,13 +295,32 @@ TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
 // Device view of a table: bucket b's slots for this list start at
 // slots[b * stride + half] (stride 8, half 0 for a standalone table; stride 16 and half 0 / 8
 // for the hapA / hapB halves of a paired table).
+//
+// The `guests` word of the views carries two flags:
+#define TBK_FLAG_GUESTS 1u   // a full half's surplus may sit, tagged, in the other half of the line
+#define TBK_FLAG_FRONT 2u    // paired table in front layout (below)
+// Front layout.  A touched line costs the CU's L1 path the same whether 16 or 128 of its bytes are
+// wanted, and a whole [8 hapA | 8 hapB] line is two 64-byte requests per quad; with a key or two per
+// bucket nearly every window can be answered from four slots of each list.  So the line is laid out
+//     [ A0 A1 A2 A3 | B0 B1 B2 B3 | A4 A5 A6 A7 | B4 B5 B6 B7 ]
+// and the probe kernel fetches the first 64 bytes only (one 16-byte load per quad lane: lanes 0,1 hold
+// hapA's first four slots, lanes 2,3 hapB's).  Slots fill in index order, so a list's keys 5.. of a
+// bucket, its guests and everything "past the half" lie behind the front; whether a list has anything
+// there is the order of its slots 2 and 3 (slot 2 > slot 3: look further - tbk_order_kernel), and a
+// window that misses in such a front is settled exactly by the deferred walk, starting at the home
+// line.  Logical slot numbers, flags in slots 4..7, guests and probe sequences are those of the
+// plain layout: only tbk_slot_at() knows where a slot lies.
+TBK_HD uint32_t tbk_slot_at(uint32_t flags, uint32_t stride, uint32_t half, uint32_t s) {
+    if ((flags & TBK_FLAG_FRONT) && stride == 16) return ((s & 4u) << 1) + (half >> 1) + (s & 3u);
+    return half + s;
+}
 struct TbkTableView {
     const uint64_t *slots;
     uint32_t n_buckets;
     uint32_t stride;  // slots per bucket line (8 or 16)
     uint32_t half;    // first slot of this list inside the line (0 or 8)
     TbkMz mz;         // bucket selection
-    uint32_t guests;  // paired table, k < 32: a full half's surplus may sit, tagged, in the other half of the line
+    uint32_t guests;  // TBK_FLAG_GUESTS (paired table, k < 32) | TBK_FLAG_FRONT
 };
 
 // The probe sequence of a key: its home bucket (chosen by the minimizer, shared with its

@@ -28,7 +28,7 @@
 #include "tbk_common.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
-extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, const uint32_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
@@ -165,7 +165,8 @@ struct tbk_classifier {
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
-    uint32_t guests = 0;         // k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line
+    uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line
+    uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
     hipStream_t compute = nullptr, copy = nullptr;
     Slot ring[RING];
@@ -269,10 +270,10 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
 static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz, uint32_t *d_overflowed,
                        const uint64_t *d_keys, uint64_t n, uint64_t *distinct_out,
                        TbkTableView skip = TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, uint64_t *skipped_out = nullptr,
-                       uint32_t *d_left_line = nullptr, uint32_t guests = 0, uint64_t *past_out = nullptr) {
+                       uint32_t *d_left_line = nullptr, uint32_t guests = 0, uint64_t *past_out = nullptr, uint64_t *back_out = nullptr) {
     // counters: [0] distinct keys stored, [1] keys dropped because `skip` holds them, [2] keys that found
-    // their own half of their home line full
-    unsigned long long *d_cnt = nullptr, cnt[3] = {0, 0, 0};
+    // their own half of their home line full, [3] keys stored behind the first four slots of it
+    unsigned long long *d_cnt = nullptr, cnt[4] = {0, 0, 0, 0};
     int *d_failed = nullptr;
     hipError_t e = hipMalloc((void **)&d_cnt, sizeof cnt);
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
@@ -289,6 +290,7 @@ static int insert_keys(uint64_t *d_slots, uint32_t n_buckets, uint32_t stride, u
     *distinct_out = cnt[0];
     if (skipped_out) *skipped_out = cnt[1];
     if (past_out) *past_out = cnt[2];
+    if (back_out) *back_out = cnt[3] + cnt[2];  // not in the front of their home line: behind it in the same half, or past it
     return TBK_OK;
 }
 
@@ -302,8 +304,9 @@ static int overflow_bitmap(uint64_t n_halves, uint32_t **out) {
     return TBK_OK;
 }
 
-static int order_table(uint64_t *d_slots, uint64_t n_halves, const uint32_t *d_overflowed, const uint32_t *d_left_line = nullptr) {
-    hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, d_left_line, nullptr);
+static int order_table(uint64_t *d_slots, uint64_t n_halves, const uint32_t *d_overflowed, const uint32_t *d_left_line = nullptr,
+                       uint32_t flags = 0, uint32_t stride = 8) {
+    hipError_t e = tbk_launch_order(d_slots, n_halves, d_overflowed, d_left_line, flags, stride, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "table order pass: %s", hipGetErrorString(e));
     return TBK_OK;
@@ -576,21 +579,22 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
         return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     uint32_t *d_over = nullptr, *d_left = nullptr;
-    uint64_t past_a = 0, past_b = 0;
+    uint64_t past_a = 0, past_b = 0, back_a = 0, back_b = 0;
     int rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_over);
-    if (!rc && c->guests) rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_left);
+    if (!rc && (c->guests & TBK_FLAG_GUESTS)) rc = overflow_bitmap((uint64_t)c->n_buckets * 2, &d_left);
     if (!rc) {
         rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
-                         TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests, &past_a);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
+                         TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests, &past_a, &back_a);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left, c->guests, 16);
         if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
-                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests, &past_b);
-        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left);
+                                  TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests, &past_b, &back_b);
+        if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left, c->guests, 16);
     }
     if (d_over) (void)hipFree(d_over);
     if (d_left) (void)hipFree(d_left);
     if (rc) { (void)hipFree(c->d_pair); c->d_pair = nullptr; return rc; }
     c->past_half = past_a + past_b;
+    c->behind_front = back_a + back_b;
     *past = past_a + past_b;
     return TBK_OK;
 }
@@ -628,7 +632,18 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
     const bool load_pinned = env_double("TBK_TABLE_LOAD", 0) > 0;
-    c->guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? 1u : 0u;
+    const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
+    // Front layout (tbk_common.h): the probe kernel fetches 64 bytes of a line, the first four slots of
+    // each list, and settles what lies behind them in the deferred walk.  Every step in which one of
+    // the wave's 64 windows meets a front with keys behind it goes through the careful part, so the
+    // layout pays only while such fronts are rare: measured on 2 x 3e8 uniform keys, 174 Gbases/s at
+    // load 0.04 (0.5 % of the keys behind a front) and 182 at 0.02 (0.24 %) against 157 for whole lines,
+    // but 151 at load 0.08 (1.3 %: at that size keys that share their sampled 16-mer are no rarity, and
+    // they share a bucket whatever the table's size).  So it is taken when at most TBK_BEHIND_FRONT
+    // (default 0.4 %) of the keys lie behind a front - small lists, roomy tables - and the whole-line
+    // layout stands otherwise: one more build of a fraction of a second.  TBK_FRONT=1 / 0 pins the
+    // layout (mod-sampling only).
+    const double front_pin = env_double("TBK_FRONT", -1);
     int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
     for (int attempt = 0; attempt < 2; attempt++) {
         const int mod_sampling = pin >= 0 ? (pin != 0) : (attempt == 0);
@@ -640,10 +655,24 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (c->d_pair) { (void)hipFree(c->d_pair); c->d_pair = nullptr; }
         built_t = c->mz.t;
         c->layout_builds++;
+        // (lists beyond 1e8 keys - TBK_FRONT_MAX_KEYS - are not even tried in it: at 3e8 keys three times the
+        // allowance lies behind the fronts, and the trial would be a 60 GB build thrown away)
+        const bool front = c->mz.t > 0 && (front_pin >= 0 ? front_pin != 0 : attempt == 0 && (double)n_big <= env_double("TBK_FRONT_MAX_KEYS", 1e8));
+        c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
         if (rc) { delete c; return rc; }
-        const double clustered = (double)past / (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
+        const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
+        const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
+        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.004)) {
+            // the lists spread, but too many keys lie behind a front: the same table in whole lines
+            (void)hipFree(c->d_pair); c->d_pair = nullptr;
+            c->guests = guests;
+            c->layout_builds++;
+            rc = build_pair_table(c, a, b, 0.08, &past);
+            if (rc) { delete c; return rc; }
+            break;
+        }
         if (attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
     }
     rc = classifier_streams(c);
@@ -668,7 +697,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->max_blocks = src->max_blocks;
     c->packed_h2d = src->packed_h2d;
     c->guests = src->guests;
-    c->layout_builds = src->layout_builds; c->past_half = src->past_half;
+    c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) {
@@ -753,6 +782,13 @@ extern "C" int tbk_classifier_build_info(const tbk_classifier *c, int *layout_bu
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
     if (layout_builds) *layout_builds = c->layout_builds;
     if (keys_past_half) *keys_past_half = c->past_half;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_behind_front) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (front) *front = (c->guests & TBK_FLAG_FRONT) ? 1 : 0;
+    if (keys_behind_front) *keys_behind_front = c->behind_front;
     return TBK_OK;
 }
 

@@ -23,15 +23,14 @@ __device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t k
     if (key >= TBK_NOKEY) return false;
     uint32_t b = tbk_bucket_of(key, t.mz, t.n_buckets);
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
-        const uint64_t *line = t.slots + (uint64_t)b * t.stride + t.half;
-        for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
-            if (line[s] == key) return true;
-        if (!(line[6] > line[7])) return false;  // no key went past this half
-        if (t.guests) {
-            const uint64_t *other = t.slots + (uint64_t)b * t.stride + (t.half ^ 8u);
-            for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
-                if (other[s] == (key | TBK_GUEST)) return true;
-            if (!(line[4] > line[5])) return false;  // keys went past the half, none left the line
+        const uint64_t *line = t.slots + (uint64_t)b * t.stride;
+        for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
+            if (line[tbk_slot_at(t.guests, t.stride, t.half, s)] == key) return true;
+        if (!(line[tbk_slot_at(t.guests, t.stride, t.half, 6)] > line[tbk_slot_at(t.guests, t.stride, t.half, 7)])) return false;  // no key went past this half
+        if (t.guests & TBK_FLAG_GUESTS) {
+            for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
+                if (line[tbk_slot_at(t.guests, t.stride, t.half ^ 8u, s)] == (key | TBK_GUEST)) return true;
+            if (!(line[tbk_slot_at(t.guests, t.stride, t.half, 4)] > line[tbk_slot_at(t.guests, t.stride, t.half, 5)])) return false;  // keys went past the half, none left the line
         }
         b = tbk_next_bucket(key, t.mz, t.n_buckets, b, walked == 0);
     }
@@ -52,7 +51,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET, which = half / TBK_SLOTS_PER_BUCKET;
-    unsigned long long mine = 0, skipped = 0, past = 0;  // past: keys that found their own half of their home line full
+    unsigned long long mine = 0, skipped = 0, past = 0, back = 0;  // past: keys that found their own half of their home line full; back: keys behind the first four slots of it
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;  // TBK_EMPTY / TBK_NOKEY: never a canonical key, never stored
@@ -81,13 +80,14 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
             c++;
             bool done = false;
             for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
-                unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride + half);
-                for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
-                    unsigned long long cur = __hip_atomic_load(&line[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride);
+                for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
+                    unsigned long long *slot = &line[tbk_slot_at(guests, stride, half, s)];
+                    unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cur == key) { done = true; break; }
                     if (cur == TBK_EMPTY) {
-                        unsigned long long old = atomicCAS(&line[s], (unsigned long long)TBK_EMPTY, (unsigned long long)key);
-                        if (old == TBK_EMPTY) { if (c == 0) mine++; done = true; }
+                        unsigned long long old = atomicCAS(slot, (unsigned long long)TBK_EMPTY, (unsigned long long)key);
+                        if (old == TBK_EMPTY) { if (c == 0) { mine++; back += (s >= 4 && walked == 0); } done = true; }
                         else if (old == key) { done = true; }
                         // else: somebody else's key took the slot; keep scanning
                     }
@@ -98,16 +98,16 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
                     const uint64_t bit = (uint64_t)b * halves + which;
                     atomicOr(&overflowed[bit >> 5], 1u << (bit & 31));
                     past += (c == 0 && walked == 0);
-                    if (guests) {
+                    if (guests & TBK_FLAG_GUESTS) {
                         // ... first into a free slot of the other list's half of the same line, tagged: lookups
                         // hold the whole line, so a guest costs them two compares, not another random line
-                        unsigned long long *other = (unsigned long long *)(slots + (uint64_t)b * stride + (half ^ 8u));
                         const unsigned long long tagged = key | TBK_GUEST;
-                        for (int s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
-                            unsigned long long cur = __hip_atomic_load(&other[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
+                            unsigned long long *slot = &line[tbk_slot_at(guests, stride, half ^ 8u, s)];
+                            unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur == tagged) { done = true; break; }
                             if (cur == TBK_EMPTY) {
-                                unsigned long long old = atomicCAS(&other[s], (unsigned long long)TBK_EMPTY, tagged);
+                                unsigned long long old = atomicCAS(slot, (unsigned long long)TBK_EMPTY, tagged);
                                 if (old == TBK_EMPTY) { if (c == 0) mine++; done = true; }
                                 else if (old == tagged) { done = true; }
                             }
@@ -124,6 +124,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     if (mine) atomicAdd(n_distinct, mine);
     if (skipped) atomicAdd(n_skipped, skipped);
     if (past) atomicAdd(n_past, past);
+    if (back) atomicAdd(n_past + 1, back);
 }
 
 // After all inserts: give every full half the order of its last two slots that says whether a key
@@ -131,16 +132,29 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
 // slots 4 and 5 that says whether one of those keys left the line (slot 4 > slot 5).  One thread per half.
 __global__ void __launch_bounds__(256)
 tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t *__restrict__ overflowed,
-                 const uint32_t *__restrict__ left_line) {
+                 const uint32_t *__restrict__ left_line, uint32_t flags, uint32_t stride) {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n_halves) return;
-    ulonglong2 *last = reinterpret_cast<ulonglong2 *>(slots + h * TBK_SLOTS_PER_BUCKET + 6);
+    const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET;
+    uint64_t *line = slots + (h / halves) * stride;
+    const uint32_t half = (uint32_t)(h % halves) * TBK_SLOTS_PER_BUCKET;
+    // slot pairs (2,3), (4,5), (6,7) of a list are 16 contiguous bytes in either layout
+    if (flags & TBK_FLAG_FRONT) {
+        // front layout: slot 2 > slot 3 says "this list has keys behind the front" (a fifth key, or beyond)
+        ulonglong2 *front = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 2));
+        const ulonglong2 f = *front;
+        if (f.y != TBK_EMPTY) {
+            const bool more = line[tbk_slot_at(flags, stride, half, 4)] != TBK_EMPTY;
+            if ((f.x > f.y) != more) *front = make_ulonglong2(f.y, f.x);
+        }
+    }
+    ulonglong2 *last = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 6));
     ulonglong2 v = *last;
     if (v.y == TBK_EMPTY) return;  // not full: nothing went past it, and slot 6 <= slot 7 = EMPTY already says so
     const bool past = (overflowed[h >> 5] >> (h & 31)) & 1u;
     if ((v.x > v.y) != past) *last = make_ulonglong2(v.y, v.x);
     if (left_line != nullptr) {
-        ulonglong2 *mid = reinterpret_cast<ulonglong2 *>(slots + h * TBK_SLOTS_PER_BUCKET + 4);
+        ulonglong2 *mid = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 4));
         const ulonglong2 m = *mid;
         const bool left = (left_line[h >> 5] >> (h & 31)) & 1u;
         if ((m.x > m.y) != left) *mid = make_ulonglong2(m.y, m.x);
@@ -303,33 +317,38 @@ constexpr int TBK_QCAP = 256;  // queue entries per wave; a window-loop step add
 
 // follow the probe sequence of a key of list `half` (0 hapA, 8 hapB) past its home bucket, until the
 // key is found or a half that no key went past
+template <bool FRONT>
 __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uint64_t key, uint32_t bucket, bool pend) {
+    constexpr uint32_t LAYOUT = FRONT ? TBK_FLAG_FRONT : 0u;  // compile-time: the whole-line walk keeps its plain pointer arithmetic
     bool found = false, first = true;
+    // front layout: the window loop saw the first four slots of the home line only - the walk begins
+    // with that line (its other four slots, its guests), not behind it
+    bool at_home = FRONT;
     uint32_t guard = 0;
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
-            bucket = tbk_next_bucket(key, t.mz, t.n_buckets, bucket, first);
+            if (at_home) at_home = false;
+            else { bucket = tbk_next_bucket(key, t.mz, t.n_buckets, bucket, first); first = false; }
             // 32 bytes at a time: this rare path must not set the kernel's register high-water mark
-            const ulonglong2 *h = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + half);
+            const uint64_t *line = t.slots + (uint64_t)bucket * 16;
             bool hit = false;
             ulonglong2 v2 = make_ulonglong2(0, 0), v3 = make_ulonglong2(0, 0);
 #pragma unroll 1
-            for (int i = 0; i < 4; i += 2) {
-                v2 = h[i];
-                v3 = h[i + 1];
+            for (uint32_t i = 0; i < 8; i += 4) {
+                v2 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half, i));
+                v3 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half, i + 2));
                 hit = hit || v2.x == key || v2.y == key || v3.x == key || v3.y == key;
             }
             found = found || hit;
             bool past = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
-            if (past && t.guests) {
+            if (past && (t.guests & TBK_FLAG_GUESTS)) {
                 // ... into the other half of this line (tagged), or - slot 4 > slot 5 - out of the line
                 const bool left = v2.x > v2.y;
-                const ulonglong2 *g = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)bucket * 16 + (half ^ 8u));
                 const uint64_t tagged = key | TBK_GUEST;
                 bool guest = false;
 #pragma unroll 1
-                for (int i = 0; i < 4; i++) {
-                    const ulonglong2 w = g[i];
+                for (uint32_t i = 0; i < 8; i += 2) {
+                    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half ^ 8u, i));
                     guest = guest || w.x == tagged || w.y == tagged;
                 }
                 found = found || guest;
@@ -337,7 +356,6 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
             }
             pend = past;
         }
-        first = false;
     }
     return found;
 }
@@ -354,7 +372,7 @@ __device__ __forceinline__ void count_hits(const ProbeArgs &p, uint32_t *rcnt, u
     else atomicAdd(&p.counts[2 * (r_first + rrel) + hap], (int)n);
 }
 
-template <bool MULTI>
+template <bool MULTI, bool FRONT>
 __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, uint32_t qn, uint64_t r_first,
                                             uint32_t lane, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     for (uint32_t base = 0; base < qn; base += 64) {
@@ -362,7 +380,7 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
         uint4 it = make_uint4(0, 0, 0, 0);
         if (act) it = q[base + lane];
         const uint64_t key = (uint64_t)it.x | ((uint64_t)it.y << 32);
-        const bool found = walk_one(p.t, (it.w & 1u) * 8u, key, it.z, act);
+        const bool found = walk_one<FRONT>(p.t, (it.w & 1u) * 8u, key, it.z, act);
         const bool count_a = found && !(it.w & 1u), count_b = found && (it.w & 1u);
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(ballot(count_a));
@@ -376,7 +394,7 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
 
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
 // window).  MULTI = the pass touches more than one read.
-template <int W, bool M64, bool SAMP, bool MULTI>
+template <int W, bool M64, bool SAMP, bool MULTI, bool FRONT>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
@@ -564,7 +582,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     };
     // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
     constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
-    constexpr bool LA = TBK_LOOKAHEAD && !MULTI;  // single-read passes only: the multi-read pass has no scalar registers to spare
+    constexpr bool LA = TBK_LOOKAHEAD && !MULTI && !FRONT;  // single-read passes only: the multi-read pass has no scalar registers to spare
     // One window of look-ahead.  A wave that asks for its lines and then needs them at once sits
     // out the whole HBM latency every step, and four waves per SIMD do not cover it (measured: the
     // kernel moved 0.79 of the line ceiling).  So the bucket of window j+1 is worked out during step j,
@@ -624,7 +642,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             TBK_COUNT(4, __popcll(ballot((int32_t)bk[s] < 0)));
             if ((int32_t)bk[s] < 0) {
                 const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
-                if (LA) {
+                if (FRONT) {
+                    va[s] = load_slots(line);  // the front of the line: [A0 A1 | A2 A3 | B0 B1 | B2 B3], 16 bytes per quad lane
+                } else if (LA) {
                     load_line_async(line, va[s], vb[s]);
                 } else {
                     va[s] = load_slots(line);
@@ -648,6 +668,73 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 #endif
             tbk_wait_lines(va, vb);  // this step's lines are in; the look-ahead load stays in flight
         }
+        if constexpr (FRONT) {
+            // Front layout (tbk_common.h): quad lanes 0,1 hold hapA's first four slots of the line, lanes 2,3
+            // hapB's.  One compare pair serves both lists - which list a hit counts for is the lane it
+            // fell on - and the order of a lane's two slots is, on lanes 1 and 3, the list's "look behind
+            // the front" flag.  A window that misses in a front with that flag goes to the deferred walk,
+            // which begins at the home line; everything else is settled here.
+            const uint32_t klo0 = quad_bcast<0>(my_klo), khi0 = quad_bcast<0>(my_khi), klo1 = quad_bcast<1>(my_klo), khi1 = quad_bcast<1>(my_khi);
+            const uint32_t klo2 = quad_bcast<2>(my_klo), khi2 = quad_bcast<2>(my_khi), klo3 = quad_bcast<3>(my_klo), khi3 = quad_bcast<3>(my_khi);
+            const uint32_t klo[4] = {klo0, klo1, klo2, klo3}, khi[4] = {khi0, khi1, khi2, khi3};
+            uint64_t hit[4], more[4], any_hit = 0, any_more = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
+                hit[s] = ballot(va[s].x == kk) | ballot(va[s].y == kk);
+                more[s] = ballot(va[s].x > va[s].y) & 0xAAAAAAAAAAAAAAAAull;  // lane 1: hapA's slots 2,3; lane 3: hapB's
+                any_hit |= hit[s];
+                any_more |= more[s];
+            }
+            TBK_COUNT(0, 1);
+            if (any_more != 0) {
+                TBK_COUNT(1, 1);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (more[s] == 0) continue;
+                    TBK_COUNT(2, 1);
+                    const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
+                    const uint64_t valid = ballot(kk != TBK_NOKEY) & 0x1111111111111111ull;
+                    const uint64_t miss = valid & ~quad_any(hit[s]);  // a hit in either list's front is final (the lists are disjoint)
+                    const uint64_t walk_a = miss & ((more[s] & 0x2222222222222222ull) >> 1);
+                    const uint64_t walk_b = miss & ((more[s] & 0x8888888888888888ull) >> 3);
+                    const uint64_t queued = walk_a | walk_b;
+                    if (queued) {
+                        const uint64_t me = 1ull << lane;
+                        const uint32_t rid_s = !MULTI ? 0u : s == 0 ? quad_bcast<0>(my_rid) : s == 1 ? quad_bcast<1>(my_rid)
+                                                       : s == 2 ? quad_bcast<2>(my_rid) : quad_bcast<3>(my_rid);
+                        const uint32_t n_a = (uint32_t)__popcll(walk_a);
+                        if (queued & me) {
+                            const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
+                            const uint32_t home = bk[s] & 0x7FFFFFFFu;
+                            if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(klo[s], khi[s], home, rrel << 1);
+                            if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(klo[s], khi[s], home, (rrel << 1) | 1u);
+                        }
+                        qn += n_a + (uint32_t)__popcll(walk_b);
+                        TBK_COUNT(3, __popcll(queued));
+                    }
+                }
+            }
+            if (any_hit != 0) {
+                if (!MULTI) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        acc_a += (uint32_t)__popcll(hit[s] & 0x3333333333333333ull);
+                        acc_b += (uint32_t)__popcll(hit[s] & 0xCCCCCCCCCCCCCCCCull);
+                    }
+                } else {
+                    uint64_t wa = 0, wb = 0;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const uint64_t ha = hit[s] & 0x3333333333333333ull, hb = hit[s] & 0xCCCCCCCCCCCCCCCCull;
+                        wa |= ((ha | (ha >> 1)) & 0x1111111111111111ull) << s;
+                        wb |= (((hb >> 2) | (hb >> 3)) & 0x1111111111111111ull) << s;
+                    }
+                    lane_a += (uint32_t)(wa >> lane) & 1u;
+                    lane_b += (uint32_t)(wb >> lane) & 1u;
+                }
+            }
+        } else {
         // Fast path.  A key is stored at most once, in one of the two halves (hapB keys that hapA
         // holds are dropped at build time), so the raw ballots count windows and hapA-over-hapB
         // priority (c/kmers.c:291-294) needs no work here.  Only a window whose home half was left
@@ -684,7 +771,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 const uint64_t fa = full_a[s] >> 3, fb = full_b[s] >> 3;  // at the quad's lane-0 bit
                 TBK_COUNT(2, 1);
                 uint64_t walk_a, walk_b;
-                if (p.t.guests) {
+                if (p.t.guests & TBK_FLAG_GUESTS) {
                     // The keys that went past a half went, tagged, into free slots of the line's other half
                     // first, and the quad holds that half already.  A tagged slot equal to the window's key
                     // IS the key (stored once, and only in its home line's other half when its own half was
@@ -756,16 +843,17 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 lane_b += (uint32_t)(wb >> lane) & 1u;
             }
         }
+        }  // !FRONT
         if (qn > TBK_QCAP - 128) {  // make room for the next step's worst case
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+            drain_walks<MULTI, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qn = 0;
         }
     }
     if (qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_walks<MULTI>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+        drain_walks<MULTI, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #ifdef TBK_COUNTERS
@@ -802,7 +890,7 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
 }
 
-template <int W, bool M64, bool SAMP>
+template <int W, bool M64, bool SAMP, bool FRONT>
 // 4 waves per SIMD (<= 128 VGPRs).  Measured same-box A/B (tools/gpu_ab.sh): asking for 5 or 6
 // waves makes the allocator spill and loses 12-50 %; a third pass variant specialised for
 // two-read passes bloats the code and loses 8-14 % even on single-read passes.
@@ -840,8 +928,8 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, SAMP, false>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
-        else probe_pass<W, M64, SAMP, true>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
+        if (last_pos < r_end) probe_pass<W, M64, SAMP, false, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
+        else probe_pass<W, M64, SAMP, true, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
     }
 }
 
@@ -862,9 +950,9 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uin
 
 // n_halves = n_buckets * stride / 8; d_overflowed has one bit per half (bit index = bucket * halves + which)
 extern "C" hipError_t tbk_launch_order(uint64_t *slots, uint64_t n_halves, const uint32_t *d_overflowed, const uint32_t *d_left_line,
-                                       hipStream_t stream) {
+                                       uint32_t flags, uint32_t stride, hipStream_t stream) {
     if (n_halves == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_order_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, d_overflowed, d_left_line);
+    hipLaunchKernelGGL(tbk_order_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, d_overflowed, d_left_line, flags, stride);
     return hipGetLastError();
 }
 
@@ -908,13 +996,15 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d
     const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
     // kernel variant: W m-mers per span; 32-bit (m <= 16) or 64-bit m-mers; random-minimizer or
     // mod-sampling selection
-    const bool m64 = t.mz.m > 16, samp = t.mz.t > 0;
-#define TBK_LAUNCH(N, M, S) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S>), grid, block, 0, stream, p)
-#define TBK_W(N) case N: if (samp) { if (m64) TBK_LAUNCH(N, true, true); else TBK_LAUNCH(N, false, true); } \
-                         else { if (m64) TBK_LAUNCH(N, true, false); else TBK_LAUNCH(N, false, false); } break;
+    const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0;
+    if (front && !samp) return hipErrorInvalidValue;  // front tables are built for mod-sampling only (tbk_host.cpp)
+#define TBK_LAUNCH(N, M, S, F) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F>), grid, block, 0, stream, p)
+#define TBK_W(N) case N: if (samp && front) { if (m64) TBK_LAUNCH(N, true, true, true); else TBK_LAUNCH(N, false, true, true); } \
+                         else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
+                         else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
     switch (t.mz.w) {
-        case 0: TBK_LAUNCH(0, false, false); break;
-        case 1: if (m64) TBK_LAUNCH(1, true, false); else TBK_LAUNCH(1, false, false); break;
+        case 0: TBK_LAUNCH(0, false, false, false); break;
+        case 1: if (m64) TBK_LAUNCH(1, true, false, false); else TBK_LAUNCH(1, false, false, false); break;
         TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
         default: return hipErrorInvalidValue;
     }
