@@ -441,7 +441,8 @@ def main():
             t = json.load(open(tfile))
             same = (t.get("read_len") == L and t.get("kmers_per_list") == n_list
                     and t.get("k") == k and t.get("bucket_select") == bucket_select and t.get("lists", "uniform") == args.lists
-                    and abs(t.get("table_load", 0) - table_load) < 2e-3)
+                    and abs(t.get("table_load", 0) - table_load) < 2e-3
+                    and bool(t.get("front_layout", False)) == bool(stats.get("front_layout")))
             if same:  # measured in separate rocprofv3 --pmc passes on this configuration; scaled to this launch's windows
                 traffic = t["hbm_bytes_per_window"] * windows
         except Exception:

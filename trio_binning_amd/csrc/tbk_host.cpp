@@ -634,15 +634,15 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     const bool load_pinned = env_double("TBK_TABLE_LOAD", 0) > 0;
     const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
     // Front layout (tbk_common.h): the probe kernel fetches 64 bytes of a line, the first four slots of
-    // each list, and settles what lies behind them in the deferred walk.  Every step in which one of
-    // the wave's 64 windows meets a front with keys behind it goes through the careful part, so the
-    // layout pays only while such fronts are rare: measured on 2 x 3e8 uniform keys, 174 Gbases/s at
-    // load 0.04 (0.5 % of the keys behind a front) and 182 at 0.02 (0.24 %) against 157 for whole lines,
-    // but 151 at load 0.08 (1.3 %: at that size keys that share their sampled 16-mer are no rarity, and
-    // they share a bucket whatever the table's size).  So it is taken when at most TBK_BEHIND_FRONT
-    // (default 0.4 %) of the keys lie behind a front - small lists, roomy tables - and the whole-line
-    // layout stands otherwise: one more build of a fraction of a second.  TBK_FRONT=1 / 0 pins the
-    // layout (mod-sampling only).
+    // each list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list
+    // first), and settles what lies behind them in the deferred walk.  Every step in which one of the
+    // wave's 64 windows meets a front with keys behind it goes through the careful part, so the layout
+    // pays while such fronts are rare.  Measured on 2 x 3e8 uniform keys against 155-157 Gbases/s for
+    // whole lines: 160-162 at load 0.08 (0.29 % of the keys behind a front), 178 at load 0.04 (0.06 %).
+    // Lists that cluster put a third of their keys behind the fronts (103-106 Gbases/s) and are rebuilt
+    // in whole lines together with the sampling rule, as before; lists that spread but still leave more
+    // than TBK_BEHIND_FRONT (default 0.6 %) of their keys behind a front get the same table in whole
+    // lines.  TBK_FRONT=1 / 0 pins the layout (mod-sampling only).
     const double front_pin = env_double("TBK_FRONT", -1);
     int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -655,16 +655,14 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (c->d_pair) { (void)hipFree(c->d_pair); c->d_pair = nullptr; }
         built_t = c->mz.t;
         c->layout_builds++;
-        // (lists beyond 1e8 keys - TBK_FRONT_MAX_KEYS - are not even tried in it: at 3e8 keys three times the
-        // allowance lies behind the fronts, and the trial would be a 60 GB build thrown away)
-        const bool front = c->mz.t > 0 && (front_pin >= 0 ? front_pin != 0 : attempt == 0 && (double)n_big <= env_double("TBK_FRONT_MAX_KEYS", 1e8));
+        const bool front = c->mz.t > 0 && (front_pin >= 0 ? front_pin != 0 : attempt == 0);
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
         if (rc) { delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
-        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.004)) {
+        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.006)) {
             // the lists spread, but too many keys lie behind a front: the same table in whole lines
             (void)hipFree(c->d_pair); c->d_pair = nullptr;
             c->guests = guests;

@@ -26,6 +26,9 @@ __device__ __forceinline__ bool tbk_lookup_slow(const TbkTableView t, uint64_t k
         const uint64_t *line = t.slots + (uint64_t)b * t.stride;
         for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
             if (line[tbk_slot_at(t.guests, t.stride, t.half, s)] == key) return true;
+        if (t.stride == 16 && (t.guests & (TBK_FLAG_FRONT | TBK_FLAG_GUESTS)) == (TBK_FLAG_FRONT | TBK_FLAG_GUESTS))
+            for (uint32_t s = 0; s < 4; s++)  // front layout: a key may sit, tagged, in the other list's front of any line on its way
+                if (line[tbk_slot_at(t.guests, t.stride, t.half ^ 8u, s)] == (key | TBK_GUEST)) return true;
         if (!(line[tbk_slot_at(t.guests, t.stride, t.half, 6)] > line[tbk_slot_at(t.guests, t.stride, t.half, 7)])) return false;  // no key went past this half
         if (t.guests & TBK_FLAG_GUESTS) {
             for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET; s++)
@@ -51,6 +54,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t halves = stride / TBK_SLOTS_PER_BUCKET, which = half / TBK_SLOTS_PER_BUCKET;
+    const bool front_guests = stride == 16 && (guests & (TBK_FLAG_FRONT | TBK_FLAG_GUESTS)) == (TBK_FLAG_FRONT | TBK_FLAG_GUESTS);
     unsigned long long mine = 0, skipped = 0, past = 0, back = 0;  // past: keys that found their own half of their home line full; back: keys behind the first four slots of it
     for (; i < n; i += step) {
         const uint64_t key = keys[i];
@@ -82,6 +86,23 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
             for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                 unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * stride);
                 for (uint32_t s = 0; s < TBK_SLOTS_PER_BUCKET && !done; s++) {
+                    if (s == 4 && front_guests) {
+                        // front layout: the list's four front slots are taken - before the key goes behind the
+                        // front it may sit, tagged, in a free front slot of the other list (a window then still
+                        // finds it in the 64 bytes it fetches)
+                        const unsigned long long tagged = key | TBK_GUEST;
+                        for (uint32_t g = 0; g < 4 && !done; g++) {
+                            unsigned long long *slot = &line[tbk_slot_at(guests, stride, half ^ 8u, g)];
+                            unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (cur == tagged) { done = true; break; }
+                            if (cur == TBK_EMPTY) {
+                                unsigned long long old = atomicCAS(slot, (unsigned long long)TBK_EMPTY, tagged);
+                                if (old == TBK_EMPTY) { if (c == 0) mine++; done = true; }
+                                else if (old == tagged) { done = true; }
+                            }
+                        }
+                        if (done) break;
+                    }
                     unsigned long long *slot = &line[tbk_slot_at(guests, stride, half, s)];
                     unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cur == key) { done = true; break; }
@@ -146,6 +167,15 @@ tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t
         if (f.y != TBK_EMPTY) {
             const bool more = line[tbk_slot_at(flags, stride, half, 4)] != TBK_EMPTY;
             if ((f.x > f.y) != more) *front = make_ulonglong2(f.y, f.x);
+        }
+        if (flags & TBK_FLAG_GUESTS) {
+            // ... and slot 0 > slot 1 says "some of these four slots hold the other list's keys" (tagged;
+            // a lone guest in slot 0 moves to slot 1 for that: EMPTY is larger than anything)
+            ulonglong2 *head = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 0));
+            const ulonglong2 h0 = *head;
+            const bool tagged = ((h0.x != TBK_EMPTY) && (h0.x & TBK_GUEST)) || ((h0.y != TBK_EMPTY) && (h0.y & TBK_GUEST)) ||
+                                ((f.x != TBK_EMPTY) && (f.x & TBK_GUEST)) || ((f.y != TBK_EMPTY) && (f.y & TBK_GUEST));
+            if ((h0.x > h0.y) != tagged) *head = make_ulonglong2(h0.y, h0.x);
         }
     }
     ulonglong2 *last = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 6));
@@ -338,6 +368,13 @@ __device__ __forceinline__ bool walk_one(const TbkPairView t, uint32_t half, uin
                 v2 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half, i));
                 v3 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half, i + 2));
                 hit = hit || v2.x == key || v2.y == key || v3.x == key || v3.y == key;
+            }
+            if (FRONT && !hit && (t.guests & TBK_FLAG_GUESTS)) {
+                // front layout: the key may sit, tagged, in the other list's front slots of this line
+                const uint64_t tagged = key | TBK_GUEST;
+                const ulonglong2 g0 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half ^ 8u, 0));
+                const ulonglong2 g1 = *reinterpret_cast<const ulonglong2 *>(line + tbk_slot_at(LAYOUT, 16, half ^ 8u, 2));
+                hit = g0.x == tagged || g0.y == tagged || g1.x == tagged || g1.y == tagged;
             }
             found = found || hit;
             bool past = !hit && v3.x > v3.y;  // slot 6 > slot 7: a key went past this half
@@ -682,10 +719,29 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             for (int s = 0; s < 4; s++) {
                 const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
                 hit[s] = ballot(va[s].x == kk) | ballot(va[s].y == kk);
-                more[s] = ballot(va[s].x > va[s].y) & 0xAAAAAAAAAAAAAAAAull;  // lane 1: hapA's slots 2,3; lane 3: hapB's
-                any_hit |= hit[s];
+                // the order of a lane's two slots: lanes 1 and 3 - the list has keys behind its front;
+                // lanes 0 and 2 - these four slots hold keys of the OTHER list (tagged)
+                more[s] = ballot(va[s].x > va[s].y);
                 any_more |= more[s];
             }
+            if ((p.t.guests & TBK_FLAG_GUESTS) && (any_more & 0x5555555555555555ull) != 0) {  // (without guests the order of slots 0 and 1 means nothing)
+                // A list's fifth key of a bucket sits, tagged, in a free front slot of the other list before it
+                // goes behind the front.  Found there it counts for the list whose lanes these are not: the
+                // hit moves over to that list's lanes of the quad.
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if ((more[s] & 0x5555555555555555ull) == 0) continue;
+                    const uint64_t tagged = ((uint64_t)klo[s] | ((uint64_t)khi[s] << 32)) | TBK_GUEST;
+                    const uint64_t g = ballot(va[s].x == tagged) | ballot(va[s].y == tagged);
+                    hit[s] |= ((g & 0x3333333333333333ull) << 2) | ((g & 0xCCCCCCCCCCCCCCCCull) >> 2);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                more[s] &= 0xAAAAAAAAAAAAAAAAull;
+                any_hit |= hit[s];
+            }
+            any_more &= 0xAAAAAAAAAAAAAAAAull;
             TBK_COUNT(0, 1);
             if (any_more != 0) {
                 TBK_COUNT(1, 1);
