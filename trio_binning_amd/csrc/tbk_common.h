@@ -304,12 +304,16 @@ TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
 // bucket nearly every window can be answered from four slots of each list.  So the line is laid out
 //     [ A0 A1 A2 A3 | B0 B1 B2 B3 | A4 A5 A6 A7 | B4 B5 B6 B7 ]
 // and the probe kernel fetches the first 64 bytes only (one 16-byte load per quad lane: lanes 0,1 hold
-// hapA's first four slots, lanes 2,3 hapB's).  Slots fill in index order, so a list's keys 5.. of a
-// bucket, its guests and everything "past the half" lie behind the front; whether a list has anything
-// there is the order of its slots 2 and 3 (slot 2 > slot 3: look further - tbk_order_kernel), and a
-// window that misses in such a front is settled exactly by the deferred walk, starting at the home
-// line.  Logical slot numbers, flags in slots 4..7, guests and probe sequences are those of the
-// plain layout: only tbk_slot_at() knows where a slot lies.
+// hapA's first four slots, lanes 2,3 hapB's).  Slots fill in index order.  With guests (k < 32) a list's
+// fifth key of a bucket first tries the free front slots of the OTHER list, tagged with TBK_GUEST - a
+// window still finds it in the 64 bytes it fetches, and counts it for the list whose lanes those are
+// not; whether four front slots hold such keys is the order of their slots 0 and 1 (slot 0 > slot 1:
+// compare the tagged key too).  What lies behind the front - a list's slots 4..7, the guests there,
+// everything "past the half" - is announced by the order of the list's slots 2 and 3 (slot 2 > slot 3:
+// look further), and a window that misses in such a front is settled exactly by the deferred walk,
+// starting at the home line (tbk_order_kernel writes both orders after the inserts).  Logical slot
+// numbers, flags in slots 4..7, guests and probe sequences are those of the plain layout: only
+// tbk_slot_at() knows where a slot lies.
 TBK_HD uint32_t tbk_slot_at(uint32_t flags, uint32_t stride, uint32_t half, uint32_t s) {
     if ((flags & TBK_FLAG_FRONT) && stride == 16) return ((s & 4u) << 1) + (half >> 1) + (s & 3u);
     return half + s;
