@@ -549,6 +549,7 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
 
     monkeypatch.delenv("TBK_MOD_SAMPLING", raising=False)
     monkeypatch.delenv("TBK_TABLE_LOAD", raising=False)
+    monkeypatch.delenv("TBK_FRONT", raising=False)
     dev, k, n = 0, 21, 400_000
 
     def dalloc(nbytes):
