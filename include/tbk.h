@@ -178,6 +178,10 @@ int tbk_stream_wait(tbk_classifier *c, uint64_t ticket);
  *     exc_chunk[n_exc], exc_mask[n_exc]   the chunks holding a byte outside ACGT, or positions at or
  *                                         past the end of the stream: chunk index and 16-bit mask
  * = 0.25 bytes per base for clean reads.  Counts are identical to the ASCII path's by construction.
+ * The library ORs the exceptions into its dense mask array (an index listed twice is harmless) and marks
+ * the positions at or past the end of the stream in the last, partial chunk itself, so a caller's own
+ * packer, or a batch re-sliced after packing, need not list that tail.  Code bits of masked positions are
+ * ignored.
  * tbk_stream_submit itself packs a host batch this way before the copy (all host threads, straight
  * from the caller's memory into pinned staging) unless TBK_PACKED_H2D=0 / tbk_classifier_set_transfer
  * (c, 0); tbk_pack_bases + tbk_stream_submit_packed let a caller pack ahead of time (a reader thread). */

@@ -338,6 +338,52 @@ def test_writer_empty_bins_are_valid_files(built, tmp_path):
     assert all(os.path.getsize(n) == 0 for n in w.names)
 
 
+def test_plain_bin_streams_into_a_fifo(built, tmp_path):
+    """A plain bin whose target cannot seek (a FIFO, /dev/stdout through a pipe) is written with
+    sequential write(), as the reference's open(name, 'w') handle would; regular files keep pwrite."""
+    import threading
+
+    from trio_binning_amd import seq
+
+    src = tmp_path / "in.fq"
+    recs = [seq.Read(f"r{i}", "ACGT" * (5 + i % 7), "I" * (4 * (5 + i % 7))) for i in range(200)]
+    with open(src, "w") as fh:
+        for r in recs:
+            r.print(file=fh)
+    os.mkfifo(tmp_path / "pa.fq")
+    got = {}
+
+    def drain():
+        with open(tmp_path / "pa.fq", "rb") as fh:
+            got["a"] = fh.read()
+
+    t = threading.Thread(target=drain)
+    t.start()
+    w = seq.BinWriter(str(tmp_path / "pa"), str(tmp_path / "pb"), str(tmp_path / "pu"), ".fq", False, threads=3)
+    bins = ("AB" * len(recs))[:len(recs)]
+    n = 0
+    with seq.BatchReader(str(src)) as r:
+        b = seq.Batch()
+        while r.next_batch(b, 50, 0):
+            w.write(b, bins[n:n + b.n_reads].encode())
+            n += b.n_reads
+    w.close()
+    t.join(30)
+    assert not t.is_alive()
+    import io
+
+    want = io.StringIO()
+    for r, c in zip(recs, bins):
+        if c == "A":
+            r.print(file=want)
+    assert got["a"].decode() == want.getvalue()
+    want_b = io.StringIO()
+    for r, c in zip(recs, bins):
+        if c == "B":
+            r.print(file=want_b)
+    assert open(tmp_path / "pb.fq").read() == want_b.getvalue()
+
+
 def test_float_format_is_python_str(built):
     import ctypes as C
 

@@ -1312,6 +1312,8 @@ struct TextBuf {
 struct BinFile {
     int fd = -1;
     uint64_t file_off = 0;  // bytes written so far (this descriptor's own offset: plain output is written with pwrite)
+    bool positional = false;  // a regular file no other bin names: slices may go out with pwrite from several threads;
+                              // anything else (FIFO, /dev/stdout, two prefixes naming one file) gets sequential write()
     TextBuf text;           // records not yet written
 };
 
@@ -1424,6 +1426,13 @@ static int flush_bins(tbk_bin_writer *w, bool final) {
         const size_t slice_bytes = (size_t)8 << 20;
         for (Piece &pc : pieces) {
             BinFile &f = w->bin[pc.bin];
+            if (!f.positional) {
+                // not seekable, or a file another bin writes too: the bytes go out in order through the
+                // descriptor's own offset, as the reference's open(name, "w") handles do (seq.py:128-134)
+                if (!write_all(f.fd, pc.src, pc.n, w->err)) return ffail(TBK_ERR_IO, "%s", w->err.c_str());
+                f.file_off += pc.n;
+                continue;
+            }
             for (size_t o = 0; o < pc.n; o += slice_bytes) slices.push_back(Slice{f.fd, pc.src + o, std::min(slice_bytes, pc.n - o), f.file_off + o});
             f.file_off += pc.n;
         }
@@ -1476,6 +1485,16 @@ extern "C" int tbk_bin_writer_open(const char *path_a, const char *path_b, const
             return ffail(TBK_ERR_IO, "cannot create %s: %s", paths[b], strerror(e));
         }
     }
+    // pwrite needs a seekable target of this bin's own: probe each descriptor once
+    struct stat st[3];
+    bool have[3];
+    for (int b = 0; b < 3; b++) {
+        have[b] = ::fstat(w->bin[b].fd, &st[b]) == 0;
+        w->bin[b].positional = have[b] && S_ISREG(st[b].st_mode) && ::lseek(w->bin[b].fd, 0, SEEK_CUR) >= 0;
+    }
+    for (int b = 0; b < 3; b++)
+        for (int c = 0; c < 3; c++)
+            if (c != b && have[b] && have[c] && st[b].st_dev == st[c].st_dev && st[b].st_ino == st[c].st_ino) w->bin[b].positional = false;
     *out = w;
     return TBK_OK;
 }

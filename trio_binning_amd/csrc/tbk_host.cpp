@@ -34,7 +34,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, int, hipStream_t);
-extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
 int tbk_pack_bases_vec(const uint8_t *bases, uint64_t total, uint32_t *codes, std::vector<uint32_t> &exc_chunk, std::vector<uint16_t> &exc_mask, int threads);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
@@ -1072,8 +1072,9 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
             if (n_exc) {
                 HIP_TRY(hipMemcpyAsync(s.d_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
                 HIP_TRY(hipMemcpyAsync(s.d_exc_mask, exc_mask, n_exc * sizeof(uint16_t), hipMemcpyHostToDevice, c->copy));
-                HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, c->copy));
             }
+            // exceptions into the dense masks; the tail of the last partial chunk is masked here too
+            HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, c->copy));
         } else {
             const uint8_t *src_b = bases;
             if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }

@@ -221,7 +221,7 @@ TbkInflate::Status TbkInflate::run16(uint16_t *out, size_t *pos, size_t cap, uin
 }
 
 // T = uint8_t: the text.  T = uint16_t: one symbol per element - a byte value, or whatever the caller put
-// in front of the write position and a match copied from there (tbk_pinflate.cpp: markers for a
+// in front of the write position and a match copied from there (LineSource::pinflate_loop in tbk_fastx.cpp: markers for a
 // window that is not known yet).
 template <class T>
 TbkInflate::Status TbkInflate::run_impl(T *out, size_t *pos, size_t cap, size_t member_start, uint64_t stop_bit) {

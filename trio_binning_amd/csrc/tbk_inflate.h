@@ -1,6 +1,6 @@
 // tbk_inflate.h — a DEFLATE (RFC 1951) decoder for gzip members (RFC 1952), written for the one
 // thing the FASTX reader needs: inflate a memory-mapped .gz file into a text window as fast as one
-// core can.  A single gzip stream is one chain of dependencies (tbk_pinflate.cpp breaks it by
+// core can.  A single gzip stream is one chain of dependencies (LineSource::pinflate_loop in tbk_fastx.cpp breaks it by
 // guessing), and for FASTQ(.gz) input that stream is what both CLIs wait for; zlib 1.2.11 delivers ~0.55 GB/s of text here.  This decoder
 // works the way the fast ones do: a 64-bit bit buffer refilled eight bytes at a time, one table
 // lookup per symbol (11-bit primary table for literals/lengths, 8-bit for distances, sub-tables
@@ -29,7 +29,7 @@ public:
     Status run(uint8_t *out, size_t *pos, size_t cap, size_t member_start);
     // The same machine with 16-bit output elements: a literal is its byte value; a match copies
     // elements, whatever they are - out[*pos - 32768 .. *pos) holds the window, as byte values where it
-    // is known and as markers of the caller's choosing where it is not (tbk_pinflate.cpp).  Returns
+    // is known and as markers of the caller's choosing where it is not (LineSource::pinflate_loop, tbk_fastx.cpp).  Returns
     // BOUNDARY in front of the first block header at or past bit `stop_bit` of the input.
     Status run16(uint16_t *out, size_t *pos, size_t cap, uint64_t stop_bit);
     // bits of the input consumed so far (exact between blocks and between symbols)

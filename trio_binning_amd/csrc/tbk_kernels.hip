@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "tbk_common.h"
@@ -1021,17 +1022,28 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
 }
 
 // Scatter the packed format's exceptions into the dense per-chunk mask array (zeroed by the caller).
+// Masks are OR-ed in 32-bit words (two chunks per word), so an index listed twice is harmless, and the
+// positions at or past `total` in the last, partial chunk are marked here whether or not the caller's
+// packer listed them: the probe kernel relies on that mask (load_packed_chunk).
 __global__ void __launch_bounds__(256)
 tbk_scatter_bad_kernel(const uint32_t *__restrict__ exc_chunk, const uint16_t *__restrict__ exc_mask, uint64_t n,
-                       uint16_t *__restrict__ bad16) {
+                       uint16_t *__restrict__ bad16, uint64_t total) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) bad16[exc_chunk[i]] = exc_mask[i];
+    uint32_t *words = reinterpret_cast<uint32_t *>(bad16);  // hipMalloc'ed: 4-byte aligned, capacity even
+    if (i < n) {
+        const uint32_t c = exc_chunk[i];
+        atomicOr(&words[c >> 1], (uint32_t)exc_mask[i] << (16 * (c & 1u)));
+    }
+    if (i == 0 && (total & 15u) != 0) {
+        const uint64_t c = total >> 4;
+        atomicOr(&words[c >> 1], ((0xFFFFu << (total & 15u)) & 0xFFFFu) << (16 * (c & 1u)));
+    }
 }
 
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *d_exc_chunk, const uint16_t *d_exc_mask, uint64_t n, uint16_t *d_bad16,
-                                             hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_scatter_bad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_exc_chunk, d_exc_mask, n, d_bad16);
+                                             uint64_t total, hipStream_t stream) {
+    if (n == 0 && (total & 15u) == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbk_scatter_bad_kernel, dim3((unsigned)((std::max<uint64_t>(n, 1) + 255) / 256)), dim3(256), 0, stream, d_exc_chunk, d_exc_mask, n, d_bad16, total);
     return hipGetLastError();
 }
 
