@@ -424,7 +424,8 @@ def main():
         dbg_read(buf, 1)
         w_ = n_r0 * max(1, L - k + 1)
         print("tbk-counters", json.dumps({"careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
-                                         "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4)}), file=sys.stderr)
+                                         "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4),
+                                         "back_half_looks_per_window": round(buf[5] / w_, 5)}), file=sys.stderr)
     hit_a_frac = float(counts[:, 0].sum()) / max(1, n_r0 * max(0, L - k + 1))
     reads_per_launch = sum(b[2] for b in batches) / len(batches) if strong else n_r0
     windows = reads_per_launch * max(0, L - k + 1)

@@ -61,6 +61,7 @@ const char *tbk_last_error(void);
 int tbk_device_count(int *count);
 /* Short description of device `device` ("gfx950 AMD Instinct MI355X, 256 CUs, 288 GB"). */
 int tbk_device_name(int device, char *buf, size_t buflen);
+int tbk_device_identity(int device, char *buf, size_t buflen);  /* "<pci bus id> <uuid>" */
 
 /* ---- unit-level API kept for parity with the reference's ctypes surface ------------ */
 /* Replaces kmer_to_int (c/kmers.c:50-72; bound kmers.py:75-82): base i -> bits 2i..2i+1,
@@ -211,11 +212,59 @@ int tbk_classifier_sync(tbk_classifier *c);
 int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, const void *d_offsets,
                              uint64_t n_reads, uint64_t total_bases, int32_t *counts, uint64_t *ticket);
 
-/* HIP-event timing of the probe kernel on the stream it is launched on.  While enabled,
- * every probe-kernel launch of this classifier is bracketed by an event pair; read
- * returns the number of launches and their summed duration since enable, and resets. */
+/* ---- one handle over several devices ("one host feeder thread + pinned ring + 2-3 streams per
+ * device", tables replicated, reads dealt in batches, no collective) ---------------------------------------
+ * tbk_pipeline_create hashes the two lists once (tbk_classifier_create_multi), gives every entry of
+ * `devices` a replica with its own stream ring and starts one feeder thread per entry.  submit only queues a
+ * batch (ASCII, or already in the packed transfer format); the next feeder whose ring has room takes it and
+ * does what is left to do on the host - packing an ASCII batch with its share of the host threads, staging,
+ * launching copies and kernels - off the caller's thread.  wait(ticket) returns when that batch's counts
+ * are in `counts`, whichever device computed them; *device_slot (optional) = index into `devices` of the ring
+ * that did.  Tickets may be waited for in any order; the caller's arrays must stay valid until then.  At most
+ * tbk_pipeline_depth() + n_devices batches may be submitted and not yet waited for.  A device may be listed
+ * several times (several rings on one GPU).  The handle itself may be used from one thread at a time.
+ * Replaces the per-read loop of classify_by_kmers.py:99-102 for any number of GPUs of one node. */
+typedef struct tbk_pipeline tbk_pipeline;
+int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_pipeline **out);
+void tbk_pipeline_destroy(tbk_pipeline *p);
+int tbk_pipeline_depth(const tbk_pipeline *p);     /* sum of the rings' depths */
+int tbk_pipeline_devices(const tbk_pipeline *p);
+tbk_classifier *tbk_pipeline_classifier(tbk_pipeline *p, int slot);  /* for stats / timing; never submit to it directly */
+int tbk_pipeline_submit(tbk_pipeline *p, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket);
+int tbk_pipeline_submit_packed(tbk_pipeline *p, const uint32_t *codes, const uint32_t *exc_chunk, const uint16_t *exc_mask, uint64_t n_exc,
+                               const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket);
+int tbk_pipeline_wait(tbk_pipeline *p, uint64_t ticket, int *device_slot);
+int tbk_pipeline_batches(const tbk_pipeline *p, uint64_t *per_slot, int n);  /* batches each ring has taken so far */
+/* Testing hook, no GPU needed: the same queue and feeder threads over n_rings rings whose submit / wait are the
+ * caller's callbacks (same contract as tbk_stream_submit / tbk_stream_wait; `slot` says which ring asks). */
+typedef int (*tbk_pipeline_test_submit_fn)(void *user, int slot, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                           int32_t *counts, uint64_t *ticket);
+typedef int (*tbk_pipeline_test_wait_fn)(void *user, int slot, uint64_t ticket);
+int tbk_pipeline_create_test_(int n_rings, int ring_depth, tbk_pipeline_test_submit_fn submit, tbk_pipeline_test_wait_fn wait, void *user,
+                              tbk_pipeline **out);
+
+/* The whole read / classify / write loop of classify-by-kmers as native threads (classify_by_kmers.py:80-117):
+ * a reader thread (tbk_fastx_next with packing on), the calling thread feeding the pipeline and taking the
+ * batches back in input order, a writer thread (tbk_score_and_bin, tbk_bin_writer_write, tbk_format_tsv ->
+ * tsv_fd; tsv_fd < 0: no TSV).  out_a/out_b/out_u are the bins' file names as the reference derives them
+ * (seq.py:127-134).  batch_bases / batch_reads bound a batch (0: 64 Mbases / unbounded). */
+typedef struct tbk_run_stats {
+    uint64_t reads, bases, batches;
+    double read_s, gpu_wait_s, write_s, total_s;  /* busy seconds of the reader / waiting for tickets / of the writer; wall */
+} tbk_run_stats;
+int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64_t num_kmers_a, uint64_t num_kmers_b, const char *out_a,
+                      const char *out_b, const char *out_u, int gzip_output, int gzip_level, int tsv_fd, uint64_t batch_bases,
+                      uint64_t batch_reads, tbk_run_stats *stats);
+
+/* HIP-event timing of the probe on the stream it is launched on.  A probe is three kernels: the pass
+ * index, the kernel of the passes that touch several reads, and the kernel of the passes inside one read
+ * (on long reads nearly all the work: the dominant kernel).  While enabled, every probe of this classifier
+ * is bracketed by events - before the first kernel, between the last two, after the last; read returns
+ * the number of probes and their summed duration since enable (total_ms: all three kernels; single_ms:
+ * the single-read kernel alone), and resets. */
 int tbk_kernel_timing_enable(tbk_classifier *c, int on);
 int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms);
+int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, double *total_ms, double *single_ms);
 
 /* Replaces calculate_scaling_factors (classify_by_kmers.py:57-77) and the binning rule
  * (classify_by_kmers.py:104-115): float64, same operation order (1.0*max/n, count*factor,
@@ -240,6 +289,14 @@ void tbk_fastx_batch_destroy(tbk_fastx_batch *b);
  * (0 = no limit).  An empty batch means end of input.  The sequence bytes of a batch lie back
  * to back in pinned host memory: pass them straight to tbk_stream_submit. */
 int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads);
+/* on != 0: every batch of this reader also carries its bases in the packed transfer format (see
+ * tbk_stream_submit_packed), made while the records are copied - the chunk-parallel scan packs each record's
+ * 16-base chunks right after copying it - so that the classify stage moves a quarter of the bytes and
+ * nobody reads the batch a second time.  tbk_fastx_batch_packed hands the arrays out (*codes = NULL when the
+ * batch carries none); they stay valid until the batch is refilled or destroyed. */
+int tbk_fastx_set_packing(tbk_fastx_reader *r, int on);
+int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, const uint32_t **exc_chunk, const uint16_t **exc_mask,
+                           uint64_t *n_exc);
 /* Borrow the batch's arrays: offsets have n_reads+1 entries; has_qual[i] = 1 when the record
  * was read as FASTQ (readfq's qual is not None). */
 int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint8_t **bases,

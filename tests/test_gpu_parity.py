@@ -540,8 +540,8 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
     """Without TBK_MOD_SAMPLING / TBK_TABLE_LOAD the lists decide how buckets are selected and how roomy
     the table is: keys that fall evenly into buckets keep mod-sampling at load 0.08 (one build), lists
     that cluster the way real find-unique-kmers output does (runs of overlapping k-mers around
-    variants) are rebuilt with the random minimizer at load 0.04.  Either way, and with the rule or the
-    load pinned, the counts are the oracle's."""
+    variants) are rebuilt with the random minimizer at load 0.04, both in the front layout.  Either way,
+    and with the rule or the load pinned, the counts are the oracle's."""
     import ctypes as C
 
     from trio_binning_amd import kmers
@@ -588,9 +588,9 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
             assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
-            # lists that spread, with few keys behind the first four slots of a bucket, are probed front-first
-            # (64 of a line's 128 bytes); clustered ones in whole lines
-            assert st["front_layout"] == want_t and (not want_t or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
+            # both are probed front-first (64 of a line's 128 bytes; the back half only where a list has keys there);
+            # lists that spread leave few keys behind the first four slots of a bucket
+            assert st["front_layout"] and (not want_t or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
             load = half / (st["n_buckets"] * 8)
             assert abs(load - (0.08 if want_builds == 1 else 0.04)) < 0.005, (name, load)
             assert np.array_equal(cls.classify_batch(bases, offs), want), name

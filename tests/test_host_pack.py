@@ -116,3 +116,66 @@ def test_pack_bases_capacity_protocol(built):
     assert lib.tbk_pack_bases(bases.ctypes.data, bases.size, codes.ctypes.data, ec.ctypes.data, em.ctypes.data, 3, C.byref(n)) == 0
     assert ec.tolist() == [0, 1, 2] and em.tolist() == [1 << 4, 0b11110, 0xFF80]
     assert lib.tbk_pack_bases(None, 5, codes.ctypes.data, None, None, 0, C.byref(n)) == _lib.TBK_ERR_INVALID
+
+
+def _fastq_text(rng, n, lo, hi, bad_every=0):
+    out = []
+    nrng = np.random.default_rng(rng.randrange(1 << 30))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n):
+        ln = rng.randrange(lo, hi)
+        s = acgt[nrng.integers(0, 4, ln)].tobytes().decode()
+        if bad_every and i % bad_every == 0 and ln > 3:
+            p = rng.randrange(ln)
+            s = s[:p] + rng.choice("Nnacgt-") + s[p + 1:]
+        out.append(f"@r{i} c\n{s}\n+\n{'I' * ln}\n")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gz", "fasta", "inflated_scan"])
+def test_reader_emits_the_packed_form_of_its_batches(built, tmp_path, monkeypatch, kind):
+    """BatchReader(packing=True): every batch carries its bases in the packed transfer format, identical to
+    what tbk_pack_bases makes of the same bases - whether the chunk-parallel scan packed the records as it
+    copied them (plain FASTQ; several threads, several windows per batch) or the batch was packed in one go
+    (records that came through the sequential machine)."""
+    import gzip
+    import random
+
+    from trio_binning_amd import kmers, seq
+
+    rng = random.Random(11)
+    monkeypatch.setenv("TBK_HOST_THREADS", "5")
+    if kind == "fasta":
+        text = "".join(f">s{i}\n{''.join(rng.choice('ACGTN') for _ in range(rng.randrange(0, 300)))}\n" for i in range(500))
+        path = tmp_path / "r.fa"
+        path.write_text(text)
+    else:
+        # big enough for the scan to cut it into several pieces (4 MiB apiece), with tiny and empty reads and bad bytes
+        text = _fastq_text(rng, 3000, 0, 40, bad_every=7) + _fastq_text(rng, 2600, 9000, 21000, bad_every=50) + _fastq_text(rng, 500, 1, 18)
+        if kind == "plain":
+            path = tmp_path / "r.fq"
+            path.write_text(text)
+        else:
+            path = tmp_path / "r.fq.gz"
+            with gzip.open(path, "wt") as fh:
+                fh.write(text)
+            if kind == "inflated_scan":
+                monkeypatch.setenv("TBK_INFLATED_SCAN", "1")
+    n_batches = 0
+    for limit in (0, 7_000_000, 1_000_003):
+        with seq.BatchReader(str(path), packing=True) as r:
+            b = seq.Batch()
+            while r.next_batch(b, limit, 0):
+                n_batches += 1
+                bases, off = b.arrays()[0], b.arrays()[1]
+                got = b.packed_arrays()
+                assert got is not None
+                want = kmers.pack_bases(bases, off, pinned=False)
+                assert np.array_equal(got[0], want.codes)
+                assert sorted(zip(got[1].tolist(), got[2].tolist())) == sorted(zip(want.exc_chunk.tolist(), want.exc_mask.tolist()))
+            b.close()
+    assert n_batches >= 3
+    with seq.BatchReader(str(path)) as r:  # packing off: no packed form
+        b = seq.Batch()
+        assert r.next_batch(b, 0, 0) and b.packed_pointers() is None
+        b.close()

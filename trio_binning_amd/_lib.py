@@ -108,6 +108,22 @@ _sig("tbk_classifier_sync", C.c_int, _vp)
 _sig("tbk_stream_submit_device", C.c_int, _vp, _vp, _vp, _u64, _u64, _vp, _u64p)
 _sig("tbk_kernel_timing_enable", C.c_int, _vp, C.c_int)
 _sig("tbk_kernel_timing_read", C.c_int, _vp, _u64p, _dp)
+if hasattr(lib, "tbk_kernel_timing_read2"):  # (variant builds of tools/build_variant.sh may predate it)
+    _sig("tbk_kernel_timing_read2", C.c_int, _vp, _u64p, _dp, _dp)
+if hasattr(lib, "tbk_pipeline_create"):
+    _sig("tbk_device_identity", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
+    _sig("tbk_pipeline_create", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(_vp))
+    _sig("tbk_pipeline_destroy", None, _vp)
+    _sig("tbk_pipeline_depth", C.c_int, _vp)
+    _sig("tbk_pipeline_devices", C.c_int, _vp)
+    _sig("tbk_pipeline_classifier", _vp, _vp, C.c_int)
+    _sig("tbk_pipeline_submit", C.c_int, _vp, _vp, _vp, _u64, _vp, _u64p)
+    _sig("tbk_pipeline_submit_packed", C.c_int, _vp, _vp, _vp, _vp, _u64, _vp, _u64, _vp, _u64p)
+    _sig("tbk_pipeline_wait", C.c_int, _vp, _u64, C.POINTER(C.c_int))
+    _sig("tbk_pipeline_batches", C.c_int, _vp, _u64p, C.c_int)
+    _sig("tbk_classify_file", C.c_int, _vp, C.c_char_p, _u64, _u64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _u64, _u64, _vp)
+    _sig("tbk_fastx_set_packing", C.c_int, _vp, C.c_int)
+    _sig("tbk_fastx_batch_packed", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u64p)
 _sig("tbk_score_and_bin", C.c_int, _vp, _u64, _u64, _u64, _vp, _vp, _vp)
 _sig("tbk_device_alloc", C.c_int, C.c_int, C.c_size_t, C.POINTER(_vp))
 _sig("tbk_device_free", C.c_int, C.c_int, _vp)
@@ -203,6 +219,13 @@ def warm_up() -> None:
     import atexit
 
     atexit.register(thread.join)
+
+
+def device_identity(device: int = 0) -> str:
+    """``<pci bus id> <uuid>`` of a device: what tells the GPUs of a multi-rank run apart."""
+    buf = C.create_string_buffer(128)
+    check(lib.tbk_device_identity(device, buf, 128))
+    return buf.value.decode()
 
 
 def device_name(device: int = 0) -> str:

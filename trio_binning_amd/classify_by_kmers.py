@@ -18,7 +18,7 @@ import argparse
 import os
 import sys
 from os import path
-from typing import List, Tuple
+from typing import Tuple
 
 from . import _lib
 
@@ -75,13 +75,10 @@ def output_extension(reads_path: str) -> str:
 
 
 def make_classifier(haplotype_a_kmers, haplotype_b_kmers):
-    """The batch classifier for this run: one per device of TBK_DEVICES (default: every visible
-    device), tables replicated, batches dealt to them and results taken back in input order; a plain
-    ``Classifier`` when that is a single device."""
-    devices = kmers.visible_devices()
-    if len(devices) > 1:
-        return kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, devices)
-    return kmers.Classifier(haplotype_a_kmers, haplotype_b_kmers)
+    """The classify pipeline of this run: one feeder thread and stream ring per device of TBK_DEVICES
+    (default: every visible device; a device may repeat), tables replicated, batches dealt to them and
+    taken back in input order - the library's ``tbk_pipeline``, also when that is a single device."""
+    return kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, kmers.visible_devices())
 
 
 def main():
@@ -92,129 +89,44 @@ def main():
     num_b = kmers.get_number_kmers_in_set(args.haplotype_b_kmers)
     import time
 
-    stats = {"reads": 0, "bases": 0, "batches": 0, "read_s": 0.0, "gpu_wait_s": 0.0, "write_s": 0.0}
     t_start = time.perf_counter()
     classifier = make_classifier(args.haplotype_a_kmers, args.haplotype_b_kmers)
-    stats["table_build_s"] = time.perf_counter() - t_start
-    stats["devices"] = list(getattr(classifier, "devices", [classifier.device]))
+    t_built = time.perf_counter()
 
-    # native reader / writer (same records as seq.readfq, same bytes as Read.print)
-    reader = seq.BatchReader(args.reads)
-    writer = seq.BinWriter(
-        args.haplotype_a_out_prefix,
-        args.haplotype_b_out_prefix,
-        args.unclassified_out_prefix,
-        output_extension(args.reads),
-        not args.no_gzip_output,
-        # zlib level of the gzip members: default 6; the reference's gzip.open uses 9, which only
-        # changes the container bytes (and costs 3x the CPU time), never the decompressed bins
-        level=int(os.environ.get("TBK_GZIP_LEVEL", "-1")),
-    )
-    stdout = sys.stdout
-
-    def emit(batch: seq.Batch, counts) -> None:
-        """Score, bin and write one batch in input order (classify_by_kmers.py:104-117)."""
-        t = time.perf_counter()
-        score_a, score_b, bins = kmers.score_and_bin(counts, num_a, num_b)
-        writer.write(batch, bins)
-        stdout.write(seq.format_tsv(batch, bins, score_a, score_b))
-        stats["write_s"] += time.perf_counter() - t
-
-    # Three stages run side by side, one batch apiece (the native calls release the GIL):
-    #   reader thread   parses the next batch into pinned memory,
-    #   this thread     keeps up to `depth` batches in flight on the GPU,
-    #   writer thread   scores, bins and writes finished batches in input order.
-    import queue
-    import threading
-
-    depth = classifier.depth
-    n_batches = depth + 3  # in flight on the GPU(s) + one apiece for reader, queues and writer
-    free_q: "queue.Queue" = queue.Queue()
-    filled_q: "queue.Queue" = queue.Queue(maxsize=2)
-    done_q: "queue.Queue" = queue.Queue(maxsize=2)
-    batches = [seq.Batch() for _ in range(n_batches)]
-    for b in batches:
-        free_q.put(b)
-    failure: List[BaseException] = []
-
-    def read_loop() -> None:
-        try:
-            while not failure:
-                batch = free_q.get()
-                t = time.perf_counter()
-                n = reader.next_batch(batch, _BATCH_BASES, _BATCH_READS)
-                stats["read_s"] += time.perf_counter() - t
-                if n == 0:
-                    free_q.put(batch)
-                    break
-                stats["reads"] += n
-                stats["batches"] += 1
-                stats["bases"] += int(batch.arrays()[1][-1])
-                filled_q.put(batch)
-        except BaseException as exc:  # handed to the main thread
-            failure.append(exc)
-        finally:
-            filled_q.put(None)
-
-    def write_loop() -> None:
-        try:
-            while True:
-                item = done_q.get()
-                if item is None:
-                    break
-                batch, counts = item
-                if not failure:
-                    emit(batch, counts)
-                free_q.put(batch)
-        except BaseException as exc:
-            failure.append(exc)
-            while done_q.get() is not None:  # keep the main thread from blocking on a full queue
-                pass
-
-    rt = threading.Thread(target=read_loop, name="tbk-reader", daemon=True)
-    wt = threading.Thread(target=write_loop, name="tbk-writer", daemon=True)
-    rt.start()
-    wt.start()
-    in_flight: List[Tuple[int, seq.Batch]] = []  # (ticket, batch) in submission order
-
-    def drain(keep: int) -> None:
-        while len(in_flight) > keep:
-            ticket, batch = in_flight.pop(0)
-            t = time.perf_counter()
-            counts = classifier.wait(ticket)
-            stats["gpu_wait_s"] += time.perf_counter() - t
-            done_q.put((batch, counts))
-
+    # The loop of the reference (classify_by_kmers.py:99-117: count, score, bin, print one read at a time)
+    # runs inside the library on native threads - a reader filling batches in pinned memory (their bases
+    # packed for the link on the way), this thread feeding the device(s) and taking the batches back in
+    # input order, a writer scoring, binning, writing the three bins and the TSV.  Python only names the
+    # files; the TSV goes to the process's stdout descriptor.
+    names = seq.output_names(args.haplotype_a_out_prefix, args.haplotype_b_out_prefix, args.unclassified_out_prefix,
+                             output_extension(args.reads), not args.no_gzip_output)
+    # zlib level of the gzip members when zlib is asked for (TBK_GZIP_ENCODER): default 6; the reference's
+    # gzip.open uses 9, which only changes the container bytes, never the decompressed bins
+    level = int(os.environ.get("TBK_GZIP_LEVEL", "-1"))
+    sys.stdout.flush()
+    spool = None
     try:
-        while not failure:
-            batch = filled_q.get()
-            if batch is None:
-                break
-            drain(depth - 1)
-            in_flight.append((classifier.submit_batch(batch), batch))
-        drain(0)
-    finally:
-        done_q.put(None)
-        wt.join()
-        if failure:  # unblock a reader waiting for a free batch, then report
-            for _ in range(n_batches):
-                free_q.put(seq.Batch())
-        rt.join(timeout=5)
-    if failure:
-        raise failure[0]
-    free = batches
+        tsv_fd = sys.stdout.fileno()
+    except (AttributeError, OSError, ValueError):  # stdout is not a file (a test harness's capture): spool, then hand over
+        import tempfile
 
-    # The reference never closes its outputs (interpreter shutdown does); closing here
-    # finalises the files at the same point in the byte stream.
-    writer.close()
-    reader.close()
-    for b in free:
-        b.close()
+        spool = tempfile.TemporaryFile()
+        tsv_fd = spool.fileno()
+    try:
+        stats = classifier.classify_file(args.reads, num_a, num_b, names, not args.no_gzip_output, level, tsv_fd, _BATCH_BASES, _BATCH_READS)
+    finally:
+        if spool is not None:
+            spool.seek(0)
+            sys.stdout.write(spool.read().decode())
+            spool.close()
+    devices = list(getattr(classifier, "devices", [classifier.device]))
     classifier.close()
     if os.environ.get("TBK_STATS"):
         # stderr is free-form in the reference too (progress chatter); stdout stays pure TSV
         import json
 
+        stats["table_build_s"] = t_built - t_start
+        stats["devices"] = devices
         stats["total_s"] = time.perf_counter() - t_start
         stats["gbases_per_s"] = stats["bases"] / stats["total_s"] / 1e9 if stats["total_s"] > 0 else 0.0
         print("tbk-stats " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}), file=sys.stderr)

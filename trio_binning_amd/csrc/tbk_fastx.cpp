@@ -43,6 +43,7 @@
 
 #include "../../include/tbk.h"
 #include "tbk_inflate.h"
+#include "tbk_pack.h"
 
 uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp: zlib's crc32() by carry-less multiplication
 
@@ -704,11 +705,38 @@ struct tbk_fastx_batch {
     uint64_t n_bases = 0;
     // record under construction
     uint64_t rec_seq0 = 0, rec_qual0 = 0;
+    // The packed transfer form of `bases` (tbk_pack.cpp: 16 bases to a word + the exceptions), made by the
+    // reader itself when asked (tbk_fastx_set_packing): the chunk-parallel scan packs a record's chunks right
+    // after it copied the record, from its own cache, so the classify stage copies a quarter of the bytes
+    // and nobody reads the batch a second time.  `fused` = every base of the batch came through that scan.
+    bool want_packed = false, fused = false, packed_ok = false;
+    uint32_t *codes = nullptr;
+    size_t codes_cap = 0;
+    bool codes_pinned = false;
+    std::vector<TbkExc> exc;
+    std::vector<uint32_t> exc_chunk;
+    std::vector<uint16_t> exc_mask;
 
-    ~tbk_fastx_batch() { release(); }
-    void release() {
+    ~tbk_fastx_batch() {
+        release();
+        if (codes) { if (codes_pinned) (void)hipHostFree(codes); else free(codes); }
+    }
+    void release() {  // the bases buffer (reserve_bases replaces it when it grows)
         if (bases) { if (pinned) (void)hipHostFree(bases); else free(bases); }
         bases = nullptr; bases_cap = 0;
+    }
+    bool reserve_codes(size_t need_chunks) {
+        if (need_chunks <= codes_cap) return true;
+        const size_t cap = std::max<size_t>(need_chunks + need_chunks / 2, (size_t)1 << 18);
+        uint32_t *nc = nullptr;
+        bool np = false;
+        if (pinned && hipHostMalloc((void **)&nc, cap * sizeof(uint32_t), hipHostMallocPortable) == hipSuccess) np = true;
+        else { (void)hipGetLastError(); nc = (uint32_t *)malloc(cap * sizeof(uint32_t)); }
+        if (!nc) return false;
+        if (codes && codes_cap) memcpy(nc, codes, codes_cap * sizeof(uint32_t));
+        if (codes) { if (codes_pinned) (void)hipHostFree(codes); else free(codes); }
+        codes = nc; codes_cap = cap; codes_pinned = np;
+        return true;
     }
     // Pinned when a device is there (the batch then goes to the GPU without a staging copy).
     // Pinning is tried once per process: a failing hipHostMalloc (no device) is slow.
@@ -732,6 +760,8 @@ struct tbk_fastx_batch {
     void clear() {
         base_off.assign(1, 0); names.clear(); name_off.assign(1, 0); quals.clear(); qual_off.assign(1, 0);
         has_qual.clear(); n_bases = 0; rec_seq0 = rec_qual0 = 0;
+        fused = want_packed; packed_ok = false;
+        exc.clear(); exc_chunk.clear(); exc_mask.clear();
     }
     void begin(const uint8_t *name, size_t n) {
         names.insert(names.end(), name, name + n);
@@ -741,6 +771,7 @@ struct tbk_fastx_batch {
         if (!reserve_bases(n_bases + n + 16)) return false;
         memcpy(bases + n_bases, p, n);
         n_bases += n;
+        fused = false;  // the sequential machine's bytes are packed in one go when the batch is complete
         return true;
     }
     void qual(const uint8_t *p, size_t n) { quals.insert(quals.end(), p, p + n); }
@@ -838,6 +869,7 @@ struct tbk_fastx_reader {
     bool have_pending = false;
     uint64_t seq_len = 0;       // current record (QUAL state)
     int64_t qual_have = 0;
+    bool packing = false;       // batches also carry the packed transfer form of their bases
 };
 
 static void name_of(const uint8_t *body, size_t n, const uint8_t *&np, size_t &nn) {
@@ -991,6 +1023,8 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
     const size_t n0 = (size_t)b->n_reads(), on0 = b->names.size(), oq0 = b->quals.size();
     const uint64_t ob0 = b->n_bases;
     if (!b->reserve_bases((size_t)(ob0 + n_bases) + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
+    const bool pack = b->want_packed && b->fused;
+    if (pack && !b->reserve_codes((size_t)((ob0 + n_bases + 15) / 16) + 1)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     b->base_off.resize(n0 + (size_t)n_reads + 1);
     b->name_off.resize(n0 + (size_t)n_reads + 1);
     b->qual_off.resize(n0 + (size_t)n_reads + 1);
@@ -1008,17 +1042,22 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
     b->n_bases = ob;
     {
         const int ct = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, tbk_host_threads()), (size_t)n_bases / ((size_t)8 << 20)));
+        // records [cut(t), cut(t + 1)) are thread t's: split where the bases split evenly (reads differ in length; empty ones have none)
+        auto cut = [&](int u) -> size_t {
+            if (u <= 0) return 0;
+            if (u >= ct) return chosen.size();
+            const uint64_t at_b = ob0 + n_bases * (uint64_t)u / (uint64_t)ct;
+            const auto first = b->base_off.begin() + (ptrdiff_t)n0;
+            return (size_t)(std::lower_bound(first, first + (ptrdiff_t)chosen.size(), at_b) - first);
+        };
+        std::vector<std::vector<TbkExc>> found(pack ? (size_t)ct : 0);
         auto copy = [&](int t) {
-            // records [first, last) of thread t: split where the bases split evenly (reads differ in length; empty ones have none)
-            auto cut = [&](int u) -> size_t {
-                if (u <= 0) return 0;
-                if (u >= ct) return chosen.size();
-                const uint64_t at_b = ob0 + n_bases * (uint64_t)u / (uint64_t)ct;
-                const auto first = b->base_off.begin() + (ptrdiff_t)n0;
-                return (size_t)(std::lower_bound(first, first + (ptrdiff_t)chosen.size(), at_b) - first);
-            };
-            const size_t last = cut(t + 1);
-            for (size_t i = cut(t); i < last; i++) {
+            const size_t first = cut(t), last = cut(t + 1);
+            // packing: the 16-base chunks that lie wholly inside this thread's stretch of the stream are its own, and
+            // each is packed as soon as the record that completes it has been copied (from this core's cache)
+            const uint64_t hi_b = b->base_off[n0 + last];
+            uint64_t next_chunk = (b->base_off[n0 + first] + 15) / 16;
+            for (size_t i = first; i < last; i++) {
                 const FastqRec &rc = *chosen[i];
                 const size_t len = (size_t)(rc.plus - 1 - rc.seq);
                 if (len) {
@@ -1026,12 +1065,29 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
                     memcpy(b->quals.data() + b->qual_off[n0 + i], d + rc.qual, len);
                 }
                 if (rc.name_len) memcpy(b->names.data() + b->name_off[n0 + i], d + rc.head + 1, rc.name_len);
+                if (pack) {
+                    const uint64_t done = std::min(b->base_off[n0 + i + 1], hi_b) / 16;
+                    if (done > next_chunk) { tbk_pack_chunk_range_(b->bases, next_chunk, done, b->codes, found[(size_t)t]); next_chunk = done; }
+                }
             }
         };
         std::vector<std::thread> pool;
         for (int t = 1; t < ct; t++) pool.emplace_back(copy, t);
         copy(0);
         for (std::thread &th : pool) th.join();
+        if (pack) {
+            for (const auto &f : found) b->exc.insert(b->exc.end(), f.begin(), f.end());
+            // a chunk that holds the boundary between two threads' stretches (or the start of this window, which
+            // the previous window left as its partial last chunk) belongs to neither: packed here, once whole
+            uint64_t last_done = ~0ull;
+            for (int u = 0; u < ct; u++) {
+                const uint64_t pb = b->base_off[n0 + cut(u)];
+                const uint64_t c = pb / 16;
+                if (pb % 16 == 0 || c == last_done || 16 * c + 16 > ob) continue;
+                tbk_pack_chunk_range_(b->bases, c, c + 1, b->codes, b->exc);
+                last_done = c;
+            }
+        }
     }
     if (timing && n_ok < nt)
         fprintf(stderr, "tbk-scan chain broke at piece %d: prev end %zu bad %d, synced %d begin %zu (lo %zu hi %zu)\n", n_ok, pieces[(size_t)n_ok - 1].end,
@@ -1103,8 +1159,53 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
     }
 }
 
+static int fastx_next_records(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads);
+
+extern "C" int tbk_fastx_set_packing(tbk_fastx_reader *r, int on) {
+    if (!r) return ffail(TBK_ERR_INVALID, "NULL argument");
+    r->packing = on != 0;
+    return TBK_OK;
+}
+
+// the batch's packed form: what the scan has packed already plus the last, partial chunk - or, for bytes
+// that came through the sequential machine, the whole stream in one go on all host threads
+static int finish_packing(tbk_fastx_batch *b) {
+    if (!b->want_packed || b->n_reads() == 0) return TBK_OK;
+    if (!b->reserve_codes((size_t)((b->n_bases + 15) / 16) + 1)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
+    if (b->fused) {
+        tbk_pack_tail_chunk_(b->bases, b->n_bases, b->codes, b->exc);
+        b->exc_chunk.resize(b->exc.size());
+        b->exc_mask.resize(b->exc.size());
+        for (size_t i = 0; i < b->exc.size(); i++) { b->exc_chunk[i] = b->exc[i].chunk; b->exc_mask[i] = b->exc[i].mask; }
+    } else {
+        const int rc = tbk_pack_bases_vec(b->bases, b->n_bases, b->codes, b->exc_chunk, b->exc_mask, 0);
+        if (rc) return rc;
+    }
+    b->packed_ok = true;
+    return TBK_OK;
+}
+
 extern "C" int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
     if (!r || !b) return ffail(TBK_ERR_INVALID, "NULL argument");
+    b->want_packed = r->packing;
+    const int rc = fastx_next_records(r, b, max_bases, max_reads);
+    if (rc) return rc;
+    return finish_packing(b);
+}
+
+extern "C" int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, const uint32_t **exc_chunk, const uint16_t **exc_mask,
+                                      uint64_t *n_exc) {
+    if (!b || !codes || !exc_chunk || !exc_mask || !n_exc) return ffail(TBK_ERR_INVALID, "NULL argument");
+    static const uint32_t none32 = 0;
+    static const uint16_t none16 = 0;
+    *codes = b->packed_ok ? b->codes : nullptr;
+    *exc_chunk = b->packed_ok && !b->exc_chunk.empty() ? b->exc_chunk.data() : &none32;
+    *exc_mask = b->packed_ok && !b->exc_mask.empty() ? b->exc_mask.data() : &none16;
+    *n_exc = b->packed_ok ? b->exc_chunk.size() : 0;
+    return TBK_OK;
+}
+
+static int fastx_next_records(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, uint64_t max_reads) {
     b->clear();
     if (r->state == tbk_fastx_reader::DONE) return TBK_OK;
     if (max_reads == 0) max_reads = ~0ull;

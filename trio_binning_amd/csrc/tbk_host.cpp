@@ -26,6 +26,7 @@
 
 #include "../../include/tbk.h"
 #include "tbk_common.h"
+#include "tbk_pack.h"
 
 // ---- kernels' launchers (tbk_kernels.hip, tbk_synth.hip) -------------------------------
 extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, const uint32_t *, uint32_t, uint32_t, hipStream_t);
@@ -33,10 +34,9 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
-                                       int32_t *, uint32_t *, int, hipStream_t);
+                                       int32_t *, uint32_t *, uint64_t, int, hipEvent_t, hipStream_t);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
-int tbk_pack_bases_vec(const uint8_t *bases, uint64_t total, uint32_t *codes, std::vector<uint32_t> &exc_chunk, std::vector<uint16_t> &exc_mask, int threads);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
@@ -175,18 +175,22 @@ struct tbk_classifier {
     // how tbk_stream_submit moves a host batch's bases: 1 = packed on the host first (0.25 B/base over
     // PCIe), 0 = as ASCII (1 B/base).  TBK_PACKED_H2D, tbk_classifier_set_transfer.
     int packed_h2d = 1;
+    int pack_threads = 0;             // host threads a submit-time pack may use (0: all; a pipeline's feeders share them)
     std::vector<uint32_t> exc_chunk;  // scratch of the packer
     std::vector<uint16_t> exc_mask;
     // scratch for the pass -> read index (launches on `compute` are stream-ordered, so one
     // buffer serves them all)
     uint32_t *d_pass_read = nullptr;
     uint64_t cap_passes = 0;
-    // kernel timing
+    // kernel timing: per probe launch three events - before the pass-index kernel, between the multi-read and
+    // the single-read probe kernel, after the latter
     bool timing = false;
-    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<hipEvent_t> ev;  // triples
     size_t ev_used = 0;
     uint64_t timed_launches = 0;
-    double timed_ms = 0.0;
+    double timed_ms = 0.0;         // whole probe: index + both kernels
+    double timed_single_ms = 0.0;  // the single-read probe kernel alone
+    int fold_timing();
 };
 
 // ---- library ---------------------------------------------------------------------------
@@ -199,6 +203,24 @@ extern "C" int tbk_device_count(int *count) {
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess) { *count = 0; return fail(TBK_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
+    return TBK_OK;
+}
+
+// "<pci bus id> <uuid>": what tells two devices apart in a multi-rank run's record
+extern "C" int tbk_device_identity(int device, char *buf, size_t buflen) {
+    if (!buf || buflen < 2) return fail(TBK_ERR_INVALID, "buf is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    char bus[64] = "?";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); strcpy(bus, "?"); }
+    hipUUID uuid;
+    char hex[40] = "?";
+    if (hipDeviceGetUuid(&uuid, device) == hipSuccess) {
+        for (int i = 0; i < 16; i++) snprintf(hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)uuid.bytes[i]);
+    } else {
+        (void)hipGetLastError();
+    }
+    snprintf(buf, buflen, "%s %s", bus, hex);
     return TBK_OK;
 }
 
@@ -234,15 +256,15 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 
 // ---- tables ----------------------------------------------------------------------------
 static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes) {
-    // Target load (keys per slot).  A probe should be decided by one line: a lookup goes on to another
-    // bucket only when keys left its home line.  Plain hashing: 2 keys per 8-slot half (load 0.25).
-    // Minimizer bucketing clusters keys that share a minimizer, and real lists cluster further (the k
-    // overlapping k-mers around one variant share ~6 minimizers, in both lists at once), so it gets
-    // 0.64 keys per half (load 0.08; 2 x 3e8 keys = 60 GB).  Measured at that scale, uniform /
-    // haplotype-shaped lists (profiles/r02_final/ab_load_lean.log): load 0.04 155-159 / 141 Gbases/s,
-    // 0.08 154 / 133-134, 0.10 148 / 124-128 - guests in the other half of the line carry most of what
-    // twice the memory used to buy.  The table may take up to 60 % of the free HBM; bigger lists get
-    // a proportionally higher load.  TBK_TABLE_LOAD overrides (0.04: the last 2-5 %, for 120 GB).
+    // Target load (keys per slot).  A probe should be decided by the 64 bytes it asks for first: a lookup looks
+    // at the back half of its line only where its list has keys there, and leaves the line only when keys did.
+    // Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing puts keys that share a sampled
+    // m-mer into one bucket, and real lists cluster further (the k overlapping k-mers around one variant
+    // share ~6 minimizers, in both lists at once).  Measured at 2 x 3e8 keys, front layout, 5 waves per SIMD
+    // (profiles/r03/): uniform lists 166-174 Gbases/s at load 0.08 (60 GB) = 0.06 = 0.04 within the box-to-box
+    // spread, 148 at 0.12, 136 at 0.16; haplotype-shaped lists 140 at 0.04 (120 GB), 133 at 0.06, 125 at 0.08.
+    // So lists that spread get 0.08 and lists that cluster 0.04 (tbk_classifier_create).  The table is capped
+    // at 60 % of the device's memory; bigger lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
     double load = env_double("TBK_TABLE_LOAD", 0);
     const bool forced = load > 0;
     if (!forced) load = default_load;
@@ -250,9 +272,11 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
     if (load > 0.9) load = 0.9;
     double want = (double)n_keys / (TBK_SLOTS_PER_BUCKET * load);
     if (!forced) {
+        // the cap is a share of the device's TOTAL memory, not of what happens to be free: the same lists
+        // give the same table whatever else lives on the device (and a table that does not fit fails loudly)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const double fit = 0.6 * (double)free_b / (double)line_bytes;
+            const double fit = 0.6 * (double)total_b / (double)line_bytes;
             const double floor_ = (double)n_keys / (TBK_SLOTS_PER_BUCKET * 0.5);  // never denser than load 0.5 on our own account
             if (want > fit) want = fit > floor_ ? fit : floor_;
         } else {
@@ -614,35 +638,31 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
-    // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers,
-    // default 6; 0 = plain hashing of the whole key).  Which m-mer is sampled, and how roomy the table
-    // is, is decided by the lists.  Mod-sampling reads 18 % fewer lines than the random minimizer on
-    // lists whose keys fall evenly into buckets (BASELINE's uniform lists: 154-159 against 143-148
-    // Gbases/s), and such lists do not care about the load (0.64 keys per 8-slot half = load 0.08 =
-    // 60 GB for 2 x 3e8 keys measures the same as half that load).  Lists that cluster the way real
-    // find-unique-kmers output does (the k overlapping k-mers around one variant share ~6 minimizers,
-    // in both lists at once) overflow more halves under mod-sampling's longer runs per bucket (122-129
-    // against 129-140), and they do care: 140 Gbases/s at load 0.04 against 129-134 at 0.08.  Nothing
-    // of that is observable in the results and building the table takes a fraction of a second, so:
-    // build with mod-sampling at load 0.08; if more than TBK_CLUSTERED (default 0.3 %) of the keys
-    // found their own half of their home line full (uniform lists: 1e-5; haplotype-shaped: 2-10 %),
-    // build again with the random minimizer at load 0.04.  TBK_MOD_SAMPLING=1 / 0 pins the rule
-    // (the load still follows the lists), TBK_TABLE_LOAD pins the load.
+    // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers, default 6;
+    // 0 = plain hashing of the whole key).  Which m-mer is sampled, and how roomy the table is, is decided by
+    // the lists.  Mod-sampling switches lines 18 % less often than the random minimizer and is the faster rule
+    // on lists whose keys fall evenly into buckets (BASELINE's uniform lists); lists that cluster the way real
+    // find-unique-kmers output does (the k overlapping k-mers around one variant share ~6 minimizers, in both
+    // lists at once) overflow more fronts under mod-sampling's longer runs per bucket (haplotype-shaped lists,
+    // front layout, load 0.04: 127 against 140 Gbases/s) and care about room (0.04: 140, 0.08: 125).  Nothing
+    // of that is observable in the results and building the table takes a fraction of a second, so: build with
+    // mod-sampling at load 0.08; if more than TBK_CLUSTERED (default 0.3 %) of the keys found their own half of
+    // their home line full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), build again with the random
+    // minimizer at load 0.04.  TBK_MOD_SAMPLING=1 / 0 pins the rule (the load still follows the lists),
+    // TBK_TABLE_LOAD pins the load.
     const double pin = env_double("TBK_MOD_SAMPLING", -1);
     const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
     const bool load_pinned = env_double("TBK_TABLE_LOAD", 0) > 0;
     const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
-    // Front layout (tbk_common.h): the probe kernel fetches 64 bytes of a line, the first four slots of
-    // each list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list
-    // first), and settles what lies behind them in the deferred walk.  Every step in which one of the
-    // wave's 64 windows meets a front with keys behind it goes through the careful part, so the layout
-    // pays while such fronts are rare.  Measured on 2 x 3e8 uniform keys against 155-157 Gbases/s for
-    // whole lines: 160-162 at load 0.08 (0.29 % of the keys behind a front), 178 at load 0.04 (0.06 %).
-    // Lists that cluster put a third of their keys behind the fronts (103-106 Gbases/s) and are rebuilt
-    // in whole lines together with the sampling rule, as before; lists that spread but still leave more
-    // than TBK_BEHIND_FRONT (default 0.6 %) of their keys behind a front get the same table in whole
-    // lines.  TBK_FRONT=1 / 0 pins the layout (mod-sampling only).
+    // Front layout (tbk_common.h): the probe kernel asks for 64 bytes of a line, the first four slots of each
+    // list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list first); a
+    // window that misses in a front whose list has keys behind it is queued, and the queue is settled 16
+    // windows at a time from the back half of the line, which the L2 holds already (tbk_kernels.hip:
+    // drain_back).  One request per line instead of two, and - 96 VGPRs - five waves per SIMD.  Both
+    // sampling rules use it since round 3.  Lists that spread but still leave more than TBK_BEHIND_FRONT
+    // (default 0.6 %) of their keys behind a front (tables denser than the default) get the same table in
+    // whole lines, as does TBK_FRONT=0.
     const double front_pin = env_double("TBK_FRONT", -1);
     int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -655,7 +675,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (c->d_pair) { (void)hipFree(c->d_pair); c->d_pair = nullptr; }
         built_t = c->mz.t;
         c->layout_builds++;
-        const bool front = c->mz.t > 0 && (front_pin >= 0 ? front_pin != 0 : attempt == 0);
+        const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : true);
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
@@ -863,37 +883,45 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         if (c->d_pass_read) HIP_TRY(hipFree(c->d_pass_read));
         c->d_pass_read = nullptr; c->cap_passes = 0;
         const uint64_t cap = passes + passes / 4 + 1024;
-        HIP_TRY(hipMalloc((void **)&c->d_pass_read, cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void **)&c->d_pass_read, (2 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, its length
         c->cap_passes = cap;
     }
     // (the per-read counters are cleared by the pass-index kernel inside tbk_launch_probe)
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, em = nullptr, e1 = nullptr;
     if (c->timing) {
-        if (c->ev_used + 2 > c->ev.size()) {
-            if (c->ev.size() >= 2 * TIMING_POOL) {  // fold what we have, then reuse the pool
+        if (c->ev_used + 3 > c->ev.size()) {
+            if (c->ev.size() >= 3 * TIMING_POOL) {  // fold what we have, then reuse the pool
                 HIP_TRY(hipStreamSynchronize(c->compute));
-                for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-                    float ms = 0;
-                    HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-                    c->timed_ms += ms;
-                }
-                c->ev_used = 0;
+                int rc = c->fold_timing();
+                if (rc) return rc;
             } else {
-                hipEvent_t a, b;
-                HIP_TRY(hipEventCreate(&a));
-                HIP_TRY(hipEventCreate(&b));
-                c->ev.push_back(a);
-                c->ev.push_back(b);
+                for (int i = 0; i < 3; i++) {
+                    hipEvent_t a;
+                    HIP_TRY(hipEventCreate(&a));
+                    c->ev.push_back(a);
+                }
             }
         }
-        e0 = c->ev[c->ev_used]; e1 = c->ev[c->ev_used + 1];
-        c->ev_used += 2;
+        e0 = c->ev[c->ev_used]; em = c->ev[c->ev_used + 1]; e1 = c->ev[c->ev_used + 2];
+        c->ev_used += 3;
         c->timed_launches++;
         HIP_TRY(hipEventRecord(e0, c->compute));
     }
-    HIP_TRY(tbk_launch_probe(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->max_blocks,
-                             c->compute));
+    HIP_TRY(tbk_launch_probe(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes, c->max_blocks,
+                             em, c->compute));
     if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
+    return TBK_OK;
+}
+
+int tbk_classifier::fold_timing() {
+    for (size_t i = 0; i + 3 <= ev_used; i += 3) {
+        float ms = 0, ms_single = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 2]));
+        HIP_TRY(hipEventElapsedTime(&ms_single, ev[i + 1], ev[i + 2]));
+        timed_ms += ms;
+        timed_single_ms += ms_single;
+    }
+    ev_used = 0;
     return TBK_OK;
 }
 
@@ -1022,7 +1050,7 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         // packer reads it once, where a copy into pinned memory would read and write it).
         rc = slot_reserve_packed_host(s, n_chunks, 0);
         if (rc) return rc;
-        rc = tbk_pack_bases_vec(bases, total, s.h_codes, c->exc_chunk, c->exc_mask, 0);
+        rc = tbk_pack_bases_vec(bases, total, s.h_codes, c->exc_chunk, c->exc_mask, c->pack_threads);
         if (rc) return fail(rc, "%s", g_err.c_str());
         n_exc = c->exc_chunk.size();
         rc = slot_reserve_packed_host(s, n_chunks, n_exc);
@@ -1119,6 +1147,13 @@ extern "C" int tbk_classifier_set_transfer(tbk_classifier *c, int packed) {
 
 extern "C" int tbk_classifier_transfer(const tbk_classifier *c) { return c ? c->packed_h2d : -1; }
 
+// (library-internal) the share of the host threads this classifier's submit-time packing may use
+extern "C" int tbk_classifier_set_pack_threads_(tbk_classifier *c, int threads) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    c->pack_threads = threads > 0 ? threads : 0;
+    return TBK_OK;
+}
+
 extern "C" int tbk_stream_wait(tbk_classifier *c, uint64_t ticket) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
     Slot &s = c->ring[ticket % RING];
@@ -1213,24 +1248,26 @@ extern "C" int tbk_kernel_timing_enable(tbk_classifier *c, int on) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
     c->timing = on != 0;
-    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0;
+    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0; c->timed_single_ms = 0.0;
     return TBK_OK;
 }
 
-extern "C" int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms) {
+extern "C" int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, double *total_ms, double *single_ms) {
     if (!c || !launches || !total_ms) return fail(TBK_ERR_INVALID, "NULL argument");
     int rc = use_device(c->device);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
-    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-        c->timed_ms += ms;
-    }
+    rc = c->fold_timing();
+    if (rc) return rc;
     *launches = c->timed_launches;
     *total_ms = c->timed_ms;
-    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0;
+    if (single_ms) *single_ms = c->timed_single_ms;
+    c->timed_launches = 0; c->timed_ms = 0.0; c->timed_single_ms = 0.0;
     return TBK_OK;
+}
+
+extern "C" int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms) {
+    return tbk_kernel_timing_read2(c, launches, total_ms, nullptr);
 }
 
 // ---- single read (compat with kmers.count_kmers_in_read) ----------------------------------

@@ -240,7 +240,27 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #define TBK_SAMP_UNROLL 4 // j-loop unroll of the mod-sampling variants
 #endif
 #ifndef TBK_MIN_WAVES
-#define TBK_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
+#define TBK_MIN_WAVES 5         // waves per SIMD the register allocator must leave room for: single-read passes, front layout ...
+#endif
+#ifndef TBK_MIN_WAVES_WHOLE
+#define TBK_MIN_WAVES_WHOLE 4   // ... single-read passes in whole lines (two requests per line: a fifth wave loses 5 %, measured) ...
+#endif
+#ifndef TBK_MIN_WAVES_MULTI
+#define TBK_MIN_WAVES_MULTI 4   // ... and multi-read passes (tbk_probe_kernel)
+#endif
+// Timing diagnostics (tools/build_variant.sh; WRONG COUNTS, never shipped): where does a step's time go?
+//   TBK_DIAG_NOLOAD   no window ever fetches a line: the arithmetic alone
+//   TBK_DIAG_CHEAP    the bucket is a cheap hash of (position / 4): the line traffic of a scheme of density 0.25
+//                     without the minimizer arithmetic
+//   TBK_OCC_PAD=n     n more bytes of LDS per block: fewer waves per CU (13000: 3 per SIMD, 20000: 2)
+#ifndef TBK_DIAG_NOLOAD
+#define TBK_DIAG_NOLOAD 0
+#endif
+#ifndef TBK_DIAG_CHEAP
+#define TBK_DIAG_CHEAP 0
+#endif
+#ifndef TBK_OCC_PAD
+#define TBK_OCC_PAD 0
 #endif
 constexpr int TBK_WAVES_PER_BLOCK = 1;      // waves of a block share nothing; one-wave blocks schedule best (measured: 1 > 2 > 4 > 8)
 
@@ -268,6 +288,8 @@ struct ProbeArgs {
     int k;
     int32_t *counts;          // [n_reads][2], zeroed by the caller
     const uint32_t *pass_read;  // [n_passes] read that contains each pass's first position
+    const uint32_t *multi_list; // passes that touch more than one read (the multi-read kernel's work list)
+    const uint32_t *n_multi;    // their number
 };
 
 // largest r in [0, n_reads] with offsets[r] <= pos (pos <= total, offsets[n_reads] = total)
@@ -342,7 +364,9 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 // lookup, so that the latency of a walk step is paid once per 64 walks.  The halves are
 // disjoint, so a queued lookup counts for hapA if the hapA walk finds the key, else for hapB if
 // the hapB walk does.
-constexpr int TBK_QCAP = 256;  // queue entries per wave; a window-loop step adds at most 128
+constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
+constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
+constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
 
 // entry: x = key low, y = key high, z = home bucket, w = list (0 hapA, 1 hapB) | (read - first read of pass) << 1
 
@@ -430,13 +454,72 @@ __device__ __forceinline__ void drain_walks(const ProbeArgs &p, const uint4 *q, 
     }
 }
 
+// Front layout: a window that missed in a front with keys behind it (the order of a list's slots 2 and 3)
+// is settled from the BACK half of its home line - the list's slots 4..7 and, tagged, the other list's
+// guests there - which the L2 already holds (it fetched the whole 128-byte line).  The window loop only
+// queues such windows (owner lane: key, home bucket, which lists have keys behind their front);
+// drain_back takes 16 entries at a time, one quad per entry, each lane loading 16 bytes of the back half
+// [A4 A5 | A6 A7 | B4 B5 | B6 B7] - the same coalesced 64-byte request shape as the window loop's - so the
+// latency of the second look is paid once per 16 windows instead of once per step.  Only a window whose
+// key may have LEFT THE LINE (the list's slots 6 > 7: keys went past the half, and 4 > 5: out of the
+// line) goes on to the exact walk, which starts over at the home line.
+template <bool MULTI>
+__device__ __forceinline__ void drain_back(const ProbeArgs &p, const uint4 *bq, uint32_t qb, uint4 *walkq, uint32_t &qn,
+                                           uint64_t r_first, uint32_t lane, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+    const uint32_t sub = lane & 3u, quad = lane >> 2;
+    const bool guests = (p.t.guests & TBK_FLAG_GUESTS) != 0;
+    for (uint32_t base = 0; base < qb; base += 16) {
+        const bool act = base + quad < qb;
+        uint4 it = make_uint4((uint32_t)TBK_NOKEY, (uint32_t)(TBK_NOKEY >> 32), 0, 0);
+        ulonglong2 v = make_ulonglong2(TBK_EMPTY, TBK_EMPTY);
+        if (act) {
+            it = bq[base + quad];
+            v = load_slots(p.t.slots + (uint64_t)it.z * 16 + 8 + sub * 2);
+        }
+        const uint64_t key = (uint64_t)it.x | ((uint64_t)it.y << 32);
+        const uint64_t plain = ballot(v.x == key) | ballot(v.y == key);
+        uint64_t tagged = 0;
+        if (guests) { const uint64_t kt = key | TBK_GUEST; tagged = ballot(v.x == kt) | ballot(v.y == kt); }
+        // quad lanes 0,1 hold hapA's slots 4..7, lanes 2,3 hapB's; a tagged match belongs to the other list
+        const uint64_t hit_a = (plain & 0x3333333333333333ull) | (tagged & 0xCCCCCCCCCCCCCCCCull);
+        const uint64_t hit_b = (plain & 0xCCCCCCCCCCCCCCCCull) | (tagged & 0x3333333333333333ull);
+        // order of a lane's two slots: lane 0 - hapA keys left the line, lane 1 - keys went past hapA's half; lanes 2, 3: hapB
+        const uint64_t ord = ballot(v.x > v.y);
+        const uint64_t want_a = ballot((it.w & 2u) != 0) & 0x1111111111111111ull, want_b = ballot((it.w & 1u) != 0) & 0x1111111111111111ull;
+        const uint64_t miss = ~quad_any(hit_a | hit_b);
+        uint64_t walk_a = want_a & miss & (ord >> 1), walk_b = want_b & miss & (ord >> 3);
+        if (guests) { walk_a &= ord; walk_b &= ord >> 2; }  // without guests a key past its half is out of the line
+        if (!MULTI) {
+            acc_a += (uint32_t)__popcll(hit_a);
+            acc_b += (uint32_t)__popcll(hit_b);
+        } else {
+            if ((hit_a >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w >> 2, 0, 1);
+            if ((hit_b >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w >> 2, 1, 1);
+        }
+        const uint64_t queued = walk_a | walk_b;
+        if (queued) {
+            const uint64_t me = 1ull << lane;
+            const uint32_t n_a = (uint32_t)__popcll(walk_a);
+            if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(it.x, it.y, it.z, (it.w >> 2) << 1);
+            if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(it.x, it.y, it.z, ((it.w >> 2) << 1) | 1u);
+            qn += n_a + (uint32_t)__popcll(walk_b);
+            if (qn > TBK_QCAP_FRONT - 32) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                drain_walks<MULTI, true>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qn = 0;
+            }
+        }
+    }
+}
+
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
 // window).  MULTI = the pass touches more than one read.
 template <int W, bool M64, bool SAMP, bool MULTI, bool FRONT>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                           uint4 *walkq, uint32_t *rcnt, uint32_t *sink) {
+                                           uint4 *walkq, uint4 *backq, uint32_t *rcnt, uint32_t *sink) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
@@ -573,6 +656,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     for (int s = 0; s < 4; s++) { va[s] = make_ulonglong2(0, 0); vb[s] = make_ulonglong2(0, 0); }
     uint32_t last_bk = 0x7FFFFFFFu;  // bucket of this lane's previous valid window (none yet)
     uint32_t qn = 0;                 // queued walks (wave-uniform)
+    uint32_t qb = 0;                 // front layout: windows waiting for the back half of their line (wave-uniform)
 #ifdef TBK_COUNTERS
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -581,7 +665,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     // state on by one window, so it is called once per window, in order
     auto bucket_here = [&](const int jj) -> uint32_t {
         uint32_t hsel;
-        if (W > 0 && SAMP) {
+        if (TBK_DIAG_CHEAP) {
+            hsel = tbk_mmer_hash((uint32_t)((p_lane + (uint64_t)jj) >> 2));
+        } else if (W > 0 && SAMP) {
             // mod-sampling: shift in the span's newest t-mer, find the smallest rank (any of the
             // tied ones will do: the table holds the key under each, see tbk_common.h), turn its
             // stream index into a position inside this window's span, sample the m-mer at
@@ -678,7 +764,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             // fetch only when this window's line differs from the one the slot already holds
             // (minimizer mode: consecutive windows mostly share it)
             TBK_COUNT(4, __popcll(ballot((int32_t)bk[s] < 0)));
-            if ((int32_t)bk[s] < 0) {
+            if ((int32_t)bk[s] < 0 && !TBK_DIAG_NOLOAD) {
                 const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
                 if (FRONT) {
                     va[s] = load_slots(line);  // the front of the line: [A0 A1 | A2 A3 | B0 B1 | B2 B3], 16 bytes per quad lane
@@ -746,30 +832,30 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             TBK_COUNT(0, 1);
             if (any_more != 0) {
                 TBK_COUNT(1, 1);
+                // Windows that missed in a front with keys behind it: brought to the bit of the lane that owns the
+                // window (quad q's sub-step s window belongs to lane 4q + s), so that every such lane queues its own
+                // window - key, home bucket, which lists have keys behind their front - once per step.
+                uint64_t need = 0, beh_a = 0, beh_b = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     if (more[s] == 0) continue;
                     TBK_COUNT(2, 1);
-                    const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
-                    const uint64_t valid = ballot(kk != TBK_NOKEY) & 0x1111111111111111ull;
-                    const uint64_t miss = valid & ~quad_any(hit[s]);  // a hit in either list's front is final (the lists are disjoint)
-                    const uint64_t walk_a = miss & ((more[s] & 0x2222222222222222ull) >> 1);
-                    const uint64_t walk_b = miss & ((more[s] & 0x8888888888888888ull) >> 3);
-                    const uint64_t queued = walk_a | walk_b;
-                    if (queued) {
-                        const uint64_t me = 1ull << lane;
-                        const uint32_t rid_s = !MULTI ? 0u : s == 0 ? quad_bcast<0>(my_rid) : s == 1 ? quad_bcast<1>(my_rid)
-                                                       : s == 2 ? quad_bcast<2>(my_rid) : quad_bcast<3>(my_rid);
-                        const uint32_t n_a = (uint32_t)__popcll(walk_a);
-                        if (queued & me) {
-                            const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
-                            const uint32_t home = bk[s] & 0x7FFFFFFFu;
-                            if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(klo[s], khi[s], home, rrel << 1);
-                            if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(klo[s], khi[s], home, (rrel << 1) | 1u);
-                        }
-                        qn += n_a + (uint32_t)__popcll(walk_b);
-                        TBK_COUNT(3, __popcll(queued));
+                    const uint64_t ma = (more[s] & 0x2222222222222222ull) >> 1, mb = (more[s] & 0x8888888888888888ull) >> 3;
+                    const uint64_t miss = ~quad_any(hit[s]);  // a hit in either list's front is final (the lists are disjoint)
+                    need |= ((ma | mb) & miss) << s;
+                    beh_a |= ma << s;
+                    beh_b |= mb << s;
+                }
+                need &= ballot(ok);  // an invalid window looks up TBK_NOKEY: never stored, nothing to look for
+                if (need) {
+                    const uint64_t me = 1ull << lane;
+                    if (need & me) {
+                        const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : 0u;
+                        backq[qb + (uint32_t)__popcll(need & (me - 1))] =
+                            make_uint4(my_klo, my_khi, last_bk, (rrel << 2) | ((uint32_t)((beh_a >> lane) & 1ull) << 1) | (uint32_t)((beh_b >> lane) & 1ull));
                     }
+                    qb += (uint32_t)__popcll(need);
+                    TBK_COUNT(5, __popcll(need));
                 }
             }
             if (any_hit != 0) {
@@ -901,12 +987,24 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             }
         }
         }  // !FRONT
-        if (qn > TBK_QCAP - 128) {  // make room for the next step's worst case
+        if (FRONT) {
+            if (qb > TBK_BQCAP - 64) {  // make room for the next step's worst case
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                drain_back<MULTI>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qb = 0;
+            }
+        } else if (qn > TBK_QCAP - 128) {  // make room for the next step's worst case
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain_walks<MULTI, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qn = 0;
         }
+    }
+    if (FRONT && qb) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        drain_back<MULTI>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -936,37 +1034,68 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 }
 
 // Which read contains the first position of each pass (one thread per pass): keeps the
-// binary search over the offsets out of the probe kernel's waves.
+// binary search over the offsets out of the probe kernels' waves.  Passes that touch more than one
+// read are listed for the multi-read kernel (*n_multi is zeroed by the launcher).
 __global__ void __launch_bounds__(256)
-tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t n_passes,
-                      uint32_t *__restrict__ pass_read, int32_t *__restrict__ counts) {
+tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t total, uint64_t n_passes,
+                      uint32_t *__restrict__ pass_read, uint32_t *__restrict__ multi_list, uint32_t *__restrict__ n_multi,
+                      int32_t *__restrict__ counts) {
     const uint64_t pass = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pass < n_passes) pass_read[pass] = (uint32_t)find_read(offsets, n_reads, pass * TBK_PASS);
-    // the same launch clears the per-read counters the probe kernel adds to
+    if (pass < n_passes) {
+        const uint64_t P0 = pass * TBK_PASS;
+        const uint64_t r_first = find_read(offsets, n_reads, P0);
+        pass_read[pass] = (uint32_t)r_first;
+        const uint64_t last_pos = P0 + TBK_PASS - 1 < total ? P0 + TBK_PASS - 1 : total - 1;
+        const uint64_t r_end = r_first < n_reads ? offsets[r_first + 1] : total;
+        if (last_pos >= r_end) multi_list[atomicAdd(n_multi, 1u)] = (uint32_t)pass;
+    }
+    // the same launch clears the per-read counters the probe kernels add to
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
 }
 
-template <int W, bool M64, bool SAMP, bool FRONT>
-// 4 waves per SIMD (<= 128 VGPRs).  Measured same-box A/B (tools/gpu_ab.sh): asking for 5 or 6
-// waves makes the allocator spill and loses 12-50 %; a third pass variant specialised for
-// two-read passes bloats the code and loses 8-14 % even on single-read passes.
-__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, TBK_MIN_WAVES)
+// Two kernels share probe_pass: one for the passes that lie inside a single read and one for those that
+// touch several (MULTI).  They were one kernel until round 3; its register allocation was the
+// maximum over both passes (125 VGPRs: 4 waves per SIMD), while a single-read pass alone needs 95-103.
+// The probe is bound by memory latency - measured with LDS padding that only lowers occupancy, the
+// kernel's time goes 23.8 / 31.6 / 41.4 ms at 4 / 3 / 2 waves per SIMD - so the single-read kernel,
+// which does nearly all the work on long reads, is compiled for 5 waves per SIMD where the line is asked for
+// front-first (96 VGPRs, 0-9 spills; same box, uniform lists: 23.2 against 24.0 ms, haplotype-shaped lists
+// 27.8 against 31.6) and the multi-read kernel keeps 4.  The whole-line variants keep 4 as well: with two
+// requests per line a fifth wave measured 5 % slower (30.2 against 28.5 ms).  The pass-index kernel lists the multi-read passes; the
+// single-read kernel skips them.
+template <int W, bool M64, bool SAMP, bool FRONT, bool MULTI>
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : (FRONT ? TBK_MIN_WAVES : TBK_MIN_WAVES_WHOLE))
 tbk_probe_kernel(const ProbeArgs p) {
     // LDS staging of the read tile, one region per wave: a wave only ever reads what it wrote
     // itself, so wave-scope ordering is enough and the waves of a block never wait for each
     // other (no s_barrier in this kernel).
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
-    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP];
-    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][2 * TBK_RCNT];
+    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_QCAP_FRONT : TBK_QCAP];
+    __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_BQCAP : 1];
+    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : 1];
     __shared__ uint32_t sink[TBK_WAVES_PER_BLOCK][64];  // where the look-ahead loads land (never read)
     const uint32_t lane = threadIdx.x & 63u;
+#if TBK_OCC_PAD
+    __shared__ uint32_t occ_pad[TBK_OCC_PAD / 4];
+    occ_pad[threadIdx.x] = 0;
+    if (p.k == 99) p.counts[0] = (int32_t)occ_pad[(threadIdx.x * 97u) % (TBK_OCC_PAD / 4)];
+#endif
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t passes_per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
-    rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0;  // per-read tallies of multi-read passes (zero between passes)
+    const uint64_t per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
+    if (MULTI) { rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0; }  // per-read tallies (zero between passes)
+    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : p.n_passes;
 
-    for (uint64_t pass = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; pass < p.n_passes; pass += passes_per_iter) {
+    for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
+        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : item;
         const uint64_t P0 = pass * TBK_PASS;
+        // which read(s) does this pass touch?  (wave-uniform)
+        const uint64_t r_first = p.pass_read[pass];
+        const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
+        if (!MULTI) {
+            const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
+            if (last_pos >= r_end) continue;  // the multi-read kernel's
+        }
         if (p.codes != nullptr) {  // packed input (wave-uniform): the chunk words are there already
             const uint64_t c0 = P0 / 16 + lane;
             stage[wave][lane] = load_packed_chunk(p.codes, p.bad16, c0, p.n_chunks);
@@ -981,12 +1110,7 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // which read(s) does this pass touch?  (wave-uniform)
-        const uint64_t r_first = p.pass_read[pass];
-        const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
-        const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (last_pos < r_end) probe_pass<W, M64, SAMP, false, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
-        else probe_pass<W, M64, SAMP, true, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], rcnt[wave], sink[wave]);
+        probe_pass<W, M64, SAMP, MULTI, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave], sink[wave]);
     }
 }
 
@@ -1048,37 +1172,56 @@ extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *d_exc_chunk, const 
 }
 
 // d_codes == nullptr: the read stream is d_bases (ASCII); else it is (d_codes, d_bad16) and d_bases is not read.
+// d_scratch: 2 * pass_cap + 16 words (pass -> read index, the multi-read passes' list, their number).
 extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
-                                       uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_pass_read,
-                                       int max_blocks, hipStream_t stream) {
+                                       uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch,
+                                       uint64_t pass_cap, int max_blocks, hipEvent_t between, hipStream_t stream) {
     if (total == 0 || n_reads == 0) return hipSuccess;
     ProbeArgs p;
     p.codes = d_codes; p.bad16 = d_bad16; p.n_chunks = (total + 15) / 16;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_pass_read;
+    if (p.n_passes > pass_cap) return hipErrorInvalidValue;
+    uint32_t *d_multi = d_scratch + pass_cap, *d_n_multi = d_scratch + 2 * pass_cap;
+    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_multi; p.n_multi = d_n_multi;
+    hipError_t e = hipMemsetAsync(d_n_multi, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((p.n_passes + 255) / 256)), dim3(256), 0, stream,
-                       d_offsets, n_reads, p.n_passes, d_pass_read, d_counts);
+                       d_offsets, n_reads, total, p.n_passes, d_scratch, d_multi, d_n_multi, d_counts);
     uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
-    const dim3 grid((unsigned)blocks), block(64 * TBK_WAVES_PER_BLOCK);
+    // the multi-read kernel walks its list with a grid that fills the chip a few times over
+    const uint64_t blocks_multi = std::min<uint64_t>(blocks, 16384);
+    const dim3 grid((unsigned)blocks), grid_multi((unsigned)blocks_multi), block(64 * TBK_WAVES_PER_BLOCK);
     // kernel variant: W m-mers per span; 32-bit (m <= 16) or 64-bit m-mers; random-minimizer or
-    // mod-sampling selection
+    // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0;
-    if (front && !samp) return hipErrorInvalidValue;  // front tables are built for mod-sampling only (tbk_host.cpp)
-#define TBK_LAUNCH(N, M, S, F) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F>), grid, block, 0, stream, p)
+    if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
+    for (int multi = 1; multi >= 0; multi--) {
+#define TBK_LAUNCH(N, M, S, F) do { if (multi) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, true>), grid_multi, block, 0, stream, p); \
+                                    else hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, false>), grid, block, 0, stream, p); } while (0)
 #define TBK_W(N) case N: if (samp && front) { if (m64) TBK_LAUNCH(N, true, true, true); else TBK_LAUNCH(N, false, true, true); } \
                          else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
+                         else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
-    switch (t.mz.w) {
-        case 0: TBK_LAUNCH(0, false, false, false); break;
-        case 1: if (m64) TBK_LAUNCH(1, true, false, false); else TBK_LAUNCH(1, false, false, false); break;
-        TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
-        default: return hipErrorInvalidValue;
-    }
+        switch (t.mz.w) {
+#ifdef TBK_ONLY_W6  // experiment builds (tools/build_variant.sh): the bench configuration's kernels only
+            TBK_W(6)
+#else
+            case 0: TBK_LAUNCH(0, false, false, false); break;
+            case 1: if (m64) TBK_LAUNCH(1, true, false, false); else TBK_LAUNCH(1, false, false, false); break;
+            TBK_W(2) TBK_W(3) TBK_W(4) TBK_W(5) TBK_W(6) TBK_W(7) TBK_W(8)
+#endif
+            default: return hipErrorInvalidValue;
+        }
 #undef TBK_W
 #undef TBK_LAUNCH
-    return hipGetLastError();
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        // the event between the two kernels: the host times them separately (tbk_kernel_timing_read)
+        if (multi && between != nullptr) { e = hipEventRecord(between, stream); if (e != hipSuccess) return e; }
+    }
+    return hipSuccess;
 }
 
 #ifdef TBK_COUNTERS

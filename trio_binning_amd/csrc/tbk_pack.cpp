@@ -22,8 +22,11 @@
 #include <vector>
 
 #include "../../include/tbk.h"
+#include "tbk_pack.h"
 
 extern "C" void tbk_set_error_(int code, const char *msg);
+
+using Exc = TbkExc;
 
 namespace {
 
@@ -50,8 +53,6 @@ inline void pack16_scalar(const uint8_t *p, uint32_t &code, uint32_t &bad) {
     code = c0 | (c1 << 16);
     bad = b0 | (b1 << 8);
 }
-
-struct Exc { uint32_t chunk; uint16_t mask; };
 
 void pack_range_scalar(const uint8_t *bases, uint64_t c_lo, uint64_t c_hi, uint32_t *codes, std::vector<Exc> &exc) {
     for (uint64_t c = c_lo; c < c_hi; c++) {
@@ -103,6 +104,30 @@ bool have_avx2() {
 }  // namespace
 
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases) { return (total_bases + 15) / 16; }
+
+// The full chunks [c_lo, c_hi) of a base stream, on the calling thread (the FASTX reader packs a record's
+// chunks right after it copied the record, while the bytes are still in its cache).
+void tbk_pack_chunk_range_(const uint8_t *bases, uint64_t c_lo, uint64_t c_hi, uint32_t *codes, std::vector<TbkExc> &exc) {
+    if (c_lo >= c_hi) return;
+    if (have_avx2()) pack_range_avx2(bases, c_lo, c_hi, codes, exc);
+    else pack_range_scalar(bases, c_lo, c_hi, codes, exc);
+}
+
+// The last, partial chunk of a stream of `total` bases (total % 16 != 0): positions at or past the end
+// count as not ACGT.
+void tbk_pack_tail_chunk_(const uint8_t *bases, uint64_t total, uint32_t *codes, std::vector<TbkExc> &exc) {
+    const uint64_t full = total / 16;
+    const unsigned valid = (unsigned)(total - full * 16);
+    if (!valid) return;
+    uint8_t tmp[16] = {0};
+    memcpy(tmp, bases + full * 16, valid);
+    uint32_t code, bad;
+    pack16_scalar(tmp, code, bad);
+    bad |= 0xFFFFu << valid;
+    code &= (1u << (2 * valid)) - 1u;
+    codes[full] = code;
+    exc.push_back(TbkExc{(uint32_t)full, (uint16_t)bad});
+}
 
 // Pack `total` ASCII bases.  codes must hold tbk_packed_chunks(total) words.  The exceptions of the
 // whole stream are appended to exc (ordered by chunk).  `threads` <= 0: tbk_host_threads().

@@ -1,0 +1,214 @@
+// tbk_run.cpp — the read / classify / write loop of classify-by-kmers as native threads.
+//
+// Replaces the body of classify_by_kmers.main (classify_by_kmers.py:80-117): for every read of the input,
+// count_kmers_in_read, the two scores, the bin, the record written to that bin and a TSV line on stdout.
+// The reference does that one read at a time in Python; here three stages run side by side on batches:
+//     reader thread    tbk_fastx_next: the next batch of records into pinned memory, its bases packed
+//                      into the transfer format on the way (tbk_fastx_set_packing);
+//     calling thread   tbk_pipeline_submit_packed / _wait: up to `depth` batches in flight on the
+//                      device(s), taken back in input order;
+//     writer thread    tbk_score_and_bin, tbk_bin_writer_write, tbk_format_tsv -> tsv_fd, in input order.
+// Batches circulate through a fixed set of buffers (depth + 3), so memory is bounded and nothing is
+// allocated per batch.  Output bytes are those of the Python mirror's loop, which are those of the
+// reference (tests/test_gpu_cli.py runs both and the reference's recorded output).
+#include <hip/hip_runtime.h>
+
+#include <unistd.h>
+
+#include <cerrno>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tbk.h"
+
+extern "C" void tbk_set_error_(int code, const char *msg);
+extern "C" int tbk_pipeline_takes_packed_(const tbk_pipeline *p);
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+inline double since(Clock::time_point t) { return std::chrono::duration<double>(Clock::now() - t).count(); }
+
+struct Item {
+    tbk_fastx_batch *batch = nullptr;
+    int32_t *counts = nullptr;  // [cap_reads][2], pinned when a device is there
+    bool counts_pinned = false;
+    size_t cap_reads = 0;
+    uint64_t n_reads = 0, n_bases = 0;
+};
+
+template <class T>
+struct Chan {  // a small blocking queue; close() wakes everybody
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<T> q;
+    bool closed = false;
+    void put(T v) { { std::lock_guard<std::mutex> lk(mu); q.push_back(v); } cv.notify_one(); }
+    bool get(T &v) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return closed || !q.empty(); });
+        if (q.empty()) return false;
+        v = q.front(); q.pop_front();
+        return true;
+    }
+    void close() { { std::lock_guard<std::mutex> lk(mu); closed = true; } cv.notify_all(); }
+};
+
+struct Failure {
+    std::mutex mu;
+    int rc = 0;
+    std::string msg;
+    void set(int code, const char *m) { std::lock_guard<std::mutex> lk(mu); if (!rc) { rc = code; msg = m ? m : ""; } }
+    bool any() { std::lock_guard<std::mutex> lk(mu); return rc != 0; }
+};
+
+bool write_fd(int fd, const char *p, size_t n) {
+    while (n) {
+        const ssize_t w = ::write(fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        p += w; n -= (size_t)w;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64_t num_kmers_a, uint64_t num_kmers_b, const char *out_a,
+                                 const char *out_b, const char *out_u, int gzip_output, int gzip_level, int tsv_fd, uint64_t batch_bases,
+                                 uint64_t batch_reads, tbk_run_stats *stats) {
+    if (!p || !reads_path || !out_a || !out_b || !out_u) { tbk_set_error_(TBK_ERR_INVALID, "NULL argument"); return TBK_ERR_INVALID; }
+    const auto t_start = Clock::now();
+    tbk_run_stats st;
+    memset(&st, 0, sizeof st);
+    if (!batch_bases) batch_bases = (uint64_t)64 << 20;
+    tbk_fastx_reader *reader = nullptr;
+    int rc = tbk_fastx_open(reads_path, &reader);
+    if (rc) return rc;
+    (void)tbk_fastx_set_packing(reader, tbk_pipeline_takes_packed_(p));  // (TBK_PACKED_H2D=0 and test pipelines take ASCII)
+    tbk_bin_writer *writer = nullptr;
+    rc = tbk_bin_writer_open(out_a, out_b, out_u, gzip_output, gzip_level, 0, &writer);
+    if (rc) { tbk_fastx_close(reader); return rc; }
+
+    const int depth = tbk_pipeline_depth(p);
+    const int n_items = depth + 3;  // in flight on the device(s) + one apiece for reader, queues and writer
+    std::vector<Item> items((size_t)n_items);
+    Chan<Item *> free_q, filled_q, done_q;
+    Failure failure;
+    for (Item &it : items) {
+        rc = tbk_fastx_batch_create(&it.batch);
+        if (rc) break;
+        free_q.put(&it);
+    }
+    auto counts_for = [](Item *it, uint64_t n) -> bool {
+        if (n <= it->cap_reads) return true;
+        if (it->counts) { if (it->counts_pinned) tbk_host_free(it->counts); else free(it->counts); }
+        const size_t cap = (size_t)n + (size_t)n / 4 + 1024;
+        it->counts = (int32_t *)tbk_host_alloc(cap * 2 * sizeof(int32_t));
+        it->counts_pinned = it->counts != nullptr;
+        if (!it->counts) it->counts = (int32_t *)malloc(cap * 2 * sizeof(int32_t));  // no device (the testing hook's stub rings)
+        it->cap_reads = it->counts ? cap : 0;
+        return it->counts != nullptr;
+    };
+
+    double read_s = 0, write_s = 0, gpu_wait_s = 0;
+    std::thread reader_thread, writer_thread;
+    if (!rc) {
+        reader_thread = std::thread([&] {
+            Item *it = nullptr;
+            while (!failure.any() && free_q.get(it)) {
+                const auto t = Clock::now();
+                const int r = tbk_fastx_next(reader, it->batch, batch_bases, batch_reads);
+                read_s += since(t);
+                if (r) { failure.set(r, tbk_last_error()); break; }
+                uint64_t n = 0;
+                const uint64_t *off = nullptr;
+                (void)tbk_fastx_batch_view(it->batch, &n, nullptr, &off, nullptr, nullptr, nullptr, nullptr, nullptr);
+                if (n == 0) break;
+                it->n_reads = n;
+                it->n_bases = off[n];
+                filled_q.put(it);
+            }
+            filled_q.close();
+        });
+        writer_thread = std::thread([&] {
+            Item *it = nullptr;
+            std::vector<double> sa, sb;
+            std::vector<char> bins, tsv;
+            while (done_q.get(it)) {
+                if (!failure.any()) {
+                    const auto t = Clock::now();
+                    const uint64_t n = it->n_reads;
+                    sa.resize(n); sb.resize(n); bins.resize(n);
+                    int r = tbk_score_and_bin(it->counts, n, num_kmers_a, num_kmers_b, sa.data(), sb.data(), bins.data());
+                    if (!r) r = tbk_bin_writer_write(writer, it->batch, bins.data());
+                    size_t len = 0;
+                    if (!r && tsv_fd >= 0) {
+                        r = tbk_format_tsv(it->batch, bins.data(), sa.data(), sb.data(), nullptr, 0, &len);
+                        if (!r) { tsv.resize(len); r = tbk_format_tsv(it->batch, bins.data(), sa.data(), sb.data(), tsv.data(), tsv.size(), &len); }
+                        if (!r && !write_fd(tsv_fd, tsv.data(), len)) { r = TBK_ERR_IO; tbk_set_error_(r, (std::string("writing the TSV: ") + strerror(errno)).c_str()); }
+                    }
+                    if (r) failure.set(r, tbk_last_error());
+                    write_s += since(t);
+                }
+                free_q.put(it);
+            }
+        });
+
+        // this thread: keep the device(s) fed, take the batches back in input order
+        std::deque<std::pair<uint64_t, Item *>> flying;
+        auto drain = [&](size_t keep) {
+            while (flying.size() > keep) {
+                auto [tk, it] = flying.front();
+                flying.pop_front();
+                const auto t = Clock::now();
+                const int r = tbk_pipeline_wait(p, tk, nullptr);
+                gpu_wait_s += since(t);
+                if (r) failure.set(r, tbk_last_error());
+                done_q.put(it);
+            }
+        };
+        Item *it = nullptr;
+        while (filled_q.get(it)) {
+            if (failure.any()) { free_q.put(it); continue; }
+            drain((size_t)depth - 1);
+            const uint32_t *codes = nullptr, *exc_chunk = nullptr;
+            const uint16_t *exc_mask = nullptr;
+            const uint8_t *bases = nullptr;
+            const uint64_t *off = nullptr;
+            uint64_t n_exc = 0, tk = 0;
+            int r = counts_for(it, it->n_reads) ? TBK_OK : TBK_ERR_NOMEM;
+            if (!r) r = tbk_fastx_batch_view(it->batch, nullptr, &bases, &off, nullptr, nullptr, nullptr, nullptr, nullptr);
+            if (!r) r = tbk_fastx_batch_packed(it->batch, &codes, &exc_chunk, &exc_mask, &n_exc);
+            if (!r) {
+                if (codes) r = tbk_pipeline_submit_packed(p, codes, exc_chunk, exc_mask, n_exc, off, it->n_reads, it->counts, &tk);
+                else r = tbk_pipeline_submit(p, bases, off, it->n_reads, it->counts, &tk);
+            }
+            if (r) { failure.set(r, tbk_last_error()); free_q.put(it); continue; }
+            st.reads += it->n_reads; st.bases += it->n_bases; st.batches++;
+            flying.emplace_back(tk, it);
+        }
+        drain(0);
+        done_q.close();
+        writer_thread.join();
+        free_q.close();
+        reader_thread.join();
+    }
+    int rc_close = tbk_bin_writer_close(writer);
+    tbk_fastx_close(reader);
+    for (Item &it : items) {
+        if (it.batch) tbk_fastx_batch_destroy(it.batch);
+        if (it.counts) { if (it.counts_pinned) tbk_host_free(it.counts); else free(it.counts); }
+    }
+    st.read_s = read_s; st.write_s = write_s; st.gpu_wait_s = gpu_wait_s; st.total_s = since(t_start);
+    if (stats) *stats = st;
+    if (rc) return rc;
+    if (failure.any()) { tbk_set_error_(failure.rc, failure.msg.c_str()); return failure.rc; }
+    return rc_close;
+}

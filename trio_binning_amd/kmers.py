@@ -384,6 +384,13 @@ class Classifier:
         check(lib.tbk_kernel_timing_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def kernel_timing_read2(self) -> Tuple[int, float, float]:
+        """Probes since enable, their summed milliseconds (pass index + both probe kernels) and those of
+        the single-read kernel alone - on long reads the dominant kernel."""
+        n, ms, single = C.c_uint64(), C.c_double(), C.c_double()
+        check(lib.tbk_kernel_timing_read2(self._h, C.byref(n), C.byref(ms), C.byref(single)))
+        return n.value, ms.value, single.value
+
     def close(self) -> None:
         if self._h is not None and self._h.value:
             lib.tbk_classifier_destroy(self._h)
@@ -412,14 +419,15 @@ def visible_devices() -> list:
 
 
 class MultiClassifier:
-    """Reads sharded over several classifiers, one per device, behind ``Classifier``'s interface
-    (tables replicated, no collective; the reference's loop, classify_by_kmers.py:99-102,
-    has no cross-read state).
+    """Reads dealt over several devices behind ``Classifier``'s interface (tables replicated,
+    no collective; the reference's loop, classify_by_kmers.py:99-102, has no cross-read state).
 
-    ``submit`` deals a batch to the classifier with the fewest batches in flight (the next one in
-    turn when several tie) and returns a ticket of its own numbering; ``wait(ticket)`` returns that
-    batch's counts whatever device computed them, so a caller that waits in submission order gets its
-    results in input order.  ``depth`` batches may be in flight in total.
+    A thin wrapper over the library's ``tbk_pipeline``: one feeder thread and one stream ring per entry of
+    ``devices`` (a device may repeat), one ordered queue.  ``submit`` only queues a batch and returns a
+    ticket; the next feeder whose ring has room takes it.  ``wait(ticket)`` returns that batch's counts
+    whichever device computed them, so a caller that waits in submission order gets its results in input
+    order.  ``depth`` batches may be in flight on the devices; ``depth + len(devices)`` may be submitted
+    and not yet waited for.  Nothing per batch happens in Python.
     """
 
     def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, devices: Optional[Sequence[int]] = None):
@@ -427,73 +435,144 @@ class MultiClassifier:
         if not devices:
             raise _lib.TbkError(_lib.TBK_ERR_NO_DEVICE, "no HIP device visible; there is no CPU fallback")
         arr = (C.c_int * len(devices))(*devices)
-        out = (C.c_void_p * len(devices))()
-        check(lib.tbk_classifier_create_multi(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), out))
-        self._init([Classifier(kmers_hap_a, kmers_hap_b, _handle=h) for h in out])
+        h = C.c_void_p()
+        check(lib.tbk_pipeline_create(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), C.byref(h)))
+        self._h = h
+        self._a, self._b = kmers_hap_a, kmers_hap_b  # keep the tables alive
+        self._keep = {}
+        self._stubs = None
+        self.devices = devices
+        self.device = devices[0]
 
     @classmethod
-    def from_classifiers(cls, classifiers) -> "MultiClassifier":
-        """Deal over already-built classifier-like objects (tests use stubs here)."""
+    def from_classifiers(cls, classifiers, ring_depth: Optional[int] = None) -> "MultiClassifier":
+        """The same queue and feeder threads over classifier-like Python objects (``submit(bases, offsets)
+        -> ticket``, ``wait(ticket) -> counts``): the library's testing hook, no GPU needed."""
         self = cls.__new__(cls)
-        self._init(list(classifiers))
-        return self
-
-    def _init(self, parts) -> None:
-        self._parts = parts
-        self._load = [0] * len(parts)      # batches in flight per part
-        self._turn = 0                     # tie-break: the part after the last one dealt to
-        self._tickets = {}                 # our ticket -> (part index, its ticket)
-        self._next = 1
+        parts = list(classifiers)
+        self._stubs = parts
+        self._keep = {}
+        self._a = self._b = None
         self.devices = [getattr(p, "device", None) for p in parts]
         self.device = self.devices[0]
-        self.dealt = [0] * len(parts)      # batches each part has been given (for reports and tests)
+        pending = {}  # (slot, stub ticket) -> (counts pointer, n_reads)
+
+        def on_submit(user, slot, bases, offsets, n_reads, counts, ticket):
+            try:
+                off = np.ctypeslib.as_array(C.cast(offsets, C.POINTER(C.c_uint64)), (n_reads + 1,))
+                total = int(off[n_reads])
+                b = np.ctypeslib.as_array(C.cast(bases, C.POINTER(C.c_uint8)), (total,)) if total else np.zeros(0, dtype=np.uint8)
+                t = parts[slot].submit(b, off)
+                pending[(slot, t)] = (counts, n_reads)
+                ticket[0] = t
+                return 0
+            except Exception as exc:  # reported through the job's status
+                self._stub_error = exc
+                return _lib.TBK_ERR_STATE
+
+        def on_wait(user, slot, ticket):
+            try:
+                got = np.ascontiguousarray(parts[slot].wait(ticket), dtype=np.int32)
+                ptr, n = pending.pop((slot, ticket))
+                if n:
+                    C.memmove(ptr, got.ctypes.data, n * 8)
+                return 0
+            except Exception as exc:
+                self._stub_error = exc
+                return _lib.TBK_ERR_STATE
+
+        sub_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64))
+        wait_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64)
+        self._callbacks = (sub_t(on_submit), wait_t(on_wait))  # kept alive with the pipeline
+        lib.tbk_pipeline_create_test_.restype = C.c_int
+        lib.tbk_pipeline_create_test_.argtypes = [C.c_int, C.c_int, sub_t, wait_t, C.c_void_p, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        depth = ring_depth if ring_depth is not None else min(getattr(p, "depth", 3) for p in parts)
+        check(lib.tbk_pipeline_create_test_(len(parts), depth, self._callbacks[0], self._callbacks[1], None, C.byref(h)))
+        self._h = h
+        return self
 
     @property
     def depth(self) -> int:
-        return sum(p.depth for p in self._parts)
+        return lib.tbk_pipeline_depth(self._h)
+
+    @property
+    def dealt(self) -> list:
+        """Batches each ring has taken so far."""
+        n = lib.tbk_pipeline_devices(self._h)
+        out = (C.c_uint64 * n)()
+        check(lib.tbk_pipeline_batches(self._h, out, n))
+        return [int(x) for x in out]
+
+    def _part(self, slot: int) -> "Classifier":
+        c = Classifier.__new__(Classifier)
+        c._h = C.c_void_p(lib.tbk_pipeline_classifier(self._h, slot))
+        c._a, c._b, c._keep = self._a, self._b, {}
+        c.device = lib.tbk_classifier_device(c._h)
+        c.close = lambda: None  # the pipeline owns it
+        return c
 
     def stats(self) -> dict:
-        st = dict(self._parts[0].stats())
+        st = dict(self._stubs[0].stats() if self._stubs is not None else self._part(0).stats())
         st["devices"] = list(self.devices)
-        st["table_bytes_total"] = st.get("table_bytes", 0) * len(self._parts)
+        st["table_bytes_total"] = st.get("table_bytes", 0) * len(self.devices)
         return st
 
-    def _pick(self) -> int:
-        n = len(self._parts)
-        best = None
-        for step in range(n):
-            i = (self._turn + step) % n
-            if self._load[i] < self._parts[i].depth and (best is None or self._load[i] < self._load[best]):
-                best = i
-        if best is None:
-            raise _lib.TbkError(_lib.TBK_ERR_STATE, f"all {self.depth} stream slots are in flight; wait for a ticket first")
-        self._turn = (best + 1) % n
-        return best
+    def kernel_timing(self, on: bool) -> None:
+        for i in range(len(self.devices)):
+            self._part(i).kernel_timing(on)
 
-    def _deal(self, method: str, *args) -> int:
-        i = self._pick()
-        inner = getattr(self._parts[i], method)(*args)
-        self._load[i] += 1
-        self.dealt[i] += 1
-        ticket = self._next
-        self._next += 1
-        self._tickets[ticket] = (i, inner)
-        return ticket
+    def kernel_timing_read(self):
+        """Summed over the rings: probes, their milliseconds, the single-read kernel's milliseconds."""
+        tot = [0, 0.0, 0.0]
+        for i in range(len(self.devices)):
+            for j, v in enumerate(self._part(i).kernel_timing_read2()):
+                tot[j] += v
+        return tuple(tot)
 
     def submit(self, bases: np.ndarray, offsets: np.ndarray) -> int:
-        return self._deal("submit", bases, offsets)
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        counts = np.zeros((n, 2), dtype=np.int32)
+        ticket = C.c_uint64()
+        check(lib.tbk_pipeline_submit(self._h, bases.ctypes.data, offsets.ctypes.data, n, counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (bases, offsets, counts)
+        return ticket.value
+
+    def submit_packed(self, packed: PackedBatch, counts: Optional[np.ndarray] = None) -> int:
+        if counts is None:
+            counts = np.zeros((packed.n_reads, 2), dtype=np.int32)
+        ticket = C.c_uint64()
+        check(lib.tbk_pipeline_submit_packed(self._h, packed.codes.ctypes.data, packed.exc_chunk.ctypes.data, packed.exc_mask.ctypes.data,
+                                             packed.exc_chunk.size, packed.offsets.ctypes.data, packed.n_reads, counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (packed, None, counts)
+        return ticket.value
 
     def submit_batch(self, batch) -> int:
-        return self._deal("submit_batch", batch)
+        """Submit a ``seq.Batch``: in the packed transfer format when the reader made it, else its ASCII bases."""
+        counts = np.zeros((batch.n_reads, 2), dtype=np.int32)
+        ticket = C.c_uint64()
+        bases_ptr, off_ptr = batch.pointers()
+        packed = batch.packed_pointers() if self._stubs is None else None
+        if packed is not None:
+            codes, exc_chunk, exc_mask, n_exc = packed
+            check(lib.tbk_pipeline_submit_packed(self._h, C.c_void_p(codes), C.c_void_p(exc_chunk), C.c_void_p(exc_mask), n_exc,
+                                                 C.c_void_p(off_ptr), batch.n_reads, counts.ctypes.data, C.byref(ticket)))
+        else:
+            check(lib.tbk_pipeline_submit(self._h, C.c_void_p(bases_ptr), C.c_void_p(off_ptr), batch.n_reads, counts.ctypes.data, C.byref(ticket)))
+        self._keep[ticket.value] = (batch, None, counts)
+        return ticket.value
 
     def wait(self, ticket: int) -> np.ndarray:
-        if ticket not in self._tickets:
-            raise _lib.TbkError(_lib.TBK_ERR_STATE, f"ticket {ticket} is not in flight")
-        i, inner = self._tickets.pop(ticket)
         try:
-            return self._parts[i].wait(inner)
-        finally:
-            self._load[i] -= 1
+            check(lib.tbk_pipeline_wait(self._h, ticket, None))
+        except _lib.TbkError:
+            exc, self._stub_error = getattr(self, "_stub_error", None), None
+            if exc is not None:
+                raise exc
+            raise
+        return self._keep.pop(ticket)[2]
 
     wait_ticket = wait
 
@@ -503,19 +582,46 @@ class MultiClassifier:
     def classify_reads(self, seqs: Sequence[str]) -> np.ndarray:
         return self.classify_batch(*pack_reads(seqs))
 
+    def classify_file(self, reads_path: str, num_kmers_a: int, num_kmers_b: int, out_names: Sequence[str], gzip_output: bool,
+                      gzip_level: int = -1, tsv_fd: int = 1, batch_bases: int = 0, batch_reads: int = 0) -> dict:
+        """The whole read / classify / write loop of classify-by-kmers on native threads (``tbk_classify_file``);
+        the TSV goes to ``tsv_fd``.  Returns the run's statistics."""
+
+        class Stats(C.Structure):
+            _fields_ = [("reads", C.c_uint64), ("bases", C.c_uint64), ("batches", C.c_uint64), ("read_s", C.c_double),
+                        ("gpu_wait_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double)]
+
+        st = Stats()
+        a, b, u = [os.fsencode(n) for n in out_names]
+        check(lib.tbk_classify_file(self._h, os.fsencode(reads_path), num_kmers_a, num_kmers_b, a, b, u, int(bool(gzip_output)), gzip_level,
+                                    tsv_fd, batch_bases, batch_reads, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in Stats._fields_}
+
     def sync(self) -> None:
-        for p in self._parts:
-            p.sync()
+        pass  # every ticket that was waited for is complete; there is nothing else in flight to wait for
 
     def close(self) -> None:
-        for p in self._parts:
-            p.close()
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            lib.tbk_pipeline_destroy(h)
+        if self._stubs is not None:
+            for p in self._stubs:
+                p.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.close()
+
+
+Pipeline = MultiClassifier
 
 
 class _PinnedOwner:

@@ -193,6 +193,35 @@ class Batch:
         _, p = self._view()
         return p[0], p[1]
 
+    def packed_pointers(self):
+        """(codes_ptr, exc_chunk_ptr, exc_mask_ptr, n_exc) of the batch's packed transfer form, or None when the
+        reader did not make one (``BatchReader(..., packing=True)``)."""
+        import ctypes as C
+
+        from ._lib import check, lib
+
+        codes, ec, em, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        check(lib.tbk_fastx_batch_packed(self._h, C.byref(codes), C.byref(ec), C.byref(em), C.byref(n)))
+        if not codes.value:
+            return None
+        return codes.value, ec.value, em.value, n.value
+
+    def packed_arrays(self):
+        """(codes, exc_chunk, exc_mask) as numpy copies (tests), or None."""
+        import ctypes as C
+
+        import numpy as np
+
+        p = self.packed_pointers()
+        if p is None:
+            return None
+        total = int(self.arrays()[1][-1])
+        n_chunks = (total + 15) // 16
+        codes = np.ctypeslib.as_array(C.cast(p[0], C.POINTER(C.c_uint32)), (max(n_chunks, 1),))[:n_chunks].copy()
+        ec = np.ctypeslib.as_array(C.cast(p[1], C.POINTER(C.c_uint32)), (max(p[3], 1),))[:p[3]].copy()
+        em = np.ctypeslib.as_array(C.cast(p[2], C.POINTER(C.c_uint16)), (max(p[3], 1),))[:p[3]].copy()
+        return codes, ec, em
+
     def reads(self) -> List[Read]:
         """The batch as ``Read`` objects (tests; the CLI never materialises them)."""
         bases, boff, names, noff, quals, qoff, hq = self.arrays()
@@ -222,7 +251,7 @@ class BatchReader:
     """Native FASTA/FASTQ(.gz) reader: ``next_batch(batch, max_bases, max_reads)`` fills a
     ``Batch`` and returns the number of records (0 at end of input)."""
 
-    def __init__(self, filename: str):
+    def __init__(self, filename: str, packing: bool = False):
         import ctypes as C
         import os
 
@@ -231,6 +260,8 @@ class BatchReader:
         h = C.c_void_p()
         check(lib.tbk_fastx_open(os.fsencode(filename), C.byref(h)))
         self._h = h
+        if packing:  # batches also carry the packed transfer form of their bases (Batch.packed_pointers)
+            check(lib.tbk_fastx_set_packing(h, 1))
 
     def next_batch(self, batch: Batch, max_bases: int = 0, max_reads: int = 0) -> int:
         import ctypes as C
