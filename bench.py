@@ -5,19 +5,25 @@
 
 Workload (N=1 default = BASELINE.json configs[2], the configuration the metric is quoted
 on): k = 21, two 300 M-entry synthetic unique-k-mer tables replicated in each GPU's HBM,
-synthetic 15 kb reads with planted list k-mers.  A *step* is one pass of the
-hot path over one batch of reads that is already resident in HBM when the timed region
-starts: zero the counts, run the probe kernel, copy the per-read counts to the host and
-take the A/B/U binning decision there (the host part of step i-1 overlaps the kernel of
-step i; every step's host part is inside the timed region).  `value` = bases classified by
-all ranks / wall time of K steps between two barriers (max over ranks).  A region of K steps
-that lasts less than --min-timed-s is repeated until that much time has been measured, and the
-median region is reported (`timed_regions` says how many).
+synthetic 15 kb reads with planted list k-mers.
+
+A *step* is one pass of the classify stage over one batch of reads: the batch lies in
+pinned host memory in the form the product's reader hands batches over (its bases in the packed
+transfer format, tbk_fastx_set_packing), goes through the library's pipeline - queue, feeder thread,
+H2D on the side stream overlapped with the previous batch's kernel, probe kernels, D2H of the counts
+- and the host takes the A/B/U binning decision (the host part of step i-1 overlaps the device part of
+step i; every step's host part is inside the timed region).  `value` = bases classified by all ranks /
+wall time of K steps between two barriers (max over ranks): the host-fed, PCIe-inclusive rate.
+`kernel_resident` beside it is the same K steps with the batches already in HBM (no H2D): what the
+kernels alone sustain.  (`--timed-path resident` makes that one the `value`, as rounds 1-2 reported it.)
+A region of K steps that lasts less than --min-timed-s is repeated until that much time has been
+measured, and the median region is reported (`timed_regions` says how many).
 
 Scaling.  Default "weak": every rank classifies its own reads (the generator is indexed by
-read number, ranks take disjoint ranges), tables replicated, no collective on the data path.
-`--scaling strong` is BASELINE configs[3]: ONE fixed read set (--strong-reads reads, default
-the 90 Gbp of configs[3]) split over the ranks by read index; a step is one pass of a rank over
+read number, ranks take disjoint ranges), tables replicated, no collective on the data path; every rank
+runs the host-fed stage at the same time (what N GPUs of one node share is the host: DRAM, PCIe root
+complexes, cores).  `--scaling strong` is BASELINE configs[3]: ONE fixed read set (--strong-reads reads,
+default the 90 Gbp of configs[3]) split over the ranks by read index; a step is one pass of a rank over
 its whole shard, `value` = the set's bases / the slowest rank's time.
 
 Ranks are started by the driver's launcher (`python -m torch.distributed.run ... bench.py`, which
@@ -26,15 +32,18 @@ Nothing here imports torch: the barrier and the max/sum of the timing scalars go
 a run-private directory (the ranks of one node share /tmp); `TBK_BENCH_DIST=gloo` selects a
 torch.distributed gloo group instead (tests cover both).
 
-The JSON line also carries
-  roofline      the probe kernel's algorithmic bytes per launch / its HIP-event-timed
-                average duration, against the 8 TB/s HBM peak;
-  streaming     the north-star pipeline on the same tables in the same run: batches in pinned
-                host memory through tbk_stream_submit (H2D on a side stream overlapped with
-                the kernel), PCIe-inclusive Gbases/s, as ASCII and in the packed transfer format;
-  cpu_baseline  the oracle (faithful CPU restatement of c/kmers.c) timed on this box's
-                host cores on a bounded sample of the same reads and tables, with a
-                count-for-count parity check of the GPU result on that sample.
+The JSON line also carries, at every N,
+  roofline      the dominant kernel's (the single-read probe kernel's) algorithmic bytes per launch / its
+                HIP-event-timed average duration inside the timed region, against the 8 TB/s HBM peak,
+                under both readings of SURVEY §8d (P = 2: two probes per window; P = 1: merged table);
+  parity        every rank classifies the same fixed reads (read 0 .. 4095 of the generator) through the
+                host-fed path; the count checksums must agree across ranks, and rank 0 checks the counts
+                read for read against the oracle;
+  cpu_baseline  the oracle (faithful CPU restatement of c/kmers.c) timed on rank 0's host cores on a
+                bounded sample of the same reads and tables;
+  devices       each rank's device (PCI bus id, uuid), so that N distinct GPUs are provable;
+and at N = 1 `pipeline_variants`: the same stage fed with ASCII batches (packed by the feeder thread
+before the copy) and with ASCII over PCIe (the kernel packs).
 
 `--path count` benches the k-mer counting kernel of the find-unique-kmers step instead
 (SURVEY §8f N4): Gbases/s counted, atomic adds per second against the chip's measured ceiling,
@@ -83,7 +92,11 @@ def parse(argv=None):
     ap.add_argument("--plant-minor", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time per cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-streaming", action="store_true", help="skip the host-fed (PCIe-inclusive) leg")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the pipeline variants (ASCII batches in; ASCII over PCIe)")
+    ap.add_argument("--timed-path", choices=["host_fed", "resident"], default="host_fed",
+                    help="what `value` times: the host-fed classify stage (pinned packed batches -> H2D -> kernels -> D2H -> binning), "
+                         "or the same steps with the batches resident in HBM")
+    ap.add_argument("--parity-reads", type=int, default=4096, help="reads of the generator's start every rank classifies for the parity check")
     ap.add_argument("--stream-batch-reads", type=int, default=65_536, help="reads per host batch of the streaming leg")
     ap.add_argument("--stream-seconds", type=float, default=2.0)
     ap.add_argument("--calibrate", action="store_true", help="also run the random-line gather calibration")
@@ -150,41 +163,43 @@ class Dist:
             "/tmp", "tbk_bench_rdv_%s_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
         os.makedirs(self.dir, exist_ok=True)
 
-    def gather(self, value=0.0):
-        """Every rank's value, in rank order (a barrier as a side effect)."""
+    def gather_obj(self, obj=None):
+        """Every rank's (JSON-able) object, in rank order (a barrier as a side effect)."""
         if self.world <= 1:
-            return [float(value)]
+            return [obj]
         if self.dist:
-            import torch
-
-            t = torch.zeros(self.world, dtype=torch.float64)
-            t[self.rank] = float(value)
-            self.dist.all_reduce(t)
-            return [float(x) for x in t]
+            out = [None] * self.world
+            self.dist.all_gather_object(out, obj)
+            return out
         self.seq += 1
         mine = os.path.join(self.dir, "%d.%d" % (self.seq, self.rank))
         with open(mine + ".tmp", "w") as fh:
-            fh.write(repr(float(value)))
+            json.dump(obj, fh)
         os.rename(mine + ".tmp", mine)  # atomic: a reader sees the whole value or no file
-        out, deadline = [None] * self.world, time.monotonic() + self.timeout_s
+        out, have, deadline = [None] * self.world, [False] * self.world, time.monotonic() + self.timeout_s
         while True:
             for r in range(self.world):
-                if out[r] is None:
+                if not have[r]:
                     try:
                         with open(os.path.join(self.dir, "%d.%d" % (self.seq, r))) as fh:
-                            out[r] = float(fh.read())
+                            out[r] = json.load(fh)
+                        have[r] = True
                     except (OSError, ValueError):
                         pass
-            if all(v is not None for v in out):
+            if all(have):
                 break
             if time.monotonic() > deadline:
-                raise TimeoutError("bench rendezvous: ranks %s never reached round %d" % ([r for r, v in enumerate(out) if v is None], self.seq))
+                raise TimeoutError("bench rendezvous: ranks %s never reached round %d" % ([r for r, h in enumerate(have) if not h], self.seq))
             time.sleep(0.0002)
         # a rank may remove its own file of the round before last: everyone has passed that round
         old = os.path.join(self.dir, "%d.%d" % (self.seq - 2, self.rank))
         if self.seq > 2 and os.path.exists(old):
             os.unlink(old)
         return out
+
+    def gather(self, value=0.0):
+        """Every rank's value, in rank order (a barrier as a side effect)."""
+        return [float(v) for v in self.gather_obj(float(value))]
 
     def barrier(self):
         self.gather(0.0)
@@ -309,14 +324,18 @@ def main():
     t0 = time.time()
     hap_a = kmers.HashSet.from_device_keys(d_keys, n_list, k, device=dev)
     hap_b = kmers.HashSet.from_device_keys(d_keys + key_stride * 8, n_list, k, device=dev)
-    cls = kmers.Classifier(hap_a, hap_b)  # hashes both lists into the paired table in HBM
+    # the library's pipeline over this rank's device: it hashes both lists into the paired table in HBM and
+    # starts the device's feeder thread; `cls` is its classifier (the resident leg and the timing read it
+    # directly while the pipeline is idle)
+    pipe = kmers.MultiClassifier(hap_a, hap_b, [dev])
+    cls = pipe._part(0)
     check(lib.tbk_device_sync(dev))
     t_build = time.time() - t0
     stats = cls.stats()
     if not hap:
         assert stats["distinct_a"] == n_list and stats["distinct_b"] == n_list, stats
 
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    want_cpu = rank == 0 and not args.no_cpu_baseline
     h_keys = None
     if want_cpu:
         h_keys = np.empty(2 * n_list, dtype=np.uint64)
@@ -324,11 +343,20 @@ def main():
         check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data + n_list * 8, C.c_void_p(d_keys + key_stride * 8), n_list * 8))
     check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
 
-    # ---- reads resident in HBM ------------------------------------------------------------------
+    def synth_reads(first, n_r, d_bases, d_offs):
+        if hap:
+            check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first, n_r, L, err24,
+                                                 C.c_void_p(d_bases), C.c_void_p(d_offs)))
+        else:
+            check(lib.tbk_synth_reads_device(dev, READ_SEED, first, n_r, L, KEY_SEED, n_list, n_list, k,
+                                             args.plant_major, args.plant_minor, C.c_void_p(d_bases), C.c_void_p(d_offs)))
+
+    # ---- reads ------------------------------------------------------------------------------------
     # weak: `resident_batches` batches per rank, cycled; read indices disjoint between ranks.
-    # strong: the rank's shard [lo, hi) of ONE fixed set of reads, all of it resident, in batches of
-    # at most R reads; the generator is indexed by absolute read number, so the set does not depend
-    # on how many ranks share it.
+    # strong: the rank's shard [lo, hi) of ONE fixed set of reads in batches of at most R reads; the
+    # generator is indexed by absolute read number, so the set does not depend on how many ranks share it.
+    # Every batch exists twice: in pinned host memory in the packed transfer format (what the reader hands
+    # over; the host-fed path's input) and, for the resident leg, as ASCII in HBM.
     strong = args.scaling == "strong"
     if strong:
         lo, hi = shard_plan(args.strong_reads, rank, world)
@@ -336,32 +364,36 @@ def main():
     else:
         nb = max(1, args.resident_batches)
         spans = [((rank * nb + b) * R, (rank * nb + b + 1) * R) for b in range(nb)]
-    batches = []  # (d_bases, d_offsets, n_reads, total_bases)
+    if not spans:
+        raise SystemExit(f"rank {rank}: empty shard (more ranks than reads?)")
+    host_fed = args.timed_path == "host_fed"
+    keep_resident = (not strong) or not host_fed  # a strong shard is kept in HBM only when that is what is timed
+    r_cap = max(last - first for first, last in spans)
+    stage = kmers.pinned_empty((r_cap * L,), np.uint8)  # ASCII on its way from the generator (HBM) to the packer
+    batches = []  # (d_bases, d_offsets, n_reads, total_bases, packed host batch)
+    d_bases = d_offs = None
     for first, last in spans:
         n_r = last - first
         tot = n_r * L
-        d_bases = dalloc((tot + 15) // 16 * 16 + 16)
-        d_offs = dalloc((n_r + 1) * 8)
-        if hap:
-            check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first, n_r, L, err24,
-                                                 C.c_void_p(d_bases), C.c_void_p(d_offs)))
-        else:
-            check(lib.tbk_synth_reads_device(dev, READ_SEED, first, n_r, L, KEY_SEED, n_list, n_list, k,
-                                             args.plant_major, args.plant_minor, C.c_void_p(d_bases), C.c_void_p(d_offs)))
-        batches.append((d_bases, d_offs, n_r, tot))
+        if d_bases is None or keep_resident:
+            d_bases = dalloc((r_cap * L + 15) // 16 * 16 + 16)
+            d_offs = dalloc((r_cap + 1) * 8)
+        synth_reads(first, n_r, d_bases, d_offs)
+        check(lib.tbk_memcpy_d2h(dev, stage.ctypes.data, C.c_void_p(d_bases), tot))
+        offs = np.arange(n_r + 1, dtype=np.uint64) * np.uint64(L)
+        packed = kmers.pack_bases(stage[:tot], offs, pinned=True)
+        batches.append((d_bases if keep_resident else None, d_offs if keep_resident else None, n_r, tot, packed))
+    del stage
     t_setup = time.time() - t_setup
-    if not batches:
-        raise SystemExit(f"rank {rank}: empty shard (more ranks than reads?)")
 
-    depth = cls.depth
-    r_max = max(b[2] for b in batches)
-    counts_ring = [kmers.pinned_empty((r_max, 2), np.int32) for _ in range(depth)]
+    depth = pipe.depth
+    counts_ring = [kmers.pinned_empty((r_cap, 2), np.int32) for _ in range(depth)]
     num_a, num_b = hap_a.num_kmers, hap_b.num_kmers
     bins_total = {"A": 0, "B": 0, "U": 0}
 
-    def finish(ticket, slot, n_r, tally):
-        """Host side of a launch: wait for its counts, take the A/B/U decision."""
-        cls.wait(ticket)
+    def finish(waiter, ticket, slot, n_r, tally):
+        """Host side of a step: wait for its counts, take the A/B/U decision."""
+        waiter(ticket)
         _, _, bins = kmers.score_and_bin(counts_ring[slot][:n_r], num_a, num_b)
         if tally:
             for name, ch in (("A", b"A"), ("B", b"B"), ("U", b"U")):
@@ -371,37 +403,65 @@ def main():
     launches_per_step = len(batches) if strong else 1
     bases_per_step = sum(b[3] for b in batches) if strong else batches[0][3]
 
-    def run(n_steps, tally):
-        """n_steps steps, pipelined: the host finishes launch i-1 while the GPU probes launch i."""
+    def run(n_steps, tally, fed):
+        """n_steps steps, pipelined: the host finishes step i-1 while the device works on step i.
+        fed: through the pipeline from pinned host memory; else: batches resident in HBM."""
         pending = []
+        waiter = pipe.wait if fed else cls.wait
         for i in range(n_steps * launches_per_step):
-            d_bases, d_offs, n_r, tot = batches[i % len(batches)]
+            d_b, d_o, n_r, tot, packed = batches[i % len(batches)]
             slot = i % depth
             if len(pending) == depth - 1 + (depth == 1):
-                finish(*pending.pop(0), tally)
-            pending.append((cls.submit_device(d_bases, d_offs, n_r, tot, counts_ring[slot][:n_r]), slot, n_r))
+                finish(waiter, *pending.pop(0), tally)
+            if fed:
+                t = pipe.submit_packed(packed, counts_ring[slot][:n_r])
+            else:
+                t = cls.submit_device(d_b, d_o, n_r, tot, counts_ring[slot][:n_r])
+            pending.append((t, slot, n_r))
         while pending:
-            finish(*pending.pop(0), tally)
+            finish(waiter, *pending.pop(0), tally)
 
-    run(args.warmup, False)
-    cls.kernel_timing(True)
+    def region_of(fed, tally):
+        def region():
+            check(lib.tbk_device_sync(dev))
+            dist.barrier()
+            t0 = time.perf_counter()
+            run(args.steps, tally, fed)
+            check(lib.tbk_device_sync(dev))
+            dist.barrier()
+            return time.perf_counter() - t0
+        return region
 
-    def region():
-        check(lib.tbk_device_sync(dev))
-        dist.barrier()
-        t0 = time.perf_counter()
-        run(args.steps, True)
-        check(lib.tbk_device_sync(dev))
-        dist.barrier()
-        return time.perf_counter() - t0
+    def timed(fed, tally):
+        run(args.warmup, False, fed)
+        cls.kernel_timing(True)
+        region_s = timed_regions(region_of(fed, tally), dist, args.min_timed_s)
+        launches, probe_ms, single_ms = cls.kernel_timing_read2()
+        cls.kernel_timing(False)
+        return region_s, launches, probe_ms, single_ms
 
-    region_s = timed_regions(region, dist, args.min_timed_s)
-    launches, kernel_ms = cls.kernel_timing_read()
-    cls.kernel_timing(False)
-
-    elapsed = statistics.median(region_s)
     bases_all = dist.reduce(args.steps * bases_per_step, "SUM")
+    region_s, launches, probe_ms, single_ms = timed(host_fed, True)
+    n_passes, multi_passes = cls.last_passes()  # of the last probe (weak scaling: every batch has this shape)
+    elapsed = statistics.median(region_s)
     value = bases_all / elapsed / 1e9
+    other = None
+    if keep_resident and host_fed:
+        o_region_s, o_l, o_probe_ms, o_single_ms = timed(False, False)
+        o_el = statistics.median(o_region_s)
+        other = {"gbases_per_s": round(bases_all / o_el / 1e9, 3), "ms_per_step": round(o_el / args.steps * 1e3, 3),
+                 "probe_ms_avg": round(o_probe_ms / max(1, o_l), 4), "single_read_kernel_ms_avg": round(o_single_ms / max(1, o_l), 4),
+                 "note": "the same steps with the batches already in HBM (no H2D): what the kernels alone sustain"}
+
+    if hasattr(lib, "tbk_debug_counters"):  # debug build (-DTBK_COUNTERS): event counts of one step, to stderr
+        buf = (C.c_ulonglong * 8)()
+        lib.tbk_debug_counters(buf, 1)
+        run(1, False, host_fed)
+        lib.tbk_debug_counters(buf, 1)
+        w_ = launches_per_step * batches[0][2] * max(1, L - k + 1)
+        print("tbk-counters", json.dumps({"careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
+                                         "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4),
+                                         "back_half_looks_per_window": round(buf[5] / w_, 5)}), file=sys.stderr)
 
     if not stats["minimizer_w"]:
         bucket_select = "plain hash"
@@ -409,31 +469,43 @@ def main():
         bucket_select = "mod-sampling w=%d m=%d t=%d" % (stats["minimizer_w"], stats["minimizer_m"], stats["sampling_t"])
     else:
         bucket_select = "minimizer w=%d m=%d" % (stats["minimizer_w"], stats["minimizer_m"])
-    # ---- roofline of the probe kernel (rank 0's device) -----------------------------------------
-    # algorithmic bytes per window: 1 read byte + 8 B for the hapA slot + 8 B for the
-    # hapB slot when hapA missed.  Per launch: windows = reads * (L - k + 1), averaged over the
-    # launches of the timed regions (all batches have the same shape except a shard's last one).
-    d_b0, d_o0, n_r0, tot0 = batches[0]
-    counts = counts_ring[0][:n_r0]
-    dbg_read = getattr(lib, "tbk_debug_counters", None) if hasattr(lib, "tbk_debug_counters") else None
-    if dbg_read is not None:  # debug build (-DTBK_COUNTERS): event counts of one launch, to stderr
-        buf = (C.c_ulonglong * 8)()
-        dbg_read(buf, 1)
-    finish(cls.submit_device(d_b0, d_o0, n_r0, tot0, counts), 0, n_r0, False)
-    if dbg_read is not None:
-        dbg_read(buf, 1)
-        w_ = n_r0 * max(1, L - k + 1)
-        print("tbk-counters", json.dumps({"careful_jstep_frac": round(buf[1] / max(buf[0], 1), 4), "careful_substeps_per_jstep": round(buf[2] / max(buf[0], 1), 4),
-                                         "walks_per_window": round(buf[3] / w_, 6), "lines_per_window": round(buf[4] / 4 / w_, 4),
-                                         "back_half_looks_per_window": round(buf[5] / w_, 5)}), file=sys.stderr)
-    hit_a_frac = float(counts[:, 0].sum()) / max(1, n_r0 * max(0, L - k + 1))
-    reads_per_launch = sum(b[2] for b in batches) / len(batches) if strong else n_r0
+
+    # ---- parity: every rank classifies the generator's first reads through the host-fed path ------------
+    n_par = max(1, min(args.parity_reads, 1 << 16))
+    d_pb, d_po = dalloc((n_par * L + 15) // 16 * 16 + 16), dalloc((n_par + 1) * 8)
+    synth_reads(0, n_par, d_pb, d_po)
+    par_bases = kmers.pinned_empty((n_par * L,), np.uint8)
+    check(lib.tbk_memcpy_d2h(dev, par_bases.ctypes.data, C.c_void_p(d_pb), par_bases.nbytes))
+    par_offs = np.arange(n_par + 1, dtype=np.uint64) * np.uint64(L)
+    par_counts = pipe.wait(pipe.submit(par_bases, par_offs)).copy()                      # ASCII in, packed by the feeder
+    par_counts2 = pipe.wait(pipe.submit_packed(kmers.pack_bases(par_bases, par_offs)))   # packed ahead, as the reader does
+    import zlib
+
+    mine = {"rank": rank, "device_index": dev, "device": _lib.device_identity(dev), "sum_a": int(par_counts[:, 0].sum()), "sum_b": int(par_counts[:, 1].sum()),
+            "crc32": zlib.crc32(par_counts.tobytes()), "transfers_agree": bool(np.array_equal(par_counts, par_counts2))}
+    everyone = dist.gather_obj(mine)
+    parity = {"reads_checked_per_rank": n_par, "bases_checked_per_rank": n_par * L, "count_checksum": [mine["sum_a"], mine["sum_b"], mine["crc32"]],
+              "all_ranks_equal": all((e["sum_a"], e["sum_b"], e["crc32"]) == (mine["sum_a"], mine["sum_b"], mine["crc32"]) for e in everyone),
+              "packed_and_ascii_transfers_agree": all(e["transfers_agree"] for e in everyone)}
+    devices = [{"rank": e["rank"], "device_index": e["device_index"], "id": e["device"]} for e in everyone]
+
+    # ---- roofline of the dominant kernel (rank 0's device) ----------------------------------------------
+    # The probe is three kernels: pass index, the multi-read kernel (passes that touch several reads) and the
+    # single-read kernel (passes inside one read: on 15 kb reads 86 % of the passes).  The roofline is the
+    # single-read kernel's: its windows x the algorithmic bytes per window (1 read byte + 8 B for
+    # the hapA slot + 8 B for the hapB slot when hapA missed; P = 1 reading: 1 + 8) / its HIP-event time.
+    hit_a_frac = float(par_counts[:, 0].sum()) / max(1, n_par * max(0, L - k + 1))
+    reads_per_launch = sum(b[2] for b in batches) / len(batches)
     windows = reads_per_launch * max(0, L - k + 1)
-    alg_bytes = windows * (9 + 8 * (1 - hit_a_frac))
-    avg_kernel_s = kernel_ms / max(1, launches) * 1e-3
-    achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+    single_frac = 1.0 - multi_passes / max(1, n_passes)
+    windows_single = windows * single_frac
+    b_alg = 9 + 8 * (1 - hit_a_frac)
+    alg_bytes = windows_single * b_alg
+    single_s = single_ms / max(1, launches) * 1e-3
+    probe_s = probe_ms / max(1, launches) * 1e-3
+    achieved = alg_bytes / single_s / 1e9 if single_s > 0 else 0.0
     table_load = n_list / (stats["n_buckets"] * 8)
-    traffic = None
+    traffic = traffic_src = None
     for tname in ("pmc_traffic.json", "pmc_traffic_haplotypes.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if not os.path.isfile(tfile):
@@ -443,25 +515,33 @@ def main():
             same = (t.get("read_len") == L and t.get("kmers_per_list") == n_list
                     and t.get("k") == k and t.get("bucket_select") == bucket_select and t.get("lists", "uniform") == args.lists
                     and abs(t.get("table_load", 0) - table_load) < 2e-3
-                    and bool(t.get("front_layout", False)) == bool(stats.get("front_layout")))
-            if same:  # measured in separate rocprofv3 --pmc passes on this configuration; scaled to this launch's windows
-                traffic = t["hbm_bytes_per_window"] * windows
+                    and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
+                    and t.get("kernel") == "tbk_probe_kernel<single-read>")
+            if same:  # measured in separate rocprofv3 --pmc passes on this configuration (not in this run); scaled to this launch's windows
+                traffic = t["hbm_bytes_per_window"] * windows_single
+                traffic_src = "profiles/" + tname + " (rocprofv3 --pmc passes of this configuration, replayed per window; not measured in this run)"
         except Exception:
             pass
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic),
-        "kernel": "tbk_probe_kernel", "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "launches": int(launches),
-        "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(alg_bytes / max(1, windows), 3),
-        "windows_per_launch": int(windows),
-        "kernel_only_gbases_per_s": round(reads_per_launch * L / avg_kernel_s / 1e9, 2) if avg_kernel_s > 0 else None,
+        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_src,
+        "kernel": "tbk_probe_kernel<..., MULTI=false> (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
+        "timed_in": "the timed region of `value` (HIP events on the compute stream)",
+        "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
+        "share_of_the_batch_windows": round(single_frac, 4), "passes": int(n_passes), "multi_read_passes": int(multi_passes),
+        "frac_P1_merged_table_reading": round(windows_single * 9 / single_s / 1e9 / HBM_PEAK_GBPS, 4) if single_s > 0 else None,
+        "whole_probe_ms_avg": round(probe_s * 1e3, 4),
+        "whole_probe": {"what": "pass index + multi-read kernel + single-read kernel, per batch", "alg_bytes": int(windows * b_alg),
+                        "achieved": round(windows * b_alg / probe_s / 1e9, 1) if probe_s > 0 else None,
+                        "frac": round(windows * b_alg / probe_s / 1e9 / HBM_PEAK_GBPS, 4) if probe_s > 0 else None},
+        "kernel_only_gbases_per_s": round(reads_per_launch * L / probe_s / 1e9, 2) if probe_s > 0 else None,
     }
-    if traffic is not None and avg_kernel_s > 0:
+    if traffic is not None and single_s > 0:
         # where the kernel sits against what the memory system can actually deliver: PMC-measured
         # bytes per launch over this run's kernel time, and 128-byte lines per second against the
         # random-line ceiling measured by tools/calib_footprint.py (profiles/calibration.json)
-        roofline["traffic_GBps"] = round(traffic / avg_kernel_s / 1e9, 1)
-        roofline["traffic_frac_of_peak"] = round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBPS, 4)
+        roofline["traffic_GBps"] = round(traffic / single_s / 1e9, 1)
+        roofline["traffic_frac_of_peak"] = round(traffic / single_s / 1e9 / HBM_PEAK_GBPS, 4)
         roofline["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
         cfile = os.path.join(ROOT, "profiles", "calibration.json")
         if os.path.isfile(cfile):
@@ -472,10 +552,10 @@ def main():
                 key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
                 ceiling = rows[key]["line128"]
                 roofline["random_line_ceiling_footprint"] = key
-                roofline["random_lines_Gps"] = round(traffic / 128 / avg_kernel_s / 1e9, 2)
+                roofline["random_lines_Gps"] = round(traffic / 128 / single_s / 1e9, 2)
                 roofline["random_line_ceiling_Gps"] = ceiling
-                roofline["random_line_frac"] = round(traffic / 128 / avg_kernel_s / 1e9 / ceiling, 3)
-                roofline["traffic_frac_of_measured_stream"] = round(traffic / avg_kernel_s / 1e9 / cal["guide_stream_GBps"], 3)
+                roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
+                roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / cal["guide_stream_GBps"], 3)
             except Exception:
                 pass
 
@@ -483,13 +563,15 @@ def main():
         # the CPU sample works in whole reads; one read of this length is minutes of oracle time
         print(f"bench: reads of {L} bases are too long for a bounded CPU sample: cpu_baseline skipped", file=sys.stderr)
         want_cpu = False
+    fed_txt = ("batches in pinned host memory in the packed transfer format (what the reader hands over), through the pipeline: H2D on the side stream, "
+               "kernels, D2H, host binning" if host_fed else "batches resident in HBM")
     if strong:
         workload = (f"BASELINE configs[3]: one fixed set of {args.strong_reads} synthetic {L} b reads ({args.strong_reads * L / 1e9:.1f} Gbp) "
-                    f"split over {world} rank(s) by read index, 2x{n_list} unique {k}-mers replicated per GPU, each rank's shard resident in HBM; "
+                    f"split over {world} rank(s) by read index, 2x{n_list} unique {k}-mers replicated per GPU; {fed_txt}; "
                     f"a step = one pass of every rank over its shard")
     else:
         workload = (f"BASELINE configs[2] shape: {L} b synthetic reads, 2x{n_list} unique {k}-mers replicated per GPU, "
-                    f"{R} reads ({R * L / 1e9:.3f} Gbases) per step per GPU resident in HBM, reads sharded over ranks")
+                    f"{R} reads ({R * L / 1e9:.3f} Gbases) per step per GPU, reads sharded over ranks; {fed_txt}")
     out = {
         "metric": metric_label(k, n_list), "value": round(value, 3), "unit": "Gbases/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -497,47 +579,56 @@ def main():
         "vs_baseline": None, "dtype": "u64",
         "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g})",
         "config": {
-            "workload": workload,
+            "workload": workload, "timed_path": args.timed_path,
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R if not strong else None,
-            "resident_batches": len(batches), "launches_per_step": launches_per_step, "bases_per_step_per_rank": bases_per_step,
-            "table_bytes_per_gpu": stats["table_bytes"], "table_load": round(table_load, 4),
+            "distinct_batches": len(batches), "launches_per_step": launches_per_step, "bases_per_step_per_rank": bases_per_step,
+            "h2d_bytes_per_base": round(sum(b[4].nbytes for b in batches) / max(1, sum(b[3] for b in batches)), 4) if host_fed else 0,
+            "table_bytes_per_gpu": stats["table_bytes"], "table_bytes_per_key": round(stats["table_bytes"] / max(1, 2 * n_list), 1), "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
-            "line_layout": "front: 64 of a line's 128 bytes fetched per window" if stats.get("front_layout") else "whole lines", "keys_behind_front": stats.get("keys_behind_front"),
+            "line_layout": "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines", "keys_behind_front": stats.get("keys_behind_front"),
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
         },
         "timed_regions": len(region_s), "timed_total_s": round(sum(region_s), 3),
         "region_s_min_median_max": [round(min(region_s), 4), round(elapsed, 4), round(max(region_s), 4)],
-        "roofline": roofline,
+        ("kernel_resident" if host_fed else "host_fed"): other,
+        "roofline": roofline, "parity": parity, "devices": devices, "distinct_devices": len({d["id"] for d in devices}),
         "bins": bins_total, "setup_s": round(t_setup, 2), "table_build_s": round(t_build, 2),
         "device": _lib.device_name(dev),
     }
+    if args.share_device:
+        out["devices_note"] = "--share-device: every rank uses device 0 (a plumbing run, not a scaling result)"
 
-    # ---- the north-star pipeline: pinned host batches through the stream ring (rank 0, N = 1) -----
+    # ---- the same stage fed differently (rank 0, N = 1) ----------------------------------------------
     if rank == 0 and world == 1 and not args.no_streaming:
-        out["streaming"] = streaming_leg(args, np, kmers, lib, check, dev, cls, batches[0], counts, L)
+        out["pipeline_variants"] = pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batches[0], L)
 
     if args.calibrate and rank == 0:
         out["calibration"] = calibrate(lib, check, dev, stats["table_bytes"])
 
-    # ---- CPU baseline + parity on a bounded sample (rank 0, N=1 only) -----------------------------
+    # ---- CPU baseline + read-for-read parity on a bounded sample (rank 0, every N) ---------------------
     if want_cpu:
-        out["cpu_baseline"], out["parity"] = cpu_baseline(args, np, lib, check, dev, batches[0], counts, h_keys, n_list, k, L, n_r0)
+        out["cpu_baseline"], cpu_par = cpu_baseline(args, np, lib, par_bases, par_offs, par_counts, h_keys, n_list, k, L, n_par)
+        out["parity"].update(cpu_par)
 
-    cls.close()
+    pipe.close()
     dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.close()
 
 
-def streaming_leg(args, np, kmers, lib, check, dev, cls, batch0, gpu_counts_batch0, L):
-    """Host-fed classify rate: what SURVEY §8d calls the classify stage (pinned batches -> H2D on the
-    side stream, overlapped -> probe kernel -> D2H of the counts).  Three pinned host batches (the
-    first reads of resident batch 0, copied back) are cycled through tbk_stream_submit for
-    ~stream_seconds; the counts must equal those the device-resident path got for the same reads.
-    Reported beside `value`, never as `value`."""
-    d_bases, _, n_r0, _ = batch0
+def pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batch0, L):
+    """The same classify stage fed with ASCII batches instead of the reader's packed ones (rank 0, N = 1):
+      ascii_in_packed_by_feeder   ASCII batches in pinned host memory; the device's feeder thread packs each
+                                  (all host threads) before the copy: what a caller without the reader gets;
+      ascii_over_pcie             ASCII crosses the link, the kernel packs (TBK_PACKED_H2D=0): PCIe-bound.
+    Three host batches are cycled through the pipeline for ~stream_seconds per variant; the counts must equal
+    those of the packed path for the same reads."""
+    d_bases = batch0[0]
+    n_r0 = batch0[2]
+    if d_bases is None:
+        return None
     Rs = min(args.stream_batch_reads, n_r0 // 3 if n_r0 >= 3 else n_r0)
     if Rs < 1:
         return None
@@ -548,65 +639,48 @@ def streaming_leg(args, np, kmers, lib, check, dev, cls, batch0, gpu_counts_batc
         ho = kmers.pinned_empty((Rs + 1,), np.uint64)
         check(lib.tbk_memcpy_d2h(dev, hb.ctypes.data, C.c_void_p(d_bases + b * tot), tot))
         ho[:] = np.arange(Rs + 1, dtype=np.uint64) * np.uint64(L)
-        host.append((hb, ho, gpu_counts_batch0[b * Rs:(b + 1) * Rs]))
-    res = {"batch_reads": Rs, "batch_gbases": round(tot / 1e9, 4), "pinned_host_batches": len(host),
-           "note": "inputs in pinned host memory, H2D inside the timed loop (PCIe-inclusive); not `value`"}
+        want = pipe.wait(pipe.submit_packed(kmers.pack_bases(hb, ho))).copy()
+        host.append((hb, ho, want))
+    res = {"batch_reads": Rs, "batch_gbases": round(tot / 1e9, 4), "pinned_host_batches": len(host)}
+    depth = pipe.depth
 
-    def cycle(submit, n_batches, check_counts):
+    def cycle(n_batches, check_counts):
         pend, same = [], True
         for i in range(n_batches):
-            if len(pend) == cls.depth:
+            if len(pend) == depth:
                 j, t = pend.pop(0)
-                c = cls.wait(t)
+                c = pipe.wait(t)
                 same = same and (not check_counts or bool(np.array_equal(c, host[j][2])))
             j = i % len(host)
-            pend.append((j, submit(j)))
+            pend.append((j, pipe.submit(host[j][0], host[j][1])))
         while pend:
             j, t = pend.pop(0)
-            c = cls.wait(t)
+            c = pipe.wait(t)
             same = same and (not check_counts or bool(np.array_equal(c, host[j][2])))
         return same
 
-    def leg(submit):
-        cycle(submit, 3, False)
+    def leg():
+        cycle(3, False)
         t = time.perf_counter()
-        cycle(submit, 6, False)
+        cycle(6, False)
         per = (time.perf_counter() - t) / 6
         n = int(max(6, min(2000, args.stream_seconds / max(per, 1e-6))))
         t = time.perf_counter()
-        same = cycle(submit, n, True)
+        same = cycle(n, True)
         dt = time.perf_counter() - t
         return n, dt, same
 
-    # (1) ASCII over PCIe: 1 byte per base, the kernel packs
-    cls.packed_transfer = False
-    n, dt, same = leg(lambda j: cls.submit(host[j][0], host[j][1]))
-    res["ascii"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * (tot + (Rs + 1) * 8) / dt / 1e9, 2),
-                    "bytes_per_base": 1.0, "batches": n, "seconds": round(dt, 3), "counts_equal_resident_path": same}
-    # (2) the default of tbk_stream_submit: the same ASCII host batches, packed by the host's threads
-    # inside submit (the packing of batch i+1 overlaps the GPU's work on batch i), 0.25 bytes per base cross
-    cls.packed_transfer = True
-    n, dt, same = leg(lambda j: cls.submit(host[j][0], host[j][1]))
-    res["packed_on_submit"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * (tot / 4 + (Rs + 1) * 8) / dt / 1e9, 2),
-                               "bytes_per_base": 0.25, "batches": n, "seconds": round(dt, 3), "counts_equal_resident_path": same,
-                               "host_pack_threads": int(lib.tbk_host_threads())}
-    # (3) batches packed ahead of time (what a reader thread that packs while it parses hands over)
-    packed = [kmers.pack_bases(hb, ho) for hb, ho, _ in host]
-    reps = 3
-    t = time.perf_counter()
-    for _ in range(reps):
-        for hb, ho, _ in host:
-            kmers.pack_bases(hb, ho, pinned=False)
-    pack_s = time.perf_counter() - t
-    n, dt, same = leg(lambda j: cls.submit_packed(packed[j]))
-    nbytes = sum(p.nbytes for p in packed) / len(packed)
-    res["prepacked"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * nbytes / dt / 1e9, 2),
-                        "bytes_per_base": round(nbytes / tot, 4), "batches": n, "seconds": round(dt, 3), "counts_equal_resident_path": same,
-                        "host_pack_alone_gbases_per_s": round(reps * len(host) * tot / pack_s / 1e9, 2)}
-    # the figure of the pipeline as shipped: ASCII batches in, tbk_stream_submit's default transfer
-    res["gbases_per_s"] = res["packed_on_submit"]["gbases_per_s"]
-    res["h2d_GBps"] = res["packed_on_submit"]["h2d_GBps"]
-    res["ascii_gbases_per_s"] = res["ascii"]["gbases_per_s"]
+    part = pipe._part(0)
+    part.packed_transfer = True
+    n, dt, same = leg()
+    res["ascii_in_packed_by_feeder"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * (tot / 4 + (Rs + 1) * 8) / dt / 1e9, 2),
+                                        "bytes_per_base": 0.25, "batches": n, "seconds": round(dt, 3), "counts_equal_packed_path": same,
+                                        "host_pack_threads": int(lib.tbk_host_threads())}
+    part.packed_transfer = False
+    n, dt, same = leg()
+    res["ascii_over_pcie"] = {"gbases_per_s": round(n * tot / dt / 1e9, 2), "h2d_GBps": round(n * (tot + (Rs + 1) * 8) / dt / 1e9, 2),
+                              "bytes_per_base": 1.0, "batches": n, "seconds": round(dt, 3), "counts_equal_packed_path": same}
+    part.packed_transfer = True
     return res
 
 
@@ -624,8 +698,9 @@ def calibrate(lib, check, dev, footprint):
     return res
 
 
-def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n_list, k, L, R):
-    """The oracle on this box's host cores, same tables, a prefix of batch 0's reads."""
+def cpu_baseline(args, np, lib, h_bases, offs, gpu_counts, h_keys, n_list, k, L, sample_reads):
+    """The oracle on this box's host cores, same tables, the parity reads (the generator's first reads, which
+    the GPU classified through the host-fed path)."""
     import oracle
 
     orc = oracle.load()
@@ -637,10 +712,8 @@ def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n
     oa = orc.table_from_keys(h_keys[:n_list], k, threads=cores)
     ob = orc.table_from_keys(h_keys[n_list:], k, threads=cores)
     t_tables = time.time() - t0
-    sample_reads = min(R, 4096)
-    h_bases = np.empty(sample_reads * L, dtype=np.uint8)
-    check(lib.tbk_memcpy_d2h(dev, h_bases.ctypes.data, C.c_void_p(batch0[0]), h_bases.nbytes))
-    offs = (np.arange(sample_reads + 1, dtype=np.uint64) * np.uint64(L))
+    h_bases = np.asarray(h_bases)
+    gpu_counts_batch0 = gpu_counts
 
     def timed(n_reads, threads):
         t = time.perf_counter()
@@ -667,15 +740,15 @@ def cpu_baseline(args, np, lib, check, dev, batch0, gpu_counts_batch0, h_keys, n
     g = gpu_counts_batch0[:nall]
     equal = (bool(np.array_equal(g, cn)) and bool(np.array_equal(g[:n1], c1))
              and bool(np.array_equal(gpu_counts_batch0[:sample_reads], cf)))
-    parity = {"reads_checked": int(nall), "bases_checked": int(nall * L), "gpu_equals_cpu": equal,
-              "count_checksum": [int(cn[:, 0].sum()), int(cn[:, 1].sum())]}
+    parity = {"reads_checked_against_the_oracle": int(nall), "bases_checked_against_the_oracle": int(nall * L), "gpu_equals_cpu": equal,
+              "cpu_count_sums": [int(cn[:, 0].sum()), int(cn[:, 1].sum())]}
     if not equal:
         bad = np.nonzero((g != cn).any(axis=1))[0][:5]
         parity["first_mismatches"] = [[int(i), g[i].tolist(), cn[i].tolist()] for i in bad]
     base = {
         "value": round(rate1, 6), "unit": "Gbases/s", "cores": 1, "kind": "port", "host_hardware_threads": hw_threads, "host_usable_cpus": cores,
         "sample": f"oracle (faithful restatement of c/kmers.c: 2 linear-probe tables at load 0.75, non-rolling encode) "
-                  f"on the first {n1} reads ({n1 * L / 1e6:.1f} Mbases) of batch 0, same 2x{n_list} {k}-mer tables, {dt1:.1f} s",
+                  f"on the first {n1} reads ({n1 * L / 1e6:.1f} Mbases) of the generator, same 2x{n_list} {k}-mer tables, {dt1:.1f} s",
         "all_cores": {"value": round(raten, 6), "unit": "Gbases/s", "cores": cores,
                       "sample": f"first {nall} reads ({nall * L / 1e6:.1f} Mbases), reads sharded over {cores} threads, {dtn:.1f} s"},
         "optimised_rolling_all_cores": {"value": round(ratef, 6), "unit": "Gbases/s", "cores": cores,

@@ -77,8 +77,17 @@ void tbk_reverse_complement(const char *kmer_in, char *kmer_out, unsigned char k
  * returns it, minus one; every line is one k-mer (duplicates counted, a last line without
  * '\n' counted); each line contributes its first k bytes, verbatim (no canonicalisation).
  * The packed keys are placed in HBM on `device`; tbk_classifier_create hashes two such lists
- * into the paired open-addressing table the probe kernel reads. */
+ * into the paired open-addressing table the probe kernel reads.
+ * Where the keys come from, in this order: (1) the binary key cache `<path>.tbk` when it was made from this
+ * very file (same size and modification time; a stale or damaged cache is ignored; TBK_LIST_CACHE=0: never
+ * read one, TBK_LIST_CACHE=1: write one after parsing the text); (2) the GPU parser, for lists in the shape
+ * every tool writes them - each line k bytes and a newline - whose text is staged through pinned memory and
+ * packed one line per thread (TBK_LIST_GPU_PARSE=0: off); (3) the general host parser (the reference's getline
+ * rules line by line) for anything else.  All three give the same keys.  tbk_table_origin says which it was
+ * (0 keys from the caller / the host parser, 1 the GPU parser, 2 the cache); tbk_table_keys copies the keys out. */
 int tbk_table_create_from_file(const char *path, int device, tbk_table **out);
+int tbk_table_origin(const tbk_table *t);
+int tbk_table_keys(const tbk_table *t, uint64_t *keys, uint64_t capacity);
 /* Host-only half of the above: parse the list (all host threads when every line is k bytes +
  * newline, the sequential general parser otherwise) into malloc'd packed keys; free with
  * tbk_list_free. */
@@ -171,6 +180,8 @@ int tbk_stream_depth(const tbk_classifier *c);
 int tbk_stream_submit(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
                       uint64_t n_reads, int32_t *counts, uint64_t *ticket);
 int tbk_stream_wait(tbk_classifier *c, uint64_t ticket);
+/* 1 when that ticket's batch is complete (tbk_stream_wait will not block), 0 when not yet, below -1 on error. */
+int tbk_stream_query(tbk_classifier *c, uint64_t ticket);
 /* The packed transfer format.  ASCII reads cost a byte per base over PCIe (Gen5 x16: ~56 GB/s, a
  * third of what the probe kernel consumes); the kernel's first step on a 16-base chunk is to turn it
  * into a 32-bit word of 2-bit codes (c/kmers.c:50-72's encoding) and a 16-bit not-ACGT mask, and that
@@ -265,6 +276,9 @@ int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64_t num_kmer
 int tbk_kernel_timing_enable(tbk_classifier *c, int on);
 int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms);
 int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, double *total_ms, double *single_ms);
+/* Passes (2048 window starts each) of the classifier's most recent probe, and how many of them touched more
+ * than one read: the multi-read kernel's share of the work; the rest was the single-read kernel's. */
+int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes, uint64_t *n_multi);
 
 /* Replaces calculate_scaling_factors (classify_by_kmers.py:57-77) and the binning rule
  * (classify_by_kmers.py:104-115): float64, same operation order (1.0*max/n, count*factor,
@@ -374,7 +388,11 @@ int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, u
  * kmc_tools transform histogram; kmc_tools simple kmers_subtract; kmc_dump -ci -cx): canonical
  * k-mers of all reads, both strands, k-mers holding a symbol outside ACGT skipped, lower case
  * counted as upper case; k-mers seen once are not in the database; counters saturate at 255.
- * KMC itself is not part of the reference checkout: parity with it is unpinned. */
+ * KMC itself is not part of the reference checkout: parity with it is unpinned.
+ * Limit: the table's counters are 32-bit and neighbours share a 64-bit atomic add, so a k-mer that occurs
+ * 2^32 times or more in one library (a satellite k-mer of a very deep read set) would carry into the
+ * neighbouring slot's counter; readers cap at 255 long before, but the neighbour's count would be off by
+ * the carry.  Not reachable below 4.3e9 occurrences of ONE k-mer; split such a library over two counters. */
 typedef struct tbk_counter tbk_counter;
 /* Table for `capacity_kmers` distinct k-mers to start with (16 bytes per slot at load <= 0.6: a
  * bucket is one 128-byte line holding 8 keys and their 8 counters).  Before a batch that could

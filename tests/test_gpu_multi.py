@@ -37,17 +37,22 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
         assert multi.devices == [0, 0, 0] and multi.depth == 9
         st = multi.stats()
         assert st["devices"] == [0, 0, 0] and st["table_bytes_total"] == 3 * st["table_bytes"]
-        for part in multi._parts:       # every replica on its own
-            assert part.stats() == multi._parts[0].stats()
+        for i in range(3):              # every replica on its own (the pipeline is idle)
+            part = multi._part(i)
+            assert part.stats() == multi._part(0).stats()
             assert np.array_equal(part.classify_batch(bases, offs), want)
-        # dealt: nine batches in flight at once, waited for out of order
-        cuts = [0, 10, 11, 40, 41, 41, 90, 120, 149, len(v["reads"])]
+        # queued: twelve batches submitted before the first wait (depth 9 + one waiting per ring), ASCII and
+        # packed ahead alike, waited for out of order
+        cuts = [0, 10, 11, 40, 41, 41, 60, 75, 90, 100, 120, 149, len(v["reads"])]
         tickets = []
-        for lo, hi in zip(cuts, cuts[1:]):
-            tickets.append((lo, hi, multi.submit(*kmers.pack_reads(v["reads"][lo:hi]))))
-        assert multi.dealt == [3, 3, 3]
+        for i, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+            bb, oo = kmers.pack_reads(v["reads"][lo:hi])
+            tickets.append((lo, hi, multi.submit(bb, oo) if i % 2 else multi.submit_packed(kmers.pack_bases(bb, oo))))
+        with pytest.raises(_lib.TbkError):
+            multi.submit(bases, offs)   # further ahead than depth + rings
         for lo, hi, t in reversed(tickets):
             assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
+        assert sum(multi.dealt) == 12 + 0 and min(multi.dealt) >= 1, multi.dealt
     # a replica of a replica, and the error paths of the C entry points
     with kmers.Classifier(a, b) as one:
         h = C.c_void_p()

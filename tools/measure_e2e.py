@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""End-to-end `classify-by-kmers` at BASELINE configs[1] scale: 1 M x 15 kb reads (15 Gbases, a 30 GB FASTQ)
+against 2 x 100 M-line TEXT lists, from process start to the last byte of the three bins.
+
+What is timed is the product's command line as a user runs it (a child process); the JSON says how long the
+lists took (parse + table build, with and without the binary key cache), the stages' busy seconds inside the
+native loop (reader / waiting for the GPU / writer) and the overall Gbases/s.  Inputs are synthetic (lists:
+the bench's key generator; reads: its read generator, planted list k-mers) and are written by this script
+just before the run, so the page cache is warm - stated in the output; nothing here can drop it.
+
+    python tools/measure_e2e.py [--reads 1000000] [--kmers 100000000] [--gz-output] [--dir /tmp]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--kmers", type=int, default=100_000_000)
+ap.add_argument("--reads", type=int, default=1_000_000)
+ap.add_argument("--read-len", type=int, default=15_000)
+ap.add_argument("--k", type=int, default=21)
+ap.add_argument("--dir", default=None)
+ap.add_argument("--modes", default="plain,gzip")
+ap.add_argument("--keep", action="store_true")
+a = ap.parse_args()
+
+from trio_binning_amd import _lib, kmers  # noqa: E402
+from trio_binning_amd._lib import check, lib  # noqa: E402
+
+k, L, R, N = a.k, a.read_len, a.reads, a.kmers
+tmp = tempfile.mkdtemp(prefix="tbk_e2e_", dir=a.dir)
+res = {"config": f"BASELINE configs[1] shape: {R} x {L} b reads, 2 x {N} unique {k}-mers as text lists", "dir": tmp,
+       "page_cache": "warm (the inputs were written by this script just before the runs)", "host_usable_cpus": int(lib.tbk_host_threads())}
+dev = 0
+
+
+def dalloc(n):
+    p = C.c_void_p()
+    check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+    return p.value
+
+
+# ---- the two lists as text ----------------------------------------------------------------------
+t0 = time.time()
+d_keys = dalloc(2 * N * 8)
+check(lib.tbk_synth_keys_device(dev, 0x5EED0001, 0, 2 * N, k, C.c_void_p(d_keys)))
+lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+paths = []
+for which in range(2):
+    path = os.path.join(tmp, "hap%s.txt" % "AB"[which])
+    paths.append(path)
+    with open(path, "wb") as fh:
+        step = 10_000_000
+        for lo in range(0, N, step):
+            n = min(step, N - lo)
+            keys = np.empty(n, dtype=np.uint64)
+            check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data, C.c_void_p(d_keys + (which * N + lo) * 8), n * 8))
+            out = np.empty((n, k + 1), dtype=np.uint8)
+            for i in range(k):
+                out[:, i] = lut[((keys >> np.uint64(2 * i)) & np.uint64(3)).astype(np.intp)]
+            out[:, k] = 10
+            out.tofile(fh)
+check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
+res["lists_GB"] = round(sum(os.path.getsize(p) for p in paths) / 1e9, 2)
+
+# ---- the reads as FASTQ ----------------------------------------------------------------------------
+fq = os.path.join(tmp, "reads.fastq")
+chunk = 20_000
+d_b, d_o = dalloc(chunk * L + 64), dalloc((chunk + 1) * 8)
+qual = np.full(L, ord("I"), dtype=np.uint8)
+with open(fq, "wb") as fh:
+    for first in range(0, R, chunk):
+        n = min(chunk, R - first)
+        check(lib.tbk_synth_reads_device(dev, 0x5EED0002, first, n, L, 0x5EED0001, N, N, k, 30, 3, C.c_void_p(d_b), C.c_void_p(d_o)))
+        bases = np.empty((n, L), dtype=np.uint8)
+        check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_b), n * L))
+        names = [b"@read%09d c\n" % (first + i) for i in range(n)]  # fixed-width names: one record layout for the whole chunk
+        w = len(names[0])
+        rec = np.empty((n, w + L + 3 + L + 1), dtype=np.uint8)
+        rec[:, :w] = np.frombuffer(b"".join(names), dtype=np.uint8).reshape(n, w)
+        rec[:, w:w + L] = bases
+        rec[:, w + L:w + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        rec[:, w + L + 3:w + 2 * L + 3] = qual
+        rec[:, -1] = 10
+        rec.tofile(fh)
+check(lib.tbk_device_free(dev, C.c_void_p(d_b)))
+check(lib.tbk_device_free(dev, C.c_void_p(d_o)))
+res["fastq_GB"] = round(os.path.getsize(fq) / 1e9, 2)
+res["gbases"] = R * L / 1e9
+res["inputs_written_s"] = round(time.time() - t0, 1)
+
+# ---- list loading alone, three ways (in this process) ----------------------------------------------
+for label, env in (("gpu_parser", {"TBK_LIST_CACHE": "0"}), ("host_parser", {"TBK_LIST_CACHE": "0", "TBK_LIST_GPU_PARSE": "0"}),
+                   ("gpu_parser_writing_the_cache", {"TBK_LIST_CACHE": "1"}), ("key_cache", {})):
+    for key in ("TBK_LIST_CACHE", "TBK_LIST_GPU_PARSE"):
+        os.environ.pop(key, None)
+    os.environ.update(env)
+    t = time.perf_counter()
+    ha, hb = kmers.HashSet.from_file(paths[0], dev), kmers.HashSet.from_file(paths[1], dev)
+    t_lists = time.perf_counter() - t
+    origin = ha.origin
+    t = time.perf_counter()
+    with kmers.Classifier(ha, hb):
+        check(lib.tbk_device_sync(dev))
+    t_table = time.perf_counter() - t
+    res.setdefault("lists", {})[label] = {"origin": origin, "both_lists_s": round(t_lists, 3), "Mlines_per_s": round(2 * N / t_lists / 1e6, 1),
+                                           "paired_table_build_s": round(t_table, 3)}
+    ha.close(); hb.close()
+for key in ("TBK_LIST_CACHE", "TBK_LIST_GPU_PARSE"):
+    os.environ.pop(key, None)
+
+# ---- the command line ---------------------------------------------------------------------------------
+env = dict(os.environ, PYTHONPATH=ROOT, TBK_STATS="1")
+for mode in a.modes.split(","):
+    for cache in ("text_lists", "cached_lists"):
+        e = dict(env, TBK_LIST_CACHE="0") if cache == "text_lists" else dict(env)
+        out = os.path.join(tmp, mode + "_" + cache)
+        os.makedirs(out)
+        tsv = os.path.join(out, "stdout.tsv")
+        t = time.time()
+        with open(tsv, "wb") as so:
+            p = subprocess.run([sys.executable, "-m", "trio_binning_amd.classify_by_kmers", fq, paths[0], paths[1],
+                                "--haplotype-a-out-prefix", os.path.join(out, "hapA"), "--haplotype-b-out-prefix", os.path.join(out, "hapB"),
+                                "--unclassified-out-prefix", os.path.join(out, "unc")] + (["--no-gzip-output"] if mode == "plain" else []),
+                               env=e, stdout=so, stderr=subprocess.PIPE)
+        dt = time.time() - t
+        if p.returncode != 0:
+            res[mode + "_" + cache] = {"failed": p.stderr.decode()[-1500:]}
+            continue
+        st = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-stats ")]
+        stages = json.loads(st[-1][10:]) if st else {}
+        bins = {}
+        with open(tsv, "rb") as fh:
+            for line in fh:
+                b = line.split(b"\t")[1].decode()
+                bins[b] = bins.get(b, 0) + 1
+        res[mode + "_" + cache] = {
+            "wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
+            "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None,
+            "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins,
+            "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
+        shutil.rmtree(out, ignore_errors=True)
+if not a.keep:
+    shutil.rmtree(tmp, ignore_errors=True)
+print(json.dumps(res))

@@ -110,6 +110,7 @@ _sig("tbk_kernel_timing_enable", C.c_int, _vp, C.c_int)
 _sig("tbk_kernel_timing_read", C.c_int, _vp, _u64p, _dp)
 if hasattr(lib, "tbk_kernel_timing_read2"):  # (variant builds of tools/build_variant.sh may predate it)
     _sig("tbk_kernel_timing_read2", C.c_int, _vp, _u64p, _dp, _dp)
+    _sig("tbk_classifier_last_passes", C.c_int, _vp, _u64p, _u64p)
 if hasattr(lib, "tbk_pipeline_create"):
     _sig("tbk_device_identity", C.c_int, C.c_int, C.c_char_p, C.c_size_t)
     _sig("tbk_pipeline_create", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(_vp))
@@ -122,6 +123,8 @@ if hasattr(lib, "tbk_pipeline_create"):
     _sig("tbk_pipeline_wait", C.c_int, _vp, _u64, C.POINTER(C.c_int))
     _sig("tbk_pipeline_batches", C.c_int, _vp, _u64p, C.c_int)
     _sig("tbk_classify_file", C.c_int, _vp, C.c_char_p, _u64, _u64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _u64, _u64, _vp)
+    _sig("tbk_table_origin", C.c_int, _vp)
+    _sig("tbk_table_keys", C.c_int, _vp, _vp, _u64)
     _sig("tbk_fastx_set_packing", C.c_int, _vp, C.c_int)
     _sig("tbk_fastx_batch_packed", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u64p)
 _sig("tbk_score_and_bin", C.c_int, _vp, _u64, _u64, _u64, _vp, _vp, _vp)

@@ -35,7 +35,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, uint64_t, int, hipEvent_t, hipStream_t);
-extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, hipStream_t);
+extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
@@ -124,6 +124,7 @@ struct tbk_table {
     int device = 0;
     int k = 0;
     uint64_t num_lines = 0;  // what the reference calls num_kmers (c/kmers.c:37)
+    int origin = 0;          // how the keys got here: 0 caller's keys / general host parser, 1 GPU parser, 2 binary key cache
     uint64_t *d_keys = nullptr;
     // lazily built standalone table
     uint64_t *d_slots = nullptr;
@@ -145,6 +146,7 @@ struct Slot {
     // packed transfer format (tbk_pack.cpp): code words, dense masks, exceptions; pinned staging for
     // batches packed at submit time
     uint32_t *d_codes = nullptr; uint16_t *d_bad = nullptr; size_t cap_chunks = 0;
+    bool bad_clean = false;  // d_bad is all zero (it is between batches: a batch's exceptions are taken out again behind its probe)
     uint32_t *d_exc_chunk = nullptr; uint16_t *d_exc_mask = nullptr; size_t cap_exc = 0;
     uint32_t *h_codes = nullptr; size_t hcap_chunks = 0;
     uint32_t *h_exc_chunk = nullptr; uint16_t *h_exc_mask = nullptr; size_t hcap_exc = 0;
@@ -182,6 +184,7 @@ struct tbk_classifier {
     // buffer serves them all)
     uint32_t *d_pass_read = nullptr;
     uint64_t cap_passes = 0;
+    uint64_t last_passes = 0;  // passes of the most recent probe (tbk_classifier_last_passes)
     // kernel timing: per probe launch three events - before the pass-index kernel, between the multi-read and
     // the single-read probe kernel, after the latter
     bool timing = false;
@@ -515,15 +518,236 @@ extern "C" int tbk_list_parse_file(const char *path, uint64_t **keys_out, uint64
 }
 extern "C" void tbk_list_free(uint64_t *keys) { free(keys); }
 
+// ---- lists from files: the GPU parses regular lists; a binary key cache skips the text ------------------
+extern "C" hipError_t tbk_launch_parse_lines(const uint8_t *, uint64_t, int, int, uint64_t *, int *, hipStream_t);
+
+// pread of [off, off + n) of a file into `dst` over several host threads (the copy out of the page cache is
+// what reading a cached file costs; one thread moves ~5-10 GB/s, PCIe wants 50)
+static bool par_pread(int fd, uint8_t *dst, size_t n, size_t off, uint64_t *sum64 = nullptr) {
+    const size_t piece = (size_t)8 << 20;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)tbk_host_threads(), n / piece));
+    std::atomic<bool> ok{true};
+    std::vector<uint64_t> sums((size_t)nt, 0);
+    auto work = [&](int t) {
+        size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+        if (sum64) { lo &= ~(size_t)7; hi = t + 1 == nt ? n : (hi & ~(size_t)7); }  // whole 8-byte words per thread
+        size_t at = lo;
+        while (at < hi) {
+            const ssize_t got = ::pread(fd, dst + at, hi - at, (off_t)(off + at));
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) { ok.store(false); return; }
+            at += (size_t)got;
+        }
+        if (sum64) {
+            uint64_t acc = 0;
+            const uint64_t *w = (const uint64_t *)(dst + lo);
+            for (size_t i = 0; i < (hi - lo) / 8; i++) acc += w[i];
+            sums[(size_t)t] = acc;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work, t);
+    work(0);
+    for (std::thread &th : pool) th.join();
+    if (sum64) for (uint64_t v : sums) *sum64 += v;
+    return ok.load();
+}
+
+// Two pinned staging buffers and two events: piece p is read from the file into buffer p & 1 while piece
+// p - 1 crosses PCIe.  `consume(slot, staged bytes, piece offset, piece bytes)` enqueues the piece's copy
+// (and kernel) on `stream`.
+template <class F>
+static int staged_file_upload(int fd, size_t file_off, size_t bytes, size_t piece_bytes, hipStream_t stream, uint64_t *sum64, F consume) {
+    uint8_t *h[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = TBK_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc((void **)&h[i], piece_bytes, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "list staging: %s", hipGetErrorString(e));
+    size_t p = 0;
+    for (size_t off = 0; off < bytes && !rc; off += piece_bytes, p++) {
+        const int slot = (int)(p & 1);
+        const size_t n = std::min(piece_bytes, bytes - off);
+        if (p >= 2) {
+            e = hipEventSynchronize(ev[slot]);  // the copy that last read this buffer is done
+            if (e != hipSuccess) { rc = fail(TBK_ERR_HIP, "list staging: %s", hipGetErrorString(e)); break; }
+        }
+        if (!par_pread(fd, h[slot], n, file_off + off, sum64)) { rc = fail(TBK_ERR_IO, "reading the list: %s", strerror(errno)); break; }
+        rc = consume(h[slot], off, n, slot);
+        if (!rc) {
+            e = hipEventRecord(ev[slot], stream);
+            if (e != hipSuccess) rc = fail(TBK_ERR_HIP, "list staging: %s", hipGetErrorString(e));
+        }
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess && !rc) rc = fail(TBK_ERR_HIP, "list upload failed");
+    for (int i = 0; i < 2; i++) {
+        if (h[i]) (void)hipHostFree(h[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    return rc;
+}
+
+// The binary key cache of a list, `<list>.tbk`: what parsing the text produces, kept so that the next run
+// skips the text.  Valid only for the very file it was made from (size and modification time).
+struct ListCacheHeader {
+    char magic[8];         // "TBKLIST1"
+    uint32_t k, reserved;
+    uint64_t n_lines;      // = num_kmers of the reference (c/kmers.c:124-146), duplicates and all
+    uint64_t src_size;
+    int64_t src_mtime_ns;
+    uint64_t key_sum;      // wrapping sum of the keys
+};
+
+static std::string cache_path_of(const char *path) { return std::string(path) + ".tbk"; }
+
+static int64_t mtime_ns_of(const struct stat &st) { return (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec; }
+
+// 1 = table made from the cache, 0 = no usable cache (never an error: a stale or damaged cache is ignored)
+static int table_from_cache(const char *path, const struct stat &src, int device, tbk_table **out) {
+    const char *env = getenv("TBK_LIST_CACHE");
+    if (env && *env == '0') return 0;
+    const std::string cp = cache_path_of(path);
+    const int fd = ::open(cp.c_str(), O_RDONLY);
+    if (fd < 0) return 0;
+    ListCacheHeader hd;
+    struct stat cst;
+    bool good = ::pread(fd, &hd, sizeof hd, 0) == (ssize_t)sizeof hd && memcmp(hd.magic, "TBKLIST1", 8) == 0 && fstat(fd, &cst) == 0 &&
+                hd.k >= 1 && hd.k <= 32 && hd.n_lines > 0 && (uint64_t)cst.st_size == sizeof hd + hd.n_lines * 8 &&
+                hd.src_size == (uint64_t)src.st_size && hd.src_mtime_ns == mtime_ns_of(src);
+    if (!good || use_device(device) != TBK_OK) { ::close(fd); return 0; }
+    tbk_table *t = new tbk_table();
+    t->device = device; t->k = (int)hd.k; t->num_lines = hd.n_lines; t->origin = 2;
+    uint64_t sum = 0;
+    int rc = TBK_OK;
+    if (hipMalloc((void **)&t->d_keys, hd.n_lines * 8) != hipSuccess) { (void)hipGetLastError(); rc = TBK_ERR_NOMEM; }
+    if (!rc) {
+        uint64_t *d_keys = t->d_keys;
+        rc = staged_file_upload(fd, sizeof hd, (size_t)hd.n_lines * 8, (size_t)128 << 20, nullptr, &sum, [&](uint8_t *staged, size_t off, size_t n, int) -> int {
+            HIP_TRY(hipMemcpyAsync((uint8_t *)d_keys + off, staged, n, hipMemcpyHostToDevice, nullptr));
+            return TBK_OK;
+        });
+    }
+    ::close(fd);
+    if (rc || sum != hd.key_sum) {  // damaged: parse the text instead
+        if (t->d_keys) (void)hipFree(t->d_keys);
+        delete t;
+        return 0;
+    }
+    *out = t;
+    return 1;
+}
+
+static void write_list_cache(const char *path, const struct stat &src, const tbk_table *t) {
+    const char *env = getenv("TBK_LIST_CACHE");
+    if (!env || *env != '1') return;  // opt-in: a cache is as big as a third of its list
+    std::vector<uint64_t> keys((size_t)t->num_lines);
+    if (hipMemcpy(keys.data(), t->d_keys, keys.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    ListCacheHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "TBKLIST1", 8);
+    hd.k = (uint32_t)t->k; hd.n_lines = t->num_lines; hd.src_size = (uint64_t)src.st_size; hd.src_mtime_ns = mtime_ns_of(src);
+    for (uint64_t v : keys) hd.key_sum += v;
+    const std::string cp = cache_path_of(path), tmp = cp + ".tmp." + std::to_string((long)getpid());
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return;  // a directory we may not write to: no cache, no complaint
+    bool ok = ::write(fd, &hd, sizeof hd) == (ssize_t)sizeof hd;
+    const char *p = (const char *)keys.data();
+    size_t left = keys.size() * 8;
+    while (ok && left) {
+        const ssize_t w = ::write(fd, p, std::min(left, (size_t)1 << 30));
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { ok = false; break; }
+        p += w; left -= (size_t)w;
+    }
+    ok = ::close(fd) == 0 && ok;
+    if (!ok || ::rename(tmp.c_str(), cp.c_str()) != 0) (void)::unlink(tmp.c_str());
+}
+
+// 1 = table made by the GPU parser, 0 = the file is not a regular list (the general parser's), < 0 = error
+static int table_from_regular_text(const char *path, const struct stat &st, int device, tbk_table **out) {
+    const char *env = getenv("TBK_LIST_GPU_PARSE");
+    if (env && *env == '0') return 0;
+    const size_t size = (size_t)st.st_size;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return 0;
+    char head[40];
+    const ssize_t got = ::pread(fd, head, sizeof head, 0);
+    const char *nl = got > 0 ? (const char *)memchr(head, '\n', (size_t)got) : nullptr;
+    const long k = nl ? (long)(nl - head) : -1;
+    const size_t stride = (size_t)k + 1;
+    const bool closed_end = k >= 1 && size % stride == 0, open_end = k >= 1 && !closed_end && (size + 1) % stride == 0;
+    if (k < 1 || k > 32 || !(closed_end || open_end) || use_device(device) != TBK_OK) { ::close(fd); return 0; }
+    const uint64_t n = (size + 1) / stride;
+    tbk_table *t = new tbk_table();
+    t->device = device; t->k = (int)k; t->num_lines = n; t->origin = 1;
+    const size_t piece_lines = std::max<size_t>(1, ((size_t)128 << 20) / stride), piece_bytes = piece_lines * stride;
+    uint8_t *d_text[2] = {nullptr, nullptr};
+    int *d_irregular = nullptr, irregular = 0;
+    hipError_t e = hipMalloc((void **)&t->d_keys, n * 8);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipMalloc((void **)&d_text[i], piece_bytes + 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_irregular, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d_irregular, 0, sizeof(int));
+    int rc = e == hipSuccess ? TBK_OK : fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "list buffers: %s", hipGetErrorString(e));
+    if (!rc) {
+        uint64_t *d_keys = t->d_keys;
+        rc = staged_file_upload(fd, 0, size, piece_bytes, nullptr, nullptr, [&](uint8_t *staged, size_t off, size_t nb, int slot) -> int {
+            // the copy into d_text[slot] waits for the kernel that last read it: same stream, in order
+            HIP_TRY(hipMemcpyAsync(d_text[slot], staged, nb, hipMemcpyHostToDevice, nullptr));
+            const uint64_t first = off / stride, lines = (nb + 1) / stride;
+            HIP_TRY(tbk_launch_parse_lines(d_text[slot], lines, (int)k, open_end && off + nb == size, d_keys + first, d_irregular, nullptr));
+            return TBK_OK;
+        });
+    }
+    if (!rc && hipMemcpy(&irregular, d_irregular, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(TBK_ERR_HIP, "list parse: reading the flag failed");
+    ::close(fd);
+    for (int i = 0; i < 2; i++) if (d_text[i]) (void)hipFree(d_text[i]);
+    if (d_irregular) (void)hipFree(d_irregular);
+    if (rc || irregular) {
+        if (t->d_keys) (void)hipFree(t->d_keys);
+        delete t;
+        return rc ? rc : 0;
+    }
+    *out = t;
+    return 1;
+}
+
+// Replaces create_kmer_hash_set's file handling (c/kmers.c:185-229).  In order: the binary key cache of this
+// very file (`<list>.tbk`, used when it matches the list's size and modification time; written after a parse
+// when TBK_LIST_CACHE=1); the GPU parser for lists of the regular shape (every line k bytes + newline); the
+// general host parser, which implements the reference's getline rules for everything else.  All three give
+// the same keys (tests/test_gpu_lists.py).
 extern "C" int tbk_table_create_from_file(const char *path, int device, tbk_table **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!path) return fail(TBK_ERR_INVALID, "path is NULL");
+    struct stat st;
+    if (::stat(path, &st) != 0) return fail(TBK_ERR_IO, "cannot open %s: %s", path, strerror(errno));
+    if (S_ISREG(st.st_mode) && st.st_size > 0) {
+        if (table_from_cache(path, st, device, out) == 1) return TBK_OK;
+        const int got = table_from_regular_text(path, st, device, out);
+        if (got < 0) return got;
+        if (got == 1) { write_list_cache(path, st, *out); return TBK_OK; }
+    }
     std::vector<uint64_t> keys;
     int k = 0;
     int rc = parse_list(path, keys, k);
     if (rc) return rc;
-    return tbk_table_create_from_keys(keys.data(), keys.size(), k, device, out);
+    rc = tbk_table_create_from_keys(keys.data(), keys.size(), k, device, out);
+    if (!rc && S_ISREG(st.st_mode)) write_list_cache(path, st, *out);
+    return rc;
+}
+
+// the packed keys of a table, copied to the host (tests; tools)
+extern "C" int tbk_table_keys(const tbk_table *t, uint64_t *keys, uint64_t capacity) {
+    if (!t || (!keys && capacity)) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (capacity < t->num_lines) return fail(TBK_ERR_INVALID, "capacity %llu below the table's %llu keys", (unsigned long long)capacity, (unsigned long long)t->num_lines);
+    int rc = use_device(t->device);
+    if (rc) return rc;
+    if (t->num_lines) HIP_TRY(hipMemcpy(keys, t->d_keys, t->num_lines * 8, hipMemcpyDeviceToHost));
+    return TBK_OK;
 }
 
 static void drop_cached_classifier(const tbk_table *t);
@@ -541,6 +765,7 @@ extern "C" void tbk_table_destroy(tbk_table *t) {
 extern "C" uint64_t tbk_table_num_kmers(const tbk_table *t) { return t ? t->num_lines : 0; }
 extern "C" int tbk_table_k(const tbk_table *t) { return t ? t->k : 0; }
 extern "C" int tbk_table_device(const tbk_table *t) { return t ? t->device : -1; }
+extern "C" int tbk_table_origin(const tbk_table *t) { return t ? t->origin : -1; }
 extern "C" uint64_t tbk_table_bytes(const tbk_table *t) {
     return t ? t->num_lines * sizeof(uint64_t) + (t->hashed ? (uint64_t)t->n_buckets * TBK_BUCKET_BYTES : 0) : 0;
 }
@@ -909,6 +1134,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
     }
     HIP_TRY(tbk_launch_probe(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes, c->max_blocks,
                              em, c->compute));
+    c->last_passes = passes;
     if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
     return TBK_OK;
 }
@@ -990,8 +1216,9 @@ static int slot_reserve_packed(Slot &s, uint64_t n_chunks, uint64_t n_exc) {
         s.d_codes = nullptr; s.d_bad = nullptr; s.cap_chunks = 0;
         const size_t cap = std::max((size_t)n_chunks + (size_t)n_chunks / 8, (size_t)1 << 16);
         HIP_TRY(hipMalloc((void **)&s.d_codes, cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void **)&s.d_bad, cap * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_bad, (cap + 2) * sizeof(uint16_t)));
         s.cap_chunks = cap;
+        s.bad_clean = false;
     }
     if (n_exc > s.cap_exc) {
         if (s.d_exc_chunk) HIP_TRY(hipFree(s.d_exc_chunk));
@@ -1096,13 +1323,14 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         // side stream: H2D of this batch overlaps the previous batch's kernel
         if (packed) {
             HIP_TRY(hipMemcpyAsync(s.d_codes, codes, n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
-            HIP_TRY(hipMemsetAsync(s.d_bad, 0, n_chunks * sizeof(uint16_t), c->copy));
+            if (!s.bad_clean) HIP_TRY(hipMemsetAsync(s.d_bad, 0, (s.cap_chunks + 2) * sizeof(uint16_t), c->copy));  // a new buffer, or a batch that failed half-way
+            s.bad_clean = false;
             if (n_exc) {
                 HIP_TRY(hipMemcpyAsync(s.d_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
                 HIP_TRY(hipMemcpyAsync(s.d_exc_mask, exc_mask, n_exc * sizeof(uint16_t), hipMemcpyHostToDevice, c->copy));
             }
             // exceptions into the dense masks; the tail of the last partial chunk is masked here too
-            HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, c->copy));
+            HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 0, c->copy));
         } else {
             const uint8_t *src_b = bases;
             if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
@@ -1114,6 +1342,11 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? s.d_codes : nullptr,
                                 packed ? s.d_bad : nullptr);
         if (rc) return rc;
+        if (packed) {
+            // behind the probe: the batch's exceptions out of the dense masks again, which are all zero between batches
+            HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 1, c->compute));
+            s.bad_clean = true;
+        }
         HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
                                hipMemcpyDeviceToHost, c->compute));
     } else if (n_reads) {
@@ -1164,6 +1397,18 @@ extern "C" int tbk_stream_wait(tbk_classifier *c, uint64_t ticket) {
     if (s.counts_staged && s.n_reads) memcpy(s.user_counts, s.h_counts, s.n_reads * 2 * sizeof(int32_t));
     s.busy = false;
     return TBK_OK;
+}
+
+// 1: that ticket's batch is complete (tbk_stream_wait will not block), 0: not yet; < -1: an error
+extern "C" int tbk_stream_query(tbk_classifier *c, uint64_t ticket) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL") - 10;
+    Slot &s = c->ring[ticket % RING];
+    if (!s.busy || s.ticket != ticket) return fail(TBK_ERR_STATE, "ticket %llu is not in flight", (unsigned long long)ticket) - 10;
+    if (use_device(c->device)) return TBK_ERR_HIP - 10;
+    const hipError_t e = hipEventQuery(s.done);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();
+    return e == hipErrorNotReady ? 0 : TBK_ERR_HIP - 10;
 }
 
 extern "C" int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
@@ -1263,6 +1508,21 @@ extern "C" int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, do
     *total_ms = c->timed_ms;
     if (single_ms) *single_ms = c->timed_single_ms;
     c->timed_launches = 0; c->timed_ms = 0.0; c->timed_single_ms = 0.0;
+    return TBK_OK;
+}
+
+// the most recent probe's passes (2048 window starts each) and how many of them touched more than one read
+// (the multi-read kernel's share; the rest is the single-read kernel's)
+extern "C" int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes, uint64_t *n_multi) {
+    if (!c || !n_passes || !n_multi) return fail(TBK_ERR_INVALID, "NULL argument");
+    *n_passes = c->last_passes; *n_multi = 0;
+    if (!c->last_passes || !c->d_pass_read) return TBK_OK;
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->compute));
+    uint32_t m = 0;
+    HIP_TRY(hipMemcpy(&m, c->d_pass_read + 2 * c->cap_passes, sizeof m, hipMemcpyDeviceToHost));
+    *n_multi = m;
     return TBK_OK;
 }
 

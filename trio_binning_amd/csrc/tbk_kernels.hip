@@ -1145,29 +1145,34 @@ extern "C" hipError_t tbk_launch_contains(TbkTableView t, const uint64_t *d_keys
     return hipGetLastError();
 }
 
-// Scatter the packed format's exceptions into the dense per-chunk mask array (zeroed by the caller).
-// Masks are OR-ed in 32-bit words (two chunks per word), so an index listed twice is harmless, and the
-// positions at or past `total` in the last, partial chunk are marked here whether or not the caller's
-// packer listed them: the probe kernel relies on that mask (load_packed_chunk).
+// Scatter the packed format's exceptions into the dense per-chunk mask array, which is all zero between
+// batches: `clear` = 0 ORs the masks in before the probe, `clear` = 1 takes the same entries out again
+// after it - a batch touches a handful of entries, and zeroing the whole array (an eighth of the batch's
+// bases in bytes) on the copy stream cost more than the batch's H2D copy.  Masks are OR-ed in 32-bit words
+// (two chunks per word), so an index listed twice is harmless, and the positions at or past `total` in the
+// last, partial chunk are marked here whether or not the caller's packer listed them: the probe kernel
+// relies on that mask (load_packed_chunk).
 __global__ void __launch_bounds__(256)
 tbk_scatter_bad_kernel(const uint32_t *__restrict__ exc_chunk, const uint16_t *__restrict__ exc_mask, uint64_t n,
-                       uint16_t *__restrict__ bad16, uint64_t total) {
+                       uint16_t *__restrict__ bad16, uint64_t total, int clear) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t *words = reinterpret_cast<uint32_t *>(bad16);  // hipMalloc'ed: 4-byte aligned, capacity even
     if (i < n) {
         const uint32_t c = exc_chunk[i];
-        atomicOr(&words[c >> 1], (uint32_t)exc_mask[i] << (16 * (c & 1u)));
+        if (clear) atomicAnd(&words[c >> 1], ~(0xFFFFu << (16 * (c & 1u))));
+        else atomicOr(&words[c >> 1], (uint32_t)exc_mask[i] << (16 * (c & 1u)));
     }
     if (i == 0 && (total & 15u) != 0) {
         const uint64_t c = total >> 4;
-        atomicOr(&words[c >> 1], ((0xFFFFu << (total & 15u)) & 0xFFFFu) << (16 * (c & 1u)));
+        if (clear) atomicAnd(&words[c >> 1], ~(0xFFFFu << (16 * (c & 1u))));
+        else atomicOr(&words[c >> 1], ((0xFFFFu << (total & 15u)) & 0xFFFFu) << (16 * (c & 1u)));
     }
 }
 
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *d_exc_chunk, const uint16_t *d_exc_mask, uint64_t n, uint16_t *d_bad16,
-                                             uint64_t total, hipStream_t stream) {
+                                             uint64_t total, int clear, hipStream_t stream) {
     if (n == 0 && (total & 15u) == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_scatter_bad_kernel, dim3((unsigned)((std::max<uint64_t>(n, 1) + 255) / 256)), dim3(256), 0, stream, d_exc_chunk, d_exc_mask, n, d_bad16, total);
+    hipLaunchKernelGGL(tbk_scatter_bad_kernel, dim3((unsigned)((std::max<uint64_t>(n, 1) + 255) / 256)), dim3(256), 0, stream, d_exc_chunk, d_exc_mask, n, d_bad16, total, clear);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 // tests the dealing).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -61,6 +62,8 @@ struct Ring {
         return tbk_stream_submit(c, j->bases, j->offsets, j->n_reads, j->counts, tk);
     }
     int wait(uint64_t tk) const { return c ? tbk_stream_wait(c, tk) : t_wait(user, slot, tk); }
+    // 1: that batch is complete (wait will not block), 0: not yet, -1: cannot tell without waiting (test rings)
+    int done(uint64_t tk) const { return c ? tbk_stream_query(c, tk) : -1; }
 };
 
 struct tbk_pipeline {
@@ -99,20 +102,35 @@ static void feeder_loop(tbk_pipeline *p, int slot) {
     };
     for (;;) {
         Job *job = nullptr;
+        bool collect = false;  // take the oldest batch in flight off the ring
         {
             std::unique_lock<std::mutex> lk(p->mu);
-            if ((int)flying.size() < ring) {
-                // room in the ring: take the next batch; with batches in flight and none waiting, go and
-                // collect the oldest instead of sleeping on the queue
-                if (flying.empty()) p->cv_work.wait(lk, [&] { return p->stop || !p->queue.empty(); });
-                if (!p->queue.empty()) {
-                    job = p->queue.front();
-                    p->queue.pop_front();
-                    job->device_slot = slot;
-                    p->batches_by_slot[(size_t)slot]++;
-                } else if (p->stop && flying.empty()) {
-                    return;
+            if ((int)flying.size() >= ring) {
+                collect = true;  // the ring is full: nothing to do but wait for its oldest batch
+            } else if (flying.empty()) {
+                p->cv_work.wait(lk, [&] { return p->stop || !p->queue.empty(); });
+                if (p->queue.empty()) return;  // stop, nothing queued, nothing in flight
+            } else {
+                // Batches in flight and room in the ring: whichever comes first - a new batch to submit (its copy
+                // must start NOW, beside the kernel that is running, not when that kernel ends) or the oldest
+                // batch completing.  The device is polled, the queue is waited on in short naps.
+                int idle_naps = 0;
+                while (p->queue.empty() && !p->stop) {
+                    lk.unlock();  // (the query is a runtime call: not under the queue's lock)
+                    const int d = rg.done(flying.front().first);
+                    lk.lock();
+                    if (d == 1 || d < -1 || (d == -1 && idle_naps >= 20)) { collect = true; break; }
+                    if (!p->queue.empty() || p->stop) break;
+                    p->cv_work.wait_for(lk, std::chrono::microseconds(100));
+                    idle_naps++;
                 }
+                if (p->queue.empty() && p->stop) collect = true;
+            }
+            if (!collect && !p->queue.empty()) {
+                job = p->queue.front();
+                p->queue.pop_front();
+                job->device_slot = slot;
+                p->batches_by_slot[(size_t)slot]++;
             }
         }
         if (!job) {

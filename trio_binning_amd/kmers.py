@@ -112,6 +112,17 @@ class HashSet:
     def contents(self) -> _Contents:
         return _Contents(self)
 
+    @property
+    def origin(self) -> str:
+        """Where the keys came from: "keys" (the caller's, or the general host parser), "gpu-parser", "cache"."""
+        return {0: "keys", 1: "gpu-parser", 2: "cache"}.get(lib.tbk_table_origin(self._h), "?")
+
+    def keys(self) -> np.ndarray:
+        """The packed keys, one per list line, copied to the host."""
+        out = np.empty(self.num_kmers, dtype=np.uint64)
+        check(lib.tbk_table_keys(self._h, out.ctypes.data, out.size))
+        return out
+
     def contains(self, keys) -> np.ndarray:
         """Membership of raw packed keys (no canonicalisation)."""
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -390,6 +401,13 @@ class Classifier:
         n, ms, single = C.c_uint64(), C.c_double(), C.c_double()
         check(lib.tbk_kernel_timing_read2(self._h, C.byref(n), C.byref(ms), C.byref(single)))
         return n.value, ms.value, single.value
+
+    def last_passes(self) -> Tuple[int, int]:
+        """(passes, multi-read passes) of the most recent probe: 2048 window starts each; the multi-read ones
+        went through the multi-read kernel, the rest through the single-read kernel."""
+        n, m = C.c_uint64(), C.c_uint64()
+        check(lib.tbk_classifier_last_passes(self._h, C.byref(n), C.byref(m)))
+        return n.value, m.value
 
     def close(self) -> None:
         if self._h is not None and self._h.value:
