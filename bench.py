@@ -408,10 +408,13 @@ def main():
         fed: through the pipeline from pinned host memory; else: batches resident in HBM."""
         pending = []
         waiter = pipe.wait if fed else cls.wait
+        # host-fed: as many batches submitted as the ring holds (the third one's copy runs beside the first one's
+        # kernel); resident: one fewer is enough to keep the compute stream busy
+        ahead = depth if fed else depth - 1 + (depth == 1)
         for i in range(n_steps * launches_per_step):
             d_b, d_o, n_r, tot, packed = batches[i % len(batches)]
             slot = i % depth
-            if len(pending) == depth - 1 + (depth == 1):
+            if len(pending) == ahead:
                 finish(waiter, *pending.pop(0), tally)
             if fed:
                 t = pipe.submit_packed(packed, counts_ring[slot][:n_r])

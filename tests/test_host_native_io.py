@@ -338,6 +338,45 @@ def test_writer_empty_bins_are_valid_files(built, tmp_path):
     assert all(os.path.getsize(n) == 0 for n in w.names)
 
 
+def test_long_records_go_straight_to_the_files(built, tmp_path):
+    """Plain output of long records is gathered from the batch's arrays straight into the files (pwritev from
+    several threads, no bin buffer): same bytes as the Python mirror's writer, over several batches, FASTQ and
+    FASTA records mixed, a record without a name among them."""
+    from trio_binning_amd import seq
+
+    rng = random.Random(21)
+    nrng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    recs = []
+    for i in range(90):
+        n = rng.randrange(6000, 30000)
+        s = acgt[nrng.integers(0, 4, n)].tobytes().decode()
+        q = None if i % 7 == 3 else "".join(chr(33 + int(x)) for x in nrng.integers(0, 60, n))
+        recs.append(seq.Read("" if i == 11 else f"long{i}/x", s, q))
+    src = tmp_path / "in.fq"
+    with open(src, "w") as fh:
+        for r in recs:
+            r.print(file=fh)
+    bins_all = "".join(rng.choice("ABU") for _ in recs)
+    outs = seq.open_outfiles(str(tmp_path / "pa"), str(tmp_path / "pb"), str(tmp_path / "pu"), ".fq", False)
+    parsed = list(seq.open_fastx_read(str(src)))
+    for r, b in zip(parsed, bins_all):
+        r.print(file=outs["ABU".index(b)])
+    for fh in outs:
+        fh.close()
+    w = seq.BinWriter(str(tmp_path / "na"), str(tmp_path / "nb"), str(tmp_path / "nu"), ".fq", False, threads=4)
+    got_n = 0
+    with seq.BatchReader(str(src)) as r:
+        b = seq.Batch()
+        while r.next_batch(b, 400_000, 0):
+            w.write(b, bins_all[got_n:got_n + b.n_reads].encode())
+            got_n += b.n_reads
+    w.close()
+    assert got_n == len(parsed)
+    for py_name, nat_name in zip(seq.output_names(str(tmp_path / "pa"), str(tmp_path / "pb"), str(tmp_path / "pu"), ".fq", False), w.names):
+        assert open(nat_name, "rb").read() == open(py_name, "rb").read()
+
+
 def test_plain_bin_streams_into_a_fifo(built, tmp_path):
     """A plain bin whose target cannot seek (a FIFO, /dev/stdout through a pipe) is written with
     sequential write(), as the reference's open(name, 'w') handle would; regular files keep pwrite."""

@@ -150,6 +150,7 @@ for mode in a.modes.split(","):
             "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins,
             "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
         shutil.rmtree(out, ignore_errors=True)
+        os.sync()  # the next run does not inherit this one's dirty pages
 if not a.keep:
     shutil.rmtree(tmp, ignore_errors=True)
 print(json.dumps(res))

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Copy the summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<round>/ and write that
+directory's README.md from the JSON lines themselves (no number is typed by hand).
+
+    python tools/profile_readme.py r03
+"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json",
+        "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
+        "reader_hifi.json", "cli_configs1.json", "cli_gz_input.json"]
+for name in KEEP:
+    p = os.path.join(src, name)
+    if os.path.isfile(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, name))
+for name in ("pmc_traffic.json", "pmc_traffic_haplotypes.json"):  # bench.py replays these (roofline.traffic)
+    p = os.path.join(src, name)
+    if os.path.isfile(p):
+        shutil.copy(p, os.path.join(ROOT, "profiles", name))
+
+
+def load(name):
+    try:
+        return json.load(open(os.path.join(dst, name)))
+    except Exception:
+        return None
+
+
+u, h = load("bench_default.json"), load("bench_haplotypes.json")
+pu, ph = load("pmc_summary_uniform.json") or {}, load("pmc_summary_haplotypes.json") or {}
+trace = load("kernel_trace_by_launch_size.json") or []
+two, tr2, strong, count = load("bench_2ranks_shared_device.json"), load("bench_2ranks_torchrun.json"), load("bench_strong.json"), load("bench_count.json")
+cli, reader = load("cli_configs1.json"), load("reader_hifi.json")
+
+
+def g(d, *path, default="-"):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return default
+        d = d[k]
+    return d
+
+
+def col(b, p):
+    if not b:
+        return ["-"] * 20
+    r, c = b["roofline"], b["config"]
+    w = r["windows_per_launch"]
+    lines = p.get("TCC_MISS_sum", 0) / w if w and p else None
+    hbm = p.get("hbm_bytes_per_launch_from_FETCH_SIZE")
+    ms = r["kernel_ms_avg"]
+    insts = lambda k: round(p[k] / w, 2) if p and k in p and w else "-"
+    return [
+        f"{b['value']} ({b['ms_per_step']} ms per {c['bases_per_step_per_rank'] / 1e9:.2f}-Gbase step)",
+        f"{g(b, 'kernel_resident', 'gbases_per_s')}",
+        f"{c['bucket_select']}, load {c['table_load']}, {c['line_layout'][:5]} layout, {c['table_bytes_per_gpu'] / 1e9:.0f} GB ({c['table_bytes_per_key']} B per key)",
+        f"{ms} ({r['launches']} launches); whole probe {r['whole_probe_ms_avg']}",
+        f"{r['alg_bytes_per_launch'] / 1e9:.1f} / {r['achieved']} / **{r['frac']}** (P = 1 reading: {r['frac_P1_merged_table_reading']})",
+        f"{hbm / 1e9:.1f} / {p.get('hbm_bytes_per_launch_from_TCC_MISS', 0) / 1e9:.1f}" if hbm else "-",
+        f"{hbm / w:.1f} / {lines:.4f}" if hbm and lines else "-",
+        f"{hbm / ms / 1e9:.2f} / {hbm / ms / 1e9 / 6.29:.2f}" if hbm else "-",
+        f"{p['TCC_MISS_sum'] / ms / 1e6:.1f} / {p['TCC_MISS_sum'] / ms / 1e6 / 47.75:.2f}" if p.get("TCC_MISS_sum") else "-",
+        f"{insts('SQ_INSTS_VALU')} / {insts('SQ_INSTS_SALU')} / {insts('SQ_INSTS_VMEM_RD')}",
+        f"{p['SQ_WAIT_ANY'] / p['SQ_WAVE_CYCLES']:.2f}" if p.get("SQ_WAVE_CYCLES") else "-",
+        f"{g(b, 'parity', 'gpu_equals_cpu')} on {g(b, 'parity', 'reads_checked_against_the_oracle')} reads; transfers agree: {g(b, 'parity', 'packed_and_ascii_transfers_agree')}",
+        f"{g(b, 'cpu_baseline', 'value', default=0) * 1e3:.2f} / {g(b, 'cpu_baseline', 'all_cores', 'value', default=0) * 1e3:.1f} / {g(b, 'cpu_baseline', 'optimised_rolling_all_cores', 'value', default=0) * 1e3:.1f}",
+        f"{g(b, 'pipeline_variants', 'ascii_in_packed_by_feeder', 'gbases_per_s')} / {g(b, 'pipeline_variants', 'ascii_over_pcie', 'gbases_per_s')}",
+    ]
+
+
+rows = ["`value`: host-fed classify stage (Gbases/s)", "`kernel_resident` (Gbases/s)", "table", "single-read probe kernel, HIP events inside the timed region (ms per launch)",
+        "its algorithmic bytes per launch (GB) / `roofline.achieved` (GB/s) / `frac`", "its HBM bytes per launch: FETCH_SIZE x 1024 x 2 / TCC_MISS x 128 B (GB)",
+        "bytes per window / 128-B lines per window", "HBM traffic rate (TB/s) / of the 6.29 TB/s stream ceiling", "random 128-B lines (G/s) / of the 47.75 G/s a pure gather reaches",
+        "VALU / SALU / VMEM-read instructions per window", "SQ_WAIT_ANY / SQ_WAVE_CYCLES", "parity in the run (GPU counts == oracle)",
+        "CPU baseline, oracle: 1 thread / 16 CPUs / rolling, 16 CPUs (Mbases/s)", "same stage fed with ASCII batches: packed by the feeder / ASCII over PCIe (Gbases/s)"]
+cu, ch = col(u, pu), col(h, ph)
+full = [t for t in trace if "tbk_probe_kernel" in t["kernel"]][:4]
+
+out = [f"# Round 3 reference profile ({rnd})", "",
+       "Made by `tools/gpu_profile.sh` on one MI355X box (ROCm 7.2), condensed by `tools/profile_summary.py`, and this file by",
+       "`tools/profile_readme.py` from the JSON lines beside it - no number here is typed by hand.  Box-to-box spread of the pool: +-4 %.", "",
+       "    python bench.py                                  -> bench_default.json (host-fed value, kernel_resident, pipeline variants, cpu_baseline, parity)",
+       "    python bench.py --lists haplotypes               -> bench_haplotypes.json (lists shaped like real find-unique-kmers output)",
+       "    python bench.py --gpus 2 --share-device          -> bench_2ranks_shared_device.json (two ranks on the one GPU: plumbing of the N > 1 line)",
+       "    python -m torch.distributed.run ... bench.py --gpus 2 --share-device   -> bench_2ranks_torchrun.json (the driver's launcher)",
+       "    python bench.py --scaling strong --strong-reads 3000000 --steps 3      -> bench_strong.json (fixed 45 Gbp set, host-fed, one rank)",
+       "    python bench.py --path count                     -> bench_count.json",
+       "    rocprofv3 --kernel-trace --stats -- python3 bench.py --no-streaming    -> kernel_stats.csv, kernel_trace_by_launch_size.json",
+       "    rocprofv3 --kernel-trace --pmc <one set per run> -- python3 bench.py [--lists haplotypes] --steps 4 --warmup 1 ...   -> pmc_summary_<lists>.json", "",
+       "Workload: bench.py defaults = k = 21, 2 x 3e8 keys, 262144 x 15 kb reads (3.932 Gbases) per step, 20 steps per timed region.", "",
+       "| | uniform lists (BASELINE) | haplotype-shaped lists |", "|---|---|---|"]
+out += [f"| {r} | {a} | {b} |" for r, a, b in zip(rows, cu, ch)]
+out += ["", "rocprofv3 `--kernel-trace` of `python3 bench.py --no-streaming`, per kernel and launch size (`kernel_stats.csv` averages over every launch of a kernel,",
+        "the two small parity launches included; the roofline's duration is that of the full-size launches):", "",
+        "| kernel | grid | launches | avg ms | min | max |", "|---|---|---|---|---|---|"]
+out += [f"| `{t['kernel']}` | {t['grid']} | {t['launches']} | {t['avg_ms']} | {t['min_ms']} | {t['max_ms']} |" for t in full]
+if two:
+    out += ["", f"Two ranks on the one device (`--share-device`; a plumbing run, not a scaling result): value {two['value']} Gbases/s, kernel_resident {g(two, 'kernel_resident', 'gbases_per_s')}, "
+            f"parity all_ranks_equal = {g(two, 'parity', 'all_ranks_equal')}, gpu_equals_cpu = {g(two, 'parity', 'gpu_equals_cpu')}, devices {json.dumps(two.get('devices'))}."]
+if tr2:
+    out += [f"Under `python -m torch.distributed.run`: value {tr2['value']}, parity all_ranks_equal = {g(tr2, 'parity', 'all_ranks_equal')}."]
+if strong:
+    out += [f"Strong scaling plumbing (one rank, 45 Gbp set in 12 host-fed batches per step): value {strong['value']} Gbases/s."]
+if count:
+    out += [f"`--path count`: {count['value']} Gbases/s counted, atomic_frac {g(count, 'roofline', 'atomic_frac')}."]
+if cli:
+    out += ["", f"End to end (`tools/measure_e2e.py`, {cli['config']}; {cli['fastq_GB']} GB of FASTQ, {cli['lists_GB']} GB of list text; page cache {cli['page_cache']}; {cli['host_usable_cpus']} usable CPUs):", "",
+            "| lists | both lists (s) | M lines/s | paired table build (s) |", "|---|---|---|---|"]
+    out += [f"| {k} | {v['both_lists_s']} | {v['Mlines_per_s']} | {v['paired_table_build_s']} |" for k, v in cli.get("lists", {}).items()]
+    out += ["", "| run | wall (s) | Gbases/s, wall | loop (s) | reader busy (s) | writer busy (s) | waiting for the GPU (s) | before the loop (s) | output (GB) |", "|---|---|---|---|---|---|---|---|---|"]
+    for k, v in cli.items():
+        if isinstance(v, dict) and "wall_s" in v:
+            st = v["stages"]
+            out += [f"| {k} | {v['wall_s']} | {v['gbases_per_s_wall']} | {st.get('loop_s')} | {st.get('read_s')} | {st.get('write_s')} | {st.get('gpu_wait_s')} | {v['before_the_loop_s']} | {v['out_GB']} |"]
+if reader:
+    out += ["", f"Reader alone (`tools/measure_reader.py --qual hifi`, {reader['text_GB']} GB of FASTQ text, GB/s of text): plain first pass {g(reader, 'plain_first_pass', 'text_GB_per_s')}, "
+            f"plain warm {g(reader, 'plain', 'text_GB_per_s')}, gzip {g(reader, 'gzip', 'text_GB_per_s')}, bgzf {g(reader, 'bgzf', 'text_GB_per_s')}."]
+out += ["", "Experiment logs of the round (same-box A/B runs; `EXPERIMENTS.md` reads them): `ab_diagnostics.log` (occupancy / cheap-bucket / no-load timing builds),",
+        "`ab_occupancy.log` (split kernels at 4 / 5 / 6 waves, both list shapes, 150 b and 1 kb reads), `ab_front_layout_4waves.log`, `ab_m15w7.log`, `counters.log`",
+        "(event counters of a `-DTBK_COUNTERS` build), `hostfed_timeline_before_fix.log` (copy / kernel timeline that exposed the serialised host-fed step).", ""]
+open(os.path.join(dst, "README.md"), "w").write("\n".join(out))
+print("\n".join(out[:40]))

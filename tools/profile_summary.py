@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a tools/gpu_profile.sh run (gpurun_out/) into the small files kept under profiles/rNN_*:
 kernel_stats.csv (rocprofv3 --stats), pmc_summary_<lists>.json (per-launch means of every PMC pass for
-the probe kernel) and pmc_traffic[_haplotypes].json (HBM bytes per window, which bench.py scales to
+the single-read probe kernel, the dominant one) and pmc_traffic[_haplotypes].json (HBM bytes per window, which bench.py scales to
 its own launch size for `roofline.traffic`).
 
 HBM bytes from the counters as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950:
@@ -18,15 +18,45 @@ import sys
 out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 
 
-def probe_means(pattern, kernel="probe_kernel"):
-    agg, meta = collections.defaultdict(list), {}
+def is_single_read_probe(name):
+    """The dominant kernel: tbk_probe_kernel<W, M64, SAMP, FRONT, MULTI = false> (passes inside one read)."""
+    return "tbk_probe_kernel" in name and name.replace(" ", "").endswith("false>(ProbeArgs)")
+
+
+def probe_means(pattern):
+    """Per-launch means over the FULL-SIZE launches of the single-read kernel: a bench run also classifies the
+    4096 parity reads (two small launches), which must not dilute a per-launch figure."""
+    rows = []
     for f in sorted(glob.glob(os.path.join(out_dir, pattern, "*", "*_counter_collection.csv"))):
-        for r in csv.DictReader(open(f)):
-            if kernel in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-                meta = {"VGPR_Count": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
-                        "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80]}
+        rows += [r for r in csv.DictReader(open(f)) if is_single_read_probe(r["Kernel_Name"])]
+    if not rows:
+        return {}, {}
+    full = max(int(r["Grid_Size"]) for r in rows)
+    agg, meta = collections.defaultdict(list), {}
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {"VGPR_Count_as_rocprofv3_reports_it": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
+                    "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80], "launches_averaged": len(agg[r["Counter_Name"]]),
+                    "VGPR_note": "the code object's .vgpr_count is 96 (tools/kernel_regs.sh): 5 waves per SIMD; rocprofv3's column is not the allocation"}
     return {k: sum(v) / len(v) for k, v in agg.items()}, meta
+
+
+def trace_summary(name, dst):
+    """rocprofv3 --kernel-trace of a bench run, per kernel and launch size: the stats CSV averages over every
+    launch of a kernel, small parity and variant batches included; the roofline's duration is that of the
+    full-size launches."""
+    hits = glob.glob(os.path.join(out_dir, name, "*", "*_kernel_trace.csv"))
+    if not hits:
+        return
+    groups = collections.defaultdict(list)
+    for r in csv.DictReader(open(hits[0])):
+        if "tbk_" in r["Kernel_Name"]:
+            groups[(r["Kernel_Name"].split("(")[0][:70], int(r["Grid_Size_X"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    out = [{"kernel": k, "grid": g, "launches": len(v), "avg_ms": round(sum(v) / len(v), 4), "min_ms": round(min(v), 4), "max_ms": round(max(v), 4)}
+           for (k, g), v in sorted(groups.items(), key=lambda kv: -sum(kv[1]))]
+    json.dump(out, open(os.path.join(out_dir, dst), "w"), indent=1)
+    print(dst, json.dumps(out[:6]))
 
 
 for lists in ("uniform", "haplotypes"):
@@ -55,7 +85,8 @@ for lists in ("uniform", "haplotypes"):
         summary["lines_per_window"] = round(summary.get("TCC_MISS_sum", 0) / windows, 4)
         cfg = bench["config"]
         traffic = {
-            "note": "HBM bytes of one tbk_probe_kernel launch, from rocprofv3 PMC passes run separately from the timed bench "
+            "kernel": "tbk_probe_kernel<single-read>",
+            "note": "HBM bytes of one launch of the single-read probe kernel (tbk_probe_kernel<..., MULTI = false>), from rocprofv3 PMC passes run separately from the timed bench "
                     "(tools/gpu_profile.sh): FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM), "
                     "cross-checked by TCC_MISS_sum x 128 B; divided by the launch's window starts so that bench.py can scale it to its own launch size.",
             "read_len": cfg["read_len"], "kmers_per_list": cfg["kmers_per_list"], "k": cfg["k"], "bucket_select": cfg["bucket_select"],
@@ -68,6 +99,7 @@ for lists in ("uniform", "haplotypes"):
     json.dump(summary, open(os.path.join(out_dir, f"pmc_summary_{lists}.json"), "w"), indent=1)
     print(lists, json.dumps(summary))
 
+trace_summary("prof_trace", "kernel_trace_by_launch_size.json")
 for name, dst in (("prof_trace", "kernel_stats.csv"), ("prof_trace_count", "count_kernel_stats.csv")):
     hits = glob.glob(os.path.join(out_dir, name, "*", "*_kernel_stats.csv"))
     if hits:

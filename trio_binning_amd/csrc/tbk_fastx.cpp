@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <immintrin.h>
 #include <zlib.h>
@@ -861,6 +862,33 @@ static bool regular_record(const uint8_t *d, size_t size, size_t at, FastqRec &r
     return true;
 }
 
+// Why the record at `at` is not a regular, complete record: true = the text at hand ends inside it (more text
+// may complete it), false = it is irregular whatever follows (the sequential machine's).
+static bool regular_record_cut_off(const uint8_t *d, size_t size, size_t at) {
+    const uint8_t *end = d + size;
+    if (at >= size) return true;
+    if (d[at] != '@') return false;
+    const uint8_t *e0 = find_eol(d + at, end);
+    if (e0 == end) return true;
+    if (*e0 != '\n') return false;
+    const uint8_t *s = e0 + 1;
+    if (s == end) return true;
+    if (*s == '@' || *s == '+' || *s == '>') return false;
+    const uint8_t *e1 = find_eol(s, end);
+    if (e1 == end) return true;
+    if (*e1 != '\n') return false;
+    const uint8_t *pl = e1 + 1;
+    if (pl >= end) return true;
+    if (*pl != '+') return false;
+    const uint8_t *e2 = find_eol(pl, end);
+    if (e2 == end) return true;
+    if (*e2 != '\n') return false;
+    const uint8_t *q = e2 + 1;
+    const size_t len = (size_t)(e1 - s), have = (size_t)(end - q);
+    if (have < len + 1) return find_eol(q, end) == end;  // a line end inside the quality that is there: irregular already
+    return false;
+}
+
 struct tbk_fastx_reader {
     LineSource src;
     RegularScan scan;
@@ -1152,8 +1180,12 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
             if (leave && src.text_eof) { sc.inflated = false; return TBK_OK; }
             continue;
         }
-        // the record at src.pos: cut off by the end of the window (read on), or not regular (the machine's)
-        if (!src.text_eof && src.end - src.pos < ((size_t)64 << 20)) { at_least = src.end - src.pos + ((size_t)8 << 20); continue; }
+        // the record at src.pos: cut off by the end of the text at hand (read on: only then is a longer window worth
+        // another scan), or not regular whatever follows (the machine's, at once)
+        if (!src.text_eof && src.end - src.pos < ((size_t)64 << 20) && regular_record_cut_off(src.buf.data(), src.end, src.pos)) {
+            at_least = src.end - src.pos + ((size_t)8 << 20);
+            continue;
+        }
         sc.inflated = false;
         return TBK_OK;
     }
@@ -1621,11 +1653,80 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         at[which] += len;
         upto[(size_t)i + 1] = upto[(size_t)i] + len;
     }
+    const uint64_t total = upto[(size_t)n];
+    // Plain output of long records into regular files: the records go from the batch's arrays straight to
+    // their places in the files (pwritev, gathered from the name / sequence / quality arrays and three constant
+    // strings), written by several threads - no copy into a bin buffer first.  What a sequence of write()
+    // calls would have produced, byte for byte.  Short records (many system calls per megabyte), gzip output
+    // and targets that cannot seek take the buffered path below.
+    if (!w->gz && n > 0 && total / n >= 4096 && w->bin[0].positional && w->bin[1].positional && w->bin[2].positional &&
+        w->bin[0].text.size() == 0 && w->bin[1].text.size() == 0 && w->bin[2].text.size() == 0) {
+        const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)8 << 20)));
+        std::atomic<int> failed_errno{0};
+        static const char at_c = '@', gt_c = '>', nl_c = '\n';
+        static const char plus_c[3] = {'\n', '+', '\n'};
+        auto put = [&](int t) {
+            auto cut = [&](int u) -> size_t {
+                if (u <= 0) return 0;
+                if (u >= nt) return (size_t)n;
+                return (size_t)(std::lower_bound(upto.begin(), upto.begin() + (ptrdiff_t)n, total * (uint64_t)u / (uint64_t)nt) - upto.begin());
+            };
+            const size_t last = cut(t + 1);
+            // a thread's records of one bin are consecutive in that bin's file: their pieces are gathered, up to
+            // ~1000 at a time, into one pwritev per bin
+            constexpr int CAP = 1008;
+            std::vector<struct iovec> iov[3];
+            uint64_t start[3] = {0, 0, 0};
+            for (int k = 0; k < 3; k++) iov[k].reserve(CAP + 8);
+            auto flush = [&](int which) {
+                struct iovec *v = iov[which].data();
+                int c = (int)iov[which].size();
+                uint64_t off = start[which];
+                while (c > 0 && !failed_errno.load()) {
+                    const ssize_t k = ::pwritev(w->bin[which].fd, v, c, (off_t)off);
+                    if (k < 0) { if (errno == EINTR) continue; failed_errno.store(errno); return; }
+                    off += (uint64_t)k;
+                    size_t done = (size_t)k;
+                    while (c > 0 && done >= v->iov_len) { done -= v->iov_len; v++; c--; }
+                    if (c > 0 && done) { v->iov_base = (char *)v->iov_base + done; v->iov_len -= done; }
+                }
+                start[which] = off;
+                iov[which].clear();
+            };
+            for (size_t i = cut(t); i < last && !failed_errno.load(); i++) {
+                const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
+                const size_t nn = b->name_off[i + 1] - b->name_off[i];
+                const size_t ns = b->base_off[i + 1] - b->base_off[i];
+                const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
+                const bool fq = b->has_qual[i] && nq > 0;
+                std::vector<struct iovec> &v = iov[which];
+                // (dst[i] counts from the bin's buffer start, which is empty here: an offset into this batch's share)
+                if (v.empty()) start[which] = w->bin[which].file_off + dst[i];
+                v.push_back({(void *)(fq ? &at_c : &gt_c), 1});
+                if (nn) v.push_back({(void *)(b->names.data() + b->name_off[i]), nn});
+                v.push_back({(void *)&nl_c, 1});
+                if (ns) v.push_back({(void *)(b->bases + b->base_off[i]), ns});
+                if (fq) {
+                    v.push_back({(void *)plus_c, 3});
+                    v.push_back({(void *)(b->quals.data() + b->qual_off[i]), nq});
+                }
+                v.push_back({(void *)&nl_c, 1});
+                if ((int)v.size() >= CAP) flush(which);
+            }
+            for (int k = 0; k < 3; k++) if (!iov[k].empty()) flush(k);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(put, t);
+        put(0);
+        for (std::thread &th : pool) th.join();
+        if (failed_errno.load()) return ffail(TBK_ERR_IO, "write: %s", strerror(failed_errno.load()));
+        for (int k = 0; k < 3; k++) w->bin[k].file_off += at[k];
+        return TBK_OK;
+    }
     for (int k = 0; k < 3; k++) {
         if (!w->bin[k].text.grow_to((size_t)at[k])) return ffail(TBK_ERR_NOMEM, "out of memory buffering a bin");
         w->bin[k].text.n = (size_t)at[k];
     }
-    const uint64_t total = upto[(size_t)n];
     const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)4 << 20)));
     auto fill = [&](int t) {
         auto cut = [&](int u) -> size_t {

@@ -170,7 +170,7 @@ struct tbk_classifier {
     uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
-    hipStream_t compute = nullptr, copy = nullptr;
+    hipStream_t compute = nullptr, copy = nullptr, out = nullptr;  // kernels; H2D of the next batch; D2H of finished counts
     Slot ring[RING];
     uint64_t next_ticket = 1;
     int max_blocks = 0;
@@ -802,6 +802,7 @@ extern "C" int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n
 static int classifier_streams(tbk_classifier *c) {
     hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->out, hipStreamNonBlocking);
     for (int i = 0; i < RING && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
@@ -1046,6 +1047,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
     if (hipSetDevice(c->device) == hipSuccess) {
         if (c->compute) (void)hipStreamSynchronize(c->compute);
         if (c->copy) (void)hipStreamSynchronize(c->copy);
+        if (c->out) (void)hipStreamSynchronize(c->out);
         for (Slot &s : c->ring) {
             if (s.d_bases) (void)hipFree(s.d_bases);
             if (s.d_offsets) (void)hipFree(s.d_offsets);
@@ -1069,6 +1071,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
         if (c->d_pass_read) (void)hipFree(c->d_pass_read);
         if (c->compute) (void)hipStreamDestroy(c->compute);
         if (c->copy) (void)hipStreamDestroy(c->copy);
+        if (c->out) (void)hipStreamDestroy(c->out);
     }
     delete c;
 }
@@ -1347,13 +1350,18 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
             HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 1, c->compute));
             s.bad_clean = true;
         }
+        // the counts travel home on a stream of their own: a copy between two probes on the compute stream costs
+        // the next probe a hand-over to the copy engine and back (measured: 1 ms per 25 ms step)
+        HIP_TRY(hipEventRecord(s.probed, c->compute));
+        HIP_TRY(hipStreamWaitEvent(c->out, s.probed, 0));
         HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, c->compute));
-    } else if (n_reads) {
-        memset(counts, 0, n_reads * 2 * sizeof(int32_t));
+                               hipMemcpyDeviceToHost, c->out));
+        HIP_TRY(hipEventRecord(s.done, c->out));
+    } else {
+        if (n_reads) memset(counts, 0, n_reads * 2 * sizeof(int32_t));
         s.counts_staged = false;
+        HIP_TRY(hipEventRecord(s.done, c->compute));
     }
-    HIP_TRY(hipEventRecord(s.done, c->compute));
     s.busy = true;
     c->next_ticket++;
     *ticket = tk;
@@ -1461,12 +1469,12 @@ extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, 
     if (n_reads && total_bases) {
         rc = launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases, s.d_counts);
         if (rc) return rc;
-        // the counts travel home on the side stream, beside the next batch's kernels
+        // the counts travel home on a stream of their own, beside the next batch's kernels
         HIP_TRY(hipEventRecord(s.probed, c->compute));
-        HIP_TRY(hipStreamWaitEvent(c->copy, s.probed, 0));
+        HIP_TRY(hipStreamWaitEvent(c->out, s.probed, 0));
         HIP_TRY(hipMemcpyAsync(out_pinned ? counts : s.h_counts, s.d_counts, n_reads * 2 * sizeof(int32_t),
-                               hipMemcpyDeviceToHost, c->copy));
-        HIP_TRY(hipEventRecord(s.done, c->copy));
+                               hipMemcpyDeviceToHost, c->out));
+        HIP_TRY(hipEventRecord(s.done, c->out));
     } else {
         if (n_reads) memset(counts, 0, n_reads * 2 * sizeof(int32_t));
         s.counts_staged = false;
@@ -1484,6 +1492,7 @@ extern "C" int tbk_classifier_sync(tbk_classifier *c) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->copy));
     HIP_TRY(hipStreamSynchronize(c->compute));
+    HIP_TRY(hipStreamSynchronize(c->out));
     return TBK_OK;
 }
 
