@@ -26,6 +26,15 @@ for name in ("pmc_traffic.json", "pmc_traffic_haplotypes.json"):  # bench.py rep
         shutil.copy(p, os.path.join(ROOT, "profiles", name))
 
 
+# the bench line printed by the run that rocprofv3 traced: its HIP-event durations belong beside the trace's
+try:
+    lines = [l for l in open(os.path.join(src, "prof_trace.log")) if l.startswith('{"metric"')]
+    if lines:
+        open(os.path.join(dst, "bench_under_rocprofv3.json"), "w").write(lines[-1])
+except OSError:
+    pass
+
+
 def load(name):
     try:
         return json.load(open(os.path.join(dst, name)))
@@ -101,6 +110,11 @@ out += ["", "rocprofv3 `--kernel-trace` of `python3 bench.py --no-streaming`, pe
         "the two small parity launches included; the roofline's duration is that of the full-size launches):", "",
         "| kernel | grid | launches | avg ms | min | max |", "|---|---|---|---|---|---|"]
 out += [f"| `{t['kernel']}` | {t['grid']} | {t['launches']} | {t['avg_ms']} | {t['min_ms']} | {t['max_ms']} |" for t in full]
+prof = load("bench_under_rocprofv3.json")
+if prof:
+    out += ["", f"The traced process's own bench line (`bench_under_rocprofv3.json`): single-read kernel by HIP events {prof['roofline']['kernel_ms_avg']} ms in the host-fed region, "
+            f"{g(prof, 'kernel_resident', 'single_read_kernel_ms_avg')} ms in the resident region - the trace's average over the same process's full-size launches is the figure above "
+            f"(value {prof['value']}, kernel_resident {g(prof, 'kernel_resident', 'gbases_per_s')} Gbases/s under the profiler; separate processes on one box differ by up to 5 %)."]
 if two:
     out += ["", f"Two ranks on the one device (`--share-device`; a plumbing run, not a scaling result): value {two['value']} Gbases/s, kernel_resident {g(two, 'kernel_resident', 'gbases_per_s')}, "
             f"parity all_ranks_equal = {g(two, 'parity', 'all_ranks_equal')}, gpu_equals_cpu = {g(two, 'parity', 'gpu_equals_cpu')}, devices {json.dumps(two.get('devices'))}."]
