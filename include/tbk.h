@@ -166,9 +166,6 @@ int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint6
  * line only (the first four slots of each list; csrc/tbk_common.h "front layout"), and how many keys lie
  * behind that front (settled by the deferred walk).  TBK_FRONT=1 / 0 pins the layout. */
 int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_behind_front);
-/* Front layout, k <= 31: fronts whose fourth slot holds a filter word (a 62-bit Bloom word over the list's keys
- * behind the front: a window that misses in such a front looks behind it only when its two bits are set). */
-int tbk_classifier_filters(const tbk_classifier *c, uint64_t *n_filters);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

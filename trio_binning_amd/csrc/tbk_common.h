@@ -299,7 +299,6 @@ TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
 // The `guests` word of the views carries two flags:
 #define TBK_FLAG_GUESTS 1u   // a full half's surplus may sit, tagged, in the other half of the line
 #define TBK_FLAG_FRONT 2u    // paired table in front layout (below)
-#define TBK_FLAG_FILTER 4u   // front layout: a list's slot 3 may hold a filter word over its back keys (below)
 // Front layout.  A touched line costs the CU's L1 path the same whether 16 or 128 of its bytes are
 // wanted, and a whole [8 hapA | 8 hapB] line is two 64-byte requests per quad; with a key or two per
 // bucket nearly every window can be answered from four slots of each list.  So the line is laid out
@@ -315,22 +314,6 @@ TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
 // starting at the home line (tbk_order_kernel writes both orders after the inserts).  Logical slot
 // numbers, flags in slots 4..7, guests and probe sequences are those of the plain layout: only
 // tbk_slot_at() knows where a slot lies.
-// Filter words (k <= 31: keys are below 2^62).  Most windows miss, and a window that misses in a front whose
-// list has keys behind it must look at the back half of the line - on lists shaped like real data that is one
-// window in 13 to 30.  So where a list has keys behind its front and its half still has room, its fourth front
-// slot gives up its key to the back half and holds instead a 62-bit Bloom word over the list's back keys (two
-// bits per key), marked by bits 63..62 = 01: larger than any key, smaller than any tagged guest and EMPTY, so no
-// key compare ever matches it and the order flags of its pair read "nothing behind" - the probe kernel tests the
-// window's two bits instead and looks behind the front only when both are set (tbk_filter_kernel writes the
-// words after a list's inserts; a list whose half is full keeps the order flag and is always looked up).
-#define TBK_FILTER_BIT 0x4000000000000000ull
-TBK_HD bool tbk_is_filter(uint64_t v) { return (v >> 62) == 1ull; }
-TBK_HD uint64_t tbk_filter_bits(uint64_t key) {
-    const uint32_t h = tbk_mix32(key ^ 0x9E3779B97F4A7C15ull);
-    const uint32_t b1 = ((h & 63u) * 62u) >> 6, b2 = (((h >> 6) & 63u) * 62u) >> 6;  // 0..61
-    return (1ull << b1) | (1ull << b2);
-}
-
 TBK_HD uint32_t tbk_slot_at(uint32_t flags, uint32_t stride, uint32_t half, uint32_t s) {
     if ((flags & TBK_FLAG_FRONT) && stride == 16) return ((s & 4u) << 1) + (half >> 1) + (s & 3u);
     return half + s;

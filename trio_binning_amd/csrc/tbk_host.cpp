@@ -33,7 +33,6 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, c
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_filter(uint64_t *, uint64_t, uint32_t, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                        int32_t *, uint32_t *, uint64_t, int, hipEvent_t, hipStream_t);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
@@ -169,7 +168,6 @@ struct tbk_classifier {
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
     uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line
-    uint64_t filters = 0;        // fronts whose fourth slot holds a filter word over the list's back keys (tbk_common.h)
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
     hipStream_t compute = nullptr, copy = nullptr, out = nullptr;  // kernels; H2D of the next batch; D2H of finished counts
@@ -820,22 +818,7 @@ static int classifier_streams(tbk_classifier *c) {
 // order pass after each list turns "a key went past this half" / "left the line" into the order of
 // the half's last slots, which is what lookups (hapB's inserts included) read.  *past = keys that
 // found their own half of their home line full.
-// Front layout: the filter words of the lists whose inserts are done (tbk_filter_kernel; a no-op elsewhere)
-static int filter_table(tbk_classifier *c) {
-    if (!(c->guests & TBK_FLAG_FILTER)) return TBK_OK;
-    unsigned long long *d_n = nullptr, n = 0;
-    hipError_t e = hipMalloc((void **)&d_n, sizeof n);
-    if (e == hipSuccess) e = hipMemset(d_n, 0, sizeof n);
-    if (e == hipSuccess) e = tbk_launch_filter(c->d_pair, (uint64_t)c->n_buckets * 2, c->guests, d_n, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(&n, d_n, sizeof n, hipMemcpyDeviceToHost);
-    if (d_n) (void)hipFree(d_n);
-    if (e != hipSuccess) return fail(TBK_ERR_HIP, "filter pass: %s", hipGetErrorString(e));
-    c->filters += n;
-    return TBK_OK;
-}
-
 static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past) {
-    c->filters = 0;
     c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
@@ -853,11 +836,9 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
         rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
                          TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests, &past_a, &back_a);
         if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left, c->guests, 16);
-        if (!rc) rc = filter_table(c);
         if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
                                   TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests, &past_b, &back_b);
         if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left, c->guests, 16);
-        if (!rc) rc = filter_table(c);
     }
     if (d_over) (void)hipFree(d_over);
     if (d_left) (void)hipFree(d_left);
@@ -921,9 +902,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         built_t = c->mz.t;
         c->layout_builds++;
         const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : true);
-        // filter words over a list's back keys need two free bits above the key (k <= 31) and the front layout
-        const uint32_t filter = front && c->k <= 31 && env_double("TBK_FILTER", 1) != 0 ? TBK_FLAG_FILTER : 0u;
-        c->guests = guests | (front ? TBK_FLAG_FRONT : 0u) | filter;
+        c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
         if (rc) { delete c; return rc; }
@@ -932,7 +911,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.006)) {
             // the lists spread, but too many keys lie behind a front: the same table in whole lines
             (void)hipFree(c->d_pair); c->d_pair = nullptr;
-            c->guests = guests;  // whole lines: no front, no filter words
+            c->guests = guests;
             c->layout_builds++;
             rc = build_pair_table(c, a, b, 0.08, &past);
             if (rc) { delete c; return rc; }
@@ -962,7 +941,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->max_blocks = src->max_blocks;
     c->packed_h2d = src->packed_h2d;
     c->guests = src->guests;
-    c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front; c->filters = src->filters;
+    c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
     if (e == hipSuccess) {
@@ -1054,12 +1033,6 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
     if (front) *front = (c->guests & TBK_FLAG_FRONT) ? 1 : 0;
     if (keys_behind_front) *keys_behind_front = c->behind_front;
-    return TBK_OK;
-}
-
-extern "C" int tbk_classifier_filters(const tbk_classifier *c, uint64_t *n_filters) {
-    if (!c || !n_filters) return fail(TBK_ERR_INVALID, "NULL argument");
-    *n_filters = c->filters;
     return TBK_OK;
 }
 

@@ -165,7 +165,7 @@ tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t
         // front layout: slot 2 > slot 3 says "this list has keys behind the front" (a fifth key, or beyond)
         ulonglong2 *front = reinterpret_cast<ulonglong2 *>(line + tbk_slot_at(flags, stride, half, 2));
         const ulonglong2 f = *front;
-        if (f.y != TBK_EMPTY && !tbk_is_filter(f.y)) {  // (a filter word in slot 3 speaks for the back keys itself)
+        if (f.y != TBK_EMPTY) {
             const bool more = line[tbk_slot_at(flags, stride, half, 4)] != TBK_EMPTY;
             if ((f.x > f.y) != more) *front = make_ulonglong2(f.y, f.x);
         }
@@ -190,39 +190,6 @@ tbk_order_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, const uint32_t
         const bool left = (left_line[h >> 5] >> (h & 31)) & 1u;
         if ((m.x > m.y) != left) *mid = make_ulonglong2(m.y, m.x);
     }
-}
-
-// Front layout, after a list's inserts and their order pass: where a list has keys behind its front, its own key
-// in front slot 3, and room in its half, the key of slot 3 moves to the half's first free back slot and slot 3
-// becomes the filter word over the list's back keys (tbk_common.h).  One thread per half; halves that carry a
-// filter already are left alone (hapA's, when this runs again after hapB's inserts: hapB adds no hapA keys).
-__global__ void __launch_bounds__(256)
-tbk_filter_kernel(uint64_t *__restrict__ slots, uint64_t n_halves, uint32_t flags, unsigned long long *__restrict__ n_filters) {
-    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= n_halves) return;
-    uint64_t *line = slots + (h / 2) * 16;
-    const uint32_t half = (uint32_t)(h % 2) * TBK_SLOTS_PER_BUCKET;
-    uint64_t *s3 = line + tbk_slot_at(flags, 16, half, 3);
-    const uint64_t k3 = *s3;
-    uint64_t back[4];
-    for (uint32_t i = 0; i < 4; i++) back[i] = line[tbk_slot_at(flags, 16, half, 4 + i)];
-    // keys behind the front, slot 3 an own key (not empty, not a guest of the other list, not a filter), slots 6 and 7
-    // free (so that the half does not become full: its pair (6,7) keeps saying "nothing went past")
-    if (back[0] == TBK_EMPTY || k3 == TBK_EMPTY || (k3 >> 62) != 0 || back[2] != TBK_EMPTY || back[3] != TBK_EMPTY) return;
-    const uint32_t to = back[1] == TBK_EMPTY ? 1u : 2u;
-    back[to] = k3;
-    uint64_t word = TBK_FILTER_BIT;
-    for (uint32_t i = 0; i <= to; i++)
-        if (!(back[i] & TBK_GUEST)) word |= tbk_filter_bits(back[i]);  // (a tagged entry there is the other list's guest)
-    line[tbk_slot_at(flags, 16, half, 4 + to)] = k3;
-    *s3 = word;
-    atomicAdd(n_filters, 1ull);
-}
-
-extern "C" hipError_t tbk_launch_filter(uint64_t *slots, uint64_t n_halves, uint32_t flags, unsigned long long *d_n_filters, hipStream_t stream) {
-    if (n_halves == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_filter_kernel, dim3((unsigned)((n_halves + 255) / 256)), dim3(256), 0, stream, slots, n_halves, flags, d_n_filters);
-    return hipGetLastError();
 }
 
 __global__ void __launch_bounds__(256)
@@ -834,8 +801,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             const uint32_t klo0 = quad_bcast<0>(my_klo), khi0 = quad_bcast<0>(my_khi), klo1 = quad_bcast<1>(my_klo), khi1 = quad_bcast<1>(my_khi);
             const uint32_t klo2 = quad_bcast<2>(my_klo), khi2 = quad_bcast<2>(my_khi), klo3 = quad_bcast<3>(my_klo), khi3 = quad_bcast<3>(my_khi);
             const uint32_t klo[4] = {klo0, klo1, klo2, klo3}, khi[4] = {khi0, khi1, khi2, khi3};
-            uint64_t hit[4], more[4], filt[4], any_hit = 0, any_more = 0;
-            const bool filters = (p.t.guests & TBK_FLAG_FILTER) != 0;
+            uint64_t hit[4], more[4], any_hit = 0, any_more = 0;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const uint64_t kk = (uint64_t)klo[s] | ((uint64_t)khi[s] << 32);
@@ -843,9 +809,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 // the order of a lane's two slots: lanes 1 and 3 - the list has keys behind its front;
                 // lanes 0 and 2 - these four slots hold keys of the OTHER list (tagged)
                 more[s] = ballot(va[s].x > va[s].y);
-                // lanes 1 and 3 hold a list's slots 2 and 3: slot 3 may be the filter word over the list's back keys
-                filt[s] = filters ? ballot(((uint32_t)(va[s].y >> 32) & 0xC0000000u) == 0x40000000u) & 0xAAAAAAAAAAAAAAAAull : 0ull;
-                any_more |= more[s] | filt[s];
+                any_more |= more[s];
             }
             if ((p.t.guests & TBK_FLAG_GUESTS) && (any_more & 0x5555555555555555ull) != 0) {  // (without guests the order of slots 0 and 1 means nothing)
                 // A list's fifth key of a bucket sits, tagged, in a free front slot of the other list before it
@@ -874,16 +838,9 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 uint64_t need = 0, beh_a = 0, beh_b = 0;
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    if ((more[s] | filt[s]) == 0) continue;
+                    if (more[s] == 0) continue;
                     TBK_COUNT(2, 1);
-                    uint64_t behind = more[s];
-                    if (filt[s] != 0) {
-                        // a filter word speaks for its list's back keys: look behind the front only when the
-                        // window's two bits are both set in it
-                        const uint64_t fb = tbk_filter_bits((uint64_t)klo[s] | ((uint64_t)khi[s] << 32));
-                        behind |= filt[s] & ballot((va[s].y & fb) == fb);
-                    }
-                    const uint64_t ma = (behind & 0x2222222222222222ull) >> 1, mb = (behind & 0x8888888888888888ull) >> 3;
+                    const uint64_t ma = (more[s] & 0x2222222222222222ull) >> 1, mb = (more[s] & 0x8888888888888888ull) >> 3;
                     const uint64_t miss = ~quad_any(hit[s]);  // a hit in either list's front is final (the lists are disjoint)
                     need |= ((ma | mb) & miss) << s;
                     beh_a |= ma << s;

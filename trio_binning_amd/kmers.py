@@ -311,10 +311,7 @@ class Classifier:
         front, behind = C.c_int(), C.c_uint64()
         if hasattr(lib, "tbk_classifier_front"):
             check(lib.tbk_classifier_front(self._h, C.byref(front), C.byref(behind)))
-        nf = C.c_uint64()
-        if hasattr(lib, "tbk_classifier_filters"):
-            check(lib.tbk_classifier_filters(self._h, C.byref(nf)))
-        return {"filter_words": nf.value, "shared_keys": sh.value, "layout_builds": nb_.value, "keys_past_half": past.value, "front_layout": bool(front.value), "keys_behind_front": behind.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
+        return {"shared_keys": sh.value, "layout_builds": nb_.value, "keys_past_half": past.value, "front_layout": bool(front.value), "keys_behind_front": behind.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
                 "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
                 "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
 
