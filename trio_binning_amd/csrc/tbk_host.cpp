@@ -1332,8 +1332,6 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
                 HIP_TRY(hipMemcpyAsync(s.d_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
                 HIP_TRY(hipMemcpyAsync(s.d_exc_mask, exc_mask, n_exc * sizeof(uint16_t), hipMemcpyHostToDevice, c->copy));
             }
-            // exceptions into the dense masks; the tail of the last partial chunk is masked here too
-            HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 0, c->copy));
         } else {
             const uint8_t *src_b = bases;
             if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
@@ -1342,6 +1340,9 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(s.copied, c->copy));
         HIP_TRY(hipStreamWaitEvent(c->compute, s.copied, 0));
+        // exceptions into the dense masks (the tail of the last partial chunk is masked there too): a kernel, so on the
+        // compute stream - the copy stream carries copies only and never waits for a free compute unit
+        if (packed) HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 0, c->compute));
         rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? s.d_codes : nullptr,
                                 packed ? s.d_bad : nullptr);
         if (rc) return rc;
