@@ -96,6 +96,9 @@ def parse(argv=None):
     ap.add_argument("--timed-path", choices=["host_fed", "resident"], default="host_fed",
                     help="what `value` times: the host-fed classify stage (pinned packed batches -> H2D -> kernels -> D2H -> binning), "
                          "or the same steps with the batches resident in HBM")
+    ap.add_argument("--rings", type=int, default=1,
+                    help="feeder threads + stream rings (+ table replicas) per rank, all on the rank's device: 1 is the product's "
+                         "shape per GPU; more exercise the pipeline's dealing on a one-GPU box")
     ap.add_argument("--parity-reads", type=int, default=4096, help="reads of the generator's start every rank classifies for the parity check")
     ap.add_argument("--stream-batch-reads", type=int, default=65_536, help="reads per host batch of the streaming leg")
     ap.add_argument("--stream-seconds", type=float, default=2.0)
@@ -327,7 +330,7 @@ def main():
     # the library's pipeline over this rank's device: it hashes both lists into the paired table in HBM and
     # starts the device's feeder thread; `cls` is its classifier (the resident leg and the timing read it
     # directly while the pipeline is idle)
-    pipe = kmers.MultiClassifier(hap_a, hap_b, [dev])
+    pipe = kmers.MultiClassifier(hap_a, hap_b, [dev] * max(1, args.rings))
     cls = pipe._part(0)
     check(lib.tbk_device_sync(dev))
     t_build = time.time() - t0
@@ -410,7 +413,7 @@ def main():
         waiter = pipe.wait if fed else cls.wait
         # host-fed: as many batches submitted as the ring holds (the third one's copy runs beside the first one's
         # kernel); resident: one fewer is enough to keep the compute stream busy
-        ahead = depth if fed else depth - 1 + (depth == 1)
+        ahead = depth if fed else max(1, cls.depth - 1)  # (the resident leg drives ring 0's classifier alone)
         for i in range(n_steps * launches_per_step):
             d_b, d_o, n_r, tot, packed = batches[i % len(batches)]
             slot = i % depth
@@ -591,6 +594,7 @@ def main():
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
             "line_layout": "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines", "keys_behind_front": stats.get("keys_behind_front"),
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
+            "rings_per_rank": max(1, args.rings), "batches_per_ring": pipe.dealt,
         },
         "timed_regions": len(region_s), "timed_total_s": round(sum(region_s), 3),
         "region_s_min_median_max": [round(min(region_s), 4), round(elapsed, 4), round(max(region_s), 4)],

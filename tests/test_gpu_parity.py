@@ -213,6 +213,7 @@ def test_seeded_fuzz_of_layout_and_input_shapes(gpu, orc, tmp_path, seed, monkey
     monkeypatch.setenv("TBK_MOD_SAMPLING", str(int(rng.integers(0, 2))))
     monkeypatch.setenv("TBK_TABLE_LOAD", str(rng.choice([0.04, 0.2, 0.6, 0.9])))
     monkeypatch.setenv("TBK_GUESTS", str(seed % 3 and 1))     # a third of the seeds without guests in the other half
+    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))  # an empty ring takes a batch in up to 8 slices
     monkeypatch.setenv("TBK_FRONT", str(seed // 3 % 2))       # half of them in the front layout (where mod-sampling is drawn): crowded fronts, walks from the home line
     n_a, n_b = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
 

@@ -12,6 +12,10 @@ export TBK_SKIP_BUILD=1
 ( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_haplotypes.log | tail -1 > gpurun_out/bench_haplotypes.json
 ( time timeout 900 python bench.py --gpus 2 --share-device ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
 ( time timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-device --steps 10 --warmup 2 ) > gpurun_out/bench_2ranks_torchrun.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_torchrun.log | tail -1 > gpurun_out/bench_2ranks_torchrun.json
+( time timeout 900 python bench.py --rings 3 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_3rings.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_3rings.log | tail -1 > gpurun_out/bench_3rings.json
+# BASELINE configs[4]'s table and read shape on one GPU: 2 x 1e9 31-mers (64-bit m-mer kernels), 100 kb reads
+( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_uniform.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_uniform.log | tail -1 > gpurun_out/bench_c5_uniform.json
+( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --lists haplotypes --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_haplotypes.log | tail -1 > gpurun_out/bench_c5_haplotypes.json
 ( time timeout 600 python bench.py --path count ) > gpurun_out/bench_count.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_count.log | tail -1 > gpurun_out/bench_count.json
 ( time timeout 900 python bench.py --scaling strong --strong-reads 3000000 --steps 3 --warmup 1 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
 FLAGS="--steps 4 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-streaming"

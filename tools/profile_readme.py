@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json",
+KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
         "reader_hifi.json", "cli_configs1.json", "cli_gz_input.json"]
 for name in KEEP:
@@ -120,6 +120,17 @@ if two:
             f"parity all_ranks_equal = {g(two, 'parity', 'all_ranks_equal')}, gpu_equals_cpu = {g(two, 'parity', 'gpu_equals_cpu')}, devices {json.dumps(two.get('devices'))}."]
 if tr2:
     out += [f"Under `python -m torch.distributed.run`: value {tr2['value']}, parity all_ranks_equal = {g(tr2, 'parity', 'all_ranks_equal')}."]
+rings3 = load("bench_3rings.json")
+if rings3:
+    out += [f"Three feeder threads + rings + table replicas on the one device (`--rings 3`, SURVEY 8e's per-device feeders dealing from one queue): value {rings3['value']} Gbases/s "
+            f"(one ring, same script: {g(u, 'value')}), batches per ring {g(rings3, 'config', 'batches_per_ring')}, parity {g(rings3, 'parity', 'all_ranks_equal')}."]
+for nm, label in (("bench_c5_uniform.json", "uniform"), ("bench_c5_haplotypes.json", "haplotype-shaped")):
+    c5 = load(nm)
+    if c5:
+        cc = c5["config"]
+        out += [f"BASELINE configs[4]'s table and read shape on one GPU (k = 31, 2 x {cc['kmers_per_list']} keys, {cc['read_len']} b reads, {label} lists): value {c5['value']} Gbases/s host-fed, "
+                f"kernel_resident {g(c5, 'kernel_resident', 'gbases_per_s')}; {cc['bucket_select']}, load {cc['table_load']}, {cc['table_bytes_per_gpu'] / 1e9:.0f} GB table, {cc['line_layout'][:5]} layout; "
+                f"transfers agree: {g(c5, 'parity', 'packed_and_ascii_transfers_agree')} (oracle parity at this scale: tests/test_gpu_scale.py)."]
 if strong:
     out += [f"Strong scaling plumbing (one rank, 45 Gbp set in 12 host-fed batches per step): value {strong['value']} Gbases/s."]
 if count:

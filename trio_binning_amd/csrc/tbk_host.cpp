@@ -33,11 +33,13 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, c
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_probe(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
-                                       int32_t *, uint32_t *, uint64_t, int, hipEvent_t, hipStream_t);
+extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, hipStream_t);
+extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
+                                             int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, hipEvent_t, hipStream_t);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
+static constexpr uint64_t TBK_PASS_BASES = 2048;  // window starts per pass (tbk_device.h: TBK_PASS)
 extern "C" hipError_t tbk_launch_synth_keys(uint64_t, uint64_t, uint64_t, int, uint64_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_synth_reads(uint64_t, uint64_t, uint64_t, uint32_t, uint64_t, uint64_t, uint64_t,
                                              int, int, int, uint8_t *, uint64_t *, hipStream_t);
@@ -135,7 +137,7 @@ struct tbk_table {
 };
 
 static constexpr int RING = 3;
-static constexpr int TIMING_POOL = 1024;
+static constexpr int TIMING_POOL = 4096;  // events kept for kernel timing before they are folded into sums
 
 struct Slot {
     uint8_t *d_bases = nullptr; size_t cap_bases = 0;
@@ -151,6 +153,7 @@ struct Slot {
     uint32_t *h_codes = nullptr; size_t hcap_chunks = 0;
     uint32_t *h_exc_chunk = nullptr; uint16_t *h_exc_mask = nullptr; size_t hcap_exc = 0;
     hipEvent_t copied = nullptr, probed = nullptr, done = nullptr;
+    hipEvent_t sliced[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // a host batch's bases arrive (and are probed) in up to 8 slices
     bool busy = false;
     uint64_t ticket = 0, n_reads = 0;
     int32_t *user_counts = nullptr;
@@ -178,6 +181,7 @@ struct tbk_classifier {
     // PCIe), 0 = as ASCII (1 B/base).  TBK_PACKED_H2D, tbk_classifier_set_transfer.
     int packed_h2d = 1;
     int pack_threads = 0;             // host threads a submit-time pack may use (0: all; a pipeline's feeders share them)
+    uint64_t slice_bases = (uint64_t)384 << 20;  // an empty ring takes a host batch in slices of at least this many bases (TBK_SLICE_BASES; tests shrink it)
     std::vector<uint32_t> exc_chunk;  // scratch of the packer
     std::vector<uint16_t> exc_mask;
     // scratch for the pass -> read index (launches on `compute` are stream-ordered, so one
@@ -188,7 +192,8 @@ struct tbk_classifier {
     // kernel timing: per probe launch three events - before the pass-index kernel, between the multi-read and
     // the single-read probe kernel, after the latter
     bool timing = false;
-    std::vector<hipEvent_t> ev;  // triples
+    std::vector<hipEvent_t> ev;        // per probe: before the index kernel, after it; per slice: before the multi-read kernel, between the two, after the single-read kernel
+    std::vector<uint32_t> ev_slices;   // slices of every timed probe, in order (a probe uses 2 + 3 * slices events)
     size_t ev_used = 0;
     uint64_t timed_launches = 0;
     double timed_ms = 0.0;         // whole probe: index + both kernels
@@ -807,6 +812,7 @@ static int classifier_streams(tbk_classifier *c) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
+        for (int j = 0; j < 8 && e == hipSuccess; j++) e = hipEventCreateWithFlags(&c->ring[i].sliced[j], hipEventDisableTiming);
     }
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
     return TBK_OK;
@@ -864,6 +870,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->k = a->k;
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
+    c->slice_bases = (uint64_t)std::max(2048.0, env_double("TBK_SLICE_BASES", (double)((uint64_t)384 << 20)));
     // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers, default 6;
     // 0 = plain hashing of the whole key).  Which m-mer is sampled, and how roomy the table is, is decided by
     // the lists.  Mod-sampling switches lines 18 % less often than the random minimizer and is the faster rule
@@ -940,6 +947,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->mz = src->mz;
     c->max_blocks = src->max_blocks;
     c->packed_h2d = src->packed_h2d;
+    c->slice_bases = src->slice_bases;
     c->guests = src->guests;
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
@@ -1065,6 +1073,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             if (s.copied) (void)hipEventDestroy(s.copied);
             if (s.probed) (void)hipEventDestroy(s.probed);
             if (s.done) (void)hipEventDestroy(s.done);
+            for (hipEvent_t e : s.sliced) if (e) (void)hipEventDestroy(e);
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         if (c->d_pair) (void)hipFree(c->d_pair);
@@ -1097,9 +1106,12 @@ static bool is_pinned(const void *p) {
     return at.type == hipMemoryTypeHost;
 }
 
+// A slice of a batch's passes and the event (on another stream) behind which its bases are on the device.
+struct ProbeSlice { uint64_t pass_lo, pass_hi; hipEvent_t arrived; };
+
 static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const uint64_t *d_offsets,
                               uint64_t n_reads, uint64_t total, int32_t *d_counts, const uint32_t *d_codes = nullptr,
-                              const uint16_t *d_bad16 = nullptr) {
+                              const uint16_t *d_bad16 = nullptr, const ProbeSlice *slices = nullptr, int n_slices = 0) {
     if (n_reads >= 0xFFFFFFF0ull) return fail(TBK_ERR_INVALID, "more than 2^32 reads in one batch");
     if (total == 0) {  // nothing to probe (every read empty): all counts are zero
         HIP_TRY(hipMemsetAsync(d_counts, 0, n_reads * 2 * sizeof(int32_t), c->compute));
@@ -1114,43 +1126,58 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         HIP_TRY(hipMalloc((void **)&c->d_pass_read, (2 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, its length
         c->cap_passes = cap;
     }
-    // (the per-read counters are cleared by the pass-index kernel inside tbk_launch_probe)
-    hipEvent_t e0 = nullptr, em = nullptr, e1 = nullptr;
+    const ProbeSlice whole = {0, passes, nullptr};
+    if (n_slices <= 0) { slices = &whole; n_slices = 1; }
+    // (the per-read counters are cleared by the pass-index kernel)
+    hipEvent_t *ev = nullptr;
     if (c->timing) {
-        if (c->ev_used + 3 > c->ev.size()) {
-            if (c->ev.size() >= 3 * TIMING_POOL) {  // fold what we have, then reuse the pool
-                HIP_TRY(hipStreamSynchronize(c->compute));
-                int rc = c->fold_timing();
-                if (rc) return rc;
-            } else {
-                for (int i = 0; i < 3; i++) {
-                    hipEvent_t a;
-                    HIP_TRY(hipEventCreate(&a));
-                    c->ev.push_back(a);
-                }
-            }
+        const size_t need = 2 + 3 * (size_t)n_slices;
+        if (c->ev_used + need > c->ev.size() && c->ev.size() >= (size_t)TIMING_POOL) {  // fold what we have, then reuse the pool
+            HIP_TRY(hipStreamSynchronize(c->compute));
+            int rc = c->fold_timing();
+            if (rc) return rc;
         }
-        e0 = c->ev[c->ev_used]; em = c->ev[c->ev_used + 1]; e1 = c->ev[c->ev_used + 2];
-        c->ev_used += 3;
+        while (c->ev_used + need > c->ev.size()) {
+            hipEvent_t a;
+            HIP_TRY(hipEventCreate(&a));
+            c->ev.push_back(a);
+        }
+        ev = c->ev.data() + c->ev_used;
+        c->ev_used += need;
+        c->ev_slices.push_back((uint32_t)n_slices);
         c->timed_launches++;
-        HIP_TRY(hipEventRecord(e0, c->compute));
+        HIP_TRY(hipEventRecord(ev[0], c->compute));
     }
-    HIP_TRY(tbk_launch_probe(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes, c->max_blocks,
-                             em, c->compute));
+    HIP_TRY(tbk_launch_probe_index(d_offsets, n_reads, total, d_counts, c->d_pass_read, c->cap_passes, c->compute));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], c->compute));
+    for (int j = 0; j < n_slices; j++) {
+        if (slices[j].arrived) HIP_TRY(hipStreamWaitEvent(c->compute, slices[j].arrived, 0));
+        if (ev) HIP_TRY(hipEventRecord(ev[2 + 3 * j], c->compute));  // (behind the wait: the slice's own time starts when its bases are there)
+        HIP_TRY(tbk_launch_probe_range(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes,
+                                       slices[j].pass_lo, slices[j].pass_hi, c->max_blocks, ev ? ev[3 + 3 * j] : nullptr, c->compute));
+        if (ev) HIP_TRY(hipEventRecord(ev[4 + 3 * j], c->compute));
+    }
     c->last_passes = passes;
-    if (e1) HIP_TRY(hipEventRecord(e1, c->compute));
     return TBK_OK;
 }
 
 int tbk_classifier::fold_timing() {
-    for (size_t i = 0; i + 3 <= ev_used; i += 3) {
-        float ms = 0, ms_single = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 2]));
-        HIP_TRY(hipEventElapsedTime(&ms_single, ev[i + 1], ev[i + 2]));
+    size_t at = 0;
+    for (uint32_t n_slices : ev_slices) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ev[at], ev[at + 1]));  // the pass-index kernel
         timed_ms += ms;
-        timed_single_ms += ms_single;
+        for (uint32_t j = 0; j < n_slices; j++) {
+            float whole = 0, single = 0;
+            HIP_TRY(hipEventElapsedTime(&whole, ev[at + 2 + 3 * j], ev[at + 4 + 3 * j]));
+            HIP_TRY(hipEventElapsedTime(&single, ev[at + 3 + 3 * j], ev[at + 4 + 3 * j]));
+            timed_ms += whole;
+            timed_single_ms += single;
+        }
+        at += 2 + 3 * (size_t)n_slices;
     }
     ev_used = 0;
+    ev_slices.clear();
     return TBK_OK;
 }
 
@@ -1323,28 +1350,54 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
     if (n_reads && total) {
         const uint64_t *src_o = offsets;
         if (!offs_pinned) { memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t)); src_o = s.h_offsets; }
-        // side stream: H2D of this batch overlaps the previous batch's kernel
+        // Side stream: the H2D of this batch overlaps the previous batch's kernels.  The small arrays go first; the
+        // bases follow - when the ring is empty in up to 8 slices, each with its own event, and the probe of a slice's
+        // passes starts as soon as that slice is on the device: an empty pipeline starts computing after an eighth of
+        // its first copy instead of after all of it.
+        HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
         if (packed) {
-            HIP_TRY(hipMemcpyAsync(s.d_codes, codes, n_chunks * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
             if (!s.bad_clean) HIP_TRY(hipMemsetAsync(s.d_bad, 0, (s.cap_chunks + 2) * sizeof(uint16_t), c->copy));  // a new buffer, or a batch that failed half-way
             s.bad_clean = false;
             if (n_exc) {
                 HIP_TRY(hipMemcpyAsync(s.d_exc_chunk, exc_chunk, n_exc * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
                 HIP_TRY(hipMemcpyAsync(s.d_exc_mask, exc_mask, n_exc * sizeof(uint16_t), hipMemcpyHostToDevice, c->copy));
             }
-        } else {
-            const uint8_t *src_b = bases;
-            if (!bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
-            HIP_TRY(hipMemcpyAsync(s.d_bases, src_b, total, hipMemcpyHostToDevice, c->copy));
         }
-        HIP_TRY(hipMemcpyAsync(s.d_offsets, src_o, (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy));
         HIP_TRY(hipEventRecord(s.copied, c->copy));
+        const uint8_t *src_b = bases;
+        if (!packed && !bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
+        const uint64_t passes = tbk_probe_passes(total);
+        // Slices pay where nothing else keeps the device busy (an empty ring: the first batch of a run); behind a
+        // batch that is still in flight one copy and one pair of kernels is best (every kernel launch ends in a
+        // partly filled device: eight slices per batch measured 4 % slower in the steady state).
+        bool alone = true;
+        for (const Slot &other : c->ring) alone = alone && (&other == &s || !other.busy);
+        const int n_slices = alone ? (int)std::max<uint64_t>(1, std::min<uint64_t>(8, total / c->slice_bases)) : 1;
+        ProbeSlice slices[8];
+        uint64_t sent = 0;  // chunks (of 16 bases) on their way so far
+        for (int j = 0; j < n_slices; j++) {
+            slices[j].pass_lo = passes * (uint64_t)j / (uint64_t)n_slices;
+            slices[j].pass_hi = passes * (uint64_t)(j + 1) / (uint64_t)n_slices;
+            slices[j].arrived = s.sliced[j];
+            // a pass reads 130 chunks from its first one: the slice needs the stream up to chunk pass_hi * 128 + 2
+            const uint64_t upto = j + 1 == n_slices ? n_chunks : std::min<uint64_t>(n_chunks, slices[j].pass_hi * (TBK_PASS_BASES / 16) + 2);
+            if (upto > sent) {
+                if (packed) {
+                    HIP_TRY(hipMemcpyAsync(s.d_codes + sent, codes + sent, (upto - sent) * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
+                } else {
+                    const uint64_t b0 = sent * 16, b1 = std::min<uint64_t>(total, upto * 16);
+                    HIP_TRY(hipMemcpyAsync(s.d_bases + b0, src_b + b0, b1 - b0, hipMemcpyHostToDevice, c->copy));
+                }
+                sent = upto;
+            }
+            HIP_TRY(hipEventRecord(s.sliced[j], c->copy));
+        }
         HIP_TRY(hipStreamWaitEvent(c->compute, s.copied, 0));
         // exceptions into the dense masks (the tail of the last partial chunk is masked there too): a kernel, so on the
         // compute stream - the copy stream carries copies only and never waits for a free compute unit
         if (packed) HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 0, c->compute));
         rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? s.d_codes : nullptr,
-                                packed ? s.d_bad : nullptr);
+                                packed ? s.d_bad : nullptr, slices, n_slices);
         if (rc) return rc;
         if (packed) {
             // behind the probe: the batch's exceptions out of the dense masks again, which are all zero between batches
@@ -1503,7 +1556,7 @@ extern "C" int tbk_kernel_timing_enable(tbk_classifier *c, int on) {
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
     c->timing = on != 0;
-    c->ev_used = 0; c->timed_launches = 0; c->timed_ms = 0.0; c->timed_single_ms = 0.0;
+    c->ev_used = 0; c->ev_slices.clear(); c->timed_launches = 0; c->timed_ms = 0.0; c->timed_single_ms = 0.0;
     return TBK_OK;
 }
 

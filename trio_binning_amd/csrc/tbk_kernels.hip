@@ -290,6 +290,7 @@ struct ProbeArgs {
     const uint32_t *pass_read;  // [n_passes] read that contains each pass's first position
     const uint32_t *multi_list; // passes that touch more than one read (the multi-read kernel's work list)
     const uint32_t *n_multi;    // their number
+    uint64_t pass_lo, pass_hi;  // this launch's share of the passes (a batch may be probed slice by slice, as its bases arrive)
 };
 
 // largest r in [0, n_reads] with offsets[r] <= pos (pos <= total, offsets[n_reads] = total)
@@ -1084,10 +1085,11 @@ tbk_probe_kernel(const ProbeArgs p) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
     if (MULTI) { rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0; }  // per-read tallies (zero between passes)
-    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : p.n_passes;
+    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : p.pass_hi - p.pass_lo;
 
     for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
-        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : item;
+        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : p.pass_lo + item;
+        if (MULTI && (pass < p.pass_lo || pass >= p.pass_hi)) continue;  // (the list is the whole batch's, in no order)
         const uint64_t P0 = pass * TBK_PASS;
         // which read(s) does this pass touch?  (wave-uniform)
         const uint64_t r_first = p.pass_read[pass];
@@ -1178,22 +1180,40 @@ extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *d_exc_chunk, const 
 
 // d_codes == nullptr: the read stream is d_bases (ASCII); else it is (d_codes, d_bad16) and d_bases is not read.
 // d_scratch: 2 * pass_cap + 16 words (pass -> read index, the multi-read passes' list, their number).
-extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
-                                       uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch,
-                                       uint64_t pass_cap, int max_blocks, hipEvent_t between, hipStream_t stream) {
-    if (total == 0 || n_reads == 0) return hipSuccess;
-    ProbeArgs p;
+// A probe is launched in two parts so that a batch can be probed slice by slice while its bases are still
+// arriving: tbk_launch_probe_index (needs the offsets only) once, then tbk_launch_probe_range for every slice of
+// passes [pass_lo, pass_hi) once the bases up to (pass_hi * 2048 + 2080) are there.
+static void fill_args(ProbeArgs &p, const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
+                      uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch, uint64_t pass_cap) {
     p.codes = d_codes; p.bad16 = d_bad16; p.n_chunks = (total + 15) / 16;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    if (p.n_passes > pass_cap) return hipErrorInvalidValue;
+    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_scratch + pass_cap; p.n_multi = d_scratch + 2 * pass_cap;
+    p.pass_lo = 0; p.pass_hi = p.n_passes;
+}
+
+extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t n_reads, uint64_t total, int32_t *d_counts, uint32_t *d_scratch,
+                                             uint64_t pass_cap, hipStream_t stream) {
+    if (total == 0 || n_reads == 0) return hipSuccess;
+    const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
+    if (n_passes > pass_cap) return hipErrorInvalidValue;
     uint32_t *d_multi = d_scratch + pass_cap, *d_n_multi = d_scratch + 2 * pass_cap;
-    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_multi; p.n_multi = d_n_multi;
     hipError_t e = hipMemsetAsync(d_n_multi, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((p.n_passes + 255) / 256)), dim3(256), 0, stream,
-                       d_offsets, n_reads, total, p.n_passes, d_scratch, d_multi, d_n_multi, d_counts);
-    uint64_t blocks = (p.n_passes + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((n_passes + 255) / 256)), dim3(256), 0, stream,
+                       d_offsets, n_reads, total, n_passes, d_scratch, d_multi, d_n_multi, d_counts);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
+                                             uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch,
+                                             uint64_t pass_cap, uint64_t pass_lo, uint64_t pass_hi, int max_blocks, hipEvent_t between, hipStream_t stream) {
+    if (total == 0 || n_reads == 0 || pass_hi <= pass_lo) return hipSuccess;
+    ProbeArgs p;
+    fill_args(p, d_bases, d_codes, d_bad16, d_offsets, n_reads, total, t, k, d_counts, d_scratch, pass_cap);
+    if (p.n_passes > pass_cap || pass_hi > p.n_passes) return hipErrorInvalidValue;
+    p.pass_lo = pass_lo; p.pass_hi = pass_hi;
+    uint64_t blocks = (pass_hi - pass_lo + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
     if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
     // the multi-read kernel walks its list with a grid that fills the chip a few times over
     const uint64_t blocks_multi = std::min<uint64_t>(blocks, 16384);
@@ -1202,6 +1222,7 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d
     // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
+    hipError_t e = hipSuccess;
     for (int multi = 1; multi >= 0; multi--) {
 #define TBK_LAUNCH(N, M, S, F) do { if (multi) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, true>), grid_multi, block, 0, stream, p); \
                                     else hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, false>), grid, block, 0, stream, p); } while (0)
@@ -1223,7 +1244,7 @@ extern "C" hipError_t tbk_launch_probe(const uint8_t *d_bases, const uint32_t *d
 #undef TBK_LAUNCH
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        // the event between the two kernels: the host times them separately (tbk_kernel_timing_read)
+        // the event between the two kernels: the host times them separately (tbk_kernel_timing_read2)
         if (multi && between != nullptr) { e = hipEventRecord(between, stream); if (e != hipSuccess) return e; }
     }
     return hipSuccess;
