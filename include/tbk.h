@@ -166,6 +166,10 @@ int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint6
  * line only (the first four slots of each list; csrc/tbk_common.h "front layout"), and how many keys lie
  * behind that front (settled by the deferred walk).  TBK_FRONT=1 / 0 pins the layout. */
 int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_behind_front);
+/* Random 64-byte reads, a quad of lanes per line as the probe asks for a front, over this table where it lies
+ * in HBM: lines per second (a diagnostic: the same table measures up to 15 % differently from one placement in
+ * the device's memory to another). */
+int tbk_classifier_calibrate(tbk_classifier *c, double *lines_per_sec);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,
@@ -233,7 +237,7 @@ int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, const void 
  * are in `counts`, whichever device computed them; *device_slot (optional) = index into `devices` of the ring
  * that did.  Tickets may be waited for in any order; the caller's arrays must stay valid until then.  At most
  * tbk_pipeline_depth() + n_devices batches may be submitted and not yet waited for.  A device may be listed
- * several times (several rings on one GPU).  The handle itself may be used from one thread at a time.
+ * several times: several rings on one GPU, which share that device's (read-only) table.  The handle itself may be used from one thread at a time.
  * Replaces the per-read loop of classify_by_kmers.py:99-102 for any number of GPUs of one node. */
 typedef struct tbk_pipeline tbk_pipeline;
 int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_pipeline **out);

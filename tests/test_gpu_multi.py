@@ -36,7 +36,7 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
     with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
         assert multi.devices == [0, 0, 0] and multi.depth == 9
         st = multi.stats()
-        assert st["devices"] == [0, 0, 0] and st["table_bytes_total"] == 3 * st["table_bytes"]
+        assert st["devices"] == [0, 0, 0] and st["table_bytes_total"] == st["table_bytes"]   # three rings on one device share its table
         for i in range(3):              # every replica on its own (the pipeline is idle)
             part = multi._part(i)
             assert part.stats() == multi._part(0).stats()

@@ -189,3 +189,35 @@ def test_device_list_from_environment(built, monkeypatch):
     assert kmers.default_device() == 5
     monkeypatch.delenv("TBK_DEVICES")
     assert kmers.visible_devices() == list(range(__import__("trio_binning_amd")._lib.device_count()))
+
+
+def test_native_loop_reports_errors_and_handles_empty_input(built, tmp_path):
+    """tbk_classify_file over stub rings: a reads file that does not exist is an IOError (the type the reference's
+    open() raises), an empty reads file gives three valid empty bins and no TSV line, and a ring that fails a batch
+    fails the run instead of writing a partial TSV silently."""
+    import io
+
+    from trio_binning_amd import kmers
+
+    multi = kmers.MultiClassifier.from_classifiers([StubClassifier(0, _lens, 1)])
+    names = [str(tmp_path / n) for n in ("a.fa.gz", "b.fa.gz", "u.fa.gz")]
+    with pytest.raises(IOError):
+        multi.classify_file(str(tmp_path / "nope.fa"), 3, 4, names, True, tsv_fd=-1)
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    with open(tmp_path / "tsv", "wb") as fh:
+        st = multi.classify_file(str(empty), 3, 4, names, True, tsv_fd=fh.fileno())
+    assert st["reads"] == 0 and os.path.getsize(tmp_path / "tsv") == 0
+    assert all(gzip.open(n, "rb").read() == b"" for n in names)
+    multi.close()
+
+    class Broken(StubClassifier):
+        def submit(self, bases, offsets):
+            raise RuntimeError("no device")
+
+    broken = kmers.MultiClassifier.from_classifiers([Broken(0, _lens, 1)])
+    reads = tmp_path / "r.fa"
+    reads.write_text(">r1\nACGTACGTAC\n>r2\nGGGG\n")
+    with pytest.raises(Exception):
+        broken.classify_file(str(reads), 3, 4, names, False, tsv_fd=-1)
+    broken.close()

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <sched.h>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -163,7 +164,33 @@ struct Slot {
 struct tbk_classifier {
     int device = 0;
     int k = 0;
-    uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B: [8 hapA slots | 8 hapB slots]
+    uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B (front layout: [A0-3 | B0-3 | A4-7 | B4-7])
+    // who frees it: the classifiers of one device share one read-only table (several stream rings on one GPU need
+    // no second copy of it); every other device holds its own replica
+    std::shared_ptr<uint64_t> pair_owner;
+    void *pair_base = nullptr;   // what hipMalloc returned (d_pair may be aligned up inside it: TBK_TABLE_ALIGN)
+    void own_pair() {
+        const int dev = device;
+        void *base = pair_base ? pair_base : (void *)d_pair;
+        pair_owner = std::shared_ptr<uint64_t>(d_pair, [dev, base](uint64_t *) { if (base && hipSetDevice(dev) == hipSuccess) (void)hipFree(base); });
+        pair_base = nullptr;
+    }
+    // the table's memory: `bytes`, aligned to TBK_TABLE_ALIGN when that is set (the allocation is made that much larger)
+    hipError_t alloc_pair(size_t bytes) {
+        const size_t align = (size_t)env_double("TBK_TABLE_ALIGN", 0);
+        pair_base = nullptr; d_pair = nullptr;
+        hipError_t e = hipMalloc(&pair_base, bytes + align);
+        if (e != hipSuccess) { pair_base = nullptr; return e; }
+        uintptr_t p = (uintptr_t)pair_base;
+        if (align > 1) p = (p + align - 1) / align * align;
+        d_pair = (uint64_t *)p;
+        return hipSuccess;
+    }
+    void free_pair() {  // before own_pair(): a table that is being rebuilt
+        if (pair_base) (void)hipFree(pair_base);
+        else if (d_pair) (void)hipFree(d_pair);
+        pair_base = nullptr; d_pair = nullptr;
+    }
     uint32_t n_buckets = 0;
     uint64_t distinct_a = 0, distinct_b = 0;
     uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
@@ -827,11 +854,10 @@ static int classifier_streams(tbk_classifier *c) {
 static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past) {
     c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
-    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
+    hipError_t e = c->alloc_pair(bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
     if (e != hipSuccess) {
-        if (c->d_pair) (void)hipFree(c->d_pair);
-        c->d_pair = nullptr;
+        c->free_pair();
         return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table (%zu bytes): %s", bytes, hipGetErrorString(e));
     }
     uint32_t *d_over = nullptr, *d_left = nullptr;
@@ -848,7 +874,7 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
     }
     if (d_over) (void)hipFree(d_over);
     if (d_left) (void)hipFree(d_left);
-    if (rc) { (void)hipFree(c->d_pair); c->d_pair = nullptr; return rc; }
+    if (rc) { c->free_pair(); return rc; }
     c->past_half = past_a + past_b;
     c->behind_front = back_a + back_b;
     *past = past_a + past_b;
@@ -905,7 +931,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (built_t == c->mz.t && load_pinned) break;
         // mod-sampling is not available for this k / table size and the load is pinned: one build, below
         if (pin < 0 && attempt == 0 && c->mz.t == 0 && load_pinned) continue;
-        if (c->d_pair) { (void)hipFree(c->d_pair); c->d_pair = nullptr; }
+        c->free_pair();
         built_t = c->mz.t;
         c->layout_builds++;
         const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : true);
@@ -917,7 +943,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
         if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.006)) {
             // the lists spread, but too many keys lie behind a front: the same table in whole lines
-            (void)hipFree(c->d_pair); c->d_pair = nullptr;
+            c->free_pair();
             c->guests = guests;
             c->layout_builds++;
             rc = build_pair_table(c, a, b, 0.08, &past);
@@ -926,6 +952,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         }
         if (attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
     }
+    c->own_pair();
     rc = classifier_streams(c);
     if (rc) { tbk_classifier_destroy(c); return rc; }
     *out = c;
@@ -951,28 +978,35 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->guests = src->guests;
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
-    hipError_t e = hipMalloc((void **)&c->d_pair, bytes);
-    if (e == hipSuccess) {
-        if (device == src->device) {
-            e = hipMemcpy(c->d_pair, src->d_pair, bytes, hipMemcpyDeviceToDevice);
-        } else {
-            // the finished table travels device to device (xGMI when the two are peers; the runtime
-            // stages through the host otherwise) - once, outside any timed region
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
-                const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    if (device == src->device && src->pair_owner) {
+        // another stream ring on the device that holds the table already: the table is read-only, so it is shared
+        c->d_pair = src->d_pair;
+        c->pair_owner = src->pair_owner;
+    } else {
+        hipError_t e = c->alloc_pair(bytes);
+        if (e == hipSuccess) {
+            if (device == src->device) {
+                e = hipMemcpy(c->d_pair, src->d_pair, bytes, hipMemcpyDeviceToDevice);
+            } else {
+                // the finished table travels device to device (xGMI when the two are peers; the runtime
+                // stages through the host otherwise) - once, outside any timed region
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+                (void)hipGetLastError();
+                e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
             }
-            (void)hipGetLastError();
-            e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-    }
-    if (e != hipSuccess) {
-        if (c->d_pair) (void)hipFree(c->d_pair);
-        delete c;
-        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "replicating the paired table (%zu bytes) to device %d: %s", bytes, device,
-                    hipGetErrorString(e));
+        if (e != hipSuccess) {
+            c->free_pair();
+            delete c;
+            return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "replicating the paired table (%zu bytes) to device %d: %s", bytes, device,
+                        hipGetErrorString(e));
+        }
+        c->own_pair();
     }
     rc = classifier_streams(c);
     if (rc) { tbk_classifier_destroy(c); return rc; }
@@ -1044,6 +1078,37 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
     return TBK_OK;
 }
 
+// Random 64-byte reads (a quad per line, as the probe asks for a front) over THIS table where it lies in HBM:
+// lines per second.  The same table in another place of the device's memory measures up to 15 % differently
+// (EXPERIMENTS.md, round 3); this is the yardstick for that.
+extern "C" int tbk_classifier_calibrate(tbk_classifier *c, double *lines_per_sec) {
+    if (!c || !lines_per_sec) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    const uint64_t bytes = ((uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES) & ~(uint64_t)255;
+    if (bytes < (1u << 20)) { *lines_per_sec = 0; return TBK_OK; }
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 16));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t done = 0;
+    float ms = 0;
+    const uint64_t n_lines = (uint64_t)1 << 27;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_gather(c->d_pair, bytes, 64, 4, 4, n_lines >> 3, 5, sink, &done, c->compute);  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, c->compute);
+    if (e == hipSuccess) e = tbk_launch_gather(c->d_pair, bytes, 64, 4, 4, n_lines, 9, sink, &done, c->compute);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->compute);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(TBK_ERR_HIP, "tbk_classifier_calibrate: %s", hipGetErrorString(e));
+    *lines_per_sec = ms > 0 ? (double)done / (ms * 1e-3) : 0;
+    return TBK_OK;
+}
+
 extern "C" int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared) {
     if (!c || !n_shared) return fail(TBK_ERR_INVALID, "NULL argument");
     *n_shared = c->shared;
@@ -1076,7 +1141,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             for (hipEvent_t e : s.sliced) if (e) (void)hipEventDestroy(e);
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
-        if (c->d_pair) (void)hipFree(c->d_pair);
+        c->pair_owner.reset();  // (the table itself goes with its last user)
         if (c->d_pass_read) (void)hipFree(c->d_pass_read);
         if (c->compute) (void)hipStreamDestroy(c->compute);
         if (c->copy) (void)hipStreamDestroy(c->copy);

@@ -402,6 +402,12 @@ class Classifier:
         check(lib.tbk_kernel_timing_read2(self._h, C.byref(n), C.byref(ms), C.byref(single)))
         return n.value, ms.value, single.value
 
+    def calibrate(self) -> float:
+        """Random 64-byte line reads per second over this table where it lies in HBM (a diagnostic)."""
+        v = C.c_double()
+        check(lib.tbk_classifier_calibrate(self._h, C.byref(v)))
+        return v.value
+
     def last_passes(self) -> Tuple[int, int]:
         """(passes, multi-read passes) of the most recent probe: 2048 window starts each; the multi-read ones
         went through the multi-read kernel, the rest through the single-read kernel."""
@@ -533,7 +539,7 @@ class MultiClassifier:
     def stats(self) -> dict:
         st = dict(self._stubs[0].stats() if self._stubs is not None else self._part(0).stats())
         st["devices"] = list(self.devices)
-        st["table_bytes_total"] = st.get("table_bytes", 0) * len(self.devices)
+        st["table_bytes_total"] = st.get("table_bytes", 0) * len(set(self.devices))  # the rings of one device share its table
         return st
 
     def kernel_timing(self, on: bool) -> None:
