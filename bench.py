@@ -389,7 +389,9 @@ def main():
     del stage
     t_setup = time.time() - t_setup
 
-    depth = pipe.depth
+    # batches the bench keeps submitted: the rings' slots plus one waiting per ring (what the pipeline admits), so
+    # that a feeder whose ring has just got room finds its next batch queued already
+    depth = pipe.depth + len(pipe.devices)
     counts_ring = [kmers.pinned_empty((r_cap, 2), np.int32) for _ in range(depth)]
     num_a, num_b = hap_a.num_kmers, hap_b.num_kmers
     bins_total = {"A": 0, "B": 0, "U": 0}
@@ -413,7 +415,7 @@ def main():
         waiter = pipe.wait if fed else cls.wait
         # host-fed: as many batches submitted as the ring holds (the third one's copy runs beside the first one's
         # kernel); resident: one fewer is enough to keep the compute stream busy
-        ahead = depth if fed else max(1, cls.depth - 1)  # (the resident leg drives ring 0's classifier alone)
+        ahead = depth if fed else max(1, cls.depth - 1)  # (the resident leg drives ring 0's classifier alone, its own ring of 3)
         for i in range(n_steps * launches_per_step):
             d_b, d_o, n_r, tot, packed = batches[i % len(batches)]
             slot = i % depth

@@ -1087,6 +1087,9 @@ tbk_probe_kernel(const ProbeArgs p) {
     if (MULTI) { rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0; }  // per-read tallies (zero between passes)
     const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : p.pass_hi - p.pass_lo;
 
+    // The multi-read kernel walks its list with a fixed grid; the single-read kernel is launched with one block per
+    // pass and has no loop around the pass: the loop's live state cost it 8 spilled registers, and a kernel that
+    // uses scratch memory at all ran 18-22 ms from one stream to the next where this one runs 18-19 (EXPERIMENTS.md).
     for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
         const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : p.pass_lo + item;
         if (MULTI && (pass < p.pass_lo || pass >= p.pass_hi)) continue;  // (the list is the whole batch's, in no order)
@@ -1096,7 +1099,7 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
         if (!MULTI) {
             const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
-            if (last_pos >= r_end) continue;  // the multi-read kernel's
+            if (last_pos >= r_end) return;  // the multi-read kernel's
         }
         if (p.codes != nullptr) {  // packed input (wave-uniform): the chunk words are there already
             const uint64_t c0 = P0 / 16 + lane;
@@ -1113,6 +1116,7 @@ tbk_probe_kernel(const ProbeArgs p) {
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         probe_pass<W, M64, SAMP, MULTI, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave], sink[wave]);
+        if (!MULTI) return;  // one pass per block
     }
 }
 
@@ -1213,10 +1217,10 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     fill_args(p, d_bases, d_codes, d_bad16, d_offsets, n_reads, total, t, k, d_counts, d_scratch, pass_cap);
     if (p.n_passes > pass_cap || pass_hi > p.n_passes) return hipErrorInvalidValue;
     p.pass_lo = pass_lo; p.pass_hi = pass_hi;
-    uint64_t blocks = (pass_hi - pass_lo + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;
-    if (max_blocks > 0 && blocks > (uint64_t)max_blocks) blocks = (uint64_t)max_blocks;
-    // the multi-read kernel walks its list with a grid that fills the chip a few times over
-    const uint64_t blocks_multi = std::min<uint64_t>(blocks, 16384);
+    const uint64_t blocks = (pass_hi - pass_lo + TBK_WAVES_PER_BLOCK - 1) / TBK_WAVES_PER_BLOCK;  // single-read kernel: one block per pass
+    // the multi-read kernel walks its list with a grid that fills the chip a few times over (max_blocks caps it: a test knob)
+    uint64_t blocks_multi = std::min<uint64_t>(blocks, 16384);
+    if (max_blocks > 0 && blocks_multi > (uint64_t)max_blocks) blocks_multi = (uint64_t)max_blocks;
     const dim3 grid((unsigned)blocks), grid_multi((unsigned)blocks_multi), block(64 * TBK_WAVES_PER_BLOCK);
     // kernel variant: W m-mers per span; 32-bit (m <= 16) or 64-bit m-mers; random-minimizer or
     // mod-sampling selection; front or whole-line layout

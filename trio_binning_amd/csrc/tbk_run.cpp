@@ -96,8 +96,10 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     rc = tbk_bin_writer_open(out_a, out_b, out_u, gzip_output, gzip_level, 0, &writer);
     if (rc) { tbk_fastx_close(reader); return rc; }
 
-    const int depth = tbk_pipeline_depth(p);
-    const int n_items = depth + 3;  // in flight on the device(s) + one apiece for reader, queues and writer
+    // batches kept submitted: the rings' slots plus one waiting per ring (what the pipeline admits), so that a feeder
+    // whose ring has just got room finds its next batch queued already
+    const int depth = tbk_pipeline_depth(p) + tbk_pipeline_devices(p);
+    const int n_items = depth + 3;  // submitted + one apiece for reader, queues and writer
     std::vector<Item> items((size_t)n_items);
     Chan<Item *> free_q, filled_q, done_q;
     Failure failure;
