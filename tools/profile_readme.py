@@ -122,8 +122,9 @@ if tr2:
     out += [f"Under `python -m torch.distributed.run`: value {tr2['value']}, parity all_ranks_equal = {g(tr2, 'parity', 'all_ranks_equal')}."]
 rings3 = load("bench_3rings.json")
 if rings3:
-    out += [f"Three feeder threads + rings + table replicas on the one device (`--rings 3`, SURVEY 8e's per-device feeders dealing from one queue): value {rings3['value']} Gbases/s "
-            f"(one ring, same script: {g(u, 'value')}), batches per ring {g(rings3, 'config', 'batches_per_ring')}, parity {g(rings3, 'parity', 'all_ranks_equal')}."]
+    out += [f"Three feeder threads + rings on the one device, sharing its table (`--rings 3`: the pipeline's dealing from one queue, as it would run over three GPUs): value {rings3['value']} Gbases/s "
+            f"(one ring, same script: {g(u, 'value')}: a 20-step region fills and drains three rings instead of one, and one ring already keeps a GPU busy), "
+            f"batches per ring {g(rings3, 'config', 'batches_per_ring')}, parity {g(rings3, 'parity', 'all_ranks_equal')}."]
 for nm, label in (("bench_c5_uniform.json", "uniform"), ("bench_c5_haplotypes.json", "haplotype-shaped")):
     c5 = load(nm)
     if c5:
