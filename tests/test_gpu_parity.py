@@ -541,8 +541,8 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
     """Without TBK_MOD_SAMPLING / TBK_TABLE_LOAD the lists decide how buckets are selected and how roomy
     the table is: keys that fall evenly into buckets keep mod-sampling at load 0.08 (one build), lists
     that cluster the way real find-unique-kmers output does (runs of overlapping k-mers around
-    variants) are rebuilt with the random minimizer at load 0.04, both in the front layout.  Either way,
-    and with the rule or the load pinned, the counts are the oracle's."""
+    variants) are rebuilt with the random minimizer in whole lines, at the same load.  Either way, and with
+    the rule or the load pinned, the counts are the oracle's."""
     import ctypes as C
 
     from trio_binning_amd import kmers
@@ -589,11 +589,11 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
             assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
-            # both are probed front-first (64 of a line's 128 bytes; the back half only where a list has keys there);
-            # lists that spread leave few keys behind the first four slots of a bucket
-            assert st["front_layout"] and (not want_t or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
+            # lists that spread are probed front-first (64 of a line's 128 bytes; few of their keys lie behind the first
+            # four slots of a bucket), clustered ones in whole lines
+            assert st["front_layout"] == want_t and (not want_t or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
             load = half / (st["n_buckets"] * 8)
-            assert abs(load - (0.08 if want_builds == 1 else 0.04)) < 0.005, (name, load)
+            assert abs(load - 0.08) < 0.005, (name, load)   # 100 B of HBM per key either way
             assert np.array_equal(cls.classify_batch(bases, offs), want), name
         for pin in ("0", "1"):
             monkeypatch.setenv("TBK_MOD_SAMPLING", pin)   # the rule is pinned, the load still follows the lists

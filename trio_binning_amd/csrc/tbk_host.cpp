@@ -291,15 +291,13 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 
 // ---- tables ----------------------------------------------------------------------------
 static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes) {
-    // Target load (keys per slot).  A probe should be decided by the 64 bytes it asks for first: a lookup looks
-    // at the back half of its line only where its list has keys there, and leaves the line only when keys did.
-    // Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing puts keys that share a sampled
-    // m-mer into one bucket, and real lists cluster further (the k overlapping k-mers around one variant
-    // share ~6 minimizers, in both lists at once).  Measured at 2 x 3e8 keys, front layout, 5 waves per SIMD
-    // (profiles/r03/): uniform lists 166-174 Gbases/s at load 0.08 (60 GB) = 0.06 = 0.04 within the box-to-box
-    // spread, 148 at 0.12, 136 at 0.16; haplotype-shaped lists 140 at 0.04 (120 GB), 133 at 0.06, 125 at 0.08.
-    // So lists that spread get 0.08 and lists that cluster 0.04 (tbk_classifier_create).  The table is capped
-    // at 60 % of the device's memory; bigger lists get a proportionally higher load.  TBK_TABLE_LOAD overrides.
+    // Target load (keys per slot).  Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing puts
+    // keys that share a sampled m-mer into one bucket, and real lists cluster further, so it gets 0.64 keys per
+    // half: load 0.08, 100 B of HBM per key, 2 x 3e8 keys = 60 GB.  Measured at that scale, resident, same box
+    // (profiles/r03/ab_policy.log): uniform lists, front layout: load 0.08 184 Gbases/s, 0.12 (67 B per key) 169,
+    // 0.16 (50 B) 152; haplotype-shaped lists in whole lines at 0.08: 138 (front layout at 0.04, 120 GB: 145).
+    // The table is capped at 60 % of the device's memory; bigger lists get a proportionally higher load.
+    // TBK_TABLE_LOAD overrides.
     double load = env_double("TBK_TABLE_LOAD", 0);
     const bool forced = load > 0;
     if (!forced) load = default_load;
@@ -898,17 +896,20 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
     c->slice_bases = (uint64_t)std::max(2048.0, env_double("TBK_SLICE_BASES", (double)((uint64_t)384 << 20)));
     // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers, default 6;
-    // 0 = plain hashing of the whole key).  Which m-mer is sampled, and how roomy the table is, is decided by
-    // the lists.  Mod-sampling switches lines 18 % less often than the random minimizer and is the faster rule
-    // on lists whose keys fall evenly into buckets (BASELINE's uniform lists); lists that cluster the way real
-    // find-unique-kmers output does (the k overlapping k-mers around one variant share ~6 minimizers, in both
-    // lists at once) overflow more fronts under mod-sampling's longer runs per bucket (haplotype-shaped lists,
-    // front layout, load 0.04: 127 against 140 Gbases/s) and care about room (0.04: 140, 0.08: 125).  Nothing
-    // of that is observable in the results and building the table takes a fraction of a second, so: build with
-    // mod-sampling at load 0.08; if more than TBK_CLUSTERED (default 0.3 %) of the keys found their own half of
-    // their home line full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), build again with the random
-    // minimizer at load 0.04.  TBK_MOD_SAMPLING=1 / 0 pins the rule (the load still follows the lists),
-    // TBK_TABLE_LOAD pins the load.
+    // 0 = plain hashing of the whole key).  Which m-mer is sampled, and in which layout the probe reads a line,
+    // is decided by the lists; the load is 0.08 either way (100 B of HBM per key).  Mod-sampling switches lines
+    // 18 % less often than the random minimizer and is the faster rule on lists whose keys fall evenly into buckets
+    // (BASELINE's uniform lists: 184 Gbases/s front-first).  Lists that cluster the way real find-unique-kmers
+    // output does (the k overlapping k-mers around one variant share ~6 minimizers, in both lists at once) overflow
+    // the fronts - one window in 13 to 17 needs the back half of its line - and longer runs per bucket make that
+    // worse, so they get the random minimizer and whole lines (two requests per line, both halves at hand).
+    // Measured on haplotype-shaped lists, same box, resident (profiles/r03/ab_policy.log): whole lines, random
+    // minimizer, load 0.08 (60 GB) 138 Gbases/s; front, random minimizer 0.08 129, 0.04 (120 GB) 145; front,
+    // mod-sampling 0.08 122, 0.04 133.  Half the memory for 4 %: 0.08 in whole lines it is.  Nothing of that is
+    // observable in the results and building the table takes a fraction of a second, so: build with mod-sampling,
+    // front-first; if more than TBK_CLUSTERED (default 0.3 %) of the keys found their own half of their home line
+    // full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), build again with the random minimizer in whole lines.
+    // TBK_MOD_SAMPLING=1 / 0 pins the rule, TBK_FRONT the layout, TBK_TABLE_LOAD the load.
     const double pin = env_double("TBK_MOD_SAMPLING", -1);
     const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
@@ -934,10 +935,10 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         c->free_pair();
         built_t = c->mz.t;
         c->layout_builds++;
-        const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : true);
+        const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : attempt == 0);  // clustered lists: whole lines (below)
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
-        rc = build_pair_table(c, a, b, attempt == 0 ? 0.08 : 0.04, &past);
+        rc = build_pair_table(c, a, b, 0.08, &past);
         if (rc) { delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
