@@ -919,10 +919,10 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list first); a
     // window that misses in a front whose list has keys behind it is queued, and the queue is settled 16
     // windows at a time from the back half of the line, which the L2 holds already (tbk_kernels.hip:
-    // drain_back).  One request per line instead of two, and - 96 VGPRs - five waves per SIMD.  Both
-    // sampling rules use it since round 3.  Lists that spread but still leave more than TBK_BEHIND_FRONT
-    // (default 0.6 %) of their keys behind a front (tables denser than the default) get the same table in
-    // whole lines, as does TBK_FRONT=0.
+    // drain_back).  One request per line instead of two.  Lists that spread keep it while at most
+    // TBK_BEHIND_FRONT (default 5 %) of their keys lie behind a front - at the default load 0.3 % do, and denser
+    // tables still gain from it (load 0.12: 0.7 % behind, 169 Gbases/s front-first against 151 in whole lines);
+    // clustered lists and TBK_FRONT=0 get whole lines.
     const double front_pin = env_double("TBK_FRONT", -1);
     int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -942,7 +942,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (rc) { delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
-        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.006)) {
+        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.05)) {
             // the lists spread, but too many keys lie behind a front: the same table in whole lines
             c->free_pair();
             c->guests = guests;
