@@ -233,9 +233,6 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #ifndef TBK_UNROLL
 #define TBK_UNROLL 2      // j-loop unroll of the probe pass
 #endif
-#ifndef TBK_LOOKAHEAD
-#define TBK_LOOKAHEAD 0   // 1: each step asks for the lines of the next one (see probe_pass)
-#endif
 #ifndef TBK_SAMP_UNROLL
 #define TBK_SAMP_UNROLL 4 // j-loop unroll of the mod-sampling variants
 #endif
@@ -301,33 +298,6 @@ __device__ __forceinline__ uint64_t find_read(const uint64_t *offsets, uint64_t 
         if (offsets[mid] <= pos) lo = mid; else hi = mid;
     }
     return lo;
-}
-
-// Look-ahead builds (TBK_LOOKAHEAD): the line loads of the probe loop are issued and waited for by
-// hand.  hipcc drains the VM counter completely (vmcnt(0)) at the first use of a load result while an
-// LDS-DMA is in flight, which would make every step wait for the look-ahead load it has just issued;
-// issued from inline asm the line loads are invisible to that bookkeeping, and tbk_wait_lines() waits
-// with the exact count instead: "all but the youngest one" - the look-ahead load, issued after them.
-// (The counter is in order, so loads the compiler does know about are at worst waited for longer.)
-typedef uint32_t tbk_v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_line_async(const uint64_t *line, ulonglong2 &a, ulonglong2 &b) {
-    tbk_v4u x = __builtin_bit_cast(tbk_v4u, a), y = __builtin_bit_cast(tbk_v4u, b);
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64" : "+v"(x), "+v"(y) : "v"(line));
-    a = __builtin_bit_cast(ulonglong2, x);
-    b = __builtin_bit_cast(ulonglong2, y);
-}
-__device__ __forceinline__ void tbk_wait_lines(ulonglong2 (&va)[4], ulonglong2 (&vb)[4]) {
-    tbk_v4u a0 = __builtin_bit_cast(tbk_v4u, va[0]), a1 = __builtin_bit_cast(tbk_v4u, va[1]), a2 = __builtin_bit_cast(tbk_v4u, va[2]),
-            a3 = __builtin_bit_cast(tbk_v4u, va[3]), b0 = __builtin_bit_cast(tbk_v4u, vb[0]), b1 = __builtin_bit_cast(tbk_v4u, vb[1]),
-            b2 = __builtin_bit_cast(tbk_v4u, vb[2]), b3 = __builtin_bit_cast(tbk_v4u, vb[3]);
-#ifdef TBK_LA_NOPF
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-#else
-    asm volatile("s_waitcnt vmcnt(1)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
-#endif
-    va[0] = __builtin_bit_cast(ulonglong2, a0); va[1] = __builtin_bit_cast(ulonglong2, a1); va[2] = __builtin_bit_cast(ulonglong2, a2);
-    va[3] = __builtin_bit_cast(ulonglong2, a3); vb[0] = __builtin_bit_cast(ulonglong2, b0); vb[1] = __builtin_bit_cast(ulonglong2, b1);
-    vb[2] = __builtin_bit_cast(ulonglong2, b2); vb[3] = __builtin_bit_cast(ulonglong2, b3);
 }
 
 // 16 bytes (two slots) of a bucket line.  -DTBK_NT_LOADS marks the load non-temporal: a line is used by the
@@ -520,7 +490,7 @@ template <int W, bool M64, bool SAMP, bool MULTI, bool FRONT>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                           uint4 *walkq, uint4 *backq, uint32_t *rcnt, uint32_t *sink) {
+                                           uint4 *walkq, uint4 *backq, uint32_t *rcnt) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 3u;
@@ -707,17 +677,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     };
     // mod-sampling: a deeper unroll lets the 2W-deep shift register be renamed instead of moved
     constexpr int kUnroll = SAMP ? TBK_SAMP_UNROLL : TBK_UNROLL;
-    constexpr bool LA = TBK_LOOKAHEAD && !MULTI && !FRONT;  // single-read passes only: the multi-read pass has no scalar registers to spare
-    // One window of look-ahead.  A wave that asks for its lines and then needs them at once sits
-    // out the whole HBM latency every step, and four waves per SIMD do not cover it (measured: the
-    // kernel moved 0.79 of the line ceiling).  So the bucket of window j+1 is worked out during step j,
-    // after step j's own loads have been issued, and every lane touches its next line with a 4-byte
-    // load that lands in LDS (global_load_lds: no VGPR, nothing to wait for, and being younger
-    // than the step's real loads it does not hold up the wait for them).  A step later the real
-    // loads find the line in L2 or on its way.  Lanes whose next window stays in the same line touch
-    // bucket 0 instead (one address for all of them).
-    uint32_t bkt_next = 0;
-    if (LA) bkt_next = bucket_here(0);
 #pragma unroll kUnroll
     for (int j = 0; j < TBK_WPL; j++) {
         // ---- this lane's window j ---------------------------------------------------
@@ -737,9 +696,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         }
         bool ok = (bad_lo & badk) == 0;  // single-read pass: the read end is part of the mask
         if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
-        uint32_t bkt;
-        if (LA) bkt = bkt_next;   // worked out one window ago, its line asked for then
-        else bkt = bucket_here(j);
+        const uint32_t bkt = bucket_here(j);
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
         // TBK_NOKEY, which is never stored (it can never hit)
         // Bit 31 of the broadcast bucket says "not the bucket of this lane's previous window": only
@@ -769,8 +726,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 const uint64_t *line = p.t.slots + (uint64_t)(bk[s] & 0x7FFFFFFFu) * 16 + sub * 2;
                 if (FRONT) {
                     va[s] = load_slots(line);  // the front of the line: [A0 A1 | A2 A3 | B0 B1 | B2 B3], 16 bytes per quad lane
-                } else if (LA) {
-                    load_line_async(line, va[s], vb[s]);
                 } else {
                     va[s] = load_slots(line);
                     vb[s] = load_slots(line + 8);
@@ -778,21 +733,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             }
         }
 
-        if (LA) {
-            if (j + 1 < TBK_WPL) bkt_next = bucket_here(j + 1);
-#ifdef TBK_LA_COMMON
-            const uint32_t ahead = bkt_next != bkt ? bkt_next : 0u;   // lanes that stay in their line all touch bucket 0
-#else
-            const uint32_t ahead = bkt_next;                          // ... or the line they hold (no address shared by the whole chip)
-#endif
-#ifndef TBK_LA_NOPF
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p.t.slots + (uint64_t)ahead * 16),
-                                             (__attribute__((address_space(3))) void *)sink, 4, 0, 0);
-#else
-            asm volatile("" :: "v"(ahead));
-#endif
-            tbk_wait_lines(va, vb);  // this step's lines are in; the look-ahead load stays in flight
-        }
         if constexpr (FRONT) {
             // Front layout (tbk_common.h): quad lanes 0,1 hold hapA's first four slots of the line, lanes 2,3
             // hapB's.  One compare pair serves both lists - which list a hit counts for is the lane it
@@ -1075,7 +1015,6 @@ tbk_probe_kernel(const ProbeArgs p) {
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_QCAP_FRONT : TBK_QCAP];
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_BQCAP : 1];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : 1];
-    __shared__ uint32_t sink[TBK_WAVES_PER_BLOCK][64];  // where the look-ahead loads land (never read)
     const uint32_t lane = threadIdx.x & 63u;
 #if TBK_OCC_PAD
     __shared__ uint32_t occ_pad[TBK_OCC_PAD / 4];
@@ -1115,7 +1054,7 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass<W, M64, SAMP, MULTI, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave], sink[wave]);
+        probe_pass<W, M64, SAMP, MULTI, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave]);
         if (!MULTI) return;  // one pass per block
     }
 }
