@@ -537,12 +537,12 @@ def test_streaming_order_and_overlap(gpu, orc, tmp_path):
         assert np.array_equal(got, orc.count_batch(bases, offs, oa, ob))
 
 
-def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
-    """Without TBK_MOD_SAMPLING / TBK_TABLE_LOAD the lists decide how buckets are selected and how roomy
-    the table is: keys that fall evenly into buckets keep mod-sampling at load 0.08 (one build), lists
-    that cluster the way real find-unique-kmers output does (runs of overlapping k-mers around
-    variants) are rebuilt with the random minimizer in whole lines, at the same load.  Either way, and with
-    the rule or the load pinned, the counts are the oracle's."""
+def test_lists_choose_the_line_layout(gpu, orc, monkeypatch):
+    """Without TBK_FRONT the lists decide in which layout the probe reads a bucket's line: keys that fall
+    evenly into buckets are read front-first (one build), lists that cluster the way real find-unique-kmers
+    output does (runs of overlapping k-mers around variants) are built again in whole lines - same sampling
+    rule (mod-sampling unless TBK_MOD_SAMPLING=0), same load (0.08 unless TBK_TABLE_LOAD).  Either way, and
+    with the rule, the layout or the load pinned, the counts are the oracle's."""
     import ctypes as C
 
     from trio_binning_amd import kmers
@@ -577,7 +577,7 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
     def decode(key):
         return "".join("ACGT"[(int(key) >> (2 * i)) & 3] for i in range(k))
 
-    for name, keys, half, want_t, want_builds in (("uniform", uni, n, True, 1), ("clustered", hap, m, False, 2)):
+    for name, keys, half, want_front, want_builds in (("uniform", uni, n, True, 1), ("clustered", hap, m, False, 2)):
         ka, kb = keys[:half], keys[half:]
         oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
         plants = [decode(x) for x in np.concatenate([ka[:300], kb[:300]])]
@@ -588,41 +588,34 @@ def test_lists_choose_the_sampling_rule(gpu, orc, monkeypatch):
         a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
-            assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, st)
+            assert st["sampling_t"] > 0 and st["layout_builds"] == want_builds, (name, st)
             # lists that spread are probed front-first (64 of a line's 128 bytes; few of their keys lie behind the first
             # four slots of a bucket), clustered ones in whole lines
-            assert st["front_layout"] == want_t and (not want_t or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
+            assert st["front_layout"] == want_front and (not want_front or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
             load = half / (st["n_buckets"] * 8)
             assert abs(load - 0.08) < 0.005, (name, load)   # 100 B of HBM per key either way
             assert np.array_equal(cls.classify_batch(bases, offs), want), name
         for pin in ("0", "1"):
-            monkeypatch.setenv("TBK_MOD_SAMPLING", pin)   # the rule is pinned, the load still follows the lists
+            monkeypatch.setenv("TBK_MOD_SAMPLING", pin)   # the rule is pinned, the layout still follows the lists
             with kmers.Classifier(a, b) as cls:
                 st = cls.stats()
-                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == want_builds, (name, pin, st)
+                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == want_builds and st["front_layout"] == want_front, (name, pin, st)
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin)
-            monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")   # both pinned: one build
+            monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")   # and the load
             with kmers.Classifier(a, b) as cls:
                 st = cls.stats()
-                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == 1, (name, pin, st)
+                assert (st["sampling_t"] > 0) == (pin == "1") and st["front_layout"] == want_front, (name, pin, st)
                 assert abs(half / (st["n_buckets"] * 8) - 0.1) < 0.005
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin, "load")
             monkeypatch.delenv("TBK_TABLE_LOAD")
         monkeypatch.delenv("TBK_MOD_SAMPLING")
-        for front in ("0", "1"):                          # the layout pinned either way
+        for front in ("0", "1"):                          # the layout pinned either way: one build
             monkeypatch.setenv("TBK_FRONT", front)
-            monkeypatch.setenv("TBK_MOD_SAMPLING", "1")
             with kmers.Classifier(a, b) as cls:
-                assert cls.stats()["front_layout"] == (front == "1"), (name, front, cls.stats())
+                st = cls.stats()
+                assert st["front_layout"] == (front == "1") and st["layout_builds"] == 1 and st["sampling_t"] > 0, (name, front, st)
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, "front", front)
-            monkeypatch.delenv("TBK_MOD_SAMPLING")
         monkeypatch.delenv("TBK_FRONT")
-        monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")       # the load is pinned, the rule still follows the lists
-        with kmers.Classifier(a, b) as cls:
-            st = cls.stats()
-            assert (st["sampling_t"] > 0) == want_t and st["layout_builds"] == want_builds, (name, "load pinned", st)
-            assert np.array_equal(cls.classify_batch(bases, offs), want), (name, "load pinned")
-        monkeypatch.delenv("TBK_TABLE_LOAD")
 
 
 def test_prepacked_batches(gpu, orc, transfer):

@@ -34,7 +34,7 @@ python tools/profile_summary.py gpurun_out > gpurun_out/profile_summary.log 2>&1
 find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete; find gpurun_out -name "*counter_collection.csv" -size +2M -delete
 # host side of the boundary
 ( timeout 600 python tools/measure_reader.py --qual hifi ) > gpurun_out/reader_hifi.json 2> gpurun_out/reader_hifi.err
-( timeout 1500 python tools/measure_e2e.py ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
+( timeout 1500 python tools/measure_e2e.py --devices 0,0,0 ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
 ( timeout 600 python tools/measure_cli.py --reads 60000 --gz-input ) > gpurun_out/cli_gz_input.json 2> gpurun_out/cli_gz_input.err
 tail -c 600 gpurun_out/reader_hifi.json; tail -c 1500 gpurun_out/cli_configs1.json
 exit 0

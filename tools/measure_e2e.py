@@ -31,6 +31,7 @@ ap.add_argument("--read-len", type=int, default=15_000)
 ap.add_argument("--k", type=int, default=21)
 ap.add_argument("--dir", default=None)
 ap.add_argument("--modes", default="plain,gzip")
+ap.add_argument("--devices", default="", help="also run the plain mode with TBK_DEVICES set to this list (e.g. 0,0,0: three rings on one GPU)")
 ap.add_argument("--keep", action="store_true")
 a = ap.parse_args()
 
@@ -121,9 +122,14 @@ for key in ("TBK_LIST_CACHE", "TBK_LIST_GPU_PARSE"):
 
 # ---- the command line ---------------------------------------------------------------------------------
 env = dict(os.environ, PYTHONPATH=ROOT, TBK_STATS="1")
-for mode in a.modes.split(","):
-    for cache in ("text_lists", "cached_lists"):
+runs = [(mode, cache) for mode in a.modes.split(",") for cache in ("text_lists", "cached_lists")]
+if a.devices:
+    runs.append(("plain", "devices_" + a.devices.replace(",", "_")))
+for mode, cache in runs:
+    if True:
         e = dict(env, TBK_LIST_CACHE="0") if cache == "text_lists" else dict(env)
+        if cache.startswith("devices_"):
+            e["TBK_DEVICES"] = a.devices
         out = os.path.join(tmp, mode + "_" + cache)
         os.makedirs(out)
         tsv = os.path.join(out, "stdout.tsv")

@@ -123,7 +123,7 @@ if tr2:
 rings3 = load("bench_3rings.json")
 if rings3:
     out += [f"Three feeder threads + rings on the one device, sharing its table (`--rings 3`: the pipeline's dealing from one queue, as it would run over three GPUs): value {rings3['value']} Gbases/s "
-            f"(one ring, same script: {g(u, 'value')}: a 20-step region fills and drains three rings instead of one, and one ring already keeps a GPU busy), "
+            f"(one ring, same script: {g(u, 'value')}; the rings of one device share its three streams), "
             f"batches per ring {g(rings3, 'config', 'batches_per_ring')}, parity {g(rings3, 'parity', 'all_ranks_equal')}."]
 for nm, label in (("bench_c5_uniform.json", "uniform"), ("bench_c5_haplotypes.json", "haplotype-shaped")):
     c5 = load(nm)

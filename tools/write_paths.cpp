@@ -1,0 +1,79 @@
+// write_paths.cpp: how fast can N threads put G gigabytes into ONE regular file?
+//   pwrite : every thread pwrite()s its 8 MiB slices at their offsets (buffered writes take the inode lock)
+//   mmap   : the file is grown with ftruncate, mapped shared, and the threads memcpy their slices into the mapping
+//   mmap+fa: the same behind posix_fallocate (space reserved first: ENOSPC instead of SIGBUS)
+// Build: g++ -O2 -pthread tools/write_paths.cpp -o /tmp/write_paths ; run: /tmp/write_paths DIR [GB] [threads]
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv) {
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    const size_t total = (size_t)(atof(argc > 2 ? argv[2] : "8") * (1 << 30));
+    const int nt = argc > 3 ? atoi(argv[3]) : 16;
+    const size_t slice = (size_t)8 << 20, window = (size_t)64 << 20;  // a "batch" share of one bin
+    std::vector<char> src(window);
+    for (size_t i = 0; i < src.size(); i++) src[i] = "ACGT"[(i * 2654435761u >> 13) & 3];
+    auto run = [&](const char *label, int mode, int files) {
+        std::vector<int> fds;
+        std::vector<std::string> names;
+        for (int f = 0; f < files; f++) {
+            names.push_back(dir + "/write_paths_" + std::to_string(getpid()) + "_" + std::to_string(f));
+            fds.push_back(open(names.back().c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600));
+            if (fds.back() < 0) { perror("open"); exit(1); }
+        }
+        const double t0 = now();
+        const size_t per_file = total / files;
+        for (size_t off = 0; off < per_file; off += window) {
+            const size_t n = std::min(window, per_file - off);
+            std::vector<char *> maps(files, nullptr);
+            if (mode >= 1)
+                for (int f = 0; f < files; f++) {
+                    if (mode == 2) { if (posix_fallocate(fds[f], (off_t)off, (off_t)n)) { perror("fallocate"); exit(1); } }
+                    else if (ftruncate(fds[f], (off_t)(off + n))) { perror("ftruncate"); exit(1); }
+                    maps[f] = (char *)mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fds[f], (off_t)off);
+                    if (maps[f] == MAP_FAILED) { perror("mmap"); exit(1); }
+                }
+            std::atomic<size_t> next{0};
+            const size_t per = (n + slice - 1) / slice, jobs = per * files;
+            auto work = [&]() {
+                for (size_t j; (j = next.fetch_add(1)) < jobs;) {
+                    const int f = (int)(j % files);
+                    const size_t o = (j / files) * slice, len = std::min(slice, n - o);
+                    if (mode >= 1) memcpy(maps[f] + o, src.data() + o, len);
+                    else {
+                        size_t done = 0;
+                        while (done < len) { ssize_t k = pwrite(fds[f], src.data() + o + done, len - done, (off_t)(off + o + done)); if (k < 0) { perror("pwrite"); exit(1); } done += (size_t)k; }
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+            for (int f = 0; f < files; f++) if (maps[f]) munmap(maps[f], n);
+        }
+        const double t1 = now();
+        for (int f = 0; f < files; f++) { close(fds[f]); unlink(names[f].c_str()); }
+        printf("%-8s files %d threads %2d: %6.2f GB/s (%.2f s for %.1f GB; unlink %.2f s)\n", label, files, nt, total / 1e9 / (t1 - t0), t1 - t0, total / 1e9, now() - t1);
+        fflush(stdout);
+    };
+    for (int files : {1, 3}) {
+        run("pwrite", 0, files);
+        run("mmap", 1, files);
+        run("mmap+fa", 2, files);
+    }
+    return 0;
+}

@@ -161,9 +161,28 @@ struct Slot {
     bool counts_staged = false;
 };
 
+// The three streams of a device's rings.  Several rings on ONE device (TBK_DEVICES=0,0,0) share them: the runtime maps
+// a process's streams onto a handful of hardware queues (4 by default), and nine streams on four queues put one
+// ring's copy in front of another ring's kernels (three rings of their own streams: 122 Gbases/s where one ring
+// does 178; GPU_MAX_HW_QUEUES=8: 166 - profiles/r03/ab_rings_hw_queues.log).  `enqueue` keeps one batch's sequence of
+// launches together on the shared streams (the feeder threads of the rings submit concurrently).
+struct DeviceStreams {
+    int device = 0;
+    hipStream_t compute = nullptr, copy = nullptr, out = nullptr;
+    std::mutex enqueue;
+    std::atomic<int> in_flight{0};  // batches submitted and not yet waited for, over all rings of the device
+    ~DeviceStreams() {
+        if (hipSetDevice(device) != hipSuccess) return;
+        if (compute) (void)hipStreamDestroy(compute);
+        if (copy) (void)hipStreamDestroy(copy);
+        if (out) (void)hipStreamDestroy(out);
+    }
+};
+
 struct tbk_classifier {
     int device = 0;
     int k = 0;
+    std::shared_ptr<DeviceStreams> streams;
     uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B (front layout: [A0-3 | B0-3 | A4-7 | B4-7])
     // who frees it: the classifiers of one device share one read-only table (several stream rings on one GPU need
     // no second copy of it); every other device holds its own replica
@@ -829,10 +848,18 @@ extern "C" int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n
 
 // ---- classifier ------------------------------------------------------------------------
 // streams and the ticket ring's events (the current device is the classifier's)
-static int classifier_streams(tbk_classifier *c) {
-    hipError_t e = hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->out, hipStreamNonBlocking);
+static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_device = nullptr) {
+    hipError_t e = hipSuccess;
+    if (same_device && same_device->streams && same_device->device == c->device) {
+        c->streams = same_device->streams;
+    } else {
+        c->streams = std::make_shared<DeviceStreams>();
+        c->streams->device = c->device;
+        e = hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->copy, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->out, hipStreamNonBlocking);
+    }
+    c->compute = c->streams->compute; c->copy = c->streams->copy; c->out = c->streams->out;
     for (int i = 0; i < RING && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
@@ -896,62 +923,44 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
     c->slice_bases = (uint64_t)std::max(2048.0, env_double("TBK_SLICE_BASES", (double)((uint64_t)384 << 20)));
     // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers, default 6;
-    // 0 = plain hashing of the whole key).  Which m-mer is sampled, and in which layout the probe reads a line,
-    // is decided by the lists; the load is 0.08 either way (100 B of HBM per key).  Mod-sampling switches lines
-    // 18 % less often than the random minimizer and is the faster rule on lists whose keys fall evenly into buckets
-    // (BASELINE's uniform lists: 184 Gbases/s front-first).  Lists that cluster the way real find-unique-kmers
-    // output does (the k overlapping k-mers around one variant share ~6 minimizers, in both lists at once) overflow
-    // the fronts - one window in 13 to 17 needs the back half of its line - and longer runs per bucket make that
-    // worse, so they get the random minimizer and whole lines (two requests per line, both halves at hand).
-    // Measured on haplotype-shaped lists, same box, resident (profiles/r03/ab_policy.log): whole lines, random
-    // minimizer, load 0.08 (60 GB) 138 Gbases/s; front, random minimizer 0.08 129, 0.04 (120 GB) 145; front,
-    // mod-sampling 0.08 122, 0.04 133.  Half the memory for 4 %: 0.08 in whole lines it is.  Nothing of that is
-    // observable in the results and building the table takes a fraction of a second, so: build with mod-sampling,
+    // 0 = plain hashing of the whole key) by mod-sampling, which switches lines 18 % less often than the random
+    // minimizer; the load is 0.08 (100 B of HBM per key).  In which layout the probe reads a line is decided by
+    // the lists.  Front layout (tbk_common.h): the probe kernel asks for 64 bytes of a line, the first four slots
+    // of each list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list first); a
+    // window that misses in a front whose list has keys behind it is queued, and the queue is settled 16 windows
+    // at a time from the back half of the line, which the L2 holds already (tbk_kernels.hip: drain_back).  One
+    // request per line instead of two: the faster layout on lists whose keys fall evenly into buckets (BASELINE's
+    // uniform lists: 184 Gbases/s; at load 0.12, 0.7 % of the keys behind a front: 169 against 151 in whole lines).
+    // Lists that cluster the way real find-unique-kmers output does (the k overlapping k-mers around one variant
+    // share ~5 sampled m-mers, in both lists at once) overflow the fronts - one window in 13 to 17 needs the back
+    // half of its line - and are read in whole lines (two requests per line, both halves at hand).  Measured on
+    // haplotype-shaped lists, same box, resident, Gbases/s (profiles/r03/ab_policy.log, ab_policy_whole.log):
+    //   k = 21, 2 x 3e8 keys, load 0.08 (60 GB): whole lines, mod-sampling 137, random minimizer 135; front-first
+    //     122 / 129 (front-first at load 0.04, 120 GB: 133 / 145 - twice the memory for 6 %);
+    //   k = 31, 2 x 1e9 keys (186 GB): whole lines, mod-sampling 153, random minimizer 145.
+    // Nothing of that is observable in the results and building the table takes a fraction of a second, so: build
     // front-first; if more than TBK_CLUSTERED (default 0.3 %) of the keys found their own half of their home line
-    // full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), build again with the random minimizer in whole lines.
-    // TBK_MOD_SAMPLING=1 / 0 pins the rule, TBK_FRONT the layout, TBK_TABLE_LOAD the load.
+    // full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), or more than TBK_BEHIND_FRONT (default 5 %) lie behind
+    // a front, build the same table again in whole lines.  TBK_MOD_SAMPLING=0 pins the random minimizer, TBK_FRONT
+    // the layout, TBK_TABLE_LOAD the load.
     const double pin = env_double("TBK_MOD_SAMPLING", -1);
     const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
-    const bool load_pinned = env_double("TBK_TABLE_LOAD", 0) > 0;
     const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
-    // Front layout (tbk_common.h): the probe kernel asks for 64 bytes of a line, the first four slots of each
-    // list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list first); a
-    // window that misses in a front whose list has keys behind it is queued, and the queue is settled 16
-    // windows at a time from the back half of the line, which the L2 holds already (tbk_kernels.hip:
-    // drain_back).  One request per line instead of two.  Lists that spread keep it while at most
-    // TBK_BEHIND_FRONT (default 5 %) of their keys lie behind a front - at the default load 0.3 % do, and denser
-    // tables still gain from it (load 0.12: 0.7 % behind, 169 Gbases/s front-first against 151 in whole lines);
-    // clustered lists and TBK_FRONT=0 get whole lines.
     const double front_pin = env_double("TBK_FRONT", -1);
-    int built_t = -1;  // sampling rule of the table that stands (-1: none yet)
-    for (int attempt = 0; attempt < 2; attempt++) {
-        const int mod_sampling = pin >= 0 ? (pin != 0) : (attempt == 0);
-        c->mz = tbk_mz_params(c->k, w_target, n_big, m_force, mod_sampling);
-        // nothing to decide between: the same rule and (pinned) the same load as the table that stands
-        if (built_t == c->mz.t && load_pinned) break;
-        // mod-sampling is not available for this k / table size and the load is pinned: one build, below
-        if (pin < 0 && attempt == 0 && c->mz.t == 0 && load_pinned) continue;
+    c->mz = tbk_mz_params(c->k, w_target, n_big, m_force, pin != 0);
+    bool front = c->mz.w >= 2 && front_pin != 0;
+    for (;;) {
         c->free_pair();
-        built_t = c->mz.t;
         c->layout_builds++;
-        const bool front = c->mz.w >= 2 && (front_pin >= 0 ? front_pin != 0 : attempt == 0);  // clustered lists: whole lines (below)
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, 0.08, &past);
         if (rc) { delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
-        if (attempt == 0 && clustered <= env_double("TBK_CLUSTERED", 0.003) && front && front_pin < 0 && behind > env_double("TBK_BEHIND_FRONT", 0.05)) {
-            // the lists spread, but too many keys lie behind a front: the same table in whole lines
-            c->free_pair();
-            c->guests = guests;
-            c->layout_builds++;
-            rc = build_pair_table(c, a, b, 0.08, &past);
-            if (rc) { delete c; return rc; }
-            break;
-        }
-        if (attempt == 1 || clustered <= env_double("TBK_CLUSTERED", 0.003)) break;
+        if (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05))) break;
+        front = false;  // clustered lists, or too many keys behind the fronts: whole lines
     }
     c->own_pair();
     rc = classifier_streams(c);
@@ -1009,7 +1018,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
         }
         c->own_pair();
     }
-    rc = classifier_streams(c);
+    rc = classifier_streams(c, env_double("TBK_RING_STREAMS", 0) != 0 ? nullptr : src);  // (TBK_RING_STREAMS=1: streams of its own, the measurement above)
     if (rc) { tbk_classifier_destroy(c); return rc; }
     *out = c;
     return TBK_OK;
@@ -1144,9 +1153,8 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         c->pair_owner.reset();  // (the table itself goes with its last user)
         if (c->d_pass_read) (void)hipFree(c->d_pass_read);
-        if (c->compute) (void)hipStreamDestroy(c->compute);
-        if (c->copy) (void)hipStreamDestroy(c->copy);
-        if (c->out) (void)hipStreamDestroy(c->out);
+        for (const Slot &s : c->ring) if (s.busy && c->streams) c->streams->in_flight--;
+        c->streams.reset();  // (the streams go with their last ring)
     }
     delete c;
 }
@@ -1416,6 +1424,9 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
     if (n_reads && total) {
         const uint64_t *src_o = offsets;
         if (!offs_pinned) { memcpy(s.h_offsets, offsets, (n_reads + 1) * sizeof(uint64_t)); src_o = s.h_offsets; }
+        const uint8_t *src_b = bases;
+        if (!packed && !bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
+        std::lock_guard<std::mutex> together(c->streams->enqueue);  // (rings sharing the device's streams: one batch's launches stay together)
         // Side stream: the H2D of this batch overlaps the previous batch's kernels.  The small arrays go first; the
         // bases follow - when the ring is empty in up to 8 slices, each with its own event, and the probe of a slice's
         // passes starts as soon as that slice is on the device: an empty pipeline starts computing after an eighth of
@@ -1430,14 +1441,11 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
             }
         }
         HIP_TRY(hipEventRecord(s.copied, c->copy));
-        const uint8_t *src_b = bases;
-        if (!packed && !bases_pinned) { par_memcpy(s.h_bases, bases, total); src_b = s.h_bases; }
         const uint64_t passes = tbk_probe_passes(total);
         // Slices pay where nothing else keeps the device busy (an empty ring: the first batch of a run); behind a
         // batch that is still in flight one copy and one pair of kernels is best (every kernel launch ends in a
         // partly filled device: eight slices per batch measured 4 % slower in the steady state).
-        bool alone = true;
-        for (const Slot &other : c->ring) alone = alone && (&other == &s || !other.busy);
+        const bool alone = c->streams->in_flight.load() == 0;  // (over all rings of the device)
         const int n_slices = alone ? (int)std::max<uint64_t>(1, std::min<uint64_t>(8, total / c->slice_bases)) : 1;
         ProbeSlice slices[8];
         uint64_t sent = 0;  // chunks (of 16 bases) on their way so far
@@ -1483,6 +1491,7 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         HIP_TRY(hipEventRecord(s.done, c->compute));
     }
     s.busy = true;
+    c->streams->in_flight++;
     c->next_ticket++;
     *ticket = tk;
     return TBK_OK;
@@ -1524,6 +1533,7 @@ extern "C" int tbk_stream_wait(tbk_classifier *c, uint64_t ticket) {
     HIP_TRY(hipEventSynchronize(s.done));
     if (s.counts_staged && s.n_reads) memcpy(s.user_counts, s.h_counts, s.n_reads * 2 * sizeof(int32_t));
     s.busy = false;
+    c->streams->in_flight--;
     return TBK_OK;
 }
 
@@ -1564,6 +1574,7 @@ extern "C" int tbk_classify_device(tbk_classifier *c, const void *d_bases, const
     int rc = use_device(c->device);
     if (rc) return rc;
     if (!n_reads) return TBK_OK;
+    std::lock_guard<std::mutex> together(c->streams->enqueue);
     return launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases,
                               (int32_t *)d_counts);
 }
@@ -1587,6 +1598,7 @@ extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, 
     if (rc) return rc;
     s.ticket = tk; s.n_reads = n_reads; s.user_counts = counts; s.counts_staged = !out_pinned;
     if (n_reads && total_bases) {
+        std::lock_guard<std::mutex> together(c->streams->enqueue);
         rc = launch_probe_timed(c, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, total_bases, s.d_counts);
         if (rc) return rc;
         // the counts travel home on a stream of their own, beside the next batch's kernels
@@ -1601,6 +1613,7 @@ extern "C" int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, 
         HIP_TRY(hipEventRecord(s.done, c->compute));
     }
     s.busy = true;
+    c->streams->in_flight++;
     c->next_ticket++;
     *ticket = tk;
     return TBK_OK;

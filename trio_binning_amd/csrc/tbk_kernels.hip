@@ -240,7 +240,7 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #define TBK_MIN_WAVES 5         // waves per SIMD the register allocator must leave room for: single-read passes, front layout ...
 #endif
 #ifndef TBK_MIN_WAVES_WHOLE
-#define TBK_MIN_WAVES_WHOLE 4   // ... single-read passes in whole lines (two requests per line: a fifth wave loses 5 %, measured) ...
+#define TBK_MIN_WAVES_WHOLE 5   // ... single-read passes in whole lines up to W = 6 (W = 7, 8 would spill vector registers: 4) ...
 #endif
 #ifndef TBK_MIN_WAVES_MULTI
 #define TBK_MIN_WAVES_MULTI 4   // ... and multi-read passes (tbk_probe_kernel)
@@ -1002,11 +1002,11 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
 // kernel's time goes 23.8 / 31.6 / 41.4 ms at 4 / 3 / 2 waves per SIMD - so the single-read kernel,
 // which does nearly all the work on long reads, is compiled for 5 waves per SIMD where the line is asked for
 // front-first (96 VGPRs, 0-9 spills; same box, uniform lists: 23.2 against 24.0 ms, haplotype-shaped lists
-// 27.8 against 31.6) and the multi-read kernel keeps 4.  The whole-line variants keep 4 as well: with two
-// requests per line a fifth wave measured 5 % slower (30.2 against 28.5 ms).  The pass-index kernel lists the multi-read passes; the
-// single-read kernel skips them.
+// 27.8 against 31.6) and the multi-read kernel keeps 4.  So are the whole-line variants up to W = 6 (96 VGPRs, no
+// vector spills; haplotype-shaped lists, same box: 22.6 ms at 5 waves, 25.4 at 4 - profiles/r03/ab_policy_whole.log).
+// The pass-index kernel lists the multi-read passes; the single-read kernel skips them.
 template <int W, bool M64, bool SAMP, bool FRONT, bool MULTI>
-__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : (FRONT ? TBK_MIN_WAVES : TBK_MIN_WAVES_WHOLE))
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : (FRONT ? TBK_MIN_WAVES : (W <= 6 ? TBK_MIN_WAVES_WHOLE : 4)))
 tbk_probe_kernel(const ProbeArgs p) {
     // LDS staging of the read tile, one region per wave: a wave only ever reads what it wrote
     // itself, so wave-scope ordering is enough and the waves of a block never wait for each
