@@ -315,6 +315,17 @@ int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, 
 int tbk_fastx_set_packing(tbk_fastx_reader *r, int on);
 int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, const uint32_t **exc_chunk, const uint16_t **exc_mask,
                            uint64_t *n_exc);
+/* on != 0 (and packing on): batches taken from a plain FASTQ file by the chunk-parallel scan do not copy their
+ * records.  The reader maps its input; such a batch records where each record lies, carries names, offsets,
+ * has_qual and the packed form as usual - the bases are packed straight from the mapping - and has no `bases` /
+ * `quals` arrays (tbk_fastx_batch_view hands out one zero byte for them).  tbk_bin_writer_write writes the
+ * records to their bins from the mapping: the bytes Read.print would write (seq.py:27-31), a record without a
+ * header comment and with a bare '+' line as it stands in the input.  Such batches are valid until
+ * tbk_fastx_close.  Batches of any other input (gzip, FASTA, irregular records) are copied as always;
+ * tbk_fastx_batch_borrowed says which kind a batch is.  The loop of tbk_classify_file turns this on
+ * (TBK_BORROW=0 turns it off). */
+int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on);
+int tbk_fastx_batch_borrowed(const tbk_fastx_batch *b);
 /* Borrow the batch's arrays: offsets have n_reads+1 entries; has_qual[i] = 1 when the record
  * was read as FASTQ (readfq's qual is not None). */
 int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint8_t **bases,

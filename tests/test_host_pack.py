@@ -179,3 +179,99 @@ def test_reader_emits_the_packed_form_of_its_batches(built, tmp_path, monkeypatc
         b = seq.Batch()
         assert r.next_batch(b, 0, 0) and b.packed_pointers() is None
         b.close()
+
+
+def _mixed_fastq(rng, n, lo, hi, bad_every=0):
+    """Regular 4-line records in every shape the borrowed path distinguishes: with and without a header comment,
+    bare and named '+' lines, empty sequences, bytes outside ACGT."""
+    out = []
+    nrng = np.random.default_rng(rng.randrange(1 << 30))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for i in range(n):
+        ln = rng.randrange(lo, hi)
+        s = acgt[nrng.integers(0, 4, ln)].tobytes().decode()
+        if bad_every and i % bad_every == 0 and ln > 3:
+            p = rng.randrange(ln)
+            s = s[:p] + rng.choice("Nnacgt-") + s[p + 1:]
+        q = "".join(chr(33 + (j * 7 + i) % 40) for j in range(ln)).replace("@", "A").replace("+", "B") if ln < 200 else chr(40 + i % 30) * ln
+        name = f"m{i}/{rng.randrange(10**6)}/ccs"
+        head = name + (f" np={i} rq=0.99" if rng.random() < 0.4 else "")
+        plus = "+" + (name if rng.random() < 0.3 else "")
+        out.append(f"@{head}\n{s}\n{plus}\n{q}\n")
+        _MIXED_RECORDS.append((name, s, q))
+    return "".join(out)
+
+
+_MIXED_RECORDS = []
+
+
+@pytest.mark.parametrize("shape", ["long", "short", "mixed"])
+def test_borrowed_batches_equal_copied_ones(built, tmp_path, monkeypatch, shape):
+    """BatchReader(packing=True, borrowing=True) - what the native loop reads with: batches of a plain FASTQ file leave
+    their records in the reader's mapping.  Names, offsets and the packed form equal those of the copied batch of the
+    same records, and the bin writer writes the same bytes from the mapping (plain long records: gathered pwritev;
+    short records: bin buffers; gzip members) as from the copied arrays - the bytes Read.print would write."""
+    import gzip
+    import random
+
+    from trio_binning_amd import seq
+
+    rng = random.Random({"long": 5, "short": 6, "mixed": 7}[shape])
+    monkeypatch.setenv("TBK_HOST_THREADS", "5")
+    del _MIXED_RECORDS[:]
+    if shape == "long":     # several scan pieces and several copy threads per batch
+        text = _mixed_fastq(rng, 2500, 9000, 21000, bad_every=40)
+    elif shape == "short":  # many records per 16-base chunk, empty sequences, chunks spanning several records
+        text = _mixed_fastq(rng, 60000, 0, 40, bad_every=7) + _mixed_fastq(rng, 1500, 9000, 21000)
+    else:
+        text = _mixed_fastq(rng, 3000, 0, 40, bad_every=7) + _mixed_fastq(rng, 2600, 9000, 21000, bad_every=50) + _mixed_fastq(rng, 500, 1, 18)
+    path = tmp_path / "r.fq"
+    path.write_text(text)
+    records = list(_MIXED_RECORDS)  # (name, seq, qual) of every record, for the expected bins
+
+    def expected(bins_all):
+        out = {b"A": [], b"B": [], b"U": []}
+        k = 0
+        for name, s, q in records:
+            out[bins_all[k:k + 1]].append(f"@{name}\n{s}\n+\n{q}\n" if q else f">{name}\n{s}\n")
+            k += 1
+        return {b: "".join(v).encode() for b, v in out.items()}
+
+    for limit in (0, 7_000_000, 1_000_003):
+        results = {}
+        for borrowing in (False, True):
+            for gz in (False, True):
+                prefix = [str(tmp_path / f"{x}_{int(borrowing)}_{int(gz)}_{limit}") for x in "abu"]
+                w = seq.BinWriter(prefix[0], prefix[1], prefix[2], ".fq", gz)
+                meta, bins_all = [], b""
+                brng = random.Random(limit)
+                with seq.BatchReader(str(path), packing=True, borrowing=borrowing) as r:
+                    b = seq.Batch()
+                    while r.next_batch(b, limit, 0):
+                        assert b.borrowed == borrowing
+                        a = b.arrays()
+                        got = b.packed_arrays()
+                        assert got is not None
+                        meta.append((a[1].copy(), a[2].copy(), a[3].copy(), a[5].copy(), a[6].copy(), got[0].copy(),
+                                     sorted(zip(got[1].tolist(), got[2].tolist()))))
+                        # runs of one bin (neighbours merge into one piece) and single records
+                        bins = b"".join(brng.choice([b"A", b"B", b"U"]) * brng.choice([1, 1, 2, 5]) for _ in range(b.n_reads))[:b.n_reads]
+                        w.write(b, bins)
+                        bins_all += bins
+                    b.close()
+                    w.close()  # (borrowed batches are valid until the reader is closed)
+                data = {}
+                for key, name in zip((b"A", b"B", b"U"), w.names):
+                    raw = open(name, "rb").read()
+                    data[key] = gzip.decompress(raw) if gz else raw
+                results[(borrowing, gz)] = (meta, data, bins_all)
+        base_meta, base_data, bins_all = results[(False, False)]
+        want = expected(bins_all)
+        assert base_data == want
+        for key, (meta, data, bins) in results.items():
+            assert bins == bins_all and data == want, key
+            assert len(meta) == len(base_meta)
+            for m, bm in zip(meta, base_meta):
+                for x, y in zip(m[:6], bm[:6]):
+                    assert np.array_equal(x, y), key
+                assert m[6] == bm[6], key

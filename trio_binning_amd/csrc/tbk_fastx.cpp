@@ -693,6 +693,8 @@ struct LineSource {
 // =======================================================================================
 // batch
 // =======================================================================================
+struct FastqRec { uint64_t head, seq, plus, qual, end; uint32_t name_len; };  // line starts of a regular FASTQ record; `end` = start of the next record
+
 struct tbk_fastx_batch {
     uint8_t *bases = nullptr;  // pinned (hipHostMalloc) when a device is present, else malloc
     size_t bases_cap = 0;
@@ -717,6 +719,12 @@ struct tbk_fastx_batch {
     std::vector<TbkExc> exc;
     std::vector<uint32_t> exc_chunk;
     std::vector<uint16_t> exc_mask;
+    // A borrowed batch (tbk_fastx_set_borrowing): its records lie in the reader's mapping of the input file and
+    // were not copied - `recs` says where, names / offsets / has_qual / the packed form are filled as usual, `bases`
+    // and `quals` are not.  The bin writer writes such records from the mapping.  Valid until the reader is closed.
+    bool borrowed = false;
+    const uint8_t *text = nullptr;
+    std::vector<FastqRec> recs;
 
     ~tbk_fastx_batch() {
         release();
@@ -763,6 +771,7 @@ struct tbk_fastx_batch {
         has_qual.clear(); n_bases = 0; rec_seq0 = rec_qual0 = 0;
         fused = want_packed; packed_ok = false;
         exc.clear(); exc_chunk.clear(); exc_mask.clear();
+        borrowed = false; text = nullptr; recs.clear();
     }
     void begin(const uint8_t *name, size_t n) {
         names.insert(names.end(), name, name + n);
@@ -803,8 +812,6 @@ struct tbk_fastx_batch {
 // (CR anywhere, a multi-line sequence, a quality line of another length, a blank line, '>' records,
 // a last line without newline ...) ends this mode for good: the sequential machine takes over at
 // that record's first byte.
-struct FastqRec { uint64_t head, seq, plus, qual, end; uint32_t name_len; };  // line starts; `end` = start of the next record
-
 struct RegularScan {
     const uint8_t *map = nullptr;
     size_t size = 0, pos = 0;   // pos: a record starts here (or pos == size)
@@ -898,6 +905,7 @@ struct tbk_fastx_reader {
     uint64_t seq_len = 0;       // current record (QUAL state)
     int64_t qual_have = 0;
     bool packing = false;       // batches also carry the packed transfer form of their bases
+    bool borrowing = false;     // batches of the mapped plain file reference its text instead of copying it (needs packing)
 };
 
 static void name_of(const uint8_t *body, size_t n, const uint8_t *&np, size_t &nn) {
@@ -955,13 +963,26 @@ extern "C" int tbk_fastx_batch_create(tbk_fastx_batch **out) {
 
 extern "C" void tbk_fastx_batch_destroy(tbk_fastx_batch *b) { delete b; }
 
+// `n` bases of a borrowed batch's stream (the records' sequences back to back) from stream position `at`
+static void borrowed_bases(const tbk_fastx_batch *b, uint64_t at, size_t n, uint8_t *out) {
+    size_t i = (size_t)(std::upper_bound(b->base_off.begin(), b->base_off.end(), at) - b->base_off.begin());
+    i = i ? i - 1 : 0;  // the record that holds position `at` (empty records before it share its offset and are skipped)
+    for (; n && i < b->recs.size(); i++) {
+        const uint64_t lo = b->base_off[i], hi = b->base_off[i + 1];
+        if (at >= hi) continue;
+        const size_t k = (size_t)std::min<uint64_t>(n, hi - at);
+        memcpy(out, b->text + b->recs[i].seq + (at - lo), k);
+        out += k; at += k; n -= k;
+    }
+}
+
 // One batch by the chunk-parallel scan (see RegularScan) of the text d[pos..size): a mapped file
 // (final: nothing follows d[size-1]) or the inflated text at hand (more may follow: a record cut off by
 // the end of the window is not irregular, only incomplete).  Leaves the batch empty when the record
 // at `pos` is not regular and complete.  *new_pos = where the next record starts; *leave = every
 // record that chained up was taken and the one after them is not regular (meaningful when final).
 static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, const size_t pos, tbk_fastx_batch *b,
-                          uint64_t max_bases, uint64_t max_reads, size_t *new_pos_out, bool *leave) {
+                          uint64_t max_bases, uint64_t max_reads, size_t *new_pos_out, bool *leave, bool may_borrow = false) {
     *new_pos_out = pos;
     *leave = false;
     if (pos >= size) return TBK_OK;
@@ -1050,15 +1071,20 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
     // appended behind what the batch holds already (inflated text comes window by window)
     const size_t n0 = (size_t)b->n_reads(), on0 = b->names.size(), oq0 = b->quals.size();
     const uint64_t ob0 = b->n_bases;
-    if (!b->reserve_bases((size_t)(ob0 + n_bases) + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     const bool pack = b->want_packed && b->fused;
+    // Borrowing (d is the reader's mapping of the file, the batch is empty): the records stay where they are.  Their
+    // bases are packed straight from the mapping, names and offsets are filled as usual, sequences and qualities
+    // are not copied - the bin writer writes the records from the mapping.
+    const bool borrow = may_borrow && pack && n0 == 0 && ob0 == 0;
+    if (!borrow && !b->reserve_bases((size_t)(ob0 + n_bases) + 16)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     if (pack && !b->reserve_codes((size_t)((ob0 + n_bases + 15) / 16) + 1)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     b->base_off.resize(n0 + (size_t)n_reads + 1);
     b->name_off.resize(n0 + (size_t)n_reads + 1);
     b->qual_off.resize(n0 + (size_t)n_reads + 1);
     b->has_qual.resize(n0 + (size_t)n_reads, 1);
     b->names.resize(on0 + (size_t)n_name);
-    b->quals.resize(oq0 + (size_t)n_bases);
+    if (borrow) { b->borrowed = true; b->text = d; b->recs.resize((size_t)n_reads); }
+    else b->quals.resize(oq0 + (size_t)n_bases);
     uint64_t ob = ob0, on = on0, oq = oq0;
     for (size_t i = 0; i < chosen.size(); i++) {
         b->base_off[n0 + i] = ob; b->qual_off[n0 + i] = oq; b->name_off[n0 + i] = on;
@@ -1099,9 +1125,40 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
                 }
             }
         };
+        // the same stretch of a borrowed batch: names copied, bases packed from where they lie.  A chunk is made of
+        // the bases of consecutive records: what a record leaves of one waits in `stage` for the next record.
+        auto take_borrowed = [&](int t) {
+            const size_t first = cut(t), last = cut(t + 1);
+            std::vector<TbkExc> &ex = found[(size_t)t];
+            uint8_t stage[16];
+            unsigned have = 0;
+            uint64_t at_b = b->base_off[first];
+            unsigned skip = (unsigned)((16 - at_b % 16) % 16);  // a chunk the stretch begins inside is packed below, once whole
+            for (size_t i = first; i < last; i++) {
+                const FastqRec &rc = *chosen[i];
+                b->recs[i] = rc;
+                if (rc.name_len) memcpy(b->names.data() + b->name_off[i], d + rc.head + 1, rc.name_len);
+                const uint8_t *sq = d + rc.seq;
+                size_t n = (size_t)(rc.plus - 1 - rc.seq);
+                if (skip && n) { const size_t k = std::min<size_t>(skip, n); sq += k; n -= k; at_b += k; skip -= (unsigned)k; }
+                if (have && n) {
+                    const size_t k = std::min<size_t>(16 - have, n);
+                    memcpy(stage + have, sq, k);
+                    have += (unsigned)k; sq += k; n -= k; at_b += k;
+                    if (have == 16) { tbk_pack_span_(stage, at_b / 16 - 1, 1, b->codes, ex); have = 0; }
+                }
+                if (n >= 16) { const size_t whole = n / 16; tbk_pack_span_(sq, at_b / 16, whole, b->codes, ex); sq += 16 * whole; n -= 16 * whole; at_b += 16 * whole; }
+                if (n) { memcpy(stage, sq, n); have = (unsigned)n; at_b += n; }
+            }
+        };
         std::vector<std::thread> pool;
-        for (int t = 1; t < ct; t++) pool.emplace_back(copy, t);
-        copy(0);
+        if (borrow) {
+            for (int t = 1; t < ct; t++) pool.emplace_back(take_borrowed, t);
+            take_borrowed(0);
+        } else {
+            for (int t = 1; t < ct; t++) pool.emplace_back(copy, t);
+            copy(0);
+        }
         for (std::thread &th : pool) th.join();
         if (pack) {
             for (const auto &f : found) b->exc.insert(b->exc.end(), f.begin(), f.end());
@@ -1112,7 +1169,13 @@ static int regular_window(RegularScan &sc, const uint8_t *d, const size_t size, 
                 const uint64_t pb = b->base_off[n0 + cut(u)];
                 const uint64_t c = pb / 16;
                 if (pb % 16 == 0 || c == last_done || 16 * c + 16 > ob) continue;
-                tbk_pack_chunk_range_(b->bases, c, c + 1, b->codes, b->exc);
+                if (borrow) {
+                    uint8_t stage[16];
+                    borrowed_bases(b, 16 * c, 16, stage);
+                    tbk_pack_span_(stage, c, 1, b->codes, b->exc);
+                } else {
+                    tbk_pack_chunk_range_(b->bases, c, c + 1, b->codes, b->exc);
+                }
                 last_done = c;
             }
         }
@@ -1140,7 +1203,7 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
     if (sc.pos >= sc.size) return TBK_OK;
     size_t new_pos = sc.pos;
     bool leave = false;
-    const int rc = regular_window(sc, sc.map, sc.size, sc.pos, b, max_bases, max_reads, &new_pos, &leave);
+    const int rc = regular_window(sc, sc.map, sc.size, sc.pos, b, max_bases, max_reads, &new_pos, &leave, r->borrowing);
     if (rc) return rc;
     if (b->n_reads() == 0 || leave) sc.active = false;
     sc.pos = new_pos;
@@ -1199,13 +1262,27 @@ extern "C" int tbk_fastx_set_packing(tbk_fastx_reader *r, int on) {
     return TBK_OK;
 }
 
+extern "C" int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on) {
+    if (!r) return ffail(TBK_ERR_INVALID, "NULL argument");
+    r->borrowing = on != 0;
+    return TBK_OK;
+}
+
+extern "C" int tbk_fastx_batch_borrowed(const tbk_fastx_batch *b) { return b && b->borrowed ? 1 : 0; }
+
 // the batch's packed form: what the scan has packed already plus the last, partial chunk - or, for bytes
 // that came through the sequential machine, the whole stream in one go on all host threads
 static int finish_packing(tbk_fastx_batch *b) {
     if (!b->want_packed || b->n_reads() == 0) return TBK_OK;
     if (!b->reserve_codes((size_t)((b->n_bases + 15) / 16) + 1)) return ffail(TBK_ERR_NOMEM, "out of memory sizing a read batch");
     if (b->fused) {
-        tbk_pack_tail_chunk_(b->bases, b->n_bases, b->codes, b->exc);
+        if (b->borrowed) {
+            const unsigned valid = (unsigned)(b->n_bases % 16);
+            uint8_t tail[16];
+            if (valid) { borrowed_bases(b, b->n_bases - valid, valid, tail); tbk_pack_tail_bytes_(tail, valid, b->n_bases / 16, b->codes, b->exc); }
+        } else {
+            tbk_pack_tail_chunk_(b->bases, b->n_bases, b->codes, b->exc);
+        }
         b->exc_chunk.resize(b->exc.size());
         b->exc_mask.resize(b->exc.size());
         for (size_t i = 0; i < b->exc.size(); i++) { b->exc_chunk[i] = b->exc[i].chunk; b->exc_mask[i] = b->exc[i].mask; }
@@ -1340,11 +1417,11 @@ extern "C" int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads,
     if (!b) return ffail(TBK_ERR_INVALID, "NULL argument");
     static const uint8_t nothing = 0;
     if (n_reads) *n_reads = b->n_reads();
-    if (bases) *bases = b->bases ? b->bases : &nothing;
+    if (bases) *bases = b->bases && !b->borrowed ? b->bases : &nothing;  // (a borrowed batch has no sequence / quality arrays)
     if (base_off) *base_off = b->base_off.data();
     if (names) *names = b->names.empty() ? &nothing : b->names.data();
     if (name_off) *name_off = b->name_off.data();
-    if (quals) *quals = b->quals.empty() ? &nothing : b->quals.data();
+    if (quals) *quals = b->quals.empty() || b->borrowed ? &nothing : b->quals.data();
     if (qual_off) *qual_off = b->qual_off.data();
     if (has_qual) *has_qual = b->has_qual.empty() ? &nothing : b->has_qual.data();
     return TBK_OK;
@@ -1632,6 +1709,46 @@ extern "C" int tbk_bin_writer_open(const char *path_a, const char *path_b, const
     return TBK_OK;
 }
 
+// The bytes Read.print writes for record i (seq.py:27-31: FASTQ when the record has a non-empty quality string, else
+// FASTA; name = header up to the first space, bare '+' line), as up to 7 pieces of memory.  A record copied into the
+// batch's arrays is gathered from them and from constants.  A borrowed record lies in the mapped input as
+// "@name[ comment]\nSEQ\n+[...]\nQUAL\n": what the header's comment and the '+' line's text do not interrupt is
+// written as it lies there - a record without either is one piece, and one piece with its neighbours of the same bin.
+static inline int record_pieces(const tbk_fastx_batch *b, size_t i, struct iovec *v) {
+    static const char at_c = '@', gt_c = '>', nl_c = '\n';
+    static const char plus_c[3] = {'\n', '+', '\n'};
+    const size_t nn = b->name_off[i + 1] - b->name_off[i];
+    const size_t ns = b->base_off[i + 1] - b->base_off[i];
+    const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
+    const bool fq = b->has_qual[i] && nq > 0;
+    int c = 0;
+    if (b->borrowed && fq) {
+        const FastqRec &r = b->recs[i];
+        const uint8_t *t = b->text;
+        const bool comment = r.seq - r.head - 2 != r.name_len, bare = r.qual - r.plus == 2;
+        if (!comment && bare) { v[c++] = {(void *)(t + r.head), (size_t)(r.end - r.head)}; return c; }
+        if (comment) {
+            v[c++] = {(void *)(t + r.head), (size_t)1 + r.name_len};                        // "@name"
+            if (bare) { v[c++] = {(void *)(t + r.seq - 1), (size_t)(r.end - r.seq + 1)}; return c; }  // "\nSEQ\n+\nQUAL\n"
+            v[c++] = {(void *)(t + r.seq - 1), (size_t)(r.plus + 1 - (r.seq - 1))};        // "\nSEQ\n+"
+        } else {
+            v[c++] = {(void *)(t + r.head), (size_t)(r.plus + 1 - r.head)};                // "@name\nSEQ\n+"
+        }
+        v[c++] = {(void *)(t + r.qual - 1), (size_t)(r.end - r.qual + 1)};                 // "\nQUAL\n"
+        return c;
+    }
+    v[c++] = {(void *)(fq ? &at_c : &gt_c), 1};
+    if (nn) v[c++] = {(void *)(b->names.data() + b->name_off[i]), nn};
+    v[c++] = {(void *)&nl_c, 1};
+    if (ns) v[c++] = {(void *)((b->borrowed ? b->text + b->recs[i].seq : b->bases + b->base_off[i])), ns};
+    if (fq) {
+        v[c++] = {(void *)plus_c, 3};
+        v[c++] = {(void *)(b->quals.data() + b->qual_off[i]), nq};
+    }
+    v[c++] = {(void *)&nl_c, 1};
+    return c;
+}
+
 // append the batch's records to their bins in input order: FASTQ when the record has a
 // non-empty quality string, else FASTA (seq.py:27-31)
 extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins) {
@@ -1663,8 +1780,6 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         w->bin[0].text.size() == 0 && w->bin[1].text.size() == 0 && w->bin[2].text.size() == 0) {
         const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)8 << 20)));
         std::atomic<int> failed_errno{0};
-        static const char at_c = '@', gt_c = '>', nl_c = '\n';
-        static const char plus_c[3] = {'\n', '+', '\n'};
         auto put = [&](int t) {
             auto cut = [&](int u) -> size_t {
                 if (u <= 0) return 0;
@@ -1695,22 +1810,16 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
             };
             for (size_t i = cut(t); i < last && !failed_errno.load(); i++) {
                 const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
-                const size_t nn = b->name_off[i + 1] - b->name_off[i];
-                const size_t ns = b->base_off[i + 1] - b->base_off[i];
-                const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
-                const bool fq = b->has_qual[i] && nq > 0;
                 std::vector<struct iovec> &v = iov[which];
                 // (dst[i] counts from the bin's buffer start, which is empty here: an offset into this batch's share)
                 if (v.empty()) start[which] = w->bin[which].file_off + dst[i];
-                v.push_back({(void *)(fq ? &at_c : &gt_c), 1});
-                if (nn) v.push_back({(void *)(b->names.data() + b->name_off[i]), nn});
-                v.push_back({(void *)&nl_c, 1});
-                if (ns) v.push_back({(void *)(b->bases + b->base_off[i]), ns});
-                if (fq) {
-                    v.push_back({(void *)plus_c, 3});
-                    v.push_back({(void *)(b->quals.data() + b->qual_off[i]), nq});
+                struct iovec pc[7];
+                const int np = record_pieces(b, i, pc);
+                for (int j = 0; j < np; j++) {
+                    // (neighbouring records of a borrowed batch that go to the same bin lie back to back in the input)
+                    if (!v.empty() && (char *)v.back().iov_base + v.back().iov_len == (char *)pc[j].iov_base) v.back().iov_len += pc[j].iov_len;
+                    else v.push_back(pc[j]);
                 }
-                v.push_back({(void *)&nl_c, 1});
                 if ((int)v.size() >= CAP) flush(which);
             }
             for (int k = 0; k < 3; k++) if (!iov[k].empty()) flush(k);
@@ -1736,25 +1845,11 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         };
         const size_t last = cut(t + 1);
         for (size_t i = cut(t); i < last; i++) {
-            // FASTQ when the record has a non-empty quality string, else FASTA (seq.py:27-31)
             const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
-            const size_t nn = b->name_off[i + 1] - b->name_off[i];
-            const size_t ns = b->base_off[i + 1] - b->base_off[i];
-            const size_t nq = b->qual_off[i + 1] - b->qual_off[i];
-            const bool fq = b->has_qual[i] && nq > 0;
             char *p = w->bin[which].text.data() + dst[i];
-            *p++ = fq ? '@' : '>';
-            if (nn) memcpy(p, b->names.data() + b->name_off[i], nn);
-            p += nn;
-            *p++ = '\n';
-            if (ns) memcpy(p, b->bases + b->base_off[i], ns);
-            p += ns;
-            *p++ = '\n';
-            if (fq) {
-                *p++ = '+'; *p++ = '\n';
-                memcpy(p, b->quals.data() + b->qual_off[i], nq); p += nq;
-                *p++ = '\n';
-            }
+            struct iovec pc[7];
+            const int np = record_pieces(b, i, pc);
+            for (int j = 0; j < np; j++) { memcpy(p, pc[j].iov_base, pc[j].iov_len); p += pc[j].iov_len; }
         }
     };
     {

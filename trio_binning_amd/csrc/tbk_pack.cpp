@@ -119,14 +119,27 @@ void tbk_pack_tail_chunk_(const uint8_t *bases, uint64_t total, uint32_t *codes,
     const uint64_t full = total / 16;
     const unsigned valid = (unsigned)(total - full * 16);
     if (!valid) return;
+    tbk_pack_tail_bytes_(bases + full * 16, valid, full, codes, exc);
+}
+
+// The same from the `valid` (1..15) bytes themselves, wherever they lie: chunk `chunk` of the stream.
+void tbk_pack_tail_bytes_(const uint8_t *bytes, unsigned valid, uint64_t chunk, uint32_t *codes, std::vector<TbkExc> &exc) {
     uint8_t tmp[16] = {0};
-    memcpy(tmp, bases + full * 16, valid);
+    memcpy(tmp, bytes, valid);
     uint32_t code, bad;
     pack16_scalar(tmp, code, bad);
     bad |= 0xFFFFu << valid;
     code &= (1u << (2 * valid)) - 1u;
-    codes[full] = code;
-    exc.push_back(TbkExc{(uint32_t)full, (uint16_t)bad});
+    codes[chunk] = code;
+    exc.push_back(TbkExc{(uint32_t)chunk, (uint16_t)bad});
+}
+
+// `n` full chunks whose bytes lie at `src` (not in a stream buffer: a record in a mapped file, a staging buffer):
+// chunks [c_lo, c_lo + n) of the stream.
+void tbk_pack_span_(const uint8_t *src, uint64_t c_lo, uint64_t n, uint32_t *codes, std::vector<TbkExc> &exc) {
+    if (!n) return;
+    const uint8_t *base = (const uint8_t *)((uintptr_t)src - (uintptr_t)(16 * c_lo));  // the stream this span would be part of
+    tbk_pack_chunk_range_(base, c_lo, c_lo + n, codes, exc);
 }
 
 // Pack `total` ASCII bases.  codes must hold tbk_packed_chunks(total) words.  The exceptions of the

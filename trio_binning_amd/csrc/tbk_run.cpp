@@ -92,6 +92,10 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     int rc = tbk_fastx_open(reads_path, &reader);
     if (rc) return rc;
     (void)tbk_fastx_set_packing(reader, tbk_pipeline_takes_packed_(p));  // (TBK_PACKED_H2D=0 and test pipelines take ASCII)
+    // records of a mapped plain FASTQ stay in the mapping: packed from there, written to their bins from there
+    // (TBK_BORROW=0: copied into the batch's arrays first, as the Python-level reader does)
+    const char *borrow_env = getenv("TBK_BORROW");
+    (void)tbk_fastx_set_borrowing(reader, tbk_pipeline_takes_packed_(p) && !(borrow_env && *borrow_env == '0'));
     tbk_bin_writer *writer = nullptr;
     rc = tbk_bin_writer_open(out_a, out_b, out_u, gzip_output, gzip_level, 0, &writer);
     if (rc) { tbk_fastx_close(reader); return rc; }

@@ -185,8 +185,16 @@ class Batch:
         base_off = arr(boff, n + 1, np.uint64)
         name_off = arr(noff, n + 1, np.uint64)
         qual_off = arr(qoff, n + 1, np.uint64)
-        return (arr(bases, int(base_off[-1]), np.uint8), base_off, arr(names, int(name_off[-1]), np.uint8), name_off,
-                arr(quals, int(qual_off[-1]), np.uint8), qual_off, arr(hq, n, np.uint8))
+        kept = 0 if self.borrowed else 1  # (a borrowed batch has no sequence / quality arrays: empty views)
+        return (arr(bases, kept * int(base_off[-1]), np.uint8), base_off, arr(names, int(name_off[-1]), np.uint8), name_off,
+                arr(quals, kept * int(qual_off[-1]), np.uint8), qual_off, arr(hq, n, np.uint8))
+
+    @property
+    def borrowed(self) -> bool:
+        """The batch's records lie in its reader's mapping of the input (``BatchReader(..., borrowing=True)``)."""
+        from ._lib import lib
+
+        return bool(lib.tbk_fastx_batch_borrowed(self._h))
 
     def pointers(self):
         """(bases_ptr, base_off_ptr) for tbk_stream_submit."""
@@ -251,7 +259,7 @@ class BatchReader:
     """Native FASTA/FASTQ(.gz) reader: ``next_batch(batch, max_bases, max_reads)`` fills a
     ``Batch`` and returns the number of records (0 at end of input)."""
 
-    def __init__(self, filename: str, packing: bool = False):
+    def __init__(self, filename: str, packing: bool = False, borrowing: bool = False):
         import ctypes as C
         import os
 
@@ -262,6 +270,8 @@ class BatchReader:
         self._h = h
         if packing:  # batches also carry the packed transfer form of their bases (Batch.packed_pointers)
             check(lib.tbk_fastx_set_packing(h, 1))
+        if borrowing:  # batches of a plain FASTQ file leave their records in the reader's mapping (what the native loop does):
+            check(lib.tbk_fastx_set_borrowing(h, 1))  # no sequence / quality arrays; valid until close()
 
     def next_batch(self, batch: Batch, max_bases: int = 0, max_reads: int = 0) -> int:
         import ctypes as C
