@@ -2,7 +2,7 @@
 //   pwrite : every thread pwrite()s its 8 MiB slices at their offsets (buffered writes take the inode lock)
 //   mmap   : the file is grown with ftruncate, mapped shared, and the threads memcpy their slices into the mapping
 //   mmap+fa: the same behind posix_fallocate (space reserved first: ENOSPC instead of SIGBUS)
-// Build: g++ -O2 -pthread tools/write_paths.cpp -o /tmp/write_paths ; run: /tmp/write_paths DIR [GB] [threads]
+// Build: g++ -O2 -pthread tools/write_paths.cpp -o /tmp/write_paths ; run: /tmp/write_paths DIR [GB] [threads] [pwrite-only]
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -14,8 +14,15 @@
 #include <vector>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+static double cpu_s() {  // user + system time of the process so far
+    struct rusage u;
+    getrusage(RUSAGE_SELF, &u);
+    return u.ru_utime.tv_sec + u.ru_stime.tv_sec + (u.ru_utime.tv_usec + u.ru_stime.tv_usec) * 1e-6;
+}
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -34,7 +41,7 @@ int main(int argc, char **argv) {
             fds.push_back(open(names.back().c_str(), O_RDWR | O_CREAT | O_TRUNC, 0600));
             if (fds.back() < 0) { perror("open"); exit(1); }
         }
-        const double t0 = now();
+        const double t0 = now(), c0 = cpu_s();
         const size_t per_file = total / files;
         for (size_t off = 0; off < per_file; off += window) {
             const size_t n = std::min(window, per_file - off);
@@ -65,13 +72,15 @@ int main(int argc, char **argv) {
             for (auto &t : pool) t.join();
             for (int f = 0; f < files; f++) if (maps[f]) munmap(maps[f], n);
         }
-        const double t1 = now();
+        const double t1 = now(), c1 = cpu_s();
         for (int f = 0; f < files; f++) { close(fds[f]); unlink(names[f].c_str()); }
-        printf("%-8s files %d threads %2d: %6.2f GB/s (%.2f s for %.1f GB; unlink %.2f s)\n", label, files, nt, total / 1e9 / (t1 - t0), t1 - t0, total / 1e9, now() - t1);
+        printf("%-8s files %d threads %2d: %6.2f GB/s (%.2f s for %.1f GB, %.1f CPU-s; unlink %.2f s)\n", label, files, nt, total / 1e9 / (t1 - t0), t1 - t0, total / 1e9, c1 - c0, now() - t1);
         fflush(stdout);
     };
-    for (int files : {1, 3}) {
+    const bool only_pwrite = argc > 4;
+    for (int files : {1, 2, 3}) {
         run("pwrite", 0, files);
+        if (only_pwrite) continue;
         run("mmap", 1, files);
         run("mmap+fa", 2, files);
     }

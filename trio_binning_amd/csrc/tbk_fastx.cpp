@@ -1629,41 +1629,37 @@ static int flush_bins(tbk_bin_writer *w, bool final) {
         }
     } else {
         // Plain output: the bytes of a bin go to the file at the offset a sequence of write() calls
-        // would have reached (each descriptor counts for itself, as the kernel does), in slices
-        // written by several threads - the copy into the page cache is what writing costs here.
-        struct Slice { int fd; const char *src; size_t n; uint64_t off; };
-        std::vector<Slice> slices;
-        const size_t slice_bytes = (size_t)8 << 20;
+        // would have reached (each descriptor counts for itself, as the kernel does).  One thread per file: a
+        // buffered write holds the file's inode lock, more threads per file only spin for it (see
+        // tbk_bin_writer_write).
+        std::atomic<int> failed_errno{0};
+        std::vector<std::thread> pool;
         for (Piece &pc : pieces) {
             BinFile &f = w->bin[pc.bin];
             if (!f.positional) {
                 // not seekable, or a file another bin writes too: the bytes go out in order through the
                 // descriptor's own offset, as the reference's open(name, "w") handles do (seq.py:128-134)
-                if (!write_all(f.fd, pc.src, pc.n, w->err)) return ffail(TBK_ERR_IO, "%s", w->err.c_str());
+                if (!write_all(f.fd, pc.src, pc.n, w->err)) { for (std::thread &th : pool) th.join(); return ffail(TBK_ERR_IO, "%s", w->err.c_str()); }
                 f.file_off += pc.n;
                 continue;
             }
-            for (size_t o = 0; o < pc.n; o += slice_bytes) slices.push_back(Slice{f.fd, pc.src + o, std::min(slice_bytes, pc.n - o), f.file_off + o});
-            f.file_off += pc.n;
-        }
-        std::atomic<size_t> next{0};
-        std::atomic<int> failed_errno{0};
-        auto work = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < slices.size() && !failed_errno.load();) {
-                const Slice &sl = slices[i];
+            const int fd = f.fd;
+            const char *src = pc.src;
+            const size_t len = pc.n;
+            const uint64_t off = f.file_off;
+            auto work = [fd, src, len, off, &failed_errno]() {
                 size_t done = 0;
-                while (done < sl.n) {
-                    const ssize_t k = ::pwrite(sl.fd, sl.src + done, sl.n - done, (off_t)(sl.off + done));
+                while (done < len) {
+                    const ssize_t k = ::pwrite(fd, src + done, len - done, (off_t)(off + done));
                     if (k < 0) { if (errno == EINTR) continue; failed_errno.store(errno); return; }
                     done += (size_t)k;
                 }
-            }
-        };
-        const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)w->threads, slices.size()));
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto &t : pool) t.join();
+            };
+            f.file_off += pc.n;
+            if (w->threads > 1 && len >= ((size_t)1 << 20)) pool.emplace_back(work);  // (plain output: one piece per bin)
+            else work();
+        }
+        for (std::thread &th : pool) th.join();
         if (failed_errno.load()) return ffail(TBK_ERR_IO, "write: %s", strerror(failed_errno.load()));
     }
     for (int b = 0; b < 3; b++) {
@@ -1771,48 +1767,42 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         upto[(size_t)i + 1] = upto[(size_t)i] + len;
     }
     const uint64_t total = upto[(size_t)n];
-    // Plain output of long records into regular files: the records go from the batch's arrays straight to
-    // their places in the files (pwritev, gathered from the name / sequence / quality arrays and three constant
-    // strings), written by several threads - no copy into a bin buffer first.  What a sequence of write()
-    // calls would have produced, byte for byte.  Short records (many system calls per megabyte), gzip output
-    // and targets that cannot seek take the buffered path below.
+    // Plain output of long records into regular files: the records go from where they lie - the batch's arrays, or
+    // the mapped input of a borrowed batch - straight to their places in the files (pwritev), no copy into a bin
+    // buffer first.  What a sequence of write() calls would have produced, byte for byte.  ONE thread per bin: a
+    // buffered write holds its file's inode lock, so a second thread on the same file adds nothing but the CPU
+    // time it spins for the lock (12.9 GB into two files, GPU box: 2 threads 20.0 GB/s and 1.3 CPU-s, 16 threads
+    // 18.7 GB/s and 5.5 CPU-s - profiles/r03/write_threads.log), CPU time the reader's threads need.  Short records
+    // (many pieces per megabyte), gzip output and targets that cannot seek take the buffered path below.
     if (!w->gz && n > 0 && total / n >= 4096 && w->bin[0].positional && w->bin[1].positional && w->bin[2].positional &&
         w->bin[0].text.size() == 0 && w->bin[1].text.size() == 0 && w->bin[2].text.size() == 0) {
-        const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)8 << 20)));
         std::atomic<int> failed_errno{0};
-        auto put = [&](int t) {
-            auto cut = [&](int u) -> size_t {
-                if (u <= 0) return 0;
-                if (u >= nt) return (size_t)n;
-                return (size_t)(std::lower_bound(upto.begin(), upto.begin() + (ptrdiff_t)n, total * (uint64_t)u / (uint64_t)nt) - upto.begin());
-            };
-            const size_t last = cut(t + 1);
-            // a thread's records of one bin are consecutive in that bin's file: their pieces are gathered, up to
-            // ~1000 at a time, into one pwritev per bin
+        auto put = [&](int which) {
+            // the bin's records are consecutive in its file: their pieces are gathered, up to ~1000 at a time, into one pwritev
             constexpr int CAP = 1008;
-            std::vector<struct iovec> iov[3];
-            uint64_t start[3] = {0, 0, 0};
-            for (int k = 0; k < 3; k++) iov[k].reserve(CAP + 8);
-            auto flush = [&](int which) {
-                struct iovec *v = iov[which].data();
-                int c = (int)iov[which].size();
-                uint64_t off = start[which];
+            std::vector<struct iovec> v;
+            v.reserve(CAP + 8);
+            uint64_t start = 0;
+            auto flush = [&]() {
+                struct iovec *q = v.data();
+                int c = (int)v.size();
+                uint64_t off = start;
                 while (c > 0 && !failed_errno.load()) {
-                    const ssize_t k = ::pwritev(w->bin[which].fd, v, c, (off_t)off);
+                    const ssize_t k = ::pwritev(w->bin[which].fd, q, c, (off_t)off);
                     if (k < 0) { if (errno == EINTR) continue; failed_errno.store(errno); return; }
                     off += (uint64_t)k;
                     size_t done = (size_t)k;
-                    while (c > 0 && done >= v->iov_len) { done -= v->iov_len; v++; c--; }
-                    if (c > 0 && done) { v->iov_base = (char *)v->iov_base + done; v->iov_len -= done; }
+                    while (c > 0 && done >= q->iov_len) { done -= q->iov_len; q++; c--; }
+                    if (c > 0 && done) { q->iov_base = (char *)q->iov_base + done; q->iov_len -= done; }
                 }
-                start[which] = off;
-                iov[which].clear();
+                start = off;
+                v.clear();
             };
-            for (size_t i = cut(t); i < last && !failed_errno.load(); i++) {
-                const int which = bins[i] == 'A' ? 0 : bins[i] == 'B' ? 1 : 2;
-                std::vector<struct iovec> &v = iov[which];
+            const char mine = "ABU"[which];
+            for (size_t i = 0; i < (size_t)n && !failed_errno.load(); i++) {
+                if ((bins[i] == 'A' || bins[i] == 'B' ? bins[i] : 'U') != mine) continue;
                 // (dst[i] counts from the bin's buffer start, which is empty here: an offset into this batch's share)
-                if (v.empty()) start[which] = w->bin[which].file_off + dst[i];
+                if (v.empty()) start = w->bin[which].file_off + dst[i];
                 struct iovec pc[7];
                 const int np = record_pieces(b, i, pc);
                 for (int j = 0; j < np; j++) {
@@ -1820,13 +1810,17 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
                     if (!v.empty() && (char *)v.back().iov_base + v.back().iov_len == (char *)pc[j].iov_base) v.back().iov_len += pc[j].iov_len;
                     else v.push_back(pc[j]);
                 }
-                if ((int)v.size() >= CAP) flush(which);
+                if ((int)v.size() >= CAP) flush();
             }
-            for (int k = 0; k < 3; k++) if (!iov[k].empty()) flush(k);
+            if (!v.empty()) flush();
         };
         std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(put, t);
-        put(0);
+        if (w->threads > 1) {
+            for (int k = 1; k < 3; k++) if (at[k]) pool.emplace_back(put, k);
+            if (at[0]) put(0);
+        } else {
+            for (int k = 0; k < 3; k++) if (at[k]) put(k);
+        }
         for (std::thread &th : pool) th.join();
         if (failed_errno.load()) return ffail(TBK_ERR_IO, "write: %s", strerror(failed_errno.load()));
         for (int k = 0; k < 3; k++) w->bin[k].file_off += at[k];
