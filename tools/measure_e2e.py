@@ -31,6 +31,7 @@ ap.add_argument("--read-len", type=int, default=15_000)
 ap.add_argument("--k", type=int, default=21)
 ap.add_argument("--dir", default=None)
 ap.add_argument("--modes", default="plain,gzip")
+ap.add_argument("--out-dir", default=None, help="where the runs write their bins (default: the inputs' temporary directory)")
 ap.add_argument("--devices", default="", help="also run the plain mode with TBK_DEVICES set to this list (e.g. 0,0,0: three rings on one GPU)")
 ap.add_argument("--keep", action="store_true")
 a = ap.parse_args()
@@ -40,7 +41,14 @@ from trio_binning_amd._lib import check, lib  # noqa: E402
 
 k, L, R, N = a.k, a.read_len, a.reads, a.kmers
 tmp = tempfile.mkdtemp(prefix="tbk_e2e_", dir=a.dir)
+out_root = tempfile.mkdtemp(prefix="tbk_e2e_out_", dir=a.out_dir) if a.out_dir else tmp
+def fs_of(path):
+    st = os.statvfs(path)
+    return {"path": path, "total_GB": round(st.f_blocks * st.f_frsize / 1e9, 1), "free_GB_at_start": round(st.f_bavail * st.f_frsize / 1e9, 1)}
+
+
 res = {"config": f"BASELINE configs[1] shape: {R} x {L} b reads, 2 x {N} unique {k}-mers as text lists", "dir": tmp,
+       "inputs_on": fs_of(tmp), "outputs_on": fs_of(out_root),
        "page_cache": "warm", "host_usable_cpus": int(lib.tbk_host_threads())}
 dev = 0
 
@@ -134,7 +142,7 @@ for mode, cache in runs:
         e = dict(env, TBK_LIST_CACHE="0") if cache == "text_lists" else dict(env)
         if cache.startswith("devices_"):
             e["TBK_DEVICES"] = a.devices
-        out = os.path.join(tmp, mode + "_" + cache)
+        out = os.path.join(out_root, mode + "_" + cache)
         os.makedirs(out)
         tsv = os.path.join(out, "stdout.tsv")
         t = time.time()
@@ -149,6 +157,7 @@ for mode, cache in runs:
             continue
         st = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-stats ")]
         stages = json.loads(st[-1][10:]) if st else {}
+        wt = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-write-timing ")]
         bins = {}
         with open(tsv, "rb") as fh:
             for line in fh:
@@ -157,10 +166,11 @@ for mode, cache in runs:
         res[mode + "_" + cache] = {
             "wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
             "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None,
-            "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins,
+            "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins, "write_timing": wt[-1] if wt else None,
             "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages
 if not a.keep:
     shutil.rmtree(tmp, ignore_errors=True)
+    shutil.rmtree(out_root, ignore_errors=True)
 print(json.dumps(res))

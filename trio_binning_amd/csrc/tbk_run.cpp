@@ -124,6 +124,8 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     };
 
     double read_s = 0, write_s = 0, gpu_wait_s = 0;
+    const bool write_timing = getenv("TBK_WRITE_TIMING") != nullptr;  // the writer's ms per batch, in tenths of the run, to stderr
+    std::vector<double> per_batch_ms;
     std::thread reader_thread, writer_thread;
     if (!rc) {
         reader_thread = std::thread([&] {
@@ -162,6 +164,7 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
                     }
                     if (r) failure.set(r, tbk_last_error());
                     write_s += since(t);
+                    if (write_timing) per_batch_ms.push_back(since(t) * 1e3);
                 }
                 free_q.put(it);
             }
@@ -205,6 +208,19 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
         writer_thread.join();
         free_q.close();
         reader_thread.join();
+    }
+    if (write_timing && !per_batch_ms.empty()) {
+        std::string line = "tbk-write-timing ms per batch, by tenth of the run:";
+        const size_t nb = per_batch_ms.size();
+        for (size_t d = 0; d < 10; d++) {
+            const size_t lo = nb * d / 10, hi = std::max(lo + 1, nb * (d + 1) / 10);
+            double sum = 0;
+            for (size_t i = lo; i < hi && i < nb; i++) sum += per_batch_ms[i];
+            char buf[32];
+            snprintf(buf, sizeof buf, " %.1f", sum / (double)(std::min(hi, nb) - lo));
+            line += buf;
+        }
+        fprintf(stderr, "%s\n", line.c_str());
     }
     int rc_close = tbk_bin_writer_close(writer);
     tbk_fastx_close(reader);
