@@ -34,7 +34,12 @@ python tools/profile_summary.py gpurun_out > gpurun_out/profile_summary.log 2>&1
 find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete; find gpurun_out -name "*counter_collection.csv" -size +2M -delete
 # host side of the boundary
 ( timeout 600 python tools/measure_reader.py --qual hifi ) > gpurun_out/reader_hifi.json 2> gpurun_out/reader_hifi.err
-( timeout 1500 python tools/measure_e2e.py --devices 0,0,0 ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
+# end to end at configs[1] scale: inputs in memory (/dev/shm) and bins on the disk - the box's 84 GB file system then holds the 30 GB
+# of bins only; and everything on that disk (34 GB of inputs + 5 GB of key caches + 30 GB of bins: ext4 runs low on free space
+# against its dirty data and stops the writer for ~2 s near the end, profiles/r03/e2e_writer_stall.log)
+( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --dir /dev/shm --out-dir /tmp --devices 0,0,0 ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
+rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*
+( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --modes plain ) > gpurun_out/cli_configs1_one_small_disk.json 2> gpurun_out/cli_configs1_one_small_disk.err
 ( timeout 600 python tools/measure_cli.py --reads 60000 --gz-input ) > gpurun_out/cli_gz_input.json 2> gpurun_out/cli_gz_input.err
 tail -c 600 gpurun_out/reader_hifi.json; tail -c 1500 gpurun_out/cli_configs1.json
 exit 0

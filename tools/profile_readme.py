@@ -15,7 +15,7 @@ src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
-        "reader_hifi.json", "cli_configs1.json", "cli_gz_input.json"]
+        "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_gz_input.json"]
 for name in KEEP:
     p = os.path.join(src, name)
     if os.path.isfile(p) and os.path.getsize(p) > 0:
@@ -141,10 +141,24 @@ if cli:
             "| lists | both lists (s) | M lines/s | paired table build (s) |", "|---|---|---|---|"]
     out += [f"| {k} | {v['both_lists_s']} | {v['Mlines_per_s']} | {v['paired_table_build_s']} |" for k, v in cli.get("lists", {}).items()]
     out += ["", "| run | wall (s) | Gbases/s, wall | loop (s) | reader busy (s) | writer busy (s) | waiting for the GPU (s) | before the loop (s) | output (GB) |", "|---|---|---|---|---|---|---|---|---|"]
-    for k, v in cli.items():
-        if isinstance(v, dict) and "wall_s" in v:
-            st = v["stages"]
-            out += [f"| {k} | {v['wall_s']} | {v['gbases_per_s_wall']} | {st.get('loop_s')} | {st.get('read_s')} | {st.get('write_s')} | {st.get('gpu_wait_s')} | {v['before_the_loop_s']} | {v['out_GB']} |"]
+    def runs(c):
+        rows = []
+        for k, v in c.items():
+            if isinstance(v, dict) and "wall_s" in v:
+                st = v["stages"]
+                rows += [f"| {k} | {v['wall_s']} | {v['gbases_per_s_wall']} | {st.get('loop_s')} | {st.get('read_s')} | {st.get('write_s')} | {st.get('gpu_wait_s')} | {v['before_the_loop_s']} | {v['out_GB']} |"]
+        return rows
+    out += runs(cli)
+    out += ["", f"(inputs on {cli.get('inputs_on')}, bins on {cli.get('outputs_on')}; inputs sync'ed in {cli.get('inputs_synced_s')} s before the runs.)"]
+    small = load("cli_configs1_one_small_disk.json")
+    if small:
+        out += ["", f"The same with inputs and bins on the one {g(small, 'outputs_on', 'total_GB')} GB file system of the box (inputs + key caches + bins = 69 GB of it: ext4 runs low on free space against its dirty data and",
+                "stops the writer for about 2 s near the end of a run - `e2e_writer_stall.log`):", "",
+                "| run | wall (s) | Gbases/s, wall | loop (s) | reader busy (s) | writer busy (s) | waiting for the GPU (s) | before the loop (s) | output (GB) |", "|---|---|---|---|---|---|---|---|---|"]
+        out += runs(small)
+        wt = [v.get("write_timing") for v in small.values() if isinstance(v, dict) and v.get("write_timing")]
+        if wt:
+            out += ["", "Writer, " + wt[0][len("tbk-write-timing "):] + "."]
 if reader:
     out += ["", f"Reader alone (`tools/measure_reader.py --qual hifi`, {reader['text_GB']} GB of FASTQ text, GB/s of text): plain first pass {g(reader, 'plain_first_pass', 'text_GB_per_s')}, "
             f"plain warm {g(reader, 'plain', 'text_GB_per_s')}, gzip {g(reader, 'gzip', 'text_GB_per_s')}, bgzf {g(reader, 'bgzf', 'text_GB_per_s')}."]
