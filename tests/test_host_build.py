@@ -2,7 +2,7 @@
 
 The single-read probe kernel - the dominant kernel - must fit five waves per SIMD (<= 96 VGPRs) without a
 single spilled VGPR: a probe kernel that touches scratch memory at all ran 18-22 ms from one stream to the next
-where the spill-free one runs 17.2 (EXPERIMENTS.md, round 3).  The multi-read kernel must not spill VGPRs either
+where the spill-free one runs 17.1-17.3 (EXPERIMENTS.md, round 3); the whole-line variants up to W = 6 too.  The multi-read kernel must not spill VGPRs either
 (<= 128, four waves)."""
 import os
 import re
@@ -34,8 +34,8 @@ def test_probe_kernels_do_not_spill_vector_registers(built):
     assert len(rows) >= 60, len(rows)   # every (W, m-mer width, sampling rule, layout) variant, single- and multi-read
     for r in rows:
         assert r["vgpr_spill"] == 0, r                         # no scratch memory in any probe kernel
-        if r["front"] and not r["multi"]:
-            assert r["vgpr"] <= 96, r                          # five waves per SIMD
+        if not r["multi"] and (r["front"] or 2 <= r["w"] <= 6):
+            assert r["vgpr"] <= 96, r                          # five waves per SIMD (whole lines: up to W = 6)
         else:
             assert r["vgpr"] <= 128, r                         # four
         assert r["lds"] <= 8192, r                             # 20 one-wave blocks per CU fit the 160 KB of LDS
