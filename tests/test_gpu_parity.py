@@ -618,6 +618,47 @@ def test_lists_choose_the_line_layout(gpu, orc, monkeypatch):
         monkeypatch.delenv("TBK_FRONT")
 
 
+@pytest.mark.parametrize("k,want_w", [(21, 7), (22, 7), (23, 8), (25, 8), (31, 8), (32, 7)])  # (lists this small leave room for m = 15 or 16; 2 x 3e8 21-mers: w = 6, m = 16)
+def test_span_follows_k(gpu, orc, monkeypatch, k, want_w):
+    """Without TBK_MINIMIZER_W the span is as long as k leaves room for, up to 8 m-mers (front layout: fewer line
+    switches per window); lists that cluster fall back to whole lines and a span of at most 6.  Counts are the
+    oracle's either way."""
+    import ctypes as C
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    for v in ("TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT"):
+        monkeypatch.delenv(v, raising=False)
+    n = 200_000
+    uni = np.empty(2 * n, dtype=np.uint64)
+    check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, k, uni.ctypes.data))
+    ka, kb = uni[:n], uni[n:]
+    oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
+    rng = np.random.default_rng(k)
+
+    def decode(key):
+        return "".join("ACGT"[(int(key) >> (2 * i)) & 3] for i in range(k))
+
+    plants = [decode(x) for x in np.concatenate([ka[:200], kb[:200]])]
+    reads = _rand_reads(rng, 200, 3000, plants, k, p_plant=0.9)
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob)
+    assert want.sum() > 200
+    a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["minimizer_w"] == want_w and st["front_layout"] and st["sampling_t"] > 0 and st["layout_builds"] == 1, st
+        span = st["minimizer_m"] + st["minimizer_w"] - 1
+        assert span <= k and (k - span) % 2 == 0, st
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
+    monkeypatch.setenv("TBK_FRONT", "0")  # whole lines (what clustered lists get): the span stays at 6 or below
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["minimizer_w"] <= 6 and not st["front_layout"], st
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
+
+
 def test_prepacked_batches(gpu, orc, transfer):
     """tbk_pack_bases + tbk_stream_submit_packed: batches packed ahead of time (pinned and pageable
     arrays), with N runs, lower case, reads ending inside a chunk, an empty batch; counts equal the

@@ -922,8 +922,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
     c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
     c->slice_bases = (uint64_t)std::max(2048.0, env_double("TBK_SLICE_BASES", (double)((uint64_t)384 << 20)));
-    // Bucket selection: an m-mer sampled from the k-mer's central span (TBK_MINIMIZER_W m-mers, default 6;
-    // 0 = plain hashing of the whole key) by mod-sampling, which switches lines 18 % less often than the random
+    // Bucket selection: an m-mer sampled from the k-mer's central span (6 to 8 m-mers, see span_for below;
+    // TBK_MINIMIZER_W = 0: plain hashing of the whole key) by mod-sampling, which switches lines 18 % less often than the random
     // minimizer; the load is 0.08 (100 B of HBM per key).  In which layout the probe reads a line is decided by
     // the lists.  Front layout (tbk_common.h): the probe kernel asks for 64 bytes of a line, the first four slots
     // of each list (a list's fifth key of a bucket sits, tagged, in a free front slot of the other list first); a
@@ -944,13 +944,29 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // a front, build the same table again in whole lines.  TBK_MOD_SAMPLING=0 pins the random minimizer, TBK_FRONT
     // the layout, TBK_TABLE_LOAD the load.
     const double pin = env_double("TBK_MOD_SAMPLING", -1);
-    const int w_target = (int)env_double("TBK_MINIMIZER_W", 6), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
+    const int w_pin = (int)env_double("TBK_MINIMIZER_W", -1), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
     const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
     const double front_pin = env_double("TBK_FRONT", -1);
-    c->mz = tbk_mz_params(c->k, w_target, n_big, m_force, pin != 0);
-    bool front = c->mz.w >= 2 && front_pin != 0;
+    // The span: as many m-mers as k leaves room for beside an m long enough for the keys, up to 8 - a window then
+    // switches lines with density 3/(2w+1): 0.176 at w = 8 against 0.231 at w = 6 (k = 21 has room for 6 only;
+    // k = 25, 2 x 3e8 keys: 208 against 182 Gbases/s; k = 31, 2 x 1e9 keys: 221 against 193 -
+    // profiles/r03/ab_spans.log).  That is for the front layout: a longer span also means longer runs of a
+    // clustered list's keys in one bucket, and the whole-line kernels of w = 7, 8 keep 4 waves per SIMD, so whole
+    // lines stay at w = 6 (k = 31, haplotype-shaped lists: 153 at w = 6, 134 at w = 8).  TBK_MINIMIZER_W pins it.
+    auto span_for = [&](bool front_layout) {
+        if (w_pin >= 0) return tbk_mz_params(c->k, w_pin, n_big, m_force, pin != 0);
+        if (front_layout && pin != 0 && m_force <= 0)
+            for (int w = 8; w > 6; w--) {
+                const TbkMz z = tbk_mz_params(c->k, w, n_big, m_force, 1);
+                if (z.w == w && z.t > 0) return z;
+            }
+        return tbk_mz_params(c->k, 6, n_big, m_force, pin != 0);
+    };
+    bool front = front_pin != 0;
     for (;;) {
+        c->mz = span_for(front);
+        if (c->mz.w < 2) front = false;  // (plain hashing and one-m-mer spans have no front layout)
         c->free_pair();
         c->layout_builds++;
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
