@@ -39,6 +39,9 @@ find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete; find gpurun_out -n
 # against its dirty data and stops the writer for ~2 s near the end, profiles/r03/e2e_writer_stall.log)
 ( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --dir /dev/shm --out-dir /tmp --devices 0,0,0 ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
 rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*
+# list loading at BASELINE configs[2] scale: 2 x 3e8-line text lists (13.2 GB), a small read set behind them
+( timeout 1500 python tools/measure_e2e.py --kmers 300000000 --reads 100000 --modes plain --dir /dev/shm --out-dir /tmp ) > gpurun_out/cli_lists_configs2.json 2> gpurun_out/cli_lists_configs2.err
+rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*
 ( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --modes plain ) > gpurun_out/cli_configs1_one_small_disk.json 2> gpurun_out/cli_configs1_one_small_disk.err
 ( timeout 600 python tools/measure_cli.py --reads 60000 --gz-input ) > gpurun_out/cli_gz_input.json 2> gpurun_out/cli_gz_input.err
 tail -c 600 gpurun_out/reader_hifi.json; tail -c 1500 gpurun_out/cli_configs1.json

@@ -15,7 +15,7 @@ src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
-        "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_gz_input.json"]
+        "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
 for name in KEEP:
     p = os.path.join(src, name)
     if os.path.isfile(p) and os.path.getsize(p) > 0:
@@ -150,6 +150,11 @@ if cli:
         return rows
     out += runs(cli)
     out += ["", f"(inputs on {cli.get('inputs_on')}, bins on {cli.get('outputs_on')}; inputs sync'ed in {cli.get('inputs_synced_s')} s before the runs.)"]
+    big = load("cli_lists_configs2.json")
+    if big:
+        out += ["", f"List loading at BASELINE configs[2] scale ({big['config']}; {big['lists_GB']} GB of list text):", "",
+                "| lists | both lists (s) | M lines/s | paired table build (s) |", "|---|---|---|---|"]
+        out += [f"| {k} | {v['both_lists_s']} | {v['Mlines_per_s']} | {v['paired_table_build_s']} |" for k, v in big.get("lists", {}).items()]
     small = load("cli_configs1_one_small_disk.json")
     if small:
         out += ["", f"The same with inputs and bins on the one {g(small, 'outputs_on', 'total_GB')} GB file system of the box (inputs + key caches + bins = 69 GB of it: ext4 runs low on free space against its dirty data and",
