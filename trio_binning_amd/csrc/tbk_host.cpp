@@ -34,7 +34,8 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, c
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, hipStream_t);
+extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
+extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
                                              int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, hipEvent_t, hipStream_t);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
@@ -1213,7 +1214,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         if (c->d_pass_read) HIP_TRY(hipFree(c->d_pass_read));
         c->d_pass_read = nullptr; c->cap_passes = 0;
         const uint64_t cap = passes + passes / 4 + 1024;
-        HIP_TRY(hipMalloc((void **)&c->d_pass_read, (2 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, its length
+        HIP_TRY(hipMalloc((void **)&c->d_pass_read, (3 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, two-read pass list, their lengths
         c->cap_passes = cap;
     }
     const ProbeSlice whole = {0, passes, nullptr};
@@ -1238,7 +1239,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         c->timed_launches++;
         HIP_TRY(hipEventRecord(ev[0], c->compute));
     }
-    HIP_TRY(tbk_launch_probe_index(d_offsets, n_reads, total, d_counts, c->d_pass_read, c->cap_passes, c->compute));
+    HIP_TRY(tbk_launch_probe_index(d_offsets, n_reads, total, d_counts, c->d_pass_read, c->cap_passes, tbk_probe_has_two_read_kernel(c->mz), c->compute));
     if (ev) HIP_TRY(hipEventRecord(ev[1], c->compute));
     for (int j = 0; j < n_slices; j++) {
         if (slices[j].arrived) HIP_TRY(hipStreamWaitEvent(c->compute, slices[j].arrived, 0));
@@ -1670,7 +1671,7 @@ extern "C" int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, do
 }
 
 // the most recent probe's passes (2048 window starts each) and how many of them touched more than one read
-// (the multi-read kernel's share; the rest is the single-read kernel's)
+// (the multi-read and two-read kernels' share; the rest is the single-read kernel's)
 extern "C" int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes, uint64_t *n_multi) {
     if (!c || !n_passes || !n_multi) return fail(TBK_ERR_INVALID, "NULL argument");
     *n_passes = c->last_passes; *n_multi = 0;
@@ -1678,9 +1679,9 @@ extern "C" int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes,
     int rc = use_device(c->device);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
-    uint32_t m = 0;
-    HIP_TRY(hipMemcpy(&m, c->d_pass_read + 2 * c->cap_passes, sizeof m, hipMemcpyDeviceToHost));
-    *n_multi = m;
+    uint32_t m[2] = {0, 0};  // passes listed for the multi-read kernel, and for the two-read kernel
+    HIP_TRY(hipMemcpy(m, c->d_pass_read + 3 * c->cap_passes, sizeof m, hipMemcpyDeviceToHost));
+    *n_multi = (uint64_t)m[0] + m[1];
     return TBK_OK;
 }
 

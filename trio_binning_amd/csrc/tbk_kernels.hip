@@ -287,6 +287,8 @@ struct ProbeArgs {
     const uint32_t *pass_read;  // [n_passes] read that contains each pass's first position
     const uint32_t *multi_list; // passes that touch more than one read (the multi-read kernel's work list)
     const uint32_t *n_multi;    // their number
+    const uint32_t *two_list;   // passes that touch exactly two reads (the two-read kernel's work list; empty where that kernel is not built)
+    const uint32_t *n_two;
     uint64_t pass_lo, pass_hi;  // this launch's share of the passes (a batch may be probed slice by slice, as its bases arrive)
 };
 
@@ -486,7 +488,10 @@ __device__ __forceinline__ void drain_back(const ProbeArgs &p, const uint4 *bq, 
 
 // One wave pass.  W = m-mers per minimizer span (0: plain hashing, one random line per
 // window).  MULTI = the pass touches more than one read.
-template <int W, bool M64, bool SAMP, bool MULTI, bool FRONT>
+// TWO = the pass touches exactly two reads (15 kb reads: one pass in seven): the single-read pass's code with the
+// boundary folded into the lanes' not-ACGT masks and into four scalar ownership masks, instead of MULTI's
+// per-lane read bookkeeping and tallies - so that these passes, too, run at five waves per SIMD.
+template <int W, bool M64, bool SAMP, bool MULTI, bool FRONT, bool TWO = false>
 __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0, const uint64_t e1,
                                            const uint64_t e2, const uint64_t e3, const uint64_t P0,
                                            const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
@@ -520,7 +525,24 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     // clean when the low k bits are zero
     uint64_t bad64 = (uint64_t)((uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16)) |
                      ((uint64_t)((uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16)) << 32);
-    if (!MULTI) {
+    // TWO: lanes whose windows all start in the pass's second read, and the lane (if any) whose windows start in the
+    // first read up to the boundary and in the second from it on.  Both kinds see their bases as the second read does;
+    // the straddling lane's windows of the first read must, besides, end before the boundary (the window loop's `cross`).
+    bool is_second = false, is_strad = false;
+    if (TWO) {
+        const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
+        const uint64_t r2_end = p.offsets[r_first + 2];  // (exists: the pass's second read is read r_first + 1)
+        is_second = p_first >= r_first_end;
+        const uint64_t inside = is_second ? 64 : r_first_end - p_first;  // bases of this lane before the first read's end
+        is_strad = inside < TBK_WPL;
+        if (is_second || is_strad) {
+            const uint64_t inside2 = r2_end > p_first ? r2_end - p_first : 0;
+            if (inside2 < 64) bad64 |= ~0ull << inside2;
+        } else if (inside < 64) {
+            bad64 |= ~0ull << inside;
+        }
+    }
+    if (!MULTI && !TWO) {
         const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
         const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;  // bases of this lane before the read end
         if (inside < 64) bad64 |= ~0ull << inside;
@@ -618,8 +640,19 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         return pos > p_lane ? (uint32_t)(pos - p_lane < 0x40000000ull ? pos - p_lane : 0x40000000ull) : 0u;
     };
     uint32_t rel_end = rel(rend);
-    uint32_t acc_a = 0, acc_b = 0;  // wave-uniform in the single-read case
+    uint32_t acc_a = 0, acc_b = 0;  // wave-uniform in the single-read case (TWO: the pass's first read)
     uint32_t lane_a = 0, lane_b = 0;  // multi-read pass: this lane's hits in read `rid`
+    // TWO: hits of the second read, and per sub-step s the lanes (all four of a quad) whose quad's window s belongs
+    // to the FIRST read at the current step: fixed but for the straddling lane's quad, which changes sides once
+    uint32_t acc2_a = 0, acc2_b = 0;
+    uint64_t own1[4] = {0, 0, 0, 0};
+    uint32_t jb_s = 0xFFFFu;  // the step at which the straddling lane changes sides (wave-uniform; none: never)
+    if (TWO) {
+        const uint32_t brel = (uint32_t)(r_first_end - P0);  // 1 .. TBK_PASS - 1
+        if (brel % TBK_WPL) jb_s = brel % TBK_WPL;
+#pragma unroll
+        for (int s = 0; s < 4; s++) own1[s] = ballot(((lane & ~3u) + (uint32_t)s) * TBK_WPL < brel);  // owner lane 4q + s starts in the first read
+    }
 
     // the line each quad slot holds from the previous window of the same lane
     ulonglong2 va[4], vb[4];
@@ -694,7 +727,18 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 rel_end = rel(rend);
             }
         }
+        if (TWO && (uint32_t)j == jb_s) {
+            // the straddling lane's windows belong to the second read from here on: its quad's bits of own1 go
+            // (sub-step = that lane's place in its quad)
+            const uint64_t strad = ballot(is_strad);  // one lane
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (strad & (0x1111111111111111ull << s)) own1[s] &= ~(quad_any(strad) * 15ull);  // (all four bits of that quad)
+        }
         bool ok = (bad_lo & badk) == 0;  // single-read pass: the read end is part of the mask
+        if (TWO) {
+            const bool cross = (uint32_t)j < jb_s && (uint32_t)(j + k) > jb_s;  // (wave-uniform) a window of the first read that would reach over the boundary
+            ok = ok && !(cross && is_strad);
+        }
         if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
         const uint32_t bkt = bucket_here(j);
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
@@ -708,6 +752,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         const uint32_t my_klo = ok ? (uint32_t)key : (uint32_t)TBK_NOKEY;
         const uint32_t my_khi = ok ? (uint32_t)(key >> 32) : (uint32_t)(TBK_NOKEY >> 32);
         const uint32_t my_rid = (uint32_t)rid;
+        auto two_rid = [&]() -> uint32_t { return (is_second || (is_strad && (uint32_t)j >= jb_s)) ? 1u : 0u; };  // TWO: 0 / 1 = this lane's window belongs to the pass's first / second read
 
         // advance to window j+1: S >>= 2, R <<= 2, bad >>= 1
         s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
@@ -791,7 +836,7 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 if (need) {
                     const uint64_t me = 1ull << lane;
                     if (need & me) {
-                        const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : 0u;
+                        const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : TWO ? two_rid() : 0u;
                         backq[qb + (uint32_t)__popcll(need & (me - 1))] =
                             make_uint4(my_klo, my_khi, last_bk, (rrel << 2) | ((uint32_t)((beh_a >> lane) & 1ull) << 1) | (uint32_t)((beh_b >> lane) & 1ull));
                     }
@@ -800,7 +845,16 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                 }
             }
             if (any_hit != 0) {
-                if (!MULTI) {
+                if (TWO) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const uint64_t h1 = hit[s] & own1[s], h2 = hit[s] & ~own1[s];
+                        acc_a += (uint32_t)__popcll(h1 & 0x3333333333333333ull);
+                        acc_b += (uint32_t)__popcll(h1 & 0xCCCCCCCCCCCCCCCCull);
+                        acc2_a += (uint32_t)__popcll(h2 & 0x3333333333333333ull);
+                        acc2_b += (uint32_t)__popcll(h2 & 0xCCCCCCCCCCCCCCCCull);
+                    }
+                } else if (!MULTI) {
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
                         acc_a += (uint32_t)__popcll(hit[s] & 0x3333333333333333ull);
@@ -863,7 +917,10 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                     const uint64_t tagged = kk[s] | TBK_GUEST;
                     const uint64_t ga = ballot(vb[s].x == tagged) | ballot(vb[s].y == tagged);  // hapA's guests sit in hapB's half
                     const uint64_t gb = ballot(va[s].x == tagged) | ballot(va[s].y == tagged);
-                    if (!MULTI) {
+                    if (TWO) {
+                        acc_a += (uint32_t)__popcll(ga & own1[s]); acc2_a += (uint32_t)__popcll(ga & ~own1[s]);
+                        acc_b += (uint32_t)__popcll(gb & own1[s]); acc2_b += (uint32_t)__popcll(gb & ~own1[s]);
+                    } else if (!MULTI) {
                         acc_a += (uint32_t)__popcll(ga);
                         acc_b += (uint32_t)__popcll(gb);
                     } else {
@@ -890,12 +947,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
                     const uint64_t me = 1ull << lane;
                     // the read of the window: its owner is quad lane s (a constant once unrolled); taken
                     // here, where the whole wave is active - a DPP move cannot read a masked-off lane
-                    const uint32_t rid_s = !MULTI ? 0u : s == 0 ? quad_bcast<0>(my_rid) : s == 1 ? quad_bcast<1>(my_rid)
-                                                   : s == 2 ? quad_bcast<2>(my_rid) : quad_bcast<3>(my_rid);
+                    const uint32_t rid_v = TWO ? two_rid() : my_rid;
+                    const uint32_t rid_s = !(MULTI || TWO) ? 0u : s == 0 ? quad_bcast<0>(rid_v) : s == 1 ? quad_bcast<1>(rid_v)
+                                                   : s == 2 ? quad_bcast<2>(rid_v) : quad_bcast<3>(rid_v);
                     // one queue entry per (window, list) so that a window's two walks run side by side
                     const uint32_t n_a = (uint32_t)__popcll(walk_a);
                     if (queued & me) {
-                        const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : 0u;
+                        const uint32_t rrel = MULTI ? rid_s - (uint32_t)r_first : TWO ? rid_s : 0u;
                         const uint32_t home = bk[s] & 0x7FFFFFFFu;
                         if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(klo[s], khi[s], home, rrel << 1);
                         if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(klo[s], khi[s], home, (rrel << 1) | 1u);
@@ -906,7 +964,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             }
         }
         if ((any_a | any_b | full_any) != 0) {
-            if (!MULTI) {
+            if (TWO) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    acc_a += (uint32_t)__popcll(hit_a[s] & own1[s]); acc2_a += (uint32_t)__popcll(hit_a[s] & ~own1[s]);
+                    acc_b += (uint32_t)__popcll(hit_b[s] & own1[s]); acc2_b += (uint32_t)__popcll(hit_b[s] & ~own1[s]);
+                }
+            } else if (!MULTI) {
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     acc_a += (uint32_t)__popcll(hit_a[s]);
@@ -931,25 +995,25 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (FRONT) {
             if (qb > TBK_BQCAP - 64) {  // make room for the next step's worst case
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                drain_back<MULTI>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+                drain_back<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 qb = 0;
             }
         } else if (qn > TBK_QCAP - 128) {  // make room for the next step's worst case
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            drain_walks<MULTI, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+            drain_walks<MULTI || TWO, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qn = 0;
         }
     }
     if (FRONT && qb) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_back<MULTI>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+        drain_back<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_walks<MULTI, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
+        drain_walks<MULTI || TWO, FRONT>(p, walkq, qn, r_first, lane, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #ifdef TBK_COUNTERS
@@ -966,7 +1030,16 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         if (cb) { atomicAdd(&p.counts[2 * (r_first + lane) + 1], (int)cb); rcnt[2 * lane + 1] = 0; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (!MULTI) {
+    if (TWO) {
+        // the two reads' counts: what the window loop counted in scalars plus what the drains counted into the tallies
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < 4) {
+            const uint32_t c = rcnt[lane] + (lane == 0 ? acc_a : lane == 1 ? acc_b : lane == 2 ? acc2_a : acc2_b);
+            if (c) atomicAdd(&p.counts[2 * r_first + lane], (int)c);  // counts[read][hap]: (r, A) (r, B) (r + 1, A) (r + 1, B)
+            rcnt[lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (!MULTI) {
         if (lane == 0) {
             if (acc_a) atomicAdd(&p.counts[2 * r_first], (int)acc_a);
             if (acc_b) atomicAdd(&p.counts[2 * r_first + 1], (int)acc_b);
@@ -980,16 +1053,35 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 __global__ void __launch_bounds__(256)
 tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t total, uint64_t n_passes,
                       uint32_t *__restrict__ pass_read, uint32_t *__restrict__ multi_list, uint32_t *__restrict__ n_multi,
-                      int32_t *__restrict__ counts) {
+                      uint32_t *__restrict__ two_list, uint32_t *__restrict__ n_two, int use_two, int32_t *__restrict__ counts) {
     const uint64_t pass = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool to_multi = false, to_two = false;
     if (pass < n_passes) {
         const uint64_t P0 = pass * TBK_PASS;
         const uint64_t r_first = find_read(offsets, n_reads, P0);
         pass_read[pass] = (uint32_t)r_first;
         const uint64_t last_pos = P0 + TBK_PASS - 1 < total ? P0 + TBK_PASS - 1 : total - 1;
         const uint64_t r_end = r_first < n_reads ? offsets[r_first + 1] : total;
-        if (last_pos >= r_end) multi_list[atomicAdd(n_multi, 1u)] = (uint32_t)pass;
+        if (last_pos >= r_end) {
+            // (a read r_first + 1 exists: r_end <= last_pos < total.)  Exactly two reads: the second one reaches past the pass.
+            to_two = use_two && r_end > P0 && offsets[r_first + 2] > last_pos;
+            to_multi = !to_two;
+        }
     }
+    // one atomic per wave and list (on 15 kb reads every seventh pass is listed: a quarter of a million atomics on one
+    // word took 2 ms, the chip's rate for that; the compiler's own aggregation does not see through the two lists)
+    const uint32_t lane = threadIdx.x & 63u;
+    auto append = [&](bool mine, uint32_t *list, uint32_t *n) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
+        if (m == 0) return;
+        const int leader = __builtin_ctzll(m);
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(n, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pass;
+    };
+    append(to_multi, multi_list, n_multi);
+    append(to_two, two_list, n_two);
     // the same launch clears the per-read counters the probe kernels add to
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
@@ -1005,8 +1097,10 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
 // 27.8 against 31.6) and the multi-read kernel keeps 4.  So are the whole-line variants up to W = 6 (96 VGPRs, no
 // vector spills; haplotype-shaped lists, same box: 22.6 ms at 5 waves, 25.4 at 4 - profiles/r03/ab_policy_whole.log).
 // The pass-index kernel lists the multi-read passes; the single-read kernel skips them.
-template <int W, bool M64, bool SAMP, bool FRONT, bool MULTI>
-__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : (FRONT ? TBK_MIN_WAVES : (W <= 6 ? TBK_MIN_WAVES_WHOLE : 4)))
+template <int W, bool M64, bool SAMP, bool FRONT, bool MULTI, bool TWO = false>
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI
+                                                               : TWO ? (FRONT && W <= 7 ? TBK_MIN_WAVES : 4)  // (front W = 8 and whole lines would spill vector registers at 5)
+                                                               : (FRONT ? TBK_MIN_WAVES : (W <= 6 ? TBK_MIN_WAVES_WHOLE : 4)))
 tbk_probe_kernel(const ProbeArgs p) {
     // LDS staging of the read tile, one region per wave: a wave only ever reads what it wrote
     // itself, so wave-scope ordering is enough and the waves of a block never wait for each
@@ -1014,7 +1108,7 @@ tbk_probe_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_QCAP_FRONT : TBK_QCAP];
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][FRONT ? TBK_BQCAP : 1];
-    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : 1];
+    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
     const uint32_t lane = threadIdx.x & 63u;
 #if TBK_OCC_PAD
     __shared__ uint32_t occ_pad[TBK_OCC_PAD / 4];
@@ -1024,21 +1118,25 @@ tbk_probe_kernel(const ProbeArgs p) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
     if (MULTI) { rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0; }  // per-read tallies (zero between passes)
-    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : p.pass_hi - p.pass_lo;
+    if (TWO && lane < 4) rcnt[wave][lane] = 0;
+    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : TWO ? (uint64_t)*p.n_two : p.pass_hi - p.pass_lo;
 
     // The multi-read kernel walks its list with a fixed grid; the single-read kernel is launched with one block per
     // pass and has no loop around the pass: the loop's live state cost it 8 spilled registers, and a kernel that
     // uses scratch memory at all ran 18-22 ms from one stream to the next where this one runs 18-19 (EXPERIMENTS.md).
+    // The two-read kernel is launched with one block per possible list entry (a batch of n reads has fewer than n
+    // two-read passes); blocks past the list's end leave at once.
     for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
-        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : p.pass_lo + item;
+        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : TWO ? (uint64_t)p.two_list[item] : p.pass_lo + item;
         if (MULTI && (pass < p.pass_lo || pass >= p.pass_hi)) continue;  // (the list is the whole batch's, in no order)
+        if (TWO && (pass < p.pass_lo || pass >= p.pass_hi)) return;
         const uint64_t P0 = pass * TBK_PASS;
         // which read(s) does this pass touch?  (wave-uniform)
         const uint64_t r_first = p.pass_read[pass];
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
-        if (!MULTI) {
+        if (!MULTI && !TWO) {
             const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
-            if (last_pos >= r_end) return;  // the multi-read kernel's
+            if (last_pos >= r_end) return;  // the multi-read or the two-read kernel's
         }
         if (p.codes != nullptr) {  // packed input (wave-uniform): the chunk words are there already
             const uint64_t c0 = P0 / 16 + lane;
@@ -1054,7 +1152,7 @@ tbk_probe_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass<W, M64, SAMP, MULTI, FRONT>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave]);
+        probe_pass<W, M64, SAMP, MULTI, FRONT, TWO>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave]);
         if (!MULTI) return;  // one pass per block
     }
 }
@@ -1131,20 +1229,28 @@ static void fill_args(ProbeArgs &p, const uint8_t *d_bases, const uint32_t *d_co
     p.codes = d_codes; p.bad16 = d_bad16; p.n_chunks = (total + 15) / 16;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_scratch + pass_cap; p.n_multi = d_scratch + 2 * pass_cap;
+    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_scratch + pass_cap; p.two_list = d_scratch + 2 * pass_cap;
+    p.n_multi = d_scratch + 3 * pass_cap; p.n_two = d_scratch + 3 * pass_cap + 1;  // (tbk_host.cpp sizes the scratch: 3 * pass_cap + 16 words)
     p.pass_lo = 0; p.pass_hi = p.n_passes;
 }
 
+// use_two != 0: passes that touch exactly two reads get a list of their own (the two-read kernel's; built for the
+// mod-sampling variants - tbk_probe_has_two_read_kernel)
+extern "C" int tbk_probe_has_two_read_kernel(TbkMz mz) {
+    static const bool off = getenv("TBK_TWO_READ") && *getenv("TBK_TWO_READ") == '0';  // (0: two-read passes go to the multi-read kernel, as before round 3)
+    return !off && mz.w >= 2 && mz.t > 0;
+}
+
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t n_reads, uint64_t total, int32_t *d_counts, uint32_t *d_scratch,
-                                             uint64_t pass_cap, hipStream_t stream) {
+                                             uint64_t pass_cap, int use_two, hipStream_t stream) {
     if (total == 0 || n_reads == 0) return hipSuccess;
     const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
     if (n_passes > pass_cap) return hipErrorInvalidValue;
-    uint32_t *d_multi = d_scratch + pass_cap, *d_n_multi = d_scratch + 2 * pass_cap;
-    hipError_t e = hipMemsetAsync(d_n_multi, 0, sizeof(uint32_t), stream);
+    uint32_t *d_multi = d_scratch + pass_cap, *d_two = d_scratch + 2 * pass_cap, *d_n = d_scratch + 3 * pass_cap;
+    hipError_t e = hipMemsetAsync(d_n, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((n_passes + 255) / 256)), dim3(256), 0, stream,
-                       d_offsets, n_reads, total, n_passes, d_scratch, d_multi, d_n_multi, d_counts);
+                       d_offsets, n_reads, total, n_passes, d_scratch, d_multi, d_n, d_two, d_n + 1, use_two, d_counts);
     return hipGetLastError();
 }
 
@@ -1165,10 +1271,17 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
+    // the two-read kernel: one block per possible list entry (fewer two-read passes than reads, and than passes)
+    const uint64_t blocks_two = tbk_probe_has_two_read_kernel(t.mz) ? std::min<uint64_t>(n_reads > 1 ? n_reads - 1 : 0, p.n_passes) : 0;  // (the list is the whole batch's: every launch walks all of it)
+    const dim3 grid_two((unsigned)std::max<uint64_t>(1, blocks_two));
     hipError_t e = hipSuccess;
-    for (int multi = 1; multi >= 0; multi--) {
-#define TBK_LAUNCH(N, M, S, F) do { if (multi) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, true>), grid_multi, block, 0, stream, p); \
-                                    else hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, false>), grid, block, 0, stream, p); } while (0)
+    for (int which = 2; which >= 0; which--) {  // 2: multi-read passes, 1: two-read passes, 0: single-read passes (timed by itself: `between`)
+        if (which == 1 && blocks_two == 0) continue;
+        // the event in front of the single-read kernel: the host times it by itself (tbk_kernel_timing_read2)
+        if (which == 0 && between != nullptr) { e = hipEventRecord(between, stream); if (e != hipSuccess) return e; }
+#define TBK_LAUNCH(N, M, S, F) do { if (which == 2) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, true>), grid_multi, block, 0, stream, p); \
+                                    else if (which == 0) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, false>), grid, block, 0, stream, p); \
+                                    else if (S && N >= 2) hipLaunchKernelGGL((tbk_probe_kernel<N, M, (S && N >= 2), F, false, (S && N >= 2)>), grid_two, block, 0, stream, p); } while (0)
 #define TBK_W(N) case N: if (samp && front) { if (m64) TBK_LAUNCH(N, true, true, true); else TBK_LAUNCH(N, false, true, true); } \
                          else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
@@ -1187,8 +1300,6 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
 #undef TBK_LAUNCH
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        // the event between the two kernels: the host times them separately (tbk_kernel_timing_read2)
-        if (multi && between != nullptr) { e = hipEventRecord(between, stream); if (e != hipSuccess) return e; }
     }
     return hipSuccess;
 }
