@@ -618,6 +618,58 @@ def test_lists_choose_the_line_layout(gpu, orc, monkeypatch):
         monkeypatch.delenv("TBK_FRONT")
 
 
+@pytest.mark.parametrize("k,front", [(21, 1), (21, 0), (31, 1), (16, 1)])
+def test_two_read_passes_at_every_boundary_offset(gpu, orc, monkeypatch, k, front):
+    """Passes that touch exactly two reads run through a kernel of their own: the boundary is folded into the lanes'
+    masks and into scalar ownership masks.  Here the boundary falls on every offset inside a lane (0..31), next to
+    the pass's first and last window, and the bases on both sides of it are dense with list k-mers - including
+    k-mers that would match ACROSS the boundary if the two reads were one.  Counts are the oracle's, with the
+    kernel (default) and without it (TBK_TWO_READ is read once per process: compared through the sliced and
+    unsliced paths instead)."""
+    from trio_binning_amd import kmers
+
+    for v in ("TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("TBK_FRONT", str(front))
+    rng = np.random.default_rng(100 * k + front)
+    genome = "".join("ACGT"[c] for c in rng.integers(0, 4, 400_000))
+    # every other k-mer of the genome is in a list: reads cut from it hit in nearly every window
+    starts = rng.permutation(len(genome) - k)[:60_000]
+    la = [genome[p:p + k] for p in starts[:30_000]]
+    lb = [genome[p:p + k] for p in starts[30_000:]]
+    canon = lambda x: min(x, _rc(x))
+    ka = np.array([kmers.kmer_to_int(canon(x)) for x in la], dtype=np.uint64)
+    kb = np.array([kmers.kmer_to_int(canon(x)) for x in lb], dtype=np.uint64)
+    oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
+    a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
+    # consecutive pieces of the genome: cut where one read ends the next begins, so a window over the cut would be a
+    # genome k-mer (a hit) if the kernel let it through.  Piece lengths put the cuts on every offset mod 32, at
+    # distance 1 .. k from both ends of a pass, and leave passes with exactly two reads between longer reads.
+    lengths = []
+    for d in list(range(0, 34)) + [2048 - 1, 2048 - k, 2048 - k + 1, 1, k - 1, k, k + 1]:
+        lengths += [2048 + 700 + d, 2048 * 2 - 700]
+    lengths += [15000] * 6 + [2048] * 3 + [4096 + 5, 2043, 33, 2048 * 3 - 38]
+    reads, at = [], 0
+    for n in lengths:
+        if at + n > len(genome):
+            at = int(rng.integers(0, 1000))
+        reads.append(genome[at:at + n])
+        at += n
+    for slice_bases in ("2048", str(1 << 30)):   # an empty ring takes the batch slice by slice / in one piece
+        monkeypatch.setenv("TBK_SLICE_BASES", slice_bases)
+        for order in (reads, reads[::-1]):
+            bases, offs = _pack(order)
+            want = orc.count_batch(bases, offs, oa, ob)
+            assert want.sum() > len(bases) // 8
+            with kmers.Classifier(a, b) as cls:
+                st = cls.stats()
+                assert st["front_layout"] == bool(front), st
+                got = cls.classify_batch(bases, offs)
+                assert np.array_equal(got, want), (k, front, slice_bases, np.nonzero((got != want).any(axis=1))[0][:10])
+                n_passes, n_listed = cls.last_passes()
+                assert n_listed >= 40   # most cuts leave a pass with two reads
+
+
 @pytest.mark.parametrize("k,want_w", [(21, 7), (22, 7), (23, 8), (25, 8), (31, 8), (32, 7)])  # (lists this small leave room for m = 15 or 16; 2 x 3e8 21-mers: w = 6, m = 16)
 def test_span_follows_k(gpu, orc, monkeypatch, k, want_w):
     """Without TBK_MINIMIZER_W the span is as long as k leaves room for, up to 8 m-mers (front layout: fewer line

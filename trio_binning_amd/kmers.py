@@ -409,8 +409,8 @@ class Classifier:
         return v.value
 
     def last_passes(self) -> Tuple[int, int]:
-        """(passes, multi-read passes) of the most recent probe: 2048 window starts each; the multi-read ones
-        went through the multi-read kernel, the rest through the single-read kernel."""
+        """(passes, passes that touch more than one read) of the most recent probe: 2048 window starts each; the
+        latter went through the two-read or the multi-read kernel, the rest through the single-read kernel."""
         n, m = C.c_uint64(), C.c_uint64()
         check(lib.tbk_classifier_last_passes(self._h, C.byref(n), C.byref(m)))
         return n.value, m.value
