@@ -542,11 +542,13 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
             bad64 |= ~0ull << inside;
         }
     }
-    if (!MULTI && !TWO) {
-        const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
-        const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;  // bases of this lane before the read end
-        if (inside < 64) bad64 |= ~0ull << inside;
-        if (lane & 1u) {
+    if (!MULTI) {
+        if (!TWO) {
+            const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
+            const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;  // bases of this lane before the read end
+            if (inside < 64) bad64 |= ~0ull << inside;
+        }
+        if ((lane & 1u) && !(TWO && is_strad)) {  // (a two-read pass's straddling lane keeps walking upwards: its windows change reads on the way)
             const int sh = 33 - k;  // >= 1
             const unsigned __int128 s_up = R128 >> (2 * sh), r_up = S128 << (2 * sh);
             S128 = s_up; R128 = r_up;
