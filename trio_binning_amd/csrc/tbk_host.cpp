@@ -1213,8 +1213,8 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         HIP_TRY(hipStreamSynchronize(c->compute));  // earlier launches may still read the old scratch
         if (c->d_pass_read) HIP_TRY(hipFree(c->d_pass_read));
         c->d_pass_read = nullptr; c->cap_passes = 0;
-        const uint64_t cap = passes + passes / 4 + 1024;
-        HIP_TRY(hipMalloc((void **)&c->d_pass_read, (3 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, two-read pass list, their lengths
+        const uint64_t cap = (passes + passes / 4 + 1024 + 1) & ~1ull;  // (even: the two-read list's 64-bit entries start at word 2 * cap)
+        HIP_TRY(hipMalloc((void **)&c->d_pass_read, (4 * cap + 16) * sizeof(uint32_t)));  // pass -> read, multi-read pass list, two-read (pass, read) list, the lists' lengths
         c->cap_passes = cap;
     }
     const ProbeSlice whole = {0, passes, nullptr};
@@ -1680,7 +1680,7 @@ extern "C" int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes,
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->compute));
     uint32_t m[2] = {0, 0};  // passes listed for the multi-read kernel, and for the two-read kernel
-    HIP_TRY(hipMemcpy(m, c->d_pass_read + 3 * c->cap_passes, sizeof m, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(m, c->d_pass_read + 4 * c->cap_passes, sizeof m, hipMemcpyDeviceToHost));
     *n_multi = (uint64_t)m[0] + m[1];
     return TBK_OK;
 }

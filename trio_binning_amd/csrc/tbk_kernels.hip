@@ -287,7 +287,7 @@ struct ProbeArgs {
     const uint32_t *pass_read;  // [n_passes] read that contains each pass's first position
     const uint32_t *multi_list; // passes that touch more than one read (the multi-read kernel's work list)
     const uint32_t *n_multi;    // their number
-    const uint32_t *two_list;   // passes that touch exactly two reads (the two-read kernel's work list; empty where that kernel is not built)
+    const uint64_t *two_list;   // passes that touch exactly two reads, as pass | first read << 32 (the two-read kernel's work list; empty where that kernel is not built)
     const uint32_t *n_two;
     uint64_t pass_lo, pass_hi;  // this launch's share of the passes (a batch may be probed slice by slice, as its bases arrive)
 };
@@ -1055,13 +1055,15 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 __global__ void __launch_bounds__(256)
 tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t total, uint64_t n_passes,
                       uint32_t *__restrict__ pass_read, uint32_t *__restrict__ multi_list, uint32_t *__restrict__ n_multi,
-                      uint32_t *__restrict__ two_list, uint32_t *__restrict__ n_two, int use_two, int32_t *__restrict__ counts) {
+                      uint64_t *__restrict__ two_list, uint32_t *__restrict__ n_two, int use_two, int32_t *__restrict__ counts) {
     const uint64_t pass = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool to_multi = false, to_two = false;
+    uint32_t r_first_of_pass = 0;
     if (pass < n_passes) {
         const uint64_t P0 = pass * TBK_PASS;
         const uint64_t r_first = find_read(offsets, n_reads, P0);
         pass_read[pass] = (uint32_t)r_first;
+        r_first_of_pass = (uint32_t)r_first;
         const uint64_t last_pos = P0 + TBK_PASS - 1 < total ? P0 + TBK_PASS - 1 : total - 1;
         const uint64_t r_end = r_first < n_reads ? offsets[r_first + 1] : total;
         if (last_pos >= r_end) {
@@ -1073,17 +1075,18 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
     // one atomic per wave and list (on 15 kb reads every seventh pass is listed: a quarter of a million atomics on one
     // word took 2 ms, the chip's rate for that; the compiler's own aggregation does not see through the two lists)
     const uint32_t lane = threadIdx.x & 63u;
-    auto append = [&](bool mine, uint32_t *list, uint32_t *n) {
+    auto slot_for = [&](bool mine, uint32_t *n) -> uint32_t {  // this thread's place in a list (meaningful where `mine`)
         const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
-        if (m == 0) return;
+        if (m == 0) return 0u;
         const int leader = __builtin_ctzll(m);
         uint32_t base = 0;
         if ((int)lane == leader) base = atomicAdd(n, (uint32_t)__popcll(m));
         base = (uint32_t)__shfl((int)base, leader, 64);
-        if (mine) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)pass;
+        return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     };
-    append(to_multi, multi_list, n_multi);
-    append(to_two, two_list, n_two);
+    const uint32_t at_multi = slot_for(to_multi, n_multi), at_two = slot_for(to_two, n_two);
+    if (to_multi) multi_list[at_multi] = (uint32_t)pass;
+    if (to_two) two_list[at_two] = pass | ((uint64_t)r_first_of_pass << 32);  // (the two-read kernel's block starts from this one load)
     // the same launch clears the per-read counters the probe kernels add to
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
@@ -1129,12 +1132,13 @@ tbk_probe_kernel(const ProbeArgs p) {
     // The two-read kernel is launched with one block per possible list entry (a batch of n reads has fewer than n
     // two-read passes); blocks past the list's end leave at once.
     for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
-        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : TWO ? (uint64_t)p.two_list[item] : p.pass_lo + item;
+        const uint64_t two_entry = TWO ? p.two_list[item] : 0;
+        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : TWO ? (two_entry & 0xFFFFFFFFull) : p.pass_lo + item;
         if (MULTI && (pass < p.pass_lo || pass >= p.pass_hi)) continue;  // (the list is the whole batch's, in no order)
         if (TWO && (pass < p.pass_lo || pass >= p.pass_hi)) return;
         const uint64_t P0 = pass * TBK_PASS;
         // which read(s) does this pass touch?  (wave-uniform)
-        const uint64_t r_first = p.pass_read[pass];
+        const uint64_t r_first = TWO ? (two_entry >> 32) : (uint64_t)p.pass_read[pass];
         const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
         if (!MULTI && !TWO) {
             const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
@@ -1231,8 +1235,8 @@ static void fill_args(ProbeArgs &p, const uint8_t *d_bases, const uint32_t *d_co
     p.codes = d_codes; p.bad16 = d_bad16; p.n_chunks = (total + 15) / 16;
     p.bases = d_bases; p.offsets = d_offsets; p.n_reads = n_reads; p.total = total;
     p.n_passes = (total + TBK_PASS - 1) / TBK_PASS;
-    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_scratch + pass_cap; p.two_list = d_scratch + 2 * pass_cap;
-    p.n_multi = d_scratch + 3 * pass_cap; p.n_two = d_scratch + 3 * pass_cap + 1;  // (tbk_host.cpp sizes the scratch: 3 * pass_cap + 16 words)
+    p.t = t; p.k = k; p.counts = d_counts; p.pass_read = d_scratch; p.multi_list = d_scratch + pass_cap; p.two_list = (const uint64_t *)(d_scratch + 2 * pass_cap);
+    p.n_multi = d_scratch + 4 * pass_cap; p.n_two = d_scratch + 4 * pass_cap + 1;  // (tbk_host.cpp sizes the scratch: 4 * pass_cap + 16 words, pass_cap even)
     p.pass_lo = 0; p.pass_hi = p.n_passes;
 }
 
@@ -1248,7 +1252,9 @@ extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t
     if (total == 0 || n_reads == 0) return hipSuccess;
     const uint64_t n_passes = (total + TBK_PASS - 1) / TBK_PASS;
     if (n_passes > pass_cap) return hipErrorInvalidValue;
-    uint32_t *d_multi = d_scratch + pass_cap, *d_two = d_scratch + 2 * pass_cap, *d_n = d_scratch + 3 * pass_cap;
+    uint32_t *d_multi = d_scratch + pass_cap, *d_n = d_scratch + 4 * pass_cap;
+    uint64_t *d_two = (uint64_t *)(d_scratch + 2 * pass_cap);
+    if (pass_cap & 1) return hipErrorInvalidValue;  // (64-bit entries)
     hipError_t e = hipMemsetAsync(d_n, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((n_passes + 255) / 256)), dim3(256), 0, stream,
