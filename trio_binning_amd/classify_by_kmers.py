@@ -128,6 +128,7 @@ def main():
         stats["loop_s"] = stats["total_s"]  # the native read / classify / write loop alone
         stats["table_build_s"] = t_built - t_start
         stats["devices"] = devices
+        stats["numpy_loaded"] = "numpy" in sys.modules  # (the command line's path needs none of it: kmers imports it at first use)
         stats["total_s"] = time.perf_counter() - t_start
         stats["gbases_per_s"] = stats["bases"] / stats["total_s"] / 1e9 if stats["total_s"] > 0 else 0.0
         print("tbk-stats " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in stats.items()}), file=sys.stderr)

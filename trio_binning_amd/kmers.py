@@ -12,13 +12,27 @@ interface the GPU needs (``Classifier``).
 
 Every function that computes needs a visible MI355X; there is no CPU fallback.
 """
+from __future__ import annotations
+
 import ctypes as C
 import os
 import sys
 from os.path import isfile
 from typing import Iterable, Optional, Sequence, Tuple
 
-import numpy as np
+
+class _LazyNumpy:
+    """numpy, imported at first use: the command line's path (lists from files, the native loop) needs none of it,
+    and its import is a quarter of a second of a run that takes under three."""
+
+    def __getattr__(self, name):
+        import numpy
+
+        globals()["np"] = numpy
+        return getattr(numpy, name)
+
+
+np = _LazyNumpy()
 
 from . import _lib
 from ._lib import check, lib
