@@ -271,17 +271,17 @@ int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64_t num_kmer
                       const char *out_b, const char *out_u, int gzip_output, int gzip_level, int tsv_fd, uint64_t batch_bases,
                       uint64_t batch_reads, tbk_run_stats *stats);
 
-/* HIP-event timing of the probe on the stream it is launched on.  A probe is three kernels: the pass
- * index, the kernel of the passes that touch several reads, and the kernel of the passes inside one read
- * (on long reads nearly all the work: the dominant kernel).  While enabled, every probe of this classifier
- * is bracketed by events - before the first kernel, between the last two, after the last; read returns
- * the number of probes and their summed duration since enable (total_ms: all three kernels; single_ms:
+/* HIP-event timing of the probe on the stream it is launched on.  A probe is four kernels: the pass
+ * index, the kernels of the passes that touch several reads (more than two; exactly two), and the kernel of the
+ * passes inside one read (on long reads nearly all the work: the dominant kernel).  While enabled, every probe of
+ * this classifier is bracketed by events - before the first kernel, in front of the last, after the last; read
+ * returns the number of probes and their summed duration since enable (total_ms: all kernels; single_ms:
  * the single-read kernel alone), and resets. */
 int tbk_kernel_timing_enable(tbk_classifier *c, int on);
 int tbk_kernel_timing_read(tbk_classifier *c, uint64_t *launches, double *total_ms);
 int tbk_kernel_timing_read2(tbk_classifier *c, uint64_t *launches, double *total_ms, double *single_ms);
 /* Passes (2048 window starts each) of the classifier's most recent probe, and how many of them touched more
- * than one read: the multi-read kernel's share of the work; the rest was the single-read kernel's. */
+ * than one read: the two-read and multi-read kernels' share of the work; the rest was the single-read kernel's. */
 int tbk_classifier_last_passes(tbk_classifier *c, uint64_t *n_passes, uint64_t *n_multi);
 
 /* Replaces calculate_scaling_factors (classify_by_kmers.py:57-77) and the binning rule

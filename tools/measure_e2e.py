@@ -158,6 +158,7 @@ for mode, cache in runs:
         st = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-stats ")]
         stages = json.loads(st[-1][10:]) if st else {}
         wt = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-write-timing ")]
+        lt = [l for l in p.stderr.decode().splitlines() if l.startswith("tbk-loop-timing ")]
         bins = {}
         with open(tsv, "rb") as fh:
             for line in fh:
@@ -166,7 +167,7 @@ for mode, cache in runs:
         res[mode + "_" + cache] = {
             "wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
             "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None,
-            "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins, "write_timing": wt[-1] if wt else None,
+            "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins, "write_timing": wt[-1] if wt else None, "loop_timing": lt[-1] if lt else None,
             "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages

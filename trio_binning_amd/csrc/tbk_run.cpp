@@ -123,7 +123,7 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
         return it->counts != nullptr;
     };
 
-    double read_s = 0, write_s = 0, gpu_wait_s = 0;
+    double read_s = 0, write_s = 0, gpu_wait_s = 0, setup_s = since(t_start), close_s = 0;
     const bool write_timing = getenv("TBK_WRITE_TIMING") != nullptr;  // the writer's ms per batch, in tenths of the run, to stderr
     std::vector<double> per_batch_ms;
     std::thread reader_thread, writer_thread;
@@ -222,12 +222,19 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
         }
         fprintf(stderr, "%s\n", line.c_str());
     }
+    const auto t_close = Clock::now();
     int rc_close = tbk_bin_writer_close(writer);
+    const double close_writer_s = since(t_close);
     tbk_fastx_close(reader);
+    const double close_reader_s = since(t_close) - close_writer_s;
     for (Item &it : items) {
         if (it.batch) tbk_fastx_batch_destroy(it.batch);
         if (it.counts) { if (it.counts_pinned) tbk_host_free(it.counts); else free(it.counts); }
     }
+    close_s = since(t_close);
+    if (write_timing)
+        fprintf(stderr, "tbk-loop-timing opening the reader, the writer and the batches %.3f s; closing them %.3f s (writer %.3f, reader %.3f, batches %.3f)\n", setup_s, close_s,
+                close_writer_s, close_reader_s, close_s - close_writer_s - close_reader_s);
     st.read_s = read_s; st.write_s = write_s; st.gpu_wait_s = gpu_wait_s; st.total_s = since(t_start);
     if (stats) *stats = st;
     if (rc) return rc;
