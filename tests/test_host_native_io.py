@@ -511,8 +511,8 @@ def test_chunk_parallel_scan_equals_the_sequential_machine(built, tmp_path, monk
 
     def rec(i, lo=200, hi=9000, qual=None):
         n = rng.randint(lo, hi)
-        s = "".join(rng.choice("ACGTN") for _ in range(n))
-        q = qual if qual is not None else "".join(rng.choice("!#5?@IJ+>") for _ in range(n))
+        s = "".join(rng.choices("ACGTN", k=n))
+        q = qual if qual is not None else "".join(rng.choices("!#5?@IJ+>", k=n))
         return "@r%d extra words %d\n%s\n+%s\n%s\n" % (i, i, s, "" if i % 3 else "r%d" % i, q)
 
     ext = ".fastq.gz" if gz else ".fastq"
