@@ -321,7 +321,8 @@ int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, con
  * `quals` arrays (tbk_fastx_batch_view hands out one zero byte for them).  tbk_bin_writer_write writes the
  * records to their bins from the mapping: the bytes Read.print would write (seq.py:27-31), a record without a
  * header comment and with a bare '+' line as it stands in the input.  Such batches are valid until
- * tbk_fastx_close.  Batches of any other input (gzip, FASTA, irregular records) are copied as always;
+ * tbk_fastx_close; a batch that is refilled lets the pages of the mapping its old records lay in go (they stay in
+ * the page cache: the 30 GB mapping of a large input is not torn down all at once at the end).  Batches of any other input (gzip, FASTA, irregular records) are copied as always;
  * tbk_fastx_batch_borrowed says which kind a batch is.  The loop of tbk_classify_file turns this on
  * (TBK_BORROW=0 turns it off). */
 int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on);
