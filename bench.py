@@ -498,7 +498,7 @@ def main():
     devices = [{"rank": e["rank"], "device_index": e["device_index"], "id": e["device"]} for e in everyone]
 
     # ---- roofline of the dominant kernel (rank 0's device) ----------------------------------------------
-    # The probe is three kernels: pass index, the multi-read kernel (passes that touch several reads) and the
+    # The probe is four kernels: pass index, the multi-read and two-read kernels (passes that touch several reads) and the
     # single-read kernel (passes inside one read: on 15 kb reads 86 % of the passes).  The roofline is the
     # single-read kernel's: its windows x the algorithmic bytes per window (1 read byte + 8 B for
     # the hapA slot + 8 B for the hapB slot when hapA missed; P = 1 reading: 1 + 8) / its HIP-event time.
@@ -533,13 +533,13 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_src,
-        "kernel": "tbk_probe_kernel<..., MULTI=false> (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
+        "kernel": "tbk_probe_kernel<..., MULTI=false, TWO=false> (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
         "timed_in": "the timed region of `value` (HIP events on the compute stream)",
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
         "share_of_the_batch_windows": round(single_frac, 4), "passes": int(n_passes), "multi_read_passes": int(multi_passes),
         "frac_P1_merged_table_reading": round(windows_single * 9 / single_s / 1e9 / HBM_PEAK_GBPS, 4) if single_s > 0 else None,
         "whole_probe_ms_avg": round(probe_s * 1e3, 4),
-        "whole_probe": {"what": "pass index + multi-read kernel + single-read kernel, per batch", "alg_bytes": int(windows * b_alg),
+        "whole_probe": {"what": "pass index + multi-read, two-read and single-read kernels, per batch", "alg_bytes": int(windows * b_alg),
                         "achieved": round(windows * b_alg / probe_s / 1e9, 1) if probe_s > 0 else None,
                         "frac": round(windows * b_alg / probe_s / 1e9 / HBM_PEAK_GBPS, 4) if probe_s > 0 else None},
         "kernel_only_gbases_per_s": round(reads_per_launch * L / probe_s / 1e9, 2) if probe_s > 0 else None,
