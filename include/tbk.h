@@ -320,13 +320,18 @@ int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, con
  * has_qual and the packed form as usual - the bases are packed straight from the mapping - and has no `bases` /
  * `quals` arrays (tbk_fastx_batch_view hands out one zero byte for them).  tbk_bin_writer_write writes the
  * records to their bins from the mapping: the bytes Read.print would write (seq.py:27-31), a record without a
- * header comment and with a bare '+' line as it stands in the input.  Such batches are valid until
- * tbk_fastx_close; a batch that is refilled lets the pages of the mapping its old records lay in go (they stay in
+ * header comment and with a bare '+' line as it stands in the input.  Such batches hold a reference to
+ * the mapping (it is unmapped with its last holder); a batch that is refilled lets the pages of the mapping its old records lay in go (they stay in
  * the page cache: the 30 GB mapping of a large input is not torn down all at once at the end).  Batches of any other input (gzip, FASTA, irregular records) are copied as always;
  * tbk_fastx_batch_borrowed says which kind a batch is.  The loop of tbk_classify_file turns this on
- * (TBK_BORROW=0 turns it off). */
+ * (TBK_BORROW=0 turns it off).  A borrowed batch keeps the mapping alive: it stays readable (and writable to
+ * the bins) after tbk_fastx_close of its reader, until it is refilled or destroyed.
+ * tbk_fastx_batch_gather copies a batch's sequences (base_off[n_reads] bytes) and qualities (qual_off[n_reads] bytes)
+ * into the caller's buffers, back to back, wherever they lie - for a borrowed batch the only way to see them as
+ * arrays (either pointer may be NULL; TBK_ERR_INVALID when a buffer is too small). */
 int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on);
 int tbk_fastx_batch_borrowed(const tbk_fastx_batch *b);
+int tbk_fastx_batch_gather(const tbk_fastx_batch *b, uint8_t *bases, uint64_t bases_cap, uint8_t *quals, uint64_t quals_cap);
 /* Borrow the batch's arrays: offsets have n_reads+1 entries; has_qual[i] = 1 when the record
  * was read as FASTQ (readfq's qual is not None). */
 int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint8_t **bases,

@@ -73,7 +73,7 @@ def test_key_cache_round_trip(gpu, tmp_path, monkeypatch):
         assert hs.origin == "gpu-parser" and not os.path.exists(cache)          # no cache is written unasked
     monkeypatch.setenv("TBK_LIST_CACHE", "1")
     with kmers.HashSet.from_file(str(p), 0) as hs:
-        assert hs.origin == "gpu-parser" and os.path.getsize(cache) == 48 + 8 * want.size
+        assert hs.origin == "gpu-parser" and os.path.getsize(cache) == 56 + 8 * want.size
     monkeypatch.delenv("TBK_LIST_CACHE")
     with kmers.HashSet.from_file(str(p), 0) as hs:                                # a valid cache is used without being asked for
         assert hs.origin == "cache" and hs.k == 21 and np.array_equal(hs.keys(), want)
@@ -83,15 +83,30 @@ def test_key_cache_round_trip(gpu, tmp_path, monkeypatch):
     monkeypatch.delenv("TBK_LIST_CACHE")
     # damaged payload: ignored, the text is parsed
     raw = bytearray(open(cache, "rb").read())
-    raw[48 + 8 * 1234] ^= 0x40
+    raw[56 + 8 * 1234] ^= 0x40
     st = os.stat(p)
     open(cache, "wb").write(bytes(raw))
     with kmers.HashSet.from_file(str(p), 0) as hs:
         assert hs.origin == "gpu-parser" and np.array_equal(hs.keys(), want)
-    raw[48 + 8 * 1234] ^= 0x40
+    raw[56 + 8 * 1234] ^= 0x40
     open(cache, "wb").write(bytes(raw))
     with kmers.HashSet.from_file(str(p), 0) as hs:
         assert hs.origin == "cache"
+    # another list of the same k and line count (= the same size to the byte) under the old name, with the old
+    # modification time (cp -p, rsync -t, tar): the text's fingerprint no longer matches, the cache is not used
+    other = tmp_path / "other.txt"
+    _write_list(other, np.random.default_rng(10), 200_000, 21)
+    assert os.path.getsize(other) == os.path.getsize(p)
+    keep = open(p, "rb").read()
+    open(p, "wb").write(open(other, "rb").read())
+    os.utime(p, ns=(st.st_atime_ns, st.st_mtime_ns))
+    want_other, _ = kmers.parse_kmer_list(str(p))
+    with kmers.HashSet.from_file(str(p), 0) as hs:
+        assert hs.origin == "gpu-parser" and np.array_equal(hs.keys(), want_other) and not np.array_equal(want_other, want)
+    open(p, "wb").write(keep)
+    os.utime(p, ns=(st.st_atime_ns, st.st_mtime_ns))
+    with kmers.HashSet.from_file(str(p), 0) as hs:
+        assert hs.origin == "cache" and np.array_equal(hs.keys(), want)
     # the list changes (size and time): the cache no longer belongs to it
     with open(p, "ab") as fh:
         fh.write(b"A" * 21 + b"\n")

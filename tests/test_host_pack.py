@@ -275,3 +275,45 @@ def test_borrowed_batches_equal_copied_ones(built, tmp_path, monkeypatch, shape)
                 for x, y in zip(m[:6], bm[:6]):
                     assert np.array_equal(x, y), key
                 assert m[6] == bm[6], key
+
+
+def test_borrowed_batch_outlives_its_reader(built, tmp_path, monkeypatch):
+    """A borrowed batch keeps the reader's mapping alive (refilling one after tbk_fastx_close let
+    MADV_DONTNEED loose on whatever had been mapped there since).  Here: fill a batch from a.fq with borrowing,
+    close the reader, allocate over the freed address range, refill the same batch from b.fq - the arrays allocated
+    in between keep their contents, the old batch was still readable after the close, and the refilled batch holds
+    b.fq's records.  Batch.reads() of a borrowed batch returns the real sequences and qualities (gathered from the
+    mapping), Batch.pointers() refuses."""
+    import random
+
+    from trio_binning_amd import seq
+
+    monkeypatch.setenv("TBK_HOST_THREADS", "3")
+    rng = random.Random(11)
+    del _MIXED_RECORDS[:]
+    text_a = _mixed_fastq(rng, 1200, 9000, 21000, bad_every=40)  # ~18 MB: many whole pages inside the batch
+    recs_a = list(_MIXED_RECORDS)
+    del _MIXED_RECORDS[:]
+    text_b = _mixed_fastq(rng, 300, 9000, 21000)
+    recs_b = list(_MIXED_RECORDS)
+    (tmp_path / "a.fq").write_text(text_a)
+    (tmp_path / "b.fq").write_text(text_b)
+
+    b = seq.Batch()
+    ra = seq.BatchReader(str(tmp_path / "a.fq"), packing=True, borrowing=True)
+    assert ra.next_batch(b, 0, 0) == len(recs_a) and b.borrowed
+    with pytest.raises(ValueError):
+        b.pointers()
+    ra.close()
+    # the mapping is still there: the records read back after the close
+    got = b.reads()
+    assert [(r.name, r.seq, r.qual) for r in got] == recs_a
+    # memory allocated now must survive the refill (it would land where the mapping was, had that been unmapped)
+    live = [np.ones(1 << 21, dtype=np.uint64) for _ in range(6)]
+    with seq.BatchReader(str(tmp_path / "b.fq"), packing=True, borrowing=True) as rb:
+        assert rb.next_batch(b, 0, 0) == len(recs_b) and b.borrowed
+        assert [(r.name, r.seq, r.qual) for r in b.reads()] == recs_b
+    assert all(int(x.min()) == 1 and int(x.max()) == 1 for x in live)
+    # ... and again after that reader is gone too
+    assert [(r.name, r.seq, r.qual) for r in b.reads()] == recs_b
+    b.close()

@@ -695,6 +695,19 @@ struct LineSource {
 // =======================================================================================
 struct FastqRec { uint64_t head, seq, plus, qual, end; uint32_t name_len; };  // line starts of a regular FASTQ record; `end` = start of the next record
 
+// The reader's mapping of a plain input file.  The reader and every borrowed batch made from it hold a reference: the
+// mapping goes with its last holder, so a borrowed batch outliving its reader (written, or refilled from another
+// reader, after tbk_fastx_close) still points into mapped text, and release_borrowed never touches memory that has
+// been given to somebody else.
+struct FastxMapping {
+    const uint8_t *p = nullptr;
+    size_t n = 0;
+    FastxMapping(const uint8_t *p_, size_t n_) : p(p_), n(n_) {}
+    FastxMapping(const FastxMapping &) = delete;
+    FastxMapping &operator=(const FastxMapping &) = delete;
+    ~FastxMapping() { if (p) munmap((void *)p, n); }
+};
+
 struct tbk_fastx_batch {
     uint8_t *bases = nullptr;  // pinned (hipHostMalloc) when a device is present, else malloc
     size_t bases_cap = 0;
@@ -725,6 +738,7 @@ struct tbk_fastx_batch {
     bool borrowed = false;
     const uint8_t *text = nullptr;
     std::vector<FastqRec> recs;
+    std::shared_ptr<FastxMapping> hold;  // keeps `text` mapped while this batch refers to it
 
     ~tbk_fastx_batch() {
         release();
@@ -771,7 +785,7 @@ struct tbk_fastx_batch {
         has_qual.clear(); n_bases = 0; rec_seq0 = rec_qual0 = 0;
         fused = want_packed; packed_ok = false;
         exc.clear(); exc_chunk.clear(); exc_mask.clear();
-        borrowed = false; text = nullptr; recs.clear();
+        borrowed = false; text = nullptr; recs.clear(); hold.reset();
     }
     void begin(const uint8_t *name, size_t n) {
         names.insert(names.end(), name, name + n);
@@ -904,6 +918,7 @@ struct tbk_fastx_reader {
     bool have_pending = false;
     uint64_t seq_len = 0;       // current record (QUAL state)
     int64_t qual_have = 0;
+    std::shared_ptr<FastxMapping> mapping;  // owner of scan.map (shared with the borrowed batches made from it)
     bool packing = false;       // batches also carry the packed transfer form of their bases
     bool borrowing = false;     // batches of the mapped plain file reference its text instead of copying it (needs packing)
 };
@@ -934,6 +949,7 @@ extern "C" int tbk_fastx_open(const char *path, tbk_fastx_reader **out) {
     if (!gz && !(scan_env && *scan_env == '0') && fstat(r->src.fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
         void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, r->src.fd, 0);
         if (m != MAP_FAILED) {
+            r->mapping = std::make_shared<FastxMapping>((const uint8_t *)m, (size_t)st.st_size);
             r->scan.map = (const uint8_t *)m;
             r->scan.size = (size_t)st.st_size;
             r->scan.active = r->scan.map[0] == '@';
@@ -950,7 +966,8 @@ extern "C" int tbk_fastx_open(const char *path, tbk_fastx_reader **out) {
 
 extern "C" void tbk_fastx_close(tbk_fastx_reader *r) {
     if (!r) return;
-    if (r->scan.map) munmap((void *)r->scan.map, r->scan.size);
+    r->scan.map = nullptr;
+    r->mapping.reset();  // (unmapped now, or with the last borrowed batch that still refers to it)
     r->src.close_all();
     delete r;
 }
@@ -1205,6 +1222,7 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
     bool leave = false;
     const int rc = regular_window(sc, sc.map, sc.size, sc.pos, b, max_bases, max_reads, &new_pos, &leave, r->borrowing);
     if (rc) return rc;
+    if (b->borrowed) b->hold = r->mapping;
     if (b->n_reads() == 0 || leave) sc.active = false;
     sc.pos = new_pos;
     return TBK_OK;
@@ -1269,6 +1287,24 @@ extern "C" int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on) {
 }
 
 extern "C" int tbk_fastx_batch_borrowed(const tbk_fastx_batch *b) { return b && b->borrowed ? 1 : 0; }
+
+extern "C" int tbk_fastx_batch_gather(const tbk_fastx_batch *b, uint8_t *bases, uint64_t bases_cap, uint8_t *quals, uint64_t quals_cap) {
+    if (!b) return ffail(TBK_ERR_INVALID, "NULL argument");
+    const uint64_t nb = b->base_off.back(), nq = b->qual_off.back();
+    if ((bases && bases_cap < nb) || (quals && quals_cap < nq)) return ffail(TBK_ERR_INVALID, "tbk_fastx_batch_gather: buffer too small (%llu bases, %llu quality bytes)",
+                                                                           (unsigned long long)nb, (unsigned long long)nq);
+    if (!b->borrowed) {
+        if (bases && nb) memcpy(bases, b->bases, (size_t)nb);
+        if (quals && nq) memcpy(quals, b->quals.data(), (size_t)nq);
+        return TBK_OK;
+    }
+    for (size_t i = 0; i < b->recs.size(); i++) {  // a regular FASTQ record: sequence and quality on one line each, equally long
+        const uint64_t len = b->base_off[i + 1] - b->base_off[i];
+        if (bases) memcpy(bases + b->base_off[i], b->text + b->recs[i].seq, (size_t)len);
+        if (quals && b->has_qual[i]) memcpy(quals + b->qual_off[i], b->text + b->recs[i].qual, (size_t)(b->qual_off[i + 1] - b->qual_off[i]));
+    }
+    return TBK_OK;
+}
 
 // the batch's packed form: what the scan has packed already plus the last, partial chunk - or, for bytes
 // that came through the sequential machine, the whole stream in one go on all host threads

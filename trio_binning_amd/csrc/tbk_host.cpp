@@ -124,7 +124,13 @@ extern "C" int tbk_host_threads(void) {
 // A k-mer list in HBM: its packed keys, one per list line, verbatim (duplicates and all).
 // The hashed forms are built from these: the paired hapA|hapB table by the classifier, and
 // a standalone table (64-byte lines) on first use of tbk_table_contains / _distinct.
+static void table_born();
+static void table_gone();
 struct tbk_table {
+    tbk_table() { table_born(); }
+    ~tbk_table() { table_gone(); }
+    tbk_table(const tbk_table &) = delete;
+    tbk_table &operator=(const tbk_table &) = delete;
     int device = 0;
     int k = 0;
     uint64_t num_lines = 0;  // what the reference calls num_kmers (c/kmers.c:37)
@@ -619,10 +625,13 @@ struct ListStaging {
     }
 };
 static ListStaging g_list_staging;
+static std::atomic<long> g_live_tables{0};  // tbk_table handles alive: the staging buffers go with the last one at the latest
 static void release_list_staging() {
     std::lock_guard<std::mutex> lk(g_list_staging.mu);
     g_list_staging.release_locked();
 }
+static void table_born() { g_live_tables.fetch_add(1); }
+static void table_gone() { if (g_live_tables.fetch_sub(1) <= 1) release_list_staging(); }
 
 template <class F>
 static int staged_file_upload(int fd, size_t file_off, size_t bytes, size_t piece_bytes, hipStream_t stream, uint64_t *sum64, F consume) {
@@ -660,15 +669,49 @@ static int staged_file_upload(int fd, size_t file_off, size_t bytes, size_t piec
 }
 
 // The binary key cache of a list, `<list>.tbk`: what parsing the text produces, kept so that the next run
-// skips the text.  Valid only for the very file it was made from (size and modification time).
+// skips the text.  Valid only for the very file it was made from: size, modification time AND a fingerprint of the
+// text itself - lists of one k and line count are equally long to the byte, and cp -p / rsync -t / tar keep the
+// modification time, so size + mtime alone would hand a replaced list its predecessor's keys.
 struct ListCacheHeader {
-    char magic[8];         // "TBKLIST1"
+    char magic[8];         // "TBKLIST2"
     uint32_t k, reserved;
     uint64_t n_lines;      // = num_kmers of the reference (c/kmers.c:124-146), duplicates and all
     uint64_t src_size;
     int64_t src_mtime_ns;
     uint64_t key_sum;      // wrapping sum of the keys
+    uint64_t src_fingerprint;  // source_fingerprint() of the text
 };
+
+// A hash of the list text's first and last MiB and of fifteen 64 KiB blocks spread evenly between them (3 MB read from
+// the page cache: about a millisecond).  Two different lists agree on all of those only by being the same list there.
+static bool source_fingerprint(const char *path, uint64_t size, uint64_t *out) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    std::vector<uint8_t> buf((size_t)1 << 20);
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ size;
+    bool ok = true;
+    auto fold = [&](uint64_t off, size_t n) {
+        if (off >= size) return;
+        n = (size_t)std::min<uint64_t>(n, size - off);
+        size_t at = 0;
+        while (at < n) {
+            const ssize_t got = ::pread(fd, buf.data() + at, n - at, (off_t)(off + at));
+            if (got < 0 && errno == EINTR) continue;
+            if (got <= 0) { ok = false; return; }
+            at += (size_t)got;
+        }
+        h = (h ^ off) * 0xD1342543DE82EF95ull;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, buf.data() + i, 8); h = (h ^ w) * 0xAF251AF3B0F025B5ull; h ^= h >> 29; }
+        for (; i < n; i++) h = (h ^ buf[i]) * 0x100000001B3ull;
+    };
+    fold(0, (size_t)1 << 20);
+    for (int i = 1; i <= 15 && ok; i++) fold(size / 16 * (uint64_t)i, (size_t)64 << 10);
+    if (ok && size > ((uint64_t)1 << 20)) fold(size - ((uint64_t)1 << 20), (size_t)1 << 20);
+    ::close(fd);
+    *out = h;
+    return ok;
+}
 
 static std::string cache_path_of(const char *path) { return std::string(path) + ".tbk"; }
 
@@ -683,9 +726,11 @@ static int table_from_cache(const char *path, const struct stat &src, int device
     if (fd < 0) return 0;
     ListCacheHeader hd;
     struct stat cst;
-    bool good = ::pread(fd, &hd, sizeof hd, 0) == (ssize_t)sizeof hd && memcmp(hd.magic, "TBKLIST1", 8) == 0 && fstat(fd, &cst) == 0 &&
+    bool good = ::pread(fd, &hd, sizeof hd, 0) == (ssize_t)sizeof hd && memcmp(hd.magic, "TBKLIST2", 8) == 0 && fstat(fd, &cst) == 0 &&
                 hd.k >= 1 && hd.k <= 32 && hd.n_lines > 0 && (uint64_t)cst.st_size == sizeof hd + hd.n_lines * 8 &&
                 hd.src_size == (uint64_t)src.st_size && hd.src_mtime_ns == mtime_ns_of(src);
+    uint64_t fp = 0;
+    good = good && source_fingerprint(path, (uint64_t)src.st_size, &fp) && fp == hd.src_fingerprint;
     if (!good || use_device(device) != TBK_OK) { ::close(fd); return 0; }
     tbk_table *t = new tbk_table();
     t->device = device; t->k = (int)hd.k; t->num_lines = hd.n_lines; t->origin = 2;
@@ -716,8 +761,9 @@ static void write_list_cache(const char *path, const struct stat &src, const tbk
     if (hipMemcpy(keys.data(), t->d_keys, keys.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
     ListCacheHeader hd;
     memset(&hd, 0, sizeof hd);
-    memcpy(hd.magic, "TBKLIST1", 8);
+    memcpy(hd.magic, "TBKLIST2", 8);
     hd.k = (uint32_t)t->k; hd.n_lines = t->num_lines; hd.src_size = (uint64_t)src.st_size; hd.src_mtime_ns = mtime_ns_of(src);
+    if (!source_fingerprint(path, (uint64_t)src.st_size, &hd.src_fingerprint)) return;
     for (uint64_t v : keys) hd.key_sum += v;
     const std::string cp = cache_path_of(path), tmp = cp + ".tmp." + std::to_string((long)getpid());
     const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -823,6 +869,9 @@ static void drop_cached_classifier(const tbk_table *t);
 
 extern "C" void tbk_table_destroy(tbk_table *t) {
     if (!t) return;
+    // (a process that only loads lists - tbk_table_contains, tbk_table_keys, tools - never makes a classifier: the pinned
+    // staging buffers of the list loader, 2 x 128 MB, go with its last table)
+    // (done by ~tbk_table: table_gone)
     drop_cached_classifier(t);
     if (hipSetDevice(t->device) == hipSuccess) {
         if (t->d_keys) (void)hipFree(t->d_keys);
@@ -993,7 +1042,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, 0.08, &past);
-        if (rc) { delete c; return rc; }
+        if (rc) { c->free_pair(); delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
         if (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05))) break;

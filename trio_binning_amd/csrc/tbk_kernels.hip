@@ -259,6 +259,10 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #ifndef TBK_OCC_PAD
 #define TBK_OCC_PAD 0
 #endif
+//   TBK_DIAG_EXTRA_VALU=n  n more (useless) vector instructions per window step: what does an instruction cost?
+#ifndef TBK_DIAG_EXTRA_VALU
+#define TBK_DIAG_EXTRA_VALU 0
+#endif
 constexpr int TBK_WAVES_PER_BLOCK = 1;      // waves of a block share nothing; one-wave blocks schedule best (measured: 1 > 2 > 4 > 8)
 
 #ifdef TBK_COUNTERS
@@ -743,6 +747,16 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         }
         if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
         const uint32_t bkt = bucket_here(j);
+#if TBK_DIAG_EXTRA_VALU
+        {
+            uint32_t d0 = s0, d1 = t2;
+#pragma unroll
+            for (int x = 0; x < TBK_DIAG_EXTRA_VALU; x += 2) {
+                asm volatile("v_xor_b32 %0, %1, %0" : "+v"(d0) : "v"(s1));
+                asm volatile("v_xor_b32 %0, %1, %0" : "+v"(d1) : "v"(t3));
+            }
+        }
+#endif
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
         // TBK_NOKEY, which is never stored (it can never hit)
         // Bit 31 of the broadcast bucket says "not the bucket of this lane's previous window": only

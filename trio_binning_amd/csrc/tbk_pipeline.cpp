@@ -13,6 +13,7 @@
 // tests the dealing).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -114,15 +115,18 @@ static void feeder_loop(tbk_pipeline *p, int slot) {
                 // Batches in flight and room in the ring: whichever comes first - a new batch to submit (its copy
                 // must start NOW, beside the kernel that is running, not when that kernel ends) or the oldest
                 // batch completing.  The device is polled, the queue is waited on in short naps.
-                int idle_naps = 0;
+                // The naps back off from 100 us to 1 ms (a new batch still wakes the feeder at once: cv_work): several
+                // rings on one device polled at 10 kHz each were runtime calls taken from the reader's and the writer's CPUs.
+                // A ring that cannot be polled (test rings) is collected from right away.
+                int nap_us = 100;
                 while (p->queue.empty() && !p->stop) {
                     lk.unlock();  // (the query is a runtime call: not under the queue's lock)
                     const int d = rg.done(flying.front().first);
                     lk.lock();
-                    if (d == 1 || d < -1 || (d == -1 && idle_naps >= 20)) { collect = true; break; }
+                    if (d == 1 || d < 0) { collect = true; break; }
                     if (!p->queue.empty() || p->stop) break;
-                    p->cv_work.wait_for(lk, std::chrono::microseconds(100));
-                    idle_naps++;
+                    p->cv_work.wait_for(lk, std::chrono::microseconds(nap_us));
+                    nap_us = std::min(1000, nap_us * 2);
                 }
                 if (p->queue.empty() && p->stop) collect = true;
             }

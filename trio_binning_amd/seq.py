@@ -169,10 +169,13 @@ class Batch:
 
     def arrays(self):
         """(bases, base_off, names, name_off, quals, qual_off, has_qual) as numpy views that
-        stay valid until the batch is refilled or destroyed."""
+        stay valid until the batch is refilled or destroyed.  A borrowed batch has no sequence / quality
+        arrays of its own: `bases` and `quals` are then copies gathered from the reader's mapping."""
         import ctypes as C
 
         import numpy as np
+
+        from ._lib import check, lib
 
         n, (bases, boff, names, noff, quals, qoff, hq) = self._view()
 
@@ -185,9 +188,13 @@ class Batch:
         base_off = arr(boff, n + 1, np.uint64)
         name_off = arr(noff, n + 1, np.uint64)
         qual_off = arr(qoff, n + 1, np.uint64)
-        kept = 0 if self.borrowed else 1  # (a borrowed batch has no sequence / quality arrays: empty views)
-        return (arr(bases, kept * int(base_off[-1]), np.uint8), base_off, arr(names, int(name_off[-1]), np.uint8), name_off,
-                arr(quals, kept * int(qual_off[-1]), np.uint8), qual_off, arr(hq, n, np.uint8))
+        if self.borrowed:
+            bases_a = np.zeros(int(base_off[-1]), dtype=np.uint8)
+            quals_a = np.zeros(int(qual_off[-1]), dtype=np.uint8)
+            check(lib.tbk_fastx_batch_gather(self._h, bases_a.ctypes.data, bases_a.size, quals_a.ctypes.data, quals_a.size))
+        else:
+            bases_a, quals_a = arr(bases, int(base_off[-1]), np.uint8), arr(quals, int(qual_off[-1]), np.uint8)
+        return (bases_a, base_off, arr(names, int(name_off[-1]), np.uint8), name_off, quals_a, qual_off, arr(hq, n, np.uint8))
 
     @property
     def borrowed(self) -> bool:
@@ -198,6 +205,8 @@ class Batch:
 
     def pointers(self):
         """(bases_ptr, base_off_ptr) for tbk_stream_submit."""
+        if self.borrowed:
+            raise ValueError("a borrowed batch has no ASCII bases array: submit its packed form (packed_pointers)")
         _, p = self._view()
         return p[0], p[1]
 
