@@ -34,8 +34,10 @@ torch.distributed gloo group instead (tests cover both).
 
 The JSON line also carries, at every N,
   roofline      the dominant kernel's (the single-read probe kernel's) algorithmic bytes per launch / its
-                HIP-event-timed average duration inside the timed region, against the 8 TB/s HBM peak,
-                under both readings of SURVEY §8d (P = 2: two probes per window; P = 1: merged table);
+                HIP-event-timed average duration inside the timed region, against the 8 TB/s HBM peak.  `frac` is
+                SURVEY §8d's reading for this design - one paired table probed once per window, P = 1: 9 bytes
+                per window; the two-probe reading (P = 2: 17 bytes) is printed beside it.  `traffic` is replayed
+                from the round's PMC passes only when those ran on this tree's kernel sources (sha256 stamp);
   parity        every rank classifies the same fixed reads (read 0 .. 4095 of the generator) through the
                 host-fed path; the count checksums must agree across ranks, and rank 0 checks the counts
                 read for read against the oracle;
@@ -43,7 +45,8 @@ The JSON line also carries, at every N,
                 bounded sample of the same reads and tables;
   devices       each rank's device (PCI bus id, uuid), so that N distinct GPUs are provable;
 and at N = 1 `pipeline_variants`: the same stage fed with ASCII batches (packed by the feeder thread
-before the copy) and with ASCII over PCIe (the kernel packs).
+before the copy) and with ASCII over PCIe (the kernel packs), and `realistic_lists`: the same bench on lists
+shaped like real find-unique-kmers output (`--lists haplotypes`), in the same run.
 
 `--path count` benches the k-mer counting kernel of the find-unique-kmers step instead
 (SURVEY §8f N4): Gbases/s counted, atomic adds per second against the chip's measured ceiling,
@@ -76,7 +79,12 @@ def parse(argv=None):
     ap.add_argument("--path", choices=["classify", "count"], default="classify")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--strong-reads", type=int, default=6_000_000, help="strong scaling: reads of the fixed set (configs[3]: 6 M x 15 kb = 90 Gbp)")
-    ap.add_argument("--min-timed-s", type=float, default=1.0, help="repeat the K-step region until this much time has been measured")
+    ap.add_argument("--min-timed-s", type=float, default=10.0,
+                    help="repeat the K-step region until this much time has been measured (10 s: a sustained-clock number the driver's "
+                         "utilisation sampler can see)")
+    ap.add_argument("--no-realistic", action="store_true",
+                    help="N = 1: skip the `realistic_lists` sub-record (the same bench on haplotype-shaped lists, a second table build and a few seconds of timing)")
+    ap.add_argument("--realistic-timed-s", type=float, default=3.0, help="timed seconds per leg of the realistic_lists sub-record")
     ap.add_argument("--k", type=int, default=BASELINE_K)
     ap.add_argument("--kmers-per-list", type=int, default=BASELINE_KEYS)
     ap.add_argument("--read-len", type=int, default=15_000)
@@ -121,7 +129,7 @@ def spawn_ranks(args):
     rdv = tempfile.mkdtemp(prefix="tbk_bench_rdv_")
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), TBK_BENCH_RDV=rdv)
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), TBK_BENCH_RDV=rdv)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
@@ -289,12 +297,72 @@ def main():
     dev = 0 if args.share_device else local_rank
     if n_dev <= dev:
         raise SystemExit(f"rank {rank}: HIP device {dev} not visible ({n_dev} devices)")
+    # one process per GPU: this rank's threads (the pipeline's feeder, the packers, everything it starts from here on) run on
+    # the CPUs of the socket its GPU hangs off, and its share of the node's CPUs is 1 / LOCAL_WORLD_SIZE (tbk_host_threads)
+    numa_node, numa_cpus = C.c_int(-1), C.c_int(0)
+    check(lib.tbk_numa_bind_to_device(dev, C.byref(numa_node), C.byref(numa_cpus)))
+    placement = {"numa_node": numa_node.value, "cpus_bound_to": numa_cpus.value, "host_threads": int(lib.tbk_host_threads())}
     if args.path == "count":
         out = bench_count(args, np, kmers, lib, check, dev, dist, world, rank)
         if rank == 0:
             print(json.dumps(out), flush=True)
         dist.close()
         return
+    out = run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement)
+    if rank == 0 and world == 1 and not args.no_realistic and args.lists == "uniform" and args.scaling == "weak":
+        out["realistic_lists"] = realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    dist.close()
+
+
+def realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement):
+    """The same bench on lists shaped like real find-unique-kmers output (find_unique_kmers.py:200-233: the k overlapping
+    k-mers around every variant, in both lists at once) - `--lists haplotypes` - as a sub-record of the default N = 1
+    line: value, resident rate, kernel time, both roofline readings, the random-line fraction, parity against the oracle."""
+    import copy
+
+    a = copy.copy(args)
+    a.lists = "haplotypes"
+    a.min_timed_s = args.realistic_timed_s
+    a.no_streaming = True
+    a.calibrate = False
+    a.cpu_seconds = min(args.cpu_seconds, 2.0)
+    a.parity_reads = min(args.parity_reads, 1024)
+    sub = run_classify(a, np, kmers, lib, check, _lib, dev, dist, 1, 0, placement)
+    r = sub["roofline"]
+    keep = {
+        "lists": "haplotypes: " + sub["data"], "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+        "kernel_resident": (sub.get("kernel_resident") or {}).get("gbases_per_s"),
+        "kernel_ms_avg": r["kernel_ms_avg"], "whole_probe_ms_avg": r["whole_probe_ms_avg"],
+        "frac": r["frac"], "frac_P2_two_probe_reading": r["frac_P2_two_probe_reading"], "achieved": r["achieved"],
+        "traffic": r["traffic"], "traffic_source": r["traffic_source"], "random_line_frac": r.get("random_line_frac"),
+        "random_lines_Gps": r.get("random_lines_Gps"),
+        "kmers_per_list": sub["config"]["kmers_per_list"], "table_bytes_per_gpu": sub["config"]["table_bytes_per_gpu"],
+        "table_bytes_per_key": sub["config"]["table_bytes_per_key"], "line_layout": sub["config"]["line_layout"],
+        "bucket_select": sub["config"]["bucket_select"], "keys_behind_front": sub["config"]["keys_behind_front"],
+        "layout_builds": sub["config"]["layout_builds"],
+        "timed_regions": sub["timed_regions"], "timed_total_s": sub["timed_total_s"], "parity": sub["parity"], "bins": sub["bins"],
+        "cpu_baseline_1_thread_gbases_per_s": (sub.get("cpu_baseline") or {}).get("value"),
+        "note": "same steps, same kernels, same host-fed stage as `value`; only the lists (and the reads drawn from the two haplotypes) differ",
+    }
+    return keep
+
+
+def kernel_fingerprint():
+    """sha256 over the sources the probe kernels are compiled from: a PMC traffic record (profiles/pmc_traffic*.json) is
+    only replayed into `roofline.traffic` when it was taken on these very kernels."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("tbk_kernels.hip", "tbk_common.h", "tbk_device.h"):
+        with open(os.path.join(ROOT, "trio_binning_amd", "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement):
     k, n_list, L, R = args.k, args.kmers_per_list, args.read_len, args.reads_per_step
 
     def dalloc(nbytes):
@@ -489,13 +557,13 @@ def main():
     par_counts2 = pipe.wait(pipe.submit_packed(kmers.pack_bases(par_bases, par_offs)))   # packed ahead, as the reader does
     import zlib
 
-    mine = {"rank": rank, "device_index": dev, "device": _lib.device_identity(dev), "sum_a": int(par_counts[:, 0].sum()), "sum_b": int(par_counts[:, 1].sum()),
+    mine = {"rank": rank, "device_index": dev, "device": _lib.device_identity(dev), "placement": placement, "sum_a": int(par_counts[:, 0].sum()), "sum_b": int(par_counts[:, 1].sum()),
             "crc32": zlib.crc32(par_counts.tobytes()), "transfers_agree": bool(np.array_equal(par_counts, par_counts2))}
     everyone = dist.gather_obj(mine)
     parity = {"reads_checked_per_rank": n_par, "bases_checked_per_rank": n_par * L, "count_checksum": [mine["sum_a"], mine["sum_b"], mine["crc32"]],
               "all_ranks_equal": all((e["sum_a"], e["sum_b"], e["crc32"]) == (mine["sum_a"], mine["sum_b"], mine["crc32"]) for e in everyone),
               "packed_and_ascii_transfers_agree": all(e["transfers_agree"] for e in everyone)}
-    devices = [{"rank": e["rank"], "device_index": e["device_index"], "id": e["device"]} for e in everyone]
+    devices = [{"rank": e["rank"], "device_index": e["device_index"], "id": e["device"], **e["placement"]} for e in everyone]
 
     # ---- roofline of the dominant kernel (rank 0's device) ----------------------------------------------
     # The probe is four kernels: pass index, the multi-read and two-read kernels (passes that touch several reads) and the
@@ -507,7 +575,11 @@ def main():
     windows = reads_per_launch * max(0, L - k + 1)
     single_frac = 1.0 - multi_passes / max(1, n_passes)
     windows_single = windows * single_frac
-    b_alg = 9 + 8 * (1 - hit_a_frac)
+    # "a merged single-table implementation must report with P = 1 (B_alg = 9 B)".  The design is one paired
+    # table probed once per window, so `frac` is the P = 1 reading; the two-probe reading
+    # (1 + 8 + 8 per window that misses hapA) is printed beside it.
+    b_alg = 9.0
+    b_alg_p2 = 9 + 8 * (1 - hit_a_frac)
     alg_bytes = windows_single * b_alg
     single_s = single_ms / max(1, launches) * 1e-3
     probe_s = probe_ms / max(1, launches) * 1e-3
@@ -525,9 +597,14 @@ def main():
                     and abs(t.get("table_load", 0) - table_load) < 2e-3
                     and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
                     and t.get("kernel") == "tbk_probe_kernel<single-read>")
-            if same:  # measured in separate rocprofv3 --pmc passes on this configuration (not in this run); scaled to this launch's windows
+            if same and t.get("kernel_source_sha256") != kernel_fingerprint():
+                # taken on other kernels than the ones in this tree: stale bytes are not reported
+                traffic_src = ("profiles/" + tname + " is STALE: its PMC passes ran on kernel sources " + str(t.get("kernel_source_sha256"))[:12]
+                               + ", this tree's are " + kernel_fingerprint()[:12] + " - re-run tools/gpu_profile.sh; traffic withheld")
+            elif same:  # measured in separate rocprofv3 --pmc passes on this configuration (not in this run); scaled to this launch's windows
                 traffic = t["hbm_bytes_per_window"] * windows_single
-                traffic_src = "profiles/" + tname + " (rocprofv3 --pmc passes of this configuration, replayed per window; not measured in this run)"
+                traffic_src = ("profiles/" + tname + " (rocprofv3 --pmc passes of this configuration on these kernel sources, sha256 "
+                               + kernel_fingerprint()[:12] + ", replayed per window; not measured in this run)")
         except Exception:
             pass
     roofline = {
@@ -537,7 +614,9 @@ def main():
         "timed_in": "the timed region of `value` (HIP events on the compute stream)",
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
         "share_of_the_batch_windows": round(single_frac, 4), "passes": int(n_passes), "multi_read_passes": int(multi_passes),
-        "frac_P1_merged_table_reading": round(windows_single * 9 / single_s / 1e9 / HBM_PEAK_GBPS, 4) if single_s > 0 else None,
+        "reading": "P = 1 (SURVEY 8d's merged-table rule: 1 read byte + one 8-byte slot per window)",
+        "frac_P2_two_probe_reading": round(windows_single * b_alg_p2 / single_s / 1e9 / HBM_PEAK_GBPS, 4) if single_s > 0 else None,
+        "alg_bytes_per_window_P2": round(b_alg_p2, 3),
         "whole_probe_ms_avg": round(probe_s * 1e3, 4),
         "whole_probe": {"what": "pass index + multi-read, two-read and single-read kernels, per batch", "alg_bytes": int(windows * b_alg),
                         "achieved": round(windows * b_alg / probe_s / 1e9, 1) if probe_s > 0 else None,
@@ -621,10 +700,9 @@ def main():
         out["parity"].update(cpu_par)
 
     pipe.close()
-    dist.barrier()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    dist.close()
+    hap_a.close()
+    hap_b.close()
+    return out
 
 
 def pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batch0, L):

@@ -62,6 +62,20 @@ int tbk_device_count(int *count);
 /* Short description of device `device` ("gfx950 AMD Instinct MI355X, 256 CUs, 288 GB"). */
 int tbk_device_name(int device, char *buf, size_t buflen);
 int tbk_device_identity(int device, char *buf, size_t buflen);  /* "<pci bus id> <uuid>" */
+/* NUMA placement (pinned, NUMA-local buffers, one feeder thread per GPU; the reference is one thread on one
+ * socket, c/kmers.c:270-299).  *node = the host NUMA node the device's PCIe root belongs to
+ * (/sys/bus/pci/devices/<bdf>/numa_node), -1 when the kernel does not say.  tbk_numa_bind_to_device restricts the
+ * CALLING thread - and the threads it starts afterwards - to that node's CPUs inside its current affinity mask
+ * (*cpus = how many; 0 = left alone: unknown node, nothing in common, TBK_NUMA=0); a pipeline's feeder threads do
+ * this for their device by themselves (tbk_pipeline_numa reports it), and a one-process-per-GPU launcher calls it
+ * once per rank before the library starts its worker threads.  Pinned buffers the thread allocates afterwards are
+ * local: hipHostMalloc places host memory on the node nearest to the current device. */
+int tbk_device_numa_node(int device, int *node);
+int tbk_numa_bind_to_device(int device, int *node, int *cpus);
+/* (library-internal, exported for the CPU tests: sysfs lookups under TBK_SYSFS_ROOT, and the binding itself) */
+int tbk_numa_node_of_pci_(const char *pci_bus_id);
+int tbk_numa_node_cpus_(int node, int *cpus, int cap);
+int tbk_numa_bind_thread_(int node);
 
 /* ---- unit-level API kept for parity with the reference's ctypes surface ------------ */
 /* Replaces kmer_to_int (c/kmers.c:50-72; bound kmers.py:75-82): base i -> bits 2i..2i+1,
@@ -135,8 +149,13 @@ void tbk_classifier_destroy(tbk_classifier *c);
  * tickets of one classifier complete in submission order).  On failure nothing is left behind. */
 int tbk_classifier_create_multi(const tbk_table *hap_a, const tbk_table *hap_b, const int *devices, int n_devices,
                                 tbk_classifier **out /* [n_devices] */);
-/* One more copy of a finished classifier's table, on `device` (which may be src's own). */
+/* One more classifier over a finished classifier's table, on `device`.  On another device the table is replicated
+ * (peer access where the devices are peers, hipMemcpyPeer); on src's own device the read-only table is shared - unless
+ * TBK_FORCE_REPLICA=1, which makes a full replica there too through the same calls (how a one-GPU box executes the
+ * replica path).  tbk_classifier_table_id: where a classifier's table lies (equal ids = one shared table) and whether
+ * it is such a copy. */
 int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out);
+int tbk_classifier_table_id(const tbk_classifier *c, uint64_t *table_id, int *is_replica);
 int tbk_classifier_device(const tbk_classifier *c);
 /* Distinct keys stored per list, bucket lines, bytes of HBM the paired table holds. */
 int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t *distinct_b,
@@ -244,6 +263,7 @@ int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const int *devic
 void tbk_pipeline_destroy(tbk_pipeline *p);
 int tbk_pipeline_depth(const tbk_pipeline *p);     /* sum of the rings' depths */
 int tbk_pipeline_devices(const tbk_pipeline *p);
+int tbk_pipeline_numa(const tbk_pipeline *p, int slot, int *node, int *cpus);  /* ring `slot`: its device's NUMA node (-1 unknown), CPUs its feeder thread is bound to (0: not bound) */
 tbk_classifier *tbk_pipeline_classifier(tbk_pipeline *p, int slot);  /* for stats / timing; never submit to it directly */
 int tbk_pipeline_submit(tbk_pipeline *p, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int32_t *counts, uint64_t *ticket);
 int tbk_pipeline_submit_packed(tbk_pipeline *p, const uint32_t *codes, const uint32_t *exc_chunk, const uint16_t *exc_mask, uint64_t n_exc,
@@ -442,8 +462,9 @@ int tbk_counter_unique(tbk_counter *a, tbk_counter *b, uint32_t min_count, uint3
                        uint64_t *n_written);
 
 /* Host threads the library starts for its own host-side work (list parsing, gzip members,
- * scoring): hardware threads limited by the CPU affinity mask and the cgroup CPU quota.
- * Env TBK_HOST_THREADS overrides. */
+ * scoring): hardware threads limited by the CPU affinity mask and the cgroup CPU quota, divided by the
+ * number of ranks the launcher started on this node (LOCAL_WORLD_SIZE, or TBK_LOCAL_RANKS): one process per GPU
+ * means N processes sharing the node's CPUs.  Env TBK_HOST_THREADS overrides. */
 int tbk_host_threads(void);
 
 /* ---- roofline calibration (SURVEY §8d "random-read roofline") -------------------------- */

@@ -67,6 +67,72 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
         assert lib.tbk_classifier_create_multi(a._h, b._h, bad, 0, out) == _lib.TBK_ERR_INVALID
 
 
+def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, monkeypatch):
+    """TBK_FORCE_REPLICA=1: every further ring on device 0 gets a full copy of the table made by the calls a second
+    GPU's replica is made by (tbk_classifier_replicate: hipMemcpyPeer) - the code of an 8-GPU node's table fan-out,
+    executed on the one GPU there is.  Three tables in three places, every one of them classifies like the oracle,
+    alone and behind the pipeline's queue; without the switch the rings share one table."""
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    v, fa, fb = _lists(tmp_path)
+    a, b = kmers.HashSet.from_file(fa, 0), kmers.HashSet.from_file(fb, 0)
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    bases, offs = kmers.pack_reads(v["reads"])
+    want = orc.count_batch(bases, offs, oa, ob)
+
+    def table_ids(multi):
+        out = []
+        for i in range(len(multi.devices)):
+            tid, rep = C.c_uint64(), C.c_int()
+            check(lib.tbk_classifier_table_id(multi._part(i)._h, C.byref(tid), C.byref(rep)))
+            out.append((tid.value, rep.value))
+        return out
+
+    monkeypatch.delenv("TBK_FORCE_REPLICA", raising=False)
+    with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
+        ids = table_ids(multi)
+        assert len({t for t, _ in ids}) == 1 and all(r == 0 for _, r in ids)
+    monkeypatch.setenv("TBK_FORCE_REPLICA", "1")
+    with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
+        ids = table_ids(multi)
+        assert len({t for t, _ in ids}) == 3 and sorted(r for _, r in ids) == [0, 1, 1], ids
+        for i in range(3):
+            assert multi._part(i).stats() == multi._part(0).stats()
+            assert np.array_equal(multi._part(i).classify_batch(bases, offs), want), i
+        cuts = [0, 7, 30, 31, 64, 100, 149, len(v["reads"])]
+        tickets = []
+        for i, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
+            bb, oo = kmers.pack_reads(v["reads"][lo:hi])
+            tickets.append((lo, hi, multi.submit(bb, oo) if i % 2 else multi.submit_packed(kmers.pack_bases(bb, oo))))
+        for lo, hi, t in tickets:
+            assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
+        assert min(multi.dealt) >= 1, multi.dealt   # every replica took batches
+
+
+def test_device_numa_node_and_feeder_binding(gpu, tmp_path):
+    """The device's NUMA node as the kernel reports it, and the pipeline's feeder bound to that node's CPUs (or left
+    alone where the node is unknown: both are legal on a box, the record must be consistent)."""
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    node = C.c_int(-2)
+    check(lib.tbk_device_numa_node(0, C.byref(node)))
+    assert node.value >= -1
+    ncpu = lib.tbk_numa_node_cpus_(node.value, None, 0)
+    v, fa, fb = _lists(tmp_path)
+    a, b = kmers.HashSet.from_file(fa, 0), kmers.HashSet.from_file(fb, 0)
+    bases, offs = kmers.pack_reads(v["reads"][:20])
+    with kmers.MultiClassifier(a, b, [0, 0]) as multi:
+        multi.wait(multi.submit(bases, offs))
+        for slot in range(2):
+            n, c = C.c_int(-2), C.c_int(-2)
+            check(lib.tbk_pipeline_numa(multi._h, slot, C.byref(n), C.byref(c)))
+            assert n.value == node.value
+            assert 0 <= c.value <= max(ncpu, 0) if node.value >= 0 else c.value == 0
+    assert lib.tbk_device_numa_node(99, C.byref(node)) != 0
+
+
 @pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0"])
 def test_cli_on_device_list_writes_the_same_bytes(gpu, capsys, tmp_path, monkeypatch, devices):
     import trio_binning_amd.classify_by_kmers as cbk

@@ -84,8 +84,12 @@ for lists in ("uniform", "haplotypes"):
         summary["windows_per_launch"] = windows
         summary["lines_per_window"] = round(summary.get("TCC_MISS_sum", 0) / windows, 4)
         cfg = bench["config"]
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from bench import kernel_fingerprint
+
         traffic = {
             "kernel": "tbk_probe_kernel<single-read>",
+            "kernel_source_sha256": kernel_fingerprint(),  # bench.py replays this record only on these very kernel sources
             "note": "HBM bytes of one launch of the single-read probe kernel (tbk_probe_kernel<..., MULTI = false>), from rocprofv3 PMC passes run separately from the timed bench "
                     "(tools/gpu_profile.sh): FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM), "
                     "cross-checked by TCC_MISS_sum x 128 B; divided by the launch's window starts so that bench.py can scale it to its own launch size.",

@@ -66,10 +66,10 @@ __global__ void __launch_bounds__(64) rate_kernel(uint64_t *out, int trips, uint
         if (OP == OP_S_AND32) { REP4(asm volatile("s_and_b32 %0, %0, %1" : "+s"(s0) : "s"((uint32_t)seed));, asm volatile("s_and_b32 %0, %0, %1" : "+s"(s1) : "s"((uint32_t)seed));,
                                      asm volatile("s_and_b32 %0, %0, %1" : "+s"(s2) : "s"((uint32_t)seed));, asm volatile("s_and_b32 %0, %0, %1" : "+s"(s3) : "s"((uint32_t)seed));) }
         if (OP == OP_MIX_VS) {  // 16 vector + 16 scalar instructions, interleaved: do the two pipes overlap across waves?
-            REP4(asm volatile("v_xor_b32 %0, %1, %0\n s_or_b64 %2, %2, %3" : "+v"(r0), "+s"(m0) : "v"(a32), "s"(seed));,
-                 asm volatile("v_xor_b32 %0, %1, %0\n s_or_b64 %2, %2, %3" : "+v"(r1), "+s"(m1) : "v"(a32), "s"(seed));,
-                 asm volatile("v_xor_b32 %0, %1, %0\n s_or_b64 %2, %2, %3" : "+v"(r2), "+s"(m2) : "v"(a32), "s"(seed));,
-                 asm volatile("v_xor_b32 %0, %1, %0\n s_or_b64 %2, %2, %3" : "+v"(r3), "+s"(m3) : "v"(a32), "s"(seed));)
+            REP4(asm volatile("v_xor_b32 %0, %2, %0\n s_or_b64 %1, %1, %3" : "+v"(r0), "+s"(m0) : "v"(a32), "s"(seed));,
+                 asm volatile("v_xor_b32 %0, %2, %0\n s_or_b64 %1, %1, %3" : "+v"(r1), "+s"(m1) : "v"(a32), "s"(seed));,
+                 asm volatile("v_xor_b32 %0, %2, %0\n s_or_b64 %1, %1, %3" : "+v"(r2), "+s"(m2) : "v"(a32), "s"(seed));,
+                 asm volatile("v_xor_b32 %0, %2, %0\n s_or_b64 %1, %1, %3" : "+v"(r3), "+s"(m3) : "v"(a32), "s"(seed));)
         }
     }
     if (r0 + r1 + r2 + r3 == 0x12345 || (m0 ^ m1 ^ m2 ^ m3) == 0x1234567 || (a ^ b ^ c64 ^ d64) == 77 || s0 + s1 + s2 + s3 == 99) out[0] = r0 + m0 + a + s0;

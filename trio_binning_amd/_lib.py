@@ -129,6 +129,13 @@ if hasattr(lib, "tbk_pipeline_create"):
     _sig("tbk_fastx_set_packing", C.c_int, _vp, C.c_int)
     _sig("tbk_fastx_set_borrowing", C.c_int, _vp, C.c_int)
     _sig("tbk_fastx_batch_borrowed", C.c_int, _vp)
+    _sig("tbk_classifier_table_id", C.c_int, _vp, _u64p, C.POINTER(C.c_int))
+    _sig("tbk_device_numa_node", C.c_int, C.c_int, C.POINTER(C.c_int))
+    _sig("tbk_numa_bind_to_device", C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))
+    _sig("tbk_numa_node_of_pci_", C.c_int, C.c_char_p)
+    _sig("tbk_numa_node_cpus_", C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int)
+    _sig("tbk_numa_bind_thread_", C.c_int, C.c_int)
+    _sig("tbk_pipeline_numa", C.c_int, _vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))
     _sig("tbk_fastx_batch_gather", C.c_int, _vp, _vp, C.c_uint64, _vp, C.c_uint64)
     _sig("tbk_fastx_batch_packed", C.c_int, _vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _u64p)
 _sig("tbk_score_and_bin", C.c_int, _vp, _u64, _u64, _u64, _vp, _vp, _vp)

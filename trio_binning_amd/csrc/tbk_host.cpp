@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+#include <pthread.h>
 #include <sched.h>
 #include <atomic>
 #include <memory>
@@ -114,10 +116,105 @@ extern "C" int tbk_host_threads(void) {
         if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
     }
     if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (long)((quota + period - 1) / period)));
+    // One process per GPU (the launcher's LOCAL_WORLD_SIZE ranks on this node; TBK_LOCAL_RANKS says the same by hand):
+    // the ranks share the node's CPUs, so each takes its share - 8 ranks in a 16-CPU cgroup start 2 workers each,
+    // not 16 each.  (A single process driving several devices divides inside tbk_pipeline_create.)
+    long ranks = (long)env_double("TBK_LOCAL_RANKS", 0);
+    if (ranks < 1) ranks = (long)env_double("LOCAL_WORLD_SIZE", 1);
+    if (ranks > 1) n = std::max<long>(1, n / ranks);
     const double forced = env_double("TBK_HOST_THREADS", 0);
     if (forced >= 1) n = (long)forced;
     cached = (int)std::max<long>(1, n);
     return cached;
+}
+
+// ---- NUMA placement ("pinned, NUMA-local buffers, one feeder thread per GPU") -------------------------
+// A GPU hangs off one socket's PCIe root; a feeder thread that packs and stages batches on the other socket moves every
+// byte across the inter-socket link first.  The node of a device is what the kernel says in
+// /sys/bus/pci/devices/<bdf>/numa_node (-1 or a missing file: unknown - nothing is bound); its CPUs are
+// /sys/devices/system/node/node<N>/cpulist.  TBK_SYSFS_ROOT replaces "/sys" (tests), TBK_NUMA=0 turns binding off.
+// Pinned buffers follow the thread: hipHostMalloc places host memory near the current device by default, and the
+// buffers are allocated (and first touched) by the bound feeder thread.
+static std::string sysfs_root() {
+    const char *r = getenv("TBK_SYSFS_ROOT");
+    return r && *r ? std::string(r) : std::string("/sys");
+}
+
+extern "C" int tbk_numa_node_of_pci_(const char *bdf) {
+    if (!bdf || !*bdf) return -1;
+    std::string id(bdf);
+    for (char &ch : id) ch = (char)tolower((unsigned char)ch);
+    FILE *f = fopen((sysfs_root() + "/bus/pci/devices/" + id + "/numa_node").c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node < 0 ? -1 : node;
+}
+
+// the CPUs of a node ("0-63,128-191"), at most `cap` of them written; returns how many the node has (0: unknown node)
+extern "C" int tbk_numa_node_cpus_(int node, int *cpus, int cap) {
+    if (node < 0) return 0;
+    FILE *f = fopen((sysfs_root() + "/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+    if (!f) return 0;
+    char buf[4096] = {0};
+    const size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    int n = 0;
+    const char *p = buf;
+    while (*p) {
+        while (*p == ',' || *p == ' ' || *p == '\n') p++;
+        if (!isdigit((unsigned char)*p)) break;
+        char *end = nullptr;
+        long lo = strtol(p, &end, 10), hi = lo;
+        p = end;
+        if (*p == '-') { hi = strtol(p + 1, &end, 10); p = end; }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) { if (cpus && n < cap) cpus[n] = (int)c; n++; }
+    }
+    return n;
+}
+
+// Bind the calling thread (and the threads it starts from now on) to the CPUs of `node` that its current affinity mask
+// allows.  Returns the number of CPUs it is bound to, 0 when nothing was changed (unknown node, no CPU in common,
+// TBK_NUMA=0, or the kernel refused).
+extern "C" int tbk_numa_bind_thread_(int node) {
+    const char *off = getenv("TBK_NUMA");
+    if (off && *off == '0') return 0;
+    std::vector<int> cpus(CPU_SETSIZE);
+    const int n = tbk_numa_node_cpus_(node, cpus.data(), (int)cpus.size());
+    if (n <= 0) return 0;
+    cpu_set_t cur, want;
+    if (pthread_getaffinity_np(pthread_self(), sizeof cur, &cur) != 0) return 0;
+    CPU_ZERO(&want);
+    for (int i = 0; i < std::min(n, (int)cpus.size()); i++) if (CPU_ISSET(cpus[(size_t)i], &cur)) CPU_SET(cpus[(size_t)i], &want);
+    const int k = CPU_COUNT(&want);
+    if (k == 0 || k == CPU_COUNT(&cur)) return k == 0 ? 0 : k;  // (nothing in common; or already inside the node)
+    if (pthread_setaffinity_np(pthread_self(), sizeof want, &want) != 0) return 0;
+    return k;
+}
+
+extern "C" int tbk_device_numa_node(int device, int *node) {
+    if (!node) return fail(TBK_ERR_INVALID, "node is NULL");
+    *node = -1;
+    char bdf[64] = {0};
+    int n_visible = 0;
+    if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0) { (void)hipGetLastError(); return fail(TBK_ERR_NO_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= n_visible) return fail(TBK_ERR_INVALID, "device %d out of range (0..%d)", device, n_visible - 1);
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return TBK_OK; }  // (unknown: -1)
+    *node = tbk_numa_node_of_pci_(bdf);
+    return TBK_OK;
+}
+
+extern "C" int tbk_numa_bind_to_device(int device, int *node_out, int *cpus_out) {
+    int node = -1;
+    const int rc = tbk_device_numa_node(device, &node);
+    if (node_out) *node_out = node;
+    if (cpus_out) *cpus_out = 0;
+    if (rc) return rc;
+    const int k = tbk_numa_bind_thread_(node);
+    if (cpus_out) *cpus_out = k;
+    return TBK_OK;
 }
 
 // ---- handles ---------------------------------------------------------------------------
@@ -221,6 +318,7 @@ struct tbk_classifier {
     uint64_t distinct_a = 0, distinct_b = 0;
     uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
+    int replica_copies = 0;      // 1: this classifier's table is a copy made by tbk_classifier_replicate (hipMemcpyPeer), 0: built here or shared
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
     uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line
@@ -1074,27 +1172,28 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->guests = src->guests;
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
-    if (device == src->device && src->pair_owner) {
+    // TBK_FORCE_REPLICA=1: a ring on the device that holds the table gets a full replica of its own all the same,
+    // made by the very calls a second GPU's replica is made by (peer query, hipMemcpyPeer) - how a one-GPU box
+    // executes and checks the replica path of an 8-GPU node (tests/test_gpu_multi.py).
+    const bool force_replica = env_double("TBK_FORCE_REPLICA", 0) != 0;
+    if (device == src->device && src->pair_owner && !force_replica) {
         // another stream ring on the device that holds the table already: the table is read-only, so it is shared
         c->d_pair = src->d_pair;
         c->pair_owner = src->pair_owner;
     } else {
         hipError_t e = c->alloc_pair(bytes);
         if (e == hipSuccess) {
-            if (device == src->device) {
-                e = hipMemcpy(c->d_pair, src->d_pair, bytes, hipMemcpyDeviceToDevice);
-            } else {
-                // the finished table travels device to device (xGMI when the two are peers; the runtime
-                // stages through the host otherwise) - once, outside any timed region
-                int can = 0;
-                if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
-                    const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
-                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                }
-                (void)hipGetLastError();
-                e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
+            // the finished table travels device to device (xGMI when the two are peers; the runtime
+            // stages through the host otherwise) - once, outside any timed region
+            int can = 0;
+            if (device != src->device && hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
             }
+            (void)hipGetLastError();
+            e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
             if (e == hipSuccess) e = hipDeviceSynchronize();
+            c->replica_copies = 1;
         }
         if (e != hipSuccess) {
             c->free_pair();
@@ -1202,6 +1301,15 @@ extern "C" int tbk_classifier_calibrate(tbk_classifier *c, double *lines_per_sec
     (void)hipFree(sink);
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "tbk_classifier_calibrate: %s", hipGetErrorString(e));
     *lines_per_sec = ms > 0 ? (double)done / (ms * 1e-3) : 0;
+    return TBK_OK;
+}
+
+// Which memory a classifier's table lies in (two classifiers with equal ids share one table), and whether that
+// table is a replica copied from another classifier's.
+extern "C" int tbk_classifier_table_id(const tbk_classifier *c, uint64_t *table_id, int *is_replica) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (table_id) *table_id = (uint64_t)(uintptr_t)c->d_pair;
+    if (is_replica) *is_replica = c->replica_copies;
     return TBK_OK;
 }
 

@@ -80,7 +80,10 @@ struct tbk_pipeline {
     int depth = 0;
     bool stop = false;
     std::vector<uint64_t> batches_by_slot;         // how many batches each ring took (stats)
+    std::vector<int> numa_node, numa_cpus;         // per ring: the device's NUMA node (-1 unknown) and the CPUs its feeder is bound to (0: not bound)
 };
+
+extern "C" int tbk_numa_bind_to_device(int device, int *node_out, int *cpus_out);
 
 static int pfail(int code, const char *msg) {
     tbk_set_error_(code, msg);
@@ -90,6 +93,9 @@ static int pfail(int code, const char *msg) {
 static void feeder_loop(tbk_pipeline *p, int slot) {
     const Ring &rg = p->rings[(size_t)slot];
     const int ring = rg.depth;
+    // this thread packs and stages its device's batches and allocates the ring's pinned buffers (at its first submit):
+    // it runs on the CPUs of the socket the device hangs off (tbk_host.cpp "NUMA placement"; unknown node: anywhere)
+    if (rg.c) (void)tbk_numa_bind_to_device(tbk_classifier_device(rg.c), &p->numa_node[(size_t)slot], &p->numa_cpus[(size_t)slot]);
     std::deque<std::pair<uint64_t, Job *>> flying;  // (ring ticket, job), oldest first
     auto finish_oldest = [&]() {
         auto [tk, job] = flying.front();
@@ -165,6 +171,7 @@ extern "C" int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const
     tbk_pipeline *p = new tbk_pipeline();
     p->cls = cls;
     p->batches_by_slot.assign((size_t)n_devices, 0);
+    p->numa_node.assign((size_t)n_devices, -1); p->numa_cpus.assign((size_t)n_devices, 0);
     // an ASCII batch is packed by its feeder with this share of the host threads
     const int share = std::max(1, tbk_host_threads() / n_devices);
     for (int i = 0; i < n_devices; i++) {
@@ -189,6 +196,7 @@ extern "C" int tbk_pipeline_create_test_(int n_rings, int ring_depth, tbk_pipeli
     if (n_rings < 1 || n_rings > 64 || ring_depth < 1 || !submit || !wait) return pfail(TBK_ERR_INVALID, "bad test pipeline parameters");
     tbk_pipeline *p = new tbk_pipeline();
     p->batches_by_slot.assign((size_t)n_rings, 0);
+    p->numa_node.assign((size_t)n_rings, -1); p->numa_cpus.assign((size_t)n_rings, 0);
     for (int i = 0; i < n_rings; i++) {
         Ring rg;
         rg.t_submit = submit; rg.t_wait = wait; rg.user = user; rg.slot = i; rg.depth = ring_depth;
@@ -208,6 +216,12 @@ extern "C" int tbk_pipeline_takes_packed_(const tbk_pipeline *p) {
     return 1;
 }
 extern "C" int tbk_pipeline_devices(const tbk_pipeline *p) { return p ? (int)p->rings.size() : 0; }
+extern "C" int tbk_pipeline_numa(const tbk_pipeline *p, int slot, int *node, int *cpus) {
+    if (!p || slot < 0 || slot >= (int)p->rings.size()) return pfail(TBK_ERR_INVALID, "pipeline is NULL or slot out of range");
+    if (node) *node = p->numa_node[(size_t)slot];
+    if (cpus) *cpus = p->numa_cpus[(size_t)slot];
+    return TBK_OK;
+}
 extern "C" tbk_classifier *tbk_pipeline_classifier(tbk_pipeline *p, int slot) {
     return p && slot >= 0 && slot < (int)p->cls.size() ? p->cls[(size_t)slot] : nullptr;
 }
