@@ -596,6 +596,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                     and t.get("k") == k and t.get("bucket_select") == bucket_select and t.get("lists", "uniform") == args.lists
                     and abs(t.get("table_load", 0) - table_load) < 2e-3
                     and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
+                    and bool(t.get("entry_layout", False)) == bool(stats.get("entry_layout"))
                     and t.get("kernel") == "tbk_probe_kernel<single-read>")
             if same and t.get("kernel_source_sha256") != kernel_fingerprint():
                 # taken on other kernels than the ones in this tree: stale bytes are not reported
@@ -610,7 +611,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_src,
-        "kernel": "tbk_probe_kernel<..., MULTI=false, TWO=false> (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
+        "kernel": ("tbk_probe_entry_kernel<W, MULTI=false, TWO=false>" if stats.get("entry_layout") else "tbk_probe_kernel<..., MULTI=false, TWO=false>") + " (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
         "timed_in": "the timed region of `value` (HIP events on the compute stream)",
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
         "share_of_the_batch_windows": round(single_frac, 4), "passes": int(n_passes), "multi_read_passes": int(multi_passes),
@@ -673,7 +674,10 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             "table_bytes_per_gpu": stats["table_bytes"], "table_bytes_per_key": round(stats["table_bytes"] / max(1, 2 * n_list), 1), "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
-            "line_layout": "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines", "keys_behind_front": stats.get("keys_behind_front"),
+            "line_layout": ("entries: a run of overlapping list k-mers stored once; 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("entry_layout")
+                            else "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines"),
+            "keys_behind_front": stats.get("keys_behind_front"),
+            "entries": [stats.get("entries_a"), stats.get("entries_b")] if stats.get("entry_layout") else None,
             "parallelism": f"read-sharded x{world}, tables replicated, no data-path collective",
             "rings_per_rank": max(1, args.rings), "batches_per_ring": pipe.dealt,
         },

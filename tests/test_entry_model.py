@@ -1,0 +1,32 @@
+"""CPU model of the entry layout (tests/native/entry_model.cpp over csrc/tbk_common.h): a sequential build with the
+insert rule of tbk_entry_insert_kernel, checked against plain set membership of canonical k-mers - list keys through
+every (tied position, orientation) form, windows of reads on both strands asked the way the probe kernel asks,
+hapA-over-hapB priority (c/kmers.c:245-299).  No GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("entry_model") / "entry_model")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "entry_model.cpp")], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("k,w,crowd", [(21, 6, 0), (21, 6, 1), (21, 5, 1), (21, 4, 0), (22, 6, 0), (22, 4, 1), (23, 6, 1), (23, 5, 0), (24, 5, 1), (25, 4, 0)])
+def test_entry_model_equals_set_membership(model, k, w, crowd):
+    for seed in (1, 2):
+        r = subprocess.run([model, str(k), str(w), str(seed), str(crowd)], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "mismatches 0" in r.stdout and "no entry layout" not in r.stdout, r.stdout
+
+
+def test_entry_geometry_limits(model):
+    # k = 27 and beyond: the flanks no longer fit an entry's 30 bits at any useful span - the key layouts stay
+    for k in (27, 31, 32):
+        r = subprocess.run([model, str(k), "6", "1", "0"], capture_output=True, text=True)
+        assert r.returncode == 0 and "no entry layout" in r.stdout, r.stdout

@@ -1,0 +1,179 @@
+"""The entry layout (csrc/tbk_common.h "entry layout"): a run of overlapping list k-mers stored once per sampled
+m-mer, compared under the window's mask by a pair-cooperative probe.  Membership must be exactly the reference's
+(kmer_in_hash_set, c/kmers.c:245-268; count_kmers_in_read, c/kmers.c:270-299): every test compares the HIP path,
+through the C-ABI, with the oracle or with the recorded output of the real reference.  The CPU model of the layout's
+arithmetic is tests/test_entry_model.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_gpu_parity import _pack, _rand_reads, _rc, _write
+
+pytestmark = pytest.mark.gpu
+
+
+def _genome_lists(rng, k, n_loci, snp_every=150, genome=40_000):
+    """Two haplotypes of a random genome that differ by SNPs; a list = the k-mers of one haplotype the other lacks, as
+    find-unique-kmers writes them (canonical, find_unique_kmers.py:200-233), in runs of up to k around every SNP."""
+    ga = rng.integers(0, 4, genome)
+    ga[5000:5300] = (np.arange(300) // 3) & 1               # low complexity
+    ga[9000:11000] = ga[2000:4000]                           # a repeat
+    pal = rng.integers(0, 4, 40)
+    ga[12000:12080] = np.concatenate([pal, 3 - pal[::-1]])   # its own reverse complement: palindromic m-mers and k-mers
+    gb = ga.copy()
+    at = rng.choice(genome, size=genome // snp_every, replace=False)
+    gb[at] = (ga[at] + rng.integers(1, 4, at.size)) & 3
+    sa, sb = "".join("ACGT"[c] for c in ga), "".join("ACGT"[c] for c in gb)
+
+    def canon(s):
+        r = _rc(s)
+        # the reference's canonical form is the smaller PACKED integer (base i at bits 2i): compare from the last base down
+        return s if s[::-1] <= r[::-1] else r
+
+    ka = {canon(sa[i:i + k]) for i in range(genome - k + 1)}
+    kb = {canon(sb[i:i + k]) for i in range(genome - k + 1)}
+    la, lb = sorted(ka - kb), sorted(kb - ka)
+    rng.shuffle(la)
+    rng.shuffle(lb)
+    return sa, sb, la[:n_loci], lb[:n_loci]
+
+
+@pytest.mark.parametrize("k,w", [(21, 6), (21, 5), (21, 4), (22, 6), (23, 6), (23, 5), (24, 5), (25, 4)])
+@pytest.mark.parametrize("crowded", [0, 1])
+def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, crowded):
+    """Lists of runs (two haplotypes' unique k-mers), uniform keys, duplicate lines, lines shared between the lists on
+    either strand, non-canonical lines (dead in the reference), low-complexity and palindromic sequence; reads drawn
+    from both haplotypes on both strands with errors, ragged shapes, bytes outside ACGT - in a roomy table and in one
+    so crowded that lists overflow their lines (second looks, walks)."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(100 * k + 10 * w + crowded)
+    monkeypatch.setenv("TBK_ENTRY", "1")
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+    monkeypatch.setenv("TBK_ENTRY_LOAD", "2.0" if crowded else "0.3")
+    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
+    sa, sb, la, lb = _genome_lists(rng, k, 6000)
+    uni = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(1500)]
+    la += uni[:700]
+    lb += uni[700:1400]
+    lb += [la[int(i)] for i in rng.integers(0, len(la), 40)] + [_rc(la[int(i)]) for i in rng.integers(0, len(la), 40)]   # shared with hapA
+    la += [la[int(i)] for i in rng.integers(0, len(la), 20)]                                                               # duplicate lines
+    la += ["A" * k, "T" * k, ("AC" * k)[:k], ("ACGT" * k)[:k]]
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "\n".join(lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    assert (a.num_kmers, b.num_kmers) == (oa.num_kmers, ob.num_kmers)
+    reads = []
+    for hap in (sa, sb):
+        for _ in range(12):
+            lo = int(rng.integers(0, len(hap) - 6000))
+            r = list(hap[lo:lo + int(rng.integers(50, 6000))])
+            for i in rng.integers(0, len(r), len(r) // 300):
+                r[int(i)] = "ACGT"[int(rng.integers(0, 4))]
+            r = "".join(r)
+            reads.append(r if rng.random() < 0.5 else _rc(r))
+    reads += _rand_reads(rng, 40, 2500, la + lb, k, p_plant=0.9)
+    reads += ["", "A" * (k - 1), la[0], _rc(lb[0]) * 2, "".join(la[:30]), sa[11990:12100], _rc(sa[11990:12100]), sa[4990:5320]]
+    body = sa[20000:26000]
+    reads += [body[: 2048 - sum(map(len, reads)) % 2048], body[:2047], body[:2048 + k - 1], body[:4096]]   # pass-boundary shapes
+    noisy = list(sb[30000:33000])
+    for i in rng.integers(0, 3000, 40):
+        noisy[int(i)] = "NnacgtR-"[int(rng.integers(0, 8))]
+    reads.append("".join(noisy))
+    reads = [reads[int(i)] for i in rng.permutation(len(reads))]
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob, strict=True)
+    assert want.sum() > 2000
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["entry_layout"] and st["minimizer_w"] == w and st["sampling_t"] > 0, st
+        assert st["entries_a"] + st["entries_b"] < st["distinct_a"] + st["distinct_b"], st     # runs merged
+        if crowded:
+            assert st["keys_behind_front"] > 0 and st["keys_past_half"] > 0, st                # second looks and walks happen
+        got = cls.classify_batch(bases, offs)
+        again = cls.classify_batch(bases, offs)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (k, w, crowded, st, bad[:10], got[bad[:5]], want[bad[:5]], [len(reads[int(i)]) for i in bad[:5]])
+    assert np.array_equal(again, want)
+
+
+def test_entry_layout_on_the_reference_vectors(gpu, monkeypatch):
+    """The recorded counts of the real reference (tests/golden/diff_vectors.json, k = 21) through the entry layout."""
+    from trio_binning_amd import kmers
+
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == 21)
+    monkeypatch.setenv("TBK_ENTRY", "1")
+    a = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_a"]], dtype=np.uint64), 21)
+    b = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_b"]], dtype=np.uint64), 21)
+    with kmers.Classifier(a, b) as cls:
+        assert cls.stats()["entry_layout"]
+        got = cls.classify_reads(v["reads"])
+    assert np.array_equal(got, np.array(v["counts"], dtype=np.int32))
+
+
+def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
+    """The policy: lists shaped like find-unique-kmers output overflow the fronts of the key layout and are rebuilt as
+    entries - a quarter of the slots, under 50 bytes of HBM per key; uniform lists stay in the key layout's front.  Where
+    the entry layout cannot be had (k = 31) clustered lists get whole lines, as before."""
+    import ctypes as C
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    for v in ("TBK_ENTRY", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_ENTRY_LOAD"):
+        monkeypatch.delenv(v, raising=False)
+    dev, n = 0, 400_000
+    rng = np.random.default_rng(3)
+
+    def hap_lists(k):
+        cap = 2 * n
+        ptrs = []
+        for _ in range(2):
+            p = C.c_void_p()
+            check(lib.tbk_device_alloc(dev, cap * 8, C.byref(p)))
+            ptrs.append(p.value)
+        got = C.c_uint64()
+        check(lib.tbk_synth_hap_keys_device(dev, 0x5EED0001, 3_000_000, int(round((1 / 500) * (1 << 24))), k, C.c_void_p(ptrs[0]), C.c_void_p(ptrs[1]), cap, C.byref(got)))
+        m = got.value
+        keys = np.empty(2 * m, dtype=np.uint64)
+        check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data, C.c_void_p(ptrs[0]), m * 8))
+        check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data + m * 8, C.c_void_p(ptrs[1]), m * 8))
+        for p in ptrs:
+            check(lib.tbk_device_free(dev, C.c_void_p(p)))
+        return keys[:m], keys[m:]
+
+    def decode(key, k):
+        return "".join("ACGT"[(int(key) >> (2 * i)) & 3] for i in range(k))
+
+    for k, want_entry in ((21, True), (23, True), (31, False)):
+        ka, kb = hap_lists(k)
+        oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
+        plants = [decode(x, k) for x in np.concatenate([ka[:300], kb[:300]])]
+        bases, offs = _pack(_rand_reads(rng, 300, 3000, plants, k, p_plant=0.9))
+        want = orc.count_batch(bases, offs, oa, ob)
+        a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
+        with kmers.Classifier(a, b) as cls:
+            st = cls.stats()
+            assert st["entry_layout"] == want_entry, (k, st)
+            if want_entry:
+                keys, entries = st["distinct_a"] + st["distinct_b"], st["entries_a"] + st["entries_b"]
+                assert keys > 3 * entries, (k, st)                          # a variant's windows: one entry per sampled m-mer
+                assert st["table_bytes"] <= 50 * (ka.size + kb.size), (k, st)
+                assert st["keys_behind_front"] <= 0.02 * entries, (k, st)   # two-slot fronts hold them
+            else:
+                assert not st["front_layout"], (k, st)
+            assert np.array_equal(cls.classify_batch(bases, offs), want), k
+        monkeypatch.setenv("TBK_ENTRY", "0")                                # switched off: whole lines, as before
+        with kmers.Classifier(a, b) as cls:
+            st = cls.stats()
+            assert not st["entry_layout"] and not st["front_layout"], (k, st)
+            assert np.array_equal(cls.classify_batch(bases, offs), want), k
+        monkeypatch.delenv("TBK_ENTRY")
+    uni = np.empty(2 * n, dtype=np.uint64)
+    check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, 21, uni.ctypes.data))
+    with kmers.Classifier(kmers.HashSet.from_keys(uni[:n], 21), kmers.HashSet.from_keys(uni[n:], 21)) as cls:
+        st = cls.stats()
+        assert not st["entry_layout"] and st["front_layout"] and st["layout_builds"] == 1, st

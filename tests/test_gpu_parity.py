@@ -588,24 +588,27 @@ def test_lists_choose_the_line_layout(gpu, orc, monkeypatch):
         a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
-            assert st["sampling_t"] > 0 and st["layout_builds"] == want_builds, (name, st)
+            assert st["sampling_t"] > 0 and st["layout_builds"] in (want_builds, want_builds + (name == "clustered")), (name, st)
             # lists that spread are probed front-first (64 of a line's 128 bytes; few of their keys lie behind the first
-            # four slots of a bucket), clustered ones in whole lines
+            # four slots of a bucket); clustered ones - runs of overlapping k-mers - are rebuilt as entries (k = 21 has
+            # room for them: tests/test_gpu_entry.py), which takes them out of the key layouts altogether
             assert st["front_layout"] == want_front and (not want_front or st["keys_behind_front"] <= 0.006 * 2 * half), (name, st)
+            assert st["entry_layout"] == (name == "clustered"), (name, st)
             load = half / (st["n_buckets"] * 8)
-            assert abs(load - 0.08) < 0.005, (name, load)   # 100 B of HBM per key either way
+            assert st["entry_layout"] or abs(load - 0.08) < 0.005, (name, load)   # 100 B of HBM per key in the key layouts
             assert np.array_equal(cls.classify_batch(bases, offs), want), name
         for pin in ("0", "1"):
             monkeypatch.setenv("TBK_MOD_SAMPLING", pin)   # the rule is pinned, the layout still follows the lists
             with kmers.Classifier(a, b) as cls:
                 st = cls.stats()
-                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] == want_builds and st["front_layout"] == want_front, (name, pin, st)
+                assert (st["sampling_t"] > 0) == (pin == "1") and st["layout_builds"] >= want_builds and st["front_layout"] == want_front, (name, pin, st)
+                assert st["entry_layout"] == (name == "clustered" and pin == "1"), (name, pin, st)   # (entries need mod-sampling's position; the random minimizer keeps whole lines)
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin)
             monkeypatch.setenv("TBK_TABLE_LOAD", "0.1")   # and the load
             with kmers.Classifier(a, b) as cls:
                 st = cls.stats()
                 assert (st["sampling_t"] > 0) == (pin == "1") and st["front_layout"] == want_front, (name, pin, st)
-                assert abs(half / (st["n_buckets"] * 8) - 0.1) < 0.005
+                assert st["entry_layout"] or abs(half / (st["n_buckets"] * 8) - 0.1) < 0.005
                 assert np.array_equal(cls.classify_batch(bases, offs), want), (name, pin, "load")
             monkeypatch.delenv("TBK_TABLE_LOAD")
         monkeypatch.delenv("TBK_MOD_SAMPLING")

@@ -129,6 +129,7 @@ if hasattr(lib, "tbk_pipeline_create"):
     _sig("tbk_fastx_set_packing", C.c_int, _vp, C.c_int)
     _sig("tbk_fastx_set_borrowing", C.c_int, _vp, C.c_int)
     _sig("tbk_fastx_batch_borrowed", C.c_int, _vp)
+    _sig("tbk_classifier_entries", C.c_int, _vp, C.POINTER(C.c_int), _u64p, _u64p)
     _sig("tbk_classifier_table_id", C.c_int, _vp, _u64p, C.POINTER(C.c_int))
     _sig("tbk_device_numa_node", C.c_int, C.c_int, C.POINTER(C.c_int))
     _sig("tbk_numa_bind_to_device", C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int))

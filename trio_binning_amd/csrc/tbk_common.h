@@ -348,6 +348,134 @@ struct TbkPairView {
     uint32_t guests;        // see TbkTableView
 };
 
+// ---- entry layout: a run of overlapping list k-mers is stored once ------------------------------------------------
+// Real find-unique-kmers output (find_unique_kmers.py:200-233) is the k overlapping k-mers around every variant, and
+// those that sample the same m-mer occurrence - 4.3 consecutive windows on average at w = 6 - land in one bucket as
+// 4.3 separate keys, in both lists at once: the fronts overflow and the probe needs whole lines.
+// All of them are windows of ONE stretch of sequence: the sampled m-mer with up to FL = o + w - 1 bases on either side.
+// The entry layout stores that stretch once per (m-mer occurrence, list):
+//     lo word   the canonical m-mer (m <= 16 bases)
+//     hi word   bits [0, 2 FL)       left flank  - context bases 0 .. FL-1, the base next to the m-mer highest
+//               bits [2 FL, 4 FL)    right flank - context bases FL+m .. FL+m+FL-1
+//               bits [4 FL, +w)      V: bit p set = "the k-mer whose sampled m-mer sits at span position p is in the list"
+//               bit 30               always 0 (a window that may not match asks for a 1 there)
+//               bit 31               a flag of the slot's place in its line, no part of the entry (see tbk_eslot_at)
+// in the orientation in which the m-mer is canonical.  The k-mer at span position p is its m-mer plus the o + p bases
+// before it and the (w - 1 - p) + o bases after it: in the flank field those are the CONTIGUOUS 2 (k - m) bits from bit
+// 2 (w - 1 - p) on (the left flank's top bases, then the right flank's low ones).  A window with oriented k-mer K and
+// position p therefore matches an entry iff   lo == m-mer   and   (hi ^ khi) & mhi == 0,   where khi holds K's flank
+// bases at that place plus the bit V[p], and mhi covers exactly those bits: one v_bfi and one 64-bit compare per slot
+// (expected = (cm, bfi(mhi, khi, hi))).  Bases of an entry outside every valid window's extent are zero and never
+// looked at.  Keys of different loci that share an m-mer share an entry as long as their flanks agree where both define
+// them; otherwise they are separate entries of the bucket.  EMPTY is 0 (no V bit: matches nothing).
+// A variant's k-mers cost one slot per bucket instead of four to five: the haplotype-shaped lists of the bench shrink
+// from 6.0e8 keys to 1.4e8 entries, fronts of two slots per list hold them, and the probe asks for 32 bytes of a line
+// with two lanes per window.  Needs m <= 16 and 4 FL + w <= 30: k = 21 (w = 6), k = 22..25 with shorter spans.
+#define TBK_FLAG_ENTRY 4u    // `guests` word of the views: the paired table is in entry layout
+#define TBK_ENTRY_NEVER 0x40000000u
+#define TBK_ENTRY_FLAG 0x80000000u
+
+struct TbkEntryGeom {
+    int fl;      // flank bases kept on each side of the m-mer: o + w - 1
+    int fbits;   // bits of one window's flank bases: 2 (k - m)
+    int vshift;  // first V bit: 4 fl
+};
+
+TBK_HD bool tbk_entry_geom(int k, TbkMz z, TbkEntryGeom *g) {
+    if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
+    const int fl = z.o + z.w - 1;
+    if (4 * fl + z.w > 30) return false;
+    g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
+    return true;
+}
+
+struct TbkEntryKey { uint32_t cm, khi, mhi; };
+
+// what a window asks an entry: `oriented` = its k-mer read in the orientation in which the sampled m-mer is canonical,
+// pos = that m-mer's position in the span as `oriented` reads
+TBK_HD TbkEntryKey tbk_entry_key(uint64_t oriented, TbkMz z, TbkEntryGeom g, int pos) {
+    const int a = 2 * (z.o + pos);
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    TbkEntryKey e;
+    e.cm = (uint32_t)(oriented >> a) & mmask;
+    const uint32_t low = (uint32_t)oriented & ((1u << a) - 1u);                 // the o + pos bases before the m-mer
+    const uint32_t high = a + 2 * z.m >= 64 ? 0u : (uint32_t)(oriented >> (a + 2 * z.m));  // the bases after it
+    const uint32_t fw = low | (high << a);
+    const int sh = 2 * (z.w - 1 - pos);
+    const uint32_t vbit = 1u << (g.vshift + pos);
+    e.khi = (fw << sh) | vbit;
+    e.mhi = (((1u << g.fbits) - 1u) << sh) | vbit;
+    return e;
+}
+
+TBK_HD bool tbk_entry_match(uint64_t slot, TbkEntryKey e) {
+    return (uint32_t)slot == e.cm && ((((uint32_t)(slot >> 32)) ^ e.khi) & e.mhi) == 0;
+}
+
+// the flank bits an entry defines: the union of its valid windows' extents
+TBK_HD uint32_t tbk_entry_defined(uint32_t hi, TbkMz z, TbkEntryGeom g) {
+    uint32_t d = 0;
+    for (int p = 0; p < z.w; p++)
+        if ((hi >> (g.vshift + p)) & 1u) d |= ((1u << g.fbits) - 1u) << (2 * (z.w - 1 - p));
+    return d;
+}
+
+// may the window `e` (a list key) join the entry in `slot`?  Same m-mer, and the flanks agree wherever both define them.
+TBK_HD bool tbk_entry_compatible(uint64_t slot, TbkEntryKey e, TbkMz z, TbkEntryGeom g) {
+    if ((uint32_t)slot != e.cm) return false;
+    const uint32_t hi = (uint32_t)(slot >> 32);
+    const uint32_t mine = e.mhi & ~(1u << 31) & ((1u << g.vshift) - 1u);  // my flank bits
+    return ((hi ^ e.khi) & mine & tbk_entry_defined(hi, z, g)) == 0;
+}
+
+// A line of the entry layout, 16 slots: [A0 A1 | B0 B1 | A2 A3 | A4 A5 | A6 A7 | B2 B3 | B4 B5 | B6 B7].  The probe's
+// window loop reads the first 32 bytes (lane 0 of a pair: hapA's two front slots, lane 1: hapB's); a list's slots fill
+// in index order, so its first empty slot ends a search.  Bit 31 of front slot 1 says "this list has entries behind the
+// front of this line" (slot 2 is taken), bit 31 of slot 7 "an entry of this list went past this line" (all eight taken
+// and one more wanted in): set by the inserts, read by the probe from slots it holds anyway.
+TBK_HD uint32_t tbk_eslot_at(uint32_t half, uint32_t s) {
+    const uint32_t b = half ? 1u : 0u;
+    return s < 2 ? 2u * b + s : 4u + 6u * b + (s - 2u);
+}
+
+TBK_HD uint32_t tbk_entry_bucket(uint32_t cm, uint32_t n_buckets) { return tbk_reduce(tbk_mmer_hash(cm), n_buckets); }
+// an entry that finds its list's eight slots of a line taken goes to a second-choice bucket (a hash of the m-mer: every
+// window that asks for this m-mer follows the same path), then linearly on
+TBK_HD uint32_t tbk_entry_next_bucket(uint32_t cm, uint32_t n_buckets, uint32_t b, bool leaving_home) {
+    if (leaving_home) return tbk_reduce(tbk_mix32((uint64_t)cm ^ 0xA5A5A5A500000000ull), n_buckets);
+    return b + 1 == n_buckets ? 0 : b + 1;
+}
+
+// Orientation(s) of a list key for the m-mer at span position p as the key stands: n = 1, or 2 when that m-mer is its
+// own reverse complement (a lookup may then read it either way round).  Returns n; out[i] = what to ask / store.
+TBK_HD uint64_t tbk_revcomp_packed(uint64_t x, int k);
+TBK_HD int tbk_entry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g, int p, TbkEntryKey *out) {
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    const uint32_t x = (uint32_t)(key >> (2 * (z.o + p))) & mmask;
+    const uint32_t y = tbk_revcomp32(x, z.m);
+    int n = 0;
+    if (x <= y) out[n++] = tbk_entry_key(key, z, g, p);
+    if (x >= y) out[n++] = tbk_entry_key(tbk_revcomp_packed(key, k), z, g, z.w - 1 - p);
+    return n;
+}
+
+// Membership of one list key in one list's entries (build-time scans, tests, the CPU model): any one of the key's
+// (orientation, tied position) forms is stored iff the key is.
+TBK_HD bool tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkEntryKey e) {
+    uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+    for (uint32_t walked = 0; walked <= n_buckets; walked++) {
+        const uint64_t *line = slots + (uint64_t)b * 16;
+        for (uint32_t s = 0; s < 8; s++) {
+            const uint64_t v = line[tbk_eslot_at(half, s)];
+            if ((v & ~((uint64_t)TBK_ENTRY_FLAG << 32)) == 0) return false;  // first empty slot of the list in this line
+            if (tbk_entry_match(v, e)) return true;
+        }
+        if (!((line[tbk_eslot_at(half, 7)] >> 63) & 1ull)) return false;     // nothing went past this line
+        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+    }
+    return false;
+}
+
 // ---- synthetic key sequence (bench inputs) ---------------------------------
 // Key i of `seed` is a k-mer whose k-2 middle bases are a bijective scramble of i over
 // 2(k-2) bits (distinct i -> distinct k-mer) and whose end bases (b0, b_{k-1}) satisfy

@@ -36,6 +36,8 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, c
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_entry_contains(const uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -321,7 +323,8 @@ struct tbk_classifier {
     int replica_copies = 0;      // 1: this classifier's table is a copy made by tbk_classifier_replicate (hipMemcpyPeer), 0: built here or shared
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
-    uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line
+    uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line (entry layout: entries behind a two-slot front)
+    uint64_t entries_a = 0, entries_b = 0;  // entry layout (TBK_FLAG_ENTRY): slots the lists' keys take (a run of overlapping keys is one entry)
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
     hipStream_t compute = nullptr, copy = nullptr, out = nullptr;  // kernels; H2D of the next batch; D2H of finished counts
@@ -1073,6 +1076,41 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
     return TBK_OK;
 }
 
+// The paired table in entry layout (tbk_common.h "entry layout"): lines of 128 bytes, EMPTY = 0, hapA's list first, then
+// hapB's minus the keys hapA holds (tbk_entry_insert_kernel looks them up in hapA's finished half).
+static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets) {
+    c->n_buckets = n_buckets;
+    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    hipError_t e = c->alloc_pair(bytes);
+    if (e == hipSuccess) e = hipMemset(c->d_pair, 0, bytes);
+    unsigned long long *d_cnt = nullptr, cnt[2][8];
+    int *d_failed = nullptr, failed = 0;
+    memset(cnt, 0, sizeof cnt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof cnt[0]);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
+    for (int list = 0; list < 2 && e == hipSuccess; list++) {
+        const tbk_table *t = list ? b : a;
+        e = hipMemset(d_cnt, 0, sizeof cnt[0]);
+        if (e == hipSuccess) e = tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished half)
+    }
+    if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_failed) (void)hipFree(d_failed);
+    if (e != hipSuccess || failed) {
+        c->free_pair();
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table in entry layout (%zu bytes): %s", bytes, hipGetErrorString(e));
+        return fail(TBK_ERR_HIP, "table insert overflowed (table full)");
+    }
+    c->distinct_a = cnt[0][0]; c->distinct_b = cnt[1][0];
+    c->shared = cnt[1][1];
+    c->entries_a = cnt[0][2]; c->entries_b = cnt[1][2];
+    c->behind_front = cnt[0][3] + cnt[1][3];
+    c->past_half = cnt[0][4] + cnt[1][4];
+    return TBK_OK;
+}
+
 extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -1131,6 +1169,52 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
             }
         return tbk_mz_params(c->k, 6, n_big, m_force, pin != 0);
     };
+    // The entry layout: a span of 6 m-mers where k leaves room for the flanks in an entry's 30 bits (k = 21 .. 23), shorter
+    // spans up to k = 25.  Its table is sized by the ENTRIES, which are known only once it is built: the first build guesses
+    // four keys per entry (what runs around SNPs give at w = 6), a second one follows when that was off by more than a
+    // quarter.  TBK_ENTRY_LOAD: entries per list and bucket (default 0.32: fronts of two slots overflow in 0.4 % of the
+    // buckets; the haplotype-shaped lists of the bench: 2 x 3e8 keys = 1.4e8 entries in 29 GB, 48 bytes per key).
+    const double entry_pin = env_double("TBK_ENTRY", -1);
+    auto try_entry_layout = [&](bool forced) -> bool {
+        if (pin == 0 || w_pin == 0 || c->k > 32) return false;
+        TbkMz z{0, 0, 0, 0};
+        TbkEntryGeom g;
+        bool ok = false;
+        for (int w = (w_pin > 0 ? w_pin : 6); w >= (w_pin > 0 ? w_pin : 4) && !ok; w--) {
+            z = tbk_mz_params(c->k, w, n_big, m_force, 1);
+            ok = z.w == w && tbk_entry_geom(c->k, z, &g);
+        }
+        if (!ok) return false;
+        const TbkMz keep_mz = c->mz;
+        const uint32_t keep_flags = c->guests;
+        const double el = std::min(2.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.32)));
+        c->mz = z;
+        c->guests = TBK_FLAG_ENTRY;
+        double want = (double)n_big / (4.0 * el);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            uint64_t nb = (uint64_t)want + 16;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) nb = std::min<uint64_t>(nb, (uint64_t)(0.6 * (double)total_b / 128.0)); else (void)hipGetLastError();
+            if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;  // (bits 30 and 31 of a bucket index are flags in the probe's queues)
+            c->free_pair();
+            if (build_entry_table(c, a, b, (uint32_t)nb)) { c->mz = keep_mz; c->guests = keep_flags; return false; }
+            const double target = (double)std::max<uint64_t>(std::max(c->entries_a, c->entries_b), 1) / el;
+            if ((double)nb >= 0.8 * target && (double)nb <= 1.25 * target) break;
+            if (attempt == 0 && (uint64_t)target + 16 == nb) break;
+            want = target;
+        }
+        const double ratio = (double)(c->distinct_a + c->distinct_b) / (double)std::max<uint64_t>(1, c->entries_a + c->entries_b);
+        if (!forced && ratio < env_double("TBK_ENTRY_MIN_RATIO", 1.5)) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
+        return true;
+    };
+    if (entry_pin > 0 && try_entry_layout(true)) {
+        c->layout_builds = 1;
+        c->own_pair();
+        rc = classifier_streams(c);
+        if (rc) { tbk_classifier_destroy(c); return rc; }
+        *out = c;
+        return TBK_OK;
+    }
     bool front = front_pin != 0;
     for (;;) {
         c->mz = span_for(front);
@@ -1144,6 +1228,11 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
         if (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05))) break;
+        // Clustered lists.  Lists shaped like real find-unique-kmers output cluster because they ARE runs of overlapping
+        // k-mers: the entry layout stores a run once (tbk_common.h), which brings them back to a front - two slots per
+        // list, asked for by two lanes - in a table a quarter of the size.  Kept when the lists really merge (at least 1.5
+        // keys per entry); lists that cluster for another reason go to whole lines, as before.  TBK_ENTRY=0: never.
+        if (entry_pin != 0 && try_entry_layout(false)) { c->layout_builds++; break; }
         front = false;  // clustered lists, or too many keys behind the fronts: whole lines
     }
     c->own_pair();
@@ -1171,6 +1260,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->slice_bases = src->slice_bases;
     c->guests = src->guests;
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
+    c->entries_a = src->entries_a; c->entries_b = src->entries_b;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     // TBK_FORCE_REPLICA=1: a ring on the device that holds the table gets a full replica of its own all the same,
     // made by the very calls a second GPU's replica is made by (peer query, hipMemcpyPeer) - how a one-GPU box
@@ -1270,6 +1360,14 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
     if (front) *front = (c->guests & TBK_FLAG_FRONT) ? 1 : 0;
     if (keys_behind_front) *keys_behind_front = c->behind_front;
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_ENTRY) ? 1 : 0;
+    if (entries_a) *entries_a = c->entries_a;
+    if (entries_b) *entries_b = c->entries_b;
     return TBK_OK;
 }
 

@@ -149,6 +149,101 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
     if (back) atomicAdd(n_past + 1, back);
 }
 
+// Entry layout (tbk_common.h): one list key per thread, stored through each of its forms - one per position that
+// attains the smallest t-mer rank (as in tbk_insert_kernel), two where the sampled m-mer is its own reverse complement.
+// A form joins the first entry of its list, along its m-mer's bucket sequence, whose flanks agree with its own
+// (a 64-bit CAS that adds the form's flank bits and its V bit), or takes the first empty slot.  Entries only ever gain
+// bits, so "compatible" can only turn into "incompatible" while a thread looks, never back: a key is stored exactly once
+// per form however the threads interleave.  Bit 63 of a list's front slot 1 / of its slot 7 is set when an entry is
+// created behind the front / when a form leaves the line.  List lines that are not canonical are dead in the reference
+// (stored verbatim, c/kmers.c:113; looked up as min(fwd, rc), c/kmers.c:255) and are not stored.
+// cnt: [0] keys stored, [1] hapB keys left out because hapA holds them, [2] entries created, [3] of those behind a
+// front, [4] forms that left a line.
+__global__ void __launch_bounds__(256)
+tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
+                        const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const unsigned long long FLAG64 = (unsigned long long)TBK_ENTRY_FLAG << 32;
+    unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
+    const int n_pos = 2 * mz.w;
+    for (; i < n; i += step) {
+        const uint64_t key = keys[i];
+        if (key >= TBK_NOKEY) continue;
+        if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
+        uint32_t best = 0xFFFFFFFFu;
+        for (int pi = 0; pi < n_pos; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); best = r < best ? r : best; }
+        bool first_form = true, drop = false;
+        for (int pi = 0; pi < n_pos && !drop; pi++) {
+            if (tbk_tmer_rank(key, mz, pi) != best) continue;
+            TbkEntryKey forms[2];
+            const int nf = tbk_entry_orientations(key, k, mz, g, pi % mz.w, forms);
+            for (int f = 0; f < nf; f++) {
+                const TbkEntryKey e = forms[f];
+                if (first_form && skip_a && tbk_entry_lookup_one(slots, n_buckets, 0, e)) { skipped++; drop = true; break; }  // (hapA's half is finished)
+                const unsigned long long entry = (unsigned long long)e.cm | ((unsigned long long)e.khi << 32);
+                uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+                bool done = false;
+                for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
+                    unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
+                    for (uint32_t sl = 0; sl < 8 && !done; sl++) {
+                        unsigned long long *slot = &line[tbk_eslot_at(half, sl)];
+                        unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (;;) {
+                            if ((cur & ~FLAG64) == 0) {  // empty: mine, unless somebody is quicker
+                                const unsigned long long old = atomicCAS(slot, cur, cur | entry);
+                                if (old == cur) {
+                                    created++; stored += first_form; done = true;
+                                    if (sl >= 2) { behind++; atomicOr(&line[tbk_eslot_at(half, 1)], FLAG64); }
+                                    break;
+                                }
+                                cur = old;
+                                continue;
+                            }
+                            if (!tbk_entry_compatible(cur, e, mz, g)) break;  // (stays incompatible: entries only gain bits) - next slot
+                            if (tbk_entry_match(cur, e)) { done = true; break; }  // a duplicate line, or this key's other tied position naming the same m-mer and place
+                            const unsigned long long old = atomicCAS(slot, cur, cur | ((unsigned long long)e.khi << 32));
+                            if (old == cur) { stored += first_form; done = true; break; }
+                            cur = old;
+                        }
+                    }
+                    if (!done) {
+                        atomicOr(&line[tbk_eslot_at(half, 7)], FLAG64);
+                        past++;
+                        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+                    }
+                }
+                if (!done) atomicExch(failed, 1);
+                first_form = false;
+            }
+        }
+    }
+    if (stored) atomicAdd(&cnt[0], stored);
+    if (skipped) atomicAdd(&cnt[1], skipped);
+    if (created) atomicAdd(&cnt[2], created);
+    if (behind) atomicAdd(&cnt[3], behind);
+    if (past) atomicAdd(&cnt[4], past);
+}
+
+// raw-key membership in a finished entry-layout table (tests; tbk_count_kmers_in_read never uses it)
+__global__ void __launch_bounds__(256)
+tbk_entry_contains_kernel(const uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
+                          const uint64_t *__restrict__ keys, uint64_t n, uint8_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    bool in = false;
+    if (key < TBK_NOKEY && !(tbk_revcomp_packed(key, k) < key)) {
+        uint32_t best = 0xFFFFFFFFu;
+        int at = 0;
+        for (int pi = 0; pi < 2 * mz.w; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); if (r < best) { best = r; at = pi; } }
+        TbkEntryKey forms[2];
+        (void)tbk_entry_orientations(key, k, mz, g, at % mz.w, forms);
+        in = tbk_entry_lookup_one(slots, n_buckets, half, forms[0]);
+    }
+    out[i] = in ? 1 : 0;
+}
+
 // After all inserts: give every full half the order of its last two slots that says whether a key
 // went past it (slot 6 > slot 7) or not (slot 6 < slot 7), and - tables with guests - the order of
 // slots 4 and 5 that says whether one of those keys left the line (slot 4 > slot 5).  One thread per half.
@@ -1063,6 +1158,390 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
     }
 }
 
+// =======================================================================================
+// probe, entry layout (tbk_common.h "entry layout")
+// =======================================================================================
+// The pass of the key layouts with three differences.  (1) A window asks with (canonical m-mer, flank bits, mask)
+// instead of its canonical k-mer: the orientation is the sampled m-mer's, which the sampling arithmetic has at hand.
+// (2) The probe is PAIR-cooperative: the front of a line is 32 bytes [A0 A1 | B0 B1], lane 0 of a pair holds hapA's two
+// front slots, lane 1 hapB's, and a window step has two sub-steps instead of four - half the broadcasts, compares and
+// scalar ballot work of the quad probe, and 8 registers of line data per lane instead of 16.  One wave instruction
+// touches 32 lines.  (3) A slot is compared under the window's mask: expected = (m-mer, bfi(mask, flanks, slot.hi)),
+// one v_bfi and one 64-bit compare.  Flags are bits (bit 63 of a list's second front slot: entries behind the front).
+// A window that misses in a front with entries behind it is queued; drain_back_entry settles eight at a time from the
+// line's other 96 bytes (six lanes x 16 bytes, an L2 hit), and only a list whose eight slots are full and were left by
+// an entry (bit 63 of its slot 7) sends the window on to the walk.
+template <int S>
+__device__ __forceinline__ uint32_t pair_bcast(uint32_t v) {
+    // DPP quad_perm:[S, S, 2 + S, 2 + S]: lane S of each pair
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6), 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint64_t pair_any(uint64_t m) { return (m | (m >> 1)) & 0x5555555555555555ull; }
+
+// walk queue entry: x = m-mer, y = flank bits + V bit, z = home bucket, w = list (0 hapA, 1 hapB) | read << 1
+// back queue entry: x = m-mer, y = flank bits + V bit, z = home bucket | hapA has entries behind its front << 30 | hapB << 31, w = read
+__device__ __forceinline__ TbkEntryKey entry_key_of(uint32_t cm, uint32_t khi, int w, int fbits, int vshift) {
+    const uint32_t v = khi >> vshift;                         // exactly one V bit
+    const int pos = 31 - (int)__clz(v);
+    TbkEntryKey e;
+    e.cm = cm; e.khi = khi;
+    e.mhi = (((1u << fbits) - 1u) << (2 * (w - 1 - pos))) | (1u << (vshift + pos));
+    return e;
+}
+
+__device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, TbkEntryKey e, uint32_t bucket, bool pend) {
+    bool found = false, first = true;
+    uint32_t guard = 0;
+    while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
+        if (pend) {
+            bucket = tbk_entry_next_bucket(e.cm, t.n_buckets, bucket, first);
+            first = false;
+            const uint64_t *line = t.slots + (uint64_t)bucket * 16;
+            bool hit = false, ended = false;
+            uint64_t last = 0;
+#pragma unroll 1
+            for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + tbk_eslot_at(half, sl));
+                hit = hit || tbk_entry_match(v.x, e) || tbk_entry_match(v.y, e);
+                ended = (v.y << 1) == 0;  // an empty slot: the list ends in this line
+                last = v.y;
+            }
+            found = found || hit;
+            pend = !hit && !ended && (last >> 63) != 0;  // all eight taken and an entry went past them
+        }
+    }
+    return found;
+}
+
+template <bool MULTI>
+__device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint4 *q, uint32_t qn, uint64_t r_first, uint32_t lane,
+                                                  int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+    for (uint32_t base = 0; base < qn; base += 64) {
+        const bool act = base + lane < qn;
+        uint4 it = make_uint4(0, 1u << vshift, 0, 0);
+        if (act) it = q[base + lane];
+        const bool found = walk_one_entry(p.t, (it.w & 1u) * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act);
+        const bool count_a = found && !(it.w & 1u), count_b = found && (it.w & 1u);
+        if (!MULTI) {
+            acc_a += (uint32_t)__popcll(ballot(count_a));
+            acc_b += (uint32_t)__popcll(ballot(count_b));
+        } else {
+            if (count_a) count_hits(p, rcnt, r_first, it.w >> 1, 0, 1);
+            if (count_b) count_hits(p, rcnt, r_first, it.w >> 1, 1, 1);
+        }
+    }
+}
+
+// eight queued windows at a time, eight lanes per window: lanes 0..2 hold hapA's slots 2..7 of the home line, lanes 3..5
+// hapB's (16 bytes each, the line's bytes 32..127), lanes 6 and 7 nothing
+template <bool MULTI>
+__device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, uint32_t qb, uint4 *walkq, uint32_t &qn, uint64_t r_first,
+                                                 uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+    const uint32_t sub = lane & 7u, oct = lane >> 3;
+    for (uint32_t base = 0; base < qb; base += 8) {
+        const bool act = base + oct < qb;
+        uint4 it = make_uint4(0, 1u << vshift, 0, 0);
+        ulonglong2 v = make_ulonglong2(0, 0);
+        if (act) {
+            it = bq[base + oct];
+            if (sub < 6) v = load_slots(p.t.slots + (uint64_t)(it.z & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
+        }
+        const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
+        const uint64_t hit = ballot(tbk_entry_match(v.x, e)) | ballot(tbk_entry_match(v.y, e));
+        const uint64_t hit_a = hit & 0x0707070707070707ull, hit_b = hit & 0x3838383838383838ull;
+        // lane 2 holds hapA's slot 7 in .y, lane 5 hapB's: bit 63 = an entry of the list went past this line
+        const uint64_t gone = ballot((v.y >> 63) != 0);
+        const uint64_t any = hit_a | hit_b;
+        const uint64_t oct_hit = (any | (any >> 1) | (any >> 2) | (any >> 3) | (any >> 4) | (any >> 5)) & 0x0101010101010101ull;
+        const uint64_t walk_a = ((gone >> 2) & 0x0101010101010101ull) & ~oct_hit, walk_b = ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit;
+        if (!MULTI) {
+            acc_a += (uint32_t)__popcll(hit_a);
+            acc_b += (uint32_t)__popcll(hit_b);
+        } else {
+            if ((hit_a >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w, 0, 1);
+            if ((hit_b >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w, 1, 1);
+        }
+        const uint64_t queued = walk_a | walk_b;
+        if (queued) {
+            const uint64_t me = 1ull << lane;
+            const uint32_t n_a = (uint32_t)__popcll(walk_a);
+            if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w << 1);
+            if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, (it.w << 1) | 1u);
+            qn += n_a + (uint32_t)__popcll(walk_b);
+            if (qn > TBK_QCAP_FRONT - 16) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                drain_walks_entry<MULTI>(p, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                qn = 0;
+            }
+        }
+    }
+}
+
+template <int W, bool MULTI, bool TWO>
+__device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint64_t e0, const uint64_t e1, const uint64_t e2, const uint64_t e3,
+                                                 const uint64_t P0, const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
+                                                 uint4 *walkq, uint4 *backq, uint32_t *rcnt) {
+    const int k = p.k;
+    const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t sub = lane & 1u;
+    // streams, read ends and the odd lanes' downward walk: as in probe_pass
+    unsigned __int128 S128 = (unsigned __int128)(uint32_t)e0 | ((unsigned __int128)(uint32_t)e1 << 32) |
+                             ((unsigned __int128)(uint32_t)e2 << 64) | ((unsigned __int128)(uint32_t)e3 << 96);
+    unsigned __int128 R128 = (unsigned __int128)rev_pairs(~(uint32_t)e3) | ((unsigned __int128)rev_pairs(~(uint32_t)e2) << 32) |
+                             ((unsigned __int128)rev_pairs(~(uint32_t)e1) << 64) | ((unsigned __int128)rev_pairs(~(uint32_t)e0) << 96);
+    uint64_t bad64 = (uint64_t)((uint32_t)(e0 >> 32) | ((uint32_t)(e1 >> 32) << 16)) |
+                     ((uint64_t)((uint32_t)(e2 >> 32) | ((uint32_t)(e3 >> 32) << 16)) << 32);
+    bool is_second = false, is_strad = false;
+    if (TWO) {
+        const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
+        const uint64_t r2_end = p.offsets[r_first + 2];
+        is_second = p_first >= r_first_end;
+        const uint64_t inside = is_second ? 64 : r_first_end - p_first;
+        is_strad = inside < TBK_WPL;
+        if (is_second || is_strad) {
+            const uint64_t inside2 = r2_end > p_first ? r2_end - p_first : 0;
+            if (inside2 < 64) bad64 |= ~0ull << inside2;
+        } else if (inside < 64) {
+            bad64 |= ~0ull << inside;
+        }
+    }
+    if (!MULTI) {
+        if (!TWO) {
+            const uint64_t p_first = P0 + (uint64_t)lane * TBK_WPL;
+            const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;
+            if (inside < 64) bad64 |= ~0ull << inside;
+        }
+        if ((lane & 1u) && !(TWO && is_strad)) {
+            const int sh = 33 - k;
+            const unsigned __int128 s_up = R128 >> (2 * sh), r_up = S128 << (2 * sh);
+            S128 = s_up; R128 = r_up;
+            bad64 = __brevll(bad64) >> sh;
+        }
+    }
+    uint32_t s0 = (uint32_t)S128, s1 = (uint32_t)(S128 >> 32), s2 = (uint32_t)(S128 >> 64), s3 = (uint32_t)(S128 >> 96);
+    uint32_t t0, t1, t2, t3;
+    {
+        const unsigned __int128 Rs = R128 >> (64 - 2 * k);
+        t0 = (uint32_t)Rs; t1 = (uint32_t)(Rs >> 32); t2 = (uint32_t)(Rs >> 64); t3 = (uint32_t)(Rs >> 96);
+    }
+    uint32_t bad_lo = (uint32_t)bad64, bad_hi = (uint32_t)(bad64 >> 32);
+    const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+
+    // mod-sampling state (probe_pass, SAMP): ranks of the span's 2W t-mers, tagged with their stream index mod 16
+    constexpr int NW = 2 * W;
+    uint32_t win[NW];
+    const int m = p.t.mz.m, o = p.t.mz.o, tlen = p.t.mz.t;
+    const uint32_t span_o = (uint32_t)o;
+    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const uint32_t tmask = tlen >= 16 ? 0xFFFFFFFFu : ((1u << (2 * tlen)) - 1u);
+    auto tmer_rank = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh, uint32_t pos) -> uint32_t {
+        const uint32_t x = (uint32_t)(fwd64 >> fsh) & tmask, y = (uint32_t)(rc64 >> bsh) & tmask;
+        return (tbk_mmer_hash(x < y ? x : y) & ~15u) | pos;
+    };
+    {
+        const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
+        win[0] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i + 1 < NW; i++) win[i + 1] = tmer_rank(fs, bs, (uint32_t)(2 * (o + i)), (uint32_t)(2 * (o + NW - 1 - i)), (uint32_t)i);
+    }
+    const uint32_t fsh_new = (uint32_t)(2 * (o + NW - 1)), bsh_new = (uint32_t)(2 * o);
+    // entry geometry
+    const int fl = o + W - 1, fbits = 2 * (k - m), vshift = 4 * fl;
+    const uint32_t fmask = (1u << fbits) - 1u;
+
+    // read bookkeeping (probe_pass)
+    const uint64_t p_lane = P0 + (uint64_t)lane * TBK_WPL;
+    uint64_t rid = r_first;
+    uint64_t rend = r_first_end;
+    if (MULTI) {
+        const uint64_t pl = p_lane < p.total ? p_lane : p.total;
+        uint64_t lo = r_first, step = 1;
+        while (lo + step <= p.n_reads && p.offsets[lo + step] <= pl) { lo += step; step <<= 1; }
+        uint64_t hi = lo + step <= p.n_reads ? lo + step : p.n_reads + 1;
+        while (hi - lo > 1) {
+            const uint64_t mid = lo + ((hi - lo) >> 1);
+            if (p.offsets[mid] <= pl) lo = mid; else hi = mid;
+        }
+        rid = lo;
+        rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
+    }
+    auto rel = [&](uint64_t pos) -> uint32_t {
+        return pos > p_lane ? (uint32_t)(pos - p_lane < 0x40000000ull ? pos - p_lane : 0x40000000ull) : 0u;
+    };
+    uint32_t rel_end = rel(rend);
+    uint32_t acc_a = 0, acc_b = 0, lane_a = 0, lane_b = 0, acc2_a = 0, acc2_b = 0;
+    uint64_t own1[2] = {0, 0};   // TWO: per sub-step the lanes (both of a pair) whose pair's window belongs to the pass's first read
+    uint32_t jb_s = 0xFFFFu;
+    if (TWO) {
+        const uint32_t brel = (uint32_t)(r_first_end - P0);
+        if (brel % TBK_WPL) jb_s = brel % TBK_WPL;
+#pragma unroll
+        for (int s = 0; s < 2; s++) own1[s] = ballot(((lane & ~1u) + (uint32_t)s) * TBK_WPL < brel);
+    }
+    ulonglong2 va[2];
+    va[0] = make_ulonglong2(0, 0); va[1] = make_ulonglong2(0, 0);
+    uint32_t last_bk = 0x7FFFFFFFu;
+    uint32_t qn = 0, qb = 0;
+
+#pragma unroll TBK_SAMP_UNROLL
+    for (int j = 0; j < TBK_WPL; j++) {
+        const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
+        if (MULTI) {
+            while ((uint32_t)j >= rel_end && rid < p.n_reads) {
+                if (lane_a) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a); lane_a = 0; }
+                if (lane_b) { count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b); lane_b = 0; }
+                rid++;
+                rend = rid < p.n_reads ? p.offsets[rid + 1] : p.total;
+                rel_end = rel(rend);
+            }
+        }
+        if (TWO && (uint32_t)j == jb_s) {
+            const uint64_t strad = ballot(is_strad);  // one lane: its pair changes sides in the sub-step that lane owns
+#pragma unroll
+            for (int s = 0; s < 2; s++) if (strad & (0x5555555555555555ull << s)) own1[s] &= ~(pair_any(strad) * 3ull);  // (both bits of that pair)
+        }
+        bool ok = (bad_lo & badk) == 0;
+        if (TWO) {
+            const bool cross = (uint32_t)j < jb_s && (uint32_t)(j + k) > jb_s;
+            ok = ok && !(cross && is_strad);
+        }
+        if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
+        // ---- sampling: newest t-mer in, smallest rank, its position, the m-mer there on both strands ----
+#pragma unroll
+        for (int i = 0; i + 1 < NW; i++) win[i] = win[i + 1];
+        win[NW - 1] = tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(j + NW - 1) & 15u);
+        uint32_t best = win[0];
+#pragma unroll
+        for (int i = 1; i < NW; i++) best = win[i] < best ? win[i] : best;
+        const uint32_t x = (best - (uint32_t)j) & 15u;
+        const uint32_t pos = x >= (uint32_t)W ? x - (uint32_t)W : x;
+        const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
+        const uint32_t mx = (uint32_t)(fs >> fsh) & mmask, my = (uint32_t)(bs >> bsh) & mmask;
+        const bool fw_or = mx < my;                       // the m-mer is canonical as the forward strand reads it
+        const uint32_t cm = fw_or ? mx : my;
+        const uint32_t bkt = tbk_reduce(tbk_mmer_hash(cm), p.t.n_buckets);
+        // ---- what this window asks an entry (tbk_entry_key): the k-mer in the m-mer's orientation, cut around the m-mer ----
+        const uint64_t orient = (fw_or ? fs : bs) & kmask;
+        const uint32_t a = fw_or ? fsh : bsh;             // 2 (o + pos'), pos' = the m-mer's position as `orient` reads
+        const uint32_t low = (uint32_t)orient & ((1u << a) - 1u);
+        const uint32_t high = (uint32_t)(orient >> (a + 2u * (uint32_t)m));
+        const uint32_t posp = (a >> 1) - span_o;
+        const uint32_t shw = 2u * ((uint32_t)W - 1u - posp);
+        const uint32_t vbit = 1u << ((uint32_t)vshift + posp);
+        const uint32_t my_khi = ok ? (((low | (high << a)) << shw) | vbit) : TBK_ENTRY_NEVER;
+        const uint32_t my_mhi = ok ? ((fmask << shw) | vbit) : TBK_ENTRY_NEVER;
+        const bool fresh = ok && bkt != last_bk;
+        const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
+        last_bk = my_bk & 0x7FFFFFFFu;
+        const uint32_t my_rid = (uint32_t)rid;
+        auto two_rid = [&]() -> uint32_t { return (is_second || (is_strad && (uint32_t)j >= jb_s)) ? 1u : 0u; };
+
+        // advance to window j + 1
+        s0 = (s0 >> 2) | (s1 << 30); s1 = (s1 >> 2) | (s2 << 30); s2 = (s2 >> 2) | (s3 << 30); s3 >>= 2;
+        t3 = (t3 << 2) | (t2 >> 30); t2 = (t2 << 2) | (t1 >> 30); t1 = (t1 << 2) | (t0 >> 30); t0 <<= 2;
+        bad_lo = (bad_lo >> 1) | (bad_hi << 31); bad_hi >>= 1;
+
+        // ---- two pair sub-steps ----
+        const uint32_t bk0 = pair_bcast<0>(my_bk), bk1 = pair_bcast<1>(my_bk);
+        if ((int32_t)bk0 < 0) va[0] = load_slots(p.t.slots + (uint64_t)(bk0 & 0x7FFFFFFFu) * 16 + sub * 2);
+        if ((int32_t)bk1 < 0) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
+        const uint32_t cm_s[2] = {pair_bcast<0>(cm), pair_bcast<1>(cm)};
+        const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
+        const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
+        uint64_t hit[2], more[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint32_t hx = (uint32_t)(va[s].x >> 32), hy = (uint32_t)(va[s].y >> 32);
+            const uint64_t wx = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hx & ~mh_s[s])) << 32);
+            const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
+            hit[s] = ballot(va[s].x == wx) | ballot(va[s].y == wy);
+            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front slot 1: entries behind the front
+        }
+        if ((more[0] | more[1]) != 0) {
+            // windows that missed in a front with entries behind it: queued by the lane that owns the window
+            uint64_t need = 0, beh_a = 0, beh_b = 0;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (more[s] == 0) continue;
+                const uint64_t ma = more[s] & 0x5555555555555555ull, mb = (more[s] >> 1) & 0x5555555555555555ull;
+                need |= ((ma | mb) & ~pair_any(hit[s])) << s;
+                beh_a |= ma << s;
+                beh_b |= mb << s;
+            }
+            need &= ballot(ok);
+            if (need) {
+                const uint64_t me = 1ull << lane;
+                if (need & me) {
+                    const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : TWO ? two_rid() : 0u;
+                    backq[qb + (uint32_t)__popcll(need & (me - 1))] =
+                        make_uint4(cm, my_khi, last_bk | ((uint32_t)((beh_a >> lane) & 1ull) << 30) | ((uint32_t)((beh_b >> lane) & 1ull) << 31), rrel);
+                }
+                qb += (uint32_t)__popcll(need);
+            }
+        }
+        if ((hit[0] | hit[1]) != 0) {
+            if (TWO) {
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const uint64_t h1 = hit[s] & own1[s], h2 = hit[s] & ~own1[s];
+                    acc_a += (uint32_t)__popcll(h1 & 0x5555555555555555ull);
+                    acc_b += (uint32_t)__popcll(h1 & 0xAAAAAAAAAAAAAAAAull);
+                    acc2_a += (uint32_t)__popcll(h2 & 0x5555555555555555ull);
+                    acc2_b += (uint32_t)__popcll(h2 & 0xAAAAAAAAAAAAAAAAull);
+                }
+            } else if (!MULTI) {
+                acc_a += (uint32_t)__popcll((hit[0] & 0x5555555555555555ull)) + (uint32_t)__popcll((hit[1] & 0x5555555555555555ull));
+                acc_b += (uint32_t)__popcll((hit[0] & 0xAAAAAAAAAAAAAAAAull)) + (uint32_t)__popcll((hit[1] & 0xAAAAAAAAAAAAAAAAull));
+            } else {
+                const uint64_t wa = (hit[0] & 0x5555555555555555ull) | ((hit[1] & 0x5555555555555555ull) << 1);
+                const uint64_t wb = ((hit[0] >> 1) & 0x5555555555555555ull) | (hit[1] & 0xAAAAAAAAAAAAAAAAull);
+                lane_a += (uint32_t)(wa >> lane) & 1u;
+                lane_b += (uint32_t)(wb >> lane) & 1u;
+            }
+        }
+        if (qb > TBK_BQCAP - 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            drain_back_entry<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qb = 0;
+        }
+    }
+    if (qb) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        drain_back_entry<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (qn) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        drain_walks_entry<MULTI || TWO>(p, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (MULTI) {
+        if (lane_a) count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 0, lane_a);
+        if (lane_b) count_hits(p, rcnt, r_first, (uint32_t)(rid - r_first), 1, lane_b);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t ca = rcnt[2 * lane], cb = rcnt[2 * lane + 1];
+        if (ca) { atomicAdd(&p.counts[2 * (r_first + lane)], (int)ca); rcnt[2 * lane] = 0; }
+        if (cb) { atomicAdd(&p.counts[2 * (r_first + lane) + 1], (int)cb); rcnt[2 * lane + 1] = 0; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (TWO) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < 4) {
+            const uint32_t c = rcnt[lane] + (lane == 0 ? acc_a : lane == 1 ? acc_b : lane == 2 ? acc2_a : acc2_b);
+            if (c) atomicAdd(&p.counts[2 * r_first + lane], (int)c);
+            rcnt[lane] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (!MULTI) {
+        if (lane == 0) {
+            if (acc_a) atomicAdd(&p.counts[2 * r_first], (int)acc_a);
+            if (acc_b) atomicAdd(&p.counts[2 * r_first + 1], (int)acc_b);
+        }
+    }
+}
+
 // Which read contains the first position of each pass (one thread per pass): keeps the
 // binary search over the offsets out of the probe kernels' waves.  Passes that touch more than one
 // read are listed for the multi-read kernel (*n_multi is zeroed by the launcher).
@@ -1177,9 +1656,74 @@ tbk_probe_kernel(const ProbeArgs p) {
     }
 }
 
+// The entry layout's probe kernels: the same three (single-read, two-read, multi-read passes) over probe_pass_entry.
+template <int W, bool MULTI, bool TWO = false>
+__global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
+tbk_probe_entry_kernel(const ProbeArgs p) {
+    __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
+    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP_FRONT];
+    __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][TBK_BQCAP];
+    __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t per_iter = (uint64_t)gridDim.x * TBK_WAVES_PER_BLOCK;
+    if (MULTI) { rcnt[wave][lane] = 0; rcnt[wave][64 + lane] = 0; }
+    if (TWO && lane < 4) rcnt[wave][lane] = 0;
+    const uint64_t n_work = MULTI ? (uint64_t)*p.n_multi : TWO ? (uint64_t)*p.n_two : p.pass_hi - p.pass_lo;
+    for (uint64_t item = (uint64_t)blockIdx.x * TBK_WAVES_PER_BLOCK + wave; item < n_work; item += per_iter) {
+        const uint64_t two_entry = TWO ? p.two_list[item] : 0;
+        const uint64_t pass = MULTI ? (uint64_t)p.multi_list[item] : TWO ? (two_entry & 0xFFFFFFFFull) : p.pass_lo + item;
+        if (MULTI && (pass < p.pass_lo || pass >= p.pass_hi)) continue;
+        if (TWO && (pass < p.pass_lo || pass >= p.pass_hi)) return;
+        const uint64_t P0 = pass * TBK_PASS;
+        const uint64_t r_first = TWO ? (two_entry >> 32) : (uint64_t)p.pass_read[pass];
+        const uint64_t r_end = r_first < p.n_reads ? p.offsets[r_first + 1] : p.total;
+        if (!MULTI && !TWO) {
+            const uint64_t last_pos = (P0 + TBK_PASS - 1 < p.total ? P0 + TBK_PASS - 1 : p.total - 1);
+            if (last_pos >= r_end) return;  // the multi-read or the two-read kernel's
+        }
+        if (p.codes != nullptr) {
+            const uint64_t c0 = P0 / 16 + lane;
+            stage[wave][lane] = load_packed_chunk(p.codes, p.bad16, c0, p.n_chunks);
+            stage[wave][64 + lane] = load_packed_chunk(p.codes, p.bad16, c0 + 64, p.n_chunks);
+            if (lane < 2) stage[wave][128 + lane] = load_packed_chunk(p.codes, p.bad16, c0 + 128, p.n_chunks);
+        } else {
+            stage[wave][lane] = load_chunk(p.bases, P0 + (uint64_t)lane * 16, p.total);
+            stage[wave][64 + lane] = load_chunk(p.bases, P0 + (uint64_t)(64 + lane) * 16, p.total);
+            if (lane < 2) stage[wave][128 + lane] = load_chunk(p.bases, P0 + (uint64_t)(128 + lane) * 16, p.total);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
+                       e3 = stage[wave][2 * lane + 3];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        probe_pass_entry<W, MULTI, TWO>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave]);
+        if (!MULTI) return;  // one pass per block
+    }
+}
+
 // =======================================================================================
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
+extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
+                                              int skip_a, unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+    TbkEntryGeom g;
+    if (!tbk_entry_geom(k, mz, &g)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(tbk_entry_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_entry_contains(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
+                                                uint8_t *d_out, hipStream_t stream) {
+    TbkEntryGeom g;
+    if (!tbk_entry_geom(k, mz, &g)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tbk_entry_contains_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, d_out);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
                                         const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, uint32_t *d_left_line, uint32_t guests, TbkTableView skip,
                                         unsigned long long *d_distinct, unsigned long long *d_skipped, int *d_failed,
@@ -1291,8 +1835,12 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     const dim3 grid((unsigned)blocks), grid_multi((unsigned)blocks_multi), block(64 * TBK_WAVES_PER_BLOCK);
     // kernel variant: W m-mers per span; 32-bit (m <= 16) or 64-bit m-mers; random-minimizer or
     // mod-sampling selection; front or whole-line layout
-    const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0;
+    const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0, entry = (t.guests & TBK_FLAG_ENTRY) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
+    if (entry) {
+        TbkEntryGeom g;
+        if (!tbk_entry_geom(k, t.mz, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
+    }
     // the two-read kernel: one block per possible list entry (fewer two-read passes than reads, and than passes)
     const uint64_t blocks_two = tbk_probe_has_two_read_kernel(t.mz) ? std::min<uint64_t>(n_reads > 1 ? n_reads - 1 : 0, p.n_passes) : 0;  // (the list is the whole batch's: every launch walks all of it)
     const dim3 grid_two((unsigned)std::max<uint64_t>(1, blocks_two));
@@ -1308,6 +1856,23 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
                          else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
+        if (entry) {
+#define TBK_E(N) case N: if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true>), grid_multi, block, 0, stream, p); \
+                         else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false>), grid, block, 0, stream, p); \
+                         else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true>), grid_two, block, 0, stream, p); break;
+            switch (t.mz.w) {
+#ifdef TBK_ONLY_W6
+                TBK_E(6)
+#else
+                TBK_E(2) TBK_E(3) TBK_E(4) TBK_E(5) TBK_E(6) TBK_E(7)
+#endif
+                default: return hipErrorInvalidValue;
+            }
+#undef TBK_E
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            continue;
+        }
         switch (t.mz.w) {
 #ifdef TBK_ONLY_W6  // experiment builds (tools/build_variant.sh): the bench configuration's kernels only
             TBK_W(6)

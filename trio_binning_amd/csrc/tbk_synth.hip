@@ -356,7 +356,7 @@ extern "C" hipError_t tbk_launch_gather(const void *d_buf, uint64_t bytes, int l
 #define TBK_G(L, P, F) \
     if (line == L && lpl == P && inf == F) return launch_gather_t<L, P, F>(d_buf, bytes, n_lines, seed, d_sink, s);
 #define TBK_GF(L, P) TBK_G(L, P, 1) TBK_G(L, P, 2) TBK_G(L, P, 4) TBK_G(L, P, 8)
-    TBK_GF(64, 1) TBK_GF(64, 4) TBK_GF(128, 1) TBK_GF(128, 8) TBK_GF(128, 4)
+    TBK_GF(64, 1) TBK_GF(64, 4) TBK_GF(128, 1) TBK_GF(128, 8) TBK_GF(128, 4) TBK_GF(32, 2)  // (32, 2): two lanes x 16 bytes of a line, the pair-cooperative probe of the entry layout
 #undef TBK_GF
 #undef TBK_G
     return hipErrorInvalidValue;
