@@ -191,7 +191,7 @@ int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_beh
  * under the window's mask (replaces kmer_in_hash_set's compare, c/kmers.c:245-268; membership is the same).
  * entry_layout = 1 when the table that stands is laid out so; entries_a/_b = slots the lists' keys take.  Chosen
  * for clustered lists whose keys merge (>= TBK_ENTRY_MIN_RATIO, default 1.5, keys per entry) where k leaves room
- * (k <= 25, m <= 16); TBK_ENTRY=1 / 0 pins it, TBK_ENTRY_LOAD sets the entries per list and bucket (default 0.32). */
+ * (k <= 25, m <= 16); TBK_ENTRY=1 / 0 pins it, TBK_ENTRY_LOAD sets the entries per list and bucket (default 0.40). */
 int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b);
 /* Random 64-byte reads, a quad of lanes per line as the probe asks for a front, over this table where it lies
  * in HBM: lines per second (a diagnostic: the same table measures up to 15 % differently from one placement in

@@ -54,7 +54,10 @@ __global__ void __launch_bounds__(64) rate_kernel(uint64_t *out, int trips, uint
         if (OP == OP_CNDMASK) { V1("v_cndmask_b32 %0, %1, %0, vcc") }
         if (OP == OP_BCNT) { V1("v_bcnt_u32_b32 %0, %1, %0") }
         if (OP == OP_AND_OR) { V1("v_and_or_b32 %0, %1, %0, %2") }
-        if (OP == OP_MAD64) { W64("v_mad_u64_u32 %0, vcc, %1, %1, %0") }
+        if (OP == OP_MAD64) {  // (writes a carry: vcc is declared clobbered - undeclared, the loop around it never ended)
+            REP4(asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(a) : "v"(b32) : "vcc");, asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(b) : "v"(b32) : "vcc");,
+                 asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(c64) : "v"(b32) : "vcc");, asm volatile("v_mad_u64_u32 %0, vcc, %1, %1, %0" : "+v"(d64) : "v"(b32) : "vcc");)
+        }
         if (OP == OP_PERM) { V1("v_perm_b32 %0, %1, %0, %2") }
         if (OP == OP_FFBH) { V1("v_ffbh_u32 %0, %0") }
         if (OP == OP_XOR_SDWA) { V1("v_xor_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD") }
@@ -97,6 +100,7 @@ static double run(const char *name, uint64_t *d_out, double base) {
 }
 
 int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     if (argc > 1) g_waves = atoi(argv[1]);
     uint64_t *d_out;
     hipMalloc(&d_out, 64);

@@ -358,7 +358,6 @@ struct TbkPairView {
 //     hi word   bits [0, 2 FL)       left flank  - context bases 0 .. FL-1, the base next to the m-mer highest
 //               bits [2 FL, 4 FL)    right flank - context bases FL+m .. FL+m+FL-1
 //               bits [4 FL, +w)      V: bit p set = "the k-mer whose sampled m-mer sits at span position p is in the list"
-//               bit 30               always 0 (a window that may not match asks for a 1 there)
 //               bit 31               a flag of the slot's place in its line, no part of the entry (see tbk_eslot_at)
 // in the orientation in which the m-mer is canonical.  The k-mer at span position p is its m-mer plus the o + p bases
 // before it and the (w - 1 - p) + o bases after it: in the flank field those are the CONTIGUOUS 2 (k - m) bits from bit
@@ -367,12 +366,15 @@ struct TbkPairView {
 // bases at that place plus the bit V[p], and mhi covers exactly those bits: one v_bfi and one 64-bit compare per slot
 // (expected = (cm, bfi(mhi, khi, hi))).  Bases of an entry outside every valid window's extent are zero and never
 // looked at.  Keys of different loci that share an m-mer share an entry as long as their flanks agree where both define
-// them; otherwise they are separate entries of the bucket.  EMPTY is 0 (no V bit: matches nothing).
+// them; otherwise they are separate entries of the bucket.  EMPTY is 0 (no V bit: matches nothing).  A window that may
+// not match (a byte outside ACGT, a read end) asks for the m-mer 0xFFFFFFFF, which no entry holds: T x 16 is not
+// canonical (its reverse complement A x 16 = 0 is smaller), and shorter m-mers stay below it.
 // A variant's k-mers cost one slot per bucket instead of four to five: the haplotype-shaped lists of the bench shrink
 // from 6.0e8 keys to 1.4e8 entries, fronts of two slots per list hold them, and the probe asks for 32 bytes of a line
-// with two lanes per window.  Needs m <= 16 and 4 FL + w <= 30: k = 21 (w = 6), k = 22..25 with shorter spans.
+// with two lanes per window.  Needs m <= 16 and 4 FL + w <= 31: k = 21 (w = 7 with m = 15, w = 6 with m = 16), k = 22 and 23
+// (w = 7 / 6), k = 24 and 25 with shorter spans.
 #define TBK_FLAG_ENTRY 4u    // `guests` word of the views: the paired table is in entry layout
-#define TBK_ENTRY_NEVER 0x40000000u
+#define TBK_ENTRY_NO_MMER 0xFFFFFFFFu   // the m-mer an invalid window asks for
 #define TBK_ENTRY_FLAG 0x80000000u
 
 struct TbkEntryGeom {
@@ -384,7 +386,7 @@ struct TbkEntryGeom {
 TBK_HD bool tbk_entry_geom(int k, TbkMz z, TbkEntryGeom *g) {
     if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
     const int fl = z.o + z.w - 1;
-    if (4 * fl + z.w > 30) return false;
+    if (4 * fl + z.w > 31) return false;
     g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
     return true;
 }

@@ -439,6 +439,7 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
 constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
 constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
+constexpr int TBK_QCAP_ENTRY = 96;   // entry kernels: walks are queued by drain_back_entry, at most 16 per round (with 96 entries a block's LDS is 4.6 KB: 32 one-wave blocks per CU, eight waves per SIMD)
 
 // entry: x = key low, y = key high, z = home bucket, w = list (0 hapA, 1 hapB) | (read - first read of pass) << 1
 
@@ -1218,7 +1219,7 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
                                                   int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     for (uint32_t base = 0; base < qn; base += 64) {
         const bool act = base + lane < qn;
-        uint4 it = make_uint4(0, 1u << vshift, 0, 0);
+        uint4 it = make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
         if (act) it = q[base + lane];
         const bool found = walk_one_entry(p.t, (it.w & 1u) * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act);
         const bool count_a = found && !(it.w & 1u), count_b = found && (it.w & 1u);
@@ -1240,7 +1241,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
     const uint32_t sub = lane & 7u, oct = lane >> 3;
     for (uint32_t base = 0; base < qb; base += 8) {
         const bool act = base + oct < qb;
-        uint4 it = make_uint4(0, 1u << vshift, 0, 0);
+        uint4 it = make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) {
             it = bq[base + oct];
@@ -1268,7 +1269,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w << 1);
             if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, (it.w << 1) | 1u);
             qn += n_a + (uint32_t)__popcll(walk_b);
-            if (qn > TBK_QCAP_FRONT - 16) {
+            if (qn > TBK_QCAP_ENTRY - 16) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 drain_walks_entry<MULTI>(p, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1429,8 +1430,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t posp = (a >> 1) - span_o;
         const uint32_t shw = 2u * ((uint32_t)W - 1u - posp);
         const uint32_t vbit = 1u << ((uint32_t)vshift + posp);
-        const uint32_t my_khi = ok ? (((low | (high << a)) << shw) | vbit) : TBK_ENTRY_NEVER;
-        const uint32_t my_mhi = ok ? ((fmask << shw) | vbit) : TBK_ENTRY_NEVER;
+        const uint32_t my_khi = ((low | (high << a)) << shw) | vbit;
+        const uint32_t my_mhi = (fmask << shw) | vbit;
+        const uint32_t cm_ask = ok ? cm : TBK_ENTRY_NO_MMER;  // an invalid window asks for an m-mer no entry holds
         const bool fresh = ok && bkt != last_bk;
         const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
         last_bk = my_bk & 0x7FFFFFFFu;
@@ -1446,7 +1448,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t bk0 = pair_bcast<0>(my_bk), bk1 = pair_bcast<1>(my_bk);
         if ((int32_t)bk0 < 0) va[0] = load_slots(p.t.slots + (uint64_t)(bk0 & 0x7FFFFFFFu) * 16 + sub * 2);
         if ((int32_t)bk1 < 0) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
-        const uint32_t cm_s[2] = {pair_bcast<0>(cm), pair_bcast<1>(cm)};
+        const uint32_t cm_s[2] = {pair_bcast<0>(cm_ask), pair_bcast<1>(cm_ask)};
         const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
         const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
         uint64_t hit[2], more[2];
@@ -1661,7 +1663,7 @@ template <int W, bool MULTI, bool TWO = false>
 __global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
 tbk_probe_entry_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
-    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP_FRONT];
+    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP_ENTRY];
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][TBK_BQCAP];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
     const uint32_t lane = threadIdx.x & 63u;
