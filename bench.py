@@ -899,6 +899,9 @@ def bench_count(args, np, kmers, lib, check, dev, dist, world, rank):
 
     run(0, args.warmup)
     ctr.kernel_timing(True)
+    adds_before = C.c_uint64()
+    check(lib.tbk_counter_adds_issued(ctr._h, C.byref(adds_before)))
+    adds_before = adds_before.value
     elapsed = dist.reduce(run(args.warmup, args.steps), "MAX")
     launches, wins, kernel_ms = ctr.kernel_timing(True)
     bases_all = dist.reduce(args.steps * total, "SUM")
@@ -925,14 +928,32 @@ def bench_count(args, np, kmers, lib, check, dev, dist, world, rank):
                      "window_starts_per_s": round(wins / k_s / 1e9, 2) if k_s > 0 else None},
         "device": __import__("trio_binning_amd")._lib.device_name(dev),
     }
+    # a step is several launches (the stream is counted in pieces of a quarter of the table's slots): kernel time per STEP
+    # beside the step's wall time says what the clock holds besides the counting kernel (the separating kernel, two small
+    # synchronising copies per piece)
+    out["roofline"]["launches_per_step"] = round(launches / max(1, args.steps), 2)
+    out["roofline"]["kernel_ms_per_step"] = round(kernel_ms / max(1, args.steps), 3)
+    out["roofline"]["step_ms_outside_the_kernel"] = round(elapsed / args.steps * 1e3 - kernel_ms / max(1, args.steps), 3)
     if rank == 0:
-        # the yardstick: fire-and-forget 32-bit atomic adds, 3-4 in a row per 128-byte line, as the chip executes
-        # them.  One add per window start would cap the kernel there; it merges the adds of consecutive windows
-        # that fall into one 64-bit word of counters, so window starts per second may exceed it (atomic_frac > 1).
+        # The yardstick: the chip's rate for the adds the kernel really issues - 64-bit atomic adds that count two
+        # neighbouring 32-bit counters at once, one or two per line visited - measured by tbk_calib_atomics64 over the
+        # same footprint; the kernel's adds are counted on the device (tbk_counter_adds_issued).  (Round 3 priced
+        # window starts against the rate of 32-bit adds and read 1.43: merged adds count two windows.)
+        adds = C.c_uint64()
+        check(lib.tbk_counter_adds_issued(ctr._h, C.byref(adds)))
+        adds_timed = adds.value - adds_before
+        run_len = max(1, min(4, int(round(adds_timed / max(1.0, wins * 0.29)))))  # adds per line visited (a window changes lines with density ~0.29)
         aps = C.c_double()
-        check(lib.tbk_calib_atomics(dev, min(st["table_bytes"], 40 << 30), 3, 3, C.byref(aps)))
+        check(lib.tbk_calib_atomics64(dev, min(st["table_bytes"], 40 << 30), run_len, 3, C.byref(aps)))
+        aps32 = C.c_double()
+        check(lib.tbk_calib_atomics(dev, min(st["table_bytes"], 40 << 30), 3, 3, C.byref(aps32)))
+        out["roofline"]["atomic_adds_issued"] = int(adds_timed)
+        out["roofline"]["atomic_adds_per_window"] = round(adds_timed / max(1, wins), 4)
+        out["roofline"]["atomic_adds_Gps"] = round(adds_timed / k_s / 1e9, 2) if k_s > 0 else None
         out["roofline"]["atomic_adds_ceiling_Gps"] = round(aps.value / 1e9, 2)
-        out["roofline"]["atomic_frac"] = round(wins / k_s / aps.value, 3) if k_s > 0 else None
+        out["roofline"]["atomic_ceiling"] = f"64-bit adds, {run_len} per random line (tbk_calib_atomics64)"
+        out["roofline"]["atomic_frac"] = round(adds_timed / k_s / aps.value, 3) if k_s > 0 else None
+        out["roofline"]["atomic_adds32_ceiling_Gps"] = round(aps32.value / 1e9, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
 

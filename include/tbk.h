@@ -456,6 +456,7 @@ int tbk_counter_add_device(tbk_counter *c, const void *d_bases, const void *d_of
 /* HIP-event timing of the counting kernel (every launch is bracketed by an event pair on the stream
  * it runs on): launches, window starts they covered and their summed duration since the last reset. */
 int tbk_counter_kernel_timing(tbk_counter *c, uint64_t *launches, uint64_t *window_starts, double *total_ms, int reset);
+int tbk_counter_adds_issued(tbk_counter *c, uint64_t *adds);
 /* hist[c], c = 1..255: number of distinct k-mers whose counter (capped at 255) is c - the rows
  * kmc_tools writes, except that KMC's -ci2 database has no row-1 k-mers (callers zero hist[1]);
  * hist[0]: all distinct k-mers met. */
@@ -486,6 +487,10 @@ int tbk_calib_gather(int device, uint64_t footprint_bytes, int line_bytes, int l
  * consecutive adds to consecutive words of one random 128-byte line, then moves to another line.
  * The ceiling of the k-mer counting kernel (one add per k-mer occurrence). */
 int tbk_calib_atomics(int device, uint64_t footprint_bytes, int run, int reps, double *atomics_per_sec);
+/* The same with the instruction the counting kernel really issues: 64-bit adds that count two neighbouring 32-bit counters
+ * at once, `run` (1..4) of them on the four counter words of one random line.  tbk_counter_adds_issued: how many of those
+ * the kernel has sent so far - adds per second over this ceiling is the counting kernel's roofline fraction (<= 1). */
+int tbk_calib_atomics64(int device, uint64_t footprint_bytes, int run, int reps, double *atomics_per_sec);
 /* Streaming read of the same buffer (the 6.3 TB/s figure on this box). */
 int tbk_calib_stream(int device, uint64_t footprint_bytes, int reps, double *bytes_per_sec);
 

@@ -164,6 +164,9 @@ _sig("tbk_counter_stats", C.c_int, _vp, _u64p, _u64p, _u64p, _u64p)
 _sig("tbk_counter_unique", C.c_int, _vp, _vp, C.c_uint32, C.c_uint32, C.c_char_p, _u64p)
 _sig("tbk_calib_gather", C.c_int, C.c_int, _u64, C.c_int, C.c_int, C.c_int, _u64, C.c_int, _dp, _dp)
 _sig("tbk_calib_atomics", C.c_int, C.c_int, _u64, C.c_int, C.c_int, _dp)
+if hasattr(lib, "tbk_calib_atomics64"):
+    _sig("tbk_calib_atomics64", C.c_int, C.c_int, _u64, C.c_int, C.c_int, _dp)
+    _sig("tbk_counter_adds_issued", C.c_int, _vp, _u64p)
 _sig("tbk_calib_stream", C.c_int, C.c_int, _u64, C.c_int, _dp)
 _sig("tbk_fastx_open", C.c_int, C.c_char_p, C.POINTER(_vp))
 _sig("tbk_fastx_close", None, _vp)

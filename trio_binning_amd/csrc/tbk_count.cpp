@@ -34,6 +34,7 @@ extern "C" hipError_t tbk_launch_separate(const uint8_t *, const uint64_t *, uin
 extern "C" hipError_t tbk_launch_count(const uint8_t *, uint64_t, uint64_t, uint64_t, int, uint64_t *, uint32_t, TbkMz, int *, unsigned long long *,
                                        hipStream_t);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
+extern "C" hipError_t tbk_launch_count_clamp(uint64_t *, uint32_t, TbkMz, hipStream_t);
 extern "C" hipError_t tbk_launch_count_rehash(uint64_t *, uint32_t, TbkMz, uint64_t *, uint32_t, TbkMz, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_count_histogram(uint64_t *, uint32_t, TbkMz, unsigned long long *, hipStream_t);
 extern "C" hipError_t tbk_launch_count_unique(uint64_t *, uint32_t, TbkMz, uint64_t *, uint32_t, TbkMz, int, uint32_t, uint32_t,
@@ -62,7 +63,8 @@ struct tbk_counter {
     uint32_t n_buckets = 0;
     TbkMz mz{0, 0, 0, 0};
     int *d_failed = nullptr;
-    unsigned long long *d_used = nullptr;  // slots taken so far (distinct k-mers met), kept by the kernels
+    unsigned long long *d_used = nullptr;  // [0] slots taken so far (distinct k-mers met), [1] 64-bit atomic adds issued: kept by the kernels
+    uint64_t since_clamp = 0;              // window starts counted since the counters were last held below 2^31 (tbk_count_clamp_kernel)
     uint64_t used = 0;
     double load = 0.6;
     // staging of one batch: reads back to back, their offsets, and the separated upper-cased copy
@@ -125,9 +127,9 @@ extern "C" int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tb
     rc = alloc_lines(k, capacity_kmers, c->load, &c->d_lines, &c->n_buckets, &c->mz);
     hipError_t e = hipSuccess;
     if (!rc) e = hipMalloc((void **)&c->d_failed, sizeof(int));
-    if (!rc && e == hipSuccess) e = hipMalloc((void **)&c->d_used, sizeof(unsigned long long));
+    if (!rc && e == hipSuccess) e = hipMalloc((void **)&c->d_used, 2 * sizeof(unsigned long long));
     if (!rc && e == hipSuccess) e = hipMemset(c->d_failed, 0, sizeof(int));
-    if (!rc && e == hipSuccess) e = hipMemset(c->d_used, 0, sizeof(unsigned long long));
+    if (!rc && e == hipSuccess) e = hipMemset(c->d_used, 0, 2 * sizeof(unsigned long long));
     if (!rc && e != hipSuccess) rc = cfail(TBK_ERR_HIP, "tbk_counter_create: %s", hipGetErrorString(e));
     if (rc) { tbk_counter_destroy(c); return rc; }
     *out = c;
@@ -190,6 +192,13 @@ static int counter_run(tbk_counter *c, const uint8_t *d_bases, const uint64_t *d
             if (rc) return rc;
             slots = (uint64_t)c->n_buckets * TBK_SLOTS_PER_BUCKET;
         }
+        // no counter may pass 2^32 (it would carry into the neighbour it shares a 64-bit word with): one grows by at most a
+        // piece's window starts, so before 2^31 of them have been added since the last clamp, every counter goes back to <= 2^31
+        if (c->since_clamp + windows >= ((uint64_t)1 << 31)) {
+            CHIP(tbk_launch_count_clamp(c->d_lines, c->n_buckets, c->mz, nullptr));
+            c->since_clamp = 0;
+        }
+        c->since_clamp += windows;
         if (!c->ev0) { CHIP(hipEventCreate(&c->ev0)); CHIP(hipEventCreate(&c->ev1)); }
         CHIP(hipEventRecord(c->ev0, nullptr));
         CHIP(tbk_launch_count(c->d_sep, sep_total, p0, np, c->k, c->d_lines, c->n_buckets, c->mz, c->d_failed, c->d_used, nullptr));
@@ -253,6 +262,16 @@ extern "C" int tbk_counter_kernel_timing(tbk_counter *c, uint64_t *launches, uin
     if (window_starts) *window_starts = c->timed_windows;
     if (total_ms) *total_ms = c->timed_ms;
     if (reset) { c->timed_launches = 0; c->timed_windows = 0; c->timed_ms = 0.0; }
+    return TBK_OK;
+}
+
+extern "C" int tbk_counter_adds_issued(tbk_counter *c, uint64_t *adds) {
+    if (!c || !adds) return cfail(TBK_ERR_INVALID, "NULL argument");
+    int rc = counter_device(c);
+    if (rc) return rc;
+    unsigned long long v = 0;
+    CHIP(hipMemcpy(&v, c->d_used + 1, sizeof v, hipMemcpyDeviceToHost));
+    *adds = v;
     return TBK_OK;
 }
 

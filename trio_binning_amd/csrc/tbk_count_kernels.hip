@@ -126,12 +126,13 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
         for (int s = 0; s < TBK_SLOTS_PER_BUCKET; s++) held[s] = 0;
         uint32_t held_bk = 0xFFFFFFFFu;
         uint32_t claimed = 0;  // slots this lane took for new k-mers
+        uint32_t adds = 0;     // 64-bit atomic adds this lane issued (bench.py prices the kernel against the chip's rate for THOSE)
         bool full = false;
         // The adds of consecutive windows are merged where they can be: a bucket's eight 32-bit counters
         // are four 64-bit words, the k-mers of a run of windows were inserted one after the other - so
         // they mostly sit in neighbouring slots - and one 64-bit add of (1 | 1 << 32) counts both
-        // halves of a word (a counter would have to pass 2^32 to carry into its neighbour; readers cap
-        // at 255).  The lane keeps the adds to the four words of ONE bucket pending and sends them when
+        // halves of a word (a counter would have to pass 2^32 to carry into its neighbour: the host keeps
+        // every counter below that, tbk_count_clamp_kernel; readers cap at 255).  The lane keeps the adds to the four words of ONE bucket pending and sends them when
         // a window counts in another bucket: the kernel runs at the rate the chip executes atomic adds,
         // so fewer adds is the lever.
         uint32_t pend_bk = 0xFFFFFFFFu;
@@ -141,7 +142,7 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
             unsigned long long *words = reinterpret_cast<unsigned long long *>(t.counts(pend_bk));
 #pragma unroll
             for (int w = 0; w < 4; w++)
-                if (pend[w]) { atomicAdd(&words[w], pend[w]); pend[w] = 0; }
+                if (pend[w]) { atomicAdd(&words[w], pend[w]); pend[w] = 0; adds++; }
         };
 #pragma unroll 2
         for (int j = 0; j < TBK_WPL; j++) {
@@ -203,7 +204,28 @@ tbk_count_kernel(const uint8_t *__restrict__ bases, uint64_t total, uint64_t fir
         uint32_t sum = claimed;
         for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
         if (lane == 0 && sum) atomicAdd(used, (unsigned long long)sum);
+        uint32_t asum = adds;
+        for (int d = 32; d > 0; d >>= 1) asum += __shfl_xor(asum, d);
+        if (lane == 0 && asum) atomicAdd(used + 1, (unsigned long long)asum);
     }
+}
+
+// Counters are 32 bits wide and neighbours share a 64-bit word that the counting kernel adds to in one piece: a counter
+// that passed 2^32 would carry into its neighbour.  Readers cap at 255, so a counter may stop anywhere above that: the host
+// runs this pass before the window starts added since the last one could take any counter from 2^31 to 2^32 - every
+// counter above 2^31 is set back to 2^31 (saturation, not a carry).
+__global__ void __launch_bounds__(256)
+tbk_count_clamp_kernel(TbkCountView t) {
+    const uint64_t n = (uint64_t)t.n_buckets * TBK_SLOTS_PER_BUCKET;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t *c = &t.counts((uint32_t)(i / TBK_SLOTS_PER_BUCKET))[i % TBK_SLOTS_PER_BUCKET];
+        if (*c > 0x80000000u) *c = 0x80000000u;
+    }
+}
+
+extern "C" hipError_t tbk_launch_count_clamp(uint64_t *d_lines, uint32_t n_buckets, TbkMz mz, hipStream_t stream) {
+    hipLaunchKernelGGL(tbk_count_clamp_kernel, dim3(4096), dim3(256), 0, stream, TbkCountView{d_lines, n_buckets, mz});
+    return hipGetLastError();
 }
 
 // Move every (key, counter) of an old table into a new, larger one (the host grows the table when

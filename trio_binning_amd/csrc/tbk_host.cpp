@@ -259,7 +259,7 @@ struct Slot {
     uint32_t *d_exc_chunk = nullptr; uint16_t *d_exc_mask = nullptr; size_t cap_exc = 0;
     uint32_t *h_codes = nullptr; size_t hcap_chunks = 0;
     uint32_t *h_exc_chunk = nullptr; uint16_t *h_exc_mask = nullptr; size_t hcap_exc = 0;
-    hipEvent_t copied = nullptr, probed = nullptr, done = nullptr;
+    hipEvent_t copied = nullptr, probed = nullptr, done = nullptr, copied2 = nullptr;
     hipEvent_t sliced[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // a host batch's bases arrive (and are probed) in up to 8 slices
     bool busy = false;
     uint64_t ticket = 0, n_reads = 0;
@@ -275,12 +275,14 @@ struct Slot {
 struct DeviceStreams {
     int device = 0;
     hipStream_t compute = nullptr, copy = nullptr, out = nullptr;
+    hipStream_t copy2 = nullptr;  // second H2D stream (TBK_H2D_STREAMS=2): a steady-state batch's bases cross PCIe in two halves on two DMA engines
     std::mutex enqueue;
     std::atomic<int> in_flight{0};  // batches submitted and not yet waited for, over all rings of the device
     ~DeviceStreams() {
         if (hipSetDevice(device) != hipSuccess) return;
         if (compute) (void)hipStreamDestroy(compute);
         if (copy) (void)hipStreamDestroy(copy);
+        if (copy2) (void)hipStreamDestroy(copy2);
         if (out) (void)hipStreamDestroy(out);
     }
 };
@@ -1028,12 +1030,14 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
         e = hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->copy, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->out, hipStreamNonBlocking);
+        if (e == hipSuccess && env_double("TBK_H2D_STREAMS", 1) >= 2) e = hipStreamCreateWithFlags(&c->streams->copy2, hipStreamNonBlocking);
     }
     c->compute = c->streams->compute; c->copy = c->streams->copy; c->out = c->streams->out;
     for (int i = 0; i < RING && e == hipSuccess; i++) {
         e = hipEventCreateWithFlags(&c->ring[i].copied, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].probed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ring[i].copied2, hipEventDisableTiming);
         for (int j = 0; j < 8 && e == hipSuccess; j++) e = hipEventCreateWithFlags(&c->ring[i].sliced[j], hipEventDisableTiming);
     }
     if (e != hipSuccess) return fail(TBK_ERR_HIP, "classifier setup: %s", hipGetErrorString(e));
@@ -1440,6 +1444,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
             if (s.copied) (void)hipEventDestroy(s.copied);
             if (s.probed) (void)hipEventDestroy(s.probed);
             if (s.done) (void)hipEventDestroy(s.done);
+            if (s.copied2) (void)hipEventDestroy(s.copied2);
             for (hipEvent_t e : s.sliced) if (e) (void)hipEventDestroy(e);
         }
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -1748,7 +1753,14 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
             // a pass reads 130 chunks from its first one: the slice needs the stream up to chunk pass_hi * 128 + 2
             const uint64_t upto = j + 1 == n_slices ? n_chunks : std::min<uint64_t>(n_chunks, slices[j].pass_hi * (TBK_PASS_BASES / 16) + 2);
             if (upto > sent) {
-                if (packed) {
+                if (packed && n_slices == 1 && c->streams->copy2 && upto - sent >= ((uint64_t)1 << 22)) {
+                    // steady state, two H2D streams: the second half of the codes travels on a DMA engine of its own
+                    const uint64_t mid = sent + (upto - sent) / 2;
+                    HIP_TRY(hipMemcpyAsync(s.d_codes + mid, codes + mid, (upto - mid) * sizeof(uint32_t), hipMemcpyHostToDevice, c->streams->copy2));
+                    HIP_TRY(hipEventRecord(s.copied2, c->streams->copy2));
+                    HIP_TRY(hipMemcpyAsync(s.d_codes + sent, codes + sent, (mid - sent) * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
+                    HIP_TRY(hipStreamWaitEvent(c->copy, s.copied2, 0));
+                } else if (packed) {
                     HIP_TRY(hipMemcpyAsync(s.d_codes + sent, codes + sent, (upto - sent) * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy));
                 } else {
                     const uint64_t b0 = sent * 16, b1 = std::min<uint64_t>(total, upto * 16);
@@ -2171,7 +2183,17 @@ extern "C" int tbk_calib_gather(int device, uint64_t footprint, int line_bytes, 
 
 extern "C" hipError_t tbk_launch_atomics(void *, uint64_t, uint32_t, uint32_t, uint64_t, unsigned, hipStream_t);
 
+extern "C" hipError_t tbk_launch_atomics64(void *, uint64_t, uint32_t, uint32_t, uint64_t, unsigned, hipStream_t);
+static int calib_atomics(int device, uint64_t footprint, int run, int reps, double *atomics_per_sec, bool wide);
 extern "C" int tbk_calib_atomics(int device, uint64_t footprint, int run, int reps, double *atomics_per_sec) {
+    return calib_atomics(device, footprint, run, reps, atomics_per_sec, false);
+}
+// the same with the counting kernel's own instruction: 64-bit adds (two counters at once), `run` (1..4) per line
+extern "C" int tbk_calib_atomics64(int device, uint64_t footprint, int run, int reps, double *atomics_per_sec) {
+    if (run > 4) return fail(TBK_ERR_INVALID, "run must be 1..4 (a line holds four 64-bit counter words)");
+    return calib_atomics(device, footprint, run, reps, atomics_per_sec, true);
+}
+static int calib_atomics(int device, uint64_t footprint, int run, int reps, double *atomics_per_sec, bool wide) {
     int rc = use_device(device);
     if (rc) return rc;
     if (run < 1 || run > 32) return fail(TBK_ERR_INVALID, "run must be 1..32");
@@ -2186,10 +2208,11 @@ extern "C" int tbk_calib_atomics(int device, uint64_t footprint, int run, int re
     hipError_t e = hipMemset(buf, 0, footprint);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = tbk_launch_atomics(buf, footprint, iters, (uint32_t)run, 1, blocks, nullptr);
+    auto launch = wide ? tbk_launch_atomics64 : tbk_launch_atomics;
+    if (e == hipSuccess) e = launch(buf, footprint, iters, (uint32_t)run, 1, blocks, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
-    for (int r = 0; r < reps && e == hipSuccess; r++) e = tbk_launch_atomics(buf, footprint, iters, (uint32_t)run, 2 + r, blocks, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = launch(buf, footprint, iters, (uint32_t)run, 2 + r, blocks, nullptr);
     if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);

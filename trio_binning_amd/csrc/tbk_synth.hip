@@ -247,6 +247,19 @@ tbk_calib_atomics_kernel(uint32_t *__restrict__ buf, uint64_t n_lines, uint32_t 
     }
 }
 
+// the counting kernel's own adds: 64-bit (two 32-bit counters at once), `run` of them on neighbouring words of one line's
+// counter block (words 8..11 of the 16-word line: tbk_count_kernels.hip)
+__global__ void __launch_bounds__(256)
+tbk_calib_atomics64_kernel(unsigned long long *__restrict__ buf, uint64_t n_lines, uint32_t iters, uint32_t run, uint64_t seed) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t state = seed ^ (gid * 0x9E3779B97F4A7C15ull);
+    for (uint32_t it = 0; it < iters; it += run) {
+        state = tbk_splitmix(state);
+        unsigned long long *line = buf + (uint64_t)(((unsigned __int128)state * n_lines) >> 64) * 16 + 8;
+        for (uint32_t r = 0; r < run && it + r < iters; r++) atomicAdd(&line[(r + (uint32_t)(state >> 62)) & 3u], 0x100000001ull);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 tbk_fill_kernel(uint4 *__restrict__ buf, uint64_t n_vec, uint64_t seed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -316,6 +329,11 @@ extern "C" hipError_t tbk_launch_synth_hap_reads(uint64_t seed, uint64_t genome_
 extern "C" hipError_t tbk_launch_atomics(void *d_buf, uint64_t bytes, uint32_t iters, uint32_t run, uint64_t seed, unsigned blocks,
                                          hipStream_t s) {
     hipLaunchKernelGGL(tbk_calib_atomics_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t *)d_buf, bytes / 128, iters, run, seed);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_atomics64(void *d_buf, uint64_t bytes, uint32_t iters, uint32_t run, uint64_t seed, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL(tbk_calib_atomics64_kernel, dim3(blocks), dim3(256), 0, s, (unsigned long long *)d_buf, bytes / 128, iters, run, seed);
     return hipGetLastError();
 }
 
