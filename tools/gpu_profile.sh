@@ -10,18 +10,21 @@ R=$GRAFT_REPO_ROOT
 ( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default.log | tail -1 > gpurun_out/bench_default.json
 export TBK_SKIP_BUILD=1
 ( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_haplotypes.log | tail -1 > gpurun_out/bench_haplotypes.json
-( time timeout 900 python bench.py --gpus 2 --share-device ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
-( time timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-device --steps 10 --warmup 2 ) > gpurun_out/bench_2ranks_torchrun.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_torchrun.log | tail -1 > gpurun_out/bench_2ranks_torchrun.json
-( time timeout 900 python bench.py --rings 3 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_3rings.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_3rings.log | tail -1 > gpurun_out/bench_3rings.json
+( time timeout 900 python bench.py --gpus 2 --share-device --min-timed-s 3 ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
+# eight ranks on the one device (smaller lists: eight tables must fit its memory): the launch, the rendezvous, parity over all ranks, every rank's NUMA placement and share of the host threads
+( time timeout 900 python bench.py --gpus 8 --share-device --kmers-per-list 30000000 --reads-per-step 32768 --steps 10 --warmup 2 --min-timed-s 2 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_8ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_8ranks_shared_device.log | tail -1 > gpurun_out/bench_8ranks_shared_device.json
+( time timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-device --steps 10 --warmup 2 --min-timed-s 3 ) > gpurun_out/bench_2ranks_torchrun.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_torchrun.log | tail -1 > gpurun_out/bench_2ranks_torchrun.json
+( time timeout 900 python bench.py --rings 3 --no-cpu-baseline --no-streaming --no-realistic --min-timed-s 3 ) > gpurun_out/bench_3rings.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_3rings.log | tail -1 > gpurun_out/bench_3rings.json
 # BASELINE configs[4]'s table and read shape on one GPU: 2 x 1e9 31-mers (64-bit m-mer kernels), 100 kb reads
-( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_uniform.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_uniform.log | tail -1 > gpurun_out/bench_c5_uniform.json
-( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --lists haplotypes --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_haplotypes.log | tail -1 > gpurun_out/bench_c5_haplotypes.json
+( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --min-timed-s 3 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_uniform.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_uniform.log | tail -1 > gpurun_out/bench_c5_uniform.json
+( time timeout 1200 python bench.py --k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --min-timed-s 3 --lists haplotypes --no-cpu-baseline --no-streaming ) > gpurun_out/bench_c5_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_haplotypes.log | tail -1 > gpurun_out/bench_c5_haplotypes.json
 ( time timeout 600 python bench.py --path count ) > gpurun_out/bench_count.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_count.log | tail -1 > gpurun_out/bench_count.json
-( time timeout 900 python bench.py --scaling strong --strong-reads 3000000 --steps 3 --warmup 1 --no-cpu-baseline --no-streaming ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
-FLAGS="--steps 4 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-streaming"
+# the literal BASELINE configs[2] line: the 90 Gbp set (6 M x 15 kb reads), one rank
+( time timeout 1500 python bench.py --scaling strong --strong-reads 6000000 --steps 2 --warmup 1 --min-timed-s 0 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
+FLAGS="--steps 4 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-streaming --no-realistic"
 cd /tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_*
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $R/bench.py --no-streaming > $R/gpurun_out/prof_trace.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $R/bench.py > $R/gpurun_out/prof_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace_count -- python3 $R/bench.py --path count --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_trace_count.log 2>&1
 for lists in uniform haplotypes; do
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES"; do

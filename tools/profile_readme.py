@@ -2,7 +2,7 @@
 """Copy the summaries of a tools/gpu_profile.sh run from gpurun_out/ into profiles/<round>/ and write that
 directory's README.md from the JSON lines themselves (no number is typed by hand).
 
-    python tools/profile_readme.py r03
+    python tools/profile_readme.py r04
 """
 import json
 import os
@@ -10,10 +10,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
+KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_8ranks_shared_device.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
         "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
 for name in KEEP:
@@ -71,7 +71,7 @@ def col(b, p):
         f"{g(b, 'kernel_resident', 'gbases_per_s')}",
         f"{c['bucket_select']}, load {c['table_load']}, {c['line_layout'][:5]} layout, {c['table_bytes_per_gpu'] / 1e9:.0f} GB ({c['table_bytes_per_key']} B per key)",
         f"{ms} ({r['launches']} launches); whole probe {r['whole_probe_ms_avg']}",
-        f"{r['alg_bytes_per_launch'] / 1e9:.1f} / {r['achieved']} / **{r['frac']}** (P = 1 reading: {r['frac_P1_merged_table_reading']})",
+        f"{r['alg_bytes_per_launch'] / 1e9:.1f} / {r['achieved']} / **{r['frac']}** (two-probe reading, P = 2: {r.get('frac_P2_two_probe_reading')})",
         f"{hbm / 1e9:.1f} / {p.get('hbm_bytes_per_launch_from_TCC_MISS', 0) / 1e9:.1f}" if hbm else "-",
         f"{hbm / w:.1f} / {lines:.4f}" if hbm and lines else "-",
         f"{hbm / ms / 1e9:.2f} / {hbm / ms / 1e9 / 6.29:.2f}" if hbm else "-",
@@ -85,28 +85,34 @@ def col(b, p):
 
 
 rows = ["`value`: host-fed classify stage (Gbases/s)", "`kernel_resident` (Gbases/s)", "table", "single-read probe kernel, HIP events inside the timed region (ms per launch)",
-        "its algorithmic bytes per launch (GB) / `roofline.achieved` (GB/s) / `frac`", "its HBM bytes per launch: FETCH_SIZE x 1024 x 2 / TCC_MISS x 128 B (GB)",
+        "its algorithmic bytes per launch (GB, P = 1: 9 B per window) / `roofline.achieved` (GB/s) / `frac`", "its HBM bytes per launch: FETCH_SIZE x 1024 x 2 / TCC_MISS x 128 B (GB)",
         "bytes per window / 128-B lines per window", "HBM traffic rate (TB/s) / of the 6.29 TB/s stream ceiling", "random 128-B lines (G/s) / of the 47.75 G/s a pure gather reaches",
         "VALU / SALU / VMEM-read instructions per window", "SQ_WAIT_ANY / SQ_WAVE_CYCLES", "parity in the run (GPU counts == oracle)",
         "CPU baseline, oracle: 1 thread / 16 CPUs / rolling, 16 CPUs (Mbases/s)", "same stage fed with ASCII batches: packed by the feeder / ASCII over PCIe (Gbases/s)"]
 cu, ch = col(u, pu), col(h, ph)
-full = [t for t in trace if "tbk_probe_kernel" in t["kernel"]][:4]
+full = [t for t in trace if "tbk_probe_kernel" in t["kernel"] or "tbk_probe_entry_kernel" in t["kernel"]][:8]
 
-out = [f"# Round 3 reference profile ({rnd})", "",
+out = [f"# Reference profile of round {rnd[1:].lstrip('0')} ({rnd})", "",
        "Made by `tools/gpu_profile.sh` on one MI355X box (ROCm 7.2), condensed by `tools/profile_summary.py`, and this file by",
        "`tools/profile_readme.py` from the JSON lines beside it - no number here is typed by hand.  Box-to-box spread of the pool: +-4 %.", "",
        "    python bench.py                                  -> bench_default.json (host-fed value, kernel_resident, pipeline variants, cpu_baseline, parity)",
        "    python bench.py --lists haplotypes               -> bench_haplotypes.json (lists shaped like real find-unique-kmers output)",
        "    python bench.py --gpus 2 --share-device          -> bench_2ranks_shared_device.json (two ranks on the one GPU: plumbing of the N > 1 line)",
        "    python -m torch.distributed.run ... bench.py --gpus 2 --share-device   -> bench_2ranks_torchrun.json (the driver's launcher)",
-       "    python bench.py --scaling strong --strong-reads 3000000 --steps 3      -> bench_strong.json (fixed 45 Gbp set, host-fed, one rank)",
+       "    python bench.py --gpus 8 --share-device --kmers-per-list 30000000 ...  -> bench_8ranks_shared_device.json (eight ranks, eight tables, one GPU)",
+       "    python bench.py --scaling strong --strong-reads 6000000 --steps 2      -> bench_strong.json (BASELINE configs[2]: the 90 Gbp set, host-fed, one rank)",
        "    python bench.py --path count                     -> bench_count.json",
-       "    rocprofv3 --kernel-trace --stats -- python3 bench.py --no-streaming    -> kernel_stats.csv, kernel_trace_by_launch_size.json",
+       "    rocprofv3 --kernel-trace --stats -- python3 bench.py                   -> kernel_stats.csv, kernel_trace_by_launch_size.json",
        "    rocprofv3 --kernel-trace --pmc <one set per run> -- python3 bench.py [--lists haplotypes] --steps 4 --warmup 1 ...   -> pmc_summary_<lists>.json", "",
        "Workload: bench.py defaults = k = 21, 2 x 3e8 keys, 262144 x 15 kb reads (3.932 Gbases) per step, 20 steps per timed region.", "",
        "| | uniform lists (BASELINE) | haplotype-shaped lists |", "|---|---|---|"]
 out += [f"| {r} | {a} | {b} |" for r, a, b in zip(rows, cu, ch)]
-out += ["", "rocprofv3 `--kernel-trace` of `python3 bench.py --no-streaming`, per kernel and launch size (`kernel_stats.csv` averages over every launch of a kernel,",
+rl = g(u, "realistic_lists", default=None)
+if isinstance(rl, dict):
+    out += ["", f"`realistic_lists` inside the default line (the same run, haplotype-shaped lists): value {rl['value']} Gbases/s host-fed, kernel_resident {rl['kernel_resident']}, "
+            f"single-read kernel {rl['kernel_ms_avg']} ms, frac {rl['frac']} (P = 2: {rl['frac_P2_two_probe_reading']}), random_line_frac {rl.get('random_line_frac')}, "
+            f"{rl['table_bytes_per_key']} B of table per key ({rl['line_layout'][:7]}), parity gpu_equals_cpu = {g(rl, 'parity', 'gpu_equals_cpu')} on {g(rl, 'parity', 'reads_checked_against_the_oracle')} reads."]
+out += ["", "rocprofv3 `--kernel-trace` of `python3 bench.py`, per kernel and launch size (`kernel_stats.csv` averages over every launch of a kernel,",
         "the two small parity launches included; the roofline's duration is that of the full-size launches):", "",
         "| kernel | grid | launches | avg ms | min | max |", "|---|---|---|---|---|---|"]
 out += [f"| `{t['kernel']}` | {t['grid']} | {t['launches']} | {t['avg_ms']} | {t['min_ms']} | {t['max_ms']} |" for t in full]
@@ -118,6 +124,11 @@ if prof:
 if two:
     out += ["", f"Two ranks on the one device (`--share-device`; a plumbing run, not a scaling result): value {two['value']} Gbases/s, kernel_resident {g(two, 'kernel_resident', 'gbases_per_s')}, "
             f"parity all_ranks_equal = {g(two, 'parity', 'all_ranks_equal')}, gpu_equals_cpu = {g(two, 'parity', 'gpu_equals_cpu')}, devices {json.dumps(two.get('devices'))}."]
+eight = load("bench_8ranks_shared_device.json")
+if eight:
+    out += [f"Eight ranks on the one device (2 x {g(eight, 'config', 'kmers_per_list')} keys so that eight tables fit; plumbing, not scaling): value {eight['value']} Gbases/s, "
+            f"all_ranks_equal = {g(eight, 'parity', 'all_ranks_equal')}, gpu_equals_cpu = {g(eight, 'parity', 'gpu_equals_cpu')}; per rank (NUMA node, CPUs bound to, host threads): "
+            f"{[(d.get('numa_node'), d.get('cpus_bound_to'), d.get('host_threads')) for d in eight.get('devices', [])]}."]
 if tr2:
     out += [f"Under `python -m torch.distributed.run`: value {tr2['value']}, parity all_ranks_equal = {g(tr2, 'parity', 'all_ranks_equal')}."]
 rings3 = load("bench_3rings.json")
@@ -133,9 +144,13 @@ for nm, label in (("bench_c5_uniform.json", "uniform"), ("bench_c5_haplotypes.js
                 f"kernel_resident {g(c5, 'kernel_resident', 'gbases_per_s')}; {cc['bucket_select']}, load {cc['table_load']}, {cc['table_bytes_per_gpu'] / 1e9:.0f} GB table, {cc['line_layout'][:5]} layout; "
                 f"transfers agree: {g(c5, 'parity', 'packed_and_ascii_transfers_agree')} (oracle parity at this scale: tests/test_gpu_scale.py)."]
 if strong:
-    out += [f"Strong scaling plumbing (one rank, 45 Gbp set in 12 host-fed batches per step): value {strong['value']} Gbases/s."]
+    out += [f"BASELINE configs[2] literally (`--scaling strong`, one rank: {g(strong, 'config', 'workload')[:110]}...): value {strong['value']} Gbases/s, {strong['ms_per_step']} ms per pass over the set, "
+            f"{g(strong, 'config', 'launches_per_step')} host-fed batches per pass, gpu_equals_cpu = {g(strong, 'parity', 'gpu_equals_cpu')}."]
 if count:
-    out += [f"`--path count`: {count['value']} Gbases/s counted, atomic_frac {g(count, 'roofline', 'atomic_frac')}."]
+    cr = count["roofline"]
+    out += [f"`--path count`: {count['value']} Gbases/s counted ({count['ms_per_step']} ms per step = {cr.get('launches_per_step')} launches, {cr.get('kernel_ms_per_step')} ms of them in the counting kernel); "
+            f"{cr.get('atomic_adds_per_window')} 64-bit atomic adds per window start, {cr.get('atomic_adds_Gps')} G adds/s against the chip's {cr.get('atomic_adds_ceiling_Gps')} ({cr.get('atomic_ceiling')}): "
+            f"atomic_frac {cr.get('atomic_frac')}; histogram parity {g(count, 'parity', 'gpu_histogram_equals_cpu')}."]
 if cli:
     out += ["", f"End to end (`tools/measure_e2e.py`, {cli['config']}; {cli['fastq_GB']} GB of FASTQ, {cli['lists_GB']} GB of list text; page cache {cli['page_cache']}; {cli['host_usable_cpus']} usable CPUs):", "",
             "| lists | both lists (s) | M lines/s | paired table build (s) |", "|---|---|---|---|"]
@@ -167,8 +182,8 @@ if cli:
 if reader:
     out += ["", f"Reader alone (`tools/measure_reader.py --qual hifi`, {reader['text_GB']} GB of FASTQ text, GB/s of text): plain first pass {g(reader, 'plain_first_pass', 'text_GB_per_s')}, "
             f"plain warm {g(reader, 'plain', 'text_GB_per_s')}, gzip {g(reader, 'gzip', 'text_GB_per_s')}, bgzf {g(reader, 'bgzf', 'text_GB_per_s')}."]
-out += ["", "Experiment logs of the round (same-box A/B runs; `EXPERIMENTS.md` reads them): `ab_diagnostics.log` (occupancy / cheap-bucket / no-load timing builds),",
-        "`ab_occupancy.log` (split kernels at 4 / 5 / 6 waves, both list shapes, 150 b and 1 kb reads), `ab_front_layout_4waves.log`, `ab_m15w7.log`, `counters.log`",
-        "(event counters of a `-DTBK_COUNTERS` build), `hostfed_timeline_before_fix.log` (copy / kernel timeline that exposed the serialised host-fed step).", ""]
+out += ["", "Experiment logs of the round (same-box A/B runs; `EXPERIMENTS.md` reads them): `ab_entry_layout.log` (entry layout on / off, entries per bucket, uniform lists forced",
+        "into entries, spans of six and seven m-mers), `ab_h2d.log` (one / two H2D streams, copy stream priority, blit kernels), `calib_shape.json` (random-line rate by access shape),",
+        "`valu_rates.log` (instruction throughput), `gate_scatter.log` (partition-then-probe gate), `gate_write_direct.log` (O_DIRECT bins gate).", ""]
 open(os.path.join(dst, "README.md"), "w").write("\n".join(out))
 print("\n".join(out[:40]))

@@ -63,7 +63,7 @@ struct tbk_counter {
     uint32_t n_buckets = 0;
     TbkMz mz{0, 0, 0, 0};
     int *d_failed = nullptr;
-    unsigned long long *d_used = nullptr;  // [0] slots taken so far (distinct k-mers met), [1] 64-bit atomic adds issued: kept by the kernels
+    unsigned long long *d_used = nullptr;  // [0] slots taken so far (distinct k-mers met), [1 .. 1024] tallies of the 64-bit atomic adds issued: kept by the kernels
     uint64_t since_clamp = 0;              // window starts counted since the counters were last held below 2^31 (tbk_count_clamp_kernel)
     uint64_t used = 0;
     double load = 0.6;
@@ -127,9 +127,9 @@ extern "C" int tbk_counter_create(int k, uint64_t capacity_kmers, int device, tb
     rc = alloc_lines(k, capacity_kmers, c->load, &c->d_lines, &c->n_buckets, &c->mz);
     hipError_t e = hipSuccess;
     if (!rc) e = hipMalloc((void **)&c->d_failed, sizeof(int));
-    if (!rc && e == hipSuccess) e = hipMalloc((void **)&c->d_used, 2 * sizeof(unsigned long long));
+    if (!rc && e == hipSuccess) e = hipMalloc((void **)&c->d_used, 1025 * sizeof(unsigned long long));
     if (!rc && e == hipSuccess) e = hipMemset(c->d_failed, 0, sizeof(int));
-    if (!rc && e == hipSuccess) e = hipMemset(c->d_used, 0, 2 * sizeof(unsigned long long));
+    if (!rc && e == hipSuccess) e = hipMemset(c->d_used, 0, 1025 * sizeof(unsigned long long));
     if (!rc && e != hipSuccess) rc = cfail(TBK_ERR_HIP, "tbk_counter_create: %s", hipGetErrorString(e));
     if (rc) { tbk_counter_destroy(c); return rc; }
     *out = c;
@@ -269,9 +269,11 @@ extern "C" int tbk_counter_adds_issued(tbk_counter *c, uint64_t *adds) {
     if (!c || !adds) return cfail(TBK_ERR_INVALID, "NULL argument");
     int rc = counter_device(c);
     if (rc) return rc;
-    unsigned long long v = 0;
-    CHIP(hipMemcpy(&v, c->d_used + 1, sizeof v, hipMemcpyDeviceToHost));
-    *adds = v;
+    std::vector<unsigned long long> v(1024);
+    CHIP(hipMemcpy(v.data(), c->d_used + 1, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    for (unsigned long long x : v) sum += x;
+    *adds = sum;
     return TBK_OK;
 }
 

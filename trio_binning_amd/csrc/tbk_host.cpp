@@ -1028,7 +1028,11 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
         c->streams = std::make_shared<DeviceStreams>();
         c->streams->device = c->device;
         e = hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->copy, hipStreamNonBlocking);
+        if (e == hipSuccess && env_double("TBK_COPY_PRIORITY", 0) != 0) {  // (experiment: the H2D stream at the highest priority the device offers)
+            int least = 0, greatest = 0;
+            e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->streams->copy, hipStreamNonBlocking, greatest);
+        } else if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->copy, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->out, hipStreamNonBlocking);
         if (e == hipSuccess && env_double("TBK_H2D_STREAMS", 1) >= 2) e = hipStreamCreateWithFlags(&c->streams->copy2, hipStreamNonBlocking);
     }
