@@ -674,7 +674,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             "table_bytes_per_gpu": stats["table_bytes"], "table_bytes_per_key": round(stats["table_bytes"] / max(1, 2 * n_list), 1), "table_load": round(table_load, 4),
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
-            "line_layout": ("entries: a run of overlapping list k-mers stored once; 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("entry_layout")
+            "line_layout": (("entries (wide, 16 bytes)" if stats.get("wide_entries") else "entries") + ": a run of overlapping list k-mers stored once; 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("entry_layout")
                             else "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines"),
             "keys_behind_front": stats.get("keys_behind_front"),
             "entries": [stats.get("entries_a"), stats.get("entries_b")] if stats.get("entry_layout") else None,

@@ -24,6 +24,7 @@ struct Table {
     TbkEntryGeom g;
     int k;
     uint64_t entries = 0, merged = 0, behind = 0, past = 0;
+    bool wide = false;
 };
 
 // the insert rule (sequential form): first compatible entry of the list along the m-mer's bucket sequence, else the first empty slot
@@ -49,6 +50,68 @@ static void insert_form(Table &t, uint32_t half, TbkEntryKey e) {
     exit(2);
 }
 
+// ---- the same for wide entries (k up to 32): one entry per 16-byte piece, four per list and line ----
+static void winsert_form(Table &t, uint32_t half, TbkWideKey e) {
+    uint32_t b = tbk_entry_bucket(e.cm, t.n_buckets);
+    for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
+        uint64_t *line = t.slots.data() + (uint64_t)b * 16;
+        for (uint32_t i = 0; i < 4; i++) {
+            uint64_t &w0 = line[2 * tbk_wepiece_at(half, i)], &w1 = line[2 * tbk_wepiece_at(half, i) + 1];
+            if (!(w0 & TBK_WENTRY_TAKEN)) {
+                w0 = (uint64_t)e.cm | TBK_WENTRY_TAKEN;
+                w1 |= e.k1;
+                t.entries++;
+                if (i >= 1) { line[2 * tbk_wepiece_at(half, 0) + 1] |= TBK_WENTRY_FLAG; t.behind++; }
+                return;
+            }
+            if (tbk_wentry_compatible(w0, w1, e, t.z, t.g)) { w1 |= e.k1; t.merged++; return; }
+        }
+        line[2 * tbk_wepiece_at(half, 3) + 1] |= TBK_WENTRY_FLAG;
+        t.past++;
+        b = tbk_entry_next_bucket(e.cm, t.n_buckets, b, walked == 0);
+    }
+    fprintf(stderr, "table full\n");
+    exit(2);
+}
+
+static int wforms_of(const Table &t, uint64_t key, TbkWideKey *out) {
+    const int nt = 2 * t.z.w;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int i = 0; i < nt; i++) { const uint32_t r = tbk_tmer_rank(key, t.z, i); best = r < best ? r : best; }
+    int n = 0;
+    for (int i = 0; i < nt; i++) {
+        if (tbk_tmer_rank(key, t.z, i) != best) continue;
+        n += tbk_wentry_orientations(key, t.k, t.z, t.g, i % t.z.w, out + n);
+    }
+    return n;
+}
+
+static bool wcontains(const Table &t, uint32_t half, uint64_t key) {
+    TbkWideKey f[64];
+    const int n = wforms_of(t, key, f);
+    bool any = false, all = true;
+    for (int i = 0; i < n; i++) { const bool h = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, half, f[i]); any = any || h; all = all && h; }
+    if (any != all) { fprintf(stderr, "forms of one key disagree\n"); exit(3); }
+    return any;
+}
+
+static TbkWideKey wwindow_key(const Table &t, uint64_t fwd, int pick_last_tie) {
+    const uint64_t rc = tbk_revcomp_packed(fwd, t.k);
+    const int nt = 2 * t.z.w;
+    uint32_t best = 0xFFFFFFFFu;
+    int x = 0;
+    for (int i = 0; i < nt; i++) {
+        const uint32_t r = tbk_tmer_rank(fwd, t.z, i);
+        if (r < best || (pick_last_tie && r == best)) { best = r; x = i; }
+    }
+    const int pos = x % t.z.w;
+    const uint32_t mmask = t.z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * t.z.m)) - 1u);
+    const uint32_t mx = (uint32_t)(fwd >> (2 * (t.z.o + pos))) & mmask;
+    const uint32_t my = (uint32_t)(rc >> (2 * (t.z.o + t.z.w - 1 - pos))) & mmask;
+    const bool f = mx < my;
+    return tbk_wentry_key(f ? fwd : rc, t.z, t.g, f ? pos : t.z.w - 1 - pos);
+}
+
 // every (tied position, orientation) form of a list key
 static int forms_of(const Table &t, uint64_t key, TbkEntryKey *out) {
     const int nt = 2 * t.z.w;
@@ -62,7 +125,9 @@ static int forms_of(const Table &t, uint64_t key, TbkEntryKey *out) {
     return n;
 }
 
+static bool wcontains(const Table &t, uint32_t half, uint64_t key);
 static bool contains(const Table &t, uint32_t half, uint64_t key) {
+    if (t.wide) return wcontains(t, half, key);
     TbkEntryKey f[64];
     const int n = forms_of(t, key, f);
     bool any = false, all = true;
@@ -74,6 +139,12 @@ static bool contains(const Table &t, uint32_t half, uint64_t key) {
 static void insert_key(Table &t, uint32_t half, uint64_t key, const Table *skip_in_a) {
     if (key != canon(key, t.k)) return;  // a non-canonical list line is dead in the reference (c/kmers.c:113 vs 251-255)
     if (skip_in_a && contains(*skip_in_a, 0, key)) return;
+    if (t.wide) {
+        TbkWideKey wf[64];
+        const int wn = wforms_of(t, key, wf);
+        for (int i = 0; i < wn; i++) winsert_form(t, half, wf[i]);
+        return;
+    }
     TbkEntryKey f[64];
     const int n = forms_of(t, key, f);
     for (int i = 0; i < n; i++) insert_form(t, half, f[i]);
@@ -103,11 +174,13 @@ int main(int argc, char **argv) {
     const int w_want = argc > 2 ? atoi(argv[2]) : 6;
     const uint64_t seed = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1;
     const int crowd = argc > 4 ? atoi(argv[4]) : 0;  // 1: a table so small that lines overflow
+    const int wide = argc > 5 ? atoi(argv[5]) : 0;   // 1: wide entries (16 bytes), m = 16
     std::mt19937_64 rng(seed);
     Table t;
     t.k = k;
-    t.z = tbk_mz_params(k, w_want, 1000000, 0, 1);
-    if (!tbk_entry_geom(k, t.z, &t.g)) { printf("k=%d w=%d: no entry layout (w=%d m=%d o=%d t=%d)\n", k, w_want, t.z.w, t.z.m, t.z.o, t.z.t); return 0; }
+    t.wide = wide != 0;
+    t.z = tbk_mz_params(k, w_want, 1000000, wide ? 16 : 0, 1);
+    if (!(wide ? tbk_wentry_geom(k, t.z, &t.g) : tbk_entry_geom(k, t.z, &t.g))) { printf("k=%d w=%d: no entry layout (w=%d m=%d o=%d t=%d)\n", k, w_want, t.z.w, t.z.m, t.z.o, t.z.t); return 0; }
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     // a genome with SNPs between two haplotypes, low-complexity stretches and a repeated segment
     const int G = 60000;
@@ -133,7 +206,7 @@ int main(int argc, char **argv) {
     for (uint64_t x : list_a) if (x == canon(x, k)) set_a.insert(x);
     for (uint64_t x : list_b) if (x == canon(x, k) && !set_a.count(x)) set_b.insert(x);
     const uint64_t n_keys = set_a.size() + set_b.size();
-    t.n_buckets = crowd ? (uint32_t)(n_keys / 12 + 7) : (uint32_t)(n_keys / 4 + 16);
+    t.n_buckets = crowd ? (uint32_t)(n_keys / (wide ? 6 : 12) + 7) : (uint32_t)(n_keys / (wide ? 2 : 4) + 16);
     t.slots.assign((size_t)t.n_buckets * 16, 0);
     for (uint64_t x : list_a) insert_key(t, 0, x, nullptr);
     for (uint64_t x : list_b) insert_key(t, 8, x, &t);
@@ -151,14 +224,20 @@ int main(int argc, char **argv) {
             for (int i = 0; i + k <= G; i++) {
                 const uint64_t fwd = kmer_at(r, i), key = canon(fwd, k);
                 const int tie = (int)(rng() & 1);
-                const TbkEntryKey e = window_key(t, fwd, tie);
-                const bool in_a = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 0, e), in_b = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 8, e);
+                bool in_a, in_b;
+                if (t.wide) {
+                    const TbkWideKey e = wwindow_key(t, fwd, tie);
+                    in_a = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, 0, e); in_b = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, 8, e);
+                } else {
+                    const TbkEntryKey e = window_key(t, fwd, tie);
+                    in_a = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 0, e); in_b = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 8, e);
+                }
                 if (in_a != (set_a.count(key) != 0) || in_b != (set_b.count(key) != 0)) bad++;
                 windows++; hits_a += in_a; hits_b += in_b;
             }
         }
-    printf("k=%d w=%d m=%d o=%d t=%d fl=%d crowd=%d: %llu keys in %llu entries (%llu merges), %u buckets, %llu behind a front, %llu past a line; %llu windows, %llu / %llu hits; mismatches %llu\n",
-           k, t.z.w, t.z.m, t.z.o, t.z.t, t.g.fl, crowd, (unsigned long long)n_keys, (unsigned long long)t.entries, (unsigned long long)t.merged, t.n_buckets,
+    printf("%sk=%d w=%d m=%d o=%d t=%d fl=%d crowd=%d: %llu keys in %llu entries (%llu merges), %u buckets, %llu behind a front, %llu past a line; %llu windows, %llu / %llu hits; mismatches %llu\n",
+           wide ? "wide " : "", k, t.z.w, t.z.m, t.z.o, t.z.t, t.g.fl, crowd, (unsigned long long)n_keys, (unsigned long long)t.entries, (unsigned long long)t.merged, t.n_buckets,
            (unsigned long long)t.behind, (unsigned long long)t.past, (unsigned long long)windows, (unsigned long long)hits_a, (unsigned long long)hits_b, (unsigned long long)bad);
     return bad ? 1 : 0;
 }

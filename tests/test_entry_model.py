@@ -25,8 +25,16 @@ def test_entry_model_equals_set_membership(model, k, w, crowd):
         assert "mismatches 0" in r.stdout and "no entry layout" not in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("k,w,crowd", [(31, 8, 0), (31, 8, 1), (31, 6, 1), (32, 7, 1), (29, 8, 0), (27, 6, 1), (26, 7, 0), (21, 6, 1)])
+def test_wide_entry_model_equals_set_membership(model, k, w, crowd):
+    for seed in (1, 2):
+        r = subprocess.run([model, str(k), str(w), str(seed), str(crowd), "1"], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert r.stdout.startswith("wide ") and "mismatches 0" in r.stdout and "no entry layout" not in r.stdout, r.stdout
+
+
 def test_entry_geometry_limits(model):
-    # k = 27 and beyond: the flanks no longer fit an entry's 30 bits at any useful span - the key layouts stay
+    # k = 27 and beyond: the flanks no longer fit a narrow entry's 31 bits at any useful span - those get wide entries
     for k in (27, 31, 32):
         r = subprocess.run([model, str(k), "6", "1", "0"], capture_output=True, text=True)
         assert r.returncode == 0 and "no entry layout" in r.stdout, r.stdout

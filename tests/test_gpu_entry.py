@@ -40,9 +40,13 @@ def _genome_lists(rng, k, n_loci, snp_every=150, genome=40_000):
     return sa, sb, la[:n_loci], lb[:n_loci]
 
 
-@pytest.mark.parametrize("k,w", [(21, 7), (21, 6), (21, 5), (21, 4), (22, 7), (22, 6), (23, 6), (23, 5), (24, 5), (25, 4)])
+NARROW = [(21, 7, 0), (21, 6, 0), (21, 5, 0), (21, 4, 0), (22, 7, 0), (22, 6, 0), (23, 6, 0), (23, 5, 0), (24, 5, 0), (25, 4, 0)]
+WIDE = [(31, 8, 1), (31, 6, 1), (32, 7, 1), (29, 8, 1), (27, 6, 1), (26, 7, 1), (21, 6, 1), (24, 7, 1)]   # wide entries (16 bytes): k up to 32, and any k when asked for
+
+
+@pytest.mark.parametrize("k,w,wide", NARROW + WIDE)
 @pytest.mark.parametrize("crowded", [0, 1])
-def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, crowded):
+def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, wide, crowded):
     """Lists of runs (two haplotypes' unique k-mers), uniform keys, duplicate lines, lines shared between the lists on
     either strand, non-canonical lines (dead in the reference), low-complexity and palindromic sequence; reads drawn
     from both haplotypes on both strands with errors, ragged shapes, bytes outside ACGT - in a roomy table and in one
@@ -52,9 +56,12 @@ def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k
     rng = np.random.default_rng(100 * k + 10 * w + crowded)
     monkeypatch.setenv("TBK_ENTRY", "1")
     monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
-    if (k, w) == (21, 7):
+    if (k, w, wide) == (21, 7, 0):
         monkeypatch.setenv("TBK_MINIMIZER_M", "15")   # the longest span k = 21 has room for: seven 15-mers, flanks and V bits fill an entry's 31 bits
     monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5" if crowded else "0.3")   # crowded: 5.5 entries per list and bucket of 8 slots
+    monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.2")  # wide entries: four per list and line
+    if wide:
+        monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
     monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
     sa, sb, la, lb = _genome_lists(rng, k, 6000)
     uni = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(1500)]
@@ -91,27 +98,32 @@ def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k
     assert want.sum() > 2000
     with kmers.Classifier(a, b) as cls:
         st = cls.stats()
-        assert st["entry_layout"] and st["minimizer_w"] == w and st["sampling_t"] > 0, st
+        assert st["entry_layout"] and st["wide_entries"] == bool(wide) and st["minimizer_w"] == w and st["sampling_t"] > 0, st
         assert st["entries_a"] + st["entries_b"] < st["distinct_a"] + st["distinct_b"], st     # runs merged
         if crowded:
             assert st["keys_behind_front"] > 0 and st["keys_past_half"] > 0, st                # second looks and walks happen
         got = cls.classify_batch(bases, offs)
         again = cls.classify_batch(bases, offs)
     bad = np.nonzero((got != want).any(axis=1))[0]
-    assert bad.size == 0, (k, w, crowded, st, bad[:10], got[bad[:5]], want[bad[:5]], [len(reads[int(i)]) for i in bad[:5]])
+    assert bad.size == 0, (k, w, wide, crowded, st, bad[:10], got[bad[:5]], want[bad[:5]], [len(reads[int(i)]) for i in bad[:5]])
     assert np.array_equal(again, want)
 
 
-def test_entry_layout_on_the_reference_vectors(gpu, monkeypatch):
-    """The recorded counts of the real reference (tests/golden/diff_vectors.json, k = 21) through the entry layout."""
+@pytest.mark.parametrize("k,wide", [(21, 0), (21, 1), (27, 1), (31, 1), (32, 1)])
+def test_entry_layout_on_the_reference_vectors(gpu, monkeypatch, k, wide):
+    """The recorded counts of the real reference (tests/golden/diff_vectors.json) through the entry layouts: k = 21 in
+    narrow and in wide entries, k = 27, 31, 32 in wide ones."""
     from trio_binning_amd import kmers
 
-    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == 21)
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == k)
     monkeypatch.setenv("TBK_ENTRY", "1")
-    a = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_a"]], dtype=np.uint64), 21)
-    b = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_b"]], dtype=np.uint64), 21)
+    if wide:
+        monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
+    a = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_a"]], dtype=np.uint64), k)
+    b = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_b"]], dtype=np.uint64), k)
     with kmers.Classifier(a, b) as cls:
-        assert cls.stats()["entry_layout"]
+        st = cls.stats()
+        assert st["entry_layout"] and st["wide_entries"] == bool(wide), st
         got = cls.classify_reads(v["reads"])
     assert np.array_equal(got, np.array(v["counts"], dtype=np.int32))
 
@@ -119,13 +131,13 @@ def test_entry_layout_on_the_reference_vectors(gpu, monkeypatch):
 def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
     """The policy: lists shaped like find-unique-kmers output overflow the fronts of the key layout and are rebuilt as
     entries - a quarter of the slots, under 50 bytes of HBM per key; uniform lists stay in the key layout's front.  Where
-    the entry layout cannot be had (k = 31) clustered lists get whole lines, as before."""
+    a k-mer's context does not fit a slot (k = 31) the entries are wide ones."""
     import ctypes as C
 
     from trio_binning_amd import kmers
     from trio_binning_amd._lib import check, lib
 
-    for v in ("TBK_ENTRY", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_ENTRY_LOAD"):
+    for v in ("TBK_ENTRY", "TBK_ENTRY_WIDE", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_ENTRY_LOAD", "TBK_WENTRY_LOAD"):
         monkeypatch.delenv(v, raising=False)
     dev, n = 0, 400_000
     rng = np.random.default_rng(3)
@@ -150,7 +162,7 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
     def decode(key, k):
         return "".join("ACGT"[(int(key) >> (2 * i)) & 3] for i in range(k))
 
-    for k, want_entry in ((21, True), (23, True), (31, False)):
+    for k, want_entry in ((21, True), (23, True), (31, True)):
         ka, kb = hap_lists(k)
         oa, ob = orc.table_from_keys(ka, k), orc.table_from_keys(kb, k)
         plants = [decode(x, k) for x in np.concatenate([ka[:300], kb[:300]])]
@@ -159,12 +171,12 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
         a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
         with kmers.Classifier(a, b) as cls:
             st = cls.stats()
-            assert st["entry_layout"] == want_entry, (k, st)
+            assert st["entry_layout"] == want_entry and st["wide_entries"] == (k > 25), (k, st)
             if want_entry:
                 keys, entries = st["distinct_a"] + st["distinct_b"], st["entries_a"] + st["entries_b"]
                 assert keys > 3 * entries, (k, st)                          # a variant's windows: one entry per sampled m-mer
-                assert st["table_bytes"] <= 51 * (ka.size + kb.size), (k, st)
-                assert st["keys_behind_front"] <= 0.05 * entries, (k, st)   # two-slot fronts hold them
+                assert st["table_bytes"] <= (51 if k <= 25 else 140) * (ka.size + kb.size), (k, st)
+                assert st["keys_behind_front"] <= (0.05 if k <= 25 else 0.15) * entries, (k, st)   # the fronts hold them (wide entries: one per list in the front)
             else:
                 assert not st["front_layout"], (k, st)
             assert np.array_equal(cls.classify_batch(bases, offs), want), k

@@ -478,6 +478,100 @@ TBK_HD bool tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint
     return false;
 }
 
+// ---- wide entries: the entry layout for k-mers too long for 64 bits of context (k up to 32) -----------------------
+// A k-mer plus its neighbours under one sampled m-mer is k + w - 1 bases: 26 at k = 21, 38 at k = 31 - more than a slot.
+// A WIDE entry is two slots, one 16-byte piece of the line (what one lane loads):
+//     word 0   bits [0, 32)  the canonical m-mer (m <= 16: the 32-bit arithmetic serves tables of any size, because the
+//                            m-mers only have to outnumber the ENTRIES);  bit 32  "taken";  bit 63  lock (build only)
+//     word 1   bits [0, 4 FL)  the flank field, laid out as in a narrow entry;  bits [4 FL, +w)  V;  bit 63  the slot's flag
+// and a window matches iff word 0's m-mer is its own and (word 1 ^ k1) & m1 == 0 - two v_bfi and one 64-bit compare
+// beside the 32-bit one.  A line is eight pieces [A0 | B0 | A1 A2 A3 | B1 B2 B3]: the front is still 32 bytes and the
+// probe still pair-cooperative, with ONE entry per list in the front (the same piece offsets as the narrow layout's:
+// pieces 0, 1 the fronts, 2..4 hapA's back, 5..7 hapB's; flags in bit 63 of word 1 of a list's piece 0 "entries behind
+// the front" and of its last piece "an entry went past this line").  There is no 128-bit compare-and-swap: an insert
+// takes the piece's lock (bit 63 of word 0) to check that its flanks agree with the entry's and ORs them in.
+#define TBK_FLAG_WIDE 8u     // `guests` word: the entry table holds wide entries (with TBK_FLAG_ENTRY)
+#define TBK_WENTRY_TAKEN 0x0000000100000000ull
+#define TBK_WENTRY_LOCK 0x8000000000000000ull
+#define TBK_WENTRY_FLAG 0x8000000000000000ull
+
+TBK_HD bool tbk_wentry_geom(int k, TbkMz z, TbkEntryGeom *g) {
+    if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
+    const int fl = z.o + z.w - 1;
+    if (4 * fl + z.w > 62 || 2 * (k - z.m) > 32) return false;  // (a window's flank bases fit 32 bits: k - m <= 16)
+    g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
+    return true;
+}
+
+struct TbkWideKey { uint32_t cm; uint64_t k1, m1; };
+
+TBK_HD TbkWideKey tbk_wentry_key(uint64_t oriented, TbkMz z, TbkEntryGeom g, int pos) {
+    const int a = 2 * (z.o + pos);
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    TbkWideKey e;
+    e.cm = (uint32_t)(oriented >> a) & mmask;
+    const uint64_t low = oriented & ((1ull << a) - 1ull);
+    const uint64_t high = a + 2 * z.m >= 64 ? 0ull : (oriented >> (a + 2 * z.m));
+    const uint64_t fw = low | (high << a);                      // 2 (k - m) <= 32 bits
+    const int sh = 2 * (z.w - 1 - pos);
+    const uint64_t vbit = 1ull << (g.vshift + pos);
+    const uint64_t fmask = g.fbits >= 64 ? ~0ull : ((1ull << g.fbits) - 1ull);
+    e.k1 = (fw << sh) | vbit;
+    e.m1 = (fmask << sh) | vbit;
+    return e;
+}
+
+TBK_HD bool tbk_wentry_match(uint64_t w0, uint64_t w1, TbkWideKey e) {
+    return (uint32_t)w0 == e.cm && (w0 & TBK_WENTRY_TAKEN) != 0 && ((w1 ^ e.k1) & e.m1) == 0;
+}
+
+TBK_HD uint64_t tbk_wentry_defined(uint64_t w1, TbkMz z, TbkEntryGeom g) {
+    uint64_t d = 0;
+    const uint64_t fmask = g.fbits >= 64 ? ~0ull : ((1ull << g.fbits) - 1ull);
+    for (int p = 0; p < z.w; p++)
+        if ((w1 >> (g.vshift + p)) & 1ull) d |= fmask << (2 * (z.w - 1 - p));
+    return d;
+}
+
+TBK_HD bool tbk_wentry_compatible(uint64_t w0, uint64_t w1, TbkWideKey e, TbkMz z, TbkEntryGeom g) {
+    if ((uint32_t)w0 != e.cm) return false;
+    const uint64_t mine = e.m1 & ((1ull << g.vshift) - 1ull);
+    return ((w1 ^ e.k1) & mine & tbk_wentry_defined(w1, z, g)) == 0;
+}
+
+// the 16-byte piece (in slots: 2 x piece) of a list's entry number e (0 .. 3) in its line
+TBK_HD uint32_t tbk_wepiece_at(uint32_t half, uint32_t e) {
+    const uint32_t b = half ? 1u : 0u;
+    return e == 0 ? b : 2u + 3u * b + (e - 1u);
+}
+
+TBK_HD int tbk_wentry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g, int p, TbkWideKey *out) {
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    const uint32_t x = (uint32_t)(key >> (2 * (z.o + p))) & mmask;
+    const uint32_t y = tbk_revcomp32(x, z.m);
+    int n = 0;
+    if (x <= y) out[n++] = tbk_wentry_key(key, z, g, p);
+    if (x >= y) out[n++] = tbk_wentry_key(tbk_revcomp_packed(key, k), z, g, z.w - 1 - p);
+    return n;
+}
+
+TBK_HD bool tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkWideKey e) {
+    uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+    for (uint32_t walked = 0; walked <= n_buckets; walked++) {
+        const uint64_t *line = slots + (uint64_t)b * 16;
+        uint64_t last1 = 0;
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint64_t w0 = line[2 * tbk_wepiece_at(half, i)], w1 = line[2 * tbk_wepiece_at(half, i) + 1];
+            if (!(w0 & TBK_WENTRY_TAKEN)) return false;  // first empty piece of the list in this line
+            if (tbk_wentry_match(w0, w1, e)) return true;
+            last1 = w1;
+        }
+        if (!(last1 >> 63)) return false;                // nothing went past this line
+        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+    }
+    return false;
+}
+
 // ---- synthetic key sequence (bench inputs) ---------------------------------
 // Key i of `seed` is a k-mer whose k-2 middle bases are a bijective scramble of i over
 // 2(k-2) bits (distinct i -> distinct k-mer) and whose end bases (b0, b_{k-1}) satisfy

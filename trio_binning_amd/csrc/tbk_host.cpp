@@ -36,7 +36,7 @@ extern "C" hipError_t tbk_launch_order(uint64_t *, uint64_t, const uint32_t *, c
 extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, const uint64_t *, uint64_t, uint32_t *, uint32_t *, uint32_t, TbkTableView,
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
-extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, int, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_entry_contains(const uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
@@ -1100,7 +1100,7 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     for (int list = 0; list < 2 && e == hipSuccess; list++) {
         const tbk_table *t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
-        if (e == hipSuccess) e = tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr);
+        if (e == hipSuccess) e = tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, (c->guests & TBK_FLAG_WIDE) != 0, d_cnt, d_failed, nullptr);
         if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished half)
     }
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
@@ -1187,18 +1187,29 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (pin == 0 || w_pin == 0 || c->k > 32) return false;
         TbkMz z{0, 0, 0, 0};
         TbkEntryGeom g;
-        bool ok = false;
-        for (int w = (w_pin > 0 ? w_pin : 6); w >= (w_pin > 0 ? w_pin : 4) && !ok; w--) {
-            z = tbk_mz_params(c->k, w, n_big, m_force, 1);
-            ok = z.w == w && tbk_entry_geom(c->k, z, &g);
-        }
+        bool ok = false, wide = false;
+        if (env_double("TBK_ENTRY_WIDE", 0) <= 0)
+            for (int w = (w_pin > 0 ? w_pin : 6); w >= (w_pin > 0 ? w_pin : 4) && !ok; w--) {
+                z = tbk_mz_params(c->k, w, n_big, m_force, 1);
+                ok = z.w == w && tbk_entry_geom(c->k, z, &g);
+            }
+        // k-mers too long for a slot's worth of context (k > 25: a k-mer and its neighbours under one m-mer are k + w - 1
+        // bases): WIDE entries, 16 bytes, with 16-mers whatever the lists' size - the m-mers only have to outnumber the
+        // entries - and the longest span k's parity allows, 8 down to 6 (tbk_common.h "wide entries").  One entry per list
+        // in the front: 0.2 entries per list and bucket (TBK_WENTRY_LOAD).  TBK_ENTRY_WIDE=1 asks for them at any k.
+        if (!ok && env_double("TBK_ENTRY_WIDE", -1) != 0)
+            for (int w = (w_pin > 0 ? w_pin : 8); w >= (w_pin > 0 ? w_pin : 6) && !ok; w--) {
+                z = tbk_mz_params(c->k, w, n_big, m_force > 0 ? m_force : 16, 1);
+                ok = wide = z.w == w && z.m <= 16 && tbk_wentry_geom(c->k, z, &g);
+            }
         if (!ok) return false;
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
-        const double el = std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.40)));  // (tests crowd the lines: 8 slots per list)
+        const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.20)))   // (four entries per list and line)
+                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.40)));  // (tests crowd the lines: 8 slots per list)
         c->mz = z;
-        c->guests = TBK_FLAG_ENTRY;
-        double want = (double)n_big / (4.0 * el);
+        c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
+        double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);
         for (int attempt = 0; attempt < 2; attempt++) {
             uint64_t nb = (uint64_t)want + 16;
             size_t free_b = 0, total_b = 0;
@@ -1373,7 +1384,7 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
 
 extern "C" int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
-    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_ENTRY) ? 1 : 0;
+    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_ENTRY) ? ((c->guests & TBK_FLAG_WIDE) ? 2 : 1) : 0;
     if (entries_a) *entries_a = c->entries_a;
     if (entries_b) *entries_b = c->entries_b;
     return TBK_OK;

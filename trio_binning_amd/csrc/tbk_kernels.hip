@@ -225,6 +225,79 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
     if (past) atomicAdd(&cnt[4], past);
 }
 
+// The same for wide entries (tbk_common.h "wide entries").  An entry is two words and there is no 128-bit compare-and-swap:
+// a form takes the piece's lock (bit 63 of word 0, by CAS on that word) to look at word 1, and ORs its flank bits in when
+// they agree with the entry's.  Every change of word 1 is an OR - the flags other threads set in it meanwhile are never
+// lost - and a lock is held for a handful of instructions inside ONE trip of the loop: the lanes of a wave that wait for
+// it wait for a lane that is not waiting for them.  Finished tables hold no lock.
+__global__ void __launch_bounds__(256)
+tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
+                         const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
+    const int n_pos = 2 * mz.w;
+    for (; i < n; i += step) {
+        const uint64_t key = keys[i];
+        if (key >= TBK_NOKEY) continue;
+        if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
+        uint32_t best = 0xFFFFFFFFu;
+        for (int pi = 0; pi < n_pos; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); best = r < best ? r : best; }
+        bool first_form = true, drop = false;
+        for (int pi = 0; pi < n_pos && !drop; pi++) {
+            if (tbk_tmer_rank(key, mz, pi) != best) continue;
+            TbkWideKey forms[2];
+            const int nf = tbk_wentry_orientations(key, k, mz, g, pi % mz.w, forms);
+            for (int f = 0; f < nf; f++) {
+                const TbkWideKey e = forms[f];
+                if (first_form && skip_a && tbk_wentry_lookup_one(slots, n_buckets, 0, e)) { skipped++; drop = true; break; }
+                const unsigned long long taken = (unsigned long long)e.cm | TBK_WENTRY_TAKEN;
+                uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+                bool done = false;
+                for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
+                    unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
+                    for (uint32_t en = 0; en < 4 && !done; en++) {
+                        unsigned long long *w0 = &line[2 * tbk_wepiece_at(half, en)], *w1 = w0 + 1;
+                        bool next_piece = false;
+                        while (!done && !next_piece) {
+                            const unsigned long long cur = __hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            if (cur & TBK_WENTRY_LOCK) continue;                                   // somebody is looking at this piece: again
+                            if (cur != 0 && (uint32_t)cur != e.cm) { next_piece = true; break; }  // another m-mer's entry
+                            // empty, or an entry of my m-mer: take the lock (the empty piece becomes mine with it)
+                            if (atomicCAS(w0, cur, (cur == 0 ? taken : cur) | TBK_WENTRY_LOCK) != cur) continue;
+                            const unsigned long long v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (cur == 0) {
+                                atomicOr(w1, (unsigned long long)e.k1);
+                                created++; stored += first_form; done = true;
+                            } else if (tbk_wentry_compatible(cur, v1, e, mz, g)) {
+                                if (!tbk_wentry_match(cur, v1, e)) { atomicOr(w1, (unsigned long long)e.k1); stored += first_form; }
+                                done = true;
+                            } else {
+                                next_piece = true;  // (stays incompatible: entries only gain bits)
+                            }
+                            __threadfence();
+                            __hip_atomic_store(w0, cur == 0 ? taken : cur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // unlock
+                            if (done && cur == 0 && en >= 1) { behind++; atomicOr(&line[2 * tbk_wepiece_at(half, 0) + 1], (unsigned long long)TBK_WENTRY_FLAG); }
+                        }
+                    }
+                    if (!done) {
+                        atomicOr(&line[2 * tbk_wepiece_at(half, 3) + 1], (unsigned long long)TBK_WENTRY_FLAG);
+                        past++;
+                        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+                    }
+                }
+                if (!done) atomicExch(failed, 1);
+                first_form = false;
+            }
+        }
+    }
+    if (stored) atomicAdd(&cnt[0], stored);
+    if (skipped) atomicAdd(&cnt[1], skipped);
+    if (created) atomicAdd(&cnt[2], created);
+    if (behind) atomicAdd(&cnt[3], behind);
+    if (past) atomicAdd(&cnt[4], past);
+}
+
 // raw-key membership in a finished entry-layout table (tests; tbk_count_kmers_in_read never uses it)
 __global__ void __launch_bounds__(256)
 tbk_entry_contains_kernel(const uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
@@ -1190,7 +1263,20 @@ __device__ __forceinline__ TbkEntryKey entry_key_of(uint32_t cm, uint32_t khi, i
     return e;
 }
 
-__device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, TbkEntryKey e, uint32_t bucket, bool pend) {
+// wide entries (tbk_common.h): the queues carry the 64-bit flank word instead - walk entry: x = m-mer, (y, z) = k1, w = home
+// bucket | list << 30; back entry: w = home bucket | flags << 30; the read of a queued window (multi-read passes) in a
+// 16-bit array beside the queue
+__device__ __forceinline__ TbkWideKey wide_key_of(uint32_t cm, uint64_t k1, int w, int fbits, int vshift) {
+    const uint32_t v = (uint32_t)(k1 >> vshift);              // exactly one V bit
+    const int pos = 31 - (int)__clz(v);
+    TbkWideKey e;
+    e.cm = cm; e.k1 = k1;
+    e.m1 = (((fbits >= 64 ? ~0ull : ((1ull << fbits) - 1ull))) << (2 * (w - 1 - pos))) | (1ull << (vshift + pos));
+    return e;
+}
+
+template <bool WIDE, class KEY>
+__device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, KEY e, uint32_t bucket, bool pend) {
     bool found = false, first = true;
     uint32_t guard = 0;
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
@@ -1201,56 +1287,81 @@ __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t hal
             bool hit = false, ended = false;
             uint64_t last = 0;
 #pragma unroll 1
-            for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {
+            for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {  // (the list's four 16-byte pieces of the line: the same places in both entry layouts)
                 const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + tbk_eslot_at(half, sl));
-                hit = hit || tbk_entry_match(v.x, e) || tbk_entry_match(v.y, e);
-                ended = (v.y << 1) == 0;  // an empty slot: the list ends in this line
+                if constexpr (WIDE) {
+                    hit = hit || tbk_wentry_match(v.x, v.y, e);
+                    ended = (v.x & TBK_WENTRY_TAKEN) == 0;
+                } else {
+                    hit = hit || tbk_entry_match(v.x, e) || tbk_entry_match(v.y, e);
+                    ended = (v.y << 1) == 0;  // an empty slot: the list ends in this line
+                }
                 last = v.y;
             }
             found = found || hit;
-            pend = !hit && !ended && (last >> 63) != 0;  // all eight taken and an entry went past them
+            pend = !hit && !ended && (last >> 63) != 0;  // all taken and an entry went past them
         }
     }
     return found;
 }
 
-template <bool MULTI>
-__device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint4 *q, uint32_t qn, uint64_t r_first, uint32_t lane,
+template <bool MULTI, bool WIDE>
+__device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint4 *q, const uint16_t *qr, uint32_t qn, uint64_t r_first, uint32_t lane,
                                                   int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     for (uint32_t base = 0; base < qn; base += 64) {
         const bool act = base + lane < qn;
-        uint4 it = make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
-        if (act) it = q[base + lane];
-        const bool found = walk_one_entry(p.t, (it.w & 1u) * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act);
-        const bool count_a = found && !(it.w & 1u), count_b = found && (it.w & 1u);
+        uint4 it = WIDE ? make_uint4(TBK_ENTRY_NO_MMER, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint32_t rrel = 0;
+        if (act) { it = q[base + lane]; if (WIDE && MULTI) rrel = qr[base + lane]; }
+        bool found;
+        uint32_t list;
+        if constexpr (WIDE) {
+            const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
+            list = (it.w >> 30) & 1u;
+            found = walk_one_entry<true>(p.t, list * 8u, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act);
+        } else {
+            list = it.w & 1u;
+            rrel = it.w >> 1;
+            found = walk_one_entry<false>(p.t, list * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act);
+        }
+        const bool count_a = found && !list, count_b = found && list;
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(ballot(count_a));
             acc_b += (uint32_t)__popcll(ballot(count_b));
         } else {
-            if (count_a) count_hits(p, rcnt, r_first, it.w >> 1, 0, 1);
-            if (count_b) count_hits(p, rcnt, r_first, it.w >> 1, 1, 1);
+            if (count_a) count_hits(p, rcnt, r_first, rrel, 0, 1);
+            if (count_b) count_hits(p, rcnt, r_first, rrel, 1, 1);
         }
     }
 }
 
-// eight queued windows at a time, eight lanes per window: lanes 0..2 hold hapA's slots 2..7 of the home line, lanes 3..5
-// hapB's (16 bytes each, the line's bytes 32..127), lanes 6 and 7 nothing
-template <bool MULTI>
-__device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, uint32_t qb, uint4 *walkq, uint32_t &qn, uint64_t r_first,
-                                                 uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+// eight queued windows at a time, eight lanes per window: lanes 0..2 hold hapA's pieces behind the front of the home line,
+// lanes 3..5 hapB's (16 bytes each, the line's bytes 32..127: two slots of the narrow layout, one wide entry), lanes 6 and 7 nothing
+template <bool MULTI, bool WIDE>
+__device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, const uint16_t *bqr, uint32_t qb, uint4 *walkq, uint16_t *walkr, uint32_t &qn,
+                                                 uint64_t r_first, uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     const uint32_t sub = lane & 7u, oct = lane >> 3;
     for (uint32_t base = 0; base < qb; base += 8) {
         const bool act = base + oct < qb;
-        uint4 it = make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint4 it = WIDE ? make_uint4(TBK_ENTRY_NO_MMER, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint32_t rrel = 0;
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) {
             it = bq[base + oct];
-            if (sub < 6) v = load_slots(p.t.slots + (uint64_t)(it.z & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
+            if (WIDE && MULTI) rrel = bqr[base + oct];
+            if (sub < 6) v = load_slots(p.t.slots + (uint64_t)((WIDE ? it.w : it.z) & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
         }
-        const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
-        const uint64_t hit = ballot(tbk_entry_match(v.x, e)) | ballot(tbk_entry_match(v.y, e));
+        uint64_t hit;
+        if constexpr (WIDE) {
+            const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
+            hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift)));
+        } else {
+            rrel = it.w;
+            const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
+            hit = ballot(tbk_entry_match(v.x, e)) | ballot(tbk_entry_match(v.y, e));
+        }
         const uint64_t hit_a = hit & 0x0707070707070707ull, hit_b = hit & 0x3838383838383838ull;
-        // lane 2 holds hapA's slot 7 in .y, lane 5 hapB's: bit 63 = an entry of the list went past this line
+        // lane 2 holds hapA's last piece, lane 5 hapB's: bit 63 of its second word = an entry of the list went past this line
         const uint64_t gone = ballot((v.y >> 63) != 0);
         const uint64_t any = hit_a | hit_b;
         const uint64_t oct_hit = (any | (any >> 1) | (any >> 2) | (any >> 3) | (any >> 4) | (any >> 5)) & 0x0101010101010101ull;
@@ -1259,19 +1370,25 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             acc_a += (uint32_t)__popcll(hit_a);
             acc_b += (uint32_t)__popcll(hit_b);
         } else {
-            if ((hit_a >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w, 0, 1);
-            if ((hit_b >> lane) & 1ull) count_hits(p, rcnt, r_first, it.w, 1, 1);
+            if ((hit_a >> lane) & 1ull) count_hits(p, rcnt, r_first, rrel, 0, 1);
+            if ((hit_b >> lane) & 1ull) count_hits(p, rcnt, r_first, rrel, 1, 1);
         }
         const uint64_t queued = walk_a | walk_b;
         if (queued) {
             const uint64_t me = 1ull << lane;
             const uint32_t n_a = (uint32_t)__popcll(walk_a);
-            if (walk_a & me) walkq[qn + (uint32_t)__popcll(walk_a & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w << 1);
-            if (walk_b & me) walkq[qn + n_a + (uint32_t)__popcll(walk_b & (me - 1))] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, (it.w << 1) | 1u);
+            const uint32_t at_a = qn + (uint32_t)__popcll(walk_a & (me - 1)), at_b = qn + n_a + (uint32_t)__popcll(walk_b & (me - 1));
+            if constexpr (WIDE) {
+                if (walk_a & me) { walkq[at_a] = make_uint4(it.x, it.y, it.z, it.w & 0x3FFFFFFFu); if (MULTI) walkr[at_a] = (uint16_t)rrel; }
+                if (walk_b & me) { walkq[at_b] = make_uint4(it.x, it.y, it.z, (it.w & 0x3FFFFFFFu) | (1u << 30)); if (MULTI) walkr[at_b] = (uint16_t)rrel; }
+            } else {
+                if (walk_a & me) walkq[at_a] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w << 1);
+                if (walk_b & me) walkq[at_b] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, (it.w << 1) | 1u);
+            }
             qn += n_a + (uint32_t)__popcll(walk_b);
             if (qn > TBK_QCAP_ENTRY - 16) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                drain_walks_entry<MULTI>(p, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+                drain_walks_entry<MULTI, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 qn = 0;
             }
@@ -1279,10 +1396,10 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
     }
 }
 
-template <int W, bool MULTI, bool TWO>
+template <int W, bool MULTI, bool TWO, bool WIDE>
 __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint64_t e0, const uint64_t e1, const uint64_t e2, const uint64_t e3,
                                                  const uint64_t P0, const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                                 uint4 *walkq, uint4 *backq, uint32_t *rcnt) {
+                                                 uint4 *walkq, uint4 *backq, uint16_t *walkr, uint16_t *backr, uint32_t *rcnt) {
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 1u;
@@ -1349,7 +1466,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     const uint32_t fsh_new = (uint32_t)(2 * (o + NW - 1)), bsh_new = (uint32_t)(2 * o);
     // entry geometry
     const int fl = o + W - 1, fbits = 2 * (k - m), vshift = 4 * fl;
-    const uint32_t fmask = (1u << fbits) - 1u;
+    const uint32_t fmask = fbits >= 32 ? 0xFFFFFFFFu : ((1u << fbits) - 1u);
 
     // read bookkeeping (probe_pass)
     const uint64_t p_lane = P0 + (uint64_t)lane * TBK_WPL;
@@ -1429,9 +1546,18 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t high = (uint32_t)(orient >> (a + 2u * (uint32_t)m));
         const uint32_t posp = (a >> 1) - span_o;
         const uint32_t shw = 2u * ((uint32_t)W - 1u - posp);
-        const uint32_t vbit = 1u << ((uint32_t)vshift + posp);
-        const uint32_t my_khi = ((low | (high << a)) << shw) | vbit;
-        const uint32_t my_mhi = (fmask << shw) | vbit;
+        const uint32_t vbit = WIDE ? 0u : 1u << ((uint32_t)vshift + posp);
+        // narrow entries: 32 bits of flanks + V; wide entries: the same field 64 bits wide (the V bit lies in its upper word)
+        uint32_t my_khi, my_mhi, my_khi2 = 0, my_mhi2 = 0;
+        if constexpr (WIDE) {
+            const uint64_t k1 = ((uint64_t)(low | (high << a)) << shw) | (1ull << ((uint32_t)vshift + posp));
+            const uint64_t m1 = ((uint64_t)fmask << shw) | (1ull << ((uint32_t)vshift + posp));
+            my_khi = (uint32_t)k1; my_khi2 = (uint32_t)(k1 >> 32);
+            my_mhi = (uint32_t)m1; my_mhi2 = (uint32_t)(m1 >> 32);
+        } else {
+            my_khi = ((low | (high << a)) << shw) | vbit;
+            my_mhi = (fmask << shw) | vbit;
+        }
         const uint32_t cm_ask = ok ? cm : TBK_ENTRY_NO_MMER;  // an invalid window asks for an m-mer no entry holds
         const bool fresh = ok && bkt != last_bk;
         const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
@@ -1451,14 +1577,26 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t cm_s[2] = {pair_bcast<0>(cm_ask), pair_bcast<1>(cm_ask)};
         const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
         const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
+        uint32_t kh2_s[2] = {0, 0}, mh2_s[2] = {0, 0};
+        if constexpr (WIDE) {
+            kh2_s[0] = pair_bcast<0>(my_khi2); kh2_s[1] = pair_bcast<1>(my_khi2);
+            mh2_s[0] = pair_bcast<0>(my_mhi2); mh2_s[1] = pair_bcast<1>(my_mhi2);
+        }
         uint64_t hit[2], more[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const uint32_t hx = (uint32_t)(va[s].x >> 32), hy = (uint32_t)(va[s].y >> 32);
-            const uint64_t wx = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hx & ~mh_s[s])) << 32);
-            const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
-            hit[s] = ballot(va[s].x == wx) | ballot(va[s].y == wy);
-            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front slot 1: entries behind the front
+            if constexpr (WIDE) {
+                // the lane's piece is ONE entry: word 0 = m-mer | taken, word 1 = flanks + V (+ the piece's flag in bit 63, outside every mask)
+                const uint32_t ly = (uint32_t)va[s].y;
+                const uint64_t want = (uint64_t)((kh_s[s] & mh_s[s]) | (ly & ~mh_s[s])) | ((uint64_t)((kh2_s[s] & mh2_s[s]) | (hy & ~mh2_s[s])) << 32);
+                hit[s] = ballot((uint32_t)va[s].x == cm_s[s]) & ballot(va[s].y == want);  // (an empty piece is all zero: its V bit is missing)
+            } else {
+                const uint64_t wx = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hx & ~mh_s[s])) << 32);
+                const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
+                hit[s] = ballot(va[s].x == wx) | ballot(va[s].y == wy);
+            }
+            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front piece: entries behind the front
         }
         if ((more[0] | more[1]) != 0) {
             // windows that missed in a front with entries behind it: queued by the lane that owns the window
@@ -1476,8 +1614,14 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                 const uint64_t me = 1ull << lane;
                 if (need & me) {
                     const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : TWO ? two_rid() : 0u;
-                    backq[qb + (uint32_t)__popcll(need & (me - 1))] =
-                        make_uint4(cm, my_khi, last_bk | ((uint32_t)((beh_a >> lane) & 1ull) << 30) | ((uint32_t)((beh_b >> lane) & 1ull) << 31), rrel);
+                    const uint32_t at = qb + (uint32_t)__popcll(need & (me - 1));
+                    const uint32_t home = last_bk | ((uint32_t)((beh_a >> lane) & 1ull) << 30) | ((uint32_t)((beh_b >> lane) & 1ull) << 31);
+                    if constexpr (WIDE) {
+                        backq[at] = make_uint4(cm, my_khi, my_khi2, home);
+                        if (MULTI || TWO) backr[at] = (uint16_t)rrel;
+                    } else {
+                        backq[at] = make_uint4(cm, my_khi, home, rrel);
+                    }
                 }
                 qb += (uint32_t)__popcll(need);
             }
@@ -1504,19 +1648,19 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         }
         if (qb > TBK_BQCAP - 64) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            drain_back_entry<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+            drain_back_entry<MULTI || TWO, WIDE>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qb = 0;
         }
     }
     if (qb) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_back_entry<MULTI || TWO>(p, backq, qb, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        drain_back_entry<MULTI || TWO, WIDE>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_walks_entry<MULTI || TWO>(p, walkq, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        drain_walks_entry<MULTI || TWO, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (MULTI) {
@@ -1659,12 +1803,14 @@ tbk_probe_kernel(const ProbeArgs p) {
 }
 
 // The entry layout's probe kernels: the same three (single-read, two-read, multi-read passes) over probe_pass_entry.
-template <int W, bool MULTI, bool TWO = false>
+template <int W, bool MULTI, bool TWO = false, bool WIDE = false>
 __global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
 tbk_probe_entry_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP_ENTRY];
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][TBK_BQCAP];
+    __shared__ uint16_t walkr[TBK_WAVES_PER_BLOCK][WIDE && (MULTI || TWO) ? TBK_QCAP_ENTRY : 1];  // wide entries: the read of a queued window travels beside the queue
+    __shared__ uint16_t backr[TBK_WAVES_PER_BLOCK][WIDE && (MULTI || TWO) ? TBK_BQCAP : 1];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1698,7 +1844,7 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass_entry<W, MULTI, TWO>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], rcnt[wave]);
+        probe_pass_entry<W, MULTI, TWO, WIDE>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
         if (!MULTI) return;  // one pass per block
     }
 }
@@ -1707,13 +1853,14 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
 // launchers (called from tbk_host.cpp)
 // =======================================================================================
 extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
-                                              int skip_a, unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+                                              int skip_a, int wide, unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
     TbkEntryGeom g;
-    if (!tbk_entry_geom(k, mz, &g)) return hipErrorInvalidValue;
+    if (!(wide ? tbk_wentry_geom(k, mz, &g) : tbk_entry_geom(k, mz, &g))) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(tbk_entry_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
+    if (wide) hipLaunchKernelGGL(tbk_wentry_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
+    else hipLaunchKernelGGL(tbk_entry_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
     return hipGetLastError();
 }
 
@@ -1839,9 +1986,10 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0, entry = (t.guests & TBK_FLAG_ENTRY) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
+    const bool wide = (t.guests & TBK_FLAG_WIDE) != 0;
     if (entry) {
         TbkEntryGeom g;
-        if (!tbk_entry_geom(k, t.mz, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
+        if (!(wide ? tbk_wentry_geom(k, t.mz, &g) : tbk_entry_geom(k, t.mz, &g)) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
     }
     // the two-read kernel: one block per possible list entry (fewer two-read passes than reads, and than passes)
     const uint64_t blocks_two = tbk_probe_has_two_read_kernel(t.mz) ? std::min<uint64_t>(n_reads > 1 ? n_reads - 1 : 0, p.n_passes) : 0;  // (the list is the whole batch's: every launch walks all of it)
@@ -1859,16 +2007,27 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
         if (entry) {
-#define TBK_E(N) case N: if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true>), grid_multi, block, 0, stream, p); \
-                         else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false>), grid, block, 0, stream, p); \
-                         else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true>), grid_two, block, 0, stream, p); break;
-            switch (t.mz.w) {
+#define TBK_E(N, WD) case N: if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true, false, WD>), grid_multi, block, 0, stream, p); \
+                         else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, false, WD>), grid, block, 0, stream, p); \
+                         else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true, WD>), grid_two, block, 0, stream, p); break;
+            if (wide) {
+                switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
-                TBK_E(6)
+                    TBK_E(6, true) TBK_E(8, true)
 #else
-                TBK_E(2) TBK_E(3) TBK_E(4) TBK_E(5) TBK_E(6) TBK_E(7)
+                    TBK_E(2, true) TBK_E(3, true) TBK_E(4, true) TBK_E(5, true) TBK_E(6, true) TBK_E(7, true) TBK_E(8, true)
 #endif
-                default: return hipErrorInvalidValue;
+                    default: return hipErrorInvalidValue;
+                }
+            } else {
+                switch (t.mz.w) {
+#ifdef TBK_ONLY_W6
+                    TBK_E(6, false)
+#else
+                    TBK_E(2, false) TBK_E(3, false) TBK_E(4, false) TBK_E(5, false) TBK_E(6, false) TBK_E(7, false)
+#endif
+                    default: return hipErrorInvalidValue;
+                }
             }
 #undef TBK_E
             e = hipGetLastError();
