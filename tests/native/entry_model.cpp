@@ -50,23 +50,24 @@ static void insert_form(Table &t, uint32_t half, TbkEntryKey e) {
     exit(2);
 }
 
-// ---- the same for wide entries (k up to 32): one entry per 16-byte piece, four per list and line ----
+// ---- the same for wide entries (k up to 32): one entry per 16-byte piece, eight pieces per line shared by both lists ----
 static void winsert_form(Table &t, uint32_t half, TbkWideKey e) {
+    const uint32_t hapb = half ? 1 : 0;
     uint32_t b = tbk_entry_bucket(e.cm, t.n_buckets);
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
         uint64_t *line = t.slots.data() + (uint64_t)b * 16;
-        for (uint32_t i = 0; i < 4; i++) {
-            uint64_t &w0 = line[2 * tbk_wepiece_at(half, i)], &w1 = line[2 * tbk_wepiece_at(half, i) + 1];
+        for (uint32_t i = 0; i < 8; i++) {
+            uint64_t &w0 = line[2 * i], &w1 = line[2 * i + 1];
             if (!(w0 & TBK_WENTRY_TAKEN)) {
                 w0 = (uint64_t)e.cm | TBK_WENTRY_TAKEN;
-                w1 |= e.k1;
+                w1 |= e.k1 | (hapb ? TBK_WENTRY_HAPB : 0ull);
                 t.entries++;
-                if (i >= 1) { line[2 * tbk_wepiece_at(half, 0) + 1] |= TBK_WENTRY_FLAG; t.behind++; }
+                if (i >= 2) { line[2 * 1 + 1] |= TBK_WENTRY_FLAG; t.behind++; }
                 return;
             }
-            if (tbk_wentry_compatible(w0, w1, e, t.z, t.g)) { w1 |= e.k1; t.merged++; return; }
+            if (tbk_wentry_compatible(w0, w1, e, hapb, t.z, t.g)) { w1 |= e.k1; t.merged++; return; }
         }
-        line[2 * tbk_wepiece_at(half, 3) + 1] |= TBK_WENTRY_FLAG;
+        line[2 * 7 + 1] |= TBK_WENTRY_FLAG;
         t.past++;
         b = tbk_entry_next_bucket(e.cm, t.n_buckets, b, walked == 0);
     }
@@ -90,7 +91,7 @@ static bool wcontains(const Table &t, uint32_t half, uint64_t key) {
     TbkWideKey f[64];
     const int n = wforms_of(t, key, f);
     bool any = false, all = true;
-    for (int i = 0; i < n; i++) { const bool h = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, half, f[i]); any = any || h; all = all && h; }
+    for (int i = 0; i < n; i++) { const bool h = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, f[i]) == (half ? 1 : 0); any = any || h; all = all && h; }
     if (any != all) { fprintf(stderr, "forms of one key disagree\n"); exit(3); }
     return any;
 }
@@ -227,7 +228,8 @@ int main(int argc, char **argv) {
                 bool in_a, in_b;
                 if (t.wide) {
                     const TbkWideKey e = wwindow_key(t, fwd, tie);
-                    in_a = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, 0, e); in_b = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, 8, e);
+                    const int which = tbk_wentry_lookup_one(t.slots.data(), t.n_buckets, e);
+                    in_a = which == 0; in_b = which == 1;
                 } else {
                     const TbkEntryKey e = window_key(t, fwd, tie);
                     in_a = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 0, e); in_b = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 8, e);

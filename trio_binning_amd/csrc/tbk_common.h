@@ -483,22 +483,27 @@ TBK_HD bool tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint
 // A WIDE entry is two slots, one 16-byte piece of the line (what one lane loads):
 //     word 0   bits [0, 32)  the canonical m-mer (m <= 16: the 32-bit arithmetic serves tables of any size, because the
 //                            m-mers only have to outnumber the ENTRIES);  bit 32  "taken";  bit 63  lock (build only)
-//     word 1   bits [0, 4 FL)  the flank field, laid out as in a narrow entry;  bits [4 FL, +w)  V;  bit 63  the slot's flag
+//     word 1   bits [0, 4 FL)  the flank field, laid out as in a narrow entry;  bits [4 FL, +w)  V;
+//              bit 62  the list (0 hapA, 1 hapB);  bit 63  the piece's flag
 // and a window matches iff word 0's m-mer is its own and (word 1 ^ k1) & m1 == 0 - two v_bfi and one 64-bit compare
-// beside the 32-bit one.  A line is eight pieces [A0 | B0 | A1 A2 A3 | B1 B2 B3]: the front is still 32 bytes and the
-// probe still pair-cooperative, with ONE entry per list in the front (the same piece offsets as the narrow layout's:
-// pieces 0, 1 the fronts, 2..4 hapA's back, 5..7 hapB's; flags in bit 63 of word 1 of a list's piece 0 "entries behind
-// the front" and of its last piece "an entry went past this line").  There is no 128-bit compare-and-swap: an insert
-// takes the piece's lock (bit 63 of word 0) to check that its flanks agree with the entry's and ORs them in.
+// beside the 32-bit one; which list the hit counts for is the entry's bit 62.  A line is eight pieces that BOTH lists
+// fill in order, the front is its first two (32 bytes, pair-cooperative probe as for narrow entries): with one entry per
+// piece, fronts of one entry per list left a quarter of the entries behind them (entries of one list that share a bucket:
+// the same 16-mer at another locus), two pieces for whoever comes first leave a few per cent.  Bit 63 of piece 1's
+// word 1: "more than two entries in this line"; of piece 7's: "an entry went past this line".  There is no 128-bit
+// compare-and-swap: an insert takes the piece's lock (bit 63 of word 0) to check that list and flanks agree with the
+// entry's and ORs its bits in.  The lists are disjoint (hapB keys that hapA holds are left out), so a window matches at
+// most one entry of its line.
 #define TBK_FLAG_WIDE 8u     // `guests` word: the entry table holds wide entries (with TBK_FLAG_ENTRY)
 #define TBK_WENTRY_TAKEN 0x0000000100000000ull
 #define TBK_WENTRY_LOCK 0x8000000000000000ull
 #define TBK_WENTRY_FLAG 0x8000000000000000ull
+#define TBK_WENTRY_HAPB 0x4000000000000000ull
 
 TBK_HD bool tbk_wentry_geom(int k, TbkMz z, TbkEntryGeom *g) {
     if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
     const int fl = z.o + z.w - 1;
-    if (4 * fl + z.w > 62 || 2 * (k - z.m) > 32) return false;  // (a window's flank bases fit 32 bits: k - m <= 16)
+    if (4 * fl + z.w > 61 || 2 * (k - z.m) > 32) return false;  // (a window's flank bases fit 32 bits: k - m <= 16)
     g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
     return true;
 }
@@ -521,6 +526,7 @@ TBK_HD TbkWideKey tbk_wentry_key(uint64_t oriented, TbkMz z, TbkEntryGeom g, int
     return e;
 }
 
+// (whichever list the entry belongs to: bit 62 of w1 says)
 TBK_HD bool tbk_wentry_match(uint64_t w0, uint64_t w1, TbkWideKey e) {
     return (uint32_t)w0 == e.cm && (w0 & TBK_WENTRY_TAKEN) != 0 && ((w1 ^ e.k1) & e.m1) == 0;
 }
@@ -533,16 +539,11 @@ TBK_HD uint64_t tbk_wentry_defined(uint64_t w1, TbkMz z, TbkEntryGeom g) {
     return d;
 }
 
-TBK_HD bool tbk_wentry_compatible(uint64_t w0, uint64_t w1, TbkWideKey e, TbkMz z, TbkEntryGeom g) {
-    if ((uint32_t)w0 != e.cm) return false;
+// may the window `e` of list `hapb` join this entry?  Same m-mer, same list, and the flanks agree wherever both define them.
+TBK_HD bool tbk_wentry_compatible(uint64_t w0, uint64_t w1, TbkWideKey e, uint32_t hapb, TbkMz z, TbkEntryGeom g) {
+    if ((uint32_t)w0 != e.cm || ((w1 >> 62) & 1ull) != (uint64_t)(hapb ? 1 : 0)) return false;
     const uint64_t mine = e.m1 & ((1ull << g.vshift) - 1ull);
     return ((w1 ^ e.k1) & mine & tbk_wentry_defined(w1, z, g)) == 0;
-}
-
-// the 16-byte piece (in slots: 2 x piece) of a list's entry number e (0 .. 3) in its line
-TBK_HD uint32_t tbk_wepiece_at(uint32_t half, uint32_t e) {
-    const uint32_t b = half ? 1u : 0u;
-    return e == 0 ? b : 2u + 3u * b + (e - 1u);
 }
 
 TBK_HD int tbk_wentry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g, int p, TbkWideKey *out) {
@@ -555,21 +556,22 @@ TBK_HD int tbk_wentry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g,
     return n;
 }
 
-TBK_HD bool tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkWideKey e) {
+// -1: no entry holds the window; 0 / 1: an entry of hapA / hapB does
+TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkWideKey e) {
     uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
     for (uint32_t walked = 0; walked <= n_buckets; walked++) {
         const uint64_t *line = slots + (uint64_t)b * 16;
         uint64_t last1 = 0;
-        for (uint32_t i = 0; i < 4; i++) {
-            const uint64_t w0 = line[2 * tbk_wepiece_at(half, i)], w1 = line[2 * tbk_wepiece_at(half, i) + 1];
-            if (!(w0 & TBK_WENTRY_TAKEN)) return false;  // first empty piece of the list in this line
-            if (tbk_wentry_match(w0, w1, e)) return true;
+        for (uint32_t i = 0; i < 8; i++) {
+            const uint64_t w0 = line[2 * i], w1 = line[2 * i + 1];
+            if (!(w0 & TBK_WENTRY_TAKEN)) return -1;    // first empty piece of the line
+            if (tbk_wentry_match(w0, w1, e)) return (int)((w1 >> 62) & 1ull);
             last1 = w1;
         }
-        if (!(last1 >> 63)) return false;                // nothing went past this line
+        if (!(last1 >> 63)) return -1;                  // nothing went past this line
         b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
     }
-    return false;
+    return -1;
 }
 
 // ---- synthetic key sequence (bench inputs) ---------------------------------

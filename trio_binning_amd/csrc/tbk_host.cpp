@@ -1210,18 +1210,27 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
         double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);
-        for (int attempt = 0; attempt < 2; attempt++) {
+        bool built = false;
+        for (int attempt = 0; attempt < 6 && !built; attempt++) {
             uint64_t nb = (uint64_t)want + 16;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) nb = std::min<uint64_t>(nb, (uint64_t)(0.6 * (double)total_b / 128.0)); else (void)hipGetLastError();
             if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;  // (bits 30 and 31 of a bucket index are flags in the probe's queues)
             c->free_pair();
-            if (build_entry_table(c, a, b, (uint32_t)nb)) { c->mz = keep_mz; c->guests = keep_flags; return false; }
+            if (build_entry_table(c, a, b, (uint32_t)nb)) {
+                // the guess of keys per entry was too high for these lists and the table ran full: twice the room (an allocation
+                // that failed, or a table that is full at the device's cap, ends the attempt)
+                if ((double)nb + 17.0 < want) break;  // (the table was capped already: more room is not to be had)
+                const std::string why = g_err;
+                if (why.find("full") == std::string::npos) break;
+                want *= 2;
+                continue;
+            }
             const double target = (double)std::max<uint64_t>(std::max(c->entries_a, c->entries_b), 1) / el;
-            if ((double)nb >= 0.8 * target && (double)nb <= 1.25 * target) break;
-            if (attempt == 0 && (uint64_t)target + 16 == nb) break;
+            if (attempt >= 4 || ((double)nb >= 0.8 * target && (double)nb <= 1.25 * target)) { built = true; break; }
             want = target;
         }
+        if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         const double ratio = (double)(c->distinct_a + c->distinct_b) / (double)std::max<uint64_t>(1, c->entries_a + c->entries_b);
         if (!forced && ratio < env_double("TBK_ENTRY_MIN_RATIO", 1.5)) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         return true;

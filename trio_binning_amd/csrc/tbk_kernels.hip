@@ -227,14 +227,16 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
 
 // The same for wide entries (tbk_common.h "wide entries").  An entry is two words and there is no 128-bit compare-and-swap:
 // a form takes the piece's lock (bit 63 of word 0, by CAS on that word) to look at word 1, and ORs its flank bits in when
-// they agree with the entry's.  Every change of word 1 is an OR - the flags other threads set in it meanwhile are never
-// lost - and a lock is held for a handful of instructions inside ONE trip of the loop: the lanes of a wave that wait for
-// it wait for a lane that is not waiting for them.  Finished tables hold no lock.
+// list and flanks agree with the entry's.  Every change of word 1 is an OR - the flags other threads set in it meanwhile
+// are never lost - and a lock is held for a handful of instructions inside ONE trip of the loop: the lanes of a wave that
+// wait for it wait for a lane that is not waiting for them.  Finished tables hold no lock.  Both lists fill a line's eight
+// pieces in order (half = 0: hapA's list, else hapB's: bit 62 of word 1).
 __global__ void __launch_bounds__(256)
 tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
                          const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t hapb = half ? 1u : 0u;
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
     const int n_pos = 2 * mz.w;
     for (; i < n; i += step) {
@@ -250,38 +252,39 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
             const int nf = tbk_wentry_orientations(key, k, mz, g, pi % mz.w, forms);
             for (int f = 0; f < nf; f++) {
                 const TbkWideKey e = forms[f];
-                if (first_form && skip_a && tbk_wentry_lookup_one(slots, n_buckets, 0, e)) { skipped++; drop = true; break; }
+                if (first_form && skip_a && tbk_wentry_lookup_one(slots, n_buckets, e) == 0) { skipped++; drop = true; break; }  // (hapA's inserts are finished)
                 const unsigned long long taken = (unsigned long long)e.cm | TBK_WENTRY_TAKEN;
+                const unsigned long long mine1 = (unsigned long long)e.k1 | (hapb ? TBK_WENTRY_HAPB : 0ull);
                 uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
                 bool done = false;
                 for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                     unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
-                    for (uint32_t en = 0; en < 4 && !done; en++) {
-                        unsigned long long *w0 = &line[2 * tbk_wepiece_at(half, en)], *w1 = w0 + 1;
+                    for (uint32_t en = 0; en < 8 && !done; en++) {
+                        unsigned long long *w0 = &line[2 * en], *w1 = w0 + 1;
                         bool next_piece = false;
                         while (!done && !next_piece) {
                             const unsigned long long cur = __hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur & TBK_WENTRY_LOCK) continue;                                   // somebody is looking at this piece: again
                             if (cur != 0 && (uint32_t)cur != e.cm) { next_piece = true; break; }  // another m-mer's entry
-                            // empty, or an entry of my m-mer: take the lock (the empty piece becomes mine with it)
+                            // empty, or an entry of my m-mer: take the lock (an empty piece becomes mine with it)
                             if (atomicCAS(w0, cur, (cur == 0 ? taken : cur) | TBK_WENTRY_LOCK) != cur) continue;
                             const unsigned long long v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur == 0) {
-                                atomicOr(w1, (unsigned long long)e.k1);
+                                atomicOr(w1, mine1);
                                 created++; stored += first_form; done = true;
-                            } else if (tbk_wentry_compatible(cur, v1, e, mz, g)) {
+                            } else if (tbk_wentry_compatible(cur, v1, e, hapb, mz, g)) {
                                 if (!tbk_wentry_match(cur, v1, e)) { atomicOr(w1, (unsigned long long)e.k1); stored += first_form; }
                                 done = true;
                             } else {
-                                next_piece = true;  // (stays incompatible: entries only gain bits)
+                                next_piece = true;  // the other list's entry, or flanks that disagree (and stay so: entries only gain bits)
                             }
                             __threadfence();
                             __hip_atomic_store(w0, cur == 0 ? taken : cur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // unlock
-                            if (done && cur == 0 && en >= 1) { behind++; atomicOr(&line[2 * tbk_wepiece_at(half, 0) + 1], (unsigned long long)TBK_WENTRY_FLAG); }
+                            if (done && cur == 0 && en >= 2) { behind++; atomicOr(&line[2 * 1 + 1], (unsigned long long)TBK_WENTRY_FLAG); }
                         }
                     }
                     if (!done) {
-                        atomicOr(&line[2 * tbk_wepiece_at(half, 3) + 1], (unsigned long long)TBK_WENTRY_FLAG);
+                        atomicOr(&line[2 * 7 + 1], (unsigned long long)TBK_WENTRY_FLAG);
                         past++;
                         b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
                     }
@@ -1275,10 +1278,13 @@ __device__ __forceinline__ TbkWideKey wide_key_of(uint32_t cm, uint64_t k1, int 
     return e;
 }
 
+// narrow entries: the walk of one list (half) of one window; wide entries: one walk per window over the pieces both lists
+// share (`half` unused), *hap = the list of the entry found
 template <bool WIDE, class KEY>
-__device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, KEY e, uint32_t bucket, bool pend) {
+__device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, KEY e, uint32_t bucket, bool pend, uint32_t *hap) {
     bool found = false, first = true;
     uint32_t guard = 0;
+    *hap = 0;
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
             bucket = tbk_entry_next_bucket(e.cm, t.n_buckets, bucket, first);
@@ -1286,17 +1292,22 @@ __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t hal
             const uint64_t *line = t.slots + (uint64_t)bucket * 16;
             bool hit = false, ended = false;
             uint64_t last = 0;
+            if constexpr (WIDE) {
 #pragma unroll 1
-            for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {  // (the list's four 16-byte pieces of the line: the same places in both entry layouts)
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + tbk_eslot_at(half, sl));
-                if constexpr (WIDE) {
-                    hit = hit || tbk_wentry_match(v.x, v.y, e);
+                for (uint32_t pc = 0; pc < 8 && !ended && !hit; pc++) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + 2 * pc);
+                    if (tbk_wentry_match(v.x, v.y, e)) { hit = true; *hap = (uint32_t)(v.y >> 62) & 1u; }
                     ended = (v.x & TBK_WENTRY_TAKEN) == 0;
-                } else {
+                    last = v.y;
+                }
+            } else {
+#pragma unroll 1
+                for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + tbk_eslot_at(half, sl));
                     hit = hit || tbk_entry_match(v.x, e) || tbk_entry_match(v.y, e);
                     ended = (v.y << 1) == 0;  // an empty slot: the list ends in this line
+                    last = v.y;
                 }
-                last = v.y;
             }
             found = found || hit;
             pend = !hit && !ended && (last >> 63) != 0;  // all taken and an entry went past them
@@ -1314,15 +1325,15 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
         uint32_t rrel = 0;
         if (act) { it = q[base + lane]; if (WIDE && MULTI) rrel = qr[base + lane]; }
         bool found;
-        uint32_t list;
+        uint32_t list = 0;
         if constexpr (WIDE) {
             const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
-            list = (it.w >> 30) & 1u;
-            found = walk_one_entry<true>(p.t, list * 8u, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act);
+            found = walk_one_entry<true>(p.t, 0, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act, &list);
         } else {
+            uint32_t unused;
             list = it.w & 1u;
             rrel = it.w >> 1;
-            found = walk_one_entry<false>(p.t, list * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act);
+            found = walk_one_entry<false>(p.t, list * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act, &unused);
         }
         const bool count_a = found && !list, count_b = found && list;
         if (!MULTI) {
@@ -1351,21 +1362,25 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             if (WIDE && MULTI) rrel = bqr[base + oct];
             if (sub < 6) v = load_slots(p.t.slots + (uint64_t)((WIDE ? it.w : it.z) & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
         }
-        uint64_t hit;
+        uint64_t hit, hit_a, hit_b;
         if constexpr (WIDE) {
+            // the six pieces behind the front belong to whichever list came: the entry's bit 62 says which
             const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
             hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift)));
+            const uint64_t hapm = ballot(((v.y >> 62) & 1ull) != 0);
+            hit_a = hit & ~hapm; hit_b = hit & hapm;
         } else {
             rrel = it.w;
             const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
             hit = ballot(tbk_entry_match(v.x, e)) | ballot(tbk_entry_match(v.y, e));
+            hit_a = hit & 0x0707070707070707ull; hit_b = hit & 0x3838383838383838ull;
         }
-        const uint64_t hit_a = hit & 0x0707070707070707ull, hit_b = hit & 0x3838383838383838ull;
-        // lane 2 holds hapA's last piece, lane 5 hapB's: bit 63 of its second word = an entry of the list went past this line
+        // narrow: lane 2 holds hapA's last slots, lane 5 hapB's; wide: lane 5 the line's last piece - bit 63 of the second word = an entry went past this line
         const uint64_t gone = ballot((v.y >> 63) != 0);
         const uint64_t any = hit_a | hit_b;
         const uint64_t oct_hit = (any | (any >> 1) | (any >> 2) | (any >> 3) | (any >> 4) | (any >> 5)) & 0x0101010101010101ull;
-        const uint64_t walk_a = ((gone >> 2) & 0x0101010101010101ull) & ~oct_hit, walk_b = ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit;
+        const uint64_t walk_a = WIDE ? ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit : ((gone >> 2) & 0x0101010101010101ull) & ~oct_hit;
+        const uint64_t walk_b = WIDE ? 0ull : ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit;  // (wide entries: one walk per window, over both lists' pieces)
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(hit_a);
             acc_b += (uint32_t)__popcll(hit_b);
@@ -1582,7 +1597,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             kh2_s[0] = pair_bcast<0>(my_khi2); kh2_s[1] = pair_bcast<1>(my_khi2);
             mh2_s[0] = pair_bcast<0>(my_mhi2); mh2_s[1] = pair_bcast<1>(my_mhi2);
         }
-        uint64_t hit[2], more[2];
+        uint64_t hit[2], more[2], hapm[2] = {0, 0};
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const uint32_t hx = (uint32_t)(va[s].x >> 32), hy = (uint32_t)(va[s].y >> 32);
@@ -1596,7 +1611,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                 const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
                 hit[s] = ballot(va[s].x == wx) | ballot(va[s].y == wy);
             }
-            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front piece: entries behind the front
+            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front slot 1 (wide entries: of the line's piece 1): entries behind the front
+            if constexpr (WIDE) hapm[s] = ballot((hy & 0x40000000u) != 0);  // which list the lane's entry belongs to
         }
         if ((more[0] | more[1]) != 0) {
             // windows that missed in a front with entries behind it: queued by the lane that owns the window
@@ -1604,7 +1620,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 if (more[s] == 0) continue;
-                const uint64_t ma = more[s] & 0x5555555555555555ull, mb = (more[s] >> 1) & 0x5555555555555555ull;
+                // narrow: the even lane's flag is hapA's, the odd lane's hapB's; wide: only piece 1 (the odd lane) carries one, for the line
+                const uint64_t ma = WIDE ? 0ull : (more[s] & 0x5555555555555555ull), mb = (more[s] >> 1) & 0x5555555555555555ull;
                 need |= ((ma | mb) & ~pair_any(hit[s])) << s;
                 beh_a |= ma << s;
                 beh_b |= mb << s;
@@ -1627,21 +1644,28 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             }
         }
         if ((hit[0] | hit[1]) != 0) {
+            // which list a hit counts for: narrow entries - the lane it fell on (even: hapA's slots, odd: hapB's); wide - the entry's list bit
+            uint64_t ha[2], hb[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                ha[s] = WIDE ? hit[s] & ~hapm[s] : hit[s] & 0x5555555555555555ull;
+                hb[s] = WIDE ? hit[s] & hapm[s] : hit[s] & 0xAAAAAAAAAAAAAAAAull;
+            }
             if (TWO) {
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
-                    const uint64_t h1 = hit[s] & own1[s], h2 = hit[s] & ~own1[s];
-                    acc_a += (uint32_t)__popcll(h1 & 0x5555555555555555ull);
-                    acc_b += (uint32_t)__popcll(h1 & 0xAAAAAAAAAAAAAAAAull);
-                    acc2_a += (uint32_t)__popcll(h2 & 0x5555555555555555ull);
-                    acc2_b += (uint32_t)__popcll(h2 & 0xAAAAAAAAAAAAAAAAull);
+                    acc_a += (uint32_t)__popcll(ha[s] & own1[s]);
+                    acc_b += (uint32_t)__popcll(hb[s] & own1[s]);
+                    acc2_a += (uint32_t)__popcll(ha[s] & ~own1[s]);
+                    acc2_b += (uint32_t)__popcll(hb[s] & ~own1[s]);
                 }
             } else if (!MULTI) {
-                acc_a += (uint32_t)__popcll((hit[0] & 0x5555555555555555ull)) + (uint32_t)__popcll((hit[1] & 0x5555555555555555ull));
-                acc_b += (uint32_t)__popcll((hit[0] & 0xAAAAAAAAAAAAAAAAull)) + (uint32_t)__popcll((hit[1] & 0xAAAAAAAAAAAAAAAAull));
+                acc_a += (uint32_t)__popcll(ha[0]) + (uint32_t)__popcll(ha[1]);
+                acc_b += (uint32_t)__popcll(hb[0]) + (uint32_t)__popcll(hb[1]);
             } else {
-                const uint64_t wa = (hit[0] & 0x5555555555555555ull) | ((hit[1] & 0x5555555555555555ull) << 1);
-                const uint64_t wb = ((hit[0] >> 1) & 0x5555555555555555ull) | (hit[1] & 0xAAAAAAAAAAAAAAAAull);
+                // to the bit of the lane that owns the window (pair p's sub-step s window belongs to lane 2p + s)
+                const uint64_t wa = pair_any(ha[0]) | (pair_any(ha[1]) << 1);
+                const uint64_t wb = pair_any(hb[0]) | (pair_any(hb[1]) << 1);
                 lane_a += (uint32_t)(wa >> lane) & 1u;
                 lane_b += (uint32_t)(wb >> lane) & 1u;
             }
