@@ -53,13 +53,13 @@ static void insert_form(Table &t, uint32_t half, TbkEntryKey e) {
 // ---- the same for wide entries (k up to 32): one entry per 16-byte piece, eight pieces per line shared by both lists ----
 static void winsert_form(Table &t, uint32_t half, TbkWideKey e) {
     const uint32_t hapb = half ? 1 : 0;
-    uint32_t b = tbk_entry_bucket(e.cm, t.n_buckets);
+    uint32_t b = tbk_wentry_bucket(e.cm, t.n_buckets);
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
         uint64_t *line = t.slots.data() + (uint64_t)b * 16;
         for (uint32_t i = 0; i < 8; i++) {
             uint64_t &w0 = line[2 * i], &w1 = line[2 * i + 1];
             if (!(w0 & TBK_WENTRY_TAKEN)) {
-                w0 = (uint64_t)e.cm | TBK_WENTRY_TAKEN;
+                w0 = e.cm | TBK_WENTRY_TAKEN;
                 w1 |= e.k1 | (hapb ? TBK_WENTRY_HAPB : 0ull);
                 t.entries++;
                 if (i >= 2) { line[2 * 1 + 1] |= TBK_WENTRY_FLAG; t.behind++; }
@@ -69,7 +69,7 @@ static void winsert_form(Table &t, uint32_t half, TbkWideKey e) {
         }
         line[2 * 7 + 1] |= TBK_WENTRY_FLAG;
         t.past++;
-        b = tbk_entry_next_bucket(e.cm, t.n_buckets, b, walked == 0);
+        b = tbk_wentry_next_bucket(e.cm, t.n_buckets, b, walked == 0);
     }
     fprintf(stderr, "table full\n");
     exit(2);
@@ -106,9 +106,10 @@ static TbkWideKey wwindow_key(const Table &t, uint64_t fwd, int pick_last_tie) {
         if (r < best || (pick_last_tie && r == best)) { best = r; x = i; }
     }
     const int pos = x % t.z.w;
-    const uint32_t mmask = t.z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * t.z.m)) - 1u);
-    const uint32_t mx = (uint32_t)(fwd >> (2 * (t.z.o + pos))) & mmask;
-    const uint32_t my = (uint32_t)(rc >> (2 * (t.z.o + t.z.w - 1 - pos))) & mmask;
+    const uint64_t mmask = (1ull << (2 * t.z.m)) - 1ull;
+    const uint64_t mx = (fwd >> (2 * (t.z.o + pos))) & mmask;
+    const uint64_t my = (rc >> (2 * (t.z.o + t.z.w - 1 - pos))) & mmask;
+    if (my != tbk_revcomp64(mx, t.z.m)) { fprintf(stderr, "strand geometry\n"); exit(4); }
     const bool f = mx < my;
     return tbk_wentry_key(f ? fwd : rc, t.z, t.g, f ? pos : t.z.w - 1 - pos);
 }
@@ -175,12 +176,12 @@ int main(int argc, char **argv) {
     const int w_want = argc > 2 ? atoi(argv[2]) : 6;
     const uint64_t seed = argc > 3 ? strtoull(argv[3], nullptr, 10) : 1;
     const int crowd = argc > 4 ? atoi(argv[4]) : 0;  // 1: a table so small that lines overflow
-    const int wide = argc > 5 ? atoi(argv[5]) : 0;   // 1: wide entries (16 bytes), m = 16
+    const int wide = argc > 5 ? atoi(argv[5]) : 0;   // m: wide entries (16 bytes) with m-mers of that length (1: of 18, the default)
     std::mt19937_64 rng(seed);
     Table t;
     t.k = k;
     t.wide = wide != 0;
-    t.z = tbk_mz_params(k, w_want, 1000000, wide ? 16 : 0, 1);
+    t.z = tbk_mz_params(k, w_want, 1000000, wide ? (wide == 1 ? 18 : wide) : 0, 1);
     if (!(wide ? tbk_wentry_geom(k, t.z, &t.g) : tbk_entry_geom(k, t.z, &t.g))) { printf("k=%d w=%d: no entry layout (w=%d m=%d o=%d t=%d)\n", k, w_want, t.z.w, t.z.m, t.z.o, t.z.t); return 0; }
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     // a genome with SNPs between two haplotypes, low-complexity stretches and a repeated segment

@@ -481,46 +481,48 @@ TBK_HD bool tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint
 // ---- wide entries: the entry layout for k-mers too long for 64 bits of context (k up to 32) -----------------------
 // A k-mer plus its neighbours under one sampled m-mer is k + w - 1 bases: 26 at k = 21, 38 at k = 31 - more than a slot.
 // A WIDE entry is two slots, one 16-byte piece of the line (what one lane loads):
-//     word 0   bits [0, 32)  the canonical m-mer (m <= 16: the 32-bit arithmetic serves tables of any size, because the
-//                            m-mers only have to outnumber the ENTRIES);  bit 32  "taken";  bit 63  lock (build only)
-//     word 1   bits [0, 4 FL)  the flank field, laid out as in a narrow entry;  bits [4 FL, +w)  V;
+//     word 0   bits [0, 2m)  the canonical m-mer, m up to 24;  bit 62  "taken";  bit 63  lock (build only)
+//     word 1   bits [0, 4 FL)  the flank field, laid out as in a narrow entry;  bits [4 FL, +w)  V  (4 FL + w <= 48);
 //              bit 62  the list (0 hapA, 1 hapB);  bit 63  the piece's flag
-// and a window matches iff word 0's m-mer is its own and (word 1 ^ k1) & m1 == 0 - two v_bfi and one 64-bit compare
-// beside the 32-bit one; which list the hit counts for is the entry's bit 62.  A line is eight pieces that BOTH lists
-// fill in order, the front is its first two (32 bytes, pair-cooperative probe as for narrow entries): with one entry per
-// piece, fronts of one entry per list left a quarter of the entries behind them (entries of one list that share a bucket:
-// the same 16-mer at another locus), two pieces for whoever comes first leave a few per cent.  Bit 63 of piece 1's
+// and a window matches iff word 0 is its m-mer | taken and (word 1 ^ k1) & m1 == 0 - two v_bfi and two 64-bit compares;
+// which list the hit counts for is the entry's bit 62.  The m-mer has room to be LONGER than 16 bases, and needs to be:
+// mod-sampling only ever samples m-mers that hold one of the span's smallest t-mers at offset 0 or w - about an eighth
+// of all m-mers - so 2 x 2e8 entries over 16-mers meet in the same buckets however roomy the table (a quarter of them lay
+// behind a front); 18-mers (the default) have sixteen times the room.  A line is eight pieces that BOTH lists fill in
+// order, the front is its first two (32 bytes, pair-cooperative probe as for narrow entries).  Bit 63 of piece 1's
 // word 1: "more than two entries in this line"; of piece 7's: "an entry went past this line".  There is no 128-bit
 // compare-and-swap: an insert takes the piece's lock (bit 63 of word 0) to check that list and flanks agree with the
 // entry's and ORs its bits in.  The lists are disjoint (hapB keys that hapA holds are left out), so a window matches at
 // most one entry of its line.
 #define TBK_FLAG_WIDE 8u     // `guests` word: the entry table holds wide entries (with TBK_FLAG_ENTRY)
-#define TBK_WENTRY_TAKEN 0x0000000100000000ull
+#define TBK_WENTRY_TAKEN 0x4000000000000000ull
 #define TBK_WENTRY_LOCK 0x8000000000000000ull
 #define TBK_WENTRY_FLAG 0x8000000000000000ull
 #define TBK_WENTRY_HAPB 0x4000000000000000ull
 
 TBK_HD bool tbk_wentry_geom(int k, TbkMz z, TbkEntryGeom *g) {
-    if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
+    if (z.w < 2 || z.t <= 0 || z.m > 24 || z.m < 8) return false;
     const int fl = z.o + z.w - 1;
-    if (4 * fl + z.w > 61 || 2 * (k - z.m) > 32) return false;  // (a window's flank bases fit 32 bits: k - m <= 16)
+    // 48 bits of flanks + V (the probe's queues carry the upper 16 of them beside the m-mer's upper 16), and a window's
+    // flank bases in 32 bits: k - m <= 16
+    if (4 * fl + z.w > 48 || 2 * (k - z.m) > 32) return false;
     g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
     return true;
 }
 
-struct TbkWideKey { uint32_t cm; uint64_t k1, m1; };
+struct TbkWideKey { uint64_t cm, k1, m1; };
 
 TBK_HD TbkWideKey tbk_wentry_key(uint64_t oriented, TbkMz z, TbkEntryGeom g, int pos) {
     const int a = 2 * (z.o + pos);
-    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    const uint64_t mmask = (1ull << (2 * z.m)) - 1ull;
     TbkWideKey e;
-    e.cm = (uint32_t)(oriented >> a) & mmask;
+    e.cm = (oriented >> a) & mmask;
     const uint64_t low = oriented & ((1ull << a) - 1ull);
     const uint64_t high = a + 2 * z.m >= 64 ? 0ull : (oriented >> (a + 2 * z.m));
     const uint64_t fw = low | (high << a);                      // 2 (k - m) <= 32 bits
     const int sh = 2 * (z.w - 1 - pos);
     const uint64_t vbit = 1ull << (g.vshift + pos);
-    const uint64_t fmask = g.fbits >= 64 ? ~0ull : ((1ull << g.fbits) - 1ull);
+    const uint64_t fmask = (1ull << g.fbits) - 1ull;
     e.k1 = (fw << sh) | vbit;
     e.m1 = (fmask << sh) | vbit;
     return e;
@@ -528,12 +530,12 @@ TBK_HD TbkWideKey tbk_wentry_key(uint64_t oriented, TbkMz z, TbkEntryGeom g, int
 
 // (whichever list the entry belongs to: bit 62 of w1 says)
 TBK_HD bool tbk_wentry_match(uint64_t w0, uint64_t w1, TbkWideKey e) {
-    return (uint32_t)w0 == e.cm && (w0 & TBK_WENTRY_TAKEN) != 0 && ((w1 ^ e.k1) & e.m1) == 0;
+    return (w0 & ~TBK_WENTRY_LOCK) == (e.cm | TBK_WENTRY_TAKEN) && ((w1 ^ e.k1) & e.m1) == 0;
 }
 
 TBK_HD uint64_t tbk_wentry_defined(uint64_t w1, TbkMz z, TbkEntryGeom g) {
     uint64_t d = 0;
-    const uint64_t fmask = g.fbits >= 64 ? ~0ull : ((1ull << g.fbits) - 1ull);
+    const uint64_t fmask = (1ull << g.fbits) - 1ull;
     for (int p = 0; p < z.w; p++)
         if ((w1 >> (g.vshift + p)) & 1ull) d |= fmask << (2 * (z.w - 1 - p));
     return d;
@@ -541,15 +543,22 @@ TBK_HD uint64_t tbk_wentry_defined(uint64_t w1, TbkMz z, TbkEntryGeom g) {
 
 // may the window `e` of list `hapb` join this entry?  Same m-mer, same list, and the flanks agree wherever both define them.
 TBK_HD bool tbk_wentry_compatible(uint64_t w0, uint64_t w1, TbkWideKey e, uint32_t hapb, TbkMz z, TbkEntryGeom g) {
-    if ((uint32_t)w0 != e.cm || ((w1 >> 62) & 1ull) != (uint64_t)(hapb ? 1 : 0)) return false;
+    if ((w0 & ~TBK_WENTRY_LOCK) != (e.cm | TBK_WENTRY_TAKEN) || ((w1 >> 62) & 1ull) != (uint64_t)(hapb ? 1 : 0)) return false;
     const uint64_t mine = e.m1 & ((1ull << g.vshift) - 1ull);
     return ((w1 ^ e.k1) & mine & tbk_wentry_defined(w1, z, g)) == 0;
 }
 
+// the bucket of a wide entry's m-mer: the placement half of the 64-bit m-mer hash (as the key layouts' long m-mers)
+TBK_HD uint32_t tbk_wentry_bucket(uint64_t cm, uint32_t n_buckets) { return tbk_reduce((uint32_t)tbk_mmer_hash64(cm), n_buckets); }
+TBK_HD uint32_t tbk_wentry_next_bucket(uint64_t cm, uint32_t n_buckets, uint32_t b, bool leaving_home) {
+    if (leaving_home) return tbk_reduce(tbk_mix32(cm ^ 0xA5A5A5A5A5A5A5A5ull), n_buckets);
+    return b + 1 == n_buckets ? 0 : b + 1;
+}
+
 TBK_HD int tbk_wentry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g, int p, TbkWideKey *out) {
-    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
-    const uint32_t x = (uint32_t)(key >> (2 * (z.o + p))) & mmask;
-    const uint32_t y = tbk_revcomp32(x, z.m);
+    const uint64_t mmask = (1ull << (2 * z.m)) - 1ull;
+    const uint64_t x = (key >> (2 * (z.o + p))) & mmask;
+    const uint64_t y = tbk_revcomp64(x, z.m);
     int n = 0;
     if (x <= y) out[n++] = tbk_wentry_key(key, z, g, p);
     if (x >= y) out[n++] = tbk_wentry_key(tbk_revcomp_packed(key, k), z, g, z.w - 1 - p);
@@ -558,7 +567,7 @@ TBK_HD int tbk_wentry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g,
 
 // -1: no entry holds the window; 0 / 1: an entry of hapA / hapB does
 TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkWideKey e) {
-    uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+    uint32_t b = tbk_wentry_bucket(e.cm, n_buckets);
     for (uint32_t walked = 0; walked <= n_buckets; walked++) {
         const uint64_t *line = slots + (uint64_t)b * 16;
         uint64_t last1 = 0;
@@ -569,7 +578,7 @@ TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkW
             last1 = w1;
         }
         if (!(last1 >> 63)) return -1;                  // nothing went past this line
-        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+        b = tbk_wentry_next_bucket(e.cm, n_buckets, b, walked == 0);
     }
     return -1;
 }

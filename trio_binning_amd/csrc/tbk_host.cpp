@@ -1194,14 +1194,18 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
                 ok = z.w == w && tbk_entry_geom(c->k, z, &g);
             }
         // k-mers too long for a slot's worth of context (k > 25: a k-mer and its neighbours under one m-mer are k + w - 1
-        // bases): WIDE entries, 16 bytes, with 16-mers whatever the lists' size - the m-mers only have to outnumber the
-        // entries - and the longest span k's parity allows, 8 down to 6 (tbk_common.h "wide entries").  One entry per list
-        // in the front: 0.2 entries per list and bucket (TBK_WENTRY_LOAD).  TBK_ENTRY_WIDE=1 asks for them at any k.
+        // bases): WIDE entries, 16 bytes, and the longest span k's parity allows, 8 down to 6 (tbk_common.h "wide entries").
+        // Two entries of either list in the front: 0.2 entries per list and bucket (TBK_WENTRY_LOAD).  TBK_ENTRY_WIDE=1
+        // asks for them at any k.
+        // m-mers of 18 bases where k has room (then 17, 16): mod-sampling samples only the m-mers that hold one of the span's
+        // smallest t-mers at offset 0 or w, about an eighth of them, and 2 x 2e8 entries over 16-mers crowd the buckets they
+        // share whatever the table's size (tbk_common.h "wide entries").
         if (!ok && env_double("TBK_ENTRY_WIDE", -1) != 0)
-            for (int w = (w_pin > 0 ? w_pin : 8); w >= (w_pin > 0 ? w_pin : 6) && !ok; w--) {
-                z = tbk_mz_params(c->k, w, n_big, m_force > 0 ? m_force : 16, 1);
-                ok = wide = z.w == w && z.m <= 16 && tbk_wentry_geom(c->k, z, &g);
-            }
+            for (int mm = (m_force > 0 ? m_force : 18); mm >= (m_force > 0 ? m_force : 16) && !ok; mm--)
+                for (int w = (w_pin > 0 ? w_pin : 8); w >= (w_pin > 0 ? w_pin : 6) && !ok; w--) {
+                    z = tbk_mz_params(c->k, w, n_big, mm, 1);
+                    ok = wide = z.w == w && z.m == mm && z.t > 0 && tbk_wentry_geom(c->k, z, &g);
+                }
         if (!ok) return false;
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;

@@ -162,12 +162,15 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
 __global__ void __launch_bounds__(256)
 tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
                         const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    // Every thread takes a contiguous stretch of the list: a list made by find-unique-kmers holds the windows of a variant
+    // side by side, and neighbouring threads working on neighbouring lines would all want the same few entries at once.
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_threads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t per = (n + n_threads - 1) / n_threads;
+    const uint64_t i_end = (tid + 1) * per < n ? (tid + 1) * per : n;
     const unsigned long long FLAG64 = (unsigned long long)TBK_ENTRY_FLAG << 32;
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
     const int n_pos = 2 * mz.w;
-    for (; i < n; i += step) {
+    for (uint64_t i = tid * per; i < i_end; i++) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;
         if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
@@ -234,12 +237,13 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
 __global__ void __launch_bounds__(256)
 tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
                          const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_threads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t per = (n + n_threads - 1) / n_threads;  // (a contiguous stretch of the list per thread: see tbk_entry_insert_kernel)
+    const uint64_t i_end = (tid + 1) * per < n ? (tid + 1) * per : n;
     const uint32_t hapb = half ? 1u : 0u;
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
     const int n_pos = 2 * mz.w;
-    for (; i < n; i += step) {
+    for (uint64_t i = tid * per; i < i_end; i++) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;
         if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
@@ -255,7 +259,7 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
                 if (first_form && skip_a && tbk_wentry_lookup_one(slots, n_buckets, e) == 0) { skipped++; drop = true; break; }  // (hapA's inserts are finished)
                 const unsigned long long taken = (unsigned long long)e.cm | TBK_WENTRY_TAKEN;
                 const unsigned long long mine1 = (unsigned long long)e.k1 | (hapb ? TBK_WENTRY_HAPB : 0ull);
-                uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
+                uint32_t b = tbk_wentry_bucket(e.cm, n_buckets);
                 bool done = false;
                 for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                     unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
@@ -263,30 +267,37 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
                         unsigned long long *w0 = &line[2 * en], *w1 = w0 + 1;
                         bool next_piece = false;
                         while (!done && !next_piece) {
-                            const unsigned long long cur = __hip_atomic_load(w0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            // Relaxed device-scope atomics only: every access to the two words is an atomic performed where the XCDs
+                            // meet, and the order that matters - my OR of word 1 before my unlock of word 0 - is kept by waiting for the
+                            // OR's return value before the unlock is issued.  Acquire / release at agent scope would make every
+                            // insert invalidate or write back an XCD's whole L2: 2e9 keys took 25 s that way.
+                            const unsigned long long cur = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur & TBK_WENTRY_LOCK) continue;                                   // somebody is looking at this piece: again
-                            if (cur != 0 && (uint32_t)cur != e.cm) { next_piece = true; break; }  // another m-mer's entry
+                            if (cur != 0 && cur != taken) { next_piece = true; break; }           // another m-mer's entry
                             // empty, or an entry of my m-mer: take the lock (an empty piece becomes mine with it)
                             if (atomicCAS(w0, cur, (cur == 0 ? taken : cur) | TBK_WENTRY_LOCK) != cur) continue;
                             const unsigned long long v1 = __hip_atomic_load(w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            unsigned long long seen = v1;  // what word 1 held when my change (if any) went in
                             if (cur == 0) {
-                                atomicOr(w1, mine1);
+                                seen = atomicOr(w1, mine1);
                                 created++; stored += first_form; done = true;
                             } else if (tbk_wentry_compatible(cur, v1, e, hapb, mz, g)) {
-                                if (!tbk_wentry_match(cur, v1, e)) { atomicOr(w1, (unsigned long long)e.k1); stored += first_form; }
+                                if (!tbk_wentry_match(cur, v1, e)) { seen = atomicOr(w1, (unsigned long long)e.k1); stored += first_form; }
                                 done = true;
                             } else {
                                 next_piece = true;  // the other list's entry, or flanks that disagree (and stay so: entries only gain bits)
                             }
-                            __threadfence();
-                            __hip_atomic_store(w0, cur == 0 ? taken : cur, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);  // unlock
+                            // unlock - behind the OR: the empty asm needs the OR's return value in a register, so the wave has waited for it,
+                            // and its memory clobber keeps the store below
+                            asm volatile("" ::"v"((uint32_t)seen), "v"((uint32_t)(seen >> 32)) : "memory");
+                            __hip_atomic_store(w0, cur == 0 ? taken : cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (done && cur == 0 && en >= 2) { behind++; atomicOr(&line[2 * 1 + 1], (unsigned long long)TBK_WENTRY_FLAG); }
                         }
                     }
                     if (!done) {
                         atomicOr(&line[2 * 7 + 1], (unsigned long long)TBK_WENTRY_FLAG);
                         past++;
-                        b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
+                        b = tbk_wentry_next_bucket(e.cm, n_buckets, b, walked == 0);
                     }
                 }
                 if (!done) atomicExch(failed, 1);
@@ -1266,15 +1277,16 @@ __device__ __forceinline__ TbkEntryKey entry_key_of(uint32_t cm, uint32_t khi, i
     return e;
 }
 
-// wide entries (tbk_common.h): the queues carry the 64-bit flank word instead - walk entry: x = m-mer, (y, z) = k1, w = home
-// bucket | list << 30; back entry: w = home bucket | flags << 30; the read of a queued window (multi-read passes) in a
-// 16-bit array beside the queue
-__device__ __forceinline__ TbkWideKey wide_key_of(uint32_t cm, uint64_t k1, int w, int fbits, int vshift) {
-    const uint32_t v = (uint32_t)(k1 >> vshift);              // exactly one V bit
-    const int pos = 31 - (int)__clz(v);
+// wide entries (tbk_common.h): the queues carry 48 bits of m-mer and 48 bits of flanks + V - walk / back entry: x = m-mer low
+// word, y = k1 low word, z = k1 bits 32..47 | m-mer bits 32..47 << 16, w = home bucket (| flags << 30); the read of a queued
+// window (multi-read passes) in a 16-bit array beside the queue
+__device__ __forceinline__ TbkWideKey wide_key_of(uint4 it, int w, int fbits, int vshift) {
     TbkWideKey e;
-    e.cm = cm; e.k1 = k1;
-    e.m1 = (((fbits >= 64 ? ~0ull : ((1ull << fbits) - 1ull))) << (2 * (w - 1 - pos))) | (1ull << (vshift + pos));
+    e.cm = (uint64_t)it.x | ((uint64_t)(it.z >> 16) << 32);
+    e.k1 = (uint64_t)it.y | ((uint64_t)(it.z & 0xFFFFu) << 32);
+    const uint32_t v = (uint32_t)(e.k1 >> vshift);            // exactly one V bit (none in a filler entry: then nothing matches)
+    const int pos = v ? 31 - (int)__clz(v) : 0;
+    e.m1 = (((1ull << fbits) - 1ull) << (2 * (w - 1 - pos))) | (1ull << (vshift + pos));
     return e;
 }
 
@@ -1287,7 +1299,8 @@ __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t hal
     *hap = 0;
     while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
         if (pend) {
-            bucket = tbk_entry_next_bucket(e.cm, t.n_buckets, bucket, first);
+            if constexpr (WIDE) bucket = tbk_wentry_next_bucket(e.cm, t.n_buckets, bucket, first);
+            else bucket = tbk_entry_next_bucket(e.cm, t.n_buckets, bucket, first);
             first = false;
             const uint64_t *line = t.slots + (uint64_t)bucket * 16;
             bool hit = false, ended = false;
@@ -1321,14 +1334,13 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
                                                   int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
     for (uint32_t base = 0; base < qn; base += 64) {
         const bool act = base + lane < qn;
-        uint4 it = WIDE ? make_uint4(TBK_ENTRY_NO_MMER, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint4 it = WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);  // (a wide filler has no V bit: it matches nothing)
         uint32_t rrel = 0;
         if (act) { it = q[base + lane]; if (WIDE && MULTI) rrel = qr[base + lane]; }
         bool found;
         uint32_t list = 0;
         if constexpr (WIDE) {
-            const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
-            found = walk_one_entry<true>(p.t, 0, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act, &list);
+            found = walk_one_entry<true>(p.t, 0, wide_key_of(it, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act, &list);
         } else {
             uint32_t unused;
             list = it.w & 1u;
@@ -1354,7 +1366,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
     const uint32_t sub = lane & 7u, oct = lane >> 3;
     for (uint32_t base = 0; base < qb; base += 8) {
         const bool act = base + oct < qb;
-        uint4 it = WIDE ? make_uint4(TBK_ENTRY_NO_MMER, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint4 it = WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
         uint32_t rrel = 0;
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) {
@@ -1365,8 +1377,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
         uint64_t hit, hit_a, hit_b;
         if constexpr (WIDE) {
             // the six pieces behind the front belong to whichever list came: the entry's bit 62 says which
-            const uint64_t k1 = act ? ((uint64_t)it.y | ((uint64_t)it.z << 32)) : (1ull << vshift);
-            hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it.x, k1, p.t.mz.w, fbits, vshift)));
+            hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it, p.t.mz.w, fbits, vshift)));
             const uint64_t hapm = ballot(((v.y >> 62) & 1ull) != 0);
             hit_a = hit & ~hapm; hit_b = hit & hapm;
         } else {
@@ -1466,7 +1477,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     uint32_t win[NW];
     const int m = p.t.mz.m, o = p.t.mz.o, tlen = p.t.mz.t;
     const uint32_t span_o = (uint32_t)o;
-    const uint32_t mmask = m >= 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+    const uint64_t mmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
     const uint32_t tmask = tlen >= 16 ? 0xFFFFFFFFu : ((1u << (2 * tlen)) - 1u);
     auto tmer_rank = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh, uint32_t pos) -> uint32_t {
         const uint32_t x = (uint32_t)(fwd64 >> fsh) & tmask, y = (uint32_t)(rc64 >> bsh) & tmask;
@@ -1550,10 +1561,14 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t x = (best - (uint32_t)j) & 15u;
         const uint32_t pos = x >= (uint32_t)W ? x - (uint32_t)W : x;
         const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
-        const uint32_t mx = (uint32_t)(fs >> fsh) & mmask, my = (uint32_t)(bs >> bsh) & mmask;
+        // (wide entries: m-mers of up to 24 bases, 64-bit arithmetic and the placement half of the 64-bit hash)
+        using mmer_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
+        const mmer_t mx = (mmer_t)(fs >> fsh) & (mmer_t)mmask, my = (mmer_t)(bs >> bsh) & (mmer_t)mmask;
         const bool fw_or = mx < my;                       // the m-mer is canonical as the forward strand reads it
-        const uint32_t cm = fw_or ? mx : my;
-        const uint32_t bkt = tbk_reduce(tbk_mmer_hash(cm), p.t.n_buckets);
+        const mmer_t cm = fw_or ? mx : my;
+        uint32_t bkt;
+        if constexpr (WIDE) bkt = tbk_reduce((uint32_t)tbk_mmer_hash64(cm), p.t.n_buckets);
+        else bkt = tbk_reduce(tbk_mmer_hash(cm), p.t.n_buckets);
         // ---- what this window asks an entry (tbk_entry_key): the k-mer in the m-mer's orientation, cut around the m-mer ----
         const uint64_t orient = (fw_or ? fs : bs) & kmask;
         const uint32_t a = fw_or ? fsh : bsh;             // 2 (o + pos'), pos' = the m-mer's position as `orient` reads
@@ -1573,7 +1588,14 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             my_khi = ((low | (high << a)) << shw) | vbit;
             my_mhi = (fmask << shw) | vbit;
         }
-        const uint32_t cm_ask = ok ? cm : TBK_ENTRY_NO_MMER;  // an invalid window asks for an m-mer no entry holds
+        // an invalid window asks for an m-mer no entry holds (narrow: T x 16, never canonical; wide: a word 0 no piece can hold)
+        uint32_t cm_ask, cm_ask2 = 0;
+        if constexpr (WIDE) {
+            const uint64_t w0_want = ok ? ((uint64_t)cm | TBK_WENTRY_TAKEN) : ~0ull;
+            cm_ask = (uint32_t)w0_want; cm_ask2 = (uint32_t)(w0_want >> 32);
+        } else {
+            cm_ask = ok ? (uint32_t)cm : TBK_ENTRY_NO_MMER;
+        }
         const bool fresh = ok && bkt != last_bk;
         const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
         last_bk = my_bk & 0x7FFFFFFFu;
@@ -1592,10 +1614,11 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t cm_s[2] = {pair_bcast<0>(cm_ask), pair_bcast<1>(cm_ask)};
         const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
         const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
-        uint32_t kh2_s[2] = {0, 0}, mh2_s[2] = {0, 0};
+        uint32_t kh2_s[2] = {0, 0}, mh2_s[2] = {0, 0}, cm2_s[2] = {0, 0};
         if constexpr (WIDE) {
             kh2_s[0] = pair_bcast<0>(my_khi2); kh2_s[1] = pair_bcast<1>(my_khi2);
             mh2_s[0] = pair_bcast<0>(my_mhi2); mh2_s[1] = pair_bcast<1>(my_mhi2);
+            cm2_s[0] = pair_bcast<0>(cm_ask2); cm2_s[1] = pair_bcast<1>(cm_ask2);
         }
         uint64_t hit[2], more[2], hapm[2] = {0, 0};
 #pragma unroll
@@ -1605,7 +1628,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                 // the lane's piece is ONE entry: word 0 = m-mer | taken, word 1 = flanks + V (+ the piece's flag in bit 63, outside every mask)
                 const uint32_t ly = (uint32_t)va[s].y;
                 const uint64_t want = (uint64_t)((kh_s[s] & mh_s[s]) | (ly & ~mh_s[s])) | ((uint64_t)((kh2_s[s] & mh2_s[s]) | (hy & ~mh2_s[s])) << 32);
-                hit[s] = ballot((uint32_t)va[s].x == cm_s[s]) & ballot(va[s].y == want);  // (an empty piece is all zero: its V bit is missing)
+                hit[s] = ballot(va[s].x == ((uint64_t)cm_s[s] | ((uint64_t)cm2_s[s] << 32))) & ballot(va[s].y == want);  // (word 0 = m-mer | taken, exactly: no lock in a finished table)
             } else {
                 const uint64_t wx = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hx & ~mh_s[s])) << 32);
                 const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
@@ -1634,10 +1657,10 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                     const uint32_t at = qb + (uint32_t)__popcll(need & (me - 1));
                     const uint32_t home = last_bk | ((uint32_t)((beh_a >> lane) & 1ull) << 30) | ((uint32_t)((beh_b >> lane) & 1ull) << 31);
                     if constexpr (WIDE) {
-                        backq[at] = make_uint4(cm, my_khi, my_khi2, home);
+                        backq[at] = make_uint4((uint32_t)cm, my_khi, (my_khi2 & 0xFFFFu) | ((uint32_t)((uint64_t)cm >> 32) << 16), home);
                         if (MULTI || TWO) backr[at] = (uint16_t)rrel;
                     } else {
-                        backq[at] = make_uint4(cm, my_khi, home, rrel);
+                        backq[at] = make_uint4((uint32_t)cm, my_khi, home, rrel);
                     }
                 }
                 qb += (uint32_t)__popcll(need);
