@@ -644,6 +644,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                 roofline["random_line_ceiling_Gps"] = ceiling
                 roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
                 roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / cal["guide_stream_GBps"], 3)
+                roofline["random_line_note"] = ("the ceiling is what a pure gather microbenchmark sustains at this footprint (tools/calib_footprint.py), a yardstick and not a "
+                                                "bound: a kernel with more loads in flight can pass it (the entry kernels do, by 4-8 %); the physical bound is traffic_frac_of_peak")
             except Exception:
                 pass
 

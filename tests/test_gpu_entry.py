@@ -59,7 +59,7 @@ def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k
     if (k, w, wide) == (21, 7, 0):
         monkeypatch.setenv("TBK_MINIMIZER_M", "15")   # the longest span k = 21 has room for: seven 15-mers, flanks and V bits fill an entry's 31 bits
     monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5" if crowded else "0.3")   # crowded: 5.5 entries per list and bucket of 8 slots
-    monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.2")  # wide entries: four per list and line
+    monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.25")  # wide entries: four per list and line
     if wide:
         monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
     monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))

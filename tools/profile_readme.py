@@ -42,6 +42,21 @@ def load(name):
         return None
 
 
+# kernel_stats.csv (rocprofv3 --stats) averages over EVERY launch of a kernel - sliced first batches and the small parity
+# launches included; the companion says what the full-size launches took, per kernel, so that the two files agree at a glance
+try:
+    tr = json.load(open(os.path.join(dst, "kernel_trace_by_launch_size.json")))
+    biggest = {}
+    for t in tr:
+        if t["kernel"] not in biggest or t["grid"] > biggest[t["kernel"]]["grid"]:
+            biggest[t["kernel"]] = t
+    with open(os.path.join(dst, "kernel_stats_full_size_launches.csv"), "w") as fh:
+        fh.write('"Name","GridSize","Calls","AverageMs","MinMs","MaxMs"\n')
+        for k, t in sorted(biggest.items(), key=lambda kv: -kv[1]["avg_ms"] * kv[1]["launches"]):
+            fh.write('"%s",%d,%d,%.4f,%.4f,%.4f\n' % (k, t["grid"], t["launches"], t["avg_ms"], t["min_ms"], t["max_ms"]))
+except Exception:
+    pass
+
 u, h = load("bench_default.json"), load("bench_haplotypes.json")
 pu, ph = load("pmc_summary_uniform.json") or {}, load("pmc_summary_haplotypes.json") or {}
 trace = load("kernel_trace_by_launch_size.json") or []

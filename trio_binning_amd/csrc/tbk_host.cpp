@@ -1195,7 +1195,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
             }
         // k-mers too long for a slot's worth of context (k > 25: a k-mer and its neighbours under one m-mer are k + w - 1
         // bases): WIDE entries, 16 bytes, and the longest span k's parity allows, 8 down to 6 (tbk_common.h "wide entries").
-        // Two entries of either list in the front: 0.2 entries per list and bucket (TBK_WENTRY_LOAD).  TBK_ENTRY_WIDE=1
+        // Two entries of either list in the front: 0.25 entries per list and bucket (TBK_WENTRY_LOAD; 2 x 1e9 haplotype-shaped
+        // 31-mers: 102 GB, 51 B per key, 209 Gbases/s resident; 0.20: 128 GB, 215-218; 0.30: 85 GB, 203).  TBK_ENTRY_WIDE=1
         // asks for them at any k.
         // m-mers of 18 bases where k has room (then 17, 16): mod-sampling samples only the m-mers that hold one of the span's
         // smallest t-mers at offset 0 or w, about an eighth of them, and 2 x 2e8 entries over 16-mers crowd the buckets they
@@ -1209,7 +1210,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (!ok) return false;
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
-        const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.20)))   // (four entries per list and line)
+        const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.25)))   // (four entries per list and line)
                                : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.40)));  // (tests crowd the lines: 8 slots per list)
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
@@ -1770,6 +1771,7 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         // Slices pay where nothing else keeps the device busy (an empty ring: the first batch of a run); behind a
         // batch that is still in flight one copy and one pair of kernels is best (every kernel launch ends in a
         // partly filled device: eight slices per batch measured 4 % slower in the steady state).
+        const bool zero_copy = packed && env_double("TBK_ZERO_COPY", 0) != 0 && is_pinned(codes);
         const bool alone = c->streams->in_flight.load() == 0;  // (over all rings of the device)
         const int n_slices = alone ? (int)std::max<uint64_t>(1, std::min<uint64_t>(8, total / c->slice_bases)) : 1;
         ProbeSlice slices[8];
@@ -1781,7 +1783,10 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
             // a pass reads 130 chunks from its first one: the slice needs the stream up to chunk pass_hi * 128 + 2
             const uint64_t upto = j + 1 == n_slices ? n_chunks : std::min<uint64_t>(n_chunks, slices[j].pass_hi * (TBK_PASS_BASES / 16) + 2);
             if (upto > sent) {
-                if (packed && n_slices == 1 && c->streams->copy2 && upto - sent >= ((uint64_t)1 << 22)) {
+                if (packed && zero_copy) {
+                    // (experiment, TBK_ZERO_COPY=1) no copy of the codes at all: the probe's coalesced tile loads read them from the
+                    // caller's pinned memory over PCIe themselves
+                } else if (packed && n_slices == 1 && c->streams->copy2 && upto - sent >= ((uint64_t)1 << 22)) {
                     // steady state, two H2D streams: the second half of the codes travels on a DMA engine of its own
                     const uint64_t mid = sent + (upto - sent) / 2;
                     HIP_TRY(hipMemcpyAsync(s.d_codes + mid, codes + mid, (upto - mid) * sizeof(uint32_t), hipMemcpyHostToDevice, c->streams->copy2));
@@ -1802,7 +1807,7 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         // exceptions into the dense masks (the tail of the last partial chunk is masked there too): a kernel, so on the
         // compute stream - the copy stream carries copies only and never waits for a free compute unit
         if (packed) HIP_TRY(tbk_launch_scatter_bad(s.d_exc_chunk, s.d_exc_mask, n_exc, s.d_bad, total, 0, c->compute));
-        rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? s.d_codes : nullptr,
+        rc = launch_probe_timed(c, packed ? nullptr : s.d_bases, s.d_offsets, n_reads, total, s.d_counts, packed ? (zero_copy ? const_cast<uint32_t *>(codes) : s.d_codes) : nullptr,
                                 packed ? s.d_bad : nullptr, slices, n_slices);
         if (rc) return rc;
         if (packed) {
