@@ -312,25 +312,6 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
     if (past) atomicAdd(&cnt[4], past);
 }
 
-// raw-key membership in a finished entry-layout table (tests; tbk_count_kmers_in_read never uses it)
-__global__ void __launch_bounds__(256)
-tbk_entry_contains_kernel(const uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, TbkEntryGeom g, int k,
-                          const uint64_t *__restrict__ keys, uint64_t n, uint8_t *__restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = keys[i];
-    bool in = false;
-    if (key < TBK_NOKEY && !(tbk_revcomp_packed(key, k) < key)) {
-        uint32_t best = 0xFFFFFFFFu;
-        int at = 0;
-        for (int pi = 0; pi < 2 * mz.w; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); if (r < best) { best = r; at = pi; } }
-        TbkEntryKey forms[2];
-        (void)tbk_entry_orientations(key, k, mz, g, at % mz.w, forms);
-        in = tbk_entry_lookup_one(slots, n_buckets, half, forms[0]);
-    }
-    out[i] = in ? 1 : 0;
-}
-
 // After all inserts: give every full half the order of its last two slots that says whether a key
 // went past it (slot 6 > slot 7) or not (slot 6 < slot 7), and - tables with guests - the order of
 // slots 4 and 5 that says whether one of those keys left the line (slot 4 > slot 5).  One thread per half.
@@ -440,10 +421,6 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #endif
 #ifndef TBK_OCC_PAD
 #define TBK_OCC_PAD 0
-#endif
-//   TBK_DIAG_EXTRA_VALU=n  n more (useless) vector instructions per window step: what does an instruction cost?
-#ifndef TBK_DIAG_EXTRA_VALU
-#define TBK_DIAG_EXTRA_VALU 0
 #endif
 constexpr int TBK_WAVES_PER_BLOCK = 1;      // waves of a block share nothing; one-wave blocks schedule best (measured: 1 > 2 > 4 > 8)
 
@@ -930,16 +907,6 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
         }
         if (MULTI) ok = ok && (uint32_t)(j + k) <= rel_end && rid < p.n_reads;
         const uint32_t bkt = bucket_here(j);
-#if TBK_DIAG_EXTRA_VALU
-        {
-            uint32_t d0 = s0, d1 = t2;
-#pragma unroll
-            for (int x = 0; x < TBK_DIAG_EXTRA_VALU; x += 2) {
-                asm volatile("v_xor_b32 %0, %1, %0" : "+v"(d0) : "v"(s1));
-                asm volatile("v_xor_b32 %0, %1, %0" : "+v"(d1) : "v"(t3));
-            }
-        }
-#endif
         // an invalid window keeps the previous bucket (it never forces a fetch) and looks up
         // TBK_NOKEY, which is never stored (it can never hit)
         // Bit 31 of the broadcast bucket says "not the bucket of this lane's previous window": only
@@ -1911,14 +1878,6 @@ extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_bucket
     return hipGetLastError();
 }
 
-extern "C" hipError_t tbk_launch_entry_contains(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
-                                                uint8_t *d_out, hipStream_t stream) {
-    TbkEntryGeom g;
-    if (!tbk_entry_geom(k, mz, &g)) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(tbk_entry_contains_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slots, n_buckets, half, mz, g, k, d_keys, n, d_out);
-    return hipGetLastError();
-}
 
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
                                         const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, uint32_t *d_left_line, uint32_t guests, TbkTableView skip,
