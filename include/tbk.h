@@ -192,7 +192,7 @@ int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_beh
  * entry_layout = 1 when the table that stands is laid out so (2: WIDE entries of 16 bytes, for k-mers whose context
  * does not fit a slot - k = 26 .. 32); entries_a/_b = entries the lists' keys take.  Chosen for clustered lists whose
  * keys merge (>= TBK_ENTRY_MIN_RATIO, default 1.5, keys per entry); TBK_ENTRY=1 / 0 pins it, TBK_ENTRY_WIDE=1 / 0 the
- * wide form, TBK_ENTRY_LOAD / TBK_WENTRY_LOAD set the entries per list and bucket (defaults 0.40 / 0.25). */
+ * wide form, TBK_ENTRY_LOAD / TBK_WENTRY_LOAD set the entries per list and bucket (defaults 0.64 / 0.25). */
 int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b);
 /* Random 64-byte reads, a quad of lanes per line as the probe asks for a front, over this table where it lies
  * in HBM: lines per second (a diagnostic: the same table measures up to 15 % differently from one placement in

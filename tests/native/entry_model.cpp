@@ -29,20 +29,21 @@ struct Table {
 
 // the insert rule (sequential form): first compatible entry of the list along the m-mer's bucket sequence, else the first empty slot
 static void insert_form(Table &t, uint32_t half, TbkEntryKey e) {
+    const uint32_t hapb = half ? 1 : 0;
     uint32_t b = tbk_entry_bucket(e.cm, t.n_buckets);
     for (uint32_t walked = 0; walked <= t.n_buckets; walked++) {
         uint64_t *line = t.slots.data() + (uint64_t)b * 16;
-        for (uint32_t s = 0; s < 8; s++) {
-            uint64_t &v = line[tbk_eslot_at(half, s)];
+        for (uint32_t s = 0; s < 16; s++) {
+            uint64_t &v = line[s];
             if ((v & ~((uint64_t)TBK_ENTRY_FLAG << 32)) == 0) {
-                v |= (uint64_t)e.cm | ((uint64_t)e.khi << 32);
+                v |= (uint64_t)e.cm | ((uint64_t)(e.khi | (hapb ? TBK_ENTRY_HAPB : 0u)) << 32);
                 t.entries++;
-                if (s >= 2) { line[tbk_eslot_at(half, 1)] |= (uint64_t)TBK_ENTRY_FLAG << 32; t.behind++; }
+                if (s >= 4) { line[3] |= (uint64_t)TBK_ENTRY_FLAG << 32; t.behind++; }
                 return;
             }
-            if (tbk_entry_compatible(v, e, t.z, t.g)) { v |= (uint64_t)e.khi << 32; t.merged++; return; }
+            if (tbk_entry_compatible(v, e, hapb, t.z, t.g)) { v |= (uint64_t)e.khi << 32; t.merged++; return; }
         }
-        line[tbk_eslot_at(half, 7)] |= (uint64_t)TBK_ENTRY_FLAG << 32;
+        line[15] |= (uint64_t)TBK_ENTRY_FLAG << 32;
         t.past++;
         b = tbk_entry_next_bucket(e.cm, t.n_buckets, b, walked == 0);
     }
@@ -133,7 +134,7 @@ static bool contains(const Table &t, uint32_t half, uint64_t key) {
     TbkEntryKey f[64];
     const int n = forms_of(t, key, f);
     bool any = false, all = true;
-    for (int i = 0; i < n; i++) { const bool h = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, half, f[i]); any = any || h; all = all && h; }
+    for (int i = 0; i < n; i++) { const bool h = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, f[i]) == (half ? 1 : 0); any = any || h; all = all && h; }
     if (any != all) { fprintf(stderr, "forms of one key disagree\n"); exit(3); }
     return any;
 }
@@ -233,7 +234,8 @@ int main(int argc, char **argv) {
                     in_a = which == 0; in_b = which == 1;
                 } else {
                     const TbkEntryKey e = window_key(t, fwd, tie);
-                    in_a = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 0, e); in_b = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, 8, e);
+                    const int which = tbk_entry_lookup_one(t.slots.data(), t.n_buckets, e);
+                    in_a = which == 0; in_b = which == 1;
                 }
                 if (in_a != (set_a.count(key) != 0) || in_b != (set_b.count(key) != 0)) bad++;
                 windows++; hits_a += in_a; hits_b += in_b;

@@ -17,7 +17,7 @@ def model(tmp_path_factory):
     return exe
 
 
-@pytest.mark.parametrize("k,w,crowd", [(21, 7, 0), (21, 7, 1), (22, 7, 1), (21, 6, 0), (21, 6, 1), (21, 5, 1), (21, 4, 0), (22, 6, 0), (22, 4, 1), (23, 6, 1), (23, 5, 0), (24, 5, 1), (25, 4, 0)])
+@pytest.mark.parametrize("k,w,crowd", [(21, 6, 0), (21, 6, 1), (21, 5, 1), (21, 4, 0), (22, 6, 0), (22, 4, 1), (23, 6, 1), (23, 5, 0), (24, 5, 1), (25, 4, 0)])
 def test_entry_model_equals_set_membership(model, k, w, crowd):
     for seed in (1, 2):
         r = subprocess.run([model, str(k), str(w), str(seed), str(crowd)], capture_output=True, text=True)

@@ -40,7 +40,7 @@ def _genome_lists(rng, k, n_loci, snp_every=150, genome=40_000):
     return sa, sb, la[:n_loci], lb[:n_loci]
 
 
-NARROW = [(21, 7, 0), (21, 6, 0), (21, 5, 0), (21, 4, 0), (22, 7, 0), (22, 6, 0), (23, 6, 0), (23, 5, 0), (24, 5, 0), (25, 4, 0)]
+NARROW = [(21, 6, 0), (21, 5, 0), (21, 4, 0), (22, 6, 0), (23, 6, 0), (23, 5, 0), (24, 5, 0), (25, 4, 0)]
 WIDE = [(31, 8, 1), (31, 6, 1), (32, 7, 1), (29, 8, 1), (27, 6, 1), (26, 7, 1), (21, 6, 1), (24, 7, 1)]   # wide entries (16 bytes): k up to 32, and any k when asked for
 
 
@@ -56,8 +56,6 @@ def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k
     rng = np.random.default_rng(100 * k + 10 * w + crowded)
     monkeypatch.setenv("TBK_ENTRY", "1")
     monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
-    if (k, w, wide) == (21, 7, 0):
-        monkeypatch.setenv("TBK_MINIMIZER_M", "15")   # the longest span k = 21 has room for: seven 15-mers, flanks and V bits fill an entry's 31 bits
     monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5" if crowded else "0.3")   # crowded: 5.5 entries per list and bucket of 8 slots
     monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.25")  # wide entries: four per list and line
     if wide:

@@ -358,24 +358,29 @@ struct TbkPairView {
 //     hi word   bits [0, 2 FL)       left flank  - context bases 0 .. FL-1, the base next to the m-mer highest
 //               bits [2 FL, 4 FL)    right flank - context bases FL+m .. FL+m+FL-1
 //               bits [4 FL, +w)      V: bit p set = "the k-mer whose sampled m-mer sits at span position p is in the list"
-//               bit 31               a flag of the slot's place in its line, no part of the entry (see tbk_eslot_at)
+//               bit 30               the list: 0 hapA, 1 hapB
+//               bit 31               a flag of the slot's place in its line, no part of the entry
 // in the orientation in which the m-mer is canonical.  The k-mer at span position p is its m-mer plus the o + p bases
 // before it and the (w - 1 - p) + o bases after it: in the flank field those are the CONTIGUOUS 2 (k - m) bits from bit
 // 2 (w - 1 - p) on (the left flank's top bases, then the right flank's low ones).  A window with oriented k-mer K and
 // position p therefore matches an entry iff   lo == m-mer   and   (hi ^ khi) & mhi == 0,   where khi holds K's flank
 // bases at that place plus the bit V[p], and mhi covers exactly those bits: one v_bfi and one 64-bit compare per slot
-// (expected = (cm, bfi(mhi, khi, hi))).  Bases of an entry outside every valid window's extent are zero and never
-// looked at.  Keys of different loci that share an m-mer share an entry as long as their flanks agree where both define
-// them; otherwise they are separate entries of the bucket.  EMPTY is 0 (no V bit: matches nothing).  A window that may
-// not match (a byte outside ACGT, a read end) asks for the m-mer 0xFFFFFFFF, which no entry holds: T x 16 is not
-// canonical (its reverse complement A x 16 = 0 is smaller), and shorter m-mers stay below it.
+// (expected = (cm, bfi(mhi, khi, hi))); which list the hit counts for is the entry's bit 30.  Bases of an entry outside
+// every valid window's extent are zero and never looked at.  Keys of ONE list that share an m-mer share an entry as long
+// as their flanks agree where both define them; otherwise they are separate entries of the bucket.  EMPTY is 0 (no V bit:
+// matches nothing).  A window that may not match (a byte outside ACGT, a read end) asks for the m-mer 0xFFFFFFFF, which
+// no entry holds: T x 16 is not canonical (its reverse complement A x 16 = 0 is smaller), and shorter m-mers stay below.
+// A line is 16 slots that BOTH lists fill in order (the lists are disjoint - hapB keys that hapA holds are left out - so
+// a window matches at most one entry of its line); the probe's window loop reads the first four, 32 bytes, with two
+// lanes per window.  Bit 31 of slot 3: "more than four entries in this line"; of slot 15: "an entry went past this line"
+// (second-choice bucket by a hash of the m-mer, then linear).
 // A variant's k-mers cost one slot per bucket instead of four to five: the haplotype-shaped lists of the bench shrink
-// from 6.0e8 keys to 1.4e8 entries, fronts of two slots per list hold them, and the probe asks for 32 bytes of a line
-// with two lanes per window.  Needs m <= 16 and 4 FL + w <= 31: k = 21 (w = 7 with m = 15, w = 6 with m = 16), k = 22 and 23
-// (w = 7 / 6), k = 24 and 25 with shorter spans.
+// from 6.0e8 keys to 1.6e8 entries.  Needs m <= 16 and 4 FL + w <= 30: k = 21 .. 23 with the span of six m-mers,
+// k = 24, 25 with shorter ones; longer k-mers take wide entries (below).
 #define TBK_FLAG_ENTRY 4u    // `guests` word of the views: the paired table is in entry layout
 #define TBK_ENTRY_NO_MMER 0xFFFFFFFFu   // the m-mer an invalid window asks for
 #define TBK_ENTRY_FLAG 0x80000000u
+#define TBK_ENTRY_HAPB 0x40000000u
 
 struct TbkEntryGeom {
     int fl;      // flank bases kept on each side of the m-mer: o + w - 1
@@ -386,7 +391,7 @@ struct TbkEntryGeom {
 TBK_HD bool tbk_entry_geom(int k, TbkMz z, TbkEntryGeom *g) {
     if (z.w < 2 || z.t <= 0 || z.m > 16 || z.m < 8) return false;
     const int fl = z.o + z.w - 1;
-    if (4 * fl + z.w > 31) return false;
+    if (4 * fl + z.w > 30) return false;
     g->fl = fl; g->fbits = 2 * (k - z.m); g->vshift = 4 * fl;
     return true;
 }
@@ -422,22 +427,13 @@ TBK_HD uint32_t tbk_entry_defined(uint32_t hi, TbkMz z, TbkEntryGeom g) {
     return d;
 }
 
-// may the window `e` (a list key) join the entry in `slot`?  Same m-mer, and the flanks agree wherever both define them.
-TBK_HD bool tbk_entry_compatible(uint64_t slot, TbkEntryKey e, TbkMz z, TbkEntryGeom g) {
+// may the window `e` (a key of list `hapb`) join the entry in `slot`?  Same m-mer, same list, and the flanks agree wherever both define them.
+TBK_HD bool tbk_entry_compatible(uint64_t slot, TbkEntryKey e, uint32_t hapb, TbkMz z, TbkEntryGeom g) {
     if ((uint32_t)slot != e.cm) return false;
     const uint32_t hi = (uint32_t)(slot >> 32);
-    const uint32_t mine = e.mhi & ~(1u << 31) & ((1u << g.vshift) - 1u);  // my flank bits
+    if (((hi & TBK_ENTRY_HAPB) != 0) != (hapb != 0)) return false;
+    const uint32_t mine = e.mhi & ((1u << g.vshift) - 1u);  // my flank bits
     return ((hi ^ e.khi) & mine & tbk_entry_defined(hi, z, g)) == 0;
-}
-
-// A line of the entry layout, 16 slots: [A0 A1 | B0 B1 | A2 A3 | A4 A5 | A6 A7 | B2 B3 | B4 B5 | B6 B7].  The probe's
-// window loop reads the first 32 bytes (lane 0 of a pair: hapA's two front slots, lane 1: hapB's); a list's slots fill
-// in index order, so its first empty slot ends a search.  Bit 31 of front slot 1 says "this list has entries behind the
-// front of this line" (slot 2 is taken), bit 31 of slot 7 "an entry of this list went past this line" (all eight taken
-// and one more wanted in): set by the inserts, read by the probe from slots it holds anyway.
-TBK_HD uint32_t tbk_eslot_at(uint32_t half, uint32_t s) {
-    const uint32_t b = half ? 1u : 0u;
-    return s < 2 ? 2u * b + s : 4u + 6u * b + (s - 2u);
 }
 
 TBK_HD uint32_t tbk_entry_bucket(uint32_t cm, uint32_t n_buckets) { return tbk_reduce(tbk_mmer_hash(cm), n_buckets); }
@@ -461,21 +457,21 @@ TBK_HD int tbk_entry_orientations(uint64_t key, int k, TbkMz z, TbkEntryGeom g, 
     return n;
 }
 
-// Membership of one list key in one list's entries (build-time scans, tests, the CPU model): any one of the key's
+// Which list holds the window (build-time scans, tests, the CPU model): -1 none, 0 hapA, 1 hapB.  Any one of a key's
 // (orientation, tied position) forms is stored iff the key is.
-TBK_HD bool tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkEntryKey e) {
+TBK_HD int tbk_entry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkEntryKey e) {
     uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
     for (uint32_t walked = 0; walked <= n_buckets; walked++) {
         const uint64_t *line = slots + (uint64_t)b * 16;
-        for (uint32_t s = 0; s < 8; s++) {
-            const uint64_t v = line[tbk_eslot_at(half, s)];
-            if ((v & ~((uint64_t)TBK_ENTRY_FLAG << 32)) == 0) return false;  // first empty slot of the list in this line
-            if (tbk_entry_match(v, e)) return true;
+        for (uint32_t s = 0; s < 16; s++) {
+            const uint64_t v = line[s];
+            if ((v & ~((uint64_t)TBK_ENTRY_FLAG << 32)) == 0) return -1;  // first empty slot of the line
+            if (tbk_entry_match(v, e)) return (int)((v >> 62) & 1ull);
         }
-        if (!((line[tbk_eslot_at(half, 7)] >> 63) & 1ull)) return false;     // nothing went past this line
+        if (!((line[15] >> 63) & 1ull)) return -1;                        // nothing went past this line
         b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
     }
-    return false;
+    return -1;
 }
 
 // ---- wide entries: the entry layout for k-mers too long for 64 bits of context (k up to 32) -----------------------

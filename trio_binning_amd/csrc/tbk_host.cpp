@@ -1179,8 +1179,10 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // The entry layout: a span of 6 m-mers where k leaves room for the flanks in an entry's 30 bits (k = 21 .. 23), shorter
     // spans up to k = 25.  Its table is sized by the ENTRIES, which are known only once it is built: the first build guesses
     // four keys per entry (what runs around SNPs give at w = 6), a second one follows when that was off by more than a
-    // quarter.  TBK_ENTRY_LOAD: entries per list and bucket (default 0.40: fronts of two slots overflow in 0.8 % of the
-    // buckets; the haplotype-shaped lists of the bench: 2 x 3e8 keys = 1.6e8 entries in 24 GB, 40 bytes per key; 0.24 .. 0.48 run alike, 0.64 loses 6 %: profiles/r04).
+    // quarter.  TBK_ENTRY_LOAD: entries per list and bucket (default 0.64: the four front slots of a line are whoever comes
+    // first's, so a bucket overflows its front with its fifth entry - the haplotype-shaped lists of the bench: 2 x 3e8 keys =
+    // 1.6e8 entries in 15 GB, 25 bytes per key, 4 % of the entries behind a front; 0.40 .. 0.64 run alike, 0.80 loses 3 %, 1.0
+    // 11 %: profiles/r04/ab_entry_layout.log).
     const double entry_pin = env_double("TBK_ENTRY", -1);
     auto try_entry_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 32) return false;
@@ -1210,7 +1212,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
         const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.25)))   // (four entries per list and line)
-                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.40)));  // (tests crowd the lines: 8 slots per list)
+                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.64)));  // (tests crowd the lines: 8 slots per list)
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
         double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);

@@ -152,11 +152,12 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
 // Entry layout (tbk_common.h): one list key per thread, stored through each of its forms - one per position that
 // attains the smallest t-mer rank (as in tbk_insert_kernel), two where the sampled m-mer is its own reverse complement.
 // A form joins the first entry of its list, along its m-mer's bucket sequence, whose flanks agree with its own
-// (a 64-bit CAS that adds the form's flank bits and its V bit), or takes the first empty slot.  Entries only ever gain
-// bits, so "compatible" can only turn into "incompatible" while a thread looks, never back: a key is stored exactly once
-// per form however the threads interleave.  Bit 63 of a list's front slot 1 / of its slot 7 is set when an entry is
-// created behind the front / when a form leaves the line.  List lines that are not canonical are dead in the reference
-// (stored verbatim, c/kmers.c:113; looked up as min(fwd, rc), c/kmers.c:255) and are not stored.
+// (a 64-bit CAS that adds the form's flank bits and its V bit), or takes the first empty slot of the line (both lists fill
+// a line's 16 slots in order; half = 0: hapA's list, else hapB's - bit 62 of the slot).  Entries only ever gain bits, so
+// "compatible" can only turn into "incompatible" while a thread looks, never back: a key is stored exactly once per form
+// however the threads interleave.  Bit 63 of slot 3 / of slot 15 is set when an entry is created behind the front / when
+// a form leaves the line.  List lines that are not canonical are dead in the reference (stored verbatim, c/kmers.c:113;
+// looked up as min(fwd, rc), c/kmers.c:255) and are not stored.
 // cnt: [0] keys stored, [1] hapB keys left out because hapA holds them, [2] entries created, [3] of those behind a
 // front, [4] forms that left a line.
 __global__ void __launch_bounds__(256)
@@ -183,27 +184,28 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
             const int nf = tbk_entry_orientations(key, k, mz, g, pi % mz.w, forms);
             for (int f = 0; f < nf; f++) {
                 const TbkEntryKey e = forms[f];
-                if (first_form && skip_a && tbk_entry_lookup_one(slots, n_buckets, 0, e)) { skipped++; drop = true; break; }  // (hapA's half is finished)
-                const unsigned long long entry = (unsigned long long)e.cm | ((unsigned long long)e.khi << 32);
+                if (first_form && skip_a && tbk_entry_lookup_one(slots, n_buckets, e) == 0) { skipped++; drop = true; break; }  // (hapA's inserts are finished)
+                const uint32_t hapb = half ? 1u : 0u;
+                const unsigned long long entry = (unsigned long long)e.cm | ((unsigned long long)(e.khi | (hapb ? TBK_ENTRY_HAPB : 0u)) << 32);
                 uint32_t b = tbk_entry_bucket(e.cm, n_buckets);
                 bool done = false;
                 for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
                     unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
-                    for (uint32_t sl = 0; sl < 8 && !done; sl++) {
-                        unsigned long long *slot = &line[tbk_eslot_at(half, sl)];
+                    for (uint32_t sl = 0; sl < 16 && !done; sl++) {
+                        unsigned long long *slot = &line[sl];
                         unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         for (;;) {
                             if ((cur & ~FLAG64) == 0) {  // empty: mine, unless somebody is quicker
                                 const unsigned long long old = atomicCAS(slot, cur, cur | entry);
                                 if (old == cur) {
                                     created++; stored += first_form; done = true;
-                                    if (sl >= 2) { behind++; atomicOr(&line[tbk_eslot_at(half, 1)], FLAG64); }
+                                    if (sl >= 4) { behind++; atomicOr(&line[3], FLAG64); }
                                     break;
                                 }
                                 cur = old;
                                 continue;
                             }
-                            if (!tbk_entry_compatible(cur, e, mz, g)) break;  // (stays incompatible: entries only gain bits) - next slot
+                            if (!tbk_entry_compatible(cur, e, hapb, mz, g)) break;  // the other list's, or flanks that disagree (and stay so: entries only gain bits) - next slot
                             if (tbk_entry_match(cur, e)) { done = true; break; }  // a duplicate line, or this key's other tied position naming the same m-mer and place
                             const unsigned long long old = atomicCAS(slot, cur, cur | ((unsigned long long)e.khi << 32));
                             if (old == cur) { stored += first_form; done = true; break; }
@@ -211,7 +213,7 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
                         }
                     }
                     if (!done) {
-                        atomicOr(&line[tbk_eslot_at(half, 7)], FLAG64);
+                        atomicOr(&line[15], FLAG64);
                         past++;
                         b = tbk_entry_next_bucket(e.cm, n_buckets, b, walked == 0);
                     }
@@ -1257,8 +1259,7 @@ __device__ __forceinline__ TbkWideKey wide_key_of(uint4 it, int w, int fbits, in
     return e;
 }
 
-// narrow entries: the walk of one list (half) of one window; wide entries: one walk per window over the pieces both lists
-// share (`half` unused), *hap = the list of the entry found
+// one walk per window over the slots / pieces both lists share (`half` unused), *hap = the list of the entry found
 template <bool WIDE, class KEY>
 __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t half, KEY e, uint32_t bucket, bool pend, uint32_t *hap) {
     bool found = false, first = true;
@@ -1282,10 +1283,11 @@ __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t hal
                 }
             } else {
 #pragma unroll 1
-                for (uint32_t sl = 0; sl < 8 && !ended; sl += 2) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + tbk_eslot_at(half, sl));
-                    hit = hit || tbk_entry_match(v.x, e) || tbk_entry_match(v.y, e);
-                    ended = (v.y << 1) == 0;  // an empty slot: the list ends in this line
+                for (uint32_t sl = 0; sl < 16 && !ended && !hit; sl += 2) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + sl);
+                    if (tbk_entry_match(v.x, e)) { hit = true; *hap = (uint32_t)(v.x >> 62) & 1u; }
+                    else if (tbk_entry_match(v.y, e)) { hit = true; *hap = (uint32_t)(v.y >> 62) & 1u; }
+                    ended = (v.y << 1) == 0;  // an empty slot: the line's entries end here
                     last = v.y;
                 }
             }
@@ -1309,10 +1311,8 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
         if constexpr (WIDE) {
             found = walk_one_entry<true>(p.t, 0, wide_key_of(it, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act, &list);
         } else {
-            uint32_t unused;
-            list = it.w & 1u;
-            rrel = it.w >> 1;
-            found = walk_one_entry<false>(p.t, list * 8u, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act, &unused);
+            rrel = it.w;
+            found = walk_one_entry<false>(p.t, 0, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act, &list);
         }
         const bool count_a = found && !list, count_b = found && list;
         if (!MULTI) {
@@ -1350,15 +1350,17 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
         } else {
             rrel = it.w;
             const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
-            hit = ballot(tbk_entry_match(v.x, e)) | ballot(tbk_entry_match(v.y, e));
-            hit_a = hit & 0x0707070707070707ull; hit_b = hit & 0x3838383838383838ull;
+            const uint64_t hx = ballot(tbk_entry_match(v.x, e)), hy = ballot(tbk_entry_match(v.y, e));
+            const uint64_t bx = ballot(((v.x >> 62) & 1ull) != 0), by = ballot(((v.y >> 62) & 1ull) != 0);
+            hit = hx | hy;
+            hit_a = (hx & ~bx) | (hy & ~by); hit_b = (hx & bx) | (hy & by);
         }
-        // narrow: lane 2 holds hapA's last slots, lane 5 hapB's; wide: lane 5 the line's last piece - bit 63 of the second word = an entry went past this line
+        // lane 5 holds the line's last slots / piece: bit 63 of its second word = an entry went past this line
         const uint64_t gone = ballot((v.y >> 63) != 0);
         const uint64_t any = hit_a | hit_b;
         const uint64_t oct_hit = (any | (any >> 1) | (any >> 2) | (any >> 3) | (any >> 4) | (any >> 5)) & 0x0101010101010101ull;
-        const uint64_t walk_a = WIDE ? ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit : ((gone >> 2) & 0x0101010101010101ull) & ~oct_hit;
-        const uint64_t walk_b = WIDE ? 0ull : ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit;  // (wide entries: one walk per window, over both lists' pieces)
+        const uint64_t walk_a = ((gone >> 5) & 0x0101010101010101ull) & ~oct_hit;  // one walk per window, over both lists' entries
+        const uint64_t walk_b = 0ull;
         if (!MULTI) {
             acc_a += (uint32_t)__popcll(hit_a);
             acc_b += (uint32_t)__popcll(hit_b);
@@ -1370,13 +1372,11 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
         if (queued) {
             const uint64_t me = 1ull << lane;
             const uint32_t n_a = (uint32_t)__popcll(walk_a);
-            const uint32_t at_a = qn + (uint32_t)__popcll(walk_a & (me - 1)), at_b = qn + n_a + (uint32_t)__popcll(walk_b & (me - 1));
+            const uint32_t at_a = qn + (uint32_t)__popcll(walk_a & (me - 1));
             if constexpr (WIDE) {
                 if (walk_a & me) { walkq[at_a] = make_uint4(it.x, it.y, it.z, it.w & 0x3FFFFFFFu); if (MULTI) walkr[at_a] = (uint16_t)rrel; }
-                if (walk_b & me) { walkq[at_b] = make_uint4(it.x, it.y, it.z, (it.w & 0x3FFFFFFFu) | (1u << 30)); if (MULTI) walkr[at_b] = (uint16_t)rrel; }
             } else {
-                if (walk_a & me) walkq[at_a] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w << 1);
-                if (walk_b & me) walkq[at_b] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, (it.w << 1) | 1u);
+                if (walk_a & me) walkq[at_a] = make_uint4(it.x, it.y, it.z & 0x3FFFFFFFu, it.w);
             }
             qn += n_a + (uint32_t)__popcll(walk_b);
             if (qn > TBK_QCAP_ENTRY - 16) {
@@ -1587,7 +1587,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             mh2_s[0] = pair_bcast<0>(my_mhi2); mh2_s[1] = pair_bcast<1>(my_mhi2);
             cm2_s[0] = pair_bcast<0>(cm_ask2); cm2_s[1] = pair_bcast<1>(cm_ask2);
         }
-        uint64_t hit[2], more[2], hapm[2] = {0, 0};
+        uint64_t hit[2], more[2], hitx[2] = {0, 0};
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const uint32_t hx = (uint32_t)(va[s].x >> 32), hy = (uint32_t)(va[s].y >> 32);
@@ -1599,10 +1599,10 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             } else {
                 const uint64_t wx = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hx & ~mh_s[s])) << 32);
                 const uint64_t wy = (uint64_t)cm_s[s] | ((uint64_t)((kh_s[s] & mh_s[s]) | (hy & ~mh_s[s])) << 32);
-                hit[s] = ballot(va[s].x == wx) | ballot(va[s].y == wy);
+                hitx[s] = ballot(va[s].x == wx);
+                hit[s] = hitx[s] | ballot(va[s].y == wy);
             }
-            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the list's front slot 1 (wide entries: of the line's piece 1): entries behind the front
-            if constexpr (WIDE) hapm[s] = ballot((hy & 0x40000000u) != 0);  // which list the lane's entry belongs to
+            more[s] = ballot((int32_t)hy < 0);  // bit 63 of the line's slot 3 / piece 1 (the odd lane's second word): entries behind the front
         }
         if ((more[0] | more[1]) != 0) {
             // windows that missed in a front with entries behind it: queued by the lane that owns the window
@@ -1610,8 +1610,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 if (more[s] == 0) continue;
-                // narrow: the even lane's flag is hapA's, the odd lane's hapB's; wide: only piece 1 (the odd lane) carries one, for the line
-                const uint64_t ma = WIDE ? 0ull : (more[s] & 0x5555555555555555ull), mb = (more[s] >> 1) & 0x5555555555555555ull;
+                // only the odd lane's second word (slot 3 / piece 1) carries the flag, for the line
+                const uint64_t ma = 0ull, mb = (more[s] >> 1) & 0x5555555555555555ull;
                 need |= ((ma | mb) & ~pair_any(hit[s])) << s;
                 beh_a |= ma << s;
                 beh_b |= mb << s;
@@ -1634,12 +1634,18 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             }
         }
         if ((hit[0] | hit[1]) != 0) {
-            // which list a hit counts for: narrow entries - the lane it fell on (even: hapA's slots, odd: hapB's); wide - the entry's list bit
+            // which list a hit counts for is the entry's list bit (bit 62 of the slot / of a wide entry's second word)
             uint64_t ha[2], hb[2];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                ha[s] = WIDE ? hit[s] & ~hapm[s] : hit[s] & 0x5555555555555555ull;
-                hb[s] = WIDE ? hit[s] & hapm[s] : hit[s] & 0xAAAAAAAAAAAAAAAAull;
+                if constexpr (WIDE) {
+                    const uint64_t bm = ballot(((uint32_t)(va[s].y >> 32) & 0x40000000u) != 0);
+                    ha[s] = hit[s] & ~bm; hb[s] = hit[s] & bm;
+                } else {
+                    const uint64_t bx = ballot(((uint32_t)(va[s].x >> 32) & TBK_ENTRY_HAPB) != 0), by = ballot(((uint32_t)(va[s].y >> 32) & TBK_ENTRY_HAPB) != 0);
+                    const uint64_t hy_ = hit[s] & ~hitx[s];  // (a window matches at most one slot of the line)
+                    ha[s] = (hitx[s] & ~bx) | (hy_ & ~by); hb[s] = (hitx[s] & bx) | (hy_ & by);
+                }
             }
             if (TWO) {
 #pragma unroll
