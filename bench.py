@@ -351,15 +351,51 @@ def realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement):
 
 
 def kernel_fingerprint():
-    """sha256 over the sources the probe kernels are compiled from: a PMC traffic record (profiles/pmc_traffic*.json) is
-    only replayed into `roofline.traffic` when it was taken on these very kernels."""
+    """sha256 over the machine code of the probe kernels: the `.text` section of the gfx950 code object inside
+    trio_binning_amd/csrc/build/tbk_kernels.o (read with a few lines of ELF / offload-bundle parsing: no tool, no child
+    process).  A PMC traffic record (profiles/pmc_traffic*.json) is only replayed into `roofline.traffic` when it was
+    taken on these very kernels; a comment in the source changes nothing, an instruction does.  (The fat binary as a
+    whole is not reproducible from one compile to the next - the device code is.)  Falls back to the sources' hash
+    when the object is not there."""
     import hashlib
+    import struct
 
-    h = hashlib.sha256()
-    for name in ("tbk_kernels.hip", "tbk_common.h", "tbk_device.h"):
-        with open(os.path.join(ROOT, "trio_binning_amd", "csrc", name), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()
+    def sections(buf, base):
+        if buf[base:base + 4] != b"\x7fELF":
+            raise ValueError("not an ELF object")
+        shoff, = struct.unpack_from("<Q", buf, base + 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", buf, base + 0x3A)
+        hdr = lambda i: struct.unpack_from("<IIQQQQIIQQ", buf, base + shoff + i * shentsize)
+        stro = base + hdr(shstrndx)[4]
+        out = {}
+        for i in range(shnum):
+            h = hdr(i)
+            name = buf[stro + h[0]:buf.index(b"\0", stro + h[0])].decode()
+            out[name] = (base + h[4], h[5])
+        return out
+
+    try:
+        buf = open(os.path.join(ROOT, "trio_binning_amd", "csrc", "build", "tbk_kernels.o"), "rb").read()
+        off, size = sections(buf, 0)[".hip_fatbin"]
+        fb = buf[off:off + size]
+        if fb[:24] != b"__CLANG_OFFLOAD_BUNDLE__":
+            raise ValueError("unexpected offload bundle")
+        n, = struct.unpack_from("<Q", fb, 24)
+        p = 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", fb, p)
+            triple = fb[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and sz:
+                to, ts = sections(fb, o)[".text"]
+                return "text:" + hashlib.sha256(fb[to:to + ts]).hexdigest()
+        raise ValueError("no gfx950 code object")
+    except Exception:
+        h = hashlib.sha256()
+        for name in ("tbk_kernels.hip", "tbk_common.h", "tbk_device.h"):
+            with open(os.path.join(ROOT, "trio_binning_amd", "csrc", name), "rb") as fh:
+                h.update(fh.read())
+        return "source:" + h.hexdigest()
 
 
 def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement):
@@ -598,14 +634,14 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                     and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
                     and bool(t.get("entry_layout", False)) == bool(stats.get("entry_layout"))
                     and t.get("kernel") == "tbk_probe_kernel<single-read>")
-            if same and t.get("kernel_source_sha256") != kernel_fingerprint():
+            if same and t.get("kernel_sha256") != kernel_fingerprint():
                 # taken on other kernels than the ones in this tree: stale bytes are not reported
-                traffic_src = ("profiles/" + tname + " is STALE: its PMC passes ran on kernel sources " + str(t.get("kernel_source_sha256"))[:12]
-                               + ", this tree's are " + kernel_fingerprint()[:12] + " - re-run tools/gpu_profile.sh; traffic withheld")
+                traffic_src = ("profiles/" + tname + " is STALE: its PMC passes ran on kernels " + str(t.get("kernel_sha256"))[:17]
+                               + ", this tree's are " + kernel_fingerprint()[:17] + " - re-run tools/gpu_profile.sh; traffic withheld")
             elif same:  # measured in separate rocprofv3 --pmc passes on this configuration (not in this run); scaled to this launch's windows
                 traffic = t["hbm_bytes_per_window"] * windows_single
-                traffic_src = ("profiles/" + tname + " (rocprofv3 --pmc passes of this configuration on these kernel sources, sha256 "
-                               + kernel_fingerprint()[:12] + ", replayed per window; not measured in this run)")
+                traffic_src = ("profiles/" + tname + " (rocprofv3 --pmc passes of this configuration on these very kernels, machine code sha256 "
+                               + kernel_fingerprint()[5:17] + ", replayed per window; not measured in this run)")
         except Exception:
             pass
     roofline = {

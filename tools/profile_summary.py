@@ -90,7 +90,7 @@ for lists in ("uniform", "haplotypes"):
 
         traffic = {
             "kernel": "tbk_probe_kernel<single-read>",
-            "kernel_source_sha256": kernel_fingerprint(),  # bench.py replays this record only on these very kernel sources
+            "kernel_sha256": kernel_fingerprint(),  # bench.py replays this record only on these very kernels (hash of their machine code)
             "note": "HBM bytes of one launch of the single-read probe kernel (tbk_probe_kernel<..., MULTI = false>), from rocprofv3 PMC passes run separately from the timed bench "
                     "(tools/gpu_profile.sh): FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM), "
                     "cross-checked by TCC_MISS_sum x 128 B; divided by the launch's window starts so that bench.py can scale it to its own launch size.",

@@ -1220,14 +1220,15 @@ __device__ __forceinline__ void probe_pass(const ProbeArgs &p, const uint64_t e0
 // =======================================================================================
 // The pass of the key layouts with three differences.  (1) A window asks with (canonical m-mer, flank bits, mask)
 // instead of its canonical k-mer: the orientation is the sampled m-mer's, which the sampling arithmetic has at hand.
-// (2) The probe is PAIR-cooperative: the front of a line is 32 bytes [A0 A1 | B0 B1], lane 0 of a pair holds hapA's two
-// front slots, lane 1 hapB's, and a window step has two sub-steps instead of four - half the broadcasts, compares and
-// scalar ballot work of the quad probe, and 8 registers of line data per lane instead of 16.  One wave instruction
-// touches 32 lines.  (3) A slot is compared under the window's mask: expected = (m-mer, bfi(mask, flanks, slot.hi)),
-// one v_bfi and one 64-bit compare.  Flags are bits (bit 63 of a list's second front slot: entries behind the front).
+// (2) The probe is PAIR-cooperative: the front of a line is 32 bytes - four slots, or two 16-byte pieces of wide
+// entries - that both lists fill in order; each lane of a pair holds half of it, and a window step has two sub-steps
+// instead of four - half the broadcasts, compares and scalar ballot work of the quad probe, and 8 registers of line
+// data per lane instead of 16.  One wave instruction touches 32 lines.  (3) A slot is compared under the window's mask:
+// expected = (m-mer, bfi(mask, flanks, slot.hi)), one v_bfi and one 64-bit compare; which list a hit counts for is a
+// bit of the entry, read only in steps that hit.  Flags are bits (bit 63 of the front's last slot: entries behind it).
 // A window that misses in a front with entries behind it is queued; drain_back_entry settles eight at a time from the
-// line's other 96 bytes (six lanes x 16 bytes, an L2 hit), and only a list whose eight slots are full and were left by
-// an entry (bit 63 of its slot 7) sends the window on to the walk.
+// line's other 96 bytes (six lanes x 16 bytes, an L2 hit), and only a line that is full and was left by an entry
+// (bit 63 of its last slot) sends the window on to the walk.
 template <int S>
 __device__ __forceinline__ uint32_t pair_bcast(uint32_t v) {
     // DPP quad_perm:[S, S, 2 + S, 2 + S]: lane S of each pair
@@ -1235,8 +1236,8 @@ __device__ __forceinline__ uint32_t pair_bcast(uint32_t v) {
 }
 __device__ __forceinline__ uint64_t pair_any(uint64_t m) { return (m | (m >> 1)) & 0x5555555555555555ull; }
 
-// walk queue entry: x = m-mer, y = flank bits + V bit, z = home bucket, w = list (0 hapA, 1 hapB) | read << 1
-// back queue entry: x = m-mer, y = flank bits + V bit, z = home bucket | hapA has entries behind its front << 30 | hapB << 31, w = read
+// walk queue entry: x = m-mer, y = flank bits + V bit, z = home bucket, w = read
+// back queue entry: x = m-mer, y = flank bits + V bit, z = home bucket | flags << 30, w = read
 __device__ __forceinline__ TbkEntryKey entry_key_of(uint32_t cm, uint32_t khi, int w, int fbits, int vshift) {
     const uint32_t v = khi >> vshift;                         // exactly one V bit
     const int pos = 31 - (int)__clz(v);
@@ -1325,8 +1326,8 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
     }
 }
 
-// eight queued windows at a time, eight lanes per window: lanes 0..2 hold hapA's pieces behind the front of the home line,
-// lanes 3..5 hapB's (16 bytes each, the line's bytes 32..127: two slots of the narrow layout, one wide entry), lanes 6 and 7 nothing
+// eight queued windows at a time, eight lanes per window: lanes 0..5 hold the six 16-byte pieces behind the front of the home
+// line (its bytes 32..127: two slots of the narrow layout, one wide entry each), lanes 6 and 7 nothing
 template <bool MULTI, bool WIDE>
 __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, const uint16_t *bqr, uint32_t qb, uint4 *walkq, uint16_t *walkr, uint32_t &qn,
                                                  uint64_t r_first, uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
