@@ -95,6 +95,9 @@ def parse(argv=None):
                          "k-mers); haplotypes: lists shaped like real find-unique-kmers output (two haplotypes of a random "
                          "genome differing by SNPs; reads drawn from them with errors)")
     ap.add_argument("--snp-rate", type=float, default=1 / 500, help="haplotypes: SNPs per base of each haplotype")
+    ap.add_argument("--repeat-fraction", type=float, default=0.0,
+                    help="haplotypes: this fraction of the genome's 8-kb blocks are copies of one of 16 family sequences, "
+                         "2 %% diverged (young interspersed repeats: the lists' crowded buckets)")
     ap.add_argument("--error-rate", type=float, default=0.002, help="haplotypes: substitution errors per read base")
     ap.add_argument("--plant-major", type=int, default=30)
     ap.add_argument("--plant-minor", type=int, default=3)
@@ -412,7 +415,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     genome_len = snp24 = err24 = 0
     if hap:
         # genome long enough for ~n_list windows that cover a position where the haplotypes differ
-        snp24 = max(1, int(round(args.snp_rate * (1 << 24))))
+        snp24 = min((1 << 24) - 1, max(1, int(round(args.snp_rate * (1 << 24))))) | (min(255, int(round(args.repeat_fraction * 256))) << 24)
         err24 = int(round(args.error_rate * (1 << 24)))
         p_diff = 2 * args.snp_rate - args.snp_rate ** 2 * (1 + 1 / 3)
         genome_len = int(n_list / (1 - (1 - p_diff) ** k))
@@ -703,7 +706,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u64",
-        "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g})",
+        "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g}" + (f", {args.repeat_fraction:g} of the genome in repeats" if args.repeat_fraction else "") + ")",
         "config": {
             "workload": workload, "timed_path": args.timed_path,
             "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R if not strong else None,

@@ -423,7 +423,9 @@ int tbk_synth_reads_device(int device, uint64_t read_seed, uint64_t first_read, 
  * snp_per_2p24 / 2^24 per base; list A / list B = the canonical k-mers of haplotype A / B that
  * cover a position where the haplotypes differ (runs of up to k overlapping k-mers sharing a few
  * minimizers, both lists clustered at the same loci).  Both lists get *n_keys entries (order not
- * deterministic, sets are); at most `capacity` are written to each of d_keys_a / d_keys_b. */
+ * deterministic, sets are); at most `capacity` are written to each of d_keys_a / d_keys_b.
+ * Bits 24..31 of snp_per_2p24, when set, add repeats: that many 256ths of the genome's 8192-base
+ * blocks are copies of one of 16 family sequences, each copy diverged at 2 % of its positions. */
 int tbk_synth_hap_keys_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24, int k,
                               void *d_keys_a, void *d_keys_b, uint64_t capacity, uint64_t *n_keys);
 /* Read r comes from haplotype (first_read + r) & 1, from a hashed position and strand, with

@@ -632,9 +632,21 @@ TBK_HD uint64_t tbk_splitmix(uint64_t x) {
 // haplotypes differ are the "haplotype-unique" lists: they come in runs of up to k overlapping
 // k-mers that share a handful of minimizers, hapA's and hapB's runs at the same loci - the
 // shape of real find-unique-kmers output, unlike tbk_synth_key's uniform keys.
-TBK_HD void tbk_hap_bases(uint64_t seed, uint64_t p, uint32_t snp24, uint32_t &base_a, uint32_t &base_b) {
+// Bits 24..31 of the shape word add repeats: rep8 / 256 of the genome's 8192-base blocks are copies of
+// one of 16 family sequences, each copy diverged from its family at 2 % of its positions (young
+// interspersed repeats: with 10 % of a 3 Gbase genome that is ~2300 near-identical copies per family,
+// whose variant k-mers all share the family's m-mers - the crowded-bucket case of a real list).
+TBK_HD void tbk_hap_bases(uint64_t seed, uint64_t p, uint32_t shape, uint32_t &base_a, uint32_t &base_b) {
+    const uint32_t snp24 = shape & 0xFFFFFFu, rep8 = shape >> 24;
     const uint64_t r = tbk_splitmix(seed ^ (p * 0x9E3779B97F4A7C15ull));
-    const uint32_t base = (uint32_t)r & 3u;
+    uint32_t base = (uint32_t)r & 3u;
+    if (rep8) {
+        const uint64_t hb = tbk_splitmix(seed ^ 0xB10CB10CB10Cull ^ ((p >> 13) * 0xD6E8FEB86659FD93ull));
+        if ((uint32_t)(hb & 0xFFu) < rep8 && (uint32_t)((r * 0x94D049BB133111EBull) >> 56) >= 5u) {
+            const uint64_t fam = (hb >> 8) & 15ull;
+            base = (uint32_t)tbk_splitmix(seed ^ ((((fam + 1ull) << 48) | (p & 8191ull)) * 0xA0761D6478BD642Full)) & 3u;
+        }
+    }
     const uint32_t draw_a = (uint32_t)(r >> 4) & 0xFFFFFFu, draw_b = (uint32_t)(r >> 28) & 0xFFFFFFu;
     const uint32_t alt_a = (base + 1u + (uint32_t)((r >> 52) & 0xFFu) % 3u) & 3u;
     const uint32_t alt_b = (base + 1u + (uint32_t)((r >> 56) & 0xFFu) % 3u) & 3u;
