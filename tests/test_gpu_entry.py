@@ -189,3 +189,54 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
     with kmers.Classifier(kmers.HashSet.from_keys(uni[:n], 21), kmers.HashSet.from_keys(uni[n:], 21)) as cls:
         st = cls.stats()
         assert not st["entry_layout"] and st["front_layout"] and st["layout_builds"] == 1, st
+
+
+@pytest.mark.parametrize("k", [21, 25, 31])
+def test_lists_from_a_genome_with_repeat_families(gpu, orc, monkeypatch, k):
+    """Half of a 60-Mbase genome in 16 repeat families (~230 copies each, 2 % diverged): the copies' variant k-mers crowd
+    the buckets of their family's m-mers - entries past their line, windows that walk - and reads drawn from that genome
+    ask for them.  Counts equal the oracle's in the entry layout the policy picks and in the key layouts."""
+    import ctypes as C
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    for v in ("TBK_ENTRY", "TBK_ENTRY_WIDE", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_ENTRY_LOAD", "TBK_WENTRY_LOAD"):
+        monkeypatch.delenv(v, raising=False)
+    dev, G, R, L = 0, 60_000_000, 160, 6000
+    shape = int(round((1 / 500) * (1 << 24))) | (128 << 24)
+    cap = 8_000_000
+
+    def dalloc(n):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, n, C.byref(p)))
+        return p.value
+
+    d_keys = dalloc(2 * cap * 8)
+    got = C.c_uint64()
+    check(lib.tbk_synth_hap_keys_device(dev, 0x5EED0077, G, shape, k, C.c_void_p(d_keys), C.c_void_p(d_keys + cap * 8), cap, C.byref(got)))
+    n = got.value
+    assert 3_000_000 < n <= cap
+    keys = np.empty(2 * cap, dtype=np.uint64)
+    check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data, C.c_void_p(d_keys), keys.nbytes))
+    ka, kb = keys[:n], keys[cap:cap + n]
+    d_bases, d_offs = dalloc(R * L + 32), dalloc((R + 1) * 8)
+    check(lib.tbk_synth_hap_reads_device(dev, 0x5EED0077, G, shape, 0xBEEF, 0, R, L, int(0.002 * (1 << 24)), C.c_void_p(d_bases), C.c_void_p(d_offs)))
+    bases, offs = np.empty(R * L, dtype=np.uint8), np.empty(R + 1, dtype=np.uint64)
+    check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_bases), bases.nbytes))
+    check(lib.tbk_memcpy_d2h(dev, offs.ctypes.data, C.c_void_p(d_offs), offs.nbytes))
+    for p in (d_keys, d_bases, d_offs):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+    want = orc.count_batch(bases, offs, orc.table_from_keys(ka, k), orc.table_from_keys(kb, k))
+    assert want.sum() > 20 * R                                           # the reads do find list k-mers
+    a, b = kmers.HashSet.from_keys(ka, k), kmers.HashSet.from_keys(kb, k)
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["entry_layout"] and st["wide_entries"] == (k > 25), st
+        assert st["keys_behind_front"] > 0, st                           # crowded: entries behind their lines' fronts
+        print(k, {x: st[x] for x in ("entries_a", "entries_b", "keys_behind_front", "keys_past_half", "table_bytes")})
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
+    monkeypatch.setenv("TBK_ENTRY", "0")
+    with kmers.Classifier(a, b) as cls:
+        assert not cls.stats()["entry_layout"]
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
