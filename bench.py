@@ -636,6 +636,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                     and abs(t.get("table_load", 0) - table_load) < 2e-3
                     and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
                     and bool(t.get("entry_layout", False)) == bool(stats.get("entry_layout"))
+                    and bool(t.get("short_keys", False)) == bool(stats.get("short_keys"))
                     and t.get("kernel") == "tbk_probe_kernel<single-read>")
             if same and t.get("kernel_sha256") != kernel_fingerprint():
                 # taken on other kernels than the ones in this tree: stale bytes are not reported
@@ -650,7 +651,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_src,
-        "kernel": ("tbk_probe_entry_kernel<W, MULTI=false, TWO=false>" if stats.get("entry_layout") else "tbk_probe_kernel<..., MULTI=false, TWO=false>") + " (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
+        "kernel": ("tbk_probe_entry_kernel<W, MULTI=false, TWO=false>" if stats.get("entry_layout") else "tbk_probe_entry_kernel<W, MULTI=false, TWO=false, KIND=2: short keys>" if stats.get("short_keys")
+                   else "tbk_probe_kernel<..., MULTI=false, TWO=false>") + " (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
         "timed_in": "the timed region of `value` (HIP events on the compute stream)",
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
         "share_of_the_batch_windows": round(single_frac, 4), "passes": int(n_passes), "multi_read_passes": int(multi_passes),
@@ -716,6 +718,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
             "line_layout": (("entries (wide, 16 bytes)" if stats.get("wide_entries") else "entries") + ": a run of overlapping list k-mers stored once; 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("entry_layout")
+                            else "short keys: a list k-mer in 32 bits (what its bucket does not say already); 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("short_keys")
                             else "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines"),
             "keys_behind_front": stats.get("keys_behind_front"),
             "entries": [stats.get("entries_a"), stats.get("entries_b")] if stats.get("entry_layout") else None,

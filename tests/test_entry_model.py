@@ -38,3 +38,28 @@ def test_entry_geometry_limits(model):
     for k in (27, 31, 32):
         r = subprocess.run([model, str(k), "6", "1", "0"], capture_output=True, text=True)
         assert r.returncode == 0 and "no entry layout" in r.stdout, r.stdout
+
+
+@pytest.fixture(scope="module")
+def short_model(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("short_model") / "short_model")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "short_model.cpp")], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("k,w,n_buckets", [(21, 6, 0), (21, 6, 65536), (21, 6, 300000), (21, 5, 0), (19, 5, 70001), (22, 4, 0), (23, 6, 0)])
+def test_short_key_model_equals_set_membership(short_model, k, w, n_buckets):
+    """Short keys (tbk_common.h): a 32-bit word plus its bucket names a k-mer exactly - list keys through every form, near
+    misses that share a line with them, windows of both strands, crowded lines that spill into the overflow table."""
+    for seed in (1, 2):
+        r = subprocess.run([short_model, str(k), str(w), str(seed), str(n_buckets)], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert r.stdout.startswith("short ") and "mismatches 0" in r.stdout, r.stdout
+        assert " 0 in the overflow table" not in r.stdout, r.stdout
+
+
+def test_short_key_geometry_limits(short_model):
+    # below the fewest buckets the word has no room for r; k = 31 has no room at any table size
+    for args in (("21", "6", "1", "65535"), ("23", "6", "1", "1000000"), ("31", "6", "1", "1000000000")):
+        r = subprocess.run([short_model, *args], capture_output=True, text=True)
+        assert r.returncode == 0 and "no short keys" in r.stdout, r.stdout

@@ -40,33 +40,28 @@ def _genome_lists(rng, k, n_loci, snp_every=150, genome=40_000):
     return sa, sb, la[:n_loci], lb[:n_loci]
 
 
-NARROW = [(21, 6, 0), (21, 5, 0), (21, 4, 0), (22, 6, 0), (23, 6, 0), (23, 5, 0), (24, 5, 0), (25, 4, 0)]
-WIDE = [(31, 8, 1), (31, 6, 1), (32, 7, 1), (29, 8, 1), (27, 6, 1), (26, 7, 1), (21, 6, 1), (24, 7, 1)]   # wide entries (16 bytes): k up to 32, and any k when asked for
-
-
-@pytest.mark.parametrize("k,w,wide", NARROW + WIDE)
-@pytest.mark.parametrize("crowded", [0, 1])
-def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, wide, crowded):
-    """Lists of runs (two haplotypes' unique k-mers), uniform keys, duplicate lines, lines shared between the lists on
-    either strand, non-canonical lines (dead in the reference), low-complexity and palindromic sequence; reads drawn
-    from both haplotypes on both strands with errors, ragged shapes, bytes outside ACGT - in a roomy table and in one
-    so crowded that lists overflow their lines (second looks, walks)."""
+def _case(rng, k, tmp_path, orc, crowd_cores=0):
+    """Lists, reads and the oracle's counts of one layout test (see test_entry_layout_counts_equal_the_oracle); crowd_cores:
+    that many stretches of sequence with 200 list k-mers each that differ from it in their end bases (all of them sample
+    an m-mer of the stretch: lines that overflow whatever the table's size)."""
     from trio_binning_amd import kmers
 
-    rng = np.random.default_rng(100 * k + 10 * w + crowded)
-    monkeypatch.setenv("TBK_ENTRY", "1")
-    monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
-    monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5" if crowded else "0.3")   # crowded: 5.5 entries per list and bucket of 8 slots
-    monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.25")  # wide entries: four per list and line
-    if wide:
-        monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
-    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
     sa, sb, la, lb = _genome_lists(rng, k, 6000)
     uni = ["".join("ACGT"[c] for c in rng.integers(0, 4, k)) for _ in range(1500)]
     la += uni[:700]
     lb += uni[700:1400]
     lb += [la[int(i)] for i in rng.integers(0, len(la), 40)] + [_rc(la[int(i)]) for i in rng.integers(0, len(la), 40)]   # shared with hapA
     la += [la[int(i)] for i in rng.integers(0, len(la), 20)]                                                               # duplicate lines
+    cores = []
+    for c in range(crowd_cores):
+        core = "".join("ACGT"[x] for x in rng.integers(0, 4, k))
+        cores.append(core)
+        for i in range(200):
+            x = list(core)
+            for j in (0, 1, 2, k - 3, k - 2, k - 1):
+                if rng.random() < 0.5:
+                    x[j] = "ACGT"[int(rng.integers(0, 4))]
+            (la if (c + i) & 1 else lb).append("".join(x))
     la += ["A" * k, "T" * k, ("AC" * k)[:k], ("ACGT" * k)[:k]]
     fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
     fb = _write(tmp_path, "b.txt", "\n".join(lb))
@@ -90,10 +85,44 @@ def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k
     for i in rng.integers(0, 3000, 40):
         noisy[int(i)] = "NnacgtR-"[int(rng.integers(0, 8))]
     reads.append("".join(noisy))
+    for core in cores:   # variants of the crowded stretches, most of them NOT in the lists, on either strand
+        vs = []
+        for _ in range(120):
+            x = list(core)
+            for j in (0, 1, 2, k - 3, k - 2, k - 1):
+                if rng.random() < 0.5:
+                    x[j] = "ACGT"[int(rng.integers(0, 4))]
+            vs.append("".join(x))
+        reads += ["".join(vs[:60]), _rc("".join(vs[60:]))]
     reads = [reads[int(i)] for i in rng.permutation(len(reads))]
     bases, offs = _pack(reads)
     want = orc.count_batch(bases, offs, oa, ob, strict=True)
     assert want.sum() > 2000
+    return a, b, bases, offs, want, reads
+
+
+NARROW = [(21, 6, 0), (21, 5, 0), (21, 4, 0), (22, 6, 0), (23, 6, 0), (23, 5, 0), (24, 5, 0), (25, 4, 0)]
+WIDE = [(31, 8, 1), (31, 6, 1), (32, 7, 1), (29, 8, 1), (27, 6, 1), (26, 7, 1), (21, 6, 1), (24, 7, 1)]   # wide entries (16 bytes): k up to 32, and any k when asked for
+
+
+@pytest.mark.parametrize("k,w,wide", NARROW + WIDE)
+@pytest.mark.parametrize("crowded", [0, 1])
+def test_entry_layout_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, wide, crowded):
+    """Lists of runs (two haplotypes' unique k-mers), uniform keys, duplicate lines, lines shared between the lists on
+    either strand, non-canonical lines (dead in the reference), low-complexity and palindromic sequence; reads drawn
+    from both haplotypes on both strands with errors, ragged shapes, bytes outside ACGT - in a roomy table and in one
+    so crowded that lists overflow their lines (second looks, walks)."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(100 * k + 10 * w + crowded)
+    monkeypatch.setenv("TBK_ENTRY", "1")
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+    monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5" if crowded else "0.3")   # crowded: 5.5 entries per list and bucket of 8 slots
+    monkeypatch.setenv("TBK_WENTRY_LOAD", "2.8" if crowded else "0.25")  # wide entries: four per list and line
+    if wide:
+        monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
+    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
+    a, b, bases, offs, want, reads = _case(rng, k, tmp_path, orc)
     with kmers.Classifier(a, b) as cls:
         st = cls.stats()
         assert st["entry_layout"] and st["wide_entries"] == bool(wide) and st["minimizer_w"] == w and st["sampling_t"] > 0, st
@@ -135,7 +164,7 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
     from trio_binning_amd import kmers
     from trio_binning_amd._lib import check, lib
 
-    for v in ("TBK_ENTRY", "TBK_ENTRY_WIDE", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_ENTRY_LOAD", "TBK_WENTRY_LOAD"):
+    for v in ("TBK_ENTRY", "TBK_ENTRY_WIDE", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT", "TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_ENTRY_LOAD", "TBK_WENTRY_LOAD", "TBK_SHORT", "TBK_SHORT_LOAD"):
         monkeypatch.delenv(v, raising=False)
     dev, n = 0, 400_000
     rng = np.random.default_rng(3)
@@ -186,9 +215,16 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
         monkeypatch.delenv("TBK_ENTRY")
     uni = np.empty(2 * n, dtype=np.uint64)
     check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, 21, uni.ctypes.data))
-    with kmers.Classifier(kmers.HashSet.from_keys(uni[:n], 21), kmers.HashSet.from_keys(uni[n:], 21)) as cls:
+    # uniform lists do not merge: short keys (50 bytes of HBM per key), one build; without them the key layout's front
+    ua, ub = kmers.HashSet.from_keys(uni[:n], 21), kmers.HashSet.from_keys(uni[n:], 21)
+    with kmers.Classifier(ua, ub) as cls:
         st = cls.stats()
-        assert not st["entry_layout"] and st["front_layout"] and st["layout_builds"] == 1, st
+        assert st["short_keys"] and not st["entry_layout"] and not st["front_layout"] and st["layout_builds"] == 1, st
+        assert st["table_bytes"] <= 52 * 2 * n and st["keys_behind_front"] <= 0.03 * 2 * n, st
+    monkeypatch.setenv("TBK_SHORT", "0")
+    with kmers.Classifier(ua, ub) as cls:
+        st = cls.stats()
+        assert not st["short_keys"] and not st["entry_layout"] and st["front_layout"] and st["layout_builds"] == 1, st
 
 
 @pytest.mark.parametrize("k", [21, 25, 31])
@@ -240,3 +276,46 @@ def test_lists_from_a_genome_with_repeat_families(gpu, orc, monkeypatch, k):
     with kmers.Classifier(a, b) as cls:
         assert not cls.stats()["entry_layout"]
         assert np.array_equal(cls.classify_batch(bases, offs), want)
+
+
+SHORT = [(21, 6), (21, 5), (21, 4), (19, 4), (20, 5), (22, 6), (23, 6), (23, 8), (24, 5), (24, 7), (25, 6), (25, 8)]
+
+
+@pytest.mark.parametrize("k,w", SHORT)
+@pytest.mark.parametrize("crowded", [0, 1])
+def test_short_keys_counts_equal_the_oracle(gpu, orc, tmp_path, monkeypatch, k, w, crowded):
+    """Short keys (tbk_common.h): a list k-mer as the 32 bits its bucket does not say already.  The same lists and reads as
+    for the entry layouts, plus stretches of sequence with hundreds of list k-mers each (their lines overflow into the
+    overflow table whatever the table's size); in the smallest table k allows (crowded: 24 keys per line asked for) and in a
+    roomy one."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(1000 * k + 10 * w + crowded)
+    monkeypatch.setenv("TBK_SHORT", "1")
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+    monkeypatch.setenv("TBK_SHORT_LOAD", "24" if crowded else "0.2")
+    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
+    a, b, bases, offs, want, reads = _case(rng, k, tmp_path, orc, crowd_cores=6)
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["short_keys"] and not st["entry_layout"] and st["minimizer_w"] == w and st["sampling_t"] > 0, st
+        assert st["keys_behind_front"] > 0 and (k < 21 or st["keys_past_half"] > 0), st     # second looks, and keys in the overflow table (k >= 21: the stretches' variant bases leave room for a shared m-mer)
+        got = cls.classify_batch(bases, offs)
+        again = cls.classify_batch(bases, offs)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (k, w, crowded, st, bad[:10], got[bad[:5]], want[bad[:5]], [len(reads[int(i)]) for i in bad[:5]])
+    assert np.array_equal(again, want)
+
+
+def test_short_keys_on_the_reference_vectors(gpu, monkeypatch):
+    """The recorded counts of the real reference (tests/golden/diff_vectors.json, k = 21) through short keys."""
+    from trio_binning_amd import kmers
+
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == 21)
+    monkeypatch.setenv("TBK_SHORT", "1")
+    a = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_a"]], dtype=np.uint64), 21)
+    b = kmers.HashSet.from_keys(np.array([kmers.kmer_to_int(s) for s in v["list_b"]], dtype=np.uint64), 21)
+    with kmers.Classifier(a, b) as cls:
+        assert cls.stats()["short_keys"]
+        got = cls.classify_reads(v["reads"])
+    assert np.array_equal(got, np.array(v["counts"], dtype=np.int32))

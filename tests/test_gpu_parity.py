@@ -397,11 +397,21 @@ def test_table_membership_and_dedupe(gpu):
         del os.environ["TBK_TABLE_LOAD"]
     assert t2.contains(keys).all() and not t2.contains(absent).any()
     assert t2.nbytes < t.nbytes
-    with kmers.Classifier(t, t2) as cls:
-        st = cls.stats()
+    os.environ["TBK_SHORT"] = "0"   # the key layout stores list lines verbatim, as the reference does (c/kmers.c:113)
+    try:
+        with kmers.Classifier(t, t2) as cls:
+            st = cls.stats()
+    finally:
+        del os.environ["TBK_SHORT"]
     # the same list on both sides: hapA holds every key, so none is stored for hapB
     assert st["distinct_a"] == t.distinct and st["distinct_b"] == 0 and st["shared_keys"] == keys.size
     assert st["table_bytes"] == st["n_buckets"] * 128
+    # short keys (what lists of this size get by themselves) leave out the lines that are not canonical - no window ever
+    # asks for them (c/kmers.c:255 looks up min(fwd, rc)) - and again nothing is stored for hapB
+    with kmers.Classifier(t, t2) as cls:
+        st = cls.stats()
+    assert st["short_keys"] and 0.4 * t.distinct < st["distinct_a"] < 0.6 * t.distinct and st["distinct_b"] == 0, st
+    assert st["shared_keys"] >= st["distinct_a"] and st["table_bytes"] > st["n_buckets"] * 128, st
 
 
 @pytest.mark.parametrize("k", [21, 31, 32])
@@ -551,6 +561,7 @@ def test_lists_choose_the_line_layout(gpu, orc, monkeypatch):
     monkeypatch.delenv("TBK_MOD_SAMPLING", raising=False)
     monkeypatch.delenv("TBK_TABLE_LOAD", raising=False)
     monkeypatch.delenv("TBK_FRONT", raising=False)
+    monkeypatch.setenv("TBK_SHORT", "0")   # the KEY layouts' policy (lists of this size that do not merge get short keys first: tests/test_gpu_entry.py)
     dev, k, n = 0, 21, 400_000
 
     def dalloc(nbytes):
@@ -685,6 +696,7 @@ def test_span_follows_k(gpu, orc, monkeypatch, k, want_w):
 
     for v in ("TBK_MINIMIZER_W", "TBK_MINIMIZER_M", "TBK_MOD_SAMPLING", "TBK_TABLE_LOAD", "TBK_FRONT"):
         monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("TBK_SHORT", "0")   # (the key layouts' spans; short keys take the front layout's span: tests/test_gpu_entry.py)
     n = 200_000
     uni = np.empty(2 * n, dtype=np.uint64)
     check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, k, uni.ctypes.data))

@@ -95,7 +95,7 @@ for lists in ("uniform", "haplotypes"):
                     "(tools/gpu_profile.sh): FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM), "
                     "cross-checked by TCC_MISS_sum x 128 B; divided by the launch's window starts so that bench.py can scale it to its own launch size.",
             "read_len": cfg["read_len"], "kmers_per_list": cfg["kmers_per_list"], "k": cfg["k"], "bucket_select": cfg["bucket_select"],
-            "table_load": cfg["table_load"], "lists": lists, "front_layout": str(cfg.get("line_layout", "")).startswith("front"), "entry_layout": str(cfg.get("line_layout", "")).startswith("entries"), "windows_per_launch": windows,
+            "table_load": cfg["table_load"], "lists": lists, "front_layout": str(cfg.get("line_layout", "")).startswith("front"), "entry_layout": str(cfg.get("line_layout", "")).startswith("entries"), "short_keys": str(cfg.get("line_layout", "")).startswith("short"), "windows_per_launch": windows,
             "hbm_bytes_per_launch": hbm, "hbm_bytes_per_window": hbm / windows,
             "fetch_size_kib_raw": summary["FETCH_SIZE"], "write_size_kib_raw": summary.get("WRITE_SIZE"),
             "tcc_miss": summary.get("TCC_MISS_sum"), "tcc_hit": summary.get("TCC_HIT_sum"),

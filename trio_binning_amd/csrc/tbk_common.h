@@ -346,6 +346,7 @@ struct TbkPairView {
     uint32_t n_buckets;
     TbkMz mz;               // bucket selection
     uint32_t guests;        // see TbkTableView
+    uint32_t over_mask;     // short keys (TBK_FLAG_SHORT): slots of the overflow table behind the lines, minus one (0: none)
 };
 
 // ---- entry layout: a run of overlapping list k-mers is stored once ------------------------------------------------
@@ -575,6 +576,104 @@ TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkW
         }
         if (!(last1 >> 63)) return -1;                  // nothing went past this line
         b = tbk_wentry_next_bucket(e.cm, n_buckets, b, walked == 0);
+    }
+    return -1;
+}
+
+// ---- short keys: a list k-mer in 32 bits, exactly (lists whose keys do NOT merge into entries) -----------------------
+// BASELINE's synthetic lists are uniform random k-mers: no two of them overlap, an entry would hold one key.  For such
+// lists the key layout spends 8 bytes a key and its probe reads 64 bytes of a line with four lanes per window.  But a
+// window that has found its bucket already knows most of its key: the bucket is a function of the sampled m-mer, and
+// what is left is
+//     r      which of the few m-mer hashes that map to this bucket it is: the low product word of tbk_reduce
+//            (hash x n_buckets) shifted right by rshift = floor(log2 n_buckets) - hashes of one bucket are consecutive,
+//            their products n_buckets apart, so distinct hashes give distinct r; tbk_mmer_hash is a bijection of the
+//            32-bit m-mers: (bucket, r) <-> m-mer, exactly;  32 - rshift bits
+//     pos    the m-mer's position in the span, 3 bits
+//     flank  the k - m bases around the m-mer in the orientation in which the m-mer is canonical (as tbk_entry_key)
+// - at k = 21 with 2^27.8 buckets that is 5 + 3 + 10 bits.  A SHORT slot is one 32-bit word:
+//     bits [0, 29)  flank | pos << fbits | r << (fbits + 3);  bit 29  taken;  bit 30  the list (1 = hapB);  bit 31  a flag
+// A line is 32 slots both lists fill in order; the probe's window loop reads the first eight (32 bytes, two lanes per
+// window as for entries, four compares of 32 bits per lane and list); bit 31 of slot 7: "slots behind the front are in
+// use" (settled from the line's other 96 bytes by drain_back, an L2 hit); bit 31 of slot 31: "a key of this bucket is in
+// the overflow table" - open addressing over 64-bit canonical keys (| list << 63) behind the lines, for the handful of
+// keys whose m-mer's bucket holds more than 32.  EMPTY is 0; a window that may not match asks 0xFFFFFFFF (every compare
+// strips the slot's bit 31 first).  Needs m <= 16 and fbits + 3 + 32 - rshift <= 29:
+// k = 21 from 65536 buckets on, k = 23 from 2^20, k = 25 from 2^24.
+#define TBK_FLAG_SHORT 16u   // `guests` word of the views: the paired table holds short keys
+#define TBK_SHORT_FLAG 0x80000000u
+#define TBK_SHORT_HAPB 0x40000000u
+#define TBK_SHORT_TAKEN 0x20000000u
+#define TBK_SHORT_NONE 0xFFFFFFFFu
+#define TBK_SHORT_EMPTY64 0xFFFFFFFFFFFFFFFFull   // empty slot of the overflow table
+
+struct TbkShortGeom {
+    int fbits;   // 2 (k - m)
+    int rshift;  // floor(log2 n_buckets)
+};
+
+TBK_HD bool tbk_short_geom(int k, TbkMz z, uint32_t n_buckets, TbkShortGeom *g) {
+    if (z.w < 2 || z.w > 8 || z.t <= 0 || z.m > 16 || z.m < 8 || n_buckets < 2 || k > 31) return false;
+    int rs = 0;
+    while (rs < 31 && (2u << rs) <= n_buckets) rs++;
+    const int fbits = 2 * (k - z.m);
+    if (fbits + 3 + (32 - rs) > 29) return false;
+    g->fbits = fbits; g->rshift = rs;
+    return true;
+}
+
+// the fewest buckets a table of short keys may have for k and the span
+TBK_HD uint32_t tbk_short_min_buckets(int k, TbkMz z) {
+    const int need = 2 * (k - z.m) + 3 + 32 - 29;  // rshift >= this
+    return need <= 1 ? 2u : need >= 31 ? 0u : (1u << need);
+}
+
+struct TbkShortKey { uint32_t word, bucket; };
+
+// what a window asks: `oriented` and pos as for tbk_entry_key
+TBK_HD TbkShortKey tbk_short_key(uint64_t oriented, TbkMz z, TbkShortGeom g, int pos, uint32_t n_buckets) {
+    const int a = 2 * (z.o + pos);
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    const uint32_t cm = (uint32_t)(oriented >> a) & mmask;
+    const uint32_t low = (uint32_t)oriented & ((1u << a) - 1u);
+    const uint32_t high = a + 2 * z.m >= 64 ? 0u : (uint32_t)(oriented >> (a + 2 * z.m));
+    const uint64_t prod = (uint64_t)tbk_mmer_hash(cm) * (uint64_t)n_buckets;
+    TbkShortKey e;
+    e.bucket = (uint32_t)(prod >> 32);
+    e.word = (low | (high << a)) | ((uint32_t)pos << g.fbits) | (((uint32_t)prod >> g.rshift) << (g.fbits + 3)) | TBK_SHORT_TAKEN;
+    return e;
+}
+
+TBK_HD int tbk_short_orientations(uint64_t key, int k, TbkMz z, TbkShortGeom g, int p, uint32_t n_buckets, TbkShortKey *out) {
+    const uint32_t mmask = z.m == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.m)) - 1u);
+    const uint32_t x = (uint32_t)(key >> (2 * (z.o + p))) & mmask;
+    const uint32_t y = tbk_revcomp32(x, z.m);
+    int n = 0;
+    if (x <= y) out[n++] = tbk_short_key(key, z, g, p, n_buckets);
+    if (x >= y) out[n++] = tbk_short_key(tbk_revcomp_packed(key, k), z, g, z.w - 1 - p, n_buckets);
+    return n;
+}
+
+TBK_HD uint32_t tbk_short_over_home(uint64_t canonical, uint32_t over_mask) {
+    uint64_t h = canonical * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    return (uint32_t)(h * 0xBF58476D1CE4E5B9ull >> 32) & over_mask;
+}
+
+// -1 none, 0 hapA, 1 hapB.  lines = the table's n_buckets x 32 words; over = the overflow table behind them
+// (over_mask + 1 slots; over_mask = 0: none).
+TBK_HD int tbk_short_lookup_one(const uint32_t *lines, uint32_t n_buckets, const uint64_t *over, uint32_t over_mask, TbkShortKey e, uint64_t canonical) {
+    const uint32_t *line = lines + (uint64_t)e.bucket * 32;
+    for (uint32_t s = 0; s < 32; s++) {
+        const uint32_t v = line[s] & ~TBK_SHORT_FLAG;
+        if (v == 0) return -1;
+        if ((v & ~TBK_SHORT_HAPB) == e.word) return (int)((v >> 30) & 1u);
+    }
+    if (!(line[31] & TBK_SHORT_FLAG) || !over_mask) return -1;
+    for (uint32_t i = tbk_short_over_home(canonical, over_mask), walked = 0; walked <= over_mask; walked++, i = (i + 1) & over_mask) {
+        const uint64_t v = over[i];
+        if (v == TBK_SHORT_EMPTY64) return -1;
+        if ((v & ~(1ull << 63)) == canonical) return (int)(v >> 63);
     }
     return -1;
 }

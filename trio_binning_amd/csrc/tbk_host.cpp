@@ -37,6 +37,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, int, unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -327,7 +328,9 @@ struct tbk_classifier {
     uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line (entry layout: entries behind a two-slot front)
     uint64_t entries_a = 0, entries_b = 0;  // entry layout (TBK_FLAG_ENTRY): slots the lists' keys take (a run of overlapping keys is one entry)
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
-    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests}; }
+    uint32_t over_mask = 0;      // short keys (TBK_FLAG_SHORT): the overflow table behind the lines has over_mask + 1 slots of 8 bytes
+    uint64_t table_bytes() const { return (uint64_t)n_buckets * 2 * TBK_BUCKET_BYTES + ((guests & TBK_FLAG_SHORT) ? ((uint64_t)over_mask + 1) * 8 : 0); }
+    TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests, over_mask}; }
     hipStream_t compute = nullptr, copy = nullptr, out = nullptr;  // kernels; H2D of the next batch; D2H of finished counts
     Slot ring[RING];
     uint64_t next_ticket = 1;
@@ -1118,6 +1121,44 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     return TBK_OK;
 }
 
+// The paired table of short keys (tbk_common.h "short keys"): n_buckets lines of 32 words, EMPTY = 0, and behind them the
+// overflow table (over_slots 64-bit slots, all ones = empty); hapA's list first, then hapB's minus the keys hapA holds.
+static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets, uint32_t over_slots) {
+    c->n_buckets = n_buckets;
+    c->over_mask = over_slots - 1;
+    const size_t line_bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES, bytes = line_bytes + (size_t)over_slots * 8;
+    hipError_t e = c->alloc_pair(bytes);
+    if (e == hipSuccess) e = hipMemset(c->d_pair, 0, line_bytes);
+    if (e == hipSuccess) e = hipMemset((char *)c->d_pair + line_bytes, 0xFF, (size_t)over_slots * 8);
+    unsigned long long *d_cnt = nullptr, cnt[2][8];
+    int *d_failed = nullptr, failed = 0;
+    memset(cnt, 0, sizeof cnt);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof cnt[0]);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
+    for (int list = 0; list < 2 && e == hipSuccess; list++) {
+        const tbk_table *t = list ? b : a;
+        e = hipMemset(d_cnt, 0, sizeof cnt[0]);
+        if (e == hipSuccess) e = tbk_launch_short_insert(c->d_pair, c->n_buckets, c->over_mask, (uint32_t)list, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished words)
+    }
+    if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
+    if (d_cnt) (void)hipFree(d_cnt);
+    if (d_failed) (void)hipFree(d_failed);
+    if (e != hipSuccess || failed) {
+        c->free_pair();
+        c->over_mask = 0;
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "paired table of short keys (%zu bytes): %s", bytes, hipGetErrorString(e));
+        return fail(TBK_ERR_HIP, "table insert overflowed (table full)");
+    }
+    c->distinct_a = cnt[0][0]; c->distinct_b = cnt[1][0];
+    c->shared = cnt[1][1];
+    c->entries_a = cnt[0][2] + cnt[0][4]; c->entries_b = cnt[1][2] + cnt[1][4];
+    c->behind_front = cnt[0][3] + cnt[1][3] + cnt[0][4] + cnt[1][4];
+    c->past_half = cnt[0][4] + cnt[1][4];
+    return TBK_OK;
+}
+
 extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -1241,8 +1282,55 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (!forced && ratio < env_double("TBK_ENTRY_MIN_RATIO", 1.5)) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
+    // Short keys (tbk_common.h): lists whose keys do not merge into entries (BASELINE's uniform k-mers) in 4 bytes a key
+    // instead of 8, read through the entry kernels' two-lane window loop: 8 keys of either list in a 32-byte front, 32 in a
+    // line.  TBK_SHORT_LOAD keys per line (default 2.56: 50 bytes of HBM per key; 2 x 3e8 uniform 21-mers: 30 GB, 1.5 % of the
+    // keys behind a front).  Built first where k and the table's size allow (k = 21: any table of 65536 lines or more,
+    // k = 25: 2 GB or more); lists that cluster (more than TBK_BEHIND_FRONT of the keys behind a front) go on to the key
+    // layout's test and from there to entries, as before.  TBK_SHORT=0: never, 1: whatever the lists look like.
+    const double short_pin = env_double("TBK_SHORT", -1);
+    auto try_short_layout = [&](bool forced) -> bool {
+        if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
+        if (!forced && getenv("TBK_TABLE_LOAD")) return false;  // (the key layouts' load is pinned: the key layouts are meant)
+        TbkMz z = span_for(true);  // (the front layout's span: as long as k leaves room for, up to 8 m-mers)
+        if (z.w < 2 || z.t <= 0 || z.m > 16) return false;
+        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.56)));
+        uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
+        const uint32_t min_nb = tbk_short_min_buckets(c->k, z);
+        if (!min_nb) return false;
+        if (nb < min_nb) { if (!forced && (double)min_nb > 2.0 * (double)nb) return false; nb = min_nb; }  // (a small table may be up to twice its size for it)
+        if (nb > 0x3FFFFFF0ull) return false;
+        TbkShortGeom g;
+        if (!tbk_short_geom(c->k, z, (uint32_t)nb, &g)) return false;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { if ((double)nb * 128.0 > 0.6 * (double)total_b) return false; } else (void)hipGetLastError();
+        const TbkMz keep_mz = c->mz;
+        const uint32_t keep_flags = c->guests;
+        c->mz = z;
+        c->guests = TBK_FLAG_SHORT;
+        bool built = false;
+        uint64_t over = 4096;
+        while (over < (a->num_lines + b->num_lines) / 256) over <<= 1;
+        for (int attempt = 0; attempt < 4 && !built; attempt++, over <<= 3) {
+            c->free_pair();
+            if (over > (1ull << 31)) break;
+            if (build_short_table(c, a, b, (uint32_t)nb, (uint32_t)over) == TBK_OK) { built = true; c->layout_builds++; break; }
+            if (g_err.find("full") == std::string::npos) break;
+        }
+        const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
+        if (built && !forced && (double)c->behind_front / n_keys > env_double("TBK_BEHIND_FRONT", 0.05)) built = false;  // the lists cluster
+        if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->over_mask = 0; c->entries_a = c->entries_b = 0; return false; }
+        return true;
+    };
+    if (entry_pin <= 0 && short_pin != 0 && front_pin < 0 && try_short_layout(short_pin > 0)) {
+        c->own_pair();
+        rc = classifier_streams(c);
+        if (rc) { tbk_classifier_destroy(c); return rc; }
+        *out = c;
+        return TBK_OK;
+    }
     if (entry_pin > 0 && try_entry_layout(true)) {
-        c->layout_builds = 1;
+        c->layout_builds++;
         c->own_pair();
         rc = classifier_streams(c);
         if (rc) { tbk_classifier_destroy(c); return rc; }
@@ -1295,7 +1383,8 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->guests = src->guests;
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     c->entries_a = src->entries_a; c->entries_b = src->entries_b;
-    const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    c->over_mask = src->over_mask;
+    const size_t bytes = (size_t)c->table_bytes();
     // TBK_FORCE_REPLICA=1: a ring on the device that holds the table gets a full replica of its own all the same,
     // made by the very calls a second GPU's replica is made by (peer query, hipMemcpyPeer) - how a one-GPU box
     // executes and checks the replica path of an 8-GPU node (tests/test_gpu_multi.py).
@@ -1379,7 +1468,7 @@ extern "C" int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_
     if (distinct_a) *distinct_a = c->distinct_a;
     if (distinct_b) *distinct_b = c->distinct_b;
     if (n_buckets) *n_buckets = c->n_buckets;
-    if (table_bytes) *table_bytes = (uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
+    if (table_bytes) *table_bytes = c->table_bytes();
     return TBK_OK;
 }
 
@@ -1399,7 +1488,7 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
 
 extern "C" int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
-    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_ENTRY) ? ((c->guests & TBK_FLAG_WIDE) ? 2 : 1) : 0;
+    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_SHORT) ? 3 : (c->guests & TBK_FLAG_ENTRY) ? ((c->guests & TBK_FLAG_WIDE) ? 2 : 1) : 0;  // (3: short keys)
     if (entries_a) *entries_a = c->entries_a;
     if (entries_b) *entries_b = c->entries_b;
     return TBK_OK;

@@ -314,6 +314,78 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
     if (past) atomicAdd(&cnt[4], past);
 }
 
+// Short keys (tbk_common.h "short keys"): a list key is stored through each of its forms as ONE 32-bit word in the first free
+// slot of its m-mer's line (32 slots both lists fill in order; half != 0: hapB's list, bit 30 of the word); a form that
+// finds all 32 taken puts the canonical key into the overflow table behind the lines (open addressing, 64-bit CAS) and flags
+// the line's last slot.  hapB's keys that hapA holds are left out (skip_a: hapA's inserts are finished).
+// cnt: [0] keys stored, [1] hapB keys left out, [2] words created, [3] of those behind a front, [4] forms in the overflow table.
+__global__ void __launch_bounds__(256)
+tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsigned long long *__restrict__ over, uint32_t over_mask, uint32_t half, TbkMz mz,
+                        TbkShortGeom g, int k, const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt,
+                        int *__restrict__ failed) {
+    unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
+    const int n_pos = 2 * mz.w;
+    const uint32_t listbit = half ? TBK_SHORT_HAPB : 0u;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        if (key >= TBK_NOKEY) continue;
+        if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
+        uint32_t best = 0xFFFFFFFFu;
+        for (int pi = 0; pi < n_pos; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); best = r < best ? r : best; }
+        bool first_form = true, drop = false;
+        for (int pi = 0; pi < n_pos && !drop; pi++) {
+            if (tbk_tmer_rank(key, mz, pi) != best) continue;
+            TbkShortKey forms[2];
+            const int nf = tbk_short_orientations(key, k, mz, g, pi % mz.w, n_buckets, forms);
+            for (int f = 0; f < nf; f++) {
+                const TbkShortKey e = forms[f];
+                if (first_form && skip_a && tbk_short_lookup_one(lines, n_buckets, (const uint64_t *)over, over_mask, e, key) == 0) { skipped++; drop = true; break; }
+                uint32_t *line = lines + (uint64_t)e.bucket * 32;
+                bool done = false;
+                for (uint32_t sl = 0; sl < 32 && !done; sl++) {
+                    uint32_t cur = __hip_atomic_load(&line[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        if ((cur & ~TBK_SHORT_FLAG) == 0) {  // empty: mine, unless somebody is quicker
+                            const uint32_t old = atomicCAS(&line[sl], cur, cur | e.word | listbit);
+                            if (old == cur) {
+                                created++; stored += first_form; done = true;
+                                if (sl >= 8) { behind++; atomicOr(&line[7], TBK_SHORT_FLAG); }
+                                break;
+                            }
+                            cur = old;
+                            continue;
+                        }
+                        if ((cur & ~(TBK_SHORT_FLAG | TBK_SHORT_HAPB)) == e.word) done = true;  // a duplicate line, or this key's other tied position naming the same m-mer and place
+                        break;
+                    }
+                }
+                if (!done) {
+                    // the line is full: the canonical key goes to the overflow table
+                    atomicOr(&line[31], TBK_SHORT_FLAG);
+                    const unsigned long long mine = (unsigned long long)key | ((unsigned long long)(half ? 1u : 0u) << 63);
+                    uint32_t at = tbk_short_over_home(key, over_mask);
+                    for (uint32_t walked = 0; walked <= over_mask && over_mask != 0 && !done; walked++, at = (at + 1) & over_mask) {
+                        unsigned long long cur = __hip_atomic_load(&over[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (cur == TBK_SHORT_EMPTY64) {
+                            const unsigned long long old = atomicCAS(&over[at], cur, mine);
+                            if (old == cur) { past++; stored += first_form; done = true; break; }
+                            cur = old;
+                        }
+                        if ((cur & ~(1ull << 63)) == key) done = true;  // there already (another form of this key, or a duplicate line)
+                    }
+                }
+                if (!done) atomicExch(failed, 1);
+                first_form = false;
+            }
+        }
+    }
+    if (stored) atomicAdd(&cnt[0], stored);
+    if (skipped) atomicAdd(&cnt[1], skipped);
+    if (created) atomicAdd(&cnt[2], created);
+    if (behind) atomicAdd(&cnt[3], behind);
+    if (past) atomicAdd(&cnt[4], past);
+}
+
 // After all inserts: give every full half the order of its last two slots that says whether a key
 // went past it (slot 6 > slot 7) or not (slot 6 < slot 7), and - tables with guests - the order of
 // slots 4 and 5 that says whether one of those keys left the line (slot 4 > slot 5).  One thread per half.
@@ -1328,22 +1400,31 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
 
 // eight queued windows at a time, eight lanes per window: lanes 0..5 hold the six 16-byte pieces behind the front of the home
 // line (its bytes 32..127: two slots of the narrow layout, one wide entry each), lanes 6 and 7 nothing
-template <bool MULTI, bool WIDE>
+// (short keys, KIND = 2: the queue entry is x = the word asked, y = home bucket | flags, z / w = the canonical k-mer; the six
+// pieces are four slots each; a window that misses in a line whose last slot is flagged asks the overflow table, here)
+template <bool MULTI, int KIND>
 __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, const uint16_t *bqr, uint32_t qb, uint4 *walkq, uint16_t *walkr, uint32_t &qn,
                                                  uint64_t r_first, uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2;
     const uint32_t sub = lane & 7u, oct = lane >> 3;
     for (uint32_t base = 0; base < qb; base += 8) {
         const bool act = base + oct < qb;
-        uint4 it = WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint4 it = SHORT ? make_uint4(TBK_SHORT_NONE, 0, 0, 0) : WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
         uint32_t rrel = 0;
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) {
             it = bq[base + oct];
-            if (WIDE && MULTI) rrel = bqr[base + oct];
-            if (sub < 6) v = load_slots(p.t.slots + (uint64_t)((WIDE ? it.w : it.z) & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
+            if ((WIDE || SHORT) && MULTI) rrel = bqr[base + oct];
+            if (sub < 6) v = load_slots(p.t.slots + (uint64_t)((SHORT ? it.y : WIDE ? it.w : it.z) & 0x3FFFFFFFu) * 16 + 4 + sub * 2);
         }
         uint64_t hit, hit_a, hit_b;
-        if constexpr (WIDE) {
+        if constexpr (SHORT) {
+            const uint32_t qa = it.x, qb2 = it.x | TBK_SHORT_HAPB;
+            const uint32_t w0 = (uint32_t)v.x, w1 = (uint32_t)(v.x >> 32), w2 = (uint32_t)v.y, w3 = (uint32_t)(v.y >> 32) & ~TBK_SHORT_FLAG;
+            hit_a = ballot(w0 == qa || w1 == qa || w2 == qa || w3 == qa);
+            hit_b = ballot(w0 == qb2 || w1 == qb2 || w2 == qb2 || w3 == qb2);
+            hit = hit_a | hit_b;
+        } else if constexpr (WIDE) {
             // the six pieces behind the front belong to whichever list came: the entry's bit 62 says which
             hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it, p.t.mz.w, fbits, vshift)));
             const uint64_t hapm = ballot(((v.y >> 62) & 1ull) != 0);
@@ -1369,6 +1450,29 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             if ((hit_a >> lane) & 1ull) count_hits(p, rcnt, r_first, rrel, 0, 1);
             if ((hit_b >> lane) & 1ull) count_hits(p, rcnt, r_first, rrel, 1, 1);
         }
+        if constexpr (SHORT) {
+            // the line is full and a key of its bucket went to the overflow table: the window's first lane asks there
+            if (walk_a != 0 && p.t.over_mask != 0) {
+                int found = -1;
+                if ((walk_a >> lane) & 1ull) {
+                    const uint64_t key = (uint64_t)it.z | ((uint64_t)it.w << 32);
+                    const uint64_t *over = p.t.slots + (uint64_t)p.t.n_buckets * 16;
+                    uint32_t i = tbk_short_over_home(key, p.t.over_mask);
+                    for (uint32_t walked = 0; walked <= p.t.over_mask; walked++, i = (i + 1) & p.t.over_mask) {
+                        const uint64_t o = over[i];
+                        if (o == TBK_SHORT_EMPTY64) break;
+                        if ((o & ~(1ull << 63)) == key) { found = (int)(o >> 63); break; }
+                    }
+                }
+                if (!MULTI) {
+                    acc_a += (uint32_t)__popcll(ballot(found == 0));
+                    acc_b += (uint32_t)__popcll(ballot(found == 1));
+                } else if (found >= 0) {
+                    count_hits(p, rcnt, r_first, rrel, (uint32_t)found, 1);
+                }
+            }
+            continue;
+        }
         const uint64_t queued = walk_a | walk_b;
         if (queued) {
             const uint64_t me = 1ull << lane;
@@ -1382,7 +1486,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             qn += n_a + (uint32_t)__popcll(walk_b);
             if (qn > TBK_QCAP_ENTRY - 16) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                drain_walks_entry<MULTI, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+                if constexpr (!SHORT) drain_walks_entry<MULTI, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 qn = 0;
             }
@@ -1390,10 +1494,11 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
     }
 }
 
-template <int W, bool MULTI, bool TWO, bool WIDE>
+template <int W, bool MULTI, bool TWO, int KIND>
 __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint64_t e0, const uint64_t e1, const uint64_t e2, const uint64_t e3,
                                                  const uint64_t P0, const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
                                                  uint4 *walkq, uint4 *backq, uint16_t *walkr, uint16_t *backr, uint32_t *rcnt) {
+    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2;
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 1u;
@@ -1461,6 +1566,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     // entry geometry
     const int fl = o + W - 1, fbits = 2 * (k - m), vshift = 4 * fl;
     const uint32_t fmask = fbits >= 32 ? 0xFFFFFFFFu : ((1u << fbits) - 1u);
+    const uint32_t rshift = 31u - (uint32_t)__clz(p.t.n_buckets);  // short keys (tbk_short_geom)
 
     // read bookkeeping (probe_pass)
     const uint64_t p_lane = P0 + (uint64_t)lane * TBK_WPL;
@@ -1534,9 +1640,13 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const mmer_t mx = (mmer_t)(fs >> fsh) & (mmer_t)mmask, my = (mmer_t)(bs >> bsh) & (mmer_t)mmask;
         const bool fw_or = mx < my;                       // the m-mer is canonical as the forward strand reads it
         const mmer_t cm = fw_or ? mx : my;
-        uint32_t bkt;
+        uint32_t bkt, short_r = 0;
         if constexpr (WIDE) bkt = tbk_reduce((uint32_t)tbk_mmer_hash64(cm), p.t.n_buckets);
-        else bkt = tbk_reduce(tbk_mmer_hash(cm), p.t.n_buckets);
+        else if constexpr (SHORT) {
+            const uint64_t prod = (uint64_t)tbk_mmer_hash((uint32_t)cm) * (uint64_t)p.t.n_buckets;  // (tbk_short_key: bucket and r are the two words of one product)
+            bkt = (uint32_t)(prod >> 32);
+            short_r = (uint32_t)prod >> rshift;
+        } else bkt = tbk_reduce(tbk_mmer_hash(cm), p.t.n_buckets);
         // ---- what this window asks an entry (tbk_entry_key): the k-mer in the m-mer's orientation, cut around the m-mer ----
         const uint64_t orient = (fw_or ? fs : bs) & kmask;
         const uint32_t a = fw_or ? fsh : bsh;             // 2 (o + pos'), pos' = the m-mer's position as `orient` reads
@@ -1552,6 +1662,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             const uint64_t m1 = ((uint64_t)fmask << shw) | (1ull << ((uint32_t)vshift + posp));
             my_khi = (uint32_t)k1; my_khi2 = (uint32_t)(k1 >> 32);
             my_mhi = (uint32_t)m1; my_mhi2 = (uint32_t)(m1 >> 32);
+        } else if constexpr (SHORT) {
+            my_khi = (low | (high << a)) | (posp << (uint32_t)fbits) | (short_r << ((uint32_t)fbits + 3u)) | TBK_SHORT_TAKEN;  // the word this window asks
+            my_mhi = 0;
         } else {
             my_khi = ((low | (high << a)) << shw) | vbit;
             my_mhi = (fmask << shw) | vbit;
@@ -1561,6 +1674,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         if constexpr (WIDE) {
             const uint64_t w0_want = ok ? ((uint64_t)cm | TBK_WENTRY_TAKEN) : ~0ull;
             cm_ask = (uint32_t)w0_want; cm_ask2 = (uint32_t)(w0_want >> 32);
+        } else if constexpr (SHORT) {
+            cm_ask = ok ? my_khi : TBK_SHORT_NONE;
         } else {
             cm_ask = ok ? (uint32_t)cm : TBK_ENTRY_NO_MMER;
         }
@@ -1588,11 +1703,17 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             mh2_s[0] = pair_bcast<0>(my_mhi2); mh2_s[1] = pair_bcast<1>(my_mhi2);
             cm2_s[0] = pair_bcast<0>(cm_ask2); cm2_s[1] = pair_bcast<1>(cm_ask2);
         }
-        uint64_t hit[2], more[2], hitx[2] = {0, 0};
+        uint64_t hit[2], more[2], hitx[2] = {0, 0}, hit_sb[2] = {0, 0};
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             const uint32_t hx = (uint32_t)(va[s].x >> 32), hy = (uint32_t)(va[s].y >> 32);
-            if constexpr (WIDE) {
+            if constexpr (SHORT) {
+                // the lane's 16 bytes are four slots of either list: the word asked with and without the list bit
+                const uint32_t qa = cm_s[s], qb2 = cm_s[s] | TBK_SHORT_HAPB, w0 = (uint32_t)va[s].x, w2 = (uint32_t)va[s].y, w3 = hy & ~TBK_SHORT_FLAG;
+                hitx[s] = ballot(w0 == qa || hx == qa || w2 == qa || w3 == qa);
+                hit_sb[s] = ballot(w0 == qb2 || hx == qb2 || w2 == qb2 || w3 == qb2);
+                hit[s] = hitx[s] | hit_sb[s];
+            } else if constexpr (WIDE) {
                 // the lane's piece is ONE entry: word 0 = m-mer | taken, word 1 = flanks + V (+ the piece's flag in bit 63, outside every mask)
                 const uint32_t ly = (uint32_t)va[s].y;
                 const uint64_t want = (uint64_t)((kh_s[s] & mh_s[s]) | (ly & ~mh_s[s])) | ((uint64_t)((kh2_s[s] & mh2_s[s]) | (hy & ~mh2_s[s])) << 32);
@@ -1624,7 +1745,11 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                     const uint32_t rrel = MULTI ? my_rid - (uint32_t)r_first : TWO ? two_rid() : 0u;
                     const uint32_t at = qb + (uint32_t)__popcll(need & (me - 1));
                     const uint32_t home = last_bk | ((uint32_t)((beh_a >> lane) & 1ull) << 30) | ((uint32_t)((beh_b >> lane) & 1ull) << 31);
-                    if constexpr (WIDE) {
+                    if constexpr (SHORT) {
+                        const uint64_t kf = fs & kmask, kr = bs & kmask, ck = kf < kr ? kf : kr;  // the canonical k-mer: what the overflow table holds
+                        backq[at] = make_uint4(my_khi, home, (uint32_t)ck, (uint32_t)(ck >> 32));
+                        if (MULTI || TWO) backr[at] = (uint16_t)rrel;
+                    } else if constexpr (WIDE) {
                         backq[at] = make_uint4((uint32_t)cm, my_khi, (my_khi2 & 0xFFFFu) | ((uint32_t)((uint64_t)cm >> 32) << 16), home);
                         if (MULTI || TWO) backr[at] = (uint16_t)rrel;
                     } else {
@@ -1639,7 +1764,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             uint64_t ha[2], hb[2];
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                if constexpr (WIDE) {
+                if constexpr (SHORT) {
+                    ha[s] = hitx[s]; hb[s] = hit_sb[s];
+                } else if constexpr (WIDE) {
                     const uint64_t bm = ballot(((uint32_t)(va[s].y >> 32) & 0x40000000u) != 0);
                     ha[s] = hit[s] & ~bm; hb[s] = hit[s] & bm;
                 } else {
@@ -1669,17 +1796,17 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         }
         if (qb > TBK_BQCAP - 64) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            drain_back_entry<MULTI || TWO, WIDE>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+            drain_back_entry<MULTI || TWO, KIND>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             qb = 0;
         }
     }
     if (qb) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_back_entry<MULTI || TWO, WIDE>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        drain_back_entry<MULTI || TWO, KIND>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (qn) {
+    if (!SHORT && qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         drain_walks_entry<MULTI || TWO, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1824,14 +1951,15 @@ tbk_probe_kernel(const ProbeArgs p) {
 }
 
 // The entry layout's probe kernels: the same three (single-read, two-read, multi-read passes) over probe_pass_entry.
-template <int W, bool MULTI, bool TWO = false, bool WIDE = false>
+// KIND: 0 narrow entries, 1 wide entries, 2 short keys (tbk_common.h)
+template <int W, bool MULTI, bool TWO = false, int KIND = 0>
 __global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
 tbk_probe_entry_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
-    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][TBK_QCAP_ENTRY];
+    __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][KIND == 2 ? 1 : TBK_QCAP_ENTRY];  // (short keys never walk: their overflow is a table of its own)
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][TBK_BQCAP];
-    __shared__ uint16_t walkr[TBK_WAVES_PER_BLOCK][WIDE && (MULTI || TWO) ? TBK_QCAP_ENTRY : 1];  // wide entries: the read of a queued window travels beside the queue
-    __shared__ uint16_t backr[TBK_WAVES_PER_BLOCK][WIDE && (MULTI || TWO) ? TBK_BQCAP : 1];
+    __shared__ uint16_t walkr[TBK_WAVES_PER_BLOCK][KIND == 1 && (MULTI || TWO) ? TBK_QCAP_ENTRY : 1];  // wide entries, short keys: the read of a queued window travels beside the queue
+    __shared__ uint16_t backr[TBK_WAVES_PER_BLOCK][KIND != 0 && (MULTI || TWO) ? TBK_BQCAP : 1];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1865,7 +1993,7 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass_entry<W, MULTI, TWO, WIDE>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
+        probe_pass_entry<W, MULTI, TWO, KIND>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
         if (!MULTI) return;  // one pass per block
     }
 }
@@ -1885,6 +2013,18 @@ extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_bucket
     return hipGetLastError();
 }
 
+
+extern "C" hipError_t tbk_launch_short_insert(uint64_t *slots, uint32_t n_buckets, uint32_t over_mask, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
+                                              int skip_a, unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+    TbkShortGeom g;
+    if (!tbk_short_geom(k, mz, n_buckets, &g)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(tbk_short_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)slots, n_buckets, (unsigned long long *)(slots + (uint64_t)n_buckets * 16), over_mask,
+                       half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t tbk_launch_insert(uint64_t *slots, uint32_t n_buckets, uint32_t stride, uint32_t half, TbkMz mz,
                                         const uint64_t *d_keys, uint64_t n, uint32_t *d_overflowed, uint32_t *d_left_line, uint32_t guests, TbkTableView skip,
@@ -1999,7 +2139,11 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0, entry = (t.guests & TBK_FLAG_ENTRY) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
-    const bool wide = (t.guests & TBK_FLAG_WIDE) != 0;
+    const bool wide = (t.guests & TBK_FLAG_WIDE) != 0, shortk = (t.guests & TBK_FLAG_SHORT) != 0;
+    if (shortk) {
+        TbkShortGeom g;
+        if (!tbk_short_geom(k, t.mz, t.n_buckets, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
+    }
     if (entry) {
         TbkEntryGeom g;
         if (!(wide ? tbk_wentry_geom(k, t.mz, &g) : tbk_entry_geom(k, t.mz, &g)) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
@@ -2019,25 +2163,34 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
                          else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
-        if (entry) {
+        if (entry || shortk) {
 #define TBK_E(N, WD) case N: if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true, false, WD>), grid_multi, block, 0, stream, p); \
                          else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, false, WD>), grid, block, 0, stream, p); \
                          else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true, WD>), grid_two, block, 0, stream, p); break;
-            if (wide) {
+            if (shortk) {
                 switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
-                    TBK_E(6, true) TBK_E(8, true)
+                    TBK_E(6, 2)
 #else
-                    TBK_E(2, true) TBK_E(3, true) TBK_E(4, true) TBK_E(5, true) TBK_E(6, true) TBK_E(7, true) TBK_E(8, true)
+                    TBK_E(2, 2) TBK_E(3, 2) TBK_E(4, 2) TBK_E(5, 2) TBK_E(6, 2) TBK_E(7, 2) TBK_E(8, 2)
+#endif
+                    default: return hipErrorInvalidValue;
+                }
+            } else if (wide) {
+                switch (t.mz.w) {
+#ifdef TBK_ONLY_W6
+                    TBK_E(6, 1) TBK_E(8, 1)
+#else
+                    TBK_E(2, 1) TBK_E(3, 1) TBK_E(4, 1) TBK_E(5, 1) TBK_E(6, 1) TBK_E(7, 1) TBK_E(8, 1)
 #endif
                     default: return hipErrorInvalidValue;
                 }
             } else {
                 switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
-                    TBK_E(6, false)
+                    TBK_E(6, 0)
 #else
-                    TBK_E(2, false) TBK_E(3, false) TBK_E(4, false) TBK_E(5, false) TBK_E(6, false) TBK_E(7, false)
+                    TBK_E(2, 0) TBK_E(3, 0) TBK_E(4, 0) TBK_E(5, 0) TBK_E(6, 0) TBK_E(7, 0)
 #endif
                     default: return hipErrorInvalidValue;
                 }
