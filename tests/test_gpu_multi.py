@@ -67,8 +67,10 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
         assert lib.tbk_classifier_create_multi(a._h, b._h, bad, 0, out) == _lib.TBK_ERR_INVALID
 
 
-def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, monkeypatch):
-    """TBK_FORCE_REPLICA=1: every further ring on device 0 gets a full copy of the table made by the calls a second
+@pytest.mark.parametrize("layout", ["key", "entry", "short"])
+def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, monkeypatch, layout):
+    """(In each of the table layouts: a replica of short keys carries the overflow table behind its lines.)
+    TBK_FORCE_REPLICA=1: every further ring on device 0 gets a full copy of the table made by the calls a second
     GPU's replica is made by (tbk_classifier_replicate: hipMemcpyPeer) - the code of an 8-GPU node's table fan-out,
     executed on the one GPU there is.  Three tables in three places, every one of them classifies like the oracle,
     alone and behind the pipeline's queue; without the switch the rings share one table."""
@@ -90,9 +92,13 @@ def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, mo
         return out
 
     monkeypatch.delenv("TBK_FORCE_REPLICA", raising=False)
+    for var, val in {"key": {"TBK_ENTRY": "0", "TBK_SHORT": "0"}, "entry": {"TBK_ENTRY": "1"}, "short": {"TBK_SHORT": "1"}}[layout].items():
+        monkeypatch.setenv(var, val)
     with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
         ids = table_ids(multi)
         assert len({t for t, _ in ids}) == 1 and all(r == 0 for _, r in ids)
+        st = multi._part(0).stats()
+        assert st["entry_layout"] == (layout == "entry") and st["short_keys"] == (layout == "short"), st
     monkeypatch.setenv("TBK_FORCE_REPLICA", "1")
     with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
         ids = table_ids(multi)

@@ -9,6 +9,8 @@ python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build.log 2>&1
 R=$GRAFT_REPO_ROOT
 ( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default.log | tail -1 > gpurun_out/bench_default.json
 export TBK_SKIP_BUILD=1
+# the same lists in the key layout (what they got before short keys): the A/B on this box
+( time TBK_SHORT=0 timeout 900 python bench.py --no-realistic --no-streaming --min-timed-s 5 --cpu-seconds 4 ) > gpurun_out/bench_default_key_layout.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default_key_layout.log | tail -1 > gpurun_out/bench_default_key_layout.json
 ( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_haplotypes.log | tail -1 > gpurun_out/bench_haplotypes.json
 ( time timeout 900 python bench.py --gpus 2 --share-device --min-timed-s 3 ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
 # eight ranks on the one device (smaller lists: eight tables must fit its memory): the launch, the rendezvous, parity over all ranks, every rank's NUMA placement and share of the host threads

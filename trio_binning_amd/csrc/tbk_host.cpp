@@ -1284,7 +1284,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     };
     // Short keys (tbk_common.h): lists whose keys do not merge into entries (BASELINE's uniform k-mers) in 4 bytes a key
     // instead of 8, read through the entry kernels' two-lane window loop: 8 keys of either list in a 32-byte front, 32 in a
-    // line.  TBK_SHORT_LOAD keys per line (default 2.56: 50 bytes of HBM per key; 2 x 3e8 uniform 21-mers: 30 GB, 1.5 % of the
+    // line.  TBK_SHORT_LOAD keys per line (default 2.6: 49 bytes of HBM per key; 2 x 3e8 uniform 21-mers: 29.6 GB, 1.5 % of the
     // keys behind a front).  Built first where k and the table's size allow (k = 21: any table of 65536 lines or more,
     // k = 25: 2 GB or more); lists that cluster (more than TBK_BEHIND_FRONT of the keys behind a front) go on to the key
     // layout's test and from there to entries, as before.  TBK_SHORT=0: never, 1: whatever the lists look like.
@@ -1294,7 +1294,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (!forced && getenv("TBK_TABLE_LOAD")) return false;  // (the key layouts' load is pinned: the key layouts are meant)
         TbkMz z = span_for(true);  // (the front layout's span: as long as k leaves room for, up to 8 m-mers)
         if (z.w < 2 || z.t <= 0 || z.m > 16) return false;
-        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.56)));
+        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.6)));
         uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
         const uint32_t min_nb = tbk_short_min_buckets(c->k, z);
         if (!min_nb) return false;
