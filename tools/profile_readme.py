@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-KEEP = ["bench_default.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_8ranks_shared_device.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
+KEEP = ["bench_default.json", "bench_default_key_layout.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_8ranks_shared_device.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
         "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
 for name in KEEP:
@@ -156,6 +156,13 @@ if eight:
             f"{[(d.get('numa_node'), d.get('cpus_bound_to'), d.get('host_threads')) for d in eight.get('devices', [])]}."]
 if tr2:
     out += [f"Under `python -m torch.distributed.run`: value {tr2['value']}, parity all_ranks_equal = {g(tr2, 'parity', 'all_ranks_equal')}."]
+keyl = load("bench_default_key_layout.json")
+if keyl:
+    out += [f"The uniform lists in the key layout (`TBK_SHORT=0`: what they got before short keys), same box, 5 s regions: value {keyl['value']} Gbases/s host-fed, "
+            f"kernel_resident {g(keyl, 'kernel_resident', 'gbases_per_s')}, single-read kernel {g(keyl, 'roofline', 'kernel_ms_avg')} ms, frac {g(keyl, 'roofline', 'frac')}, "
+            f"{g(keyl, 'config', 'table_bytes_per_gpu', default=0) / 1e9:.0f} GB ({g(keyl, 'config', 'table_bytes_per_key')} B per key); "
+            f"short keys in the default line above: {g(u, 'value')} / {g(u, 'kernel_resident', 'gbases_per_s')}, {g(u, 'roofline', 'kernel_ms_avg')} ms, "
+            f"{g(u, 'config', 'table_bytes_per_gpu', default=0) / 1e9:.0f} GB ({g(u, 'config', 'table_bytes_per_key')} B per key).", ""]
 rings3 = load("bench_3rings.json")
 if rings3:
     out += [f"Three feeder threads + rings on the one device, sharing its table (`--rings 3`: the pipeline's dealing from one queue, as it would run over three GPUs): value {rings3['value']} Gbases/s "
