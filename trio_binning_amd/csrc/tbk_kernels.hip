@@ -577,6 +577,9 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
 constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
 constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
+#ifndef TBK_SHORT_DRAIN
+#define TBK_SHORT_DRAIN (TBK_BQCAP - 64)   // short keys: the back queue is drained when it holds more than this many windows
+#endif
 constexpr int TBK_QCAP_ENTRY = 96;   // entry kernels: walks are queued by drain_back_entry, at most 16 per round (with 96 entries a block's LDS is 4.6 KB: 32 one-wave blocks per CU, eight waves per SIMD)
 
 // entry: x = key low, y = key high, z = home bucket, w = list (0 hapA, 1 hapB) | (read - first read of pass) << 1
@@ -1794,7 +1797,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                 lane_b += (uint32_t)(wb >> lane) & 1u;
             }
         }
-        if (qb > TBK_BQCAP - 64) {
+        if (qb > (SHORT ? (uint32_t)TBK_SHORT_DRAIN : (uint32_t)(TBK_BQCAP - 64))) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             drain_back_entry<MULTI || TWO, KIND>(p, backq, backr, qb, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
