@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -1225,6 +1226,17 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // 1.6e8 entries in 15 GB, 25 bytes per key, 4 % of the entries behind a front; 0.40 .. 0.64 run alike, 0.80 loses 3 %, 1.0
     // 11 %: profiles/r04/ab_entry_layout.log).
     const double entry_pin = env_double("TBK_ENTRY", -1);
+    // TBK_BUILD_TIMING=1: every build of the paired table with its duration, on stderr
+    const bool build_timing = env_double("TBK_BUILD_TIMING", 0) != 0;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, bool kept) {
+        if (!build_timing) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "tbk build: %-28s %7.3f s  %u lines, %llu + %llu keys, behind a front %llu, past %llu%s\n", what, std::chrono::duration<double>(now - t_last).count(), c->n_buckets,
+                (unsigned long long)c->distinct_a, (unsigned long long)c->distinct_b, (unsigned long long)c->behind_front, (unsigned long long)c->past_half, kept ? "  <- kept" : "");
+        t_last = now;
+    };
     auto try_entry_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 32) return false;
         TbkMz z{0, 0, 0, 0};
@@ -1264,7 +1276,9 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) nb = std::min<uint64_t>(nb, (uint64_t)(0.6 * (double)total_b / 128.0)); else (void)hipGetLastError();
             if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;  // (bits 30 and 31 of a bucket index are flags in the probe's queues)
             c->free_pair();
-            if (build_entry_table(c, a, b, (uint32_t)nb)) {
+            const int brc = build_entry_table(c, a, b, (uint32_t)nb);
+            lap(wide ? "wide entries" : "entries", false);
+            if (brc) {
                 // the guess of keys per entry was too high for these lists and the table ran full: twice the room (an allocation
                 // that failed, or a table that is full at the device's cap, ends the attempt)
                 if ((double)nb + 17.0 < want) break;  // (the table was capped already: more room is not to be had)
@@ -1289,6 +1303,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // k = 25: 2 GB or more); lists that cluster (more than TBK_BEHIND_FRONT of the keys behind a front) go on to the key
     // layout's test and from there to entries, as before.  TBK_SHORT=0: never, 1: whatever the lists look like.
     const double short_pin = env_double("TBK_SHORT", -1);
+    double short_behind = -1;  // the fraction of the keys a short-key build found behind a front (-1: none was built)
     auto try_short_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
         if (!forced && getenv("TBK_TABLE_LOAD")) return false;  // (the key layouts' load is pinned: the key layouts are meant)
@@ -1314,11 +1329,14 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         for (int attempt = 0; attempt < 4 && !built; attempt++, over <<= 3) {
             c->free_pair();
             if (over > (1ull << 31)) break;
-            if (build_short_table(c, a, b, (uint32_t)nb, (uint32_t)over) == TBK_OK) { built = true; c->layout_builds++; break; }
+            const int brc = build_short_table(c, a, b, (uint32_t)nb, (uint32_t)over);
+            lap("short keys", false);
+            if (brc == TBK_OK) { built = true; c->layout_builds++; break; }
             if (g_err.find("full") == std::string::npos) break;
         }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
-        if (built && !forced && (double)c->behind_front / n_keys > env_double("TBK_BEHIND_FRONT", 0.05)) built = false;  // the lists cluster
+        if (built) short_behind = (double)c->behind_front / n_keys;
+        if (built && !forced && short_behind > env_double("TBK_BEHIND_FRONT", 0.05)) built = false;  // the lists cluster
         if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->over_mask = 0; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
@@ -1337,6 +1355,19 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         *out = c;
         return TBK_OK;
     }
+    // Lists that the short-key build has just shown to cluster plainly (more than TBK_PLAINLY_CLUSTERED, default 12 %, of
+    // the keys behind an 8-slot front; haplotype-shaped lists: 16 %, uniform ones 1.5 %) skip the key layout's test -
+    // building a front-first key table of clustered lists only to measure them takes 2 s at 2 x 3e8 keys, ten times a
+    // build of entries - and go to entries at once; lists that do not merge come back here.
+    if (short_behind > env_double("TBK_PLAINLY_CLUSTERED", 0.12) && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
+        c->layout_builds++;
+        lap("(kept)", true);
+        c->own_pair();
+        rc = classifier_streams(c);
+        if (rc) { tbk_classifier_destroy(c); return rc; }
+        *out = c;
+        return TBK_OK;
+    }
     bool front = front_pin != 0;
     for (;;) {
         c->mz = span_for(front);
@@ -1346,6 +1377,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
         rc = build_pair_table(c, a, b, 0.08, &past);
+        lap(front ? "key layout, front" : "key layout, whole lines", false);
         if (rc) { c->free_pair(); delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
