@@ -78,14 +78,15 @@ def test_differential_cli(gpu, capsys, tmp_path, k):
         assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
 
 
-@pytest.mark.parametrize("k,wide", [(21, 0), (21, 1), (32, 1)])
+@pytest.mark.parametrize("k,wide", [(21, 0), (21, 1), (32, 1), (21, 2)])
 def test_differential_cli_through_the_entry_layouts(gpu, capsys, tmp_path, monkeypatch, k, wide):
     """The same recorded reference output with the table in entry layout (narrow entries, and the 16-byte ones k = 32
-    needs): the native loop, its packed batches and short reads' multi-read passes over tbk_probe_entry_kernel."""
+    needs) and in short keys (wide = 2): the native loop, its packed batches and short reads' multi-read passes over
+    tbk_probe_entry_kernel."""
     import trio_binning_amd.classify_by_kmers as cbk
 
-    monkeypatch.setenv("TBK_ENTRY", "1")
-    if wide:
+    monkeypatch.setenv("TBK_SHORT" if wide == 2 else "TBK_ENTRY", "1")
+    if wide == 1:
         monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
     monkeypatch.setattr(cbk, "_BATCH_BASES", 2000)
     monkeypatch.setattr(cbk, "_BATCH_READS", 40)

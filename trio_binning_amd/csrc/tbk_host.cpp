@@ -2018,7 +2018,10 @@ extern "C" int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const
 
 extern "C" void *tbk_host_alloc(size_t bytes) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    // (experiment: TBK_HOST_ALLOC_FLAGS ORs hipHostMalloc flags in - 4: write-combined, 0x80000000: non-coherent, 0x40000000: coherent;
+    // none moved the H2D rate under load, EXPERIMENTS.md)
+    static const unsigned extra = (unsigned)env_double("TBK_HOST_ALLOC_FLAGS", 0);
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | extra) != hipSuccess) {
         fail(TBK_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
         return nullptr;
     }
