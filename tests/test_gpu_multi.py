@@ -52,7 +52,7 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
             multi.submit(bases, offs)   # further ahead than depth + rings
         for lo, hi, t in reversed(tickets):
             assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
-        assert sum(multi.dealt) == 12 + 0 and min(multi.dealt) >= 1, multi.dealt
+        assert sum(multi.dealt) == 12, multi.dealt   # (how the feeders share them is a race; each ring has answered by itself above)
     # a replica of a replica, and the error paths of the C entry points
     with kmers.Classifier(a, b) as one:
         h = C.c_void_p()
@@ -113,7 +113,7 @@ def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, mo
             tickets.append((lo, hi, multi.submit(bb, oo) if i % 2 else multi.submit_packed(kmers.pack_bases(bb, oo))))
         for lo, hi, t in tickets:
             assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
-        assert min(multi.dealt) >= 1, multi.dealt   # every replica took batches
+        assert sum(multi.dealt) == len(tickets), multi.dealt   # (which ring takes a batch is a race between the feeders; every replica has answered by itself above)
 
 
 def test_device_numa_node_and_feeder_binding(gpu, tmp_path):

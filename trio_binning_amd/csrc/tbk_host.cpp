@@ -1057,7 +1057,11 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
 // order pass after each list turns "a key went past this half" / "left the line" into the order of
 // the half's last slots, which is what lookups (hapB's inserts included) read.  *past = keys that
 // found their own half of their home line full.
-static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past) {
+// give_up_past != 0: a build whose only purpose may be to find out whether the lists cluster - when hapA's list alone has sent
+// more keys than that past their halves (or more than give_up_behind behind their fronts) the answer is known, the table is dropped and *gave_up set (hapB's inserts, which
+// look every key up in hapA's crowded half first, are the slow part of such a build).
+static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past, uint64_t give_up_past = 0, bool *gave_up = nullptr,
+                            uint64_t give_up_behind = 0) {
     c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = c->alloc_pair(bytes);
@@ -1073,6 +1077,15 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
     if (!rc) {
         rc = insert_keys(c->d_pair, c->n_buckets, 16, 0, c->mz, d_over, a->d_keys, a->num_lines, &c->distinct_a,
                          TbkTableView{nullptr, 0, 0, 0, TbkMz{0, 0, 0, 0}, 0}, nullptr, d_left, c->guests, &past_a, &back_a);
+        if (!rc && give_up_past && (past_a > give_up_past || (give_up_behind && back_a > give_up_behind))) {
+            if (d_over) (void)hipFree(d_over);
+            if (d_left) (void)hipFree(d_left);
+            c->free_pair();
+            c->past_half = past_a; c->behind_front = back_a; c->distinct_b = 0;
+            *past = past_a;
+            if (gave_up) *gave_up = true;
+            return TBK_OK;
+        }
         if (!rc) rc = order_table(c->d_pair, (uint64_t)c->n_buckets * 2, d_over, d_left, c->guests, 16);
         if (!rc) rc = insert_keys(c->d_pair, c->n_buckets, 16, 8, c->mz, d_over, b->d_keys, b->num_lines, &c->distinct_b,
                                   TbkTableView{c->d_pair, c->n_buckets, 16, 0, c->mz, c->guests}, &c->shared, d_left, c->guests, &past_b, &back_b);
@@ -1376,12 +1389,17 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         c->layout_builds++;
         c->guests = guests | (front ? TBK_FLAG_FRONT : 0u);
         uint64_t past = 0;
-        rc = build_pair_table(c, a, b, 0.08, &past);
-        lap(front ? "key layout, front" : "key layout, whole lines", false);
+        // (a front-first build that may be rejected gives up after hapA's list when that alone shows the clustering: the
+        // lists' lines bound the distinct keys from above, so the test below would fail for certain)
+        const bool testing = front && front_pin < 0;
+        bool gave_up = false;
+        rc = build_pair_table(c, a, b, 0.08, &past, testing ? (uint64_t)(env_double("TBK_CLUSTERED", 0.003) * (double)(a->num_lines + b->num_lines)) + 1 : 0, &gave_up,
+                              testing ? (uint64_t)(env_double("TBK_BEHIND_FRONT", 0.05) * (double)(a->num_lines + b->num_lines)) + 1 : 0);
+        lap(gave_up ? "key layout, front (given up after hapA's list)" : front ? "key layout, front" : "key layout, whole lines", false);
         if (rc) { c->free_pair(); delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
-        if (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05))) break;
+        if (!gave_up && (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05)))) break;
         // Clustered lists.  Lists shaped like real find-unique-kmers output cluster because they ARE runs of overlapping
         // k-mers: the entry layout stores a run once (tbk_common.h), which brings them back to a front - two slots per
         // list, asked for by two lanes - in a table a quarter of the size.  Kept when the lists really merge (at least 1.5
