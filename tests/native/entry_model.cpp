@@ -77,7 +77,7 @@ static void winsert_form(Table &t, uint32_t half, TbkWideKey e) {
 }
 
 static int wforms_of(const Table &t, uint64_t key, TbkWideKey *out) {
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     for (int i = 0; i < nt; i++) { const uint32_t r = tbk_tmer_rank(key, t.z, i); best = r < best ? r : best; }
     int n = 0;
@@ -99,7 +99,7 @@ static bool wcontains(const Table &t, uint32_t half, uint64_t key) {
 
 static TbkWideKey wwindow_key(const Table &t, uint64_t fwd, int pick_last_tie) {
     const uint64_t rc = tbk_revcomp_packed(fwd, t.k);
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     int x = 0;
     for (int i = 0; i < nt; i++) {
@@ -117,7 +117,7 @@ static TbkWideKey wwindow_key(const Table &t, uint64_t fwd, int pick_last_tie) {
 
 // every (tied position, orientation) form of a list key
 static int forms_of(const Table &t, uint64_t key, TbkEntryKey *out) {
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     for (int i = 0; i < nt; i++) { const uint32_t r = tbk_tmer_rank(key, t.z, i); best = r < best ? r : best; }
     int n = 0;
@@ -156,7 +156,7 @@ static void insert_key(Table &t, uint32_t half, uint64_t key, const Table *skip_
 // what the probe kernel computes for the window whose forward k-mer is `fwd`: from the forward strand alone
 static TbkEntryKey window_key(const Table &t, uint64_t fwd, int pick_last_tie) {
     const uint64_t rc = tbk_revcomp_packed(fwd, t.k);
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     int x = 0;
     for (int i = 0; i < nt; i++) {
@@ -183,6 +183,7 @@ int main(int argc, char **argv) {
     t.k = k;
     t.wide = wide != 0;
     t.z = tbk_mz_params(k, w_want, 1000000, wide ? (wide == 1 ? 18 : wide) : 0, 1);
+    if (!wide && argc > 6 && atoi(argv[6])) t.z = tbk_mz_span3(t.z);   // 3w t-mer positions (what the library uses for narrow entries where t stays at 4 or more)
     if (!(wide ? tbk_wentry_geom(k, t.z, &t.g) : tbk_entry_geom(k, t.z, &t.g))) { printf("k=%d w=%d: no entry layout (w=%d m=%d o=%d t=%d)\n", k, w_want, t.z.w, t.z.m, t.z.o, t.z.t); return 0; }
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     // a genome with SNPs between two haplotypes, low-complexity stretches and a repeated segment

@@ -30,7 +30,7 @@ struct Table {
 };
 
 static int forms_of(const Table &t, uint64_t key, TbkShortKey *out) {
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     for (int i = 0; i < nt; i++) { const uint32_t r = tbk_tmer_rank(key, t.z, i); best = r < best ? r : best; }
     int n = 0;
@@ -83,7 +83,7 @@ static void insert_key(Table &t, uint32_t half, uint64_t key, bool skip_a) {
 // what the probe kernel computes for the window whose forward k-mer is `fwd`: from the forward strand alone
 static TbkShortKey window_key(const Table &t, uint64_t fwd, int pick_last_tie) {
     const uint64_t rc = tbk_revcomp_packed(fwd, t.k);
-    const int nt = 2 * t.z.w;
+    const int nt = tbk_mz_positions(t.z);
     uint32_t best = 0xFFFFFFFFu;
     int x = 0;
     for (int i = 0; i < nt; i++) {
@@ -108,6 +108,7 @@ int main(int argc, char **argv) {
     Table t;
     t.k = k;
     t.z = tbk_mz_params(k, w_want, 1000000, 0, 1);
+    if (argc > 5 && atoi(argv[5])) t.z = tbk_mz_span3(t.z);   // 3w t-mer positions (what the library uses where t stays at 4 or more)
     t.n_buckets = n_buckets ? n_buckets : tbk_short_min_buckets(k, t.z) + (uint32_t)(rng() % 1000);
     if (!tbk_short_geom(k, t.z, t.n_buckets, &t.g)) { printf("k=%d w=%d n_buckets=%u: no short keys (w=%d m=%d o=%d t=%d)\n", k, w_want, t.n_buckets, t.z.w, t.z.m, t.z.o, t.z.t); return 0; }
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;

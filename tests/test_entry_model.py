@@ -19,8 +19,9 @@ def model(tmp_path_factory):
 
 @pytest.mark.parametrize("k,w,crowd", [(21, 6, 0), (21, 6, 1), (21, 5, 1), (21, 4, 0), (22, 6, 0), (22, 4, 1), (23, 6, 1), (23, 5, 0), (24, 5, 1), (25, 4, 0)])
 def test_entry_model_equals_set_membership(model, k, w, crowd):
-    for seed in (1, 2):
-        r = subprocess.run([model, str(k), str(w), str(seed), str(crowd)], capture_output=True, text=True)
+    # seed 1: 2w t-mer positions ranked per span, seed 2: 3w where t stays at 4 or more (tbk_mz_span3: what the library builds)
+    for seed, span3 in ((1, 0), (2, 1)):
+        r = subprocess.run([model, str(k), str(w), str(seed), str(crowd), "0", str(span3)], capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert "mismatches 0" in r.stdout and "no entry layout" not in r.stdout, r.stdout
 
@@ -51,8 +52,8 @@ def short_model(tmp_path_factory):
 def test_short_key_model_equals_set_membership(short_model, k, w, n_buckets):
     """Short keys (tbk_common.h): a 32-bit word plus its bucket names a k-mer exactly - list keys through every form, near
     misses that share a line with them, windows of both strands, crowded lines that spill into the overflow table."""
-    for seed in (1, 2):
-        r = subprocess.run([short_model, str(k), str(w), str(seed), str(n_buckets)], capture_output=True, text=True)
+    for seed, span3 in ((1, 0), (2, 1)):   # 2w and 3w t-mer positions per span (tbk_mz_span3)
+        r = subprocess.run([short_model, str(k), str(w), str(seed), str(n_buckets), str(span3)], capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout, r.stderr)
         assert r.stdout.startswith("short ") and "mismatches 0" in r.stdout, r.stdout
         assert " 0 in the overflow table" not in r.stdout, r.stdout

@@ -228,20 +228,33 @@ TBK_HD uint32_t tbk_bucket_at(uint64_t key, TbkMz z, int p, uint32_t n_buckets) 
     return tbk_reduce((uint32_t)tbk_mmer_hash64(x < y ? x : y), n_buckets);
 }
 
-// rank of the span's t-mer at position i: the hash with its low 4 bits cleared (they carry a
+// The t-mer positions of a span under mod-sampling: l = w + m - t.  t = m - w ranks the span's 2w t-mers (density
+// 3 / (2w + 1)); t = m - 2w ranks 3w of them and switches less often still - density (floor((l - 1) / w) + 2) / (l + 1) =
+// 4 / (3w + 1): 0.2105 against 0.2308 at w = 6 (simulated on random sequence: 0.2100 / 0.2308) - at the price of shorter
+// t-mers, whose ranks tie more often (t = 4: in 6 % of the windows; a tie is a second copy of the key on the insert side).
+// The entry layouts and short keys use it where t stays at 4 or more (tbk_mz_span3); the key layouts keep 2w.
+TBK_HD int tbk_mz_positions(TbkMz z) { return z.t > 0 ? z.w + z.m - z.t : z.w; }
+// the bits of a rank that carry the position tag in the probe kernels: 4 (up to 16 positions) or 5
+TBK_HD uint32_t tbk_mz_tagmask(TbkMz z) { return tbk_mz_positions(z) > 16 ? 31u : 15u; }
+TBK_HD TbkMz tbk_mz_span3(TbkMz z) {
+    if (z.t > 0 && z.t == z.m - z.w && z.m - 2 * z.w >= 4 && z.m <= 16 && 3 * z.w <= 32) z.t = z.m - 2 * z.w;
+    return z;
+}
+
+// rank of the span's t-mer at position i: the hash with its low 4 (5) bits cleared (they carry a
 // position tag in the probe kernel)
 TBK_HD uint32_t tbk_tmer_rank(uint64_t key, TbkMz z, int i) {
     const uint32_t tmask = z.t == 16 ? 0xFFFFFFFFu : ((1u << (2 * z.t)) - 1u);
     const uint32_t x = (uint32_t)(key >> (2 * (z.o + i))) & tmask;
     const uint32_t y = tbk_revcomp32(x, z.t);
-    return tbk_mmer_hash(x < y ? x : y) & ~15u;
+    return tbk_mmer_hash(x < y ? x : y) & ~tbk_mz_tagmask(z);
 }
 
 // All buckets a lookup of `key` may select: one per position that attains the smallest t-mer
 // rank (mod-sampling), else the single bucket.  Returns the number of distinct buckets (<= 16).
 TBK_HD int tbk_bucket_candidates(uint64_t key, TbkMz z, uint32_t n_buckets, uint32_t *out) {
     if (z.w == 0 || z.t == 0) { out[0] = 0; return -1; }  // caller uses tbk_bucket_of
-    const int nt = 2 * z.w;
+    const int nt = tbk_mz_positions(z);
     uint32_t best = 0xFFFFFFFFu;
     for (int i = 0; i < nt; i++) { const uint32_t g = tbk_tmer_rank(key, z, i); best = g < best ? g : best; }
     int n = 0;
@@ -261,13 +274,13 @@ TBK_HD int tbk_bucket_candidates(uint64_t key, TbkMz z, uint32_t n_buckets, uint
 TBK_HD uint32_t tbk_bucket_of(uint64_t key, TbkMz z, uint32_t n_buckets) {
     if (z.w == 0) return tbk_reduce(tbk_mix32(key), n_buckets);
     if (z.t > 0) {
-        const int nt = 2 * z.w;
+        const int nt = tbk_mz_positions(z);
         uint32_t best = 0xFFFFFFFFu;
         for (int i = 0; i < nt; i++) {
             const uint32_t g = tbk_tmer_rank(key, z, i) | (uint32_t)i;
             best = g < best ? g : best;
         }
-        return tbk_bucket_at(key, z, (int)(best & 15u) % z.w, n_buckets);
+        return tbk_bucket_at(key, z, (int)(best & tbk_mz_tagmask(z)) % z.w, n_buckets);
     }
     uint32_t best = 0xFFFFFFFFu;
     if (z.m <= 16) {
@@ -666,7 +679,7 @@ TBK_HD int tbk_short_lookup_one(const uint32_t *lines, uint32_t n_buckets, const
     const uint32_t *line = lines + (uint64_t)e.bucket * 32;
     for (uint32_t s = 0; s < 32; s++) {
         const uint32_t v = line[s] & ~TBK_SHORT_FLAG;
-        if (v == 0) return -1;
+        if (v == 0) break;  // (the line's keys end here; the overflow table only when the line's last slot is flagged)
         if ((v & ~TBK_SHORT_HAPB) == e.word) return (int)((v >> 30) & 1u);
     }
     if (!(line[31] & TBK_SHORT_FLAG) || !over_mask) return -1;

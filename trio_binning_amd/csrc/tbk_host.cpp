@@ -38,7 +38,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
                                         unsigned long long *, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, int, unsigned long long *, int *, hipStream_t);
-extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, uint32_t, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -1153,7 +1153,8 @@ static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     for (int list = 0; list < 2 && e == hipSuccess; list++) {
         const tbk_table *t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
-        if (e == hipSuccess) e = tbk_launch_short_insert(c->d_pair, c->n_buckets, c->over_mask, (uint32_t)list, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr);
+        if (e == hipSuccess) e = tbk_launch_short_insert(c->d_pair, c->n_buckets, c->over_mask, (uint32_t)list, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed,
+                                                              (uint32_t)env_double("TBK_SHORT_LINE_CAP", 32), nullptr);  // (TBK_SHORT_LINE_CAP: tests fill the overflow table)
         if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished words)
     }
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
@@ -1239,6 +1240,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // 1.6e8 entries in 15 GB, 25 bytes per key, 4 % of the entries behind a front; 0.40 .. 0.64 run alike, 0.80 loses 3 %, 1.0
     // 11 %: profiles/r04/ab_entry_layout.log).
     const double entry_pin = env_double("TBK_ENTRY", -1);
+    const bool span3_on = env_double("TBK_SPAN3", 1) != 0;  // (0: narrow entries and short keys rank 2w t-mer positions, as the key layouts do)
     // TBK_BUILD_TIMING=1: every build of the paired table with its duration, on stderr
     const bool build_timing = env_double("TBK_BUILD_TIMING", 0) != 0;
     auto t_last = std::chrono::steady_clock::now();
@@ -1259,6 +1261,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
             for (int w = (w_pin > 0 ? w_pin : 6); w >= (w_pin > 0 ? w_pin : 4) && !ok; w--) {
                 z = tbk_mz_params(c->k, w, n_big, m_force, 1);
                 ok = z.w == w && tbk_entry_geom(c->k, z, &g);
+                if (ok && span3_on) z = tbk_mz_span3(z);  // 3w t-mer positions where t stays at 4 or more: 9 % fewer switches of line
             }
         // k-mers too long for a slot's worth of context (k > 25: a k-mer and its neighbours under one m-mer are k + w - 1
         // bases): WIDE entries, 16 bytes, and the longest span k's parity allows, 8 down to 6 (tbk_common.h "wide entries").
@@ -1322,6 +1325,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (!forced && getenv("TBK_TABLE_LOAD")) return false;  // (the key layouts' load is pinned: the key layouts are meant)
         TbkMz z = span_for(true);  // (the front layout's span: as long as k leaves room for, up to 8 m-mers)
         if (z.w < 2 || z.t <= 0 || z.m > 16) return false;
+        if (span3_on) z = tbk_mz_span3(z);
         const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.6)));
         uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
         const uint32_t min_nb = tbk_short_min_buckets(c->k, z);

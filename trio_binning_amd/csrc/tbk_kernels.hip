@@ -69,7 +69,7 @@ tbk_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t str
         // every tied position (two positions naming the same bucket: the second visit finds the key there).
         // No candidate array: positions are walked twice (arrays indexed at run time live in scratch memory).
         const bool tied_positions = mz.w > 0 && mz.t > 0;
-        const int n_pos = tied_positions ? 2 * mz.w : 1;
+        const int n_pos = tied_positions ? tbk_mz_positions(mz) : 1;
         uint32_t best = 0xFFFFFFFFu;
         if (tied_positions)
             for (int pi = 0; pi < n_pos; pi++) { const uint32_t g = tbk_tmer_rank(key, mz, pi); best = g < best ? g : best; }
@@ -170,7 +170,7 @@ tbk_entry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32
     const uint64_t i_end = (tid + 1) * per < n ? (tid + 1) * per : n;
     const unsigned long long FLAG64 = (unsigned long long)TBK_ENTRY_FLAG << 32;
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
-    const int n_pos = 2 * mz.w;
+    const int n_pos = tbk_mz_positions(mz);
     for (uint64_t i = tid * per; i < i_end; i++) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;
@@ -244,7 +244,7 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
     const uint64_t i_end = (tid + 1) * per < n ? (tid + 1) * per : n;
     const uint32_t hapb = half ? 1u : 0u;
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
-    const int n_pos = 2 * mz.w;
+    const int n_pos = tbk_mz_positions(mz);
     for (uint64_t i = tid * per; i < i_end; i++) {
         const uint64_t key = keys[i];
         if (key >= TBK_NOKEY) continue;
@@ -322,9 +322,9 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
 __global__ void __launch_bounds__(256)
 tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsigned long long *__restrict__ over, uint32_t over_mask, uint32_t half, TbkMz mz,
                         TbkShortGeom g, int k, const uint64_t *__restrict__ keys, uint64_t n, int skip_a, unsigned long long *__restrict__ cnt,
-                        int *__restrict__ failed) {
+                        int *__restrict__ failed, uint32_t line_cap) {  // line_cap: slots of a line the inserts use (32; tests lower it to fill the overflow table)
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
-    const int n_pos = 2 * mz.w;
+    const int n_pos = tbk_mz_positions(mz);
     const uint32_t listbit = half ? TBK_SHORT_HAPB : 0u;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t key = keys[i];
@@ -342,7 +342,7 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
                 if (first_form && skip_a && tbk_short_lookup_one(lines, n_buckets, (const uint64_t *)over, over_mask, e, key) == 0) { skipped++; drop = true; break; }
                 uint32_t *line = lines + (uint64_t)e.bucket * 32;
                 bool done = false;
-                for (uint32_t sl = 0; sl < 32 && !done; sl++) {
+                for (uint32_t sl = 0; sl < line_cap && !done; sl++) {
                     uint32_t cur = __hip_atomic_load(&line[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (;;) {
                         if ((cur & ~TBK_SHORT_FLAG) == 0) {  // empty: mine, unless somebody is quicker
@@ -362,6 +362,7 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
                 if (!done) {
                     // the line is full: the canonical key goes to the overflow table
                     atomicOr(&line[31], TBK_SHORT_FLAG);
+                    atomicOr(&line[7], TBK_SHORT_FLAG);  // (set already when slots behind the front are in use: a line_cap of 8 or less)
                     const unsigned long long mine = (unsigned long long)key | ((unsigned long long)(half ? 1u : 0u) << 63);
                     uint32_t at = tbk_short_over_home(key, over_mask);
                     for (uint32_t walked = 0; walked <= over_mask && over_mask != 0 && !done; walked++, at = (at + 1) & over_mask) {
@@ -1497,7 +1498,8 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
     }
 }
 
-template <int W, bool MULTI, bool TWO, int KIND>
+// LW: the t-mer positions of a span in units of W - 2 (t = m - w) or 3 (t = m - 2w: tbk_mz_span3)
+template <int W, bool MULTI, bool TWO, int KIND, int LW>
 __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint64_t e0, const uint64_t e1, const uint64_t e2, const uint64_t e3,
                                                  const uint64_t P0, const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
                                                  uint4 *walkq, uint4 *backq, uint16_t *walkr, uint16_t *backr, uint32_t *rcnt) {
@@ -1548,8 +1550,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     uint32_t bad_lo = (uint32_t)bad64, bad_hi = (uint32_t)(bad64 >> 32);
     const uint32_t badk = k == 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
 
-    // mod-sampling state (probe_pass, SAMP): ranks of the span's 2W t-mers, tagged with their stream index mod 16
-    constexpr int NW = 2 * W;
+    // mod-sampling state (probe_pass, SAMP): ranks of the span's LW x W t-mers, tagged with their stream index mod 16 (32)
+    constexpr int NW = LW * W;
+    constexpr uint32_t TAGM = NW > 16 ? 31u : 15u;
     uint32_t win[NW];
     const int m = p.t.mz.m, o = p.t.mz.o, tlen = p.t.mz.t;
     const uint32_t span_o = (uint32_t)o;
@@ -1557,7 +1560,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     const uint32_t tmask = tlen >= 16 ? 0xFFFFFFFFu : ((1u << (2 * tlen)) - 1u);
     auto tmer_rank = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh, uint32_t pos) -> uint32_t {
         const uint32_t x = (uint32_t)(fwd64 >> fsh) & tmask, y = (uint32_t)(rc64 >> bsh) & tmask;
-        return (tbk_mmer_hash(x < y ? x : y) & ~15u) | pos;
+        return (tbk_mmer_hash(x < y ? x : y) & ~TAGM) | pos;
     };
     {
         const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
@@ -1631,12 +1634,13 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         // ---- sampling: newest t-mer in, smallest rank, its position, the m-mer there on both strands ----
 #pragma unroll
         for (int i = 0; i + 1 < NW; i++) win[i] = win[i + 1];
-        win[NW - 1] = tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(j + NW - 1) & 15u);
+        win[NW - 1] = tmer_rank(fs, bs, fsh_new, bsh_new, (uint32_t)(j + NW - 1) & TAGM);
         uint32_t best = win[0];
 #pragma unroll
         for (int i = 1; i < NW; i++) best = win[i] < best ? win[i] : best;
-        const uint32_t x = (best - (uint32_t)j) & 15u;
-        const uint32_t pos = x >= (uint32_t)W ? x - (uint32_t)W : x;
+        const uint32_t x = (best - (uint32_t)j) & TAGM;
+        const uint32_t x1 = LW == 3 && x >= 2u * (uint32_t)W ? x - 2u * (uint32_t)W : x;
+        const uint32_t pos = x1 >= (uint32_t)W ? x1 - (uint32_t)W : x1;
         const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
         // (wide entries: m-mers of up to 24 bases, 64-bit arithmetic and the placement half of the 64-bit hash)
         using mmer_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
@@ -1955,7 +1959,7 @@ tbk_probe_kernel(const ProbeArgs p) {
 
 // The entry layout's probe kernels: the same three (single-read, two-read, multi-read passes) over probe_pass_entry.
 // KIND: 0 narrow entries, 1 wide entries, 2 short keys (tbk_common.h)
-template <int W, bool MULTI, bool TWO = false, int KIND = 0>
+template <int W, bool MULTI, bool TWO = false, int KIND = 0, int LW = 2>
 __global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
 tbk_probe_entry_kernel(const ProbeArgs p) {
     __shared__ uint64_t stage[TBK_WAVES_PER_BLOCK][TBK_CHUNKS + 2];
@@ -1996,7 +2000,7 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass_entry<W, MULTI, TWO, KIND>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
+        probe_pass_entry<W, MULTI, TWO, KIND, LW>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
         if (!MULTI) return;  // one pass per block
     }
 }
@@ -2018,14 +2022,14 @@ extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_bucket
 
 
 extern "C" hipError_t tbk_launch_short_insert(uint64_t *slots, uint32_t n_buckets, uint32_t over_mask, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
-                                              int skip_a, unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+                                              int skip_a, unsigned long long *d_cnt, int *d_failed, uint32_t line_cap, hipStream_t stream) {
     TbkShortGeom g;
     if (!tbk_short_geom(k, mz, n_buckets, &g)) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(tbk_short_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (uint32_t *)slots, n_buckets, (unsigned long long *)(slots + (uint64_t)n_buckets * 16), over_mask,
-                       half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed);
+                       half, mz, g, k, d_keys, n, skip_a, d_cnt, d_failed, line_cap < 1 ? 1u : line_cap > 32 ? 32u : line_cap);
     return hipGetLastError();
 }
 
@@ -2143,6 +2147,8 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0, entry = (t.guests & TBK_FLAG_ENTRY) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
     const bool wide = (t.guests & TBK_FLAG_WIDE) != 0, shortk = (t.guests & TBK_FLAG_SHORT) != 0;
+    const bool span3 = (entry || shortk) && t.mz.t > 0 && t.mz.t == t.mz.m - 2 * t.mz.w;
+    if ((entry || shortk) && t.mz.t > 0 && !span3 && t.mz.t != t.mz.m - t.mz.w) return hipErrorInvalidValue;
     if (shortk) {
         TbkShortGeom g;
         if (!tbk_short_geom(k, t.mz, t.n_buckets, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
@@ -2167,24 +2173,27 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
         if (entry || shortk) {
-#define TBK_E(N, WD) case N: if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true, false, WD>), grid_multi, block, 0, stream, p); \
-                         else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, false, WD>), grid, block, 0, stream, p); \
-                         else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true, WD>), grid_two, block, 0, stream, p); break;
+#define TBK_E1(N, WD, LW) do { if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true, false, WD, LW>), grid_multi, block, 0, stream, p); \
+                         else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, false, WD, LW>), grid, block, 0, stream, p); \
+                         else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true, WD, LW>), grid_two, block, 0, stream, p); } while (0)
+            // (3w t-mer positions: narrow entries and short keys with spans of up to six m-mers - tbk_mz_span3)
+#define TBK_E(N, WD) case N: if (span3) TBK_E1(N, WD, 3); else TBK_E1(N, WD, 2); break;
+#define TBK_E2(N, WD) case N: if (span3) return hipErrorInvalidValue; TBK_E1(N, WD, 2); break;
             if (shortk) {
                 switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
                     TBK_E(6, 2)
 #else
-                    TBK_E(2, 2) TBK_E(3, 2) TBK_E(4, 2) TBK_E(5, 2) TBK_E(6, 2) TBK_E(7, 2) TBK_E(8, 2)
+                    TBK_E(2, 2) TBK_E(3, 2) TBK_E(4, 2) TBK_E(5, 2) TBK_E(6, 2) TBK_E2(7, 2) TBK_E2(8, 2)
 #endif
                     default: return hipErrorInvalidValue;
                 }
             } else if (wide) {
                 switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
-                    TBK_E(6, 1) TBK_E(8, 1)
+                    TBK_E2(6, 1) TBK_E2(8, 1)
 #else
-                    TBK_E(2, 1) TBK_E(3, 1) TBK_E(4, 1) TBK_E(5, 1) TBK_E(6, 1) TBK_E(7, 1) TBK_E(8, 1)
+                    TBK_E2(2, 1) TBK_E2(3, 1) TBK_E2(4, 1) TBK_E2(5, 1) TBK_E2(6, 1) TBK_E2(7, 1) TBK_E2(8, 1)
 #endif
                     default: return hipErrorInvalidValue;
                 }
@@ -2193,12 +2202,14 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
 #ifdef TBK_ONLY_W6
                     TBK_E(6, 0)
 #else
-                    TBK_E(2, 0) TBK_E(3, 0) TBK_E(4, 0) TBK_E(5, 0) TBK_E(6, 0) TBK_E(7, 0)
+                    TBK_E(2, 0) TBK_E(3, 0) TBK_E(4, 0) TBK_E(5, 0) TBK_E(6, 0) TBK_E2(7, 0)
 #endif
                     default: return hipErrorInvalidValue;
                 }
             }
 #undef TBK_E
+#undef TBK_E2
+#undef TBK_E1
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             continue;
