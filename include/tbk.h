@@ -192,12 +192,12 @@ int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_beh
  * entry_layout = 1 when the table that stands is laid out so (2: WIDE entries of 16 bytes, for k-mers whose context
  * does not fit a slot - k = 26 .. 32); entries_a/_b = entries the lists' keys take.  Chosen for clustered lists whose
  * keys merge (>= TBK_ENTRY_MIN_RATIO, default 1.5, keys per entry); TBK_ENTRY=1 / 0 pins it, TBK_ENTRY_WIDE=1 / 0 the
- * wide form, TBK_ENTRY_LOAD / TBK_WENTRY_LOAD set the entries per list and bucket (defaults 0.64 / 0.25).
+ * wide form, TBK_ENTRY_LOAD / TBK_WENTRY_LOAD set the entries per list and bucket (defaults 0.5 / 0.25).
  * entry_layout = 3: SHORT KEYS (csrc/tbk_common.h "short keys") - lists whose keys do not merge (uniform k-mers), each key
  * stored as the 32 bits its bucket does not say already, 32 to a line, plus an overflow table of full keys behind the lines
  * (tbk_classifier_stats' table_bytes counts it); entries_a/_b = words the lists' keys take.  Tried first where k (17 .. ~25,
  * m-mers of at most 16 bases) and the table's size allow; TBK_SHORT=1 / 0 pins it, TBK_SHORT_LOAD sets the keys per line
- * (default 2.6: 49 bytes of device memory per key).  Like the entry layouts it leaves out list lines that are not
+ * (default 2.3: 56 bytes of device memory per key; 2.6: 49).  Like the entry layouts it leaves out list lines that are not
  * canonical (no window ever asks for them, c/kmers.c:255): distinct_a/_b count the keys stored. */
 int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b);
 /* Random 64-byte reads, a quad of lanes per line as the probe asks for a front, over this table where it lies

@@ -215,12 +215,12 @@ def test_clustered_lists_get_the_entry_layout(gpu, orc, monkeypatch):
         monkeypatch.delenv("TBK_ENTRY")
     uni = np.empty(2 * n, dtype=np.uint64)
     check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, 21, uni.ctypes.data))
-    # uniform lists do not merge: short keys (50 bytes of HBM per key), one build; without them the key layout's front
+    # uniform lists do not merge: short keys (56 bytes of HBM per key), one build; without them the key layout's front
     ua, ub = kmers.HashSet.from_keys(uni[:n], 21), kmers.HashSet.from_keys(uni[n:], 21)
     with kmers.Classifier(ua, ub) as cls:
         st = cls.stats()
         assert st["short_keys"] and not st["entry_layout"] and not st["front_layout"] and st["layout_builds"] == 1, st
-        assert st["table_bytes"] <= 52 * 2 * n and st["keys_behind_front"] <= 0.03 * 2 * n, st
+        assert st["table_bytes"] <= 58 * 2 * n and st["keys_behind_front"] <= 0.03 * 2 * n, st
     monkeypatch.setenv("TBK_SHORT", "0")
     with kmers.Classifier(ua, ub) as cls:
         st = cls.stats()

@@ -1235,10 +1235,11 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // The entry layout: a span of 6 m-mers where k leaves room for the flanks in an entry's 30 bits (k = 21 .. 23), shorter
     // spans up to k = 25.  Its table is sized by the ENTRIES, which are known only once it is built: the first build guesses
     // four keys per entry (what runs around SNPs give at w = 6), a second one follows when that was off by more than a
-    // quarter.  TBK_ENTRY_LOAD: entries per list and bucket (default 0.64: the four front slots of a line are whoever comes
+    // quarter.  TBK_ENTRY_LOAD: entries per list and bucket (default 0.5: the four front slots of a line are whoever comes
     // first's, so a bucket overflows its front with its fifth entry - the haplotype-shaped lists of the bench: 2 x 3e8 keys =
-    // 1.6e8 entries in 15 GB, 25 bytes per key, 4 % of the entries behind a front; 0.40 .. 0.64 run alike, 0.80 loses 3 %, 1.0
-    // 11 %: profiles/r04/ab_entry_layout.log).
+    // 1.5e8 entries in 19 GB, 32 bytes per key, 3 % of the entries behind a front; with 3w t-mer positions per span the
+    // probe runs 15.45 ms at 0.5, 15.63 at 0.64 (15 GB, 25 bytes per key), 16.45 at 0.8: profiles/r04/ab_loads_span3.log;
+    // with 2w positions 0.40 .. 0.64 ran alike: ab_entry_layout.log).
     const double entry_pin = env_double("TBK_ENTRY", -1);
     const bool span3_on = env_double("TBK_SPAN3", 1) != 0;  // (0: narrow entries and short keys rank 2w t-mer positions, as the key layouts do)
     // TBK_BUILD_TIMING=1: every build of the paired table with its duration, on stderr
@@ -1272,16 +1273,20 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         // smallest t-mers at offset 0 or w, about an eighth of them, and 2 x 2e8 entries over 16-mers crowd the buckets they
         // share whatever the table's size (tbk_common.h "wide entries").
         if (!ok && env_double("TBK_ENTRY_WIDE", -1) != 0)
+        {
+            // (a span of eight 20-mers ranked over 24 t-mer positions, t = 4, was measured for wide entries: 18.5 ms against 18.1 - the
+            // kernel needs 77 registers for it, six waves per SIMD instead of seven; EXPERIMENTS.md)
             for (int mm = (m_force > 0 ? m_force : 18); mm >= (m_force > 0 ? m_force : 16) && !ok; mm--)
                 for (int w = (w_pin > 0 ? w_pin : 8); w >= (w_pin > 0 ? w_pin : 6) && !ok; w--) {
                     z = tbk_mz_params(c->k, w, n_big, mm, 1);
                     ok = wide = z.w == w && z.m == mm && z.t > 0 && tbk_wentry_geom(c->k, z, &g);
                 }
+        }
         if (!ok) return false;
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
         const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.25)))   // (four entries per list and line)
-                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.64)));  // (tests crowd the lines: 8 slots per list)
+                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.5)));  // (tests crowd the lines: 8 slots per list)
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
         double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);
@@ -1314,7 +1319,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     };
     // Short keys (tbk_common.h): lists whose keys do not merge into entries (BASELINE's uniform k-mers) in 4 bytes a key
     // instead of 8, read through the entry kernels' two-lane window loop: 8 keys of either list in a 32-byte front, 32 in a
-    // line.  TBK_SHORT_LOAD keys per line (default 2.6: 49 bytes of HBM per key; 2 x 3e8 uniform 21-mers: 29.6 GB, 1.5 % of the
+    // line.  TBK_SHORT_LOAD keys per line (default 2.3: 56 bytes of HBM per key; 2 x 3e8 uniform 21-mers: 33.4 GB, 2 % of the
     // keys behind a front).  Built first where k and the table's size allow (k = 21: any table of 65536 lines or more,
     // k = 25: 2 GB or more); lists that cluster (more than TBK_BEHIND_FRONT of the keys behind a front) go on to the key
     // layout's test and from there to entries, as before.  TBK_SHORT=0: never, 1: whatever the lists look like.
@@ -1326,7 +1331,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         TbkMz z = span_for(true);  // (the front layout's span: as long as k leaves room for, up to 8 m-mers)
         if (z.w < 2 || z.t <= 0 || z.m > 16) return false;
         if (span3_on) z = tbk_mz_span3(z);
-        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.6)));
+        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.3)));
         uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
         const uint32_t min_nb = tbk_short_min_buckets(c->k, z);
         if (!min_nb) return false;
