@@ -22,8 +22,8 @@ out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 def is_single_read_probe(name):
     """The dominant kernel: tbk_probe_kernel<W, M64, SAMP, FRONT, MULTI = false> (passes inside one read)."""
     n = name.replace(" ", "")
-    # (the entry kernels: tbk_probe_entry_kernel<W, MULTI, TWO, KIND> - KIND 0 narrow entries, 1 wide entries, 2 short keys)
-    return ("tbk_probe_kernel" in n and n.endswith("false>(ProbeArgs)")) or re.search(r"tbk_probe_entry_kernel<\d+,false,false,\d+>\(ProbeArgs\)", n) is not None
+    # (the entry kernels: tbk_probe_entry_kernel<W, MULTI, TWO, KIND, LW> - KIND 0 narrow entries, 1 wide entries, 2 short keys; LW 2 or 3: t-mer positions per span)
+    return ("tbk_probe_kernel" in n and n.endswith("false>(ProbeArgs)")) or re.search(r"tbk_probe_entry_kernel<\d+,false,false,\d+(,\d+)?>\(ProbeArgs\)", n) is not None
 
 
 def probe_means(pattern):
