@@ -216,6 +216,9 @@ if reader:
             f"plain warm {g(reader, 'plain', 'text_GB_per_s')}, gzip {g(reader, 'gzip', 'text_GB_per_s')}, bgzf {g(reader, 'bgzf', 'text_GB_per_s')}."]
 out += ["", "Experiment logs of the round (same-box A/B runs; `EXPERIMENTS.md` reads them): `ab_entry_layout.log` (entry layout on / off, entries per bucket, uniform lists forced",
         "into entries, spans of six and seven m-mers), `ab_h2d.log` (one / two H2D streams, copy stream priority, blit kernels), `calib_shape.json` (random-line rate by access shape),",
-        "`valu_rates.log` (instruction throughput), `gate_scatter.log` (partition-then-probe gate), `gate_write_direct.log` (O_DIRECT bins gate).", ""]
+        "`valu_rates.log` (instruction throughput), `gate_scatter.log` (partition-then-probe gate), `gate_write_direct.log` (O_DIRECT bins gate),",
+        "`ab_wide_entries.log` (wide entries: m-mer length, loads), `ab_span3.log` (mod-sampling over 2w and 3w t-mer positions per span), `ab_loads_span3.log` (keys per line /",
+        "entries per bucket under 3w sampling), `ab_wide_span3.log` (wide entries over 24 positions: dropped), `ab_short_drain.log` (short keys: when the back queue drains),",
+        "`bench_haplotypes_repeats_*.json` (lists from a genome with repeat families, entry layout and key layouts).", ""]
 open(os.path.join(dst, "README.md"), "w").write("\n".join(out))
 print("\n".join(out[:40]))
