@@ -321,3 +321,35 @@ def test_short_keys_on_the_reference_vectors(gpu, monkeypatch):
         assert cls.stats()["short_keys"]
         got = cls.classify_reads(v["reads"])
     assert np.array_equal(got, np.array(v["counts"], dtype=np.int32))
+
+
+@pytest.mark.parametrize("layout", ["entry", "short"])
+@pytest.mark.parametrize("k,w", [(21, 6), (21, 4), (23, 6)])
+def test_sampling_over_2w_positions_still_answers(gpu, orc, tmp_path, monkeypatch, layout, k, w):
+    """Narrow entries and short keys rank 3w t-mer positions per span by default (tbk_mz_span3); TBK_SPAN3=0 keeps the 2w
+    the key layouts use - those kernels (LW = 2) stay in the library and answer like the oracle, crowded lines included."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(7000 + 100 * k + w + (layout == "short"))
+    monkeypatch.setenv("TBK_SPAN3", "0")
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(w))
+    if layout == "short":
+        monkeypatch.setenv("TBK_SHORT", "1")
+        monkeypatch.setenv("TBK_SHORT_LOAD", "24")
+        monkeypatch.setenv("TBK_SHORT_LINE_CAP", "9")
+    else:
+        monkeypatch.setenv("TBK_ENTRY", "1")
+        monkeypatch.setenv("TBK_ENTRY_LOAD", "5.5")
+    a, b, bases, offs, want, reads = _case(rng, k, tmp_path, orc, crowd_cores=3)
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["short_keys"] == (layout == "short") and st["entry_layout"] == (layout == "entry"), st
+        assert st["sampling_t"] == st["minimizer_m"] - st["minimizer_w"], st          # 2w positions: t = m - w
+        assert st["keys_behind_front"] > 0 and st["keys_past_half"] > 0, st
+        got = cls.classify_batch(bases, offs)
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("TBK_SPAN3", "1")
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        assert st["sampling_t"] == st["minimizer_m"] - 2 * st["minimizer_w"], st      # 3w positions: t = m - 2w
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
