@@ -44,6 +44,9 @@ find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete; find gpurun_out -n
 # against its dirty data and stops the writer for ~2 s near the end, profiles/r03/e2e_writer_stall.log)
 ( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --dir /dev/shm --out-dir /tmp --devices 0,0,0 ) > gpurun_out/cli_configs1.json 2> gpurun_out/cli_configs1.err
 rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*
+# the same with lists and reads shaped like real trio-binning input (the entry layout end to end)
+( TBK_WRITE_TIMING=1 timeout 1500 python tools/measure_e2e.py --lists haplotypes --dir /dev/shm --out-dir /tmp --modes plain ) > gpurun_out/cli_configs1_haplotypes.json 2> gpurun_out/cli_configs1_haplotypes.err
+rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*
 # list loading at BASELINE configs[2] scale: 2 x 3e8-line text lists (13.2 GB), a small read set behind them
 ( timeout 1500 python tools/measure_e2e.py --kmers 300000000 --reads 100000 --modes plain --dir /dev/shm --out-dir /tmp ) > gpurun_out/cli_lists_configs2.json 2> gpurun_out/cli_lists_configs2.err
 rm -rf /dev/shm/tbk_e2e_* /tmp/tbk_e2e_*

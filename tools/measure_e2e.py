@@ -34,6 +34,9 @@ ap.add_argument("--modes", default="plain,gzip")
 ap.add_argument("--out-dir", default=None, help="where the runs write their bins (default: the inputs' temporary directory)")
 ap.add_argument("--devices", default="", help="also run the plain mode with TBK_DEVICES set to this list (e.g. 0,0,0: three rings on one GPU)")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--lists", choices=["uniform", "haplotypes"], default="uniform",
+                help="haplotypes: lists and reads shaped like real trio-binning input (bench.py --lists haplotypes): the k-mers over the SNPs between two "
+                     "haplotypes of an implicit genome, reads drawn from the haplotypes with errors")
 a = ap.parse_args()
 
 from trio_binning_amd import _lib, kmers  # noqa: E402
@@ -61,8 +64,22 @@ def dalloc(n):
 
 # ---- the two lists as text ----------------------------------------------------------------------
 t0 = time.time()
-d_keys = dalloc(2 * N * 8)
-check(lib.tbk_synth_keys_device(dev, 0x5EED0001, 0, 2 * N, k, C.c_void_p(d_keys)))
+hap = a.lists == "haplotypes"
+if hap:
+    snp_rate, err_rate = 1 / 500, 0.002
+    snp24, err24 = int(round(snp_rate * (1 << 24))), int(round(err_rate * (1 << 24)))
+    genome_len = int(N / (1 - (1 - (2 * snp_rate - snp_rate ** 2 * (1 + 1 / 3))) ** k))
+    cap = int(N * 1.05) + 1024
+    d_keys = dalloc(2 * cap * 8)
+    n_got = C.c_uint64()
+    check(lib.tbk_synth_hap_keys_device(dev, 0x5EED0001, genome_len, snp24, k, C.c_void_p(d_keys), C.c_void_p(d_keys + cap * 8), cap, C.byref(n_got)))
+    assert n_got.value <= cap
+    N, key_stride = n_got.value, cap
+    res["list_shape"] = f"haplotype-shaped: 2 x {N} k-mers over the SNPs (rate {snp_rate:g}) between two haplotypes of a {genome_len}-base genome; reads from the haplotypes, error rate {err_rate:g}"
+else:
+    d_keys = dalloc(2 * N * 8)
+    check(lib.tbk_synth_keys_device(dev, 0x5EED0001, 0, 2 * N, k, C.c_void_p(d_keys)))
+    key_stride = N
 lut = np.frombuffer(b"ACGT", dtype=np.uint8)
 paths = []
 for which in range(2):
@@ -73,7 +90,7 @@ for which in range(2):
         for lo in range(0, N, step):
             n = min(step, N - lo)
             keys = np.empty(n, dtype=np.uint64)
-            check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data, C.c_void_p(d_keys + (which * N + lo) * 8), n * 8))
+            check(lib.tbk_memcpy_d2h(dev, keys.ctypes.data, C.c_void_p(d_keys + (which * key_stride + lo) * 8), n * 8))
             out = np.empty((n, k + 1), dtype=np.uint8)
             for i in range(k):
                 out[:, i] = lut[((keys >> np.uint64(2 * i)) & np.uint64(3)).astype(np.intp)]
@@ -90,7 +107,10 @@ qual = np.full(L, ord("I"), dtype=np.uint8)
 with open(fq, "wb") as fh:
     for first in range(0, R, chunk):
         n = min(chunk, R - first)
-        check(lib.tbk_synth_reads_device(dev, 0x5EED0002, first, n, L, 0x5EED0001, N, N, k, 30, 3, C.c_void_p(d_b), C.c_void_p(d_o)))
+        if hap:
+            check(lib.tbk_synth_hap_reads_device(dev, 0x5EED0001, genome_len, snp24, 0x5EED0002, first, n, L, err24, C.c_void_p(d_b), C.c_void_p(d_o)))
+        else:
+            check(lib.tbk_synth_reads_device(dev, 0x5EED0002, first, n, L, 0x5EED0001, N, N, k, 30, 3, C.c_void_p(d_b), C.c_void_p(d_o)))
         bases = np.empty((n, L), dtype=np.uint8)
         check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_b), n * L))
         names = [b"@read%09d c\n" % (first + i) for i in range(n)]  # fixed-width names: one record layout for the whole chunk

@@ -15,7 +15,7 @@ src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 KEEP = ["bench_default.json", "bench_default_key_layout.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_8ranks_shared_device.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
-        "reader_hifi.json", "cli_configs1.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
+        "reader_hifi.json", "cli_configs1.json", "cli_configs1_haplotypes.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
 for name in KEEP:
     p = os.path.join(src, name)
     if os.path.isfile(p) and os.path.getsize(p) > 0:
