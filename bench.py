@@ -37,7 +37,7 @@ The JSON line also carries, at every N,
                 HIP-event-timed average duration inside the timed region, against the 8 TB/s HBM peak.  `frac` is
                 SURVEY §8d's reading for this design - one paired table probed once per window, P = 1: 9 bytes
                 per window; the two-probe reading (P = 2: 17 bytes) is printed beside it.  `traffic` is replayed
-                from the round's PMC passes only when those ran on this tree's kernel sources (sha256 stamp);
+                from the round's PMC passes only when those ran on this tree's kernels (sha256 of their machine code);
   parity        every rank classifies the same fixed reads (read 0 .. 4095 of the generator) through the
                 host-fed path; the count checksums must agree across ranks, and rank 0 checks the counts
                 read for read against the oracle;
