@@ -89,6 +89,10 @@
 //     x of the canonical k-mer appears as x or 2w-1-x, and (2w-1-x) mod w = w-1-(x mod w) is
 //     the same m-mer seen from the other strand.  Ties are rare, the extra copies negligible,
 //     and a lookup still meets a key at most once (it reads one home bucket).
+//     The number of ranked positions is l = w + m - t in general (tbk_mz_positions): the entry
+//     layouts and short keys take t = m - 2w where that leaves t >= 4 (tbk_mz_span3), l = 3w
+//     positions, density 4/(3w+1) = 0.211 at w = 6; the mirror of position x is l-1-x, and
+//     (l-1-x) mod w = w-1-(x mod w) still.
 //
 // Mode "plain" (w = 0): bucket = reduce(mix32(key)), one random line per window.
 struct TbkMz {
@@ -96,8 +100,8 @@ struct TbkMz {
     int m;  // m-mer length (<= 16: 32-bit m-mer arithmetic; 17..32: 64-bit)
     int o;  // first base of the span inside the k-mer: (k - (m + w - 1)) / 2
     int t;  // 0: the span's m-mer with the smallest hash is sampled ("random minimizer");
-            // t = m - w > 0: mod-sampling — the span's 2w t-mers are ranked, and the m-mer at
-            // (position of the smallest t-mer) mod w is sampled
+            // t > 0: mod-sampling — the span's w + m - t t-mers are ranked (t = m - w: 2w of them;
+            // t = m - 2w: 3w), and the m-mer at (position of the smallest t-mer) mod w is sampled
 };
 
 TBK_HD uint32_t tbk_mix32(uint64_t key) {
