@@ -353,3 +353,74 @@ def test_sampling_over_2w_positions_still_answers(gpu, orc, tmp_path, monkeypatc
         st = cls.stats()
         assert st["sampling_t"] == st["minimizer_m"] - 2 * st["minimizer_w"], st      # 3w positions: t = m - 2w
         assert np.array_equal(cls.classify_batch(bases, offs), want)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TBK_FUZZ_SEEDS", "24"))))  # more seeds for a soak run
+def test_seeded_fuzz_of_the_entry_and_short_key_layouts(gpu, orc, tmp_path, seed, monkeypatch):
+    """Random small configurations of the round-4 layouts: any k they hold, any span, 2w or 3w t-mer positions, tables from
+    roomy to crowded, lists full of what makes ranks tie and m-mers palindromic (runs of one base, short-period repeats,
+    reverse complements, duplicates, lines shared between the lists), reads with N and lower case and ragged lengths."""
+    from trio_binning_amd import kmers
+
+    rng = np.random.default_rng(31000 + seed)
+    layout = ["entry", "short", "wide"][seed % 3]
+    k = int(rng.choice({"entry": [17, 19, 21, 22, 23, 24, 25], "short": [17, 19, 20, 21, 22, 23, 24, 25], "wide": [21, 26, 27, 29, 31, 32]}[layout]))
+    monkeypatch.setenv("TBK_MINIMIZER_W", str(int(rng.integers(2, 9))))
+    monkeypatch.setenv("TBK_SPAN3", str(int(rng.integers(0, 2))))
+    monkeypatch.setenv("TBK_SLICE_BASES", str(int(rng.choice([2048, 5000, 1 << 30]))))
+    if layout == "short":
+        monkeypatch.setenv("TBK_SHORT", "1")
+        monkeypatch.setenv("TBK_SHORT_LOAD", str(rng.choice([0.1, 2.3, 24])))
+        monkeypatch.setenv("TBK_SHORT_LINE_CAP", str(int(rng.choice([2, 8, 9, 32]))))
+    else:
+        monkeypatch.setenv("TBK_ENTRY", "1")
+        monkeypatch.setenv("TBK_ENTRY_LOAD", str(rng.choice([0.2, 0.5, 5.5])))
+        monkeypatch.setenv("TBK_WENTRY_LOAD", str(rng.choice([0.1, 0.25, 2.8])))
+        if layout == "wide":
+            monkeypatch.setenv("TBK_ENTRY_WIDE", "1")
+    n_a, n_b = int(rng.integers(1, 1500)), int(rng.integers(1, 1500))
+
+    def rand_kmer():
+        mode = rng.random()
+        if mode < 0.15:   # low complexity: long runs of one base
+            return ("ACGT"[int(rng.integers(0, 4))] * k)[: int(rng.integers(0, k + 1))].ljust(k, "ACGT"[int(rng.integers(0, 4))])
+        if mode < 0.3:    # short-period repeat
+            unit = "".join("ACGT"[c] for c in rng.integers(0, 4, int(rng.integers(1, 5))))
+            return (unit * k)[:k]
+        if mode < 0.4:    # its own reverse complement in the middle
+            half = "".join("ACGT"[c] for c in rng.integers(0, 4, (k + 1) // 2))
+            return (half + _rc(half))[:k]
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, k))
+
+    la = [rand_kmer() for _ in range(n_a)]
+    lb = [rand_kmer() for _ in range(n_b)]
+    run = "".join("ACGT"[c] for c in rng.integers(0, 4, 400))                 # runs of overlapping k-mers, as find-unique-kmers writes them
+    la += [run[i:i + k] for i in range(0, 150)]
+    lb += [_rc(run[i:i + k]) for i in range(200, 350)]
+    lb += [la[int(i)] for i in rng.integers(0, n_a, min(20, n_a))]          # shared with hapA
+    lb += [_rc(la[int(i)]) for i in rng.integers(0, n_a, min(10, n_a))]     # shared, other strand
+    la += [la[int(i)] for i in rng.integers(0, n_a, 5)]                     # duplicates
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in la))
+    fb = _write(tmp_path, "b.txt", "\n".join(lb))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    reads = _rand_reads(rng, int(rng.integers(1, 100)), int(rng.choice([40, 300, 2500, 9000])), la + lb, k, p_plant=0.9)
+    reads += ["", "A" * max(0, k - 1), la[0], _rc(lb[0]) * 2, "".join(la[:40]), "".join(_rc(x) for x in lb[:40]), run, _rc(run), "A" * 500, "AT" * 300, "ACG" * 200]
+    body = "".join("ACGT"[c] for c in rng.integers(0, 4, 5000))
+    reads += [body[: 2048 - sum(map(len, reads)) % 2048], body[:2047], body[:2048 + k - 1], body[:4096]]  # pass-boundary shapes
+    noisy = list(body[:3000])
+    for i in rng.integers(0, 3000, 40):
+        noisy[int(i)] = "NnacgtR-"[int(rng.integers(0, 8))]
+    reads.append("".join(noisy))
+    reads = [reads[int(i)] for i in rng.permutation(len(reads))]
+    bases, offs = _pack(reads)
+    want = orc.count_batch(bases, offs, oa, ob, strict=True)
+    with kmers.Classifier(a, b) as cls:
+        st = cls.stats()
+        # (a span the layout asked for has no room for at this k - the span is drawn at random - ends in wide entries or in the key
+        # layouts: which layout stands is not asserted here, the parametrized tests above do that; what is, is the counts)
+        got = cls.classify_batch(bases, offs)
+        again = cls.classify_batch(bases, offs)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, (seed, layout, k, st, bad[:10], got[bad[:5]], want[bad[:5]])
+    assert np.array_equal(again, want)
