@@ -89,6 +89,16 @@ def parse(argv=None):
     ap.add_argument("--kmers-per-list", type=int, default=BASELINE_KEYS)
     ap.add_argument("--read-len", type=int, default=15_000)
     ap.add_argument("--reads-per-step", type=int, default=262_144, help="reads of one batch = one step (3.9 Gbases at 15 kb)")
+    ap.add_argument("--read-lengths", choices=["fixed", "lognormal"], default="fixed",
+                    help="lognormal: BASELINE configs[4] as SURVEY 8d writes it - log-normal lengths with N50 --n50 (a tail past 1 Mb, "
+                         "a floor of short reads); --read-len is then only the figure --reads-per-step is sized by")
+    ap.add_argument("--n50", type=float, default=100_000.0)
+    ap.add_argument("--sigma", type=float, default=0.9, help="lognormal: sigma of ln(length)")
+    ap.add_argument("--short-fraction", type=float, default=0.05, help="lognormal: share of the reads that are debris of 1 b .. 5 kb")
+    ap.add_argument("--max-read-len", type=int, default=4_000_000)
+    ap.add_argument("--no-sweep", dest="sweep", action="store_false",
+                    help="skip the full-membership sweep of the built table (every list key, as many non-members, every key's near "
+                         "miss - trio_binning_amd/sweep.py; under a second at 2 x 3e8 keys, recorded under `sweep`)")
     ap.add_argument("--resident-batches", type=int, default=2, help="weak scaling: distinct read batches kept in HBM and cycled")
     ap.add_argument("--lists", choices=["uniform", "haplotypes"], default="uniform",
                     help="uniform: BASELINE.json's synthetic lists (distinct uniform random k-mers, reads with planted list "
@@ -445,6 +455,17 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     if not hap:
         assert stats["distinct_a"] == n_list and stats["distinct_b"] == n_list, stats
 
+    sweep_rec = None
+    if args.sweep and rank == 0:
+        from trio_binning_amd.sweep import full_membership_sweep
+
+        t_sw = time.time()
+        sweep_rec = full_membership_sweep(cls, hap_a, hap_b, hap_a.device_keys, hap_b.device_keys, n_list, n_list, k, device=dev,
+                                          uniform_seed=None if hap else KEY_SEED)
+        sweep_rec["seconds"] = round(time.time() - t_sw, 1)
+        sweep_rec["what"] = ("every key of both lists as a read of k bases and packed 512 to a long read, as many non-members, every key with one base "
+                             "substituted: counts compared on the device with what the lists say (c/kmers.c:112-122, 245-268)")
+
     want_cpu = rank == 0 and not args.no_cpu_baseline
     h_keys = None
     if want_cpu:
@@ -453,8 +474,28 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         check(lib.tbk_memcpy_d2h(dev, h_keys.ctypes.data + n_list * 8, C.c_void_p(d_keys + key_stride * 8), n_list * 8))
     check(lib.tbk_device_free(dev, C.c_void_p(d_keys)))
 
-    def synth_reads(first, n_r, d_bases, d_offs):
-        if hap:
+    ragged = args.read_lengths == "lognormal"
+
+    def lengths_of(first, n_r):
+        """offsets[0 .. n_r] of reads first .. first + n_r - 1 of the generator (host array)"""
+        if not ragged:
+            return np.arange(n_r + 1, dtype=np.uint64) * np.uint64(L)
+        offs = np.zeros(n_r + 1, dtype=np.uint64)
+        check(lib.tbk_synth_lognormal_lengths(READ_SEED, first, n_r, args.n50, args.sigma, args.short_fraction, 1, args.max_read_len, offs.ctypes.data))
+        return offs
+
+    def synth_reads(first, n_r, d_bases, d_offs, offs=None):
+        if ragged:
+            offs = lengths_of(first, n_r) if offs is None else offs
+            tot = int(offs[-1])
+            check(lib.tbk_memcpy_h2d(dev, C.c_void_p(d_offs), offs.ctypes.data, offs.nbytes))
+            if hap:
+                check(lib.tbk_synth_hap_reads_ragged_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first, n_r, C.c_void_p(d_offs), tot,
+                                                            int(np.diff(offs).max()), err24, C.c_void_p(d_bases)))
+            else:
+                check(lib.tbk_synth_reads_ragged_device(dev, READ_SEED, first, n_r, C.c_void_p(d_offs), tot, KEY_SEED, n_list, n_list, k,
+                                                        max(k, 15_000 // max(1, args.plant_major + args.plant_minor)), C.c_void_p(d_bases)))
+        elif hap:
             check(lib.tbk_synth_hap_reads_device(dev, KEY_SEED, genome_len, snp24, READ_SEED, first, n_r, L, err24,
                                                  C.c_void_p(d_bases), C.c_void_p(d_offs)))
         else:
@@ -479,20 +520,23 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     host_fed = args.timed_path == "host_fed"
     keep_resident = (not strong) or not host_fed  # a strong shard is kept in HBM only when that is what is timed
     r_cap = max(last - first for first, last in spans)
-    stage = kmers.pinned_empty((r_cap * L,), np.uint8)  # ASCII on its way from the generator (HBM) to the packer
+    span_offs = [lengths_of(first, last - first) for first, last in spans]
+    b_cap = max(int(o[-1]) for o in span_offs)
+    stage = kmers.pinned_empty((b_cap,), np.uint8)  # ASCII on its way from the generator (HBM) to the packer
     batches = []  # (d_bases, d_offsets, n_reads, total_bases, packed host batch)
+    windows_of = []  # window starts of every batch: sum of max(0, length - k + 1)
     d_bases = d_offs = None
-    for first, last in spans:
+    for (first, last), offs in zip(spans, span_offs):
         n_r = last - first
-        tot = n_r * L
+        tot = int(offs[-1])
         if d_bases is None or keep_resident:
-            d_bases = dalloc((r_cap * L + 15) // 16 * 16 + 16)
+            d_bases = dalloc(((b_cap if strong else tot) + 15) // 16 * 16 + 16)
             d_offs = dalloc((r_cap + 1) * 8)
-        synth_reads(first, n_r, d_bases, d_offs)
+        synth_reads(first, n_r, d_bases, d_offs, offs)
         check(lib.tbk_memcpy_d2h(dev, stage.ctypes.data, C.c_void_p(d_bases), tot))
-        offs = np.arange(n_r + 1, dtype=np.uint64) * np.uint64(L)
         packed = kmers.pack_bases(stage[:tot], offs, pinned=True)
         batches.append((d_bases if keep_resident else None, d_offs if keep_resident else None, n_r, tot, packed))
+        windows_of.append(int(np.maximum(np.diff(offs).astype(np.int64) - k + 1, 0).sum()))
     del stage
     t_setup = time.time() - t_setup
 
@@ -587,11 +631,12 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
 
     # ---- parity: every rank classifies the generator's first reads through the host-fed path ------------
     n_par = max(1, min(args.parity_reads, 1 << 16))
-    d_pb, d_po = dalloc((n_par * L + 15) // 16 * 16 + 16), dalloc((n_par + 1) * 8)
-    synth_reads(0, n_par, d_pb, d_po)
-    par_bases = kmers.pinned_empty((n_par * L,), np.uint8)
+    par_offs = lengths_of(0, n_par)
+    par_total = int(par_offs[-1])
+    d_pb, d_po = dalloc((par_total + 15) // 16 * 16 + 16), dalloc((n_par + 1) * 8)
+    synth_reads(0, n_par, d_pb, d_po, par_offs)
+    par_bases = kmers.pinned_empty((par_total,), np.uint8)
     check(lib.tbk_memcpy_d2h(dev, par_bases.ctypes.data, C.c_void_p(d_pb), par_bases.nbytes))
-    par_offs = np.arange(n_par + 1, dtype=np.uint64) * np.uint64(L)
     par_counts = pipe.wait(pipe.submit(par_bases, par_offs)).copy()                      # ASCII in, packed by the feeder
     par_counts2 = pipe.wait(pipe.submit_packed(kmers.pack_bases(par_bases, par_offs)))   # packed ahead, as the reader does
     import zlib
@@ -599,7 +644,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     mine = {"rank": rank, "device_index": dev, "device": _lib.device_identity(dev), "placement": placement, "sum_a": int(par_counts[:, 0].sum()), "sum_b": int(par_counts[:, 1].sum()),
             "crc32": zlib.crc32(par_counts.tobytes()), "transfers_agree": bool(np.array_equal(par_counts, par_counts2))}
     everyone = dist.gather_obj(mine)
-    parity = {"reads_checked_per_rank": n_par, "bases_checked_per_rank": n_par * L, "count_checksum": [mine["sum_a"], mine["sum_b"], mine["crc32"]],
+    parity = {"reads_checked_per_rank": n_par, "bases_checked_per_rank": par_total, "count_checksum": [mine["sum_a"], mine["sum_b"], mine["crc32"]],
               "all_ranks_equal": all((e["sum_a"], e["sum_b"], e["crc32"]) == (mine["sum_a"], mine["sum_b"], mine["crc32"]) for e in everyone),
               "packed_and_ascii_transfers_agree": all(e["transfers_agree"] for e in everyone)}
     devices = [{"rank": e["rank"], "device_index": e["device_index"], "id": e["device"], **e["placement"]} for e in everyone]
@@ -609,9 +654,10 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     # single-read kernel (passes inside one read: on 15 kb reads 86 % of the passes).  The roofline is the
     # single-read kernel's: its windows x the algorithmic bytes per window (1 read byte + 8 B for
     # the hapA slot + 8 B for the hapB slot when hapA missed; P = 1 reading: 1 + 8) / its HIP-event time.
-    hit_a_frac = float(par_counts[:, 0].sum()) / max(1, n_par * max(0, L - k + 1))
+    hit_a_frac = float(par_counts[:, 0].sum()) / max(1, int(np.maximum(np.diff(par_offs).astype(np.int64) - k + 1, 0).sum()))
     reads_per_launch = sum(b[2] for b in batches) / len(batches)
-    windows = reads_per_launch * max(0, L - k + 1)
+    bases_per_launch = sum(b[3] for b in batches) / len(batches)
+    windows = sum(windows_of) / len(batches)
     single_frac = 1.0 - multi_passes / max(1, n_passes)
     windows_single = windows * single_frac
     # "a merged single-table implementation must report with P = 1 (B_alg = 9 B)".  The design is one paired
@@ -663,7 +709,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "whole_probe": {"what": "pass index + multi-read, two-read and single-read kernels, per batch", "alg_bytes": int(windows * b_alg),
                         "achieved": round(windows * b_alg / probe_s / 1e9, 1) if probe_s > 0 else None,
                         "frac": round(windows * b_alg / probe_s / 1e9 / HBM_PEAK_GBPS, 4) if probe_s > 0 else None},
-        "kernel_only_gbases_per_s": round(reads_per_launch * L / probe_s / 1e9, 2) if probe_s > 0 else None,
+        "kernel_only_gbases_per_s": round(bases_per_launch / probe_s / 1e9, 2) if probe_s > 0 else None,
     }
     if traffic is not None and single_s > 0:
         # where the kernel sits against what the memory system can actually deliver: PMC-measured
@@ -696,7 +742,16 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         want_cpu = False
     fed_txt = ("batches in pinned host memory in the packed transfer format (what the reader hands over), through the pipeline: H2D on the side stream, "
                "kernels, D2H, host binning" if host_fed else "batches resident in HBM")
-    if strong:
+    if ragged:
+        lens_all = np.concatenate([np.diff(o) for o in span_offs]).astype(np.int64)
+        order = np.sort(lens_all)[::-1]
+        n50_got = int(order[np.searchsorted(np.cumsum(order), lens_all.sum() / 2)])
+        read_lengths = {"distribution": f"log-normal, N50 {args.n50:g}, sigma {args.sigma:g}, {args.short_fraction:g} of the reads debris of 1 b .. 5 kb, clamped to {args.max_read_len}",
+                        "reads": int(lens_all.size), "bases": int(lens_all.sum()), "n50": n50_got, "mean": round(float(lens_all.mean()), 1), "median": int(np.median(lens_all)),
+                        "min": int(lens_all.min()), "max": int(lens_all.max()), "reads_over_1Mb": int((lens_all > 1_000_000).sum()), "reads_under_k": int((lens_all < k).sum())}
+        workload = (f"BASELINE configs[4] shape on one GPU per rank: synthetic reads with log-normal lengths (N50 {n50_got}, {lens_all.size} reads = {lens_all.sum() / 1e9:.2f} Gbp "
+                    f"{'in all, split over ' + str(world) + ' rank(s) by read index' if strong else 'per rank, cycled'}), 2x{n_list} unique {k}-mers replicated per GPU; {fed_txt}")
+    elif strong:
         workload = (f"BASELINE configs[3]: one fixed set of {args.strong_reads} synthetic {L} b reads ({args.strong_reads * L / 1e9:.1f} Gbp) "
                     f"split over {world} rank(s) by read index, 2x{n_list} unique {k}-mers replicated per GPU; {fed_txt}; "
                     f"a step = one pass of every rank over its shard")
@@ -711,7 +766,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "data": "synthetic" if not hap else f"synthetic haplotypes (SNP rate {args.snp_rate:g}, read error rate {args.error_rate:g}" + (f", {args.repeat_fraction:g} of the genome in repeats" if args.repeat_fraction else "") + ")",
         "config": {
             "workload": workload, "timed_path": args.timed_path,
-            "k": k, "kmers_per_list": n_list, "read_len": L, "reads_per_step": R if not strong else None,
+            "k": k, "kmers_per_list": n_list, "read_len": L if not ragged else None, "read_lengths": read_lengths if ragged else "fixed", "reads_per_step": R if not strong else None,
             "distinct_batches": len(batches), "launches_per_step": launches_per_step, "bases_per_step_per_rank": bases_per_step,
             "h2d_bytes_per_base": round(sum(b[4].nbytes for b in batches) / max(1, sum(b[3] for b in batches)), 4) if host_fed else 0,
             "table_bytes_per_gpu": stats["table_bytes"], "table_bytes_per_key": round(stats["table_bytes"] / max(1, 2 * n_list), 1), "table_load": round(table_load, 4),
@@ -736,7 +791,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         out["devices_note"] = "--share-device: every rank uses device 0 (a plumbing run, not a scaling result)"
 
     # ---- the same stage fed differently (rank 0, N = 1) ----------------------------------------------
-    if rank == 0 and world == 1 and not args.no_streaming:
+    if rank == 0 and world == 1 and not args.no_streaming and not ragged:
         out["pipeline_variants"] = pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batches[0], L)
 
     if args.calibrate and rank == 0:
@@ -745,6 +800,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     # ---- CPU baseline + read-for-read parity on a bounded sample (rank 0, every N) ---------------------
     if want_cpu:
         out["cpu_baseline"], cpu_par = cpu_baseline(args, np, lib, par_bases, par_offs, par_counts, h_keys, n_list, k, L, n_par)
+    if sweep_rec is not None:
+        out["sweep"] = sweep_rec
         out["parity"].update(cpu_par)
 
     pipe.close()
@@ -852,7 +909,7 @@ def cpu_baseline(args, np, lib, h_bases, offs, gpu_counts, h_keys, n_list, k, L,
 
     def timed(n_reads, threads):
         t = time.perf_counter()
-        c = orc.count_batch(h_bases[: n_reads * L], offs[: n_reads + 1], oa, ob, threads=threads)
+        c = orc.count_batch(h_bases[: int(offs[n_reads])], offs[: n_reads + 1], oa, ob, threads=threads)
         return time.perf_counter() - t, c
 
     # 1 thread = what the reference does.  Calibrate on a few reads, then ~cpu_seconds worth.
@@ -860,22 +917,22 @@ def cpu_baseline(args, np, lib, h_bases, offs, gpu_counts, h_keys, n_list, k, L,
     dt, _ = timed(probe_n, 1)
     n1 = int(max(probe_n, min(sample_reads, args.cpu_seconds / max(dt / probe_n, 1e-9))))
     dt1, c1 = timed(n1, 1)
-    rate1 = n1 * L / dt1 / 1e9
+    rate1 = int(offs[n1]) / dt1 / 1e9
     # all host cores, reads sharded over threads sharing the read-only tables
     nall = int(max(n1, min(sample_reads, n1 * cores * 0.7)))
     dtn, cn = timed(nall, cores)
-    raten = nall * L / dtn / 1e9
+    raten = int(offs[nall]) / dtn / 1e9
     # fairness datum (SURVEY 8d CPU-opt): rolling k-mers + all threads on the same tables; not the
     # reference's algorithm
     t = time.perf_counter()
-    cf = orc.count_batch_fast(h_bases[: sample_reads * L], offs[: sample_reads + 1], oa, ob, threads=cores)
+    cf = orc.count_batch_fast(h_bases[: int(offs[sample_reads])], offs[: sample_reads + 1], oa, ob, threads=cores)
     dtf = time.perf_counter() - t
-    ratef = sample_reads * L / dtf / 1e9
+    ratef = int(offs[sample_reads]) / dtf / 1e9
     # parity: GPU counts of batch 0 (from the roofline step) vs the oracle on the sample
     g = gpu_counts_batch0[:nall]
     equal = (bool(np.array_equal(g, cn)) and bool(np.array_equal(g[:n1], c1))
              and bool(np.array_equal(gpu_counts_batch0[:sample_reads], cf)))
-    parity = {"reads_checked_against_the_oracle": int(nall), "bases_checked_against_the_oracle": int(nall * L), "gpu_equals_cpu": equal,
+    parity = {"reads_checked_against_the_oracle": int(nall), "bases_checked_against_the_oracle": int(offs[nall]), "gpu_equals_cpu": equal,
               "cpu_count_sums": [int(cn[:, 0].sum()), int(cn[:, 1].sum())]}
     if not equal:
         bad = np.nonzero((g != cn).any(axis=1))[0][:5]
@@ -883,12 +940,12 @@ def cpu_baseline(args, np, lib, h_bases, offs, gpu_counts, h_keys, n_list, k, L,
     base = {
         "value": round(rate1, 6), "unit": "Gbases/s", "cores": 1, "kind": "port", "host_hardware_threads": hw_threads, "host_usable_cpus": cores,
         "sample": f"oracle (faithful restatement of c/kmers.c: 2 linear-probe tables at load 0.75, non-rolling encode) "
-                  f"on the first {n1} reads ({n1 * L / 1e6:.1f} Mbases) of the generator, same 2x{n_list} {k}-mer tables, {dt1:.1f} s",
+                  f"on the first {n1} reads ({int(offs[n1]) / 1e6:.1f} Mbases) of the generator, same 2x{n_list} {k}-mer tables, {dt1:.1f} s",
         "all_cores": {"value": round(raten, 6), "unit": "Gbases/s", "cores": cores,
-                      "sample": f"first {nall} reads ({nall * L / 1e6:.1f} Mbases), reads sharded over {cores} threads, {dtn:.1f} s"},
+                      "sample": f"first {nall} reads ({int(offs[nall]) / 1e6:.1f} Mbases), reads sharded over {cores} threads, {dtn:.1f} s"},
         "optimised_rolling_all_cores": {"value": round(ratef, 6), "unit": "Gbases/s", "cores": cores,
                                         "sample": f"fairness datum, not the reference's algorithm: rolling canonical k-mers, "
-                                                  f"{sample_reads} reads ({sample_reads * L / 1e6:.1f} Mbases) over {cores} threads, {dtf:.1f} s"},
+                                                  f"{sample_reads} reads ({int(offs[sample_reads]) / 1e6:.1f} Mbases) over {cores} threads, {dtf:.1f} s"},
         "table_build_s": round(t_tables, 1),
     }
     return base, parity

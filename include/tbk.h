@@ -101,6 +101,9 @@ void tbk_reverse_complement(const char *kmer_in, char *kmer_out, unsigned char k
  * (0 keys from the caller / the host parser, 1 the GPU parser, 2 the cache); tbk_table_keys copies the keys out. */
 int tbk_table_create_from_file(const char *path, int device, tbk_table **out);
 int tbk_table_origin(const tbk_table *t);
+/* The list's packed keys where they lie in HBM on the list's device (num_kmers of them; read-only, valid until the list is
+ * destroyed): what the full-membership sweep reads. */
+const void *tbk_table_device_keys(const tbk_table *t);
 int tbk_table_keys(const tbk_table *t, uint64_t *keys, uint64_t capacity);
 /* Host-only half of the above: parse the list (all host threads when every line is k bytes +
  * newline, the sequential general parser otherwise) into malloc'd packed keys; free with
@@ -139,6 +142,44 @@ int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *hap_
  * destroyed afterwards. */
 int tbk_classifier_create(const tbk_table *hap_a, const tbk_table *hap_b, tbk_classifier **out);
 void tbk_classifier_destroy(tbk_classifier *c);
+/* How a classifier is built, as arguments (the reference configures itself through argparse alone,
+ * classify_by_kmers.py:14-54): nothing under tbk_classifier_create* / tbk_pipeline_create* reads the environment, and two
+ * classifiers of one process may be built with different options at the same time.  tbk_options_init writes the defaults;
+ * tbk_classifier_create(a, b, out) = tbk_classifier_create_opts(a, b, NULL, out) = the defaults.  No option changes any
+ * result (c/kmers.c:245-299: only membership is observable); they pin what the lists would decide, move the decisions'
+ * thresholds and size the table.  tbk_options_from_env overlays the TBK_* variables of the process environment
+ * (TBK_SHORT, TBK_ENTRY, TBK_ENTRY_WIDE, TBK_FRONT, TBK_MOD_SAMPLING, TBK_SPAN3, TBK_GUESTS, TBK_MINIMIZER_W/_M,
+ * TBK_TABLE_LOAD, TBK_ENTRY_LOAD, TBK_WENTRY_LOAD, TBK_SHORT_LOAD, TBK_CLUSTERED, TBK_BEHIND_FRONT, TBK_PLAINLY_CLUSTERED,
+ * TBK_ENTRY_MIN_RATIO, TBK_MEMORY_BUDGET, ...): the command-line tools' fallback, called by THEM (the Python bindings do
+ * when no options are given) - never by the library's constructors. */
+typedef struct tbk_options {
+    uint32_t size;            /* sizeof(tbk_options) of the caller (tbk_options_init sets it): the struct may grow */
+    /* the layout of the paired table: -1 the lists decide (short keys -> key layout front-first -> entries -> whole lines,
+     * csrc/tbk_common.h), 0 never this one, 1 this one whatever the lists look like */
+    int32_t short_keys, entries, wide_entries, front;
+    int32_t mod_sampling;     /* -1 / 1: mod-sampling picks the bucket; 0: the random minimizer */
+    int32_t span3;            /* -1 / 1: narrow entries and short keys rank 3w t-mer positions; 0: 2w */
+    int32_t guests;           /* -1 / 1: key layouts keep a full half's surplus in the other half of its line (k < 32); 0: not */
+    int32_t minimizer_w;      /* m-mers per span; -1: as many as k leaves room for (6 .. 8); 0: plain hashing of the key */
+    int32_t minimizer_m;      /* m-mer length; 0: by k and the lists' size */
+    int32_t two_read_kernel;  /* 0: passes that touch two reads go to the multi-read kernel */
+    double table_load;        /* key layouts: keys per slot; 0: 0.08, denser only where the memory budget says so */
+    double entry_load, wentry_load, short_load;  /* entries per list and bucket (0.5 / wide 0.25), short keys per line (2.3) */
+    double clustered, behind_front, plainly_clustered, entry_min_ratio;  /* the policy's thresholds (0.003, 0.05, 0.12, 1.5) */
+    uint64_t memory_budget_bytes;  /* what the paired table may take; 0: 60 % of the device's TOTAL memory (the same lists give
+                                      the same table whatever else lives on the device) */
+    uint64_t table_align;     /* alignment of the table's first byte (0: the allocator's) */
+    uint32_t short_line_cap;  /* slots of a line the short-key inserts use (32; tests lower it to fill the overflow table) */
+    int32_t probe_max_blocks; /* cap of the multi-read kernel's grid (0: none; tests) */
+    int32_t packed_h2d;       /* 1: host batches cross PCIe in the packed transfer format; 0: as ASCII */
+    uint64_t slice_bases;     /* an empty ring takes a host batch in slices of at least this many bases (384 Mi) */
+    int32_t build_timing;     /* 1: every build of the paired table with its duration, on stderr */
+    int32_t force_replica;    /* 1: a further ring on the table's own device gets a full replica (how one GPU runs the replica path) */
+    int32_t ring_streams, copy_priority, h2d_streams, zero_copy;  /* experiments of EXPERIMENTS.md (0, 0, 1, 0) */
+} tbk_options;
+void tbk_options_init(tbk_options *o);
+int tbk_options_from_env(tbk_options *o);
+int tbk_classifier_create_opts(const tbk_table *hap_a, const tbk_table *hap_b, const tbk_options *options, tbk_classifier **out);
 /* Several devices (the reference's per-read loop, classify_by_kmers.py:99-102, has no
  * cross-read state, so reads shard over devices and the tables are replicated).  The two lists are
  * hashed once, on their own device; out[i] is a classifier on devices[i] holding a copy of the
@@ -149,9 +190,11 @@ void tbk_classifier_destroy(tbk_classifier *c);
  * tickets of one classifier complete in submission order).  On failure nothing is left behind. */
 int tbk_classifier_create_multi(const tbk_table *hap_a, const tbk_table *hap_b, const int *devices, int n_devices,
                                 tbk_classifier **out /* [n_devices] */);
+int tbk_classifier_create_multi_opts(const tbk_table *hap_a, const tbk_table *hap_b, const int *devices, int n_devices,
+                                     const tbk_options *options, tbk_classifier **out /* [n_devices] */);
 /* One more classifier over a finished classifier's table, on `device`.  On another device the table is replicated
  * (peer access where the devices are peers, hipMemcpyPeer); on src's own device the read-only table is shared - unless
- * TBK_FORCE_REPLICA=1, which makes a full replica there too through the same calls (how a one-GPU box executes the
+ * src was created with tbk_options.force_replica, which makes a full replica there too through the same calls (how a one-GPU box executes the
  * replica path).  tbk_classifier_table_id: where a classifier's table lies (equal ids = one shared table) and whether
  * it is such a copy. */
 int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out);
@@ -167,7 +210,7 @@ int tbk_classifier_stats(const tbk_classifier *c, uint64_t *distinct_a, uint64_t
 int tbk_classifier_shared_keys(const tbk_classifier *c, uint64_t *n_shared);
 /* How a key picks its bucket: the minimizer (w m-mers of length m, starting at base
  * span_offset of the k-mer) of the k-mer's central span, or the whole key when w = 0.
- * Env TBK_MINIMIZER_W (default 6) and TBK_TABLE_LOAD tune it; neither changes any result. */
+ * tbk_options.minimizer_w and .table_load tune it; neither changes any result. */
 int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimizer_m, int *span_offset);
 /* 0: the span's m-mer with the smallest hash picks the bucket (random minimizer); t > 0: mod-sampling
  * over the span's t-mers (15 % fewer bucket switches between consecutive windows, more arithmetic per
@@ -175,7 +218,7 @@ int tbk_classifier_layout(const tbk_classifier *c, int *minimizer_w, int *minimi
  * and, if more than 0.3 % (TBK_CLUSTERED) of the keys found their own half of their home line full
  * - lists that cluster, as real find-unique-kmers output does - built again with the random
  * minimizer and at half the load (0.04 instead of 0.08 keys per slot: such lists are the ones a
- * roomier table helps).  TBK_MOD_SAMPLING=1 / 0 pins the rule, TBK_TABLE_LOAD the load.  No result
+ * roomier table helps).  tbk_options.mod_sampling pins the rule, .table_load the load.  No result
  * depends on either. */
 int tbk_classifier_sampling_t(const tbk_classifier *c);
 /* How many times the table was built (1 or 2, see above) and how many keys found their own half of
@@ -183,7 +226,7 @@ int tbk_classifier_sampling_t(const tbk_classifier *c);
 int tbk_classifier_build_info(const tbk_classifier *c, int *layout_builds, uint64_t *keys_past_half);
 /* Layout of the paired table that stands: front = 1 when the probe kernel fetches the first 64 bytes of a
  * line only (the first four slots of each list; csrc/tbk_common.h "front layout"), and how many keys lie
- * behind that front (settled by the deferred walk).  TBK_FRONT=1 / 0 pins the layout. */
+ * behind that front (settled by the deferred walk).  tbk_options.front pins the layout. */
 int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_behind_front);
 /* Entry layout (csrc/tbk_common.h "entry layout"): lists whose keys come in runs of overlapping k-mers - what
  * find-unique-kmers writes (find_unique_kmers.py:200-233): the k windows over every variant - store a run once per
@@ -191,12 +234,12 @@ int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_beh
  * under the window's mask (replaces kmer_in_hash_set's compare, c/kmers.c:245-268; membership is the same).
  * entry_layout = 1 when the table that stands is laid out so (2: WIDE entries of 16 bytes, for k-mers whose context
  * does not fit a slot - k = 26 .. 32); entries_a/_b = entries the lists' keys take.  Chosen for clustered lists whose
- * keys merge (>= TBK_ENTRY_MIN_RATIO, default 1.5, keys per entry); TBK_ENTRY=1 / 0 pins it, TBK_ENTRY_WIDE=1 / 0 the
- * wide form, TBK_ENTRY_LOAD / TBK_WENTRY_LOAD set the entries per list and bucket (defaults 0.5 / 0.25).
+ * keys merge (>= tbk_options.entry_min_ratio, default 1.5, keys per entry); .entries = 1 / 0 pins it, .wide_entries the
+ * wide form, .entry_load / .wentry_load set the entries per list and bucket (defaults 0.5 / 0.25).
  * entry_layout = 3: SHORT KEYS (csrc/tbk_common.h "short keys") - lists whose keys do not merge (uniform k-mers), each key
  * stored as the 32 bits its bucket does not say already, 32 to a line, plus an overflow table of full keys behind the lines
  * (tbk_classifier_stats' table_bytes counts it); entries_a/_b = words the lists' keys take.  Tried first where k (17 .. ~25,
- * m-mers of at most 16 bases) and the table's size allow; TBK_SHORT=1 / 0 pins it, TBK_SHORT_LOAD sets the keys per line
+ * m-mers of at most 16 bases) and the table's size allow; tbk_options.short_keys pins it, .short_load sets the keys per line
  * (default 2.3: 56 bytes of device memory per key; 2.6: 49).  Like the entry layouts it leaves out list lines that are not
  * canonical (no window ever asks for them, c/kmers.c:255): distinct_a/_b count the keys stored. */
 int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b);
@@ -275,6 +318,7 @@ int tbk_stream_submit_device(tbk_classifier *c, const void *d_bases, const void 
  * Replaces the per-read loop of classify_by_kmers.py:99-102 for any number of GPUs of one node. */
 typedef struct tbk_pipeline tbk_pipeline;
 int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_pipeline **out);
+int tbk_pipeline_create_opts(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, const tbk_options *options, tbk_pipeline **out);
 void tbk_pipeline_destroy(tbk_pipeline *p);
 int tbk_pipeline_depth(const tbk_pipeline *p);     /* sum of the rings' depths */
 int tbk_pipeline_devices(const tbk_pipeline *p);
@@ -439,6 +483,45 @@ int tbk_synth_hap_keys_device(int device, uint64_t seed, uint64_t genome_len, ui
 int tbk_synth_hap_reads_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24,
                                uint64_t read_seed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                                uint32_t err_per_2p24, void *d_bases, void *d_offsets);
+
+/* Reads of any lengths (BASELINE configs[4]: "50x ONT ultra-long (N50 100 kb)"; the reference takes a read of any length
+ * whole, c/kmers.c:285-287).  tbk_synth_lognormal_lengths (host code) writes offsets[0 .. n_reads]: read first_read + i gets a
+ * log-normal length whose base-weighted median (N50) is n50 - ln L ~ N(ln n50 - sigma^2, sigma^2); sigma 0.9: median 44 kb,
+ * mean 67 kb, 2.7e-4 of the reads beyond 1 Mb - except that a share short_fraction of the reads is debris, log-uniform
+ * between min_len and 5 kb; lengths are clamped to [min_len, max_len].  A read's length depends on (seed, its index) alone.
+ * The two generators below fill d_bases for offsets already on the device (d_offsets[n_reads] = total_bases): uniform
+ * background with one planted list k-mer per slot_len bases (slot_len 454 = the 33 plants per 15 kb of
+ * tbk_synth_reads_device; origin A / B / none as there, every 11th plant of an origin read from the other list), and
+ * reads drawn from the two haplotypes (longest_read <= genome_len). */
+int tbk_synth_lognormal_lengths(uint64_t seed, uint64_t first_read, uint64_t n_reads, double n50, double sigma, double short_fraction,
+                                uint32_t min_len, uint32_t max_len, uint64_t *offsets);
+int tbk_synth_reads_ragged_device(int device, uint64_t read_seed, uint64_t first_read, uint64_t n_reads, const void *d_offsets, uint64_t total_bases,
+                                  uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k, uint32_t slot_len, void *d_bases);
+int tbk_synth_hap_reads_ragged_device(int device, uint64_t seed, uint64_t genome_len, uint32_t snp_per_2p24, uint64_t read_seed, uint64_t first_read,
+                                      uint64_t n_reads, const void *d_offsets, uint64_t total_bases, uint64_t longest_read, uint32_t err_per_2p24, void *d_bases);
+
+/* ---- the full-membership sweep (tests/test_gpu_scale.py, bench.py --sweep) -------------------------------------------
+ * The reference stores every list line (add_to_hash, c/kmers.c:112-122) and finds every stored canonical key
+ * (kmer_in_hash_set, c/kmers.c:245-268).  The paired tables here hold compressed and merged forms of the keys (short keys,
+ * entries, wide entries), so that claim is checked key by key at the tables' full size: tbk_classifier_sweep_keys lays the n
+ * keys at d_keys (device memory, packed as a list's) out as reads - key i as it stands when i is even, reverse-complemented
+ * when odd; keys_per_read = 1: one read of k bases per key (multi-read passes); P > 1: P keys to a read with an 'N' between
+ * neighbours, so that a read counts exactly its member keys (single-read and two-read passes) - chunk_keys at a time (0: 2^25),
+ * classifies every chunk through tbk_classify_device and compares the counts on the device with what they must be:
+ * expect = 1: every key counts (1, 0); 2: (0, 1); 0: (0, 0); or per key from d_expect (uint8, same codes; keys_per_read = 1).
+ * out[0], out[1] = the sums of the hapA / hapB counts; out[2] = reads that differ from their expectation; out[3] = the index
+ * of the first such read (all ones: none).
+ * tbk_sweep_expectation_device writes d_expect for arbitrary keys from the two lists' STANDALONE tables (verbatim 64-bit
+ * keys, plain hashing - tbk_table_contains; nothing of the paired table's layouts): 1 when hapA's list holds the key's
+ * canonical form, else 2 when hapB's does, else 0.  tbk_synth_mutate_keys_device turns keys into near misses: one base
+ * substituted (position and base hashed from seed and first + i), canonicalised - a non-member, almost always, that shares
+ * m-mer, position and most flank bits with a member.  tbk_table_contains_device: tbk_table_contains with keys and answers
+ * in device memory. */
+int tbk_table_contains_device(tbk_table *t, const void *d_keys, uint64_t n, void *d_out);
+int tbk_synth_mutate_keys_device(int device, const void *d_keys, uint64_t first, uint64_t n, int k, uint64_t seed, void *d_out);
+int tbk_sweep_expectation_device(tbk_table *a, tbk_table *b, const void *d_keys, uint64_t n, void *d_expect);
+int tbk_classifier_sweep_keys(tbk_classifier *c, const void *d_keys, uint64_t n, int k, uint32_t keys_per_read, int expect, const void *d_expect,
+                              uint64_t chunk_keys, uint64_t out[4]);
 
 /* ---- k-mer counting: the find-unique-kmers step ---------------------------
  * Replaces the KMC subprocesses of find_unique_kmers.py:62-233 by a counting table in HBM.

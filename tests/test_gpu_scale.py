@@ -15,7 +15,15 @@ Each configuration is checked two ways:
     permutation      shuffling the read order permutes the counts and nothing else;
     determinism      two launches give identical counts;
     generator promise  origin reads carry at least their 30 planted k-mers / haplotype reads side
-                     with their own haplotype."""
+                     with their own haplotype;
+* through the full-membership sweep (trio_binning_amd/sweep.py): EVERY key of both lists, as a read of k bases and
+  packed 512 to a long read, must count for its list; as many non-members, and every list key with one base
+  substituted, must count what the lists' standalone tables of verbatim keys say - the reference stores every line
+  (c/kmers.c:112-122) and finds every stored canonical key and nothing else (c/kmers.c:245-268), whatever compressed
+  form (short keys, entries, wide entries, slot-pair orders) the paired table keeps;
+* a second build of the same lists gives identical stats and identical answers.
+
+configs[4]'s reads are also drawn with log-normal lengths (N50 100 kb) - `lognormal` below."""
 import ctypes as C
 import gc
 
@@ -67,9 +75,7 @@ def big(request, gpu, orc):
         check(lib.tbk_synth_keys_device(dev, KEY_SEED, 0, 2 * n, k, C.c_void_p(d_keys)))
     a = kmers.HashSet.from_device_keys(d_keys, n, k)
     b = kmers.HashSet.from_device_keys(d_keys + stride * 8, n, k)
-    cls = kmers.Classifier(a, b)
-    a.close()
-    b.close()  # the classifier owns the hashed tables; the lists may go
+    cls = kmers.Classifier(a, b)  # (the lists stay: the sweep reads their keys and asks their standalone tables)
     st = cls.stats()
     if not hap:
         assert st["distinct_a"] == n and st["distinct_b"] == n
@@ -95,11 +101,25 @@ def big(request, gpu, orc):
         check(lib.tbk_device_free(dev, C.c_void_p(p)))
     offs = np.arange(R + 1, dtype=np.uint64) * np.uint64(L)
     base_counts = cls.classify_batch(bases, offs)
-    cfg.update(stats=st, n=n, threads=threads)
-    yield cls, bases, offs, base_counts, cfg, tables
-    cls.close()
-    del tables, bases
+    cfg.update(stats=st, n=n, threads=threads, lists_ab=(a, b), genome_len=genome_len if hap else 0, snp24=snp24 if hap else 0, err24=err24 if hap else 0)
+    state = Big(cls, bases, offs, base_counts, cfg, tables)
+    yield state
+    state.cls.close()
+    a.close()
+    b.close()
+    del tables, bases, state
     gc.collect()
+
+
+class Big:
+    """What the tests of one configuration share; unpacks as (classifier, bases, offsets, counts, cfg, oracle tables).
+    test_second_build_is_identical replaces the classifier."""
+
+    def __init__(self, cls, bases, offs, counts, cfg, tables):
+        self.cls, self.bases, self.offs, self.counts, self.cfg, self.tables = cls, bases, offs, counts, cfg, tables
+
+    def __iter__(self):
+        return iter((self.cls, self.bases, self.offs, self.counts, self.cfg, self.tables))
 
 
 def test_sample_equals_the_oracle(big, orc):
@@ -164,6 +184,120 @@ def test_read_order_permutation(big):
     perm = np.random.default_rng(1).permutation(R)
     shuffled = np.ascontiguousarray(bases.reshape(R, L)[perm]).reshape(-1)
     assert np.array_equal(cls.classify_batch(shuffled, offs), counts[perm])
+
+
+def test_every_list_key_answers_and_nothing_else_does(big):
+    """The full-membership sweep: 2n members (k-base reads and long reads), n non-members, 2n near misses."""
+    from trio_binning_amd.sweep import full_membership_sweep
+
+    cls, bases, offs, counts, cfg, _ = big
+    a, b = cfg["lists_ab"]
+    n, k = cfg["n"], cfg["k"]
+    rec = full_membership_sweep(cls, a, b, a.device_keys, b.device_keys, n, n, k, device=0,
+                                uniform_seed=KEY_SEED if cfg["lists"] == "uniform" else None)
+    bad = [r for r in rec["legs"] if not r["ok"]]
+    assert not bad, (cfg["name"], bad)
+    members = [r for r in rec["legs"] if r["leg"].startswith("members")]
+    assert len(members) == 4 and all(r["keys"] == n for r in members)
+    assert len(rec["legs"]) == 7
+    if cfg["lists"] == "uniform":
+        assert rec["shared_keys"] == 0
+
+
+def test_lognormal_read_lengths(big, orc):
+    """BASELINE configs[4] as SURVEY 8d writes it: read lengths log-normal with N50 ~ 100 kb (tail past 1 Mb, a floor of
+    short reads; the reference takes a read of any length whole, c/kmers.c:285-287).  A sample against the oracle, all
+    reads through the split and permutation properties; the pass mix (single-read / two-read / multi-read) is what ragged
+    long reads make of it."""
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    cls, _, _, _, cfg, (oa, ob) = big
+    if cfg["L"] < 100_000:
+        pytest.skip("configs[4] only")
+    dev, k, n = 0, cfg["k"], cfg["n"]
+    R = 6000
+    offs = np.zeros(R + 1, dtype=np.uint64)
+    check(lib.tbk_synth_lognormal_lengths(READ_SEED, 0, R, 100_000.0, 0.9, 0.05, 1, 4_000_000, offs.ctypes.data))
+    lens = np.diff(offs).astype(np.int64)
+    total = int(offs[-1])
+    order = np.sort(lens)[::-1]
+    n50 = order[np.searchsorted(np.cumsum(order), total / 2)]
+    assert 70_000 < n50 < 140_000 and lens.max() > 600_000 and (lens < 5000).sum() > 0.03 * R and lens.min() < 1000
+
+    def dalloc(nbytes):
+        p = C.c_void_p()
+        check(lib.tbk_device_alloc(dev, nbytes, C.byref(p)))
+        return p.value
+
+    d_bases, d_offs = dalloc(total + 64), dalloc((R + 1) * 8)
+    check(lib.tbk_memcpy_h2d(dev, C.c_void_p(d_offs), offs.ctypes.data, offs.nbytes))
+    if cfg["lists"] == "haplotypes":
+        check(lib.tbk_synth_hap_reads_ragged_device(dev, KEY_SEED, cfg["genome_len"], cfg["snp24"], READ_SEED, 0, R, C.c_void_p(d_offs), total, int(lens.max()),
+                                                    cfg["err24"], C.c_void_p(d_bases)))
+    else:
+        check(lib.tbk_synth_reads_ragged_device(dev, READ_SEED, 0, R, C.c_void_p(d_offs), total, KEY_SEED, n, n, k, 454, C.c_void_p(d_bases)))
+    bases = np.empty(total, dtype=np.uint8)
+    check(lib.tbk_memcpy_d2h(dev, bases.ctypes.data, C.c_void_p(d_bases), total))
+    d_counts = dalloc(R * 8)
+    check(lib.tbk_classify_device(cls._h, C.c_void_p(d_bases), C.c_void_p(d_offs), R, total, C.c_void_p(d_counts)))
+    check(lib.tbk_classifier_sync(cls._h))
+    resident = np.empty((R, 2), dtype=np.int32)
+    check(lib.tbk_memcpy_d2h(dev, resident.ctypes.data, C.c_void_p(d_counts), resident.nbytes))
+    n_passes, n_multi = cls.last_passes()
+    for p in (d_bases, d_offs, d_counts):
+        check(lib.tbk_device_free(dev, C.c_void_p(p)))
+    counts = cls.classify_batch(bases, offs)             # host-fed (packed transfer) against device-resident ASCII
+    assert np.array_equal(counts, resident)
+    assert 0 < n_multi < 0.2 * n_passes                    # most passes lie inside one long read
+    # a sample against the oracle: the shortest reads, the longest one, and a stretch from the middle
+    idx = np.concatenate([np.argsort(lens)[:40], [int(np.argmax(lens))], np.arange(R // 2, R // 2 + 24)])
+    sb = np.concatenate([bases[int(offs[i]):int(offs[i + 1])] for i in idx])
+    so = np.zeros(idx.size + 1, dtype=np.uint64)
+    np.cumsum(lens[idx], out=so[1:])
+    want = orc.count_batch(sb, so, oa, ob, threads=cfg["threads"])
+    assert np.array_equal(counts[idx], want), cfg["name"]
+    assert want.sum() > 100
+    # every read cut in two pieces that overlap by k - 1 bases: the sums stay (reads shorter than 2 k stay whole)
+    cut = np.where(lens >= 2 * k, lens // 2, lens)
+    pieces, plens = [], []
+    for i in range(R):
+        s, e, h = int(offs[i]), int(offs[i + 1]), int(cut[i])
+        if h < e - s:
+            pieces += [bases[s:s + h + k - 1], bases[s + h:e]]
+            plens += [h + k - 1, e - s - h]
+        else:
+            pieces += [bases[s:e], bases[s:s]]
+            plens += [e - s, 0]
+    po = np.zeros(2 * R + 1, dtype=np.uint64)
+    np.cumsum(np.array(plens, dtype=np.uint64), out=po[1:])
+    got = cls.classify_batch(np.concatenate(pieces), po)
+    assert np.array_equal(got[0::2] + got[1::2], counts)
+    # reversed read order
+    rb = np.concatenate([bases[int(offs[i]):int(offs[i + 1])] for i in range(R - 1, -1, -1)])
+    ro = np.zeros(R + 1, dtype=np.uint64)
+    np.cumsum(lens[::-1], out=ro[1:])
+    assert np.array_equal(cls.classify_batch(rb, ro), counts[::-1])
+
+
+def test_second_build_is_identical(big):
+    """Build the paired table again from the same lists: identical stats, identical answers (the inserts race for slots;
+    which key got which slot may differ, what a lookup finds may not)."""
+    from trio_binning_amd import kmers
+    from trio_binning_amd.sweep import full_membership_sweep
+
+    cls, bases, offs, counts, cfg, _ = big
+    a, b = cfg["lists_ab"]
+    st = cls.stats()
+    cls.close()
+    big.cls = again = kmers.Classifier(a, b)
+    st2 = again.stats()
+    racy = ("keys_behind_front", "keys_past_half")  # (which key of a crowded bucket ends up behind the front depends on the order of arrival)
+    assert {k_: v for k_, v in st2.items() if k_ not in racy} == {k_: v for k_, v in st.items() if k_ not in racy}, (st, st2)
+    assert np.array_equal(again.classify_batch(bases, offs), counts)
+    rec = full_membership_sweep(again, a, b, a.device_keys, b.device_keys, cfg["n"], cfg["n"], cfg["k"], device=0,
+                                uniform_seed=KEY_SEED if cfg["lists"] == "uniform" else None, legs=("members",))
+    assert rec["ok"], rec
 
 
 def test_counter_properties_at_scale(gpu):

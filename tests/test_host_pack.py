@@ -317,3 +317,29 @@ def test_borrowed_batch_outlives_its_reader(built, tmp_path, monkeypatch):
     # ... and again after that reader is gone too
     assert [(r.name, r.seq, r.qual) for r in b.reads()] == recs_b
     b.close()
+
+
+def test_lognormal_lengths_are_deterministic_and_shaped(built):
+    """tbk_synth_lognormal_lengths (host code): BASELINE configs[4]'s read lengths - N50 ~ 100 kb, a tail past 1 Mb, a floor of
+    short reads; a read's length depends on (seed, index) alone, whatever batch it is drawn in."""
+    import ctypes as C
+
+    import numpy as np
+
+    from trio_binning_amd._lib import check, lib
+
+    n = 200_000
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    check(lib.tbk_synth_lognormal_lengths(0x5EED0002, 0, n, 100_000.0, 0.9, 0.05, 1, 4_000_000, offs.ctypes.data))
+    lens = np.diff(offs).astype(np.int64)
+    order = np.sort(lens)[::-1]
+    n50 = order[np.searchsorted(np.cumsum(order), lens.sum() / 2)]
+    assert 95_000 < n50 < 105_000, n50
+    assert lens.max() > 1_000_000 and lens.max() <= 4_000_000 and lens.min() >= 1
+    assert 0.045 < (lens <= 5000).mean() < 0.06
+    assert 60_000 < lens.mean() < 68_000
+    part = np.zeros(1001, dtype=np.uint64)
+    check(lib.tbk_synth_lognormal_lengths(0x5EED0002, 12_345, 1000, 100_000.0, 0.9, 0.05, 1, 4_000_000, part.ctypes.data))
+    assert np.array_equal(np.diff(part).astype(np.int64), lens[12_345:13_345])
+    with pytest.raises(ValueError):
+        check(lib.tbk_synth_lognormal_lengths(1, 0, 10, 100_000.0, -1.0, 0.05, 1, 4_000_000, part.ctypes.data))

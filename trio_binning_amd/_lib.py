@@ -152,6 +152,15 @@ _sig("tbk_synth_reads_device", C.c_int, C.c_int, _u64, _u64, _u64, C.c_uint32, _
      C.c_int, C.c_int, _vp, _vp)
 _sig("tbk_synth_hap_keys_device", C.c_int, C.c_int, _u64, _u64, C.c_uint32, C.c_int, _vp, _vp, _u64, _u64p)
 _sig("tbk_synth_hap_reads_device", C.c_int, C.c_int, _u64, _u64, C.c_uint32, _u64, _u64, _u64, C.c_uint32, C.c_uint32, _vp, _vp)
+if hasattr(lib, "tbk_classifier_sweep_keys"):  # (variant builds of tools/build_variant.sh may predate round 5)
+    _sig("tbk_synth_lognormal_lengths", C.c_int, _u64, _u64, _u64, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _vp)
+    _sig("tbk_synth_reads_ragged_device", C.c_int, C.c_int, _u64, _u64, _u64, _vp, _u64, _u64, _u64, _u64, C.c_int, C.c_uint32, _vp)
+    _sig("tbk_synth_hap_reads_ragged_device", C.c_int, C.c_int, _u64, _u64, C.c_uint32, _u64, _u64, _u64, _vp, _u64, _u64, C.c_uint32, _vp)
+    _sig("tbk_table_contains_device", C.c_int, _vp, _vp, _u64, _vp)
+    _sig("tbk_table_device_keys", _vp, _vp)
+    _sig("tbk_synth_mutate_keys_device", C.c_int, C.c_int, _vp, _u64, _u64, C.c_int, _u64, _vp)
+    _sig("tbk_sweep_expectation_device", C.c_int, _vp, _vp, _vp, _u64, _vp)
+    _sig("tbk_classifier_sweep_keys", C.c_int, _vp, _vp, _u64, C.c_int, C.c_uint32, C.c_int, _vp, _u64, _u64p)
 _sig("tbk_host_threads", C.c_int)
 _sig("tbk_counter_create", C.c_int, C.c_int, _u64, C.c_int, C.POINTER(_vp))
 _sig("tbk_counter_destroy", None, _vp)
@@ -182,6 +191,28 @@ _sig("tbk_gzip_member", C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
 _sig("tbk_crc32_c", C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t)
 _sig("tbk_format_tsv", C.c_int, _vp, C.c_char_p, _vp, _vp, _vp, C.c_size_t, C.POINTER(C.c_size_t))
 _sig("tbk_format_float", C.c_int, C.c_double, C.c_char_p, C.c_size_t)
+
+
+class tbk_options(C.Structure):
+    """include/tbk.h: tbk_options (how a classifier is built, as arguments)."""
+    _fields_ = [("size", C.c_uint32),
+                ("short_keys", C.c_int32), ("entries", C.c_int32), ("wide_entries", C.c_int32), ("front", C.c_int32),
+                ("mod_sampling", C.c_int32), ("span3", C.c_int32), ("guests", C.c_int32), ("minimizer_w", C.c_int32), ("minimizer_m", C.c_int32),
+                ("two_read_kernel", C.c_int32),
+                ("table_load", C.c_double), ("entry_load", C.c_double), ("wentry_load", C.c_double), ("short_load", C.c_double),
+                ("clustered", C.c_double), ("behind_front", C.c_double), ("plainly_clustered", C.c_double), ("entry_min_ratio", C.c_double),
+                ("memory_budget_bytes", C.c_uint64), ("table_align", C.c_uint64), ("short_line_cap", C.c_uint32), ("probe_max_blocks", C.c_int32),
+                ("packed_h2d", C.c_int32), ("slice_bases", C.c_uint64), ("build_timing", C.c_int32), ("force_replica", C.c_int32),
+                ("ring_streams", C.c_int32), ("copy_priority", C.c_int32), ("h2d_streams", C.c_int32), ("zero_copy", C.c_int32)]
+
+
+HAS_OPTIONS = hasattr(lib, "tbk_classifier_create_opts")  # (variant builds of tools/build_variant.sh may predate round 5)
+if HAS_OPTIONS:
+    _sig("tbk_options_init", None, C.POINTER(tbk_options))
+    _sig("tbk_options_from_env", C.c_int, C.POINTER(tbk_options))
+    _sig("tbk_classifier_create_opts", C.c_int, _vp, _vp, C.POINTER(tbk_options), C.POINTER(_vp))
+    _sig("tbk_classifier_create_multi_opts", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(tbk_options), C.POINTER(_vp))
+    _sig("tbk_pipeline_create_opts", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(tbk_options), C.POINTER(_vp))
 
 
 def last_error() -> str:

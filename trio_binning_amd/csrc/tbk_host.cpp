@@ -42,7 +42,7 @@ extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, ui
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
-                                             int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, hipEvent_t, hipStream_t);
+                                             int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, int, hipEvent_t, hipStream_t);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
@@ -96,6 +96,59 @@ static double env_double(const char *name, double dflt) {
     char *end = nullptr;
     double d = strtod(v, &end);
     return end == v ? dflt : d;
+}
+
+// ---- options of a classifier (include/tbk.h: tbk_options) ----------------------------------------------------------
+// Nothing under tbk_classifier_create* / tbk_pipeline_create* reads the environment: what can be chosen is in the struct.
+// tbk_options_from_env is the command-line tools' fallback (the reference configures itself by argparse alone,
+// classify_by_kmers.py:14-54; the TBK_* variables are this build's experiment knobs) and is called by the caller, never here.
+extern "C" void tbk_options_init(tbk_options *o) {
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->size = (uint32_t)sizeof *o;
+    o->short_keys = o->entries = o->wide_entries = o->front = -1;
+    o->mod_sampling = o->span3 = o->guests = -1;
+    o->minimizer_w = -1;
+    o->minimizer_m = 0;
+    o->two_read_kernel = 1;
+    o->table_load = 0.0;  // 0: the layouts' own (0.08 for the key layouts), capped by the memory budget
+    o->entry_load = 0.5; o->wentry_load = 0.25; o->short_load = 2.3;
+    o->clustered = 0.003; o->behind_front = 0.05; o->plainly_clustered = 0.12; o->entry_min_ratio = 1.5;
+    o->memory_budget_bytes = 0;  // 0: 60 % of the device's total memory
+    o->short_line_cap = 32;
+    o->packed_h2d = 1;
+    o->slice_bases = (uint64_t)384 << 20;
+    o->h2d_streams = 1;
+}
+
+extern "C" int tbk_options_from_env(tbk_options *o) {
+    if (!o) return fail(TBK_ERR_INVALID, "options is NULL");
+    if (o->size != sizeof *o) tbk_options_init(o);
+    auto tri = [](const char *name, int32_t &v) { const double d = env_double(name, -1); if (getenv(name) && *getenv(name)) v = d > 0 ? 1 : d == 0 ? 0 : -1; };
+    auto num = [](const char *name, double &v) { if (getenv(name) && *getenv(name)) v = env_double(name, v); };
+    auto inum = [](const char *name, int32_t &v) { if (getenv(name) && *getenv(name)) v = (int32_t)env_double(name, v); };
+    auto unum = [](const char *name, uint64_t &v) { if (getenv(name) && *getenv(name)) v = (uint64_t)std::max(0.0, env_double(name, (double)v)); };
+    tri("TBK_SHORT", o->short_keys); tri("TBK_ENTRY", o->entries); tri("TBK_ENTRY_WIDE", o->wide_entries); tri("TBK_FRONT", o->front);
+    tri("TBK_MOD_SAMPLING", o->mod_sampling); tri("TBK_SPAN3", o->span3); tri("TBK_GUESTS", o->guests);
+    inum("TBK_MINIMIZER_W", o->minimizer_w); inum("TBK_MINIMIZER_M", o->minimizer_m); inum("TBK_TWO_READ", o->two_read_kernel);
+    num("TBK_TABLE_LOAD", o->table_load); num("TBK_ENTRY_LOAD", o->entry_load); num("TBK_WENTRY_LOAD", o->wentry_load); num("TBK_SHORT_LOAD", o->short_load);
+    num("TBK_CLUSTERED", o->clustered); num("TBK_BEHIND_FRONT", o->behind_front); num("TBK_PLAINLY_CLUSTERED", o->plainly_clustered);
+    num("TBK_ENTRY_MIN_RATIO", o->entry_min_ratio);
+    unum("TBK_MEMORY_BUDGET", o->memory_budget_bytes); unum("TBK_TABLE_ALIGN", o->table_align); unum("TBK_SLICE_BASES", o->slice_bases);
+    { uint64_t cap = o->short_line_cap; unum("TBK_SHORT_LINE_CAP", cap); o->short_line_cap = (uint32_t)cap; }
+    inum("TBK_PROBE_MAX_BLOCKS", o->probe_max_blocks); inum("TBK_PACKED_H2D", o->packed_h2d); inum("TBK_BUILD_TIMING", o->build_timing);
+    inum("TBK_FORCE_REPLICA", o->force_replica); inum("TBK_RING_STREAMS", o->ring_streams); inum("TBK_COPY_PRIORITY", o->copy_priority);
+    inum("TBK_H2D_STREAMS", o->h2d_streams); inum("TBK_ZERO_COPY", o->zero_copy);
+    return TBK_OK;
+}
+
+// the caller's options (NULL: the defaults; a shorter struct of an older caller: its fields over the defaults)
+static tbk_options resolve_options(const tbk_options *in) {
+    tbk_options o;
+    tbk_options_init(&o);
+    if (in && in->size >= 8) memcpy(&o, in, std::min<size_t>(in->size, sizeof o));
+    o.size = (uint32_t)sizeof o;
+    return o;
 }
 
 // Host threads worth starting: hardware threads, cut down to the CPU affinity mask and to the
@@ -291,6 +344,7 @@ struct DeviceStreams {
 struct tbk_classifier {
     int device = 0;
     int k = 0;
+    tbk_options opt = resolve_options(nullptr);  // what it was created with (tbk_classifier_create_opts)
     std::shared_ptr<DeviceStreams> streams;
     uint64_t *d_pair = nullptr;  // n_buckets lines of 128 B (front layout: [A0-3 | B0-3 | A4-7 | B4-7])
     // who frees it: the classifiers of one device share one read-only table (several stream rings on one GPU need
@@ -305,7 +359,7 @@ struct tbk_classifier {
     }
     // the table's memory: `bytes`, aligned to TBK_TABLE_ALIGN when that is set (the allocation is made that much larger)
     hipError_t alloc_pair(size_t bytes) {
-        const size_t align = (size_t)env_double("TBK_TABLE_ALIGN", 0);
+        const size_t align = (size_t)opt.table_align;
         pair_base = nullptr; d_pair = nullptr;
         hipError_t e = hipMalloc(&pair_base, bytes + align);
         if (e != hipSuccess) { pair_base = nullptr; return e; }
@@ -422,15 +476,15 @@ extern "C" void tbk_reverse_complement(const char *in, char *out, unsigned char 
 }
 
 // ---- tables ----------------------------------------------------------------------------
-static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes) {
+static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_bytes, double forced_load, uint64_t budget_bytes) {
     // Target load (keys per slot).  Plain hashing: 2 keys per 8-slot half (load 0.25).  Minimizer bucketing puts
     // keys that share a sampled m-mer into one bucket, and real lists cluster further, so it gets 0.64 keys per
     // half: load 0.08, 100 B of HBM per key, 2 x 3e8 keys = 60 GB.  Measured at that scale, resident, same box
     // (profiles/r03/ab_policy.log): uniform lists, front layout: load 0.08 184 Gbases/s, 0.12 (67 B per key) 169,
     // 0.16 (50 B) 152; haplotype-shaped lists in whole lines at 0.08: 138 (front layout at 0.04, 120 GB: 145).
-    // The table is capped at 60 % of the device's memory; bigger lists get a proportionally higher load.
-    // TBK_TABLE_LOAD overrides.
-    double load = env_double("TBK_TABLE_LOAD", 0);
+    // The table is capped at the memory budget (tbk_options.memory_budget_bytes; 0: 60 % of the device's memory); bigger
+    // lists get a proportionally higher load.  forced_load > 0 (tbk_options.table_load) overrides.
+    double load = forced_load;
     const bool forced = load > 0;
     if (!forced) load = default_load;
     if (load < 0.02) load = 0.02;
@@ -441,7 +495,7 @@ static uint32_t buckets_for(uint64_t n_keys, double default_load, size_t line_by
         // give the same table whatever else lives on the device (and a table that does not fit fails loudly)
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const double fit = 0.6 * (double)total_b / (double)line_bytes;
+            const double fit = (budget_bytes ? (double)budget_bytes : 0.6 * (double)total_b) / (double)line_bytes;
             const double floor_ = (double)n_keys / (TBK_SLOTS_PER_BUCKET * 0.5);  // never denser than load 0.5 on our own account
             if (want > fit) want = fit > floor_ ? fit : floor_;
         } else {
@@ -506,7 +560,7 @@ static int table_hash(tbk_table *t) {
     if (t->hashed) return TBK_OK;
     int rc = use_device(t->device);
     if (rc) return rc;
-    t->n_buckets = buckets_for(t->num_lines, 0.25, TBK_BUCKET_BYTES);
+    t->n_buckets = buckets_for(t->num_lines, 0.25, TBK_BUCKET_BYTES, env_double("TBK_TABLE_LOAD", 0), 0);  // (a list's standalone table - tbk_table_contains, tests - not a classifier's)
     const size_t bytes = (size_t)t->n_buckets * TBK_BUCKET_BYTES;
     HIP_TRY(hipMalloc((void **)&t->d_slots, bytes));
     hipError_t e = hipMemset(t->d_slots, 0xFF, bytes);
@@ -990,6 +1044,7 @@ extern "C" uint64_t tbk_table_num_kmers(const tbk_table *t) { return t ? t->num_
 extern "C" int tbk_table_k(const tbk_table *t) { return t ? t->k : 0; }
 extern "C" int tbk_table_device(const tbk_table *t) { return t ? t->device : -1; }
 extern "C" int tbk_table_origin(const tbk_table *t) { return t ? t->origin : -1; }
+extern "C" const void *tbk_table_device_keys(const tbk_table *t) { return t ? t->d_keys : nullptr; }
 extern "C" uint64_t tbk_table_bytes(const tbk_table *t) {
     return t ? t->num_lines * sizeof(uint64_t) + (t->hashed ? (uint64_t)t->n_buckets * TBK_BUCKET_BYTES : 0) : 0;
 }
@@ -1021,6 +1076,18 @@ extern "C" int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n
     return TBK_OK;
 }
 
+// the same with keys and answers in device memory on the list's device (the full-membership sweep: tbk_verify.cpp)
+extern "C" int tbk_table_contains_device(tbk_table *t, const void *d_keys, uint64_t n, void *d_out) {
+    if (!t || (n && (!d_keys || !d_out))) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = use_device(t->device);
+    if (rc) return rc;
+    rc = table_hash(t);
+    if (rc || !n) return rc;
+    HIP_TRY(tbk_launch_contains(t->view(), (const uint64_t *)d_keys, n, (uint8_t *)d_out, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    return TBK_OK;
+}
+
 // ---- classifier ------------------------------------------------------------------------
 // streams and the ticket ring's events (the current device is the classifier's)
 static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_device = nullptr) {
@@ -1031,13 +1098,13 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
         c->streams = std::make_shared<DeviceStreams>();
         c->streams->device = c->device;
         e = hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking);
-        if (e == hipSuccess && env_double("TBK_COPY_PRIORITY", 0) != 0) {  // (experiment: the H2D stream at the highest priority the device offers)
+        if (e == hipSuccess && c->opt.copy_priority != 0) {  // (experiment: the H2D stream at the highest priority the device offers)
             int least = 0, greatest = 0;
             e = hipDeviceGetStreamPriorityRange(&least, &greatest);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->streams->copy, hipStreamNonBlocking, greatest);
         } else if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->copy, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->streams->out, hipStreamNonBlocking);
-        if (e == hipSuccess && env_double("TBK_H2D_STREAMS", 1) >= 2) e = hipStreamCreateWithFlags(&c->streams->copy2, hipStreamNonBlocking);
+        if (e == hipSuccess && c->opt.h2d_streams >= 2) e = hipStreamCreateWithFlags(&c->streams->copy2, hipStreamNonBlocking);
     }
     c->compute = c->streams->compute; c->copy = c->streams->copy; c->out = c->streams->out;
     for (int i = 0; i < RING && e == hipSuccess; i++) {
@@ -1062,7 +1129,7 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
 // look every key up in hapA's crowded half first, are the slow part of such a build).
 static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past, uint64_t give_up_past = 0, bool *gave_up = nullptr,
                             uint64_t give_up_behind = 0) {
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES);
+    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES, c->opt.table_load, c->opt.memory_budget_bytes);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = c->alloc_pair(bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
@@ -1154,7 +1221,7 @@ static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
         const tbk_table *t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
         if (e == hipSuccess) e = tbk_launch_short_insert(c->d_pair, c->n_buckets, c->over_mask, (uint32_t)list, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed,
-                                                              (uint32_t)env_double("TBK_SHORT_LINE_CAP", 32), nullptr);  // (TBK_SHORT_LINE_CAP: tests fill the overflow table)
+                                                              c->opt.short_line_cap ? c->opt.short_line_cap : 32u, nullptr);  // (short_line_cap: tests fill the overflow table)
         if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished words)
     }
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
@@ -1175,6 +1242,10 @@ static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
 }
 
 extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk_classifier **out) {
+    return tbk_classifier_create_opts(a, b, nullptr, out);
+}
+
+extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b, const tbk_options *options, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!a || !b) return fail(TBK_ERR_INVALID, "table is NULL");
@@ -1188,9 +1259,11 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     tbk_classifier *c = new tbk_classifier();
     c->device = a->device;
     c->k = a->k;
-    c->max_blocks = (int)env_double("TBK_PROBE_MAX_BLOCKS", 0);
-    c->packed_h2d = env_double("TBK_PACKED_H2D", 1) != 0;
-    c->slice_bases = (uint64_t)std::max(2048.0, env_double("TBK_SLICE_BASES", (double)((uint64_t)384 << 20)));
+    const tbk_options o = c->opt = resolve_options(options);
+    c->max_blocks = o.probe_max_blocks;
+    c->packed_h2d = o.packed_h2d != 0;
+    c->slice_bases = std::max<uint64_t>(2048, o.slice_bases ? o.slice_bases : (uint64_t)384 << 20);
+    const uint64_t budget = o.memory_budget_bytes;  // (0: 60 % of the device's total memory)
     // Bucket selection: an m-mer sampled from the k-mer's central span (6 to 8 m-mers, see span_for below;
     // TBK_MINIMIZER_W = 0: plain hashing of the whole key) by mod-sampling, which switches lines 18 % less often than the random
     // minimizer; the load is 0.08 (100 B of HBM per key).  In which layout the probe reads a line is decided by
@@ -1212,11 +1285,11 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // full (uniform lists: 1e-5; haplotype-shaped: 2-10 %), or more than TBK_BEHIND_FRONT (default 5 %) lie behind
     // a front, build the same table again in whole lines.  TBK_MOD_SAMPLING=0 pins the random minimizer, TBK_FRONT
     // the layout, TBK_TABLE_LOAD the load.
-    const double pin = env_double("TBK_MOD_SAMPLING", -1);
-    const int w_pin = (int)env_double("TBK_MINIMIZER_W", -1), m_force = (int)env_double("TBK_MINIMIZER_M", 0);
+    const double pin = o.mod_sampling;
+    const int w_pin = o.minimizer_w, m_force = o.minimizer_m;
     const uint64_t n_big = std::max(a->num_lines, b->num_lines);
-    const uint32_t guests = c->k < 32 && env_double("TBK_GUESTS", 1) != 0 ? TBK_FLAG_GUESTS : 0u;
-    const double front_pin = env_double("TBK_FRONT", -1);
+    const uint32_t guests = c->k < 32 && o.guests != 0 ? TBK_FLAG_GUESTS : 0u;
+    const double front_pin = o.front;
     // The span: as many m-mers as k leaves room for beside an m long enough for the keys, up to 8 - a window then
     // switches lines with density 3/(2w+1): 0.176 at w = 8 against 0.231 at w = 6 (k = 21 has room for 6 only;
     // k = 25, 2 x 3e8 keys: 208 against 182 Gbases/s; k = 31, 2 x 1e9 keys: 221 against 193 -
@@ -1240,10 +1313,10 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // 1.5e8 entries in 19 GB, 32 bytes per key, 3 % of the entries behind a front; with 3w t-mer positions per span the
     // probe runs 15.45 ms at 0.5, 15.63 at 0.64 (15 GB, 25 bytes per key), 16.45 at 0.8: profiles/r04/ab_loads_span3.log;
     // with 2w positions 0.40 .. 0.64 ran alike: ab_entry_layout.log).
-    const double entry_pin = env_double("TBK_ENTRY", -1);
-    const bool span3_on = env_double("TBK_SPAN3", 1) != 0;  // (0: narrow entries and short keys rank 2w t-mer positions, as the key layouts do)
+    const double entry_pin = o.entries;
+    const bool span3_on = o.span3 != 0;  // (0: narrow entries and short keys rank 2w t-mer positions, as the key layouts do)
     // TBK_BUILD_TIMING=1: every build of the paired table with its duration, on stderr
-    const bool build_timing = env_double("TBK_BUILD_TIMING", 0) != 0;
+    const bool build_timing = o.build_timing != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what, bool kept) {
         if (!build_timing) return;
@@ -1258,7 +1331,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         TbkMz z{0, 0, 0, 0};
         TbkEntryGeom g;
         bool ok = false, wide = false;
-        if (env_double("TBK_ENTRY_WIDE", 0) <= 0)
+        if (o.wide_entries <= 0)
             for (int w = (w_pin > 0 ? w_pin : 6); w >= (w_pin > 0 ? w_pin : 4) && !ok; w--) {
                 z = tbk_mz_params(c->k, w, n_big, m_force, 1);
                 ok = z.w == w && tbk_entry_geom(c->k, z, &g);
@@ -1272,7 +1345,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         // m-mers of 18 bases where k has room (then 17, 16): mod-sampling samples only the m-mers that hold one of the span's
         // smallest t-mers at offset 0 or w, about an eighth of them, and 2 x 2e8 entries over 16-mers crowd the buckets they
         // share whatever the table's size (tbk_common.h "wide entries").
-        if (!ok && env_double("TBK_ENTRY_WIDE", -1) != 0)
+        if (!ok && o.wide_entries != 0)
         {
             // (a span of eight 20-mers ranked over 24 t-mer positions, t = 4, was measured for wide entries: 18.5 ms against 18.1 - the
             // kernel needs 77 registers for it, six waves per SIMD instead of seven; EXPERIMENTS.md)
@@ -1285,8 +1358,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         if (!ok) return false;
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
-        const double el = wide ? std::min(3.5, std::max(0.02, env_double("TBK_WENTRY_LOAD", 0.25)))   // (four entries per list and line)
-                               : std::min(7.0, std::max(0.02, env_double("TBK_ENTRY_LOAD", 0.5)));  // (tests crowd the lines: 8 slots per list)
+        const double el = wide ? std::min(3.5, std::max(0.02, o.wentry_load > 0 ? o.wentry_load : 0.25))   // (four entries per list and line)
+                               : std::min(7.0, std::max(0.02, o.entry_load > 0 ? o.entry_load : 0.5));  // (tests crowd the lines: 8 slots per list)
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
         double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);
@@ -1294,7 +1367,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         for (int attempt = 0; attempt < 6 && !built; attempt++) {
             uint64_t nb = (uint64_t)want + 16;
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) nb = std::min<uint64_t>(nb, (uint64_t)(0.6 * (double)total_b / 128.0)); else (void)hipGetLastError();
+            if (budget) nb = std::min<uint64_t>(nb, budget / 128);
+            else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) nb = std::min<uint64_t>(nb, (uint64_t)(0.6 * (double)total_b / 128.0)); else (void)hipGetLastError();
             if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;  // (bits 30 and 31 of a bucket index are flags in the probe's queues)
             c->free_pair();
             const int brc = build_entry_table(c, a, b, (uint32_t)nb);
@@ -1314,7 +1388,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         }
         if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         const double ratio = (double)(c->distinct_a + c->distinct_b) / (double)std::max<uint64_t>(1, c->entries_a + c->entries_b);
-        if (!forced && ratio < env_double("TBK_ENTRY_MIN_RATIO", 1.5)) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
+        if (!forced && ratio < o.entry_min_ratio) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
     // Short keys (tbk_common.h): lists whose keys do not merge into entries (BASELINE's uniform k-mers) in 4 bytes a key
@@ -1323,15 +1397,15 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // keys behind a front).  Built first where k and the table's size allow (k = 21: any table of 65536 lines or more,
     // k = 25: 2 GB or more); lists that cluster (more than TBK_BEHIND_FRONT of the keys behind a front) go on to the key
     // layout's test and from there to entries, as before.  TBK_SHORT=0: never, 1: whatever the lists look like.
-    const double short_pin = env_double("TBK_SHORT", -1);
+    const double short_pin = o.short_keys;
     double short_behind = -1;  // the fraction of the keys a short-key build found behind a front (-1: none was built)
     auto try_short_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
-        if (!forced && getenv("TBK_TABLE_LOAD")) return false;  // (the key layouts' load is pinned: the key layouts are meant)
+        if (!forced && o.table_load > 0) return false;  // (the key layouts' load is pinned: the key layouts are meant)
         TbkMz z = span_for(true);  // (the front layout's span: as long as k leaves room for, up to 8 m-mers)
         if (z.w < 2 || z.t <= 0 || z.m > 16) return false;
         if (span3_on) z = tbk_mz_span3(z);
-        const double per_line = std::min(24.0, std::max(0.1, env_double("TBK_SHORT_LOAD", 2.3)));
+        const double per_line = std::min(24.0, std::max(0.1, o.short_load > 0 ? o.short_load : 2.3));
         uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
         const uint32_t min_nb = tbk_short_min_buckets(c->k, z);
         if (!min_nb) return false;
@@ -1340,7 +1414,8 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         TbkShortGeom g;
         if (!tbk_short_geom(c->k, z, (uint32_t)nb, &g)) return false;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { if ((double)nb * 128.0 > 0.6 * (double)total_b) return false; } else (void)hipGetLastError();
+        if (budget) { if ((double)nb * 128.0 > (double)budget) return false; }
+        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { if ((double)nb * 128.0 > 0.6 * (double)total_b) return false; } else (void)hipGetLastError();
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
         c->mz = z;
@@ -1358,7 +1433,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         if (built) short_behind = (double)c->behind_front / n_keys;
-        if (built && !forced && short_behind > env_double("TBK_BEHIND_FRONT", 0.05)) built = false;  // the lists cluster
+        if (built && !forced && short_behind > o.behind_front) built = false;  // the lists cluster
         if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->over_mask = 0; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
@@ -1381,7 +1456,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     // the keys behind an 8-slot front; haplotype-shaped lists: 16 %, uniform ones 1.5 %) skip the key layout's test -
     // building a front-first key table of clustered lists only to measure them takes 2 s at 2 x 3e8 keys, ten times a
     // build of entries - and go to entries at once; lists that do not merge come back here.
-    if (short_behind > env_double("TBK_PLAINLY_CLUSTERED", 0.12) && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
+    if (short_behind > o.plainly_clustered && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
         c->layout_builds++;
         lap("(kept)", true);
         c->own_pair();
@@ -1402,13 +1477,13 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
         // lists' lines bound the distinct keys from above, so the test below would fail for certain)
         const bool testing = front && front_pin < 0;
         bool gave_up = false;
-        rc = build_pair_table(c, a, b, 0.08, &past, testing ? (uint64_t)(env_double("TBK_CLUSTERED", 0.003) * (double)(a->num_lines + b->num_lines)) + 1 : 0, &gave_up,
-                              testing ? (uint64_t)(env_double("TBK_BEHIND_FRONT", 0.05) * (double)(a->num_lines + b->num_lines)) + 1 : 0);
+        rc = build_pair_table(c, a, b, 0.08, &past, testing ? (uint64_t)(o.clustered * (double)(a->num_lines + b->num_lines)) + 1 : 0, &gave_up,
+                              testing ? (uint64_t)(o.behind_front * (double)(a->num_lines + b->num_lines)) + 1 : 0);
         lap(gave_up ? "key layout, front (given up after hapA's list)" : front ? "key layout, front" : "key layout, whole lines", false);
         if (rc) { c->free_pair(); delete c; return rc; }
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
         const double clustered = (double)past / n_keys, behind = (double)c->behind_front / n_keys;
-        if (!gave_up && (!front || front_pin > 0 || (clustered <= env_double("TBK_CLUSTERED", 0.003) && behind <= env_double("TBK_BEHIND_FRONT", 0.05)))) break;
+        if (!gave_up && (!front || front_pin > 0 || (clustered <= o.clustered && behind <= o.behind_front))) break;
         // Clustered lists.  Lists shaped like real find-unique-kmers output cluster because they ARE runs of overlapping
         // k-mers: the entry layout stores a run once (tbk_common.h), which brings them back to a front - two slots per
         // list, asked for by two lanes - in a table a quarter of the size.  Kept when the lists really merge (at least 1.5
@@ -1433,6 +1508,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     tbk_classifier *c = new tbk_classifier();
     c->device = device;
     c->k = src->k;
+    c->opt = src->opt;
     c->n_buckets = src->n_buckets;
     c->distinct_a = src->distinct_a; c->distinct_b = src->distinct_b; c->shared = src->shared;
     c->mz = src->mz;
@@ -1447,7 +1523,7 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     // TBK_FORCE_REPLICA=1: a ring on the device that holds the table gets a full replica of its own all the same,
     // made by the very calls a second GPU's replica is made by (peer query, hipMemcpyPeer) - how a one-GPU box
     // executes and checks the replica path of an 8-GPU node (tests/test_gpu_multi.py).
-    const bool force_replica = env_double("TBK_FORCE_REPLICA", 0) != 0;
+    const bool force_replica = src->opt.force_replica != 0;
     if (device == src->device && src->pair_owner && !force_replica) {
         // another stream ring on the device that holds the table already: the table is read-only, so it is shared
         c->d_pair = src->d_pair;
@@ -1475,13 +1551,18 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
         }
         c->own_pair();
     }
-    rc = classifier_streams(c, env_double("TBK_RING_STREAMS", 0) != 0 ? nullptr : src);  // (TBK_RING_STREAMS=1: streams of its own, the measurement above)
+    rc = classifier_streams(c, src->opt.ring_streams != 0 ? nullptr : src);  // (TBK_RING_STREAMS=1: streams of its own, the measurement above)
     if (rc) { tbk_classifier_destroy(c); return rc; }
     *out = c;
     return TBK_OK;
 }
 
 extern "C" int tbk_classifier_create_multi(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_classifier **out) {
+    return tbk_classifier_create_multi_opts(a, b, devices, n_devices, nullptr, out);
+}
+
+extern "C" int tbk_classifier_create_multi_opts(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, const tbk_options *options,
+                                                tbk_classifier **out) {
     if (!out || !devices || n_devices < 1) return fail(TBK_ERR_INVALID, "devices/out is NULL or n_devices < 1");
     for (int i = 0; i < n_devices; i++) out[i] = nullptr;
     int n_visible = 0;
@@ -1491,7 +1572,7 @@ extern "C" int tbk_classifier_create_multi(const tbk_table *a, const tbk_table *
     // hash the two lists once, on the device that holds them; every other entry gets a copy of the
     // finished table (identical bytes, hence identical lookups)
     tbk_classifier *first = nullptr;
-    int rc = tbk_classifier_create(a, b, &first);
+    int rc = tbk_classifier_create_opts(a, b, options, &first);
     if (rc) return rc;
     bool placed = false;
     for (int i = 0; i < n_devices && !rc; i++) {
@@ -1697,13 +1778,13 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         c->timed_launches++;
         HIP_TRY(hipEventRecord(ev[0], c->compute));
     }
-    HIP_TRY(tbk_launch_probe_index(d_offsets, n_reads, total, d_counts, c->d_pass_read, c->cap_passes, tbk_probe_has_two_read_kernel(c->mz), c->compute));
+    HIP_TRY(tbk_launch_probe_index(d_offsets, n_reads, total, d_counts, c->d_pass_read, c->cap_passes, c->opt.two_read_kernel != 0 && tbk_probe_has_two_read_kernel(c->mz), c->compute));
     if (ev) HIP_TRY(hipEventRecord(ev[1], c->compute));
     for (int j = 0; j < n_slices; j++) {
         if (slices[j].arrived) HIP_TRY(hipStreamWaitEvent(c->compute, slices[j].arrived, 0));
         if (ev) HIP_TRY(hipEventRecord(ev[2 + 3 * j], c->compute));  // (behind the wait: the slice's own time starts when its bases are there)
         HIP_TRY(tbk_launch_probe_range(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes,
-                                       slices[j].pass_lo, slices[j].pass_hi, c->max_blocks, ev ? ev[3 + 3 * j] : nullptr, c->compute));
+                                       slices[j].pass_lo, slices[j].pass_hi, c->max_blocks, c->opt.two_read_kernel != 0, ev ? ev[3 + 3 * j] : nullptr, c->compute));
         if (ev) HIP_TRY(hipEventRecord(ev[4 + 3 * j], c->compute));
     }
     c->last_passes = passes;
@@ -1920,7 +2001,7 @@ static int submit_host(tbk_classifier *c, const uint8_t *bases, const uint32_t *
         // Slices pay where nothing else keeps the device busy (an empty ring: the first batch of a run); behind a
         // batch that is still in flight one copy and one pair of kernels is best (every kernel launch ends in a
         // partly filled device: eight slices per batch measured 4 % slower in the steady state).
-        const bool zero_copy = packed && env_double("TBK_ZERO_COPY", 0) != 0 && is_pinned(codes);
+        const bool zero_copy = packed && c->opt.zero_copy != 0 && is_pinned(codes);
         const bool alone = c->streams->in_flight.load() == 0;  // (over all rings of the device)
         const int n_slices = alone ? (int)std::max<uint64_t>(1, std::min<uint64_t>(8, total / c->slice_bases)) : 1;
         ProbeSlice slices[8];

@@ -2109,10 +2109,8 @@ static void fill_args(ProbeArgs &p, const uint8_t *d_bases, const uint32_t *d_co
 
 // use_two != 0: passes that touch exactly two reads get a list of their own (the two-read kernel's; built for the
 // mod-sampling variants - tbk_probe_has_two_read_kernel)
-extern "C" int tbk_probe_has_two_read_kernel(TbkMz mz) {
-    static const bool off = getenv("TBK_TWO_READ") && *getenv("TBK_TWO_READ") == '0';  // (0: two-read passes go to the multi-read kernel, as before round 3)
-    return !off && mz.w >= 2 && mz.t > 0;
-}
+// (tbk_options.two_read_kernel = 0: two-read passes go to the multi-read kernel, as before round 3)
+extern "C" int tbk_probe_has_two_read_kernel(TbkMz mz) { return mz.w >= 2 && mz.t > 0; }
 
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t n_reads, uint64_t total, int32_t *d_counts, uint32_t *d_scratch,
                                              uint64_t pass_cap, int use_two, hipStream_t stream) {
@@ -2131,7 +2129,7 @@ extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t
 
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
                                              uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch,
-                                             uint64_t pass_cap, uint64_t pass_lo, uint64_t pass_hi, int max_blocks, hipEvent_t between, hipStream_t stream) {
+                                             uint64_t pass_cap, uint64_t pass_lo, uint64_t pass_hi, int max_blocks, int use_two, hipEvent_t between, hipStream_t stream) {
     if (total == 0 || n_reads == 0 || pass_hi <= pass_lo) return hipSuccess;
     ProbeArgs p;
     fill_args(p, d_bases, d_codes, d_bad16, d_offsets, n_reads, total, t, k, d_counts, d_scratch, pass_cap);
@@ -2158,7 +2156,7 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
         if (!(wide ? tbk_wentry_geom(k, t.mz, &g) : tbk_entry_geom(k, t.mz, &g)) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
     }
     // the two-read kernel: one block per possible list entry (fewer two-read passes than reads, and than passes)
-    const uint64_t blocks_two = tbk_probe_has_two_read_kernel(t.mz) ? std::min<uint64_t>(n_reads > 1 ? n_reads - 1 : 0, p.n_passes) : 0;  // (the list is the whole batch's: every launch walks all of it)
+    const uint64_t blocks_two = use_two && tbk_probe_has_two_read_kernel(t.mz) ? std::min<uint64_t>(n_reads > 1 ? n_reads - 1 : 0, p.n_passes) : 0;  // (the list is the whole batch's: every launch walks all of it)
     const dim3 grid_two((unsigned)std::max<uint64_t>(1, blocks_two));
     hipError_t e = hipSuccess;
     for (int which = 2; which >= 0; which--) {  // 2: multi-read passes, 1: two-read passes, 0: single-read passes (timed by itself: `between`)

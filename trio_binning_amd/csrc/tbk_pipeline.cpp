@@ -162,11 +162,15 @@ static void feeder_loop(tbk_pipeline *p, int slot) {
 }
 
 extern "C" int tbk_pipeline_create(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, tbk_pipeline **out) {
+    return tbk_pipeline_create_opts(a, b, devices, n_devices, nullptr, out);
+}
+
+extern "C" int tbk_pipeline_create_opts(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, const tbk_options *options, tbk_pipeline **out) {
     if (!out) return pfail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!devices || n_devices < 1 || n_devices > 64) return pfail(TBK_ERR_INVALID, "devices is NULL or n_devices outside 1..64");
     std::vector<tbk_classifier *> cls((size_t)n_devices, nullptr);
-    int rc = tbk_classifier_create_multi(a, b, devices, n_devices, cls.data());
+    int rc = tbk_classifier_create_multi_opts(a, b, devices, n_devices, options, cls.data());
     if (rc) return rc;
     tbk_pipeline *p = new tbk_pipeline();
     p->cls = cls;

@@ -184,6 +184,164 @@ tbk_synth_hap_reads_kernel(uint64_t seed, uint64_t genome_len, uint32_t snp24, u
 }
 
 // ---------------------------------------------------------------------------------------
+// reads of any lengths (BASELINE configs[4]: log-normal lengths, N50 ~ 100 kb)
+// ---------------------------------------------------------------------------------------
+// The read whose bases hold stream position pos: largest r with offsets[r] <= pos (offsets[n_reads] = total > pos).
+__device__ __forceinline__ uint64_t tbk_synth_find_read(const uint64_t *offsets, uint64_t n_reads, uint64_t pos) {
+    uint64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (offsets[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Planting into reads of any lengths: one thread per read walks the read's slots of `slot_len` bases (15 000 / 33: the
+// density of tbk_synth_plant_kernel's 30 + 3 plants per 15 kb read); slot j of an origin read carries a k-mer of the
+// read's own list, every 11th one of the other list; an origin-less read plants in every 8th slot, lists alternating.
+__global__ void __launch_bounds__(256)
+tbk_synth_plant_ragged_kernel(uint64_t read_seed, uint64_t first_read, uint64_t n_reads, const uint64_t *__restrict__ offsets,
+                              uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k, uint32_t slot_len, uint8_t *__restrict__ bases) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || slot_len < (uint32_t)k) return;
+    const uint64_t start = offsets[r], len = offsets[r + 1] - start;
+    const uint64_t rr = tbk_splitmix(read_seed ^ ((first_read + r) * 0xA0761D6478BD642Full));
+    const uint32_t u = (uint32_t)(rr % 100u);
+    const int origin = u < 45 ? 0 : (u < 90 ? 1 : 2);  // 0=A 1=B 2=none
+    for (uint64_t j = 0; (j + 1) * slot_len <= len; j++) {
+        int which;
+        if (origin == 2) {
+            if (j % 8u) continue;
+            which = (int)((j / 8u) & 1u);
+        } else {
+            which = j % 11u == 10u ? 1 - origin : origin;
+        }
+        const uint64_t n_list = which == 0 ? n_a : n_b;
+        if (n_list == 0) continue;
+        const uint64_t pr = tbk_splitmix(rr ^ ((j + 1) * 0xE7037ED1A0B428DBull));
+        uint64_t key = tbk_synth_key(key_seed, (which == 0 ? 0 : n_a) + (pr >> 8) % n_list, k);
+        if (pr & 1) key = tbk_revcomp_packed(key, k);
+        uint8_t *dst = bases + start + j * slot_len + (uint32_t)((pr >> 40) % (slot_len - (uint32_t)k + 1u));
+        for (int i = 0; i < k; i++) dst[i] = (uint8_t)((0x54474341u >> (8 * ((uint32_t)(key >> (2 * i)) & 3u))) & 0xFFu);
+    }
+}
+
+// Haplotype reads of any lengths: read r comes from haplotype (first_read + r) & 1, a hashed start and strand (as
+// tbk_synth_hap_reads_kernel).  One thread writes 16 bases; it finds the read of its first base by bisection and steps on
+// from there.
+__global__ void __launch_bounds__(256)
+tbk_synth_hap_reads_ragged_kernel(uint64_t seed, uint64_t genome_len, uint32_t snp24, uint64_t read_seed, uint64_t first_read,
+                                  uint64_t n_reads, const uint64_t *__restrict__ offsets, uint32_t err24, uint8_t *__restrict__ bases) {
+    const uint64_t total = offsets[n_reads];
+    const uint64_t n_chunks = (total + 15) / 16;
+    uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; c < n_chunks; c += stride) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        uint64_t r = tbk_synth_find_read(offsets, n_reads, c * 16 < total ? c * 16 : total - 1);
+        uint64_t r_start = offsets[r], r_end = offsets[r + 1];
+        for (int j = 0; j < 16; j++) {
+            const uint64_t pos = c * 16 + (uint64_t)j;
+            uint32_t code = 0;
+            if (pos < total) {
+                while (pos >= r_end) { r++; r_start = r_end; r_end = offsets[r + 1]; }  // (empty reads are stepped over)
+                const uint64_t len = r_end - r_start, i = pos - r_start;
+                const uint64_t rr = tbk_splitmix(read_seed ^ ((first_read + r) * 0xA0761D6478BD642Full));
+                const uint64_t start = (rr >> 1) % (genome_len - len + 1);
+                const bool rev = rr & 1ull;
+                const uint64_t p = rev ? start + len - 1 - i : start + i;
+                uint32_t a, b;
+                tbk_hap_bases(seed, p, snp24, a, b);
+                code = ((first_read + r) & 1ull) ? b : a;
+                if (rev) code = 3u - code;
+                const uint64_t e = tbk_splitmix(read_seed ^ 0x5851F42D4C957F2Dull ^ (((first_read + r) * 0x9E3779B97F4A7C15ull + i) * 0xD6E8FEB86659FD93ull));
+                if (((uint32_t)e & 0xFFFFFFu) < err24) code = (code + 1u + (uint32_t)((e >> 32) % 3u)) & 3u;
+            }
+            w[j >> 2] |= ((0x54474341u >> (8 * code)) & 0xFFu) << (8 * (j & 3));
+        }
+        reinterpret_cast<uint4 *>(bases)[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// full-membership sweep: a list's own keys laid out as reads (tests/test_gpu_scale.py, bench.py --sweep)
+// ---------------------------------------------------------------------------------------
+// Key i of the list becomes k bases of a read - as it stands when i is even, reverse-complemented when odd (a lookup
+// takes min(fwd, rc), c/kmers.c:251-255: both spellings must find the key).  per_read = 1: every key is a read of k bases
+// (one window: the multi-read passes); per_read = P > 1: P keys to a read with an 'N' between neighbours (windows across
+// two keys hold the N and score nothing: a read counts exactly its member keys - the single-read passes).
+__global__ void __launch_bounds__(256)
+tbk_synth_keys_as_reads_kernel(const uint64_t *__restrict__ keys, uint64_t first, uint64_t n, int k, uint32_t per_read, uint8_t *__restrict__ bases,
+                               uint64_t *__restrict__ offsets, uint64_t n_reads) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t read_len = (uint64_t)per_read * (uint64_t)k + per_read - 1;
+    if (i <= n_reads) offsets[i] = i < n_reads ? i * read_len : (n_reads - 1) * read_len + (n - (n_reads - 1) * per_read) * ((uint64_t)k + 1) - 1;
+    if (i >= n) return;
+    uint64_t key = keys[i];
+    if ((first + i) & 1ull) key = tbk_revcomp_packed(key, k);
+    const uint64_t r = i / per_read, j = i % per_read;
+    uint8_t *dst = bases + r * read_len + j * ((uint64_t)k + 1);
+    for (int b = 0; b < k; b++) dst[b] = (uint8_t)((0x54474341u >> (8 * ((uint32_t)(key >> (2 * b)) & 3u))) & 0xFFu);
+    if (j + 1 < per_read && i + 1 < n) dst[k] = (uint8_t)'N';
+}
+
+// Near misses: key i with ONE base substituted (position and base hashed from seed and i), canonicalised - a non-member
+// that shares its m-mer, position and most flank bits with a member: what a compressed slot could confuse it with.
+__global__ void __launch_bounds__(256)
+tbk_synth_mutate_keys_kernel(const uint64_t *__restrict__ keys, uint64_t first, uint64_t n, int k, uint64_t seed, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = tbk_splitmix(seed ^ ((first + i) * 0xD6E8FEB86659FD93ull));
+    const uint32_t p = (uint32_t)(h % (uint64_t)k);
+    const uint64_t delta = 1ull + (h >> 32) % 3ull;
+    uint64_t key = keys[i];
+    const uint64_t base = (key >> (2 * p)) & 3ull;
+    key = (key & ~(3ull << (2 * p))) | (((base + delta) & 3ull) << (2 * p));
+    const uint64_t rc = tbk_revcomp_packed(key, k);
+    out[i] = rc < key ? rc : key;
+}
+
+// what a read spelling key i must count: 1 = (1, 0) when hapA's list holds its canonical form, else 2 = (0, 1) when
+// hapB's does, else 0 (in_a / in_b: tbk_table_contains_device of the canonical keys)
+__global__ void __launch_bounds__(256)
+tbk_sweep_expect_kernel(const uint8_t *__restrict__ in_a, const uint8_t *__restrict__ in_b, uint64_t n, uint8_t *__restrict__ expect) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) expect[i] = in_a[i] ? 1 : in_b[i] ? 2 : 0;
+}
+
+__global__ void __launch_bounds__(256)
+tbk_canonical_keys_kernel(const uint64_t *__restrict__ keys, uint64_t n, int k, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i], rc = tbk_revcomp_packed(key, k);
+    out[i] = rc < key ? rc : key;
+}
+
+// counts[r] against what read r must count: its n_k keys (per_read, fewer in the last read) times (1, 0) / (0, 1) / (0, 0)
+// for expect = 1 / 2 / 0, or per key from d_expect (per_read = 1).  out: [0] sum of hapA counts, [1] of hapB counts,
+// [2] reads that differ, [3] the first of them (first + r; all ones: none).
+__global__ void __launch_bounds__(256)
+tbk_counts_check_kernel(const int32_t *__restrict__ counts, uint64_t first, uint64_t n_reads, uint32_t per_read, uint64_t n_keys, int expect,
+                        const uint8_t *__restrict__ d_expect, unsigned long long *__restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long a = 0, b = 0, bad = 0;
+    if (r < n_reads) {
+        const uint64_t nk = r + 1 < n_reads ? per_read : n_keys - r * per_read;
+        const int e = d_expect ? (int)d_expect[r] : expect;
+        a = (unsigned long long)counts[2 * r]; b = (unsigned long long)counts[2 * r + 1];
+        bad = (a != (e == 1 ? nk : 0) || b != (e == 2 ? nk : 0)) ? 1 : 0;
+        if (bad) atomicMin(&out[3], (unsigned long long)(first + r));
+    }
+    // wave sums, one atomic per wave and counter
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); bad += __shfl_down(bad, off); }
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&out[0], a);
+        if (b) atomicAdd(&out[1], b);
+        if (bad) atomicAdd(&out[2], bad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // calibration: random line gather and streaming read
 // ---------------------------------------------------------------------------------------
 // LPL lanes share one line (16 B per lane when LPL > 1; the whole line per lane when
@@ -323,6 +481,57 @@ extern "C" hipError_t tbk_launch_synth_hap_reads(uint64_t seed, uint64_t genome_
                        first_read, n_reads, read_len, err24, d_bases);
     hipLaunchKernelGGL(tbk_synth_offsets_kernel, dim3((unsigned)((n_reads + 256) / 256)), dim3(256), 0, s,
                        n_reads, read_len, d_offsets);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_synth_reads_ragged(uint64_t read_seed, uint64_t first_read, uint64_t n_reads, const uint64_t *d_offsets, uint64_t total,
+                                                    uint64_t key_seed, uint64_t n_a, uint64_t n_b, int k, uint32_t slot_len, uint8_t *d_bases, hipStream_t s) {
+    if (!n_reads || !total) return hipSuccess;
+    const uint64_t n_chunks = (total + 15) / 16;
+    // (the background is a function of the absolute chunk index: batches of one run start at distinct indices)
+    hipLaunchKernelGGL(tbk_synth_background_kernel, dim3(grid_for(n_chunks)), dim3(256), 0, s, read_seed, first_read * 1024, n_chunks, (uint4 *)d_bases);
+    hipLaunchKernelGGL(tbk_synth_plant_ragged_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, read_seed, first_read, n_reads, d_offsets,
+                       key_seed, n_a, n_b, k, slot_len, d_bases);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_synth_hap_reads_ragged(uint64_t seed, uint64_t genome_len, uint32_t snp24, uint64_t read_seed, uint64_t first_read,
+                                                        uint64_t n_reads, const uint64_t *d_offsets, uint64_t total, uint32_t err24, uint8_t *d_bases, hipStream_t s) {
+    if (!n_reads || !total) return hipSuccess;
+    hipLaunchKernelGGL(tbk_synth_hap_reads_ragged_kernel, dim3(grid_for((total + 15) / 16)), dim3(256), 0, s, seed, genome_len, snp24, read_seed, first_read,
+                       n_reads, d_offsets, err24, d_bases);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_keys_as_reads(const uint64_t *d_keys, uint64_t first, uint64_t n, int k, uint32_t per_read, uint8_t *d_bases, uint64_t *d_offsets,
+                                               uint64_t n_reads, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tbk_synth_keys_as_reads_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, d_keys, first, n, k, per_read, d_bases, d_offsets, n_reads);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_mutate_keys(const uint64_t *d_keys, uint64_t first, uint64_t n, int k, uint64_t seed, uint64_t *d_out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tbk_synth_mutate_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, first, n, k, seed, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_canonical_keys(const uint64_t *d_keys, uint64_t n, int k, uint64_t *d_out, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tbk_canonical_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_keys, n, k, d_out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_sweep_expect(const uint8_t *d_in_a, const uint8_t *d_in_b, uint64_t n, uint8_t *d_expect, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tbk_sweep_expect_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_in_a, d_in_b, n, d_expect);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t tbk_launch_counts_check(const int32_t *d_counts, uint64_t first, uint64_t n_reads, uint32_t per_read, uint64_t n_keys, int expect,
+                                              const uint8_t *d_expect, unsigned long long *d_out, hipStream_t s) {
+    if (!n_reads) return hipSuccess;
+    hipLaunchKernelGGL(tbk_counts_check_kernel, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, s, d_counts, first, n_reads, per_read, n_keys, expect, d_expect, d_out);
     return hipGetLastError();
 }
 

@@ -123,6 +123,11 @@ class HashSet:
         return lib.tbk_table_bytes(self._h)
 
     @property
+    def device_keys(self) -> int:
+        """Device pointer of the list's packed keys (num_kmers of them, read-only)."""
+        return lib.tbk_table_device_keys(self._h)
+
+    @property
     def contents(self) -> _Contents:
         return _Contents(self)
 
@@ -288,6 +293,62 @@ def pack_bases(bases: np.ndarray, offsets: np.ndarray, pinned: bool = True) -> P
     return PackedBatch(codes[:n_chunks], exc_chunk, exc_mask, offsets)
 
 
+class Options:
+    """How a classifier is built (include/tbk.h: ``tbk_options``).  The reference configures itself through argparse alone
+    (classify_by_kmers.py:14-54); this library's choices - which layout the paired table takes, the sampling rule, loads,
+    the memory budget - are arguments too: ``Options(entries=1, entry_load=0.64)``, ``Options.layout("short_keys")``.
+    No option changes a result.  ``Options.from_env()`` overlays the ``TBK_*`` variables of the process environment - the
+    command-line tools' fallback, and what ``Classifier`` / ``MultiClassifier`` do when no options are given; the library's
+    constructors themselves never read the environment, so two classifiers of one process can be built differently at the
+    same time."""
+
+    LAYOUTS = {
+        "auto": {},
+        "keys": {"short_keys": 0, "entries": 0},
+        "keys_front": {"short_keys": 0, "entries": 0, "front": 1},
+        "keys_whole_lines": {"short_keys": 0, "entries": 0, "front": 0},
+        "entries": {"entries": 1, "wide_entries": 0},
+        "wide_entries": {"entries": 1, "wide_entries": 1},
+        "short_keys": {"short_keys": 1},
+    }
+
+    def __init__(self, **fields):
+        self.c = _lib.tbk_options()
+        lib.tbk_options_init(C.byref(self.c))
+        self.update(**fields)
+
+    def update(self, **fields) -> "Options":
+        names = {f[0] for f in _lib.tbk_options._fields_} - {"size"}
+        for name, value in fields.items():
+            if name not in names:
+                raise TypeError(f"tbk_options has no field {name!r}")
+            setattr(self.c, name, value)
+        return self
+
+    @classmethod
+    def layout(cls, name: str, **fields) -> "Options":
+        return cls(**dict(cls.LAYOUTS[name], **fields))
+
+    @classmethod
+    def from_env(cls, **fields) -> "Options":
+        self = cls()
+        check(lib.tbk_options_from_env(C.byref(self.c)))
+        return self.update(**fields)
+
+    def __repr__(self):
+        dflt = _lib.tbk_options()
+        lib.tbk_options_init(C.byref(dflt))
+        diff = {f[0]: getattr(self.c, f[0]) for f in _lib.tbk_options._fields_ if getattr(self.c, f[0]) != getattr(dflt, f[0])}
+        return f"Options({', '.join(f'{k}={v}' for k, v in diff.items())})"
+
+
+def _options_ptr(options):
+    """ctypes pointer for the *_opts calls: the given Options, or - none given - the TBK_* environment's (the fallback)"""
+    if options is None:
+        options = Options.from_env()
+    return C.byref(options.c)
+
+
 class Classifier:
     """The batch hot path: per-read (hapA, hapB) k-mer hit counts for many reads at once.
 
@@ -297,10 +358,13 @@ class Classifier:
     current one.
     """
 
-    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, _handle: Optional[int] = None):
+    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, _handle: Optional[int] = None, options: Optional[Options] = None):
         if _handle is None:
             h = C.c_void_p()
-            check(lib.tbk_classifier_create(kmers_hap_a._h, kmers_hap_b._h, C.byref(h)))
+            if _lib.HAS_OPTIONS:
+                check(lib.tbk_classifier_create_opts(kmers_hap_a._h, kmers_hap_b._h, _options_ptr(options), C.byref(h)))
+            else:
+                check(lib.tbk_classifier_create(kmers_hap_a._h, kmers_hap_b._h, C.byref(h)))
         else:  # one of tbk_classifier_create_multi's classifiers
             h = C.c_void_p(_handle)
         self._h = h
@@ -471,13 +535,16 @@ class MultiClassifier:
     and not yet waited for.  Nothing per batch happens in Python.
     """
 
-    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, devices: Optional[Sequence[int]] = None):
+    def __init__(self, kmers_hap_a: HashSet, kmers_hap_b: HashSet, devices: Optional[Sequence[int]] = None, options: Optional[Options] = None):
         devices = list(visible_devices() if devices is None else devices)
         if not devices:
             raise _lib.TbkError(_lib.TBK_ERR_NO_DEVICE, "no HIP device visible; there is no CPU fallback")
         arr = (C.c_int * len(devices))(*devices)
         h = C.c_void_p()
-        check(lib.tbk_pipeline_create(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), C.byref(h)))
+        if _lib.HAS_OPTIONS:
+            check(lib.tbk_pipeline_create_opts(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), _options_ptr(options), C.byref(h)))
+        else:
+            check(lib.tbk_pipeline_create(kmers_hap_a._h, kmers_hap_b._h, arr, len(devices), C.byref(h)))
         self._h = h
         self._a, self._b = kmers_hap_a, kmers_hap_b  # keep the tables alive
         self._keep = {}
