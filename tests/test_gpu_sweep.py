@@ -4,21 +4,20 @@ every layout of the paired table: every list key must answer for its list, hapB 
 sweep itself must notice a table that answers wrongly (the controls at the end).  tests/test_gpu_scale.py runs the same
 sweep at BASELINE's table sizes."""
 import ctypes as C
-import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-LAYOUTS = {
-    "key_front": {"TBK_ENTRY": "0", "TBK_SHORT": "0", "TBK_FRONT": "1"},
-    "key_whole_lines": {"TBK_ENTRY": "0", "TBK_SHORT": "0", "TBK_FRONT": "0"},
-    "entries": {"TBK_ENTRY": "1"},
-    "entries_crowded": {"TBK_ENTRY": "1", "TBK_ENTRY_LOAD": "3.0"},
-    "short_keys": {"TBK_SHORT": "1"},
-    "short_keys_overflowing": {"TBK_SHORT": "1", "TBK_SHORT_LOAD": "12", "TBK_SHORT_LINE_CAP": "10"},
-    "wide_entries": {"TBK_ENTRY": "1", "TBK_ENTRY_WIDE": "1"},
+LAYOUTS = {  # (name of Options.layout, further tbk_options fields)
+    "key_front": ("keys_front", {}),
+    "key_whole_lines": ("keys_whole_lines", {}),
+    "entries": ("entries", {}),
+    "entries_crowded": ("entries", {"entry_load": 3.0}),
+    "short_keys": ("short_keys", {}),
+    "short_keys_overflowing": ("short_keys", {"short_load": 12.0, "short_line_cap": 10}),
+    "wide_entries": ("wide_entries", {}),
 }
 
 
@@ -62,29 +61,68 @@ def test_sweep_small(gpu, layout, kind):
     check(lib.tbk_memcpy_d2h(0, hb.ctypes.data, C.c_void_p(d_b), n_b * 8))
     check(lib.tbk_device_free(0, C.c_void_p(base)))
     hb = np.concatenate([hb, ha[:2000]])
-    env = LAYOUTS[layout]
-    old = {v: os.environ.get(v) for v in env}
-    os.environ.update(env)
-    try:
-        with kmers.HashSet.from_keys(ha, k) as a, kmers.HashSet.from_keys(hb, k) as b, kmers.Classifier(a, b) as cls:
-            st = cls.stats()
-            assert st["entry_layout"] == layout.startswith(("entries", "wide")) and st["short_keys"] == layout.startswith("short"), st
-            assert st["shared_keys"] >= 2000
-            rec = full_membership_sweep(cls, a, b, a.device_keys, b.device_keys, ha.size, hb.size, k, chunk=1 << 17)
-            assert rec["ok"], [r for r in rec["legs"] if not r["ok"]]
-            assert len(rec["legs"]) == 7 and rec["shared_keys"] == st["shared_keys"]
-            by = {r["leg"]: r for r in rec["legs"]}
-            assert by["members_hapA_k_base_reads"]["sum_a"] == ha.size and by["members_hapB_k_base_reads"]["sum_b"] == hb.size - st["shared_keys"]
-            # near misses of a clustered list are often members themselves (the neighbouring haplotype's k-mer): the standalone
-            # tables say which, and the paired table must agree - so the leg's sums are not all zero there
-            if kind == "haplotypes":
-                assert by["near_misses_of_hapA_keys"]["sum_a"] + by["near_misses_of_hapA_keys"]["sum_b"] > 0
-    finally:
-        for v, val in old.items():
-            if val is None:
-                os.environ.pop(v, None)
-            else:
-                os.environ[v] = val
+    name, fields = LAYOUTS[layout]
+    with kmers.HashSet.from_keys(ha, k) as a, kmers.HashSet.from_keys(hb, k) as b, kmers.Classifier(a, b, options=kmers.Options.layout(name, **fields)) as cls:
+        st = cls.stats()
+        assert st["entry_layout"] == layout.startswith(("entries", "wide")) and st["short_keys"] == layout.startswith("short"), st
+        assert st["wide_entries"] == (layout == "wide_entries") and (layout != "key_front" or st["front_layout"])
+        assert st["shared_keys"] >= 2000
+        rec = full_membership_sweep(cls, a, b, a.device_keys, b.device_keys, ha.size, hb.size, k, chunk=1 << 17)
+        assert rec["ok"], [r for r in rec["legs"] if not r["ok"]]
+        assert len(rec["legs"]) == 7 and rec["shared_keys"] == st["shared_keys"]
+        by = {r["leg"]: r for r in rec["legs"]}
+        assert by["members_hapA_k_base_reads"]["sum_a"] == ha.size and by["members_hapB_k_base_reads"]["sum_b"] == hb.size - st["shared_keys"]
+        # near misses of a clustered list are often members themselves (the neighbouring haplotype's k-mer): the standalone
+        # tables say which, and the paired table must agree - so the leg's sums are not all zero there
+        if kind == "haplotypes":
+            assert by["near_misses_of_hapA_keys"]["sum_a"] + by["near_misses_of_hapA_keys"]["sum_b"] > 0
+
+
+def test_two_classifiers_with_different_layouts_built_at_the_same_time(gpu):
+    """tbk_options instead of the environment: four threads build four classifiers over the same two lists at the same
+    time, each with its own pinned layout; every one gets the layout it asked for and answers like the others."""
+    import threading
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    k, n = 21, 200_000
+    keys = np.empty(2 * n, dtype=np.uint64)
+    check(lib.tbk_synth_keys_host(0x5EED0001, 0, 2 * n, k, keys.ctypes.data))
+    rng = np.random.default_rng(5)
+    reads = []
+    for i in range(64):
+        r = rng.integers(0, 4, int(rng.integers(30, 4000)))
+        key = int(keys[int(rng.integers(0, 2 * n))])
+        if r.size > 60:
+            r[10:10 + k] = [(key >> (2 * j)) & 3 for j in range(k)]
+        reads.append("".join("ACGT"[c] for c in r))
+    bases, offsets = kmers.pack_reads(reads)
+    wanted = ["keys_front", "keys_whole_lines", "entries", "short_keys"]
+    got, errors = {}, []
+    with kmers.HashSet.from_keys(keys[:n], k) as a, kmers.HashSet.from_keys(keys[n:], k) as b:
+        start = threading.Barrier(len(wanted))
+
+        def build(name):
+            try:
+                start.wait()
+                with kmers.Classifier(a, b, options=kmers.Options.layout(name, memory_budget_bytes=1 << 30)) as cls:
+                    got[name] = (cls.stats(), cls.classify_batch(bases, offsets))
+            except Exception as exc:  # noqa: BLE001
+                errors.append((name, exc))
+
+        threads = [threading.Thread(target=build, args=(name,)) for name in wanted]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    assert got["keys_front"][0]["front_layout"] and not got["keys_front"][0]["entry_layout"] and not got["keys_front"][0]["short_keys"]
+    assert not got["keys_whole_lines"][0]["front_layout"] and not got["keys_whole_lines"][0]["short_keys"]
+    assert got["entries"][0]["entry_layout"] and got["short_keys"][0]["short_keys"]
+    assert all(st["table_bytes"] <= 1 << 30 for st, _ in got.values())
+    first = got[wanted[0]][1]
+    assert first.sum() >= 50 and all(np.array_equal(c, first) for _, c in got.values())
 
 
 def test_sweep_notices_wrong_answers(gpu):

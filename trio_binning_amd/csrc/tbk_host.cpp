@@ -154,9 +154,13 @@ static tbk_options resolve_options(const tbk_options *in) {
 // Host threads worth starting: hardware threads, cut down to the CPU affinity mask and to the
 // cgroup CPU quota (a container may see 256 hardware threads and be allowed 16 CPUs' worth of
 // time; more runnable threads than that only adds throttling stalls).  TBK_HOST_THREADS overrides.
-extern "C" int tbk_host_threads(void) {
-    static int cached = 0;
-    if (cached) return cached;
+static long local_ranks() {
+    long ranks = (long)env_double("TBK_LOCAL_RANKS", 0);
+    if (ranks < 1) ranks = (long)env_double("LOCAL_WORLD_SIZE", 1);
+    return std::max<long>(1, ranks);
+}
+
+static long usable_cpus() {
     long n = (long)std::thread::hardware_concurrency();
     if (n < 1) n = 1;
     cpu_set_t set;
@@ -172,16 +176,31 @@ extern "C" int tbk_host_threads(void) {
         if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
     }
     if (quota > 0 && period > 0) n = std::min<long>(n, std::max<long>(1, (long)((quota + period - 1) / period)));
+    return std::max<long>(1, n);
+}
+
+extern "C" int tbk_host_threads(void) {
+    static int cached = 0;
+    if (cached) return cached;
+    long n = usable_cpus();
     // One process per GPU (the launcher's LOCAL_WORLD_SIZE ranks on this node; TBK_LOCAL_RANKS says the same by hand):
     // the ranks share the node's CPUs, so each takes its share - 8 ranks in a 16-CPU cgroup start 2 workers each,
-    // not 16 each.  (A single process driving several devices divides inside tbk_pipeline_create.)
-    long ranks = (long)env_double("TBK_LOCAL_RANKS", 0);
-    if (ranks < 1) ranks = (long)env_double("LOCAL_WORLD_SIZE", 1);
+    // not 16 each.  (A single process driving several devices divides inside tbk_pipeline_create: tbk_host_threads_per_feeder_.)
+    const long ranks = local_ranks();
     if (ranks > 1) n = std::max<long>(1, n / ranks);
     const double forced = env_double("TBK_HOST_THREADS", 0);
     if (forced >= 1) n = (long)forced;
     cached = (int)std::max<long>(1, n);
     return cached;
+}
+
+// The packing share of one feeder of a pipeline over n_devices rings: the CPUs are divided among whatever is more -
+// the node's ranks or this process's rings - once, not by both (a process that drives several devices from inside a
+// launcher's environment would otherwise get cpus / (ranks * devices)).
+extern "C" int tbk_host_threads_per_feeder_(int n_devices) {
+    const double forced = env_double("TBK_HOST_THREADS", 0);
+    if (forced >= 1) return (int)std::max<long>(1, (long)forced / std::max(1, n_devices));
+    return (int)std::max<long>(1, usable_cpus() / std::max<long>(local_ranks(), std::max(1, n_devices)));
 }
 
 // ---- NUMA placement ("pinned, NUMA-local buffers, one feeder thread per GPU") -------------------------

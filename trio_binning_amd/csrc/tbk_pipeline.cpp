@@ -84,6 +84,7 @@ struct tbk_pipeline {
 };
 
 extern "C" int tbk_numa_bind_to_device(int device, int *node_out, int *cpus_out);
+extern "C" int tbk_host_threads_per_feeder_(int n_devices);
 
 static int pfail(int code, const char *msg) {
     tbk_set_error_(code, msg);
@@ -177,7 +178,7 @@ extern "C" int tbk_pipeline_create_opts(const tbk_table *a, const tbk_table *b, 
     p->batches_by_slot.assign((size_t)n_devices, 0);
     p->numa_node.assign((size_t)n_devices, -1); p->numa_cpus.assign((size_t)n_devices, 0);
     // an ASCII batch is packed by its feeder with this share of the host threads
-    const int share = std::max(1, tbk_host_threads() / n_devices);
+    const int share = tbk_host_threads_per_feeder_(n_devices);
     for (int i = 0; i < n_devices; i++) {
         tbk_classifier *c = p->cls[(size_t)i];
         (void)tbk_classifier_set_pack_threads_(c, share);
