@@ -411,6 +411,65 @@ def kernel_fingerprint():
         return "source:" + h.hexdigest()
 
 
+def kernel_resources(stats):
+    """Registers, LDS and the waves per SIMD they allow, of the single-read probe kernel this table runs, read from the
+    gfx950 code object in build/tbk_kernels.o (the AMDGPU metadata note: what the loader allocates - rocprofv3's VGPR column
+    is not the allocation).  None when the object or the kernel is not there."""
+    import struct
+
+    try:
+        import msgpack
+
+        buf = open(os.path.join(ROOT, "trio_binning_amd", "csrc", "build", "tbk_kernels.o"), "rb").read()
+
+        def sections(b, base):
+            shoff, = struct.unpack_from("<Q", b, base + 0x28)
+            shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, base + 0x3A)
+            hdr = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, base + shoff + i * shentsize)
+            stro = base + hdr(shstrndx)[4]
+            return {b[stro + hdr(i)[0]:b.index(b"\0", stro + hdr(i)[0])].decode(): (base + hdr(i)[4], hdr(i)[5]) for i in range(shnum)}
+
+        off, size = sections(buf, 0)[".hip_fatbin"]
+        fb = buf[off:off + size]
+        n, = struct.unpack_from("<Q", fb, 24)
+        p, meta = 32, None
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", fb, p)
+            triple = fb[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and sz:
+                no, ns = sections(fb, o)[".note"]
+                q = no
+                while q + 12 <= no + ns:
+                    namesz, descsz, ntype = struct.unpack_from("<III", fb, q)
+                    q += 12
+                    name = fb[q:q + namesz].rstrip(b"\0")
+                    q += (namesz + 3) // 4 * 4
+                    if name == b"AMDGPU" and ntype == 32:
+                        meta = msgpack.unpackb(fb[q:q + descsz], raw=False, strict_map_key=False)
+                    q += (descsz + 3) // 4 * 4
+        w, m, t = stats["minimizer_w"], stats["minimizer_m"], stats["sampling_t"]
+        if stats.get("entry_layout") or stats.get("short_keys") or stats.get("full_keys"):
+            kind = 2 if stats.get("short_keys") else 3 if stats.get("full_keys") else 1 if stats.get("wide_entries") else 0
+            lw = 3 if t and t == m - 2 * w else 2
+            want = f"_Z22tbk_probe_entry_kernelILi{w}ELb0ELb0ELi{kind}ELi{lw}EEv9ProbeArgs"
+        else:
+            b = lambda x: "Lb1" if x else "Lb0"
+            want = f"_Z16tbk_probe_kernelILi{w}E{b(m > 16)}E{b(bool(t))}E{b(stats.get('front_layout'))}ELb0ELb0EEv9ProbeArgs"
+        for kern in meta["amdhsa.kernels"]:
+            if kern[".name"] == want:
+                vgpr = kern[".vgpr_count"] + kern.get(".agpr_count", 0)
+                lds = kern[".group_segment_fixed_size"]
+                by_regs = min(8, 512 // max(8, (vgpr + 7) // 8 * 8))
+                by_lds = (160 * 1024 // max(1, lds)) // 4 if lds else 8  # one-wave blocks: a CU's 160 KB of LDS over its four SIMDs
+                return {"kernel_symbol": want, "vgpr_count": vgpr, "sgpr_count": kern.get(".sgpr_count"), "lds_bytes_per_block": lds, "scratch_bytes_per_lane": kern.get(".private_segment_fixed_size"),
+                        "vgpr_spill_count": kern.get(".vgpr_spill_count"), "waves_per_simd": min(by_regs, by_lds, 8),
+                        "source": "AMDGPU metadata note of the gfx950 code object in trio_binning_amd/csrc/build/tbk_kernels.o"}
+        return None
+    except Exception:
+        return None
+
+
 def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement):
     k, n_list, L, R = args.k, args.kmers_per_list, args.read_len, args.reads_per_step
 
@@ -683,6 +742,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                     and bool(t.get("front_layout", False)) == bool(stats.get("front_layout"))
                     and bool(t.get("entry_layout", False)) == bool(stats.get("entry_layout"))
                     and bool(t.get("short_keys", False)) == bool(stats.get("short_keys"))
+                    and bool(t.get("full_keys", False)) == bool(stats.get("full_keys"))
                     and t.get("kernel") == "tbk_probe_kernel<single-read>")
             if same and t.get("kernel_sha256") != kernel_fingerprint():
                 # taken on other kernels than the ones in this tree: stale bytes are not reported
@@ -698,6 +758,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if traffic is None else int(traffic), "traffic_source": traffic_src,
         "kernel": ("tbk_probe_entry_kernel<W, MULTI=false, TWO=false>" if stats.get("entry_layout") else "tbk_probe_entry_kernel<W, MULTI=false, TWO=false, KIND=2: short keys>" if stats.get("short_keys")
+                   else "tbk_probe_entry_kernel<W, MULTI=false, TWO=false, KIND=3: full keys>" if stats.get("full_keys")
                    else "tbk_probe_kernel<..., MULTI=false, TWO=false>") + " (single-read passes)", "kernel_ms_avg": round(single_s * 1e3, 4), "launches": int(launches),
         "timed_in": "the timed region of `value` (HIP events on the compute stream)",
         "alg_bytes_per_launch": int(alg_bytes), "alg_bytes_per_window": round(b_alg, 3), "windows_per_launch": int(windows_single),
@@ -711,6 +772,7 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                         "frac": round(windows * b_alg / probe_s / 1e9 / HBM_PEAK_GBPS, 4) if probe_s > 0 else None},
         "kernel_only_gbases_per_s": round(bases_per_launch / probe_s / 1e9, 2) if probe_s > 0 else None,
     }
+    roofline["kernel_resources"] = kernel_resources(stats)
     if traffic is not None and single_s > 0:
         # where the kernel sits against what the memory system can actually deliver: PMC-measured
         # bytes per launch over this run's kernel time, and 128-byte lines per second against the
@@ -773,7 +835,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             "bucket_select": bucket_select, "lists": args.lists,
             "layout_builds": stats.get("layout_builds"), "keys_past_their_half": stats.get("keys_past_half"),
             "line_layout": (("entries (wide, 16 bytes)" if stats.get("wide_entries") else "entries") + ": a run of overlapping list k-mers stored once; 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("entry_layout")
-                            else "short keys: a list k-mer in 32 bits (what its bucket does not say already); 32 of a line's 128 bytes asked for per window, two lanes" if stats.get("short_keys")
+                            else "short keys: a list k-mer in 32 bits (what its bucket does not say already); 32 of a line's 128 bytes asked for per window (seven keys and the line's summary), two lanes" if stats.get("short_keys")
+                            else "full keys: 64-bit keys, sixteen slots to a line; 32 of a line's 128 bytes asked for per window (three keys and the line's summary), two lanes" if stats.get("full_keys")
                             else "front: 64 of a line's 128 bytes asked for per window" if stats.get("front_layout") else "whole lines"),
             "keys_behind_front": stats.get("keys_behind_front"),
             "entries": [stats.get("entries_a"), stats.get("entries_b")] if stats.get("entry_layout") else None,
@@ -800,9 +863,9 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     # ---- CPU baseline + read-for-read parity on a bounded sample (rank 0, every N) ---------------------
     if want_cpu:
         out["cpu_baseline"], cpu_par = cpu_baseline(args, np, lib, par_bases, par_offs, par_counts, h_keys, n_list, k, L, n_par)
+        out["parity"].update(cpu_par)
     if sweep_rec is not None:
         out["sweep"] = sweep_rec
-        out["parity"].update(cpu_par)
 
     pipe.close()
     hap_a.close()

@@ -176,6 +176,8 @@ typedef struct tbk_options {
     int32_t build_timing;     /* 1: every build of the paired table with its duration, on stderr */
     int32_t force_replica;    /* 1: a further ring on the table's own device gets a full replica (how one GPU runs the replica path) */
     int32_t ring_streams, copy_priority, h2d_streams, zero_copy;  /* experiments of EXPERIMENTS.md (0, 0, 1, 0) */
+    int32_t full_keys;        /* the full-key layout (csrc/tbk_common.h "full keys"): -1 the lists decide, 0 never, 1 pinned */
+    double full_load;         /* full keys per line of sixteen slots (2.0: 64 bytes of device memory per key) */
 } tbk_options;
 void tbk_options_init(tbk_options *o);
 int tbk_options_from_env(tbk_options *o);
@@ -241,7 +243,10 @@ int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_t *keys_beh
  * (tbk_classifier_stats' table_bytes counts it); entries_a/_b = words the lists' keys take.  Tried first where k (17 .. ~25,
  * m-mers of at most 16 bases) and the table's size allow; tbk_options.short_keys pins it, .short_load sets the keys per line
  * (default 2.3: 56 bytes of device memory per key; 2.6: 49).  Like the entry layouts it leaves out list lines that are not
- * canonical (no window ever asks for them, c/kmers.c:255): distinct_a/_b count the keys stored. */
+ * canonical (no window ever asks for them, c/kmers.c:255): distinct_a/_b count the keys stored.
+ * entry_layout = 4: FULL KEYS (csrc/tbk_common.h "full keys") - lists that do not merge and do not fit short keys (uniform 26- to
+ * 31-mers): 64-bit keys in the same line shape, three keys and the line's summary in the 32-byte front, twelve more behind it;
+ * entries_a/_b = slots the lists' keys take.  tbk_options.full_keys pins it, .full_load sets the keys per line (default 2.0). */
 int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b);
 /* Random 64-byte reads, a quad of lanes per line as the probe asks for a front, over this table where it lies
  * in HBM: lines per second (a diagnostic: the same table measures up to 15 % differently from one placement in
@@ -585,6 +590,13 @@ int tbk_calib_atomics(int device, uint64_t footprint_bytes, int run, int reps, d
 int tbk_calib_atomics64(int device, uint64_t footprint_bytes, int run, int reps, double *atomics_per_sec);
 /* Streaming read of the same buffer (the 6.3 TB/s figure on this box). */
 int tbk_calib_stream(int device, uint64_t footprint_bytes, int reps, double *bytes_per_sec);
+/* The same two ceilings in tuned shapes (round 5: a yardstick must not sit below what it measures).  tbk_calib_gather_pairs: the
+ * entry kernels' own request shape - one-wave blocks, `waves_per_simd` (1..8) of them resident per SIMD, two lanes x 16 bytes of a
+ * line's first 32, `loads_in_flight` (1, 2, 3, 4, 6, 8) independent lines per pair before any is used.  tbk_calib_stream_nt:
+ * `unroll` (1, 2, 4, 8) x 16 bytes per thread in flight, non-temporal loads, a grid of `blocks` x 256 threads.
+ * tools/calib_ceilings.py sweeps both and writes profiles/calibration.json's ceilings. */
+int tbk_calib_gather_pairs(int device, uint64_t footprint_bytes, int loads_in_flight, int waves_per_simd, uint64_t n_lines, int reps, double *lines_per_sec);
+int tbk_calib_stream_nt(int device, uint64_t footprint_bytes, int unroll, int blocks, int reps, double *bytes_per_sec);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,9 @@
 //     their sampled m-mer, and therefore their line, with list keys;
 //   * a read window asks with (orientation by the sampled m-mer, position) computed from the FORWARD strand alone, as the
 //     kernel does, on either strand of the same sequence, and gets the set's answer;
-//   * lines that overflow their 32 slots send keys to the overflow table and lookups find them there;
+//   * lines that overflow their 31 slots send keys to the overflow table and lookups find them there;
+//   * the summary in slot 7 never hides a key: a window that asks as the probe's loop does (behind the front only when the
+//     summary has its word's bit) gets the same answer as a scan of the whole line;
 //   * hapA-over-hapB priority (c/kmers.c:291-294): a key of both lists is stored for hapA only.
 // Built and run by tests/test_entry_model.py (g++, no GPU).
 #include <cstdint>
@@ -62,16 +64,18 @@ static void insert_key(Table &t, uint32_t half, uint64_t key, bool skip_a) {
         uint32_t *line = t.lines.data() + (uint64_t)f[i].bucket * 32;
         bool done = false;
         for (uint32_t s = 0; s < 32 && !done; s++) {
+            if (s == TBK_SHORT_SUMMARY) continue;  // the line's summary, no key
             const uint32_t cur = line[s] & ~TBK_SHORT_FLAG;
             if (cur == 0) {
                 line[s] |= f[i].word | (half ? TBK_SHORT_HAPB : 0u);
                 t.words++;
-                if (s >= 8) { line[7] |= TBK_SHORT_FLAG; t.behind++; }
+                if (s > TBK_SHORT_SUMMARY) { line[TBK_SHORT_SUMMARY] |= TBK_SHORT_FLAG | tbk_short_filter_bit(f[i].word); t.behind++; }
                 done = true;
             } else if ((cur & ~TBK_SHORT_HAPB) == f[i].word) done = true;
         }
         if (done) continue;
         line[31] |= TBK_SHORT_FLAG;
+        line[TBK_SHORT_SUMMARY] |= TBK_SHORT_FLAG | tbk_short_filter_bit(f[i].word);
         for (uint32_t at = tbk_short_over_home(key, t.over_mask), walked = 0; walked <= t.over_mask && !done; walked++, at = (at + 1) & t.over_mask) {
             if (t.over[at] == TBK_SHORT_EMPTY64) { t.over[at] = key | ((uint64_t)(half ? 1 : 0) << 63); t.past++; done = true; }
             else if ((t.over[at] & ~(1ull << 63)) == key) done = true;
@@ -163,7 +167,8 @@ int main(int argc, char **argv) {
             if (strand) { std::vector<uint8_t> q(G); for (int i = 0; i < G; i++) q[i] = (uint8_t)(3 - r[G - 1 - i]); r = q; }
             for (int i = 0; i + k <= G; i++) {
                 const uint64_t fwd = kmer_at(r, i), key = canon(fwd, k);
-                const int which = tbk_short_lookup_one(t.lines.data(), t.n_buckets, t.over.data(), t.over_mask, window_key(t, fwd, (int)(rng() & 1)), key);
+                // as the window loop decides: the front, then - only if the line's summary has the word's bit - what lies behind it
+                const int which = tbk_short_lookup_one(t.lines.data(), t.n_buckets, t.over.data(), t.over_mask, window_key(t, fwd, (int)(rng() & 1)), key, 1);
                 if ((which == 0) != (set_a.count(key) != 0) || (which == 1) != (set_b.count(key) != 0)) bad++;
                 windows++; hits_a += which == 0; hits_b += which == 1;
             }

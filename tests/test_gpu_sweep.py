@@ -18,6 +18,9 @@ LAYOUTS = {  # (name of Options.layout, further tbk_options fields)
     "short_keys": ("short_keys", {}),
     "short_keys_overflowing": ("short_keys", {"short_load": 12.0, "short_line_cap": 10}),
     "wide_entries": ("wide_entries", {}),
+    "full_keys": ("full_keys", {}),
+    "full_keys_k31": ("full_keys", {}),
+    "full_keys_crowded": ("full_keys", {"full_load": 9.0}),   # lines that fill: keys past their line, windows that walk
 }
 
 
@@ -51,7 +54,7 @@ def test_sweep_small(gpu, layout, kind):
     from trio_binning_amd._lib import check, lib
     from trio_binning_amd.sweep import full_membership_sweep
 
-    k = 27 if layout == "wide_entries" else 21
+    k = 27 if layout in ("wide_entries", "full_keys") else 31 if layout == "full_keys_k31" else 23 if layout == "full_keys_crowded" else 21
     n = 300_000
     d_a, d_b, n_a, n_b, base = _lists(gpu, kind, k, n)
     # hapB's list also gets 2000 of hapA's keys (they must count for hapA: c/kmers.c:291-294)
@@ -65,7 +68,9 @@ def test_sweep_small(gpu, layout, kind):
     with kmers.HashSet.from_keys(ha, k) as a, kmers.HashSet.from_keys(hb, k) as b, kmers.Classifier(a, b, options=kmers.Options.layout(name, **fields)) as cls:
         st = cls.stats()
         assert st["entry_layout"] == layout.startswith(("entries", "wide")) and st["short_keys"] == layout.startswith("short"), st
-        assert st["wide_entries"] == (layout == "wide_entries") and (layout != "key_front" or st["front_layout"])
+        assert st["wide_entries"] == (layout == "wide_entries") and (layout != "key_front" or st["front_layout"]) and st["full_keys"] == layout.startswith("full")
+        if layout == "full_keys_crowded":
+            assert st["keys_past_half"] > 0, st   # keys that left their line
         assert st["shared_keys"] >= 2000
         rec = full_membership_sweep(cls, a, b, a.device_keys, b.device_keys, ha.size, hb.size, k, chunk=1 << 17)
         assert rec["ok"], [r for r in rec["legs"] if not r["ok"]]
@@ -79,7 +84,7 @@ def test_sweep_small(gpu, layout, kind):
 
 
 def test_two_classifiers_with_different_layouts_built_at_the_same_time(gpu):
-    """tbk_options instead of the environment: four threads build four classifiers over the same two lists at the same
+    """tbk_options instead of the environment: five threads build five classifiers over the same two lists at the same
     time, each with its own pinned layout; every one gets the layout it asked for and answers like the others."""
     import threading
 
@@ -98,7 +103,7 @@ def test_two_classifiers_with_different_layouts_built_at_the_same_time(gpu):
             r[10:10 + k] = [(key >> (2 * j)) & 3 for j in range(k)]
         reads.append("".join("ACGT"[c] for c in r))
     bases, offsets = kmers.pack_reads(reads)
-    wanted = ["keys_front", "keys_whole_lines", "entries", "short_keys"]
+    wanted = ["keys_front", "keys_whole_lines", "entries", "short_keys", "full_keys"]
     got, errors = {}, []
     with kmers.HashSet.from_keys(keys[:n], k) as a, kmers.HashSet.from_keys(keys[n:], k) as b:
         start = threading.Barrier(len(wanted))
@@ -119,7 +124,7 @@ def test_two_classifiers_with_different_layouts_built_at_the_same_time(gpu):
     assert not errors, errors
     assert got["keys_front"][0]["front_layout"] and not got["keys_front"][0]["entry_layout"] and not got["keys_front"][0]["short_keys"]
     assert not got["keys_whole_lines"][0]["front_layout"] and not got["keys_whole_lines"][0]["short_keys"]
-    assert got["entries"][0]["entry_layout"] and got["short_keys"][0]["short_keys"]
+    assert got["entries"][0]["entry_layout"] and got["short_keys"][0]["short_keys"] and got["full_keys"][0]["full_keys"]
     assert all(st["table_bytes"] <= 1 << 30 for st, _ in got.values())
     first = got[wanted[0]][1]
     assert first.sum() >= 50 and all(np.array_equal(c, first) for _, c in got.values())

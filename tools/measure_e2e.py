@@ -34,6 +34,11 @@ ap.add_argument("--modes", default="plain,gzip")
 ap.add_argument("--out-dir", default=None, help="where the runs write their bins (default: the inputs' temporary directory)")
 ap.add_argument("--devices", default="", help="also run the plain mode with TBK_DEVICES set to this list (e.g. 0,0,0: three rings on one GPU)")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--gz-input", action="store_true",
+                help="also feed the reads as .fastq.gz, the way the reference's own CLI test and README do (tests/test_classify_by_kmers.py:19-36, seq.py:86-92): "
+                     "once as ONE ordinary gzip member (a single DEFLATE chain: the reader's guessing inflater) and once as bgzf blocks, bins plain")
+ap.add_argument("--qual", choices=["const", "hifi"], default="const", help="quality strings: one symbol, or HiFi-like (60 %% at the cap, the rest spread: what a real .fastq.gz inflates like)")
+ap.add_argument("--gz-level", type=int, default=6)
 ap.add_argument("--lists", choices=["uniform", "haplotypes"], default="uniform",
                 help="haplotypes: lists and reads shaped like real trio-binning input (bench.py --lists haplotypes): the k-mers over the SNPs between two "
                      "haplotypes of an implicit genome, reads drawn from the haplotypes with errors")
@@ -104,6 +109,13 @@ fq = os.path.join(tmp, "reads.fastq")
 chunk = 20_000
 d_b, d_o = dalloc(chunk * L + 64), dalloc((chunk + 1) * 8)
 qual = np.full(L, ord("I"), dtype=np.uint8)
+qual_pool = None
+if a.qual == "hifi":
+    # a pool of 2048 HiFi-like strings, one drawn per read: repeats lie megabytes apart, far outside DEFLATE's 32 KiB window
+    qrng = np.random.default_rng(7)
+    qv = np.clip(qrng.normal(60, 15, (2048, L)), 2, 93).astype(np.uint8)
+    qv[qrng.random((2048, L)) < 0.6] = 93
+    qual_pool = qv + 33
 with open(fq, "wb") as fh:
     for first in range(0, R, chunk):
         n = min(chunk, R - first)
@@ -119,7 +131,7 @@ with open(fq, "wb") as fh:
         rec[:, :w] = np.frombuffer(b"".join(names), dtype=np.uint8).reshape(n, w)
         rec[:, w:w + L] = bases
         rec[:, w + L:w + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
-        rec[:, w + L + 3:w + 2 * L + 3] = qual
+        rec[:, w + L + 3:w + 2 * L + 3] = qual if qual_pool is None else qual_pool[(np.arange(first, first + n) * 2654435761 >> 7) % 2048]
         rec[:, -1] = 10
         rec.tofile(fh)
 check(lib.tbk_device_free(dev, C.c_void_p(d_b)))
@@ -131,6 +143,64 @@ t_sync = time.time()
 os.sync()  # the inputs are at rest before anything is timed: their dirty pages count against the container's dirty limit, and a run that starts beside 34 GB of them has its writer throttled to the disk's speed
 res["inputs_synced_s"] = round(time.time() - t_sync, 1)
 res["page_cache"] = "warm (the inputs were written by this script just before the runs, then sync'ed: clean pages)"
+
+# ---- the same reads as .fastq.gz ----------------------------------------------------------------------
+gz_inputs = {}
+if a.gz_input:
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    n_thr = max(2, int(lib.tbk_host_threads()))
+    t_gz = time.time()
+
+    def deflate_piece(args):
+        piece, last, level = args
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return c.compress(piece) + c.flush(zlib.Z_FINISH if last else zlib.Z_SYNC_FLUSH), zlib.crc32(piece)
+
+    def bgzf_blocks(piece):
+        out = bytearray()
+        for i in range(0, len(piece), 60000):
+            blk = piece[i:i + 60000]
+            c = zlib.compressobj(a.gz_level, zlib.DEFLATED, -15)
+            body = c.compress(blk) + c.flush()
+            out += struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk))
+        return bytes(out)
+
+    one, bg = os.path.join(tmp, "reads_one_member.fastq.gz"), os.path.join(tmp, "reads_bgzf.fastq.gz")
+    size = os.path.getsize(fq)
+    piece_len = 8 << 20
+    crc = 0
+    # ONE gzip member whose DEFLATE chain was compressed piece by piece (pigz's way: every piece ends in an empty stored block, only the
+    # last one is final): one chain to inflate, matches reach back across block borders inside a piece, nothing marks the blocks
+    with open(fq, "rb") as src, open(one, "wb") as f1, open(bg, "wb") as f2, ThreadPoolExecutor(n_thr) as pool:
+        f1.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff")
+        done = 0
+        while done < size:
+            pieces = []
+            for _ in range(n_thr * 2):
+                b = src.read(piece_len)
+                if not b:
+                    break
+                pieces.append(b)
+            last_at = done + sum(len(b) for b in pieces) >= size
+            outs = list(pool.map(deflate_piece, [(b, last_at and i == len(pieces) - 1, a.gz_level) for i, b in enumerate(pieces)]))
+            blocks = list(pool.map(bgzf_blocks, pieces))
+            for (body, _), b in zip(outs, pieces):
+                f1.write(body)
+                crc = zlib.crc32(b, crc)
+            for blk in blocks:
+                f2.write(blk)
+            done += sum(len(b) for b in pieces)
+        f1.write(struct.pack("<II", crc & 0xFFFFFFFF, size & 0xFFFFFFFF))
+        f2.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))  # bgzf's empty end block
+    gz_inputs = {"one_gzip_member": one, "bgzf": bg}
+    res["gz_inputs"] = {"level": a.gz_level, "qualities": a.qual, "one_gzip_member_GB": round(os.path.getsize(one) / 1e9, 2), "bgzf_GB": round(os.path.getsize(bg) / 1e9, 2),
+                        "written_s": round(time.time() - t_gz, 1),
+                        "note": "one_gzip_member: a single gzip member, its DEFLATE chain compressed in 8 MB pieces by " + str(n_thr) + " threads (pigz's way): the reader sees one ordinary "
+                                "stream without block markers; bgzf: 60 kB blocks, each a gzip member with a BC field"}
+    os.sync()
 
 # ---- list loading alone, three ways (in this process) ----------------------------------------------
 for label, env in (("gpu_parser", {"TBK_LIST_CACHE": "0"}), ("host_parser", {"TBK_LIST_CACHE": "0", "TBK_LIST_GPU_PARSE": "0"}),
@@ -191,6 +261,48 @@ for mode, cache in runs:
             "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages
+# ---- gzip'ed reads in, plain bins out ---------------------------------------------------------------------
+for label, path in gz_inputs.items():
+    out = os.path.join(out_root, "gz_" + label)
+    os.makedirs(out)
+    tsv = os.path.join(out, "stdout.tsv")
+    t = time.time()
+    with open(tsv, "wb") as so:
+        p = subprocess.run([sys.executable, "-m", "trio_binning_amd.classify_by_kmers", path, paths[0], paths[1],
+                            "--haplotype-a-out-prefix", os.path.join(out, "hapA"), "--haplotype-b-out-prefix", os.path.join(out, "hapB"),
+                            "--unclassified-out-prefix", os.path.join(out, "unc"), "--no-gzip-output"],
+                           env=dict(env, TBK_PINFLATE_TIMING="1"), stdout=so, stderr=subprocess.PIPE)
+    dt = time.time() - t
+    err = p.stderr.decode()
+    if p.returncode != 0:
+        res["gz_" + label] = {"failed": err[-1500:]}
+        continue
+    st = [l for l in err.splitlines() if l.startswith("tbk-stats ")]
+    stages = json.loads(st[-1][10:]) if st else {}
+    rounds = [l for l in err.splitlines() if l.startswith("tbk-pinflate round")]
+    inflate = None
+    if rounds:
+        import re
+        g = d = r = mb = 0.0
+        guesses = kept = 0
+        for l in rounds:
+            m = re.search(r"(\d+) guesses, (\d+) chunks kept, ([\d.]+) MB of text: guess ([\d.]+) ms, decode ([\d.]+) ms, resolve ([\d.]+) ms", l)
+            if m:
+                guesses += int(m.group(1)); kept += int(m.group(2)); mb += float(m.group(3)); g += float(m.group(4)); d += float(m.group(5)); r += float(m.group(6))
+        thr = int(lib.tbk_host_threads())
+        inflate = {"rounds": len(rounds), "guesses": guesses, "chunks_kept": kept, "text_GB": round(mb / 1e3, 2), "guess_s": round(g / 1e3, 3), "decode_s": round(d / 1e3, 3), "resolve_s": round(r / 1e3, 3),
+                   "threads": thr, "decode_MB_per_s_per_thread": round(mb / max(d / 1e3, 1e-9) / thr, 1), "resolve_MB_per_s_per_thread": round(mb / max(r / 1e3, 1e-9) / thr, 1),
+                   "inflater_wall_GB_per_s": round(mb / 1e3 / max((g + d + r) / 1e3, 1e-9), 2)}
+    bins = {}
+    with open(tsv, "rb") as fh:
+        for line in fh:
+            b = line.split(b"\t")[1].decode()
+            bins[b] = bins.get(b, 0) + 1
+    res["gz_" + label] = {"wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
+                          "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None, "inflate": inflate, "bins": bins,
+                          "text_GB_per_s_in_the_loop": round(res["fastq_GB"] / stages["loop_s"], 2) if stages.get("loop_s") else None}
+    shutil.rmtree(out, ignore_errors=True)
+    os.sync()
 if not a.keep:
     shutil.rmtree(tmp, ignore_errors=True)
     shutil.rmtree(out_root, ignore_errors=True)

@@ -41,7 +41,7 @@ def probe_means(pattern):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta = {"VGPR_Count_as_rocprofv3_reports_it": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
                     "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80], "launches_averaged": len(agg[r["Counter_Name"]]),
-                    "VGPR_note": "the code object's .vgpr_count is 96 (tools/kernel_regs.sh): 5 waves per SIMD; rocprofv3's column is not the allocation"}
+                    "VGPR_note": "rocprofv3's VGPR column is not the allocation: the code object's .vgpr_count, LDS bytes and the waves per SIMD they allow are in the bench line (roofline.kernel_resources) and below (kernel_resources)"}
     return {k: sum(v) / len(v) for k, v in agg.items()}, meta
 
 
@@ -79,6 +79,8 @@ for lists in ("uniform", "haplotypes"):
     except Exception:
         pass
     # the PMC passes run bench.py with its default batch: windows per launch from the bench line of the same shape
+    if bench and bench.get("roofline", {}).get("kernel_resources"):
+        summary["kernel_resources"] = bench["roofline"]["kernel_resources"]
     if bench and "FETCH_SIZE" in summary:
         windows = bench["roofline"]["windows_per_launch"]
         hbm = summary["FETCH_SIZE"] * 1024 * 2

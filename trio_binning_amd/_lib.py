@@ -177,6 +177,9 @@ if hasattr(lib, "tbk_calib_atomics64"):
     _sig("tbk_calib_atomics64", C.c_int, C.c_int, _u64, C.c_int, C.c_int, _dp)
     _sig("tbk_counter_adds_issued", C.c_int, _vp, _u64p)
 _sig("tbk_calib_stream", C.c_int, C.c_int, _u64, C.c_int, _dp)
+if hasattr(lib, "tbk_calib_gather_pairs"):
+    _sig("tbk_calib_gather_pairs", C.c_int, C.c_int, _u64, C.c_int, C.c_int, _u64, C.c_int, _dp)
+    _sig("tbk_calib_stream_nt", C.c_int, C.c_int, _u64, C.c_int, C.c_int, C.c_int, _dp)
 _sig("tbk_fastx_open", C.c_int, C.c_char_p, C.POINTER(_vp))
 _sig("tbk_fastx_close", None, _vp)
 _sig("tbk_fastx_batch_create", C.c_int, C.POINTER(_vp))
@@ -203,7 +206,8 @@ class tbk_options(C.Structure):
                 ("clustered", C.c_double), ("behind_front", C.c_double), ("plainly_clustered", C.c_double), ("entry_min_ratio", C.c_double),
                 ("memory_budget_bytes", C.c_uint64), ("table_align", C.c_uint64), ("short_line_cap", C.c_uint32), ("probe_max_blocks", C.c_int32),
                 ("packed_h2d", C.c_int32), ("slice_bases", C.c_uint64), ("build_timing", C.c_int32), ("force_replica", C.c_int32),
-                ("ring_streams", C.c_int32), ("copy_priority", C.c_int32), ("h2d_streams", C.c_int32), ("zero_copy", C.c_int32)]
+                ("ring_streams", C.c_int32), ("copy_priority", C.c_int32), ("h2d_streams", C.c_int32), ("zero_copy", C.c_int32),
+                ("full_keys", C.c_int32), ("full_load", C.c_double)]
 
 
 HAS_OPTIONS = hasattr(lib, "tbk_classifier_create_opts")  # (variant builds of tools/build_variant.sh may predate round 5)

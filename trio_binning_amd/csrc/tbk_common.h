@@ -610,12 +610,17 @@ TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkW
 //     flank  the k - m bases around the m-mer in the orientation in which the m-mer is canonical (as tbk_entry_key)
 // - at k = 21 with 2^27.8 buckets that is 5 + 3 + 10 bits.  A SHORT slot is one 32-bit word:
 //     bits [0, 29)  flank | pos << fbits | r << (fbits + 3);  bit 29  taken;  bit 30  the list (1 = hapB);  bit 31  a flag
-// A line is 32 slots both lists fill in order; the probe's window loop reads the first eight (32 bytes, two lanes per
-// window as for entries, four compares of 32 bits per lane and list); bit 31 of slot 7: "slots behind the front are in
-// use" (settled from the line's other 96 bytes by drain_back, an L2 hit); bit 31 of slot 31: "a key of this bucket is in
-// the overflow table" - open addressing over 64-bit canonical keys (| list << 63) behind the lines, for the handful of
-// keys whose m-mer's bucket holds more than 32.  EMPTY is 0; a window that may not match asks 0xFFFFFFFF (every compare
-// strips the slot's bit 31 first).  Needs m <= 16 and fbits + 3 + 32 - rshift <= 29:
+// A line is 32 slots; both lists fill slots 0..6 and then 8..31 in order, and the probe's window loop reads the first eight
+// (32 bytes, two lanes per window as for entries, four compares of 32 bits per lane and list).  Slot 7 is no key but the
+// line's SUMMARY of what lies behind its front (round 5): bit 31 "slots behind the front are in use", and in bits 0..28 one
+// bit per word stored there or in the overflow table (tbk_short_filter_bit of the word).  A window that misses in the front of
+// a flagged line looks behind it - the line's other 96 bytes, fetched a second time: by then the line has long left the L2 -
+// only when its own word's bit is set: 99.8 % of a read's windows are in no list, and before the summary every one of them
+// that met a flagged line (1.4 % of all windows on BASELINE's lists) paid that second fetch; now one in ten of those does.
+// A summary never equals a word asked (bit 29, "taken", is clear in it and set in every word).  Bit 31 of slot 31: "a key of
+// this bucket is in the overflow table" - open addressing over 64-bit canonical keys (| list << 63) behind the lines, for
+// the handful of keys whose m-mer's bucket holds more than 31.  EMPTY is 0; a window that may not match asks 0xFFFFFFFF
+// (every compare strips the slot's bit 31 first).  Needs m <= 16 and fbits + 3 + 32 - rshift <= 29:
 // k = 21 from 65536 buckets on, k = 23 from 2^20, k = 25 from 2^24.
 #define TBK_FLAG_SHORT 16u   // `guests` word of the views: the paired table holds short keys
 #define TBK_SHORT_FLAG 0x80000000u
@@ -623,6 +628,14 @@ TBK_HD int tbk_wentry_lookup_one(const uint64_t *slots, uint32_t n_buckets, TbkW
 #define TBK_SHORT_TAKEN 0x20000000u
 #define TBK_SHORT_NONE 0xFFFFFFFFu
 #define TBK_SHORT_EMPTY64 0xFFFFFFFFFFFFFFFFull   // empty slot of the overflow table
+#define TBK_SHORT_SUMMARY 7                       // the slot of a line that holds its summary
+#define TBK_SHORT_FRONT_KEYS 7                    // keys in the 32 bytes the window loop reads
+
+// the bit of its line's summary (bits 0..28 of slot 7) that a word stored behind the front sets
+TBK_HD uint32_t tbk_short_filter_bit(uint32_t word) {
+    const uint32_t h = (word ^ (word >> 5) ^ (word >> 11)) & 0xFFFFu;
+    return 1u << ((h * 29u) >> 16);
+}
 
 struct TbkShortGeom {
     int fbits;   // 2 (k - m)
@@ -678,12 +691,21 @@ TBK_HD uint32_t tbk_short_over_home(uint64_t canonical, uint32_t over_mask) {
 }
 
 // -1 none, 0 hapA, 1 hapB.  lines = the table's n_buckets x 32 words; over = the overflow table behind them
-// (over_mask + 1 slots; over_mask = 0: none).
-TBK_HD int tbk_short_lookup_one(const uint32_t *lines, uint32_t n_buckets, const uint64_t *over, uint32_t over_mask, TbkShortKey e, uint64_t canonical) {
+// (over_mask + 1 slots; over_mask = 0: none).  as_window != 0: as the probe's window loop decides - behind the front only
+// when the summary has the word's bit (build-time scans and tests pass 0 and look everywhere: both must agree).
+TBK_HD int tbk_short_lookup_one(const uint32_t *lines, uint32_t n_buckets, const uint64_t *over, uint32_t over_mask, TbkShortKey e, uint64_t canonical, int as_window = 0) {
     const uint32_t *line = lines + (uint64_t)e.bucket * 32;
-    for (uint32_t s = 0; s < 32; s++) {
+    for (uint32_t s = 0; s < TBK_SHORT_FRONT_KEYS; s++) {
         const uint32_t v = line[s] & ~TBK_SHORT_FLAG;
-        if (v == 0) break;  // (the line's keys end here; the overflow table only when the line's last slot is flagged)
+        if (v == 0) break;  // the line's keys end here (what its bucket holds beyond - a capped line of the tests - is in the overflow table, and flagged)
+        if ((v & ~TBK_SHORT_HAPB) == e.word) return (int)((v >> 30) & 1u);
+    }
+    const uint32_t summary = line[TBK_SHORT_SUMMARY];
+    if (!(summary & TBK_SHORT_FLAG)) return -1;                            // nothing behind the front
+    if (as_window && !(summary & tbk_short_filter_bit(e.word))) return -1;  // ... or not this word
+    for (uint32_t s = TBK_SHORT_SUMMARY + 1; s < 32; s++) {
+        const uint32_t v = line[s] & ~TBK_SHORT_FLAG;
+        if (v == 0) break;
         if ((v & ~TBK_SHORT_HAPB) == e.word) return (int)((v >> 30) & 1u);
     }
     if (!(line[31] & TBK_SHORT_FLAG) || !over_mask) return -1;
@@ -691,6 +713,78 @@ TBK_HD int tbk_short_lookup_one(const uint32_t *lines, uint32_t n_buckets, const
         const uint64_t v = over[i];
         if (v == TBK_SHORT_EMPTY64) return -1;
         if ((v & ~(1ull << 63)) == canonical) return (int)(v >> 63);
+    }
+    return -1;
+}
+
+// ---- full keys: 64-bit list k-mers in the entry kernels' line (lists that do not merge, k too long for short keys) ----
+// Uniform lists of 26- to 31-mers (and of 23- / 25-mers in tables whose m-mers outgrow 16 bases) do not merge into entries and
+// do not fit short keys; until round 5 they stayed in the key layout: 8 + 8 slots per line, a 64-byte front read by four
+// lanes, 94-96 registers, five waves per SIMD, 93-100 bytes of device memory per key.  FULL keys put them into the entry
+// kernels' line shape: 16 slots, a 32-byte front read by two lanes per window.  A slot =
+//     bits [0, 62)  the canonical k-mer, INVERTED (k <= 31: a key is below 2^62) - so that an empty slot is 0, the inverse of
+//                   T x 31, which is never canonical (for k < 31 no key reaches it)
+//     bit 62        the list (1 = hapB);   bit 63  a flag of the slot's place in its line, no part of the key
+// and a window matches a slot iff (slot & KEY) == ~canonical & KEY: one and, one 64-bit compare.  A window that may not
+// match asks for the inverse of TBK_FULL_NOKEY ("GTT...T": never canonical either).
+// Both lists fill slots 0, 1, 2 and then 4 .. 15 in order.  SLOT 3 IS NO KEY but the line's summary of what lies behind its
+// front (as slot 7 of a short-key line): bit 63 "slots behind the front are in use", bits 0..61 one bit per key stored there
+// or sent on past the line (tbk_full_filter_bit).  Three keys in the front is few - at two keys per line a fifth of the
+// lines holds more - but a window looks behind a front only when the summary has its own key's bit: 99.8 % of a read's
+// windows are in no list, and of those that meet a flagged line one in ~25 passes.  The probe never compares slot 3 (a
+// 62-bit summary could equal a key).  Bit 63 of slot 15: "a key went past this line" (second-choice bucket by a hash of the
+// key, then linear: tbk_next_bucket).  The bucket is the sampled m-mer's, by the placement half of the 64-bit m-mer hash
+// whatever m is (tbk_wentry_bucket: the probe's m-mer arithmetic is the wide entries'); a key is stored under the bucket of
+// every position that attains the smallest t-mer rank, as in the key layouts.  List lines that are not canonical are dead in
+// the reference (stored verbatim, c/kmers.c:113; looked up as min(fwd, rc), c/kmers.c:255) and are not stored; hapB keys
+// that hapA's list holds are left out (c/kmers.c:291-294), so a window matches at most one slot of its line.
+#define TBK_FLAG_FULL 32u    // `guests` word of the views: the paired table holds full keys
+#define TBK_FULL_FLAG 0x8000000000000000ull
+#define TBK_FULL_HAPB 0x4000000000000000ull
+#define TBK_FULL_KEY 0x3FFFFFFFFFFFFFFFull
+#define TBK_FULL_NOKEY 0x3FFFFFFFFFFFFFFEull   // what an invalid window looks up (stored form: 1)
+#define TBK_FULL_SUMMARY 3                     // the slot of a line that holds its summary
+#define TBK_FULL_FRONT_KEYS 3                  // keys in the 32 bytes the window loop reads
+
+TBK_HD bool tbk_full_geom(int k, TbkMz z) { return k >= 3 && k <= 31 && z.w >= 2 && z.w <= 8 && z.t > 0 && z.m >= 8 && z.m <= 24 && z.t <= 16; }
+
+// the stored form of a canonical key (without list bit and flag)
+TBK_HD uint64_t tbk_full_word(uint64_t canonical) { return ~canonical & TBK_FULL_KEY; }
+
+// the bit of its line's summary (bits 0..61 of slot 3) that a key stored behind the front sets; `word` = tbk_full_word
+TBK_HD uint64_t tbk_full_filter_bit(uint64_t word) {
+    const uint32_t lo = (uint32_t)word, hi = (uint32_t)(word >> 32);
+    const uint32_t h = (lo ^ (lo >> 7) ^ (lo >> 17) ^ hi ^ (hi >> 9)) & 0xFFFFu;
+    return 1ull << ((h * 62u) >> 16);
+}
+
+// the canonical m-mer of `key` at span position p (m <= 24: 64-bit arithmetic)
+TBK_HD uint64_t tbk_full_mmer(uint64_t key, TbkMz z, int p) {
+    const uint64_t mmask = (1ull << (2 * z.m)) - 1ull;
+    const uint64_t x = (key >> (2 * (z.o + p))) & mmask;
+    const uint64_t y = tbk_revcomp64(x, z.m);
+    return x < y ? x : y;
+}
+
+// -1: neither list holds the canonical key; 0 / 1: hapA's / hapB's does.  `bucket`: the home bucket of one of the key's forms.
+// as_window != 0: as the probe's window loop decides (behind the front of the HOME line only when its summary has the key's bit).
+TBK_HD int tbk_full_lookup_one(const uint64_t *slots, uint32_t n_buckets, uint64_t canonical, uint32_t bucket, TbkMz z, int as_window = 0) {
+    const uint64_t want = tbk_full_word(canonical);
+    uint32_t b = bucket;
+    for (uint32_t walked = 0; walked <= n_buckets; walked++) {
+        const uint64_t *line = slots + (uint64_t)b * 16;
+        for (uint32_t s = 0; s < 16; s++) {
+            if (s == TBK_FULL_SUMMARY) {
+                if (!(line[s] >> 63)) return -1;                                                    // nothing behind this front
+                if (as_window && walked == 0 && !(line[s] & tbk_full_filter_bit(want))) return -1;   // ... or not this key
+                continue;
+            }
+            const uint64_t v = line[s];
+            if ((v & ~TBK_FULL_FLAG) == 0) return -1;   // first empty slot of the line
+            if ((v & TBK_FULL_KEY) == want) return (int)((v >> 62) & 1ull);
+        }
+        if (!(line[15] >> 63)) return -1;               // nothing went past this line
+        b = tbk_next_bucket(canonical, z, n_buckets, b, walked == 0);
     }
     return -1;
 }

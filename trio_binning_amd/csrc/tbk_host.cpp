@@ -39,6 +39,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, int, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, uint32_t, hipStream_t);
+extern "C" hipError_t tbk_launch_full_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -107,6 +108,8 @@ extern "C" void tbk_options_init(tbk_options *o) {
     memset(o, 0, sizeof *o);
     o->size = (uint32_t)sizeof *o;
     o->short_keys = o->entries = o->wide_entries = o->front = -1;
+    o->full_keys = -1;
+    o->full_load = 2.0;
     o->mod_sampling = o->span3 = o->guests = -1;
     o->minimizer_w = -1;
     o->minimizer_m = 0;
@@ -129,6 +132,7 @@ extern "C" int tbk_options_from_env(tbk_options *o) {
     auto inum = [](const char *name, int32_t &v) { if (getenv(name) && *getenv(name)) v = (int32_t)env_double(name, v); };
     auto unum = [](const char *name, uint64_t &v) { if (getenv(name) && *getenv(name)) v = (uint64_t)std::max(0.0, env_double(name, (double)v)); };
     tri("TBK_SHORT", o->short_keys); tri("TBK_ENTRY", o->entries); tri("TBK_ENTRY_WIDE", o->wide_entries); tri("TBK_FRONT", o->front);
+    tri("TBK_FULL", o->full_keys); num("TBK_FULL_LOAD", o->full_load);
     tri("TBK_MOD_SAMPLING", o->mod_sampling); tri("TBK_SPAN3", o->span3); tri("TBK_GUESTS", o->guests);
     inum("TBK_MINIMIZER_W", o->minimizer_w); inum("TBK_MINIMIZER_M", o->minimizer_m); inum("TBK_TWO_READ", o->two_read_kernel);
     num("TBK_TABLE_LOAD", o->table_load); num("TBK_ENTRY_LOAD", o->entry_load); num("TBK_WENTRY_LOAD", o->wentry_load); num("TBK_SHORT_LOAD", o->short_load);
@@ -1188,7 +1192,9 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
 
 // The paired table in entry layout (tbk_common.h "entry layout"): lines of 128 bytes, EMPTY = 0, hapA's list first, then
 // hapB's minus the keys hapA holds (tbk_entry_insert_kernel looks them up in hapA's finished half).
-static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets) {
+// (give_up_behind != 0, full keys: a build that may only show that the lists cluster stops after hapA's list when that alone has put
+// more keys than that behind the fronts - *gave_up)
+static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets, uint64_t give_up_behind = 0, bool *gave_up = nullptr) {
     c->n_buckets = n_buckets;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = c->alloc_pair(bytes);
@@ -1202,8 +1208,14 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     for (int list = 0; list < 2 && e == hipSuccess; list++) {
         const tbk_table *t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
-        if (e == hipSuccess) e = tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, (c->guests & TBK_FLAG_WIDE) != 0, d_cnt, d_failed, nullptr);
+        if (e == hipSuccess) e = (c->guests & TBK_FLAG_FULL)
+                                     ? tbk_launch_full_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr)
+                                     : tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, (c->guests & TBK_FLAG_WIDE) != 0, d_cnt, d_failed, nullptr);
         if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished half)
+        if (e == hipSuccess && list == 0 && give_up_behind && cnt[0][3] > give_up_behind) {
+            if (gave_up) *gave_up = true;
+            break;
+        }
     }
     if (e == hipSuccess) e = hipMemcpy(&failed, d_failed, sizeof failed, hipMemcpyDeviceToHost);
     if (d_cnt) (void)hipFree(d_cnt);
@@ -1456,7 +1468,55 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
         if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->over_mask = 0; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
+    // Full keys (tbk_common.h): lists that do not merge and do not fit short keys - uniform 26- to 31-mers, 23- / 25-mers whose
+    // tables need m-mers beyond 16 bases - as 64-bit keys in the entry kernels' line: three keys and the line's summary in a
+    // 32-byte front read by two lanes, twelve more behind it.  full_load keys per line (default 2.0: 64 bytes of device
+    // memory per key; the key layout they had until round 5: 93-100).  Lists that cluster (more than behind_front x 6 of the
+    // keys behind a front - a fifth of a uniform list's keys is, with three keys to a front; runs of overlapping k-mers put
+    // well over half there) go on to the key layout's test and to entries.  full_keys = 0: never, 1: whatever the lists look like.
+    const double full_pin = o.full_keys;
+    auto try_full_layout = [&](bool forced) -> bool {
+        if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
+        if (!forced && o.table_load > 0) return false;  // (the key layouts' load is pinned: the key layouts are meant)
+        TbkMz z = span_for(true);
+        if (!tbk_full_geom(c->k, z) || z.t != z.m - z.w) return false;
+        const double per_line = std::min(12.0, std::max(0.05, o.full_load > 0 ? o.full_load : 2.0));
+        uint64_t nb = (uint64_t)((double)(a->num_lines + b->num_lines) / per_line) + 16;
+        size_t free_b = 0, total_b = 0;
+        double cap = (double)budget;
+        if (!budget) { if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap = 0.6 * (double)total_b; else (void)hipGetLastError(); }
+        if (cap > 0 && (double)nb * 128.0 > cap) {
+            if ((double)(a->num_lines + b->num_lines) / (cap / 128.0) > 6.0) return false;  // (a line holds fifteen keys: beyond six to a line on average the key layout's denser loads do better)
+            nb = (uint64_t)(cap / 128.0);
+        }
+        if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;
+        const TbkMz keep_mz = c->mz;
+        const uint32_t keep_flags = c->guests;
+        c->mz = z;
+        c->guests = TBK_FLAG_FULL;
+        c->free_pair();
+        bool gave_up = false;
+        // (hapA's list alone, at half the load: a uniform list has 2 % of its keys behind a front then, a clustered one a third: given up at 20 %)
+        const uint64_t give_up = forced ? 0 : (uint64_t)(2.0 * o.behind_front * (double)(a->num_lines + b->num_lines)) + 1;
+        const int brc = build_entry_table(c, a, b, (uint32_t)nb, give_up, &gave_up);
+        lap(gave_up ? "full keys (given up after hapA's list)" : "full keys", false);
+        bool built = brc == TBK_OK && !gave_up;
+        if (built) c->layout_builds++;
+        const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
+        if (built && !forced && (double)c->behind_front / n_keys > 6.0 * o.behind_front) built = false;  // the lists cluster
+        if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
+        return true;
+    };
     if (entry_pin <= 0 && short_pin != 0 && front_pin < 0 && try_short_layout(short_pin > 0)) {
+        c->own_pair();
+        rc = classifier_streams(c);
+        if (rc) { tbk_classifier_destroy(c); return rc; }
+        *out = c;
+        return TBK_OK;
+    }
+    // By themselves only where short keys were ALLOWED and do not apply (k, or m-mers beyond 16 bases: short_behind < 0 - lists a
+    // short-key build has measured are not in need of full keys); with short keys switched off the key layouts are meant.
+    if (entry_pin <= 0 && front_pin < 0 && (full_pin > 0 || (full_pin < 0 && short_pin < 0 && short_behind < 0)) && try_full_layout(full_pin > 0)) {
         c->own_pair();
         rc = classifier_streams(c);
         if (rc) { tbk_classifier_destroy(c); return rc; }
@@ -1647,7 +1707,7 @@ extern "C" int tbk_classifier_front(const tbk_classifier *c, int *front, uint64_
 
 extern "C" int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t *entries_a, uint64_t *entries_b) {
     if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
-    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_SHORT) ? 3 : (c->guests & TBK_FLAG_ENTRY) ? ((c->guests & TBK_FLAG_WIDE) ? 2 : 1) : 0;  // (3: short keys)
+    if (entry_layout) *entry_layout = (c->guests & TBK_FLAG_FULL) ? 4 : (c->guests & TBK_FLAG_SHORT) ? 3 : (c->guests & TBK_FLAG_ENTRY) ? ((c->guests & TBK_FLAG_WIDE) ? 2 : 1) : 0;  // (3: short keys, 4: full keys)
     if (entries_a) *entries_a = c->entries_a;
     if (entries_b) *entries_b = c->entries_b;
     return TBK_OK;
@@ -2463,6 +2523,73 @@ extern "C" int tbk_calib_gather(int device, uint64_t footprint, int line_bytes, 
     if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TBK_ERR_INVALID : TBK_ERR_HIP, "calib_gather: %s", hipGetErrorString(e));
     if (ms_per_rep) *ms_per_rep = ms / reps;
     if (lines_per_sec) *lines_per_sec = (double)done * reps / (ms * 1e-3);
+    return TBK_OK;
+}
+
+extern "C" hipError_t tbk_launch_gather_pairs(const void *, uint64_t, int, int, uint64_t, uint64_t, uint32_t *, uint64_t *, hipStream_t);
+extern "C" hipError_t tbk_launch_stream_nt(const void *, uint64_t, int, unsigned, uint32_t *, hipStream_t);
+
+// The gather in the entry kernels' shape (one-wave blocks, two lanes x 16 bytes per line, `inflight` lines per pair before any is
+// used, `waves_per_simd` resident waves) and a tuned streaming read (`unroll` x 16 bytes per thread, non-temporal, `blocks`
+// blocks of 256): the ceilings bench.py prices the probe kernel's line rate and traffic against (tools/calib_ceilings.py sweeps them).
+extern "C" int tbk_calib_gather_pairs(int device, uint64_t footprint, int inflight, int waves_per_simd, uint64_t n_lines, int reps, double *lines_per_sec) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    footprint &= ~(uint64_t)255;
+    if (footprint < (1u << 20) || reps < 1) return fail(TBK_ERR_INVALID, "footprint too small");
+    void *buf = nullptr;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, footprint));
+    hipError_t e = hipMalloc((void **)&sink, 16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t done = 0;
+    float ms = 0;
+    if (e == hipSuccess) e = tbk_launch_fill(buf, footprint, 1, nullptr);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_gather_pairs(buf, footprint, inflight, waves_per_simd, n_lines, 7, sink, &done, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = tbk_launch_gather_pairs(buf, footprint, inflight, waves_per_simd, n_lines, 11 + r, sink, &done, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TBK_ERR_INVALID : TBK_ERR_HIP, "calib_gather_pairs: %s", hipGetErrorString(e));
+    if (lines_per_sec) *lines_per_sec = (double)done * reps / (ms * 1e-3);
+    return TBK_OK;
+}
+
+extern "C" int tbk_calib_stream_nt(int device, uint64_t footprint, int unroll, int blocks, int reps, double *bytes_per_sec) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    footprint &= ~(uint64_t)255;
+    if (footprint < (1u << 20) || reps < 1 || blocks < 1) return fail(TBK_ERR_INVALID, "bad calibration parameters");
+    void *buf = nullptr;
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc(&buf, footprint));
+    hipError_t e = hipMalloc((void **)&sink, 16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (e == hipSuccess) e = tbk_launch_fill(buf, footprint, 1, nullptr);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_stream_nt(buf, footprint, unroll, (unsigned)blocks, sink, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+    for (int r = 0; r < reps && e == hipSuccess; r++) e = tbk_launch_stream_nt(buf, footprint, unroll, (unsigned)blocks, sink, nullptr);
+    if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(buf);
+    if (sink) (void)hipFree(sink);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TBK_ERR_INVALID : TBK_ERR_HIP, "calib_stream_nt: %s", hipGetErrorString(e));
+    if (bytes_per_sec) *bytes_per_sec = (double)footprint * reps / (ms * 1e-3);
     return TBK_OK;
 }
 

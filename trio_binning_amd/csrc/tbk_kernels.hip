@@ -343,13 +343,14 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
                 uint32_t *line = lines + (uint64_t)e.bucket * 32;
                 bool done = false;
                 for (uint32_t sl = 0; sl < line_cap && !done; sl++) {
+                    if (sl == TBK_SHORT_SUMMARY) continue;  // (no key: the line's summary of what lies behind its front)
                     uint32_t cur = __hip_atomic_load(&line[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (;;) {
                         if ((cur & ~TBK_SHORT_FLAG) == 0) {  // empty: mine, unless somebody is quicker
                             const uint32_t old = atomicCAS(&line[sl], cur, cur | e.word | listbit);
                             if (old == cur) {
                                 created++; stored += first_form; done = true;
-                                if (sl >= 8) { behind++; atomicOr(&line[7], TBK_SHORT_FLAG); }
+                                if (sl > TBK_SHORT_SUMMARY) { behind++; atomicOr(&line[TBK_SHORT_SUMMARY], TBK_SHORT_FLAG | tbk_short_filter_bit(e.word)); }
                                 break;
                             }
                             cur = old;
@@ -362,7 +363,7 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
                 if (!done) {
                     // the line is full: the canonical key goes to the overflow table
                     atomicOr(&line[31], TBK_SHORT_FLAG);
-                    atomicOr(&line[7], TBK_SHORT_FLAG);  // (set already when slots behind the front are in use: a line_cap of 8 or less)
+                    atomicOr(&line[TBK_SHORT_SUMMARY], TBK_SHORT_FLAG | tbk_short_filter_bit(e.word));  // (a window must get as far as the overflow table)
                     const unsigned long long mine = (unsigned long long)key | ((unsigned long long)(half ? 1u : 0u) << 63);
                     uint32_t at = tbk_short_over_home(key, over_mask);
                     for (uint32_t walked = 0; walked <= over_mask && over_mask != 0 && !done; walked++, at = (at + 1) & over_mask) {
@@ -378,6 +379,70 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
                 if (!done) atomicExch(failed, 1);
                 first_form = false;
             }
+        }
+    }
+    if (stored) atomicAdd(&cnt[0], stored);
+    if (skipped) atomicAdd(&cnt[1], skipped);
+    if (created) atomicAdd(&cnt[2], created);
+    if (behind) atomicAdd(&cnt[3], behind);
+    if (past) atomicAdd(&cnt[4], past);
+}
+
+// Full keys (tbk_common.h "full keys"): one list key per thread, stored - inverted, with its list's bit - in the first free
+// slot of the line of every position that attains the smallest t-mer rank (slots 0, 1, 2, then 4 .. 15: slot 3 is the line's
+// summary); a key placed behind the front, or sent on past a full line, sets its bit in the summary of the line it came
+// through (a window follows the same path: home line, second-choice bucket, linear).  hapB's keys that hapA holds are left
+// out (skip_a: hapA's inserts are finished).
+// cnt: [0] keys stored, [1] hapB keys left out, [2] slots taken, [3] of those behind a front, [4] forms that left a line.
+__global__ void __launch_bounds__(256)
+tbk_full_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *__restrict__ keys, uint64_t n, int skip_a,
+                       unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
+    unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
+    const int n_pos = tbk_mz_positions(mz);
+    const unsigned long long listbit = half ? TBK_FULL_HAPB : 0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        if (key >= TBK_FULL_NOKEY) continue;             // cannot be canonical
+        if (tbk_revcomp_packed(key, k) < key) continue;  // not canonical: never looked up
+        const unsigned long long word = tbk_full_word(key), fbit = tbk_full_filter_bit(word);
+        uint32_t best = 0xFFFFFFFFu;
+        for (int pi = 0; pi < n_pos; pi++) { const uint32_t r = tbk_tmer_rank(key, mz, pi); best = r < best ? r : best; }
+        bool first_form = true, drop = false;
+        for (int pi = 0; pi < n_pos && !drop; pi++) {
+            if (tbk_tmer_rank(key, mz, pi) != best) continue;
+            uint32_t b = tbk_wentry_bucket(tbk_full_mmer(key, mz, pi % mz.w), n_buckets);
+            if (first_form && skip_a && tbk_full_lookup_one(slots, n_buckets, key, b, mz) == 0) { skipped++; drop = true; break; }
+            bool done = false;
+            for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
+                unsigned long long *line = (unsigned long long *)(slots + (uint64_t)b * 16);
+                for (uint32_t sl = 0; sl < 16 && !done; sl++) {
+                    if (sl == TBK_FULL_SUMMARY) continue;
+                    unsigned long long cur = __hip_atomic_load(&line[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        if ((cur & ~TBK_FULL_FLAG) == 0) {  // empty: mine, unless somebody is quicker
+                            const unsigned long long old = atomicCAS(&line[sl], cur, cur | word | listbit);
+                            if (old == cur) {
+                                created++; stored += first_form; done = true;
+                                if (sl > TBK_FULL_SUMMARY) { behind++; atomicOr(&line[TBK_FULL_SUMMARY], TBK_FULL_FLAG | fbit); }
+                                break;
+                            }
+                            cur = old;
+                            continue;
+                        }
+                        if ((cur & TBK_FULL_KEY) == word) done = true;  // a duplicate line, or this key's other tied position naming the same bucket
+                        break;
+                    }
+                }
+                if (!done) {
+                    // the line is full: the key goes on, and a window that follows it must get past this line's front
+                    atomicOr(&line[15], TBK_FULL_FLAG);
+                    atomicOr(&line[TBK_FULL_SUMMARY], TBK_FULL_FLAG | fbit);
+                    past++;
+                    b = tbk_next_bucket(key, mz, n_buckets, b, walked == 0);
+                }
+            }
+            if (!done) atomicExch(failed, 1);
+            first_form = false;
         }
     }
     if (stored) atomicAdd(&cnt[0], stored);
@@ -578,6 +643,12 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
 constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
 constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
+#ifndef TBK_SHARE_STARTS
+#define TBK_SHARE_STARTS 1   // entry kernels, single-read passes: neighbouring lanes that start on one line fetch it once (0: each its own)
+#endif
+#ifndef TBK_TMER_LUT
+#define TBK_TMER_LUT 1   // entry kernels with 3w t-mer positions at W = 6 (t = 4): t-mer ranks from a 256-entry table in LDS (0: computed)
+#endif
 #ifndef TBK_SHORT_DRAIN
 #define TBK_SHORT_DRAIN (TBK_BQCAP - 64)   // short keys: the back queue is drained when it holds more than this many windows
 #endif
@@ -1375,18 +1446,51 @@ __device__ __forceinline__ bool walk_one_entry(const TbkPairView t, uint32_t hal
     return found;
 }
 
-template <bool MULTI, bool WIDE>
+// full keys (KIND = 3): the walk of a window whose home line is full and was left by a key - second-choice bucket by a hash of the
+// canonical key, then linear (tbk_next_bucket); whole lines, no summary test.  q = the stored form asked (tbk_full_word).
+__device__ __forceinline__ bool walk_one_full(const TbkPairView t, uint64_t q, uint32_t bucket, bool pend, uint32_t *hap) {
+    bool found = false, first = true;
+    uint32_t guard = 0;
+    *hap = 0;
+    const uint64_t canonical = ~q & TBK_FULL_KEY;
+    while (ballot(pend) != 0 && guard++ <= t.n_buckets) {
+        if (pend) {
+            bucket = tbk_next_bucket(canonical, t.mz, t.n_buckets, bucket, first);
+            first = false;
+            const uint64_t *line = t.slots + (uint64_t)bucket * 16;
+            bool hit = false, ended = false;
+            uint64_t last = 0;
+#pragma unroll 1
+            for (uint32_t sl = 0; sl < 16 && !ended && !hit; sl += 2) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(line + sl);
+                if ((v.x & TBK_FULL_KEY) == q) { hit = true; *hap = (uint32_t)(v.x >> 62) & 1u; }
+                else if (sl + 1 != TBK_FULL_SUMMARY && (v.y & TBK_FULL_KEY) == q) { hit = true; *hap = (uint32_t)(v.y >> 62) & 1u; }
+                ended = sl + 1 == TBK_FULL_SUMMARY ? (v.y >> 63) == 0 : (v.y << 1) == 0;  // nothing behind the front / an empty slot: the line's keys end here
+                last = v.y;
+            }
+            found = found || hit;
+            pend = !hit && !ended && (last >> 63) != 0;  // all taken and a key went past them
+        }
+    }
+    return found;
+}
+
+template <bool MULTI, int KIND>
 __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint4 *q, const uint16_t *qr, uint32_t qn, uint64_t r_first, uint32_t lane,
                                                   int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
+    constexpr bool WIDE = KIND == 1, FULL = KIND == 3;
     for (uint32_t base = 0; base < qn; base += 64) {
         const bool act = base + lane < qn;
-        uint4 it = WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);  // (a wide filler has no V bit: it matches nothing)
+        uint4 it = WIDE ? make_uint4(0, 0, 0, 0) : FULL ? make_uint4(1, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);  // (a wide filler has no V bit, a full one asks for no key: they match nothing)
         uint32_t rrel = 0;
         if (act) { it = q[base + lane]; if (WIDE && MULTI) rrel = qr[base + lane]; }
         bool found;
         uint32_t list = 0;
         if constexpr (WIDE) {
             found = walk_one_entry<true>(p.t, 0, wide_key_of(it, p.t.mz.w, fbits, vshift), it.w & 0x3FFFFFFFu, act, &list);
+        } else if constexpr (FULL) {
+            rrel = it.w;
+            found = walk_one_full(p.t, (uint64_t)it.x | ((uint64_t)it.y << 32), it.z, act, &list);
         } else {
             rrel = it.w;
             found = walk_one_entry<false>(p.t, 0, entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift), it.z, act, &list);
@@ -1409,11 +1513,11 @@ __device__ __forceinline__ void drain_walks_entry(const ProbeArgs &p, const uint
 template <bool MULTI, int KIND>
 __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4 *bq, const uint16_t *bqr, uint32_t qb, uint4 *walkq, uint16_t *walkr, uint32_t &qn,
                                                  uint64_t r_first, uint32_t lane, int fbits, int vshift, uint32_t &acc_a, uint32_t &acc_b, uint32_t *rcnt) {
-    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2;
+    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2, FULL = KIND == 3;
     const uint32_t sub = lane & 7u, oct = lane >> 3;
     for (uint32_t base = 0; base < qb; base += 8) {
         const bool act = base + oct < qb;
-        uint4 it = SHORT ? make_uint4(TBK_SHORT_NONE, 0, 0, 0) : WIDE ? make_uint4(0, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
+        uint4 it = SHORT ? make_uint4(TBK_SHORT_NONE, 0, 0, 0) : WIDE ? make_uint4(0, 0, 0, 0) : FULL ? make_uint4(1, 0, 0, 0) : make_uint4(TBK_ENTRY_NO_MMER, 1u << vshift, 0, 0);
         uint32_t rrel = 0;
         ulonglong2 v = make_ulonglong2(0, 0);
         if (act) {
@@ -1433,6 +1537,14 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             hit = ballot(tbk_wentry_match(v.x, v.y, wide_key_of(it, p.t.mz.w, fbits, vshift)));
             const uint64_t hapm = ballot(((v.y >> 62) & 1ull) != 0);
             hit_a = hit & ~hapm; hit_b = hit & hapm;
+        } else if constexpr (FULL) {
+            // slots 4 .. 15: keys of either list, the list in bit 62
+            rrel = it.w;
+            const uint64_t q = (uint64_t)it.x | ((uint64_t)it.y << 32);
+            const uint64_t hx = ballot((v.x & TBK_FULL_KEY) == q), hy = ballot((v.y & TBK_FULL_KEY) == q);
+            const uint64_t bx = ballot(((v.x >> 62) & 1ull) != 0), by = ballot(((v.y >> 62) & 1ull) != 0);
+            hit = hx | hy;
+            hit_a = (hx & ~bx) | (hy & ~by); hit_b = (hx & bx) | (hy & by);
         } else {
             rrel = it.w;
             const TbkEntryKey e = entry_key_of(it.x, it.y, p.t.mz.w, fbits, vshift);
@@ -1490,7 +1602,7 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
             qn += n_a + (uint32_t)__popcll(walk_b);
             if (qn > TBK_QCAP_ENTRY - 16) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if constexpr (!SHORT) drain_walks_entry<MULTI, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+                if constexpr (!SHORT) drain_walks_entry<MULTI, KIND>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 qn = 0;
             }
@@ -1502,8 +1614,9 @@ __device__ __forceinline__ void drain_back_entry(const ProbeArgs &p, const uint4
 template <int W, bool MULTI, bool TWO, int KIND, int LW>
 __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint64_t e0, const uint64_t e1, const uint64_t e2, const uint64_t e3,
                                                  const uint64_t P0, const uint64_t r_first, const uint64_t r_first_end, const uint32_t lane,
-                                                 uint4 *walkq, uint4 *backq, uint16_t *walkr, uint16_t *backr, uint32_t *rcnt) {
-    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2;
+                                                 uint4 *walkq, uint4 *backq, uint16_t *walkr, uint16_t *backr, uint32_t *rcnt, const uint32_t *tlut) {
+    constexpr bool WIDE = KIND == 1, SHORT = KIND == 2, FULL = KIND == 3;
+    constexpr bool TLUT = TBK_TMER_LUT && LW == 3 && W == 6 && !TWO && !MULTI;  // t = 4: a t-mer's rank is a table look-up (tbk_probe_entry_kernel fills the table; the two-read and multi-read kernels, at their register limits, compute)
     const int k = p.k;
     const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const uint32_t sub = lane & 1u;
@@ -1534,7 +1647,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;
             if (inside < 64) bad64 |= ~0ull << inside;
         }
-        if ((lane & 1u) && !(TWO && is_strad)) {
+        // (which lanes walk downwards: the odd ones - a two-read pass - or, in a single-read pass, the even ones: see "Lane starts" below)
+        if ((TBK_SHARE_STARTS && !TWO) ? !(lane & 1u) : ((lane & 1u) && !(TWO && is_strad))) {
             const int sh = 33 - k;
             const unsigned __int128 s_up = R128 >> (2 * sh), r_up = S128 << (2 * sh);
             S128 = s_up; R128 = r_up;
@@ -1559,6 +1673,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     const uint64_t mmask = m >= 32 ? ~0ull : ((1ull << (2 * m)) - 1ull);
     const uint32_t tmask = tlen >= 16 ? 0xFFFFFFFFu : ((1u << (2 * tlen)) - 1u);
     auto tmer_rank = [&](uint64_t fwd64, uint64_t rc64, uint32_t fsh, uint32_t bsh, uint32_t pos) -> uint32_t {
+        if constexpr (TLUT) return tlut[(uint32_t)(fwd64 >> fsh) & 0xFFu] | pos;  // (canonical form, hash and tag mask are in the table)
         const uint32_t x = (uint32_t)(fwd64 >> fsh) & tmask, y = (uint32_t)(rc64 >> bsh) & tmask;
         return (tbk_mmer_hash(x < y ? x : y) & ~TAGM) | pos;
     };
@@ -1607,6 +1722,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     va[0] = make_ulonglong2(0, 0); va[1] = make_ulonglong2(0, 0);
     uint32_t last_bk = 0x7FFFFFFFu;
     uint32_t qn = 0, qb = 0;
+    constexpr bool STARTS = TBK_SHARE_STARTS && !MULTI && !TWO;  // (single-read passes: every odd lane walks downwards)
 
 #pragma unroll TBK_SAMP_UNROLL
     for (int j = 0; j < TBK_WPL; j++) {
@@ -1643,12 +1759,12 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         const uint32_t pos = x1 >= (uint32_t)W ? x1 - (uint32_t)W : x1;
         const uint32_t fsh = 2u * (span_o + pos), bsh = 2u * (span_o + (uint32_t)W - 1u - pos);
         // (wide entries: m-mers of up to 24 bases, 64-bit arithmetic and the placement half of the 64-bit hash)
-        using mmer_t = typename std::conditional<WIDE, uint64_t, uint32_t>::type;
+        using mmer_t = typename std::conditional<WIDE || FULL, uint64_t, uint32_t>::type;  // (full keys: the wide entries' m-mer arithmetic and bucket hash)
         const mmer_t mx = (mmer_t)(fs >> fsh) & (mmer_t)mmask, my = (mmer_t)(bs >> bsh) & (mmer_t)mmask;
         const bool fw_or = mx < my;                       // the m-mer is canonical as the forward strand reads it
         const mmer_t cm = fw_or ? mx : my;
         uint32_t bkt, short_r = 0;
-        if constexpr (WIDE) bkt = tbk_reduce((uint32_t)tbk_mmer_hash64(cm), p.t.n_buckets);
+        if constexpr (WIDE || FULL) bkt = tbk_reduce((uint32_t)tbk_mmer_hash64(cm), p.t.n_buckets);
         else if constexpr (SHORT) {
             const uint64_t prod = (uint64_t)tbk_mmer_hash((uint32_t)cm) * (uint64_t)p.t.n_buckets;  // (tbk_short_key: bucket and r are the two words of one product)
             bkt = (uint32_t)(prod >> 32);
@@ -1672,6 +1788,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
         } else if constexpr (SHORT) {
             my_khi = (low | (high << a)) | (posp << (uint32_t)fbits) | (short_r << ((uint32_t)fbits + 3u)) | TBK_SHORT_TAKEN;  // the word this window asks
             my_mhi = 0;
+        } else if constexpr (FULL) {
+            my_khi = 0; my_mhi = 0;  // (set with cm_ask below: the stored form of the canonical k-mer)
         } else {
             my_khi = ((low | (high << a)) << shw) | vbit;
             my_mhi = (fmask << shw) | vbit;
@@ -1683,6 +1801,11 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             cm_ask = (uint32_t)w0_want; cm_ask2 = (uint32_t)(w0_want >> 32);
         } else if constexpr (SHORT) {
             cm_ask = ok ? my_khi : TBK_SHORT_NONE;
+        } else if constexpr (FULL) {
+            // what the slots hold: the canonical k-mer, inverted (tbk_full_word); an invalid window asks for the inverse of TBK_FULL_NOKEY
+            const uint64_t kf = fs & kmask, kr = bs & kmask;
+            const uint64_t q = ok ? (~(kf < kr ? kf : kr) & TBK_FULL_KEY) : 1ull;
+            cm_ask = (uint32_t)q; my_khi = (uint32_t)(q >> 32);
         } else {
             cm_ask = ok ? (uint32_t)cm : TBK_ENTRY_NO_MMER;
         }
@@ -1699,8 +1822,16 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
 
         // ---- two pair sub-steps ----
         const uint32_t bk0 = pair_bcast<0>(my_bk), bk1 = pair_bcast<1>(my_bk);
+        // Lane starts.  In a single-read pass the EVEN lanes walk their windows downwards: the two lanes of a pair start on
+        // neighbouring windows - lane 2p on the last of its 32, lane 2p + 1 on the first of its own - four times in five in the same
+        // bucket.  Two requests for that line, a few cycles apart in the two load instructions, were BOTH misses and both fetched
+        // from HBM (the L2 does not merge a miss with one in flight: TCC_EA0_RDREQ = TCC_MISS, profiles/r05): 40 M of a launch's
+        // 785 M lines.  In the first step a pair whose two windows name one bucket loads the line once.
+        bool twin = false;
+        if (STARTS && j == 0) twin = (int32_t)bk1 < 0 && bk1 == bk0;  // (both fresh - bit 31 - and the same bucket)
         if ((int32_t)bk0 < 0) va[0] = load_slots(p.t.slots + (uint64_t)(bk0 & 0x7FFFFFFFu) * 16 + sub * 2);
-        if ((int32_t)bk1 < 0) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
+        if ((int32_t)bk1 < 0 && !twin) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
+        if (STARTS && j == 0 && twin) va[1] = va[0];
         const uint32_t cm_s[2] = {pair_bcast<0>(cm_ask), pair_bcast<1>(cm_ask)};
         const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
         const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
@@ -1720,6 +1851,11 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                 hitx[s] = ballot(w0 == qa || hx == qa || w2 == qa || w3 == qa);
                 hit_sb[s] = ballot(w0 == qb2 || hx == qb2 || w2 == qb2 || w3 == qb2);
                 hit[s] = hitx[s] | hit_sb[s];
+            } else if constexpr (FULL) {
+                // the even lane holds slots 0 and 1, the odd lane slot 2 and - never compared: a 62-bit summary could equal a key - the line's summary
+                const uint64_t want = (uint64_t)cm_s[s] | ((uint64_t)kh_s[s] << 32);
+                hitx[s] = ballot((va[s].x & TBK_FULL_KEY) == want);
+                hit[s] = hitx[s] | (ballot((va[s].y & TBK_FULL_KEY) == want) & 0x5555555555555555ull);
             } else if constexpr (WIDE) {
                 // the lane's piece is ONE entry: word 0 = m-mer | taken, word 1 = flanks + V (+ the piece's flag in bit 63, outside every mask)
                 const uint32_t ly = (uint32_t)va[s].y;
@@ -1740,7 +1876,17 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             for (int s = 0; s < 2; s++) {
                 if (more[s] == 0) continue;
                 // only the odd lane's second word (slot 3 / piece 1) carries the flag, for the line
-                const uint64_t ma = 0ull, mb = (more[s] >> 1) & 0x5555555555555555ull;
+                uint64_t flagged = more[s];
+                if constexpr (SHORT) {
+                    // ... and that word is the line's summary: behind the front only if the window's own bit is set in it
+                    const uint32_t summary = (uint32_t)(va[s].y >> 32);
+                    flagged = ballot((int32_t)summary < 0 && (summary & tbk_short_filter_bit(cm_s[s])) != 0);
+                }
+                if constexpr (FULL) {
+                    const uint64_t summary = va[s].y;  // (the odd lane's: slot 3)
+                    flagged = ballot((summary >> 63) != 0 && (summary & tbk_full_filter_bit((uint64_t)cm_s[s] | ((uint64_t)kh_s[s] << 32))) != 0);
+                }
+                const uint64_t ma = 0ull, mb = (flagged >> 1) & 0x5555555555555555ull;
                 need |= ((ma | mb) & ~pair_any(hit[s])) << s;
                 beh_a |= ma << s;
                 beh_b |= mb << s;
@@ -1759,6 +1905,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
                     } else if constexpr (WIDE) {
                         backq[at] = make_uint4((uint32_t)cm, my_khi, (my_khi2 & 0xFFFFu) | ((uint32_t)((uint64_t)cm >> 32) << 16), home);
                         if (MULTI || TWO) backr[at] = (uint16_t)rrel;
+                    } else if constexpr (FULL) {
+                        backq[at] = make_uint4(cm_ask, my_khi, home, rrel);  // (the stored form asked, home bucket, read: the narrow entries' places)
                     } else {
                         backq[at] = make_uint4((uint32_t)cm, my_khi, home, rrel);
                     }
@@ -1815,7 +1963,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     }
     if (!SHORT && qn) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        drain_walks_entry<MULTI || TWO, WIDE>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
+        drain_walks_entry<MULTI || TWO, KIND>(p, walkq, walkr, qn, r_first, lane, fbits, vshift, acc_a, acc_b, rcnt);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (MULTI) {
@@ -1958,7 +2106,7 @@ tbk_probe_kernel(const ProbeArgs p) {
 }
 
 // The entry layout's probe kernels: the same three (single-read, two-read, multi-read passes) over probe_pass_entry.
-// KIND: 0 narrow entries, 1 wide entries, 2 short keys (tbk_common.h)
+// KIND: 0 narrow entries, 1 wide entries, 2 short keys, 3 full keys (tbk_common.h)
 template <int W, bool MULTI, bool TWO = false, int KIND = 0, int LW = 2>
 __global__ void __launch_bounds__(64 * TBK_WAVES_PER_BLOCK, MULTI ? TBK_MIN_WAVES_MULTI : TBK_MIN_WAVES)
 tbk_probe_entry_kernel(const ProbeArgs p) {
@@ -1966,7 +2114,7 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
     __shared__ uint4 walkq[TBK_WAVES_PER_BLOCK][KIND == 2 ? 1 : TBK_QCAP_ENTRY];  // (short keys never walk: their overflow is a table of its own)
     __shared__ uint4 backq[TBK_WAVES_PER_BLOCK][TBK_BQCAP];
     __shared__ uint16_t walkr[TBK_WAVES_PER_BLOCK][KIND == 1 && (MULTI || TWO) ? TBK_QCAP_ENTRY : 1];  // wide entries, short keys: the read of a queued window travels beside the queue
-    __shared__ uint16_t backr[TBK_WAVES_PER_BLOCK][KIND != 0 && (MULTI || TWO) ? TBK_BQCAP : 1];
+    __shared__ uint16_t backr[TBK_WAVES_PER_BLOCK][(KIND == 1 || KIND == 2) && (MULTI || TWO) ? TBK_BQCAP : 1];
     __shared__ uint32_t rcnt[TBK_WAVES_PER_BLOCK][MULTI ? 2 * TBK_RCNT : (TWO ? 4 : 1)];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2000,7 +2148,20 @@ tbk_probe_entry_kernel(const ProbeArgs p) {
         const uint64_t e0 = stage[wave][2 * lane], e1 = stage[wave][2 * lane + 1], e2 = stage[wave][2 * lane + 2],
                        e3 = stage[wave][2 * lane + 3];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        probe_pass_entry<W, MULTI, TWO, KIND, LW>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave]);
+        if constexpr (TBK_TMER_LUT && LW == 3 && W == 6 && !TWO && !MULTI) {
+            // The staged tile is in registers: its LDS now holds the ranks of all 256 t-mers (W = 6 with 3w positions: t = m - 12 = 4) -
+            // canonical form, hash and tag mask folded in - so that a window's new t-mer costs the loop one LDS read instead of eleven
+            // vector instructions, one of them a multiply.  The loop runs at 90 % of the vector units' issue rate (EXPERIMENTS.md).
+            uint32_t *lut = reinterpret_cast<uint32_t *>(stage[wave]);
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                const uint32_t x = 4u * lane + i, y = tbk_revcomp32(x, 4);
+                lut[x] = tbk_mmer_hash(x < y ? x : y) & ~31u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        probe_pass_entry<W, MULTI, TWO, KIND, LW>(p, e0, e1, e2, e3, P0, r_first, r_end, lane, walkq[wave], backq[wave], walkr[wave], backr[wave], rcnt[wave],
+                                                  reinterpret_cast<const uint32_t *>(stage[wave]));
         if (!MULTI) return;  // one pass per block
     }
 }
@@ -2020,6 +2181,16 @@ extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_bucket
     return hipGetLastError();
 }
 
+
+extern "C" hipError_t tbk_launch_full_insert(uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n, int skip_a,
+                                             unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+    if (!tbk_full_geom(k, mz)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(tbk_full_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, k, d_keys, n, skip_a, d_cnt, d_failed);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t tbk_launch_short_insert(uint64_t *slots, uint32_t n_buckets, uint32_t over_mask, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n,
                                               int skip_a, unsigned long long *d_cnt, int *d_failed, uint32_t line_cap, hipStream_t stream) {
@@ -2144,13 +2315,14 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     // mod-sampling selection; front or whole-line layout
     const bool m64 = t.mz.m > 16, samp = t.mz.t > 0, front = (t.guests & TBK_FLAG_FRONT) != 0, entry = (t.guests & TBK_FLAG_ENTRY) != 0;
     if (front && t.mz.w < 2) return hipErrorInvalidValue;  // front tables are built for minimizer spans only (tbk_host.cpp)
-    const bool wide = (t.guests & TBK_FLAG_WIDE) != 0, shortk = (t.guests & TBK_FLAG_SHORT) != 0;
+    const bool wide = (t.guests & TBK_FLAG_WIDE) != 0, shortk = (t.guests & TBK_FLAG_SHORT) != 0, fullk = (t.guests & TBK_FLAG_FULL) != 0;
     const bool span3 = (entry || shortk) && t.mz.t > 0 && t.mz.t == t.mz.m - 2 * t.mz.w;
     if ((entry || shortk) && t.mz.t > 0 && !span3 && t.mz.t != t.mz.m - t.mz.w) return hipErrorInvalidValue;
     if (shortk) {
         TbkShortGeom g;
         if (!tbk_short_geom(k, t.mz, t.n_buckets, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
     }
+    if (fullk && (!tbk_full_geom(k, t.mz) || t.mz.t != t.mz.m - t.mz.w || t.n_buckets > 0x3FFFFFFFu)) return hipErrorInvalidValue;
     if (entry) {
         TbkEntryGeom g;
         if (!(wide ? tbk_wentry_geom(k, t.mz, &g) : tbk_entry_geom(k, t.mz, &g)) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;
@@ -2170,14 +2342,23 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
                          else if (samp) { if (m64) TBK_LAUNCH(N, true, true, false); else TBK_LAUNCH(N, false, true, false); } \
                          else if (front) { if (m64) TBK_LAUNCH(N, true, false, true); else TBK_LAUNCH(N, false, false, true); } \
                          else { if (m64) TBK_LAUNCH(N, true, false, false); else TBK_LAUNCH(N, false, false, false); } break;
-        if (entry || shortk) {
+        if (entry || shortk || fullk) {
 #define TBK_E1(N, WD, LW) do { if (which == 2) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, true, false, WD, LW>), grid_multi, block, 0, stream, p); \
                          else if (which == 0) hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, false, WD, LW>), grid, block, 0, stream, p); \
                          else hipLaunchKernelGGL((tbk_probe_entry_kernel<N, false, true, WD, LW>), grid_two, block, 0, stream, p); } while (0)
             // (3w t-mer positions: narrow entries and short keys with spans of up to six m-mers - tbk_mz_span3)
 #define TBK_E(N, WD) case N: if (span3) TBK_E1(N, WD, 3); else TBK_E1(N, WD, 2); break;
 #define TBK_E2(N, WD) case N: if (span3) return hipErrorInvalidValue; TBK_E1(N, WD, 2); break;
-            if (shortk) {
+            if (fullk) {
+                switch (t.mz.w) {
+#ifdef TBK_ONLY_W6
+                    TBK_E2(6, 3) TBK_E2(8, 3)
+#else
+                    TBK_E2(2, 3) TBK_E2(3, 3) TBK_E2(4, 3) TBK_E2(5, 3) TBK_E2(6, 3) TBK_E2(7, 3) TBK_E2(8, 3)
+#endif
+                    default: return hipErrorInvalidValue;
+                }
+            } else if (shortk) {
                 switch (t.mz.w) {
 #ifdef TBK_ONLY_W6
                     TBK_E(6, 2)

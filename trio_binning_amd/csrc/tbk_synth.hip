@@ -391,6 +391,51 @@ tbk_calib_stream_kernel(const uint4 *__restrict__ buf, uint64_t n_vec, uint32_t 
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The gather in the probe kernels' own shape (round 5: the yardstick must not sit below what it measures): one-wave blocks -
+// so that eight waves per SIMD fit - two lanes per line, 16 bytes each of the line's first 32 (the entry kernels' front), INF
+// independent lines per pair in flight before any is used, cheap index arithmetic (one multiply per line).
+template <int INF>
+__global__ void __launch_bounds__(64, 8)
+tbk_calib_gather_pairs_kernel(const uint4 *__restrict__ buf, uint64_t n_lines_buf, uint32_t iters, uint64_t seed, uint32_t *__restrict__ sink) {
+    const uint64_t pair = ((uint64_t)blockIdx.x * 64 + threadIdx.x) >> 1;
+    const uint32_t sub = threadIdx.x & 1u;
+    uint64_t state = tbk_splitmix(seed ^ (pair * 0x9E3779B97F4A7C15ull));
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint4 v[INF];
+#pragma unroll
+        for (int f = 0; f < INF; f++) {
+            state = state * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull;  // (an LCG step: the index is its high half times the line count)
+            const uint64_t line = (uint64_t)(((unsigned __int128)(state ^ (state >> 29)) * n_lines_buf) >> 64);
+            v[f] = buf[line * 8 + sub];
+        }
+#pragma unroll
+        for (int f = 0; f < INF; f++) acc += v[f].x ^ v[f].y ^ v[f].z ^ v[f].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// Streaming read, tuned: U x 16 bytes per thread in flight, non-temporal (nothing is read twice), a grid of `blocks` that walks
+// the buffer in strides.
+template <int U>
+__global__ void __launch_bounds__(256)
+tbk_calib_stream_nt_kernel(const uint4 *__restrict__ buf, uint64_t n_vec, uint32_t *__restrict__ sink) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 *src = reinterpret_cast<const u4 *>(buf);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + (U - 1) * stride < n_vec; i += (uint64_t)U * stride) {
+        u4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(src + i + (uint64_t)u * stride);
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    for (; i < n_vec; i += stride) { const u4 a = src[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
 // Fire-and-forget 32-bit atomic adds.  `run` consecutive adds of a lane go to consecutive words of
 // one random 128-byte line (run = 1: every add to its own random line), which is the counting
 // kernel's pattern: the windows of a read that share a minimizer update counters of one line.
@@ -556,6 +601,29 @@ extern "C" hipError_t tbk_launch_stream(const void *d_buf, uint64_t bytes, uint3
     const uint64_t n_vec = bytes / 16;
     hipLaunchKernelGGL(tbk_calib_stream_kernel, dim3(256 * 16), dim3(256), 0, s, (const uint4 *)d_buf, n_vec, d_sink);
     return hipGetLastError();
+}
+
+// lines_done: what one launch gathers.  waves_per_simd blocks of one wave per SIMD of 256 CUs, each pair `iters` x inf lines.
+extern "C" hipError_t tbk_launch_gather_pairs(const void *d_buf, uint64_t bytes, int inf, int waves_per_simd, uint64_t n_lines, uint64_t seed, uint32_t *d_sink,
+                                              uint64_t *lines_done, hipStream_t s) {
+    const unsigned blocks = 256u * 4u * (unsigned)(waves_per_simd < 1 ? 1 : waves_per_simd > 8 ? 8 : waves_per_simd) * 4u;  // four rounds of resident waves
+    const uint64_t pairs = (uint64_t)blocks * 32;
+    uint64_t iters = n_lines / (pairs * (uint64_t)inf);
+    if (iters < 1) iters = 1;
+    *lines_done = iters * pairs * (uint64_t)inf;
+    const uint64_t n_lines_buf = bytes / 128;
+#define TBK_GP(F) if (inf == F) { hipLaunchKernelGGL((tbk_calib_gather_pairs_kernel<F>), dim3(blocks), dim3(64), 0, s, (const uint4 *)d_buf, n_lines_buf, (uint32_t)iters, seed, d_sink); return hipGetLastError(); }
+    TBK_GP(1) TBK_GP(2) TBK_GP(3) TBK_GP(4) TBK_GP(6) TBK_GP(8)
+#undef TBK_GP
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t tbk_launch_stream_nt(const void *d_buf, uint64_t bytes, int unroll, unsigned blocks, uint32_t *d_sink, hipStream_t s) {
+    const uint64_t n_vec = bytes / 16;
+#define TBK_SN(U) if (unroll == U) { hipLaunchKernelGGL((tbk_calib_stream_nt_kernel<U>), dim3(blocks), dim3(256), 0, s, (const uint4 *)d_buf, n_vec, d_sink); return hipGetLastError(); }
+    TBK_SN(1) TBK_SN(2) TBK_SN(4) TBK_SN(8)
+#undef TBK_SN
+    return hipErrorInvalidValue;
 }
 
 template <int LINE, int LPL, int INF>

@@ -304,9 +304,10 @@ class Options:
 
     LAYOUTS = {
         "auto": {},
-        "keys": {"short_keys": 0, "entries": 0},
-        "keys_front": {"short_keys": 0, "entries": 0, "front": 1},
-        "keys_whole_lines": {"short_keys": 0, "entries": 0, "front": 0},
+        "keys": {"short_keys": 0, "entries": 0, "full_keys": 0},
+        "keys_front": {"short_keys": 0, "entries": 0, "full_keys": 0, "front": 1},
+        "keys_whole_lines": {"short_keys": 0, "entries": 0, "full_keys": 0, "front": 0},
+        "full_keys": {"short_keys": 0, "entries": 0, "full_keys": 1},
         "entries": {"entries": 1, "wide_entries": 0},
         "wide_entries": {"entries": 1, "wide_entries": 1},
         "short_keys": {"short_keys": 1},
@@ -392,7 +393,7 @@ class Classifier:
         ent, ea, eb = C.c_int(), C.c_uint64(), C.c_uint64()
         if hasattr(lib, "tbk_classifier_entries"):
             check(lib.tbk_classifier_entries(self._h, C.byref(ent), C.byref(ea), C.byref(eb)))
-        return {"entry_layout": ent.value in (1, 2), "wide_entries": ent.value == 2, "short_keys": ent.value == 3, "entries_a": ea.value, "entries_b": eb.value, "shared_keys": sh.value, "layout_builds": nb_.value, "keys_past_half": past.value, "front_layout": bool(front.value), "keys_behind_front": behind.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
+        return {"entry_layout": ent.value in (1, 2), "wide_entries": ent.value == 2, "short_keys": ent.value == 3, "full_keys": ent.value == 4, "entries_a": ea.value, "entries_b": eb.value, "shared_keys": sh.value, "layout_builds": nb_.value, "keys_past_half": past.value, "front_layout": bool(front.value), "keys_behind_front": behind.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
                 "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
                 "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
 
