@@ -527,6 +527,13 @@ int tbk_synth_mutate_keys_device(int device, const void *d_keys, uint64_t first,
 int tbk_sweep_expectation_device(tbk_table *a, tbk_table *b, const void *d_keys, uint64_t n, void *d_expect);
 int tbk_classifier_sweep_keys(tbk_classifier *c, const void *d_keys, uint64_t n, int k, uint32_t keys_per_read, int expect, const void *d_expect,
                               uint64_t chunk_keys, uint64_t out[4]);
+/* Every line of both lists through the finished table, checked against the lists' standalone tables: the verification a build can
+ * be given in the field (a concurrent build - compare-and-swap on slots, the wide entries' per-piece lock - leaves no other
+ * trace of a lost or misfiled key).  out = {lines checked, keys counted for hapA, for hapB, lines that differ from what the
+ * standalone tables say, the first such line - hapA's lines first, then hapB's; all ones: none}.  Under a second at
+ * 2 x 3e8 keys; the standalone tables take 32 bytes of device memory per list line while it runs.  The command-line tool runs it
+ * when TBK_VERIFY_BUILD=1. */
+int tbk_classifier_verify(tbk_classifier *c, tbk_table *a, tbk_table *b, uint64_t out[5]);
 
 /* ---- k-mer counting: the find-unique-kmers step ---------------------------
  * Replaces the KMC subprocesses of find_unique_kmers.py:62-233 by a counting table in HBM.

@@ -152,6 +152,10 @@ def test_sweep_notices_wrong_answers(gpu):
         # ... and counted for the wrong list
         r = _sweep(lacking, b.device_keys, n, k, 1, 1)
         assert r["bad_reads"] == n
+        # the field check (tbk_classifier_verify; the CLI's TBK_VERIFY_BUILD=1): the classifier lacks seven of `a`'s lines
+        v = lacking.verify(a, b)
+        assert v == {"lines": 2 * n, "count_a": n - 7, "count_b": n, "bad_lines": 7, "first_bad": n - 7}, v
+        assert lacking.verify()["bad_lines"] == 0   # ... and is complete for the lists it was built from
         rec = full_membership_sweep(lacking, a, b, a.device_keys, b.device_keys, n, n, k, uniform_seed=0x5EED0001, chunk=1 << 16)
         assert not rec["ok"]
         assert [x["leg"] for x in rec["legs"] if not x["ok"]] == ["members_hapA_k_base_reads", "members_hapA_long_reads"]

@@ -6,7 +6,7 @@ for d in sorted(glob.glob(os.path.join(out, "cal_*"))):
     if not os.path.isdir(d):
         continue
     tag = os.path.basename(d)[4:]
-    variant = next((v for v in ("filter_lut", "noprompt", "prompt", "filter", "base") if tag.startswith(v + "_")), None)
+    variant = next((v for v in ("filter_lut", "noprompt", "prompt", "filter", "starts", "base") if tag.startswith(v + "_")), None)
     group = "bench_" + variant if variant else "calib"
     rows = []
     for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):

@@ -161,6 +161,8 @@ if hasattr(lib, "tbk_classifier_sweep_keys"):  # (variant builds of tools/build_
     _sig("tbk_synth_mutate_keys_device", C.c_int, C.c_int, _vp, _u64, _u64, C.c_int, _u64, _vp)
     _sig("tbk_sweep_expectation_device", C.c_int, _vp, _vp, _vp, _u64, _vp)
     _sig("tbk_classifier_sweep_keys", C.c_int, _vp, _vp, _u64, C.c_int, C.c_uint32, C.c_int, _vp, _u64, _u64p)
+    if hasattr(lib, "tbk_classifier_verify"):
+        _sig("tbk_classifier_verify", C.c_int, _vp, _vp, _vp, _u64p)
 _sig("tbk_host_threads", C.c_int)
 _sig("tbk_counter_create", C.c_int, C.c_int, _u64, C.c_int, C.POINTER(_vp))
 _sig("tbk_counter_destroy", None, _vp)

@@ -78,7 +78,17 @@ def make_classifier(haplotype_a_kmers, haplotype_b_kmers):
     """The classify pipeline of this run: one feeder thread and stream ring per device of TBK_DEVICES
     (default: every visible device; a device may repeat), tables replicated, batches dealt to them and
     taken back in input order - the library's ``tbk_pipeline``, also when that is a single device."""
-    return kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, kmers.visible_devices())
+    # (how the table is built is an argument of the library - kmers.Options; the command line has no flags for it, as the
+    # reference has none, so the TBK_* variables of the environment are its fallback: Options.from_env)
+    classifier = kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, kmers.visible_devices(), options=kmers.Options.from_env())
+    if os.environ.get("TBK_VERIFY_BUILD", "") not in ("", "0"):
+        # every line of both lists through the finished table, against the lists' standalone tables of verbatim keys
+        # (the reference stores every line and finds every stored canonical key: c/kmers.c:112-122, 245-268)
+        rec = classifier._part(0).verify(haplotype_a_kmers, haplotype_b_kmers)
+        print("tbk-verify " + str(rec), file=sys.stderr)
+        if rec["bad_lines"]:
+            raise SystemExit(f"classify-by-kmers: the built table answers {rec['bad_lines']} list lines wrongly (first: line {rec['first_bad']}): not using it")
+    return classifier
 
 
 def main():

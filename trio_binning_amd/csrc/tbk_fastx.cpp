@@ -140,9 +140,14 @@ struct LineSource {
             uint8_t head[18];
             const ssize_t n = ::pread(fd, head, sizeof head, 0);
             bgzf = threads > 1 && n == (ssize_t)sizeof head && bgzf_block_size(head, sizeof head) > 0;
-            if (bgzf) zin.resize((size_t)8 << 20);
             const char *how = getenv("TBK_INFLATE");
             struct stat st;
+            if (bgzf && fstat(fd, &st) == 0 && st.st_size > 0) {
+                // BGZF blocks are parsed and inflated where the file is mapped: no copy of the compressed bytes through read()
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL); map = (const uint8_t *)m; map_size = (size_t)st.st_size; }
+            }
+            if (bgzf && !map) zin.resize((size_t)32 << 20);
             if (!bgzf && !(how && strcmp(how, "zlib") == 0) && fstat(fd, &st) == 0 && st.st_size > 0) {
                 void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
                 if (m != MAP_FAILED) {
@@ -214,10 +219,11 @@ struct LineSource {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
             Chunk c;
             bool at_end = false;
-            const int r = bgzf_window(c.data, &at_end);
+            size_t text_len = 0;
+            const int r = bgzf_window(c.data, &text_len, &at_end);
             if (r < 0) { c.err = err; c.last = true; push(std::move(c)); return; }
             if (r == 0) { c.fallback = true; c.data.clear(); push(std::move(c)); return; }  // an ordinary member: the parser thread takes over
-            c.off = 0; c.len = c.data.size(); c.last = at_end;
+            c.off = 0; c.len = text_len; c.last = at_end;
             push(std::move(c));
             if (at_end) return;
         }
@@ -310,7 +316,12 @@ struct LineSource {
         struct Here { Here() { guessers()++; } ~Here() { guessers()--; } } here;
         constexpr size_t HIST = 32768;
         constexpr uint16_t NOTHING = 0x7FFF;  // window position before the member's first byte
-        const size_t span = std::max<size_t>(env_size("TBK_PINFLATE_SPAN", (size_t)2 << 20), 4096);
+        // A round's span per thread: 8 MB of compressed bytes where the file has them for every thread (30 GB of FASTQ as one member,
+        // 16 threads: 2.48 Gbases/s through the whole loop against 1.81 with spans of 2 MB - a round ends in three joins, and a short
+        // round is mostly joins; profiles/r05/cli_gz_configs1_spans.json), less in a smaller file so that every thread gets one.
+        const size_t span_pinned = env_size("TBK_PINFLATE_SPAN", 0);
+        const size_t span = span_pinned ? std::max<size_t>(span_pinned, 4096)
+                                        : std::min<size_t>((size_t)8 << 20, std::max<size_t>((size_t)1 << 20, map_size / (size_t)std::max(1, std::min(threads, 32))));
         size_t cap = std::max<size_t>(span * 5, (size_t)1 << 16);  // symbols per chunk; grows when chunks hit it
         const int nt_most = std::min(threads, 32);
         { std::lock_guard<std::mutex> lk(mu); queue_cap = (size_t)(2 * nt_most); }
@@ -488,29 +499,44 @@ struct LineSource {
     // Inflate as many whole BGZF blocks as the compressed window holds, side by side, straight
     // into buf[end..].  Returns 1 bytes produced (or clean end), 0 fall back to the sequential path
     // (the window does not start with a BGZF block), -1 error.
-    // `dst` receives the text of the window (its previous contents are dropped); *at_end is set when
-    // the file is exhausted.
-    int bgzf_window(std::vector<uint8_t> &dst, bool *at_end) {
+    // `dst` receives the text of the window, *text_len bytes of it (a recycled buffer: it may be longer); *at_end is set when
+    // the file is exhausted.  The compressed window is a 32 MB stretch of the mapped file (a window read() into `zin` where the
+    // file could not be mapped): enough blocks for every host thread, and no serial copy in front of them.
+    size_t bgzf_map_pos = 0;
+    int bgzf_window(std::vector<uint8_t> &dst, size_t *text_len, bool *at_end) {
+        *text_len = 0;
         for (;;) {
-            // top up the compressed window
-            if (zin_pos > 0 && zin_pos < zin_end) memmove(zin.data(), zin.data() + zin_pos, zin_end - zin_pos);
-            zin_end -= zin_pos; zin_pos = 0;
-            while (!raw_eof && zin_end < zin.size()) {
-                const ssize_t n = ::read(fd, zin.data() + zin_end, zin.size() - zin_end);
-                if (n < 0) { err = std::string("read: ") + strerror(errno); return -1; }
-                if (n == 0) raw_eof = true;
-                zin_end += (size_t)(n > 0 ? n : 0);
+            const uint8_t *zbase;
+            size_t zcap;
+            if (map) {
+                bgzf_map_pos += zin_pos; zin_pos = 0;
+                zbase = map + bgzf_map_pos;
+                zin_end = std::min<size_t>((size_t)32 << 20, map_size - bgzf_map_pos);
+                zcap = zin_end < ((size_t)32 << 20) ? zin_end + 1 : zin_end;  // (a window cut short by the end of the file is not "full")
+                raw_eof = bgzf_map_pos + zin_end >= map_size;
+            } else {
+                // top up the compressed window
+                if (zin_pos > 0 && zin_pos < zin_end) memmove(zin.data(), zin.data() + zin_pos, zin_end - zin_pos);
+                zin_end -= zin_pos; zin_pos = 0;
+                while (!raw_eof && zin_end < zin.size()) {
+                    const ssize_t n = ::read(fd, zin.data() + zin_end, zin.size() - zin_end);
+                    if (n < 0) { err = std::string("read: ") + strerror(errno); return -1; }
+                    if (n == 0) raw_eof = true;
+                    zin_end += (size_t)(n > 0 ? n : 0);
+                }
+                zbase = zin.data();
+                zcap = zin.size();
             }
             if (zin_end == 0) { *at_end = true; dst.clear(); return 1; }
             struct Blk { size_t in, in_len, out, out_len; uint32_t crc; size_t whole, whole_len; };
             std::vector<Blk> blks;
             size_t p = 0, out_total = 0;
             while (p < zin_end) {
-                if (bgzf_seen && zin[p] == 0) { p++; continue; }  // zero padding between members
-                const size_t bs = bgzf_block_size(zin.data() + p, zin_end - p);
+                if (bgzf_seen && zbase[p] == 0) { p++; continue; }  // zero padding between members
+                const size_t bs = bgzf_block_size(zbase + p, zin_end - p);
                 if (bs == 0) break;            // not a BGZF block (or its header is cut off)
                 if (bs < 26 || p + bs > zin_end) { if (bs < 26) { err = "corrupt BGZF block"; return -1; } break; }
-                const uint8_t *b = zin.data() + p;
+                const uint8_t *b = zbase + p;
                 const size_t xlen = b[10] | ((size_t)b[11] << 8), hdr = 12 + xlen;
                 if (hdr + 8 > bs) { err = "corrupt BGZF block"; return -1; }
                 const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
@@ -523,12 +549,18 @@ struct LineSource {
             }
             if (blks.empty()) {
                 if (p > 0) { zin_pos = p; continue; }  // only padding so far: drop it and look again
-                if (zin_end >= 18 && bgzf_block_size(zin.data(), zin_end) == 0) return 0;  // an ordinary gzip member follows
+                if (zin_end >= 18 && bgzf_block_size(zbase, zin_end) == 0) {  // an ordinary gzip member follows
+                    if (map) {  // the sequential path reads the file itself, from here
+                        if (lseek(fd, (off_t)bgzf_map_pos, SEEK_SET) < 0) { err = std::string("lseek: ") + strerror(errno); return -1; }
+                        zin_pos = zin_end = 0; raw_eof = false;
+                    }
+                    return 0;
+                }
                 if (raw_eof) { err = "truncated gzip file"; return -1; }
-                if (zin_end == zin.size()) { err = "corrupt BGZF block"; return -1; }
+                if (zin_end >= zcap) { err = "corrupt BGZF block"; return -1; }
                 continue;  // header or block cut off by the window: read more
             }
-            dst.resize(out_total);
+            dst = take_buffer(out_total);  // (recycled: a fresh vector of this size is zero-filled by one thread, every window)
             uint8_t *out = dst.data();
             std::atomic<size_t> next{0};
             std::atomic<bool> ok{true};
@@ -545,14 +577,14 @@ struct LineSource {
                     const Blk &k = blks[i];
                     bool good;
                     if (own && k.out_len) {
-                        blk_inf.reset(zin.data() + k.whole, k.whole_len);
+                        blk_inf.reset(zbase + k.whole, k.whole_len);
                         size_t pos = 0;
                         const TbkInflate::Status st = blk_inf.run(scratch.data(), &pos, scratch.size(), 0);
                         good = st == TbkInflate::MEMBER_DONE && pos == k.out_len;
                         if (good) memcpy(out + k.out, scratch.data(), k.out_len);
                     } else {
                         inflateReset(&z);
-                        z.next_in = zin.data() + k.in; z.avail_in = (uInt)k.in_len;
+                        z.next_in = const_cast<uint8_t *>(zbase + k.in); z.avail_in = (uInt)k.in_len;
                         z.next_out = out + k.out; z.avail_out = (uInt)k.out_len;
                         const int rc = k.out_len ? inflate(&z, Z_FINISH) : Z_STREAM_END;  // an empty block (the end-of-file marker) has nothing to inflate
                         good = rc == Z_STREAM_END && z.avail_out == 0;
@@ -568,6 +600,7 @@ struct LineSource {
             for (std::thread &t : pool) t.join();
             if (!ok.load()) { err = "inflate: corrupt BGZF block"; return -1; }
             zin_pos = p;
+            *text_len = out_total;
             if (out_total) return 1;
             // only empty blocks (the BGZF end-of-file marker): go on
         }

@@ -39,7 +39,7 @@ extern "C" hipError_t tbk_launch_insert(uint64_t *, uint32_t, uint32_t, uint32_t
 extern "C" hipError_t tbk_launch_contains(TbkTableView, const uint64_t *, uint64_t, uint8_t *, hipStream_t);
 extern "C" hipError_t tbk_launch_entry_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, int, unsigned long long *, int *, hipStream_t);
 extern "C" hipError_t tbk_launch_short_insert(uint64_t *, uint32_t, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, uint32_t, hipStream_t);
-extern "C" hipError_t tbk_launch_full_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, hipStream_t);
+extern "C" hipError_t tbk_launch_full_insert(uint64_t *, uint32_t, uint32_t, TbkMz, int, const uint64_t *, uint64_t, int, unsigned long long *, int *, uint32_t, hipStream_t);
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
@@ -1209,7 +1209,7 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
         const tbk_table *t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
         if (e == hipSuccess) e = (c->guests & TBK_FLAG_FULL)
-                                     ? tbk_launch_full_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, nullptr)
+                                     ? tbk_launch_full_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, 0u, nullptr)
                                      : tbk_launch_entry_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, (c->guests & TBK_FLAG_WIDE) != 0, d_cnt, d_failed, nullptr);
         if (e == hipSuccess) e = hipMemcpy(cnt[list], d_cnt, sizeof cnt[0], hipMemcpyDeviceToHost);  // (synchronises: hapB's inserts read hapA's finished half)
         if (e == hipSuccess && list == 0 && give_up_behind && cnt[0][3] > give_up_behind) {
@@ -1475,6 +1475,7 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
     // keys behind a front - a fifth of a uniform list's keys is, with three keys to a front; runs of overlapping k-mers put
     // well over half there) go on to the key layout's test and to entries.  full_keys = 0: never, 1: whatever the lists look like.
     const double full_pin = o.full_keys;
+    double sample_behind = -1;  // what the bucket sample of a full-key attempt found behind the fronts (-1: none was taken)
     auto try_full_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
         if (!forced && o.table_load > 0) return false;  // (the key layouts' load is pinned: the key layouts are meant)
@@ -1490,6 +1491,35 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
             nb = (uint64_t)(cap / 128.0);
         }
         if (nb > 0x3FFFFFF0ull) nb = 0x3FFFFFF0ull;
+        // Do the lists' keys crowd their buckets?  A sample BY BUCKET first: hapA's list hashed as for the whole table, stored only
+        // where the home bucket lies in the table's first sixteenth (tbk_full_insert_kernel, only_below) - whatever order the list is
+        // in, those lines fill as they would in the whole table.  Uniform keys: 2 % of what is stored lies behind a front (one
+        // list, half the load); runs of overlapping k-mers: a third and more.  2 x 1e9 keys: 0.2 s instead of a 3 s build thrown away.
+        if (!forced && nb >= ((uint64_t)1 << 22)) {
+            const uint32_t sample_nb = (uint32_t)(nb / 16);
+            uint64_t *d_sample = nullptr;
+            unsigned long long *d_cnt = nullptr, cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int *d_failed = nullptr;
+            hipError_t e = hipMalloc((void **)&d_sample, (size_t)sample_nb * 128);
+            if (e == hipSuccess) e = hipMemset(d_sample, 0, (size_t)sample_nb * 128);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, sizeof cnt);
+            if (e == hipSuccess) e = hipMemset(d_cnt, 0, sizeof cnt);
+            if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
+            if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
+            if (e == hipSuccess) e = tbk_launch_full_insert(d_sample, (uint32_t)nb, 0u, z, c->k, a->d_keys, a->num_lines, 0, d_cnt, d_failed, sample_nb, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost);
+            if (d_sample) (void)hipFree(d_sample);
+            if (d_cnt) (void)hipFree(d_cnt);
+            if (d_failed) (void)hipFree(d_failed);
+            if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+            const double f = (double)cnt[3] / (double)std::max<unsigned long long>(1, cnt[2]);
+            if (build_timing) fprintf(stderr, "tbk build: full keys, a sixteenth of the buckets: %llu of %llu slots behind a front (%.1f %%)\n", cnt[3], cnt[2], 100.0 * f);
+            t_last = std::chrono::steady_clock::now();
+            if (f > 4.0 * o.behind_front) {
+                sample_behind = f;  // (the lists cluster: the caller goes on to entries without the key layout's test build)
+                return false;
+            }
+        }
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
         c->mz = z;
@@ -1535,7 +1565,7 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
     // the keys behind an 8-slot front; haplotype-shaped lists: 16 %, uniform ones 1.5 %) skip the key layout's test -
     // building a front-first key table of clustered lists only to measure them takes 2 s at 2 x 3e8 keys, ten times a
     // build of entries - and go to entries at once; lists that do not merge come back here.
-    if (short_behind > o.plainly_clustered && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
+    if ((short_behind > o.plainly_clustered || sample_behind > 4.0 * o.behind_front) && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
         c->layout_builds++;
         lap("(kept)", true);
         c->own_pair();

@@ -273,6 +273,11 @@ tbk_wentry_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint3
                             // meet, and the order that matters - my OR of word 1 before my unlock of word 0 - is kept by waiting for the
                             // OR's return value before the unlock is issued.  Acquire / release at agent scope would make every
                             // insert invalidate or write back an XCD's whole L2: 2e9 keys took 25 s that way.
+                            // What this rests on is the hardware, not the memory model: device-scope atomics on gfx942 / gfx950 are
+                            // performed at the memory side (one point of coherence for all XCDs; MI355X_MICROARCH.md, Global float
+                            // atomics), in the order they arrive there, and a returned atomic has been performed.  What checks it:
+                            // every key of both lists is looked up again after a build - tbk_classifier_verify (the CLI's
+                            // TBK_VERIFY_BUILD=1) and, at 2 x 1e9 keys, the full-membership sweep of tests/test_gpu_scale.py.
                             const unsigned long long cur = __hip_atomic_load(w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (cur & TBK_WENTRY_LOCK) continue;                                   // somebody is looking at this piece: again
                             if (cur != 0 && cur != taken) { next_piece = true; break; }           // another m-mer's entry
@@ -396,7 +401,11 @@ tbk_short_insert_kernel(uint32_t *__restrict__ lines, uint32_t n_buckets, unsign
 // cnt: [0] keys stored, [1] hapB keys left out, [2] slots taken, [3] of those behind a front, [4] forms that left a line.
 __global__ void __launch_bounds__(256)
 tbk_full_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *__restrict__ keys, uint64_t n, int skip_a,
-                       unsigned long long *__restrict__ cnt, int *__restrict__ failed) {
+                       unsigned long long *__restrict__ cnt, int *__restrict__ failed, uint32_t only_below) {
+    // only_below != 0: a SAMPLE BY BUCKET - every key is hashed as for n_buckets lines, but only the forms whose home bucket is
+    // below only_below are stored (the table has that many lines), and a form that finds its line full is counted, not sent on.
+    // Whatever order the list is in, the sampled lines fill exactly as they would in the whole table: what the policy asks to
+    // know before it builds it (do the lists' keys crowd their buckets?) for a sixteenth of the random writes.
     unsigned long long stored = 0, skipped = 0, created = 0, behind = 0, past = 0;
     const int n_pos = tbk_mz_positions(mz);
     const unsigned long long listbit = half ? TBK_FULL_HAPB : 0ull;
@@ -411,6 +420,7 @@ tbk_full_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_
         for (int pi = 0; pi < n_pos && !drop; pi++) {
             if (tbk_tmer_rank(key, mz, pi) != best) continue;
             uint32_t b = tbk_wentry_bucket(tbk_full_mmer(key, mz, pi % mz.w), n_buckets);
+            if (only_below && b >= only_below) continue;
             if (first_form && skip_a && tbk_full_lookup_one(slots, n_buckets, key, b, mz) == 0) { skipped++; drop = true; break; }
             bool done = false;
             for (uint32_t walked = 0; walked <= n_buckets && !done; walked++) {
@@ -438,6 +448,7 @@ tbk_full_insert_kernel(uint64_t *__restrict__ slots, uint32_t n_buckets, uint32_
                     atomicOr(&line[15], TBK_FULL_FLAG);
                     atomicOr(&line[TBK_FULL_SUMMARY], TBK_FULL_FLAG | fbit);
                     past++;
+                    if (only_below) { done = true; break; }
                     b = tbk_next_bucket(key, mz, n_buckets, b, walked == 0);
                 }
             }
@@ -538,6 +549,9 @@ tbk_contains_kernel(TbkTableView t, const uint64_t *__restrict__ keys, uint64_t 
 #endif
 #ifndef TBK_SAMP_UNROLL
 #define TBK_SAMP_UNROLL 4 // j-loop unroll of the mod-sampling variants
+#endif
+#ifndef TBK_FULL_UNROLL
+#define TBK_FULL_UNROLL TBK_SAMP_UNROLL   // ... of the full-key kernels (1: 62 registers with a span of eight - eight waves per SIMD - for sixteen more moves per window)
 #endif
 #ifndef TBK_MIN_WAVES
 #define TBK_MIN_WAVES 5         // waves per SIMD the register allocator must leave room for: single-read passes, front layout ...
@@ -643,9 +657,6 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
 constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
 constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
-#ifndef TBK_SHARE_STARTS
-#define TBK_SHARE_STARTS 1   // entry kernels, single-read passes: neighbouring lanes that start on one line fetch it once (0: each its own)
-#endif
 #ifndef TBK_TMER_LUT
 #define TBK_TMER_LUT 1   // entry kernels with 3w t-mer positions at W = 6 (t = 4): t-mer ranks from a 256-entry table in LDS (0: computed)
 #endif
@@ -1647,8 +1658,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             const uint64_t inside = r_first_end > p_first ? r_first_end - p_first : 0;
             if (inside < 64) bad64 |= ~0ull << inside;
         }
-        // (which lanes walk downwards: the odd ones - a two-read pass - or, in a single-read pass, the even ones: see "Lane starts" below)
-        if ((TBK_SHARE_STARTS && !TWO) ? !(lane & 1u) : ((lane & 1u) && !(TWO && is_strad))) {
+        if ((lane & 1u) && !(TWO && is_strad)) {
             const int sh = 33 - k;
             const unsigned __int128 s_up = R128 >> (2 * sh), r_up = S128 << (2 * sh);
             S128 = s_up; R128 = r_up;
@@ -1722,9 +1732,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
     va[0] = make_ulonglong2(0, 0); va[1] = make_ulonglong2(0, 0);
     uint32_t last_bk = 0x7FFFFFFFu;
     uint32_t qn = 0, qb = 0;
-    constexpr bool STARTS = TBK_SHARE_STARTS && !MULTI && !TWO;  // (single-read passes: every odd lane walks downwards)
 
-#pragma unroll TBK_SAMP_UNROLL
+    constexpr int UNROLL = KIND == 3 ? TBK_FULL_UNROLL : TBK_SAMP_UNROLL;
+#pragma unroll UNROLL
     for (int j = 0; j < TBK_WPL; j++) {
         const uint64_t fs = ((uint64_t)s1 << 32) | s0, bs = ((uint64_t)t3 << 32) | t2;
         if (MULTI) {
@@ -1822,16 +1832,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
 
         // ---- two pair sub-steps ----
         const uint32_t bk0 = pair_bcast<0>(my_bk), bk1 = pair_bcast<1>(my_bk);
-        // Lane starts.  In a single-read pass the EVEN lanes walk their windows downwards: the two lanes of a pair start on
-        // neighbouring windows - lane 2p on the last of its 32, lane 2p + 1 on the first of its own - four times in five in the same
-        // bucket.  Two requests for that line, a few cycles apart in the two load instructions, were BOTH misses and both fetched
-        // from HBM (the L2 does not merge a miss with one in flight: TCC_EA0_RDREQ = TCC_MISS, profiles/r05): 40 M of a launch's
-        // 785 M lines.  In the first step a pair whose two windows name one bucket loads the line once.
-        bool twin = false;
-        if (STARTS && j == 0) twin = (int32_t)bk1 < 0 && bk1 == bk0;  // (both fresh - bit 31 - and the same bucket)
         if ((int32_t)bk0 < 0) va[0] = load_slots(p.t.slots + (uint64_t)(bk0 & 0x7FFFFFFFu) * 16 + sub * 2);
-        if ((int32_t)bk1 < 0 && !twin) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
-        if (STARTS && j == 0 && twin) va[1] = va[0];
+        if ((int32_t)bk1 < 0) va[1] = load_slots(p.t.slots + (uint64_t)(bk1 & 0x7FFFFFFFu) * 16 + sub * 2);
         const uint32_t cm_s[2] = {pair_bcast<0>(cm_ask), pair_bcast<1>(cm_ask)};
         const uint32_t kh_s[2] = {pair_bcast<0>(my_khi), pair_bcast<1>(my_khi)};
         const uint32_t mh_s[2] = {pair_bcast<0>(my_mhi), pair_bcast<1>(my_mhi)};
@@ -2183,12 +2185,12 @@ extern "C" hipError_t tbk_launch_entry_insert(uint64_t *slots, uint32_t n_bucket
 
 
 extern "C" hipError_t tbk_launch_full_insert(uint64_t *slots, uint32_t n_buckets, uint32_t half, TbkMz mz, int k, const uint64_t *d_keys, uint64_t n, int skip_a,
-                                             unsigned long long *d_cnt, int *d_failed, hipStream_t stream) {
+                                             unsigned long long *d_cnt, int *d_failed, uint32_t only_below, hipStream_t stream) {
     if (!tbk_full_geom(k, mz)) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
     uint64_t blocks = (n + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(tbk_full_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, k, d_keys, n, skip_a, d_cnt, d_failed);
+    hipLaunchKernelGGL(tbk_full_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, slots, n_buckets, half, mz, k, d_keys, n, skip_a, d_cnt, d_failed, only_below);
     return hipGetLastError();
 }
 

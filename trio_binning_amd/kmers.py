@@ -397,6 +397,14 @@ class Classifier:
                 "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
                 "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
 
+    def verify(self, kmers_hap_a: Optional[HashSet] = None, kmers_hap_b: Optional[HashSet] = None) -> dict:
+        """Every line of both lists through the finished table, against the lists' standalone tables of verbatim keys
+        (``tbk_classifier_verify``): {"lines", "count_a", "count_b", "bad_lines", "first_bad"}; raises nothing - the caller decides."""
+        a, b = kmers_hap_a or self._a, kmers_hap_b or self._b
+        out = (C.c_uint64 * 5)()
+        check(lib.tbk_classifier_verify(self._h, a._h, b._h, out))
+        return {"lines": out[0], "count_a": out[1], "count_b": out[2], "bad_lines": out[3], "first_bad": None if out[4] == 2 ** 64 - 1 else out[4]}
+
     def classify_batch(self, bases: np.ndarray, offsets: np.ndarray) -> np.ndarray:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
