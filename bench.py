@@ -785,16 +785,19 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             try:
                 cal = json.load(open(cfile))
                 # the calibration row whose footprint is closest to this table's
-                rows = cal["random_lines_Glines_per_s"]
+                # (round 5: the gather in the probe kernels' own shape - tbk_calib_gather_pairs, tools/calib_ceilings.py - where it was
+                # measured; the best shape of the footprint nearest to this table's)
+                rows = cal.get("random_lines_tuned_Glines_per_s") or cal["random_lines_Glines_per_s"]
                 key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
-                ceiling = rows[key]["line128"]
+                ceiling = rows[key].get("best", rows[key].get("line128"))
                 roofline["random_line_ceiling_footprint"] = key
                 roofline["random_lines_Gps"] = round(traffic / 128 / single_s / 1e9, 2)
                 roofline["random_line_ceiling_Gps"] = ceiling
                 roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
-                roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / cal["guide_stream_GBps"], 3)
-                roofline["random_line_note"] = ("the ceiling is what a pure gather microbenchmark sustains at this footprint (tools/calib_footprint.py), a yardstick and not a "
-                                                "bound: a kernel with more loads in flight can pass it (the entry kernels do, by 4-8 %); the physical bound is traffic_frac_of_peak")
+                roofline["measured_stream_GBps"] = cal.get("stream_tuned_GBps", cal["guide_stream_GBps"])
+                roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / roofline["measured_stream_GBps"], 3)
+                roofline["random_line_note"] = ("the ceiling is what a pure gather in the probe kernels' own request shape sustains at this footprint (one-wave blocks, two lanes x 16 bytes "
+                                                "of a line, the best of 1-8 lines in flight per pair and 4-8 waves per SIMD: tools/calib_ceilings.py); boxes of the pool differ by +-4 %")
             except Exception:
                 pass
 

@@ -10,12 +10,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src, dst = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 KEEP = ["bench_default.json", "bench_default_key_layout.json", "bench_haplotypes.json", "bench_2ranks_shared_device.json", "bench_2ranks_torchrun.json", "bench_8ranks_shared_device.json", "bench_strong.json", "bench_count.json", "bench_3rings.json", "bench_c5_uniform.json", "bench_c5_haplotypes.json",
         "kernel_stats.csv", "count_kernel_stats.csv", "kernel_trace_by_launch_size.json", "pmc_summary_uniform.json", "pmc_summary_haplotypes.json",
-        "reader_hifi.json", "cli_configs1.json", "cli_configs1_haplotypes.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json"]
+        "reader_hifi.json", "cli_configs1.json", "cli_configs1_haplotypes.json", "cli_configs1_one_small_disk.json", "cli_lists_configs2.json", "cli_gz_input.json", "cli_gz_configs1.json", "calib_ceilings.json",
+        "bench_c5_uniform.json", "bench_c5_uniform_key_layout.json", "bench_c5_haplotypes.json", "bench_c5_lognormal_uniform.json", "bench_c5_lognormal_haplotypes.json", "ab_full_unroll.log", "bench_count.json", "bench_3rings.json"]
 for name in KEEP:
     p = os.path.join(src, name)
     if os.path.isfile(p) and os.path.getsize(p) > 0:
@@ -43,6 +44,16 @@ try:
         open(os.path.join(dst, "bench_under_rocprofv3.json"), "w").write(lines[-1])
 except OSError:
     pass
+
+
+# the ceilings of profiles/calibration.json (tools/calib_ceilings.py: the gather in the probe kernels' shape, the tuned streaming read)
+try:
+    _cal = json.load(open(os.path.join(ROOT, "profiles", "calibration.json")))
+    STREAM_TBPS = _cal.get("stream_tuned_GBps", _cal["guide_stream_GBps"]) / 1e3
+    _rows = _cal.get("random_lines_tuned_Glines_per_s") or {}
+    GATHER_GLPS = _rows.get("33GB", {}).get("best") or 47.75
+except Exception:
+    STREAM_TBPS, GATHER_GLPS = 6.29, 47.75
 
 
 def load(name):
@@ -99,8 +110,8 @@ def col(b, p):
         f"{r['alg_bytes_per_launch'] / 1e9:.1f} / {r['achieved']} / **{r['frac']}** (two-probe reading, P = 2: {r.get('frac_P2_two_probe_reading')})",
         f"{hbm / 1e9:.1f} / {p.get('hbm_bytes_per_launch_from_TCC_MISS', 0) / 1e9:.1f}" if hbm else "-",
         f"{hbm / w:.1f} / {lines:.4f}" if hbm and lines else "-",
-        f"{hbm / ms / 1e9:.2f} / {hbm / ms / 1e9 / 6.29:.2f}" if hbm else "-",
-        f"{p['TCC_MISS_sum'] / ms / 1e6:.1f} / {p['TCC_MISS_sum'] / ms / 1e6 / 47.75:.2f}" if p.get("TCC_MISS_sum") else "-",
+        f"{hbm / ms / 1e9:.2f} / {hbm / ms / 1e9 / STREAM_TBPS:.2f}" if hbm else "-",
+        f"{p['TCC_MISS_sum'] / ms / 1e6:.1f} / {p['TCC_MISS_sum'] / ms / 1e6 / GATHER_GLPS:.2f}" if p.get("TCC_MISS_sum") else "-",
         f"{insts('SQ_INSTS_VALU')} / {insts('SQ_INSTS_SALU')} / {insts('SQ_INSTS_VMEM_RD')}",
         f"{p['SQ_WAIT_ANY'] / p['SQ_WAVE_CYCLES']:.2f}" if p.get("SQ_WAVE_CYCLES") else "-",
         f"{g(b, 'parity', 'gpu_equals_cpu')} on {g(b, 'parity', 'reads_checked_against_the_oracle')} reads; transfers agree: {g(b, 'parity', 'packed_and_ascii_transfers_agree')}",
@@ -111,7 +122,7 @@ def col(b, p):
 
 rows = ["`value`: host-fed classify stage (Gbases/s)", "`kernel_resident` (Gbases/s)", "table", "single-read probe kernel, HIP events inside the timed region (ms per launch)",
         "its algorithmic bytes per launch (GB, P = 1: 9 B per window) / `roofline.achieved` (GB/s) / `frac`", "its HBM bytes per launch: FETCH_SIZE x 1024 x 2 / TCC_MISS x 128 B (GB)",
-        "bytes per window / 128-B lines per window", "HBM traffic rate (TB/s) / of the 6.29 TB/s stream ceiling", "random 128-B lines (G/s) / of the 47.75 G/s a pure gather reaches",
+        "bytes per window / 128-B lines per window", f"HBM traffic rate (TB/s) / of the {STREAM_TBPS:.2f} TB/s a tuned streaming read reaches (profiles/calibration.json)", f"random 128-B lines (G/s) / of the {GATHER_GLPS:.2f} G/s a gather in the kernels' own shape reaches",
         "VALU / SALU / VMEM-read instructions per window", "SQ_WAIT_ANY / SQ_WAVE_CYCLES", "parity in the run (GPU counts == oracle)",
         "CPU baseline, oracle: 1 thread / 16 CPUs / rolling, 16 CPUs (Mbases/s)", "same stage fed with ASCII batches: packed by the feeder / ASCII over PCIe (Gbases/s)"]
 cu, ch = col(u, pu), col(h, ph)

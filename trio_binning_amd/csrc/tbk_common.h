@@ -455,7 +455,7 @@ TBK_HD bool tbk_entry_compatible(uint64_t slot, TbkEntryKey e, uint32_t hapb, Tb
 }
 
 TBK_HD uint32_t tbk_entry_bucket(uint32_t cm, uint32_t n_buckets) { return tbk_reduce(tbk_mmer_hash(cm), n_buckets); }
-// an entry that finds its list's eight slots of a line taken goes to a second-choice bucket (a hash of the m-mer: every
+// an entry that finds the line's sixteen slots taken goes to a second-choice bucket (a hash of the m-mer: every
 // window that asks for this m-mer follows the same path), then linearly on
 TBK_HD uint32_t tbk_entry_next_bucket(uint32_t cm, uint32_t n_buckets, uint32_t b, bool leaving_home) {
     if (leaving_home) return tbk_reduce(tbk_mix32((uint64_t)cm ^ 0xA5A5A5A500000000ull), n_buckets);

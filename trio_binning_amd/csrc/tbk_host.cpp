@@ -403,7 +403,7 @@ struct tbk_classifier {
     int replica_copies = 0;      // 1: this classifier's table is a copy made by tbk_classifier_replicate (hipMemcpyPeer), 0: built here or shared
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
-    uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line (entry layout: entries behind a two-slot front)
+    uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line (entry layouts: entries behind the line's 32-byte front - four narrow entries, two wide ones; short and full keys: keys behind the front's seven / three)
     uint64_t entries_a = 0, entries_b = 0;  // entry layout (TBK_FLAG_ENTRY): slots the lists' keys take (a run of overlapping keys is one entry)
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
     uint32_t over_mask = 0;      // short keys (TBK_FLAG_SHORT): the overflow table behind the lines has over_mask + 1 slots of 8 bytes
@@ -1390,7 +1390,7 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
         const TbkMz keep_mz = c->mz;
         const uint32_t keep_flags = c->guests;
         const double el = wide ? std::min(3.5, std::max(0.02, o.wentry_load > 0 ? o.wentry_load : 0.25))   // (four entries per list and line)
-                               : std::min(7.0, std::max(0.02, o.entry_load > 0 ? o.entry_load : 0.5));  // (tests crowd the lines: 8 slots per list)
+                               : std::min(7.0, std::max(0.02, o.entry_load > 0 ? o.entry_load : 0.5));  // (tests crowd the lines: sixteen slots that both lists share)
         c->mz = z;
         c->guests = TBK_FLAG_ENTRY | (wide ? TBK_FLAG_WIDE : 0u);
         double want = (double)n_big / ((wide ? 5.0 : 4.0) * el);

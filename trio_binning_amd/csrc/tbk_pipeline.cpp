@@ -81,6 +81,7 @@ struct tbk_pipeline {
     bool stop = false;
     std::vector<uint64_t> batches_by_slot;         // how many batches each ring took (stats)
     std::vector<int> numa_node, numa_cpus;         // per ring: the device's NUMA node (-1 unknown) and the CPUs its feeder is bound to (0: not bound)
+    int pack_share = 1;                            // host threads a feeder packs an ASCII batch with
 };
 
 extern "C" int tbk_numa_bind_to_device(int device, int *node_out, int *cpus_out);
@@ -96,7 +97,12 @@ static void feeder_loop(tbk_pipeline *p, int slot) {
     const int ring = rg.depth;
     // this thread packs and stages its device's batches and allocates the ring's pinned buffers (at its first submit):
     // it runs on the CPUs of the socket the device hangs off (tbk_host.cpp "NUMA placement"; unknown node: anywhere)
-    if (rg.c) (void)tbk_numa_bind_to_device(tbk_classifier_device(rg.c), &p->numa_node[(size_t)slot], &p->numa_cpus[(size_t)slot]);
+    if (rg.c) {
+        (void)tbk_numa_bind_to_device(tbk_classifier_device(rg.c), &p->numa_node[(size_t)slot], &p->numa_cpus[(size_t)slot]);
+        // the packers this feeder starts inherit its mask: no more of them than the CPUs it is bound to
+        const int cpus = p->numa_cpus[(size_t)slot];
+        if (cpus > 0 && cpus < p->pack_share) (void)tbk_classifier_set_pack_threads_(rg.c, cpus);
+    }
     std::deque<std::pair<uint64_t, Job *>> flying;  // (ring ticket, job), oldest first
     auto finish_oldest = [&]() {
         auto [tk, job] = flying.front();
@@ -179,6 +185,7 @@ extern "C" int tbk_pipeline_create_opts(const tbk_table *a, const tbk_table *b, 
     p->numa_node.assign((size_t)n_devices, -1); p->numa_cpus.assign((size_t)n_devices, 0);
     // an ASCII batch is packed by its feeder with this share of the host threads
     const int share = tbk_host_threads_per_feeder_(n_devices);
+    p->pack_share = share;
     for (int i = 0; i < n_devices; i++) {
         tbk_classifier *c = p->cls[(size_t)i];
         (void)tbk_classifier_set_pack_threads_(c, share);
