@@ -13,7 +13,7 @@
 enum {
     OP_XOR, OP_MUL_LO, OP_MUL_HI, OP_MUL_U24, OP_MAD_U24, OP_LSHR64, OP_LSHL_ADD64, OP_CMP_EQ64, OP_CMP_EQ32, OP_CMP_GT64, OP_DPP, OP_XOR_DPP,
     OP_BFI, OP_MIN3, OP_BITOP3, OP_BFE, OP_ALIGNBIT, OP_CNDMASK, OP_BCNT, OP_AND_OR, OP_MAD64, OP_PERM, OP_FFBH, OP_XOR_SDWA, OP_ADD3,
-    OP_LSHL_OR, OP_S_OR64, OP_S_BCNT, OP_S_AND32, OP_MIX_VS, OP_COUNT
+    OP_LSHL_OR, OP_S_OR64, OP_S_BCNT, OP_S_AND32, OP_MIX_VS, OP_CNDMASK_SGPR, OP_CMP_CNDMASK, OP_CMP_ONLY, OP_MIX_XOR_CND, OP_SUBB, OP_COUNT
 };
 
 template <int OP>
@@ -52,6 +52,25 @@ __global__ void __launch_bounds__(64) rate_kernel(uint64_t *out, int trips, uint
         if (OP == OP_BFE) { V1("v_bfe_u32 %0, %0, %1, 10") }
         if (OP == OP_ALIGNBIT) { V1("v_alignbit_b32 %0, %1, %0, 2") }
         if (OP == OP_CNDMASK) { V1("v_cndmask_b32 %0, %1, %0, vcc") }
+        if (OP == OP_CNDMASK_SGPR) {  // the mask in a scalar pair that nothing writes (the e64 form)
+            REP4(asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r0) : "v"(a32), "s"(seed));, asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r1) : "v"(a32), "s"(seed));,
+                 asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r2) : "v"(a32), "s"(seed));, asm volatile("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(r3) : "v"(a32), "s"(seed));)
+        }
+        if (OP == OP_CMP_CNDMASK) {  // a select as the compiler writes it: compare into vcc, then v_cndmask (two instructions per accumulator)
+            REP4(asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r0) : "v"(a32) : "vcc");, asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r1) : "v"(a32) : "vcc");,
+                 asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r2) : "v"(a32) : "vcc");, asm volatile("v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r3) : "v"(a32) : "vcc");)
+        }
+        if (OP == OP_CMP_ONLY) {
+            REP4(asm volatile("v_cmp_lt_u32 vcc, %1, %0" : "+v"(r0) : "v"(a32) : "vcc");, asm volatile("v_cmp_lt_u32 vcc, %1, %0" : "+v"(r1) : "v"(a32) : "vcc");,
+                 asm volatile("v_cmp_lt_u32 vcc, %1, %0" : "+v"(r2) : "v"(a32) : "vcc");, asm volatile("v_cmp_lt_u32 vcc, %1, %0" : "+v"(r3) : "v"(a32) : "vcc");)
+        }
+        if (OP == OP_MIX_XOR_CND) {  // three v_xor and one v_cndmask per accumulator round: does the slow one hide among others?
+            REP4(asm volatile("v_xor_b32 %0, %1, %0\n v_xor_b32 %0, %2, %0\n v_xor_b32 %0, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r0) : "v"(a32), "v"(b32));,
+                 asm volatile("v_xor_b32 %0, %1, %0\n v_xor_b32 %0, %2, %0\n v_xor_b32 %0, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r1) : "v"(a32), "v"(b32));,
+                 asm volatile("v_xor_b32 %0, %1, %0\n v_xor_b32 %0, %2, %0\n v_xor_b32 %0, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r2) : "v"(a32), "v"(b32));,
+                 asm volatile("v_xor_b32 %0, %1, %0\n v_xor_b32 %0, %2, %0\n v_xor_b32 %0, %1, %0\n v_cndmask_b32 %0, %1, %0, vcc" : "+v"(r3) : "v"(a32), "v"(b32));)
+        }
+        if (OP == OP_SUBB) { V1("v_subb_co_u32 %0, vcc, %1, %0, vcc") }
         if (OP == OP_BCNT) { V1("v_bcnt_u32_b32 %0, %1, %0") }
         if (OP == OP_AND_OR) { V1("v_and_or_b32 %0, %1, %0, %2") }
         if (OP == OP_MAD64) {  // (writes a carry: vcc is declared clobbered - undeclared, the loop around it never ended)
@@ -106,6 +125,18 @@ int main(int argc, char **argv) {
     hipMalloc(&d_out, 64);
     printf("waves per SIMD: %d\n", g_waves);
     const double base = run<OP_XOR>("v_xor_b32", d_out, 0);
+    if (argc > 2) {  // (`valu_rates 8 select`: what a select costs - round 5)
+        run<OP_MIN3>("v_min3_u32", d_out, base);
+        run<OP_BFI>("v_bfi_b32", d_out, base);
+        run<OP_CMP_EQ32>("v_cmp_eq_u32", d_out, base);
+        run<OP_CNDMASK>("v_cndmask_b32 vcc", d_out, base);
+        run<OP_CNDMASK_SGPR>("v_cndmask e64 sgpr", d_out, base);
+        run<OP_CMP_ONLY>("v_cmp_lt_u32 vcc", d_out, base);
+        run<OP_CMP_CNDMASK>("cmp+cndmask (x2 instr)", d_out, base);
+        run<OP_MIX_XOR_CND>("3 xor + 1 cndmask (x4)", d_out, base);
+        run<OP_SUBB>("v_subb_co_u32", d_out, base);
+        return 0;
+    }
     run<OP_MUL_LO>("v_mul_lo_u32", d_out, base);
     run<OP_MUL_HI>("v_mul_hi_u32", d_out, base);
     run<OP_MUL_U24>("v_mul_u32_u24", d_out, base);
@@ -125,6 +156,11 @@ int main(int argc, char **argv) {
     run<OP_BFE>("v_bfe_u32", d_out, base);
     run<OP_ALIGNBIT>("v_alignbit_b32", d_out, base);
     run<OP_CNDMASK>("v_cndmask_b32", d_out, base);
+    run<OP_CNDMASK_SGPR>("v_cndmask e64 sgpr", d_out, base);
+    run<OP_CMP_ONLY>("v_cmp_lt_u32 vcc", d_out, base);
+    run<OP_CMP_CNDMASK>("cmp+cndmask (x2 instr)", d_out, base);
+    run<OP_MIX_XOR_CND>("3 xor + 1 cndmask (x4)", d_out, base);
+    run<OP_SUBB>("v_subb_co_u32", d_out, base);
     run<OP_BCNT>("v_bcnt_u32_b32", d_out, base);
     run<OP_AND_OR>("v_and_or_b32", d_out, base);
     run<OP_ADD3>("v_add3_u32", d_out, base);
