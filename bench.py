@@ -36,8 +36,11 @@ The JSON line also carries, at every N,
   roofline      the dominant kernel's (the single-read probe kernel's) algorithmic bytes per launch / its
                 HIP-event-timed average duration inside the timed region, against the 8 TB/s HBM peak.  `frac` is
                 SURVEY §8d's reading for this design - one paired table probed once per window, P = 1: 9 bytes
-                per window; the two-probe reading (P = 2: 17 bytes) is printed beside it.  `traffic` is replayed
-                from the round's PMC passes only when those ran on this tree's kernels (sha256 of their machine code);
+                per window; the two-probe reading (P = 2: 17 bytes) is printed beside it.  `traffic` (N = 1) is measured
+                in the run: when the timed legs are over, rank 0 repeats four steps of the workload as a child process under
+                `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (live_traffic; --live-pmc off skips it); where that pass cannot
+                be made, the round's PMC record under profiles/ is replayed - only when it was taken on this tree's kernels
+                (sha256 of their machine code) - and `traffic_source` says which of the two it was;
   parity        every rank classifies the same fixed reads (read 0 .. 4095 of the generator) through the
                 host-fed path; the count checksums must agree across ranks, and rank 0 checks the counts
                 read for read against the oracle;
@@ -124,6 +127,11 @@ def parse(argv=None):
     ap.add_argument("--stream-batch-reads", type=int, default=65_536, help="reads per host batch of the streaming leg")
     ap.add_argument("--stream-seconds", type=float, default=2.0)
     ap.add_argument("--calibrate", action="store_true", help="also run the random-line gather calibration")
+    ap.add_argument("--live-pmc", choices=["auto", "on", "off"], default="auto",
+                    help="roofline.traffic from a counter pass of THIS run: when the timed legs are done, rank 0 starts `rocprofv3 --kernel-trace --pmc "
+                         "FETCH_SIZE -- python3 bench.py <the same workload, 4 steps>` as a child process and prices the single-read kernel's HBM "
+                         "bytes from its counter file.  auto: N = 1, fixed read lengths, weak scaling, rocprofv3 on PATH, not itself under a profiler; "
+                         "off (or a failed pass): the record of profiles/pmc_traffic*.json is replayed when it was taken on these very kernels")
     ap.add_argument("--share-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
     # --path count
@@ -322,6 +330,11 @@ def main():
         dist.close()
         return
     out = run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement)
+    if rank == 0 and world == 1:
+        note = live_traffic(args, out)
+        if note:
+            out["roofline"]["live_counter_pass"] = note
+    out["roofline"].pop("_pricing", None)
     if rank == 0 and world == 1 and not args.no_realistic and args.lists == "uniform" and args.scaling == "weak":
         out["realistic_lists"] = realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement)
     dist.barrier()
@@ -468,6 +481,133 @@ def kernel_resources(stats):
         return None
     except Exception:
         return None
+
+
+def is_single_read_probe(name):
+    """The dominant kernel by its demangled name: tbk_probe_kernel<W, M64, SAMP, FRONT, MULTI = false> or the entry kernels'
+    tbk_probe_entry_kernel<W, MULTI = false, TWO = false, LW, KIND> (passes inside one read)."""
+    import re
+
+    n = name.replace(" ", "")
+    return ("tbk_probe_kernel" in n and n.endswith("false>(ProbeArgs)")) or re.search(r"tbk_probe_entry_kernel<\d+,false,false,\d+(,\d+)?>\(ProbeArgs\)", n) is not None
+
+
+def counter_means(csv_files):
+    """Per-launch means of a rocprofv3 --pmc pass (its *_counter_collection.csv) over the FULL-SIZE launches of the single-read
+    kernel: a bench run also classifies the parity reads (small launches), which must not dilute a per-launch figure.
+    -> ({counter: mean}, {grid, launches, the row's register columns})"""
+    import collections
+    import csv
+
+    rows = []
+    for f in csv_files:
+        rows += [r for r in csv.DictReader(open(f)) if is_single_read_probe(r["Kernel_Name"])]
+    if not rows:
+        return {}, {}
+    full = max(int(r["Grid_Size"]) for r in rows)
+    agg, meta = collections.defaultdict(list), {}
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta = {"VGPR_Count_as_rocprofv3_reports_it": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
+                    "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80], "launches_averaged": len(agg[r["Counter_Name"]])}
+    return {k: sum(v) / len(v) for k, v in agg.items()}, meta
+
+
+def live_traffic(args, out):
+    """`roofline.traffic` from counters of this run: the same workload for four steps, as a child process under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (counters in a pass of their own, the program right behind `--`, cwd /tmp:
+    MI355X_MICROARCH.md's HBM recipe), started when the timed legs are over and their device memory is released.  HBM bytes
+    of one full-size launch of the single-read kernel = FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies a 128-byte request at 64).
+    Returns a note for `traffic_source` when the pass could not be made (the replayed record, if any, then stands)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if args.live_pmc == "off":
+        return "live counter pass switched off (--live-pmc off)"
+    if args.live_pmc == "auto":
+        if args.scaling != "weak" or args.read_lengths != "fixed" or args.rings > 1:
+            return "no live counter pass for this workload (--live-pmc on asks for one)"
+        if any(key.startswith(("ROCPROF", "ROCP_")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            return "no live counter pass: this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return "no live counter pass: rocprofv3 not found"
+    skip, child_args, it = {"--gpus": 1, "--steps": 1, "--warmup": 1, "--min-timed-s": 1, "--live-pmc": 1, "--timed-path": 1, "--cpu-seconds": 1,
+                            "--no-cpu-baseline": 0, "--no-streaming": 0, "--no-realistic": 0, "--no-sweep": 0, "--calibrate": 0}, [], iter(sys.argv[1:])
+    for a in it:
+        name = a.split("=", 1)[0]
+        if name in skip:
+            if skip[name] and "=" not in a:
+                next(it, None)
+            continue
+        child_args.append(a)
+    child_args += ["--steps", "4", "--warmup", "1", "--min-timed-s", "0", "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--no-sweep",
+                   "--live-pmc", "off", "--timed-path", "resident"]
+    tmp = tempfile.mkdtemp(prefix="tbk_live_pmc_", dir="/tmp")
+    t0 = time.time()
+    try:
+        env = dict(os.environ, TMPDIR="/tmp", TBK_SKIP_BUILD="1")
+        cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py")] + child_args
+        run = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+        line = next((ln for ln in reversed(run.stdout.splitlines()) if ln.startswith('{"metric"')), None)
+        means, meta = counter_means(sorted(glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)))
+        if run.returncode != 0 or line is None or "FETCH_SIZE" not in means:
+            return f"live counter pass failed (rocprofv3 exit {run.returncode}, counters {sorted(means)}): {run.stderr[-300:]!r}"
+        child = json.loads(line)
+        rf, crf = out["roofline"], child["roofline"]
+        if crf["windows_per_launch"] != rf["windows_per_launch"] or child["config"]["table_bytes_per_gpu"] != out["config"]["table_bytes_per_gpu"]:
+            return "live counter pass ran another launch shape than the timed legs; not used"
+        traffic = means["FETCH_SIZE"] * 1024 * 2
+        rf["traffic"] = int(traffic)
+        rf["traffic_source"] = (f"measured in this run: when the timed legs were over, rank 0 ran this workload for four steps as a child process under `rocprofv3 --kernel-trace --pmc "
+                                f"FETCH_SIZE` ({time.time() - t0:.0f} s; counters in a pass of their own) - FETCH_SIZE x 1024 x 2 (gfx950 tallies a 128-byte request at 64 bytes: "
+                                f"MI355X_MICROARCH.md, HBM), mean over the {meta['launches_averaged']} full-size launches of the single-read kernel (grid {meta['Grid_Size']})")
+        rf["traffic_fetch_size_kib_raw"] = round(means["FETCH_SIZE"], 1)
+        price_traffic(rf, traffic)
+        return None
+    except Exception as e:  # a profiler that cannot run here must not cost the bench line
+        return f"live counter pass failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def price_traffic(roofline, traffic):
+    """HBM bytes of one launch of the dominant kernel against what the memory system delivers (PMC-measured bytes over this run's
+    kernel time; 128-byte lines per second against the gather ceiling of profiles/calibration.json)."""
+    pr = roofline["_pricing"]
+    single_s, alg_bytes = pr["single_s"], pr["alg_bytes"]
+    stats = {"table_bytes": pr["table_bytes"]}
+    if traffic is not None and single_s > 0:
+        # where the kernel sits against what the memory system can actually deliver: PMC-measured
+        # bytes per launch over this run's kernel time, and 128-byte lines per second against the
+        # random-line ceiling measured by tools/calib_footprint.py (profiles/calibration.json)
+        roofline["traffic_GBps"] = round(traffic / single_s / 1e9, 1)
+        roofline["traffic_frac_of_peak"] = round(traffic / single_s / 1e9 / HBM_PEAK_GBPS, 4)
+        roofline["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
+        cfile = os.path.join(ROOT, "profiles", "calibration.json")
+        if os.path.isfile(cfile):
+            try:
+                cal = json.load(open(cfile))
+                # the calibration row whose footprint is closest to this table's
+                # (round 5: the gather in the probe kernels' own shape - tbk_calib_gather_pairs, tools/calib_ceilings.py - where it was
+                # measured; the best shape of the footprint nearest to this table's)
+                rows = cal.get("random_lines_tuned_Glines_per_s") or cal["random_lines_Glines_per_s"]
+                key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
+                ceiling = rows[key].get("best", rows[key].get("line128"))
+                roofline["random_line_ceiling_footprint"] = key
+                roofline["random_lines_Gps"] = round(traffic / 128 / single_s / 1e9, 2)
+                roofline["random_line_ceiling_Gps"] = ceiling
+                roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
+                roofline["measured_stream_GBps"] = cal.get("stream_tuned_GBps", cal["guide_stream_GBps"])
+                roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / roofline["measured_stream_GBps"], 3)
+                roofline["random_line_note"] = ("the ceiling is what a pure gather in the probe kernels' own request shape sustains at this footprint (one-wave blocks, two lanes x 16 bytes "
+                                                "of a line, the best of 1-8 lines in flight per pair and 4-8 waves per SIMD: tools/calib_ceilings.py); boxes of the pool differ by +-4 %")
+            except Exception:
+                pass
+
 
 
 def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, placement):
@@ -773,33 +913,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "kernel_only_gbases_per_s": round(bases_per_launch / probe_s / 1e9, 2) if probe_s > 0 else None,
     }
     roofline["kernel_resources"] = kernel_resources(stats)
-    if traffic is not None and single_s > 0:
-        # where the kernel sits against what the memory system can actually deliver: PMC-measured
-        # bytes per launch over this run's kernel time, and 128-byte lines per second against the
-        # random-line ceiling measured by tools/calib_footprint.py (profiles/calibration.json)
-        roofline["traffic_GBps"] = round(traffic / single_s / 1e9, 1)
-        roofline["traffic_frac_of_peak"] = round(traffic / single_s / 1e9 / HBM_PEAK_GBPS, 4)
-        roofline["traffic_over_algorithmic"] = round(traffic / alg_bytes, 3)
-        cfile = os.path.join(ROOT, "profiles", "calibration.json")
-        if os.path.isfile(cfile):
-            try:
-                cal = json.load(open(cfile))
-                # the calibration row whose footprint is closest to this table's
-                # (round 5: the gather in the probe kernels' own shape - tbk_calib_gather_pairs, tools/calib_ceilings.py - where it was
-                # measured; the best shape of the footprint nearest to this table's)
-                rows = cal.get("random_lines_tuned_Glines_per_s") or cal["random_lines_Glines_per_s"]
-                key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
-                ceiling = rows[key].get("best", rows[key].get("line128"))
-                roofline["random_line_ceiling_footprint"] = key
-                roofline["random_lines_Gps"] = round(traffic / 128 / single_s / 1e9, 2)
-                roofline["random_line_ceiling_Gps"] = ceiling
-                roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
-                roofline["measured_stream_GBps"] = cal.get("stream_tuned_GBps", cal["guide_stream_GBps"])
-                roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / roofline["measured_stream_GBps"], 3)
-                roofline["random_line_note"] = ("the ceiling is what a pure gather in the probe kernels' own request shape sustains at this footprint (one-wave blocks, two lanes x 16 bytes "
-                                                "of a line, the best of 1-8 lines in flight per pair and 4-8 waves per SIMD: tools/calib_ceilings.py); boxes of the pool differ by +-4 %")
-            except Exception:
-                pass
+    roofline["_pricing"] = {"single_s": single_s, "alg_bytes": alg_bytes, "table_bytes": stats["table_bytes"]}   # (price_traffic's inputs; main() drops it)
+    price_traffic(roofline, traffic)
 
     if want_cpu and L > 2_000_000:
         # the CPU sample works in whole reads; one read of this length is minutes of oracle time

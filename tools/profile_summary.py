@@ -19,30 +19,17 @@ import sys
 out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 
 
-def is_single_read_probe(name):
-    """The dominant kernel: tbk_probe_kernel<W, M64, SAMP, FRONT, MULTI = false> (passes inside one read)."""
-    n = name.replace(" ", "")
-    # (the entry kernels: tbk_probe_entry_kernel<W, MULTI, TWO, KIND, LW> - KIND 0 narrow entries, 1 wide entries, 2 short keys; LW 2 or 3: t-mer positions per span)
-    return ("tbk_probe_kernel" in n and n.endswith("false>(ProbeArgs)")) or re.search(r"tbk_probe_entry_kernel<\d+,false,false,\d+(,\d+)?>\(ProbeArgs\)", n) is not None
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import counter_means, is_single_read_probe, kernel_fingerprint  # noqa: E402
 
 
 def probe_means(pattern):
-    """Per-launch means over the FULL-SIZE launches of the single-read kernel: a bench run also classifies the
-    4096 parity reads (two small launches), which must not dilute a per-launch figure."""
-    rows = []
-    for f in sorted(glob.glob(os.path.join(out_dir, pattern, "*", "*_counter_collection.csv"))):
-        rows += [r for r in csv.DictReader(open(f)) if is_single_read_probe(r["Kernel_Name"])]
-    if not rows:
-        return {}, {}
-    full = max(int(r["Grid_Size"]) for r in rows)
-    agg, meta = collections.defaultdict(list), {}
-    for r in rows:
-        if int(r["Grid_Size"]) == full:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            meta = {"VGPR_Count_as_rocprofv3_reports_it": r.get("VGPR_Count"), "SGPR_Count": r.get("SGPR_Count"), "LDS_Block_Size": r.get("LDS_Block_Size"),
-                    "Grid_Size": r.get("Grid_Size"), "Kernel_Name": r["Kernel_Name"][:80], "launches_averaged": len(agg[r["Counter_Name"]]),
-                    "VGPR_note": "rocprofv3's VGPR column is not the allocation: the code object's .vgpr_count, LDS bytes and the waves per SIMD they allow are in the bench line (roofline.kernel_resources) and below (kernel_resources)"}
-    return {k: sum(v) / len(v) for k, v in agg.items()}, meta
+    """Per-launch means over the FULL-SIZE launches of the single-read kernel (bench.counter_means)."""
+    means, meta = counter_means(sorted(glob.glob(os.path.join(out_dir, pattern, "*", "*_counter_collection.csv"))))
+    if meta:
+        meta["VGPR_note"] = ("rocprofv3's VGPR column is not the allocation: the code object's .vgpr_count, LDS bytes and the waves per SIMD they allow are in the bench line "
+                             "(roofline.kernel_resources) and below (kernel_resources)")
+    return means, meta
 
 
 def trace_summary(name, dst):
@@ -89,9 +76,6 @@ for lists in ("uniform", "haplotypes"):
         summary["windows_per_launch"] = windows
         summary["lines_per_window"] = round(summary.get("TCC_MISS_sum", 0) / windows, 4)
         cfg = bench["config"]
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-        from bench import kernel_fingerprint
-
         traffic = {
             "kernel": "tbk_probe_kernel<single-read>",
             "kernel_sha256": kernel_fingerprint(),  # bench.py replays this record only on these very kernels (hash of their machine code)

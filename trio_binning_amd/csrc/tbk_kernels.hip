@@ -1755,7 +1755,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             for (int s = 0; s < 2; s++) if (strad & (0x5555555555555555ull << s)) own1[s] &= ~(pair_any(strad) * 3ull);  // (both bits of that pair)
         }
         bool ok = (bad_lo & badk) == 0;
-        const uint32_t bad_lo_now = bad_lo;
+        [[maybe_unused]] const uint32_t bad_lo_now = bad_lo;
         if (TWO) {
             const bool cross = (uint32_t)j < jb_s && (uint32_t)(j + k) > jb_s;
             ok = ok && !(cross && is_strad);
