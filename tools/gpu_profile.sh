@@ -12,11 +12,6 @@ export TBK_SKIP_BUILD=1
 # the same lists in the key layout (what they got before short keys): the A/B on this box
 ( time TBK_SHORT=0 timeout 900 python bench.py --no-realistic --no-streaming --min-timed-s 5 --cpu-seconds 4 ) > gpurun_out/bench_default_key_layout.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default_key_layout.log | tail -1 > gpurun_out/bench_default_key_layout.json
 ( time timeout 900 python bench.py --lists haplotypes ) > gpurun_out/bench_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_haplotypes.log | tail -1 > gpurun_out/bench_haplotypes.json
-( time timeout 900 python bench.py --gpus 2 --share-device --min-timed-s 3 ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
-# eight ranks on the one device (smaller lists: eight tables must fit its memory): the launch, the rendezvous, parity over all ranks, every rank's NUMA placement and share of the host threads
-( time timeout 900 python bench.py --gpus 8 --share-device --kmers-per-list 30000000 --reads-per-step 32768 --steps 10 --warmup 2 --min-timed-s 2 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_8ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_8ranks_shared_device.log | tail -1 > gpurun_out/bench_8ranks_shared_device.json
-( time timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-device --steps 10 --warmup 2 --min-timed-s 3 ) > gpurun_out/bench_2ranks_torchrun.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_torchrun.log | tail -1 > gpurun_out/bench_2ranks_torchrun.json
-( time timeout 900 python bench.py --rings 3 --no-cpu-baseline --no-streaming --no-realistic --min-timed-s 3 ) > gpurun_out/bench_3rings.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_3rings.log | tail -1 > gpurun_out/bench_3rings.json
 # BASELINE configs[4]'s table and read shape on one GPU: 2 x 1e9 31-mers (64-bit m-mer kernels), 100 kb reads: full keys (and the key layout they had), wide entries
 C5="--k 31 --kmers-per-list 1000000000 --read-len 100000 --reads-per-step 39322 --steps 10 --warmup 2 --min-timed-s 3 --no-cpu-baseline --no-streaming --no-realistic"
 ( time TBK_BUILD_TIMING=1 timeout 1200 python bench.py $C5 ) > gpurun_out/bench_c5_uniform.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_uniform.log | tail -1 > gpurun_out/bench_c5_uniform.json
@@ -31,8 +26,6 @@ LN="--k 31 --kmers-per-list 1000000000 --read-lengths lognormal --read-len 66000
 ( time timeout 2400 python bench.py $LN ) > gpurun_out/bench_c5_lognormal_uniform.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_lognormal_uniform.log | tail -1 > gpurun_out/bench_c5_lognormal_uniform.json
 ( time timeout 2400 python bench.py $LN --lists haplotypes ) > gpurun_out/bench_c5_lognormal_haplotypes.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_c5_lognormal_haplotypes.log | tail -1 > gpurun_out/bench_c5_lognormal_haplotypes.json
 ( time timeout 600 python bench.py --path count ) > gpurun_out/bench_count.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_count.log | tail -1 > gpurun_out/bench_count.json
-# the literal BASELINE configs[2] line: the 90 Gbp set (6 M x 15 kb reads), one rank
-( time timeout 1500 python bench.py --scaling strong --strong-reads 6000000 --steps 2 --warmup 1 --min-timed-s 0 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
 FLAGS="--steps 4 --warmup 1 --min-timed-s 0 --no-cpu-baseline --no-streaming --no-realistic"
 cd /tmp
 rm -rf $R/gpurun_out/pmc_* $R/gpurun_out/prof_*
@@ -47,6 +40,17 @@ done
 cd $R
 python tools/profile_summary.py gpurun_out > gpurun_out/profile_summary.log 2>&1; tail -c 2500 gpurun_out/profile_summary.log
 find gpurun_out -name "*_kernel_trace.csv" -size +2M -delete; find gpurun_out -name "*counter_collection.csv" -size +2M -delete
+# the lines that REPLAY the traffic record (N > 1, several rings, strong scaling, the realistic_lists sub-record of the default line) run behind the
+# PMC passes, on the record those passes have just made of these very kernels; the default line a second time for its sub-record
+cp gpurun_out/pmc_traffic.json gpurun_out/pmc_traffic_haplotypes.json profiles/ 2>/dev/null
+( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_default.log | tail -1 > gpurun_out/bench_default.json
+# eight ranks on the one device (smaller lists: eight tables must fit its memory): the launch, the rendezvous, parity over all ranks, every rank's NUMA placement and share of the host threads
+( time timeout 900 python bench.py --gpus 2 --share-device --min-timed-s 3 ) > gpurun_out/bench_2ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_shared_device.log | tail -1 > gpurun_out/bench_2ranks_shared_device.json
+( time timeout 900 python bench.py --gpus 8 --share-device --kmers-per-list 30000000 --reads-per-step 32768 --steps 10 --warmup 2 --min-timed-s 2 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_8ranks_shared_device.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_8ranks_shared_device.log | tail -1 > gpurun_out/bench_8ranks_shared_device.json
+( time timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --share-device --steps 10 --warmup 2 --min-timed-s 3 ) > gpurun_out/bench_2ranks_torchrun.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_2ranks_torchrun.log | tail -1 > gpurun_out/bench_2ranks_torchrun.json
+( time timeout 900 python bench.py --rings 3 --no-cpu-baseline --no-streaming --no-realistic --min-timed-s 3 ) > gpurun_out/bench_3rings.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_3rings.log | tail -1 > gpurun_out/bench_3rings.json
+# the literal BASELINE configs[2] line: the 90 Gbp set (6 M x 15 kb reads), one rank
+( time timeout 1500 python bench.py --scaling strong --strong-reads 6000000 --steps 2 --warmup 1 --min-timed-s 0 --no-streaming --cpu-seconds 2 ) > gpurun_out/bench_strong.log 2>&1; grep "^{\"metric\"" gpurun_out/bench_strong.log | tail -1 > gpurun_out/bench_strong.json
 # host side of the boundary
 ( timeout 600 python tools/measure_reader.py --qual hifi ) > gpurun_out/reader_hifi.json 2> gpurun_out/reader_hifi.err
 # end to end at configs[1] scale: inputs in memory (/dev/shm) and bins on the disk - the box's 84 GB file system then holds the 30 GB
