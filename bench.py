@@ -364,7 +364,8 @@ def realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement):
         "kernel_ms_avg": r["kernel_ms_avg"], "whole_probe_ms_avg": r["whole_probe_ms_avg"],
         "frac": r["frac"], "frac_P2_two_probe_reading": r["frac_P2_two_probe_reading"], "achieved": r["achieved"],
         "traffic": r["traffic"], "traffic_source": r["traffic_source"], "random_line_frac": r.get("random_line_frac"),
-        "random_lines_Gps": r.get("random_lines_Gps"),
+        "random_lines_Gps": r.get("random_lines_Gps"), "random_line_frac_same_table": r.get("random_line_frac_same_table"),
+        "random_line_ceiling_same_table_Gps": (r.get("random_line_ceiling_same_table_Gps") or {}).get("best"),
         "kmers_per_list": sub["config"]["kmers_per_list"], "table_bytes_per_gpu": sub["config"]["table_bytes_per_gpu"],
         "table_bytes_per_key": sub["config"]["table_bytes_per_key"], "line_layout": sub["config"]["line_layout"],
         "bucket_select": sub["config"]["bucket_select"], "keys_behind_front": sub["config"]["keys_behind_front"],
@@ -535,7 +536,7 @@ def live_traffic(args, out):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return "no live counter pass: rocprofv3 not found"
-    skip, child_args, it = {"--gpus": 1, "--steps": 1, "--warmup": 1, "--min-timed-s": 1, "--live-pmc": 1, "--timed-path": 1, "--cpu-seconds": 1,
+    skip, child_args, it = {"--gpus": 1, "--steps": 1, "--warmup": 1, "--min-timed-s": 1, "--live-pmc": 1, "--cpu-seconds": 1,
                             "--no-cpu-baseline": 0, "--no-streaming": 0, "--no-realistic": 0, "--no-sweep": 0, "--calibrate": 0}, [], iter(sys.argv[1:])
     for a in it:
         name = a.split("=", 1)[0]
@@ -545,7 +546,7 @@ def live_traffic(args, out):
             continue
         child_args.append(a)
     child_args += ["--steps", "4", "--warmup", "1", "--min-timed-s", "0", "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--no-sweep",
-                   "--live-pmc", "off", "--timed-path", "resident"]
+                   "--live-pmc", "off"]   # (the timed path stays the parent's: host-fed batches are read packed, resident ones as ASCII)
     tmp = tempfile.mkdtemp(prefix="tbk_live_pmc_", dir="/tmp")
     t0 = time.time()
     try:
@@ -598,13 +599,22 @@ def price_traffic(roofline, traffic):
                 key = min(rows, key=lambda name: abs(float(name[:-2]) - stats["table_bytes"] / 1e9))
                 ceiling = rows[key].get("best", rows[key].get("line128"))
                 roofline["random_line_ceiling_footprint"] = key
-                roofline["random_lines_Gps"] = round(traffic / 128 / single_s / 1e9, 2)
+                # random lines = what is not the read stream itself (the launch's bases as they lie in HBM: 0.25 B per base packed, 1 as ASCII)
+                random_lines = max(0.0, traffic - pr.get("stream_bytes", 0.0)) / 128
+                roofline["read_stream_bytes_per_launch"] = int(pr.get("stream_bytes", 0))
+                roofline["random_lines_Gps"] = round(random_lines / single_s / 1e9, 2)
                 roofline["random_line_ceiling_Gps"] = ceiling
-                roofline["random_line_frac"] = round(traffic / 128 / single_s / 1e9 / ceiling, 3)
+                roofline["random_line_frac"] = round(random_lines / single_s / 1e9 / ceiling, 3)
                 roofline["measured_stream_GBps"] = cal.get("stream_tuned_GBps", cal["guide_stream_GBps"])
                 roofline["traffic_frac_of_measured_stream"] = round(traffic / single_s / 1e9 / roofline["measured_stream_GBps"], 3)
+                if pr.get("same_table"):
+                    # ... and against the same gather over this run's own table, measured in this run behind the timed legs
+                    roofline["random_line_ceiling_same_table_Gps"] = pr["same_table"]
+                    roofline["random_line_frac_same_table"] = round(random_lines / single_s / 1e9 / pr["same_table"]["best"], 3)
                 roofline["random_line_note"] = ("the ceiling is what a pure gather in the probe kernels' own request shape sustains at this footprint (one-wave blocks, two lanes x 16 bytes "
-                                                "of a line, the best of 1-8 lines in flight per pair and 4-8 waves per SIMD: tools/calib_ceilings.py); boxes of the pool differ by +-4 %")
+                                                "of a line, the best of 1-8 lines in flight per pair and 4-8 waves per SIMD: tools/calib_ceilings.py) on the box of the reference run; boxes of the pool differ "
+                                                "by +-4 % and placements of a table on one box by +-2 %, so `random_line_frac_same_table` prices the kernel against that gather over "
+                                                "this run's own table (2^28 random lines per shape, behind the timed legs)")
             except Exception:
                 pass
 
@@ -811,6 +821,16 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
                  "probe_ms_avg": round(o_probe_ms / max(1, o_l), 4), "single_read_kernel_ms_avg": round(o_single_ms / max(1, o_l), 4),
                  "note": "the same steps with the batches already in HBM (no H2D): what the kernels alone sustain"}
 
+    # the ceiling of the window loop's line rate on THIS table (where its pages lie moves the rate by +-2 %: EXPERIMENTS.md): a pure
+    # gather in the loop's own request shape over the table the timed legs have just used - 2^28 random lines (5 ms) per shape
+    same_table = None
+    if rank == 0 and hasattr(lib, "tbk_classifier_calibrate_pairs"):
+        try:
+            shapes = {f"waves8_inflight{inf}": round(max(cls.calibrate_pairs(inf, 8) for _ in range(2)) / 1e9, 2) for inf in (2, 4, 8)}
+            same_table = {"best": max(shapes.values()), **shapes}
+        except Exception as e:
+            print(f"bench: same-table gather calibration failed: {e}", file=sys.stderr)
+
     if hasattr(lib, "tbk_debug_counters"):  # debug build (-DTBK_COUNTERS): event counts of one step, to stderr
         buf = (C.c_ulonglong * 8)()
         lib.tbk_debug_counters(buf, 1)
@@ -913,7 +933,8 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
         "kernel_only_gbases_per_s": round(bases_per_launch / probe_s / 1e9, 2) if probe_s > 0 else None,
     }
     roofline["kernel_resources"] = kernel_resources(stats)
-    roofline["_pricing"] = {"single_s": single_s, "alg_bytes": alg_bytes, "table_bytes": stats["table_bytes"]}   # (price_traffic's inputs; main() drops it)
+    roofline["_pricing"] = {"single_s": single_s, "alg_bytes": alg_bytes, "table_bytes": stats["table_bytes"], "same_table": same_table,
+                            "stream_bytes": bases_per_launch * single_frac * (sum(b[4].nbytes for b in batches) / max(1, sum(b[3] for b in batches)) if host_fed else 1.0)}   # (price_traffic's inputs; main() drops it)
     price_traffic(roofline, traffic)
 
     if want_cpu and L > 2_000_000:

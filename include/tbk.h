@@ -252,6 +252,10 @@ int tbk_classifier_entries(const tbk_classifier *c, int *entry_layout, uint64_t 
  * in HBM: lines per second (a diagnostic: the same table measures up to 15 % differently from one placement in
  * the device's memory to another). */
 int tbk_classifier_calibrate(tbk_classifier *c, double *lines_per_sec);
+/* The same in the entry kernels' own request shape - one-wave blocks, waves_per_simd (4..8) of them resident per SIMD, two lanes x
+ * 16 bytes of a line's first 32, inflight (1..8) lines per pair before any is used - over n_lines random lines of this table: the
+ * ceiling bench.py prices the window loop's line rate against (same table, same box, same process). */
+int tbk_classifier_calibrate_pairs(tbk_classifier *c, int inflight, int waves_per_simd, uint64_t n_lines, double *lines_per_sec);
 
 /* Synchronous: host batch in, host counts out (pinned staging + H2D + kernel + D2H). */
 int tbk_classify_batch(tbk_classifier *c, const uint8_t *bases, const uint64_t *offsets,

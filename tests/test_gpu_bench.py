@@ -47,3 +47,7 @@ def test_traffic_is_measured_in_the_run():
     # every window's read byte comes from HBM at least once, and a launch cannot fetch more lines than it has windows (x 128 B, + the reads)
     assert rf["windows_per_launch"] * 0.25 <= rf["traffic"] <= rf["windows_per_launch"] * 130
     assert rf["traffic_over_algorithmic"] == round(rf["traffic"] / rf["alg_bytes_per_launch"], 3)
+    # the line rate is priced against a gather over this run's own table as well
+    same = rf["random_line_ceiling_same_table_Gps"]
+    assert same["best"] == max(v for name, v in same.items() if name != "best") > 0
+    assert rf["random_line_frac_same_table"] == round(rf["random_lines_Gps"] / same["best"], 3) or abs(rf["random_line_frac_same_table"] - rf["random_lines_Gps"] / same["best"]) < 2e-3

@@ -20,7 +20,7 @@ def _asan_runtime():
 @pytest.mark.skipif(_asan_runtime() is None, reason="clang ASan runtime not found")
 def test_host_code_under_asan_ubsan(built):
     csrc = os.path.join(ROOT, "trio_binning_amd", "csrc")
-    subprocess.run(["make", "-s", "-C", csrc, "asan"], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", csrc, "asan"], check=True)  # (eleven host sources, four at a time: the 8-CPU container runs the suite beside it)
     env = dict(os.environ,
                LD_PRELOAD=_asan_runtime(),
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=97",

@@ -111,7 +111,8 @@ def col(b, p):
         f"{hbm / 1e9:.1f} / {p.get('hbm_bytes_per_launch_from_TCC_MISS', 0) / 1e9:.1f}" if hbm else "-",
         f"{hbm / w:.1f} / {lines:.4f}" if hbm and lines else "-",
         f"{hbm / ms / 1e9:.2f} / {hbm / ms / 1e9 / STREAM_TBPS:.2f}" if hbm else "-",
-        f"{p['TCC_MISS_sum'] / ms / 1e6:.1f} / {p['TCC_MISS_sum'] / ms / 1e6 / GATHER_GLPS:.2f}" if p.get("TCC_MISS_sum") else "-",
+        (f"{r.get('random_lines_Gps')} / {r.get('random_line_frac')} / **{r.get('random_line_frac_same_table')}** (this run's table: {g(r, 'random_line_ceiling_same_table_Gps', 'best')} G/s)"
+         if r.get("random_lines_Gps") else "-"),
         f"{insts('SQ_INSTS_VALU')} / {insts('SQ_INSTS_SALU')} / {insts('SQ_INSTS_VMEM_RD')}",
         f"{p['SQ_WAIT_ANY'] / p['SQ_WAVE_CYCLES']:.2f}" if p.get("SQ_WAVE_CYCLES") else "-",
         f"{g(b, 'parity', 'gpu_equals_cpu')} on {g(b, 'parity', 'reads_checked_against_the_oracle')} reads; transfers agree: {g(b, 'parity', 'packed_and_ascii_transfers_agree')}",
@@ -122,7 +123,7 @@ def col(b, p):
 
 rows = ["`value`: host-fed classify stage (Gbases/s)", "`kernel_resident` (Gbases/s)", "table", "single-read probe kernel, HIP events inside the timed region (ms per launch)",
         "its algorithmic bytes per launch (GB, P = 1: 9 B per window) / `roofline.achieved` (GB/s) / `frac`", "its HBM bytes per launch: FETCH_SIZE x 1024 x 2 / TCC_MISS x 128 B (GB)",
-        "bytes per window / 128-B lines per window", f"HBM traffic rate (TB/s) / of the {STREAM_TBPS:.2f} TB/s a tuned streaming read reaches (profiles/calibration.json)", f"random 128-B lines (G/s) / of the {GATHER_GLPS:.2f} G/s a gather in the kernels' own shape reaches",
+        "bytes per window / 128-B lines per window", f"HBM traffic rate (TB/s) / of the {STREAM_TBPS:.2f} TB/s a tuned streaming read reaches (profiles/calibration.json)", f"random 128-B lines (G/s; the bench line's own counter pass, the read stream's bytes taken off) / of the {GATHER_GLPS:.2f} G/s a gather in the kernels' own shape reached on the calibration's box / of the same gather over this run's own table, in this run",
         "VALU / SALU / VMEM-read instructions per window", "SQ_WAIT_ANY / SQ_WAVE_CYCLES", "parity in the run (GPU counts == oracle)",
         "CPU baseline, oracle: 1 thread / 16 CPUs / rolling, 16 CPUs (Mbases/s)", "same stage fed with ASCII batches: packed by the feeder / ASCII over PCIe (Gbases/s)"]
 cu, ch = col(u, pu), col(h, ph)

@@ -124,6 +124,8 @@ if hasattr(lib, "tbk_pipeline_create"):
     _sig("tbk_pipeline_batches", C.c_int, _vp, _u64p, C.c_int)
     _sig("tbk_classify_file", C.c_int, _vp, C.c_char_p, _u64, _u64, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _u64, _u64, _vp)
     _sig("tbk_classifier_calibrate", C.c_int, _vp, _dp)
+    if hasattr(lib, "tbk_classifier_calibrate_pairs"):
+        _sig("tbk_classifier_calibrate_pairs", C.c_int, _vp, C.c_int, C.c_int, _u64, _dp)
     _sig("tbk_table_origin", C.c_int, _vp)
     _sig("tbk_table_keys", C.c_int, _vp, _vp, _u64)
     _sig("tbk_fastx_set_packing", C.c_int, _vp, C.c_int)

@@ -1774,6 +1774,37 @@ extern "C" int tbk_classifier_calibrate(tbk_classifier *c, double *lines_per_sec
     return TBK_OK;
 }
 
+// The same over this table in the entry kernels' own request shape (one-wave blocks, `waves_per_simd` of them resident, two lanes x
+// 16 bytes of a line's first 32, `inflight` lines per pair before any is used): the ceiling bench.py prices the window loop's line
+// rate against - same table, same box, same process (where a table's pages lie moves the rate by +-2 %: EXPERIMENTS.md).
+extern "C" hipError_t tbk_launch_gather_pairs(const void *, uint64_t, int, int, uint64_t, uint64_t, uint32_t *, uint64_t *, hipStream_t);
+extern "C" int tbk_classifier_calibrate_pairs(tbk_classifier *c, int inflight, int waves_per_simd, uint64_t n_lines, double *lines_per_sec) {
+    if (!c || !lines_per_sec) return fail(TBK_ERR_INVALID, "NULL argument");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    const uint64_t bytes = ((uint64_t)c->n_buckets * 2 * TBK_BUCKET_BYTES) & ~(uint64_t)255;
+    if (bytes < (1u << 20) || n_lines < 4096) { *lines_per_sec = 0; return TBK_OK; }
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 16));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint64_t done = 0;
+    float ms = 0;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = tbk_launch_gather_pairs(c->d_pair, bytes, inflight, waves_per_simd, n_lines >> 3, 5, sink, &done, c->compute);  // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, c->compute);
+    if (e == hipSuccess) e = tbk_launch_gather_pairs(c->d_pair, bytes, inflight, waves_per_simd, n_lines, 9, sink, &done, c->compute);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->compute);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TBK_ERR_INVALID : TBK_ERR_HIP, "tbk_classifier_calibrate_pairs: %s", hipGetErrorString(e));
+    *lines_per_sec = ms > 0 ? (double)done / (ms * 1e-3) : 0;
+    return TBK_OK;
+}
+
 // Which memory a classifier's table lies in (two classifiers with equal ids share one table), and whether that
 // table is a replica copied from another classifier's.
 extern "C" int tbk_classifier_table_id(const tbk_classifier *c, uint64_t *table_id, int *is_replica) {

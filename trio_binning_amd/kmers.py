@@ -498,6 +498,13 @@ class Classifier:
         check(lib.tbk_classifier_calibrate(self._h, C.byref(v)))
         return v.value
 
+    def calibrate_pairs(self, inflight: int = 4, waves_per_simd: int = 8, n_lines: int = 1 << 28) -> float:
+        """The same in the entry kernels' own request shape (two lanes x 16 bytes of a line, one-wave blocks): random lines
+        per second over this table - the ceiling of the window loop's line rate on this table, on this box, in this process."""
+        v = C.c_double()
+        check(lib.tbk_classifier_calibrate_pairs(self._h, inflight, waves_per_simd, n_lines, C.byref(v)))
+        return v.value
+
     def last_passes(self) -> Tuple[int, int]:
         """(passes, passes that touch more than one read) of the most recent probe: 2048 window starts each; the
         latter went through the two-read or the multi-read kernel, the rest through the single-read kernel."""
