@@ -657,9 +657,6 @@ __device__ __forceinline__ uint64_t quad_any(uint64_t m) {
 constexpr int TBK_QCAP = 256;        // whole-line kernels: queue entries per wave; a window-loop step adds at most 128
 constexpr int TBK_QCAP_FRONT = 128;  // front kernels: walks are queued by drain_back only, at most 32 per round
 constexpr int TBK_BQCAP = 128;       // front kernels: windows waiting for the back half of their line; a step adds at most 64
-#ifndef TBK_FEWER_SELECTS
-#define TBK_FEWER_SELECTS 1   // entry kernels' window loop - 1: one select for the bucket word; 2: ORs of ballots instead of the ballot of an OR (short keys); 4: the invalid window's word by arithmetic (short keys)
-#endif
 #ifndef TBK_TMER_LUT
 #define TBK_TMER_LUT 1   // entry kernels with 3w t-mer positions at W = 6 (t = 4): t-mer ranks from a 256-entry table in LDS (0: computed)
 #endif
@@ -1755,7 +1752,6 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             for (int s = 0; s < 2; s++) if (strad & (0x5555555555555555ull << s)) own1[s] &= ~(pair_any(strad) * 3ull);  // (both bits of that pair)
         }
         bool ok = (bad_lo & badk) == 0;
-        [[maybe_unused]] const uint32_t bad_lo_now = bad_lo;
         if (TWO) {
             const bool cross = (uint32_t)j < jb_s && (uint32_t)(j + k) > jb_s;
             ok = ok && !(cross && is_strad);
@@ -1814,14 +1810,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             const uint64_t w0_want = ok ? ((uint64_t)cm | TBK_WENTRY_TAKEN) : ~0ull;
             cm_ask = (uint32_t)w0_want; cm_ask2 = (uint32_t)(w0_want >> 32);
         } else if constexpr (SHORT) {
-#if TBK_FEWER_SELECTS & 4
-            if constexpr (!MULTI && !TWO) {
-                // TBK_SHORT_NONE is all ones: OR-ing in "all ones where the window holds a bad base" (0 - min(bad bits, 1)) needs no select
-                const uint32_t badbits = bad_lo_now & badk;
-                cm_ask = my_khi | (0u - (badbits < 1u ? badbits : 1u));
-            } else
-#endif
-            cm_ask = ok ? my_khi : TBK_SHORT_NONE;
+            cm_ask = ok ? my_khi : TBK_SHORT_NONE;   // (by arithmetic - my_khi | -(min(bad bits, 1)) - measured: nothing; EXPERIMENTS.md "What a select costs")
         } else if constexpr (FULL) {
             // what the slots hold: the canonical k-mer, inverted (tbk_full_word); an invalid window asks for the inverse of TBK_FULL_NOKEY
             const uint64_t kf = fs & kmask, kr = bs & kmask;
@@ -1831,13 +1820,9 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             cm_ask = ok ? (uint32_t)cm : TBK_ENTRY_NO_MMER;
         }
         const bool fresh = ok && bkt != last_bk;
-#if TBK_FEWER_SELECTS & 1
         // (one select: a valid window that is not fresh names the bucket the lane holds already.  A select through VCC - v_cndmask_b32
         // in its 32-bit encoding - costs this chip 2 to 5 ordinary vector instructions: profiles/r05/valu_rates_select.log)
         const uint32_t my_bk = fresh ? (bkt | 0x80000000u) : last_bk;
-#else
-        const uint32_t my_bk = (ok ? bkt : last_bk) | (fresh ? 0x80000000u : 0u);
-#endif
         last_bk = my_bk & 0x7FFFFFFFu;
         const uint32_t my_rid = (uint32_t)rid;
         auto two_rid = [&]() -> uint32_t { return (is_second || (is_strad && (uint32_t)j >= jb_s)) ? 1u : 0u; };
@@ -1867,14 +1852,8 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
             if constexpr (SHORT) {
                 // the lane's 16 bytes are four slots of either list: the word asked with and without the list bit
                 const uint32_t qa = cm_s[s], qb2 = cm_s[s] | TBK_SHORT_HAPB, w0 = (uint32_t)va[s].x, w2 = (uint32_t)va[s].y, w3 = hy & ~TBK_SHORT_FLAG;
-#if TBK_FEWER_SELECTS & 2
-                // (the OR of four ballots, not the ballot of an OR: the latter builds the boolean in a vector register - v_cndmask, v_cmp - first)
-                hitx[s] = ballot(w0 == qa) | ballot(hx == qa) | ballot(w2 == qa) | ballot(w3 == qa);
-                hit_sb[s] = ballot(w0 == qb2) | ballot(hx == qb2) | ballot(w2 == qb2) | ballot(w3 == qb2);
-#else
                 hitx[s] = ballot(w0 == qa || hx == qa || w2 == qa || w3 == qa);
                 hit_sb[s] = ballot(w0 == qb2 || hx == qb2 || w2 == qb2 || w3 == qb2);
-#endif
                 hit[s] = hitx[s] | hit_sb[s];
             } else if constexpr (FULL) {
                 // the even lane holds slots 0 and 1, the odd lane slot 2 and - never compared: a 62-bit summary could equal a key - the line's summary
