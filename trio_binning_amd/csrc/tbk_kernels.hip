@@ -1998,7 +1998,7 @@ __device__ __forceinline__ void probe_pass_entry(const ProbeArgs &p, const uint6
 // Which read contains the first position of each pass (one thread per pass): keeps the
 // binary search over the offsets out of the probe kernels' waves.  Passes that touch more than one
 // read are listed for the multi-read kernel (*n_multi is zeroed by the launcher).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, uint64_t total, uint64_t n_passes,
                       uint32_t *__restrict__ pass_read, uint32_t *__restrict__ multi_list, uint32_t *__restrict__ n_multi,
                       uint64_t *__restrict__ two_list, uint32_t *__restrict__ n_two, int use_two, int32_t *__restrict__ counts) {
@@ -2018,21 +2018,31 @@ tbk_pass_index_kernel(const uint64_t *__restrict__ offsets, uint64_t n_reads, ui
             to_multi = !to_two;
         }
     }
-    // one atomic per wave and list (on 15 kb reads every seventh pass is listed: a quarter of a million atomics on one
-    // word took 2 ms, the chip's rate for that; the compiler's own aggregation does not see through the two lists)
+    // one atomic per BLOCK and list: the block's waves take their places in LDS first.  (On 15 kb reads every seventh pass is
+    // listed; a quarter of a million atomics on one word took 2 ms - the chip's rate for that, 8 ns each - and one per wave
+    // still 0.25 ms of a 0.28 ms launch: round 5.)
+    __shared__ uint32_t s_count[2], s_base[2];
+    if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u;
-    auto slot_for = [&](bool mine, uint32_t *n) -> uint32_t {  // this thread's place in a list (meaningful where `mine`)
-        const uint64_t m = __builtin_amdgcn_ballot_w64(mine);
-        if (m == 0) return 0u;
-        const int leader = __builtin_ctzll(m);
-        uint32_t base = 0;
-        if ((int)lane == leader) base = atomicAdd(n, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    };
-    const uint32_t at_multi = slot_for(to_multi, n_multi), at_two = slot_for(to_two, n_two);
-    if (to_multi) multi_list[at_multi] = (uint32_t)pass;
-    if (to_two) two_list[at_two] = pass | ((uint64_t)r_first_of_pass << 32);  // (the two-read kernel's block starts from this one load)
+    uint32_t in_wave[2] = {0, 0}, wave_at[2] = {0, 0};
+    const bool mine[2] = {to_multi, to_two};
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const uint64_t m = __builtin_amdgcn_ballot_w64(mine[l]);
+        if (m != 0) {
+            const int leader = __builtin_ctzll(m);
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(&s_count[l], (uint32_t)__popcll(m));
+            wave_at[l] = (uint32_t)__shfl((int)base, leader, 64);
+            in_wave[l] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_count[threadIdx.x] != 0) s_base[threadIdx.x] = atomicAdd(threadIdx.x == 0 ? n_multi : n_two, s_count[threadIdx.x]);
+    __syncthreads();
+    if (to_multi) multi_list[s_base[0] + wave_at[0] + in_wave[0]] = (uint32_t)pass;
+    if (to_two) two_list[s_base[1] + wave_at[1] + in_wave[1]] = pass | ((uint64_t)r_first_of_pass << 32);  // (the two-read kernel's block starts from this one load)
     // the same launch clears the per-read counters the probe kernels add to
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = pass; i < 2 * n_reads; i += step) counts[i] = 0;
@@ -2297,7 +2307,7 @@ extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t
     if (pass_cap & 1) return hipErrorInvalidValue;  // (64-bit entries)
     hipError_t e = hipMemsetAsync(d_n, 0, 2 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((n_passes + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(tbk_pass_index_kernel, dim3((unsigned)((n_passes + 1023) / 1024)), dim3(1024), 0, stream,
                        d_offsets, n_reads, total, n_passes, d_scratch, d_multi, d_n, d_two, d_n + 1, use_two, d_counts);
     return hipGetLastError();
 }
