@@ -552,7 +552,7 @@ def live_traffic(args, out):
     try:
         env = dict(os.environ, TMPDIR="/tmp", TBK_SKIP_BUILD="1")
         cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py")] + child_args
-        run = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+        run = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
         line = next((ln for ln in reversed(run.stdout.splitlines()) if ln.startswith('{"metric"')), None)
         means, meta = counter_means(sorted(glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)))
         if run.returncode != 0 or line is None or "FETCH_SIZE" not in means:
