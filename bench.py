@@ -552,7 +552,17 @@ def live_traffic(args, out):
     try:
         env = dict(os.environ, TMPDIR="/tmp", TBK_SKIP_BUILD="1")
         cmd = [exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "--", sys.executable, os.path.join(ROOT, "bench.py")] + child_args
-        run = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+        # (a process group of its own: on a timeout the profiler AND the bench under it are ended, by the group's id)
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            c_out, c_err = proc.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            import signal
+
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.communicate()
+            return "live counter pass timed out after 150 s"
+        run = argparse.Namespace(returncode=proc.returncode, stdout=c_out, stderr=c_err)
         line = next((ln for ln in reversed(run.stdout.splitlines()) if ln.startswith('{"metric"')), None)
         means, meta = counter_means(sorted(glob.glob(os.path.join(tmp, "**", "*_counter_collection.csv"), recursive=True)))
         if run.returncode != 0 or line is None or "FETCH_SIZE" not in means:
