@@ -41,6 +41,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     os.environ["TBK_TABLE_ALIGN"] = str(aligns[rep % len(aligns)])
     cls = kmers.Classifier(a, b)
     calib = [round(cls.calibrate() / 1e9, 2) for _ in range(3)]
+    pairs = round(max(cls.calibrate_pairs(4, 8) for _ in range(2)) / 1e9, 2) if hasattr(cls, "calibrate_pairs") else None
     for _ in range(2):
         cls.wait(cls.submit_device(d_bases, d_offs, R, R * L, counts))
     cls.kernel_timing(True)
@@ -49,7 +50,7 @@ for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         cls.wait(cls.submit_device(d_bases, d_offs, R, R * L, counts))
     dt = (time.perf_counter() - t) / 6
     nl, ms, single = cls.kernel_timing_read2()
-    out.append({"build": rep, "align": aligns[rep % len(aligns)], "gather_Glines_per_s": calib, "single_ms": round(single / nl, 3), "probe_ms": round(ms / nl, 3), "step_ms": round(dt * 1e3, 3), "sum_a": int(counts[:, 0].sum())})
+    out.append({"build": rep, "gather_pairs_Glines_per_s": pairs, "single_ms_x_gather": round(single / nl * pairs, 1) if pairs else None, "align": aligns[rep % len(aligns)], "gather_Glines_per_s": calib, "single_ms": round(single / nl, 3), "probe_ms": round(ms / nl, 3), "step_ms": round(dt * 1e3, 3), "sum_a": int(counts[:, 0].sum())})
     print(out[-1], flush=True)
     cls.close()
 print(json.dumps(out))
