@@ -87,6 +87,9 @@ def parse(argv=None):
                          "utilisation sampler can see)")
     ap.add_argument("--no-realistic", action="store_true",
                     help="N = 1: skip the `realistic_lists` sub-record (the same bench on haplotype-shaped lists, a second table build and a few seconds of timing)")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N = 1: skip the `strong_90gbp` sub-record (BASELINE configs[2]'s literal set: one pass per step over --strong-reads distinct reads)")
+    ap.add_argument("--strong-leg-timed-s", type=float, default=1.2, help="timed seconds of the strong_90gbp sub-record (whole passes of 0.43 s)")
     ap.add_argument("--realistic-timed-s", type=float, default=3.0, help="timed seconds per leg of the realistic_lists sub-record")
     ap.add_argument("--k", type=int, default=BASELINE_K)
     ap.add_argument("--kmers-per-list", type=int, default=BASELINE_KEYS)
@@ -337,10 +340,40 @@ def main():
     out["roofline"].pop("_pricing", None)
     if rank == 0 and world == 1 and not args.no_realistic and args.lists == "uniform" and args.scaling == "weak":
         out["realistic_lists"] = realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement)
+    if rank == 0 and world == 1 and not args.no_strong_leg and args.lists == "uniform" and args.scaling == "weak" and args.read_lengths == "fixed":
+        out["strong_90gbp"] = strong_leg(args, np, kmers, lib, check, _lib, dev, dist, placement, out)
     dist.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     dist.close()
+
+
+def strong_leg(args, np, kmers, lib, check, _lib, dev, dist, placement, headline):
+    """BASELINE configs[2] to the letter, beside the headline's two cycled batches: ONE pass per step over the whole 90 Gbp set
+    (--strong-reads reads = 23 distinct host-fed batches at the default sizes), the same tables, the same host-fed stage
+    (`--scaling strong` at N = 1).  Its own parity (the generator's first reads against the oracle) and the bins of the whole set."""
+    import copy
+
+    a = copy.copy(args)
+    a.scaling = "strong"
+    a.steps, a.warmup = 1, 1
+    a.min_timed_s = args.strong_leg_timed_s
+    a.no_streaming = True
+    a.calibrate = False
+    a.sweep = False
+    a.cpu_seconds = min(args.cpu_seconds, 1.0)
+    a.parity_reads = min(args.parity_reads, 512)
+    sub = run_classify(a, np, kmers, lib, check, _lib, dev, dist, 1, 0, placement)
+    r = sub["roofline"]
+    return {
+        "workload": sub["config"]["workload"], "value": sub["value"], "unit": sub["unit"], "ms_per_pass": sub["ms_per_step"],
+        "reads": a.strong_reads, "bases": sub["config"]["bases_per_step_per_rank"], "distinct_batches": sub["config"]["distinct_batches"],
+        "passes_timed": sub["timed_regions"], "timed_total_s": sub["timed_total_s"], "region_s_min_median_max": sub["region_s_min_median_max"],
+        "kernel_ms_avg": r["kernel_ms_avg"], "whole_probe_ms_avg": r["whole_probe_ms_avg"], "frac": r["frac"],
+        "vs_value": round(sub["value"] / headline["value"], 4) if headline.get("value") else None,
+        "bins_of_one_pass": {name: n // max(1, sub["timed_regions"]) for name, n in sub["bins"].items()}, "parity": sub["parity"], "setup_s": sub["setup_s"],
+        "note": "the headline cycles config.distinct_batches batches per rank; this leg is one pass per step over the literal set - every batch distinct, host-fed",
+    }
 
 
 def realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement):
@@ -357,7 +390,12 @@ def realistic_lists(args, np, kmers, lib, check, _lib, dev, dist, placement):
     a.cpu_seconds = min(args.cpu_seconds, 2.0)
     a.parity_reads = min(args.parity_reads, 1024)
     sub = run_classify(a, np, kmers, lib, check, _lib, dev, dist, 1, 0, placement)
+    # the same treatment as the headline's `traffic`: a counter pass of this very workload, now, as a child process
+    note = live_traffic(a, sub)
     r = sub["roofline"]
+    r.pop("_pricing", None)
+    if note:
+        r["traffic_source"] = f"{r.get('traffic_source')} [{note}]"
     keep = {
         "lists": "haplotypes: " + sub["data"], "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
         "kernel_resident": (sub.get("kernel_resident") or {}).get("gbases_per_s"),
@@ -515,7 +553,7 @@ def counter_means(csv_files):
     return {k: sum(v) / len(v) for k, v in agg.items()}, meta
 
 
-def live_traffic(args, out):
+def live_traffic(args, out, extra_child_args=()):
     """`roofline.traffic` from counters of this run: the same workload for four steps, as a child process under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (counters in a pass of their own, the program right behind `--`, cwd /tmp:
     MI355X_MICROARCH.md's HBM recipe), started when the timed legs are over and their device memory is released.  HBM bytes
@@ -528,6 +566,8 @@ def live_traffic(args, out):
 
     if args.live_pmc == "off":
         return "live counter pass switched off (--live-pmc off)"
+    if "--lists" not in extra_child_args and args.lists != "uniform":
+        extra_child_args = ["--lists", args.lists] + list(extra_child_args)
     if args.live_pmc == "auto":
         if args.scaling != "weak" or args.read_lengths != "fixed" or args.rings > 1:
             return "no live counter pass for this workload (--live-pmc on asks for one)"
@@ -537,7 +577,7 @@ def live_traffic(args, out):
     if not exe:
         return "no live counter pass: rocprofv3 not found"
     skip, child_args, it = {"--gpus": 1, "--steps": 1, "--warmup": 1, "--min-timed-s": 1, "--live-pmc": 1, "--cpu-seconds": 1,
-                            "--no-cpu-baseline": 0, "--no-streaming": 0, "--no-realistic": 0, "--no-sweep": 0, "--calibrate": 0}, [], iter(sys.argv[1:])
+                            "--no-cpu-baseline": 0, "--no-streaming": 0, "--no-realistic": 0, "--no-sweep": 0, "--no-strong-leg": 0, "--calibrate": 0, "--lists": 1}, [], iter(sys.argv[1:])
     for a in it:
         name = a.split("=", 1)[0]
         if name in skip:
@@ -545,7 +585,8 @@ def live_traffic(args, out):
                 next(it, None)
             continue
         child_args.append(a)
-    child_args += ["--steps", "4", "--warmup", "1", "--min-timed-s", "0", "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--no-sweep",
+    child_args += list(extra_child_args)   # (the realistic_lists sub-record's pass: --lists haplotypes)
+    child_args += ["--steps", "4", "--warmup", "1", "--min-timed-s", "0", "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--no-sweep", "--no-strong-leg",
                    "--live-pmc", "off"]   # (the timed path stays the parent's: host-fed batches are read packed, resident ones as ASCII)
     tmp = tempfile.mkdtemp(prefix="tbk_live_pmc_", dir="/tmp")
     t0 = time.time()

@@ -178,6 +178,10 @@ typedef struct tbk_options {
     int32_t ring_streams, copy_priority, h2d_streams, zero_copy;  /* experiments of EXPERIMENTS.md (0, 0, 1, 0) */
     int32_t full_keys;        /* the full-key layout (csrc/tbk_common.h "full keys"): -1 the lists decide, 0 never, 1 pinned */
     double full_load;         /* full keys per line of sixteen slots (2.0: 64 bytes of device memory per key) */
+    int32_t replica_copy;     /* 0: the other devices of tbk_classifier_create_multi get the lists' keys and build the table themselves, all at
+                                 once; 1: they get a copy of the finished table (asynchronous peer copies, one stream per destination) */
+    int32_t verify_build;     /* -1: a table built by inserts that MERGE keys (entries, wide entries) is asked for every line of both lists
+                                 before it is handed out (c/kmers.c:112-122: every line is stored); 1: every table; 0: none */
 } tbk_options;
 void tbk_options_init(tbk_options *o);
 int tbk_options_from_env(tbk_options *o);
@@ -538,6 +542,9 @@ int tbk_classifier_sweep_keys(tbk_classifier *c, const void *d_keys, uint64_t n,
  * 2 x 3e8 keys; the standalone tables take 32 bytes of device memory per list line while it runs.  The command-line tool runs it
  * when TBK_VERIFY_BUILD=1. */
 int tbk_classifier_verify(tbk_classifier *c, tbk_table *a, tbk_table *b, uint64_t out[5]);
+/* What tbk_options.verify_build did when the classifier was made: list lines looked up again (0: not verified) - all of them
+ * answered as the lists say, or the constructor would have failed - and the seconds that took. */
+int tbk_classifier_verified(const tbk_classifier *c, uint64_t *lines, double *seconds);
 
 /* ---- k-mer counting: the find-unique-kmers step ---------------------------
  * Replaces the KMC subprocesses of find_unique_kmers.py:62-233 by a counting table in HBM.

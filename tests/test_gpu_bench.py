@@ -12,14 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 SMALL = ["--kmers-per-list", "3000000", "--reads-per-step", "8192", "--steps", "3", "--warmup", "1", "--min-timed-s", "0",
-         "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--parity-reads", "256"]
+         "--no-cpu-baseline", "--no-streaming", "--no-realistic", "--no-strong-leg", "--parity-reads", "256"]
 
 
-def run_bench(extra):
+def run_bench(extra, base=None):
     env = dict(os.environ, TBK_SKIP_BUILD="1")
     for key in [k for k in env if k.startswith(("ROCPROF", "ROCP_"))]:
         env.pop(key)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + (SMALL if base is None else base) + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -51,3 +51,20 @@ def test_traffic_is_measured_in_the_run():
     same = rf["random_line_ceiling_same_table_Gps"]
     assert same["best"] == max(v for name, v in same.items() if name != "best") > 0
     assert rf["random_line_frac_same_table"] == round(rf["random_lines_Gps"] / same["best"], 3) or abs(rf["random_line_frac_same_table"] - rf["random_lines_Gps"] / same["best"]) < 2e-3
+
+
+@pytest.mark.skipif(shutil.which("rocprofv3") is None and not os.path.isfile("/opt/rocm/bin/rocprofv3"), reason="no rocprofv3")
+def test_sub_records_of_the_default_line():
+    """The two sub-records the default N = 1 run adds, at test size: `strong_90gbp` (BASELINE configs[2]'s literal set: one pass
+    per step over every distinct batch of a fixed read set, with its own parity against the oracle) and `realistic_lists`
+    (haplotype-shaped lists) with its `traffic` measured by a counter pass of its own - the headline's treatment."""
+    base = [a for a in SMALL if a not in ("--no-realistic", "--no-strong-leg", "--no-cpu-baseline")]
+    out = run_bench(["--live-pmc", "on", "--no-sweep", "--strong-reads", "20000", "--strong-leg-timed-s", "0", "--realistic-timed-s", "0", "--cpu-seconds", "0.5"], base)
+    st = out["strong_90gbp"]
+    assert st["reads"] == 20000 and st["distinct_batches"] == 3 and st["bases"] == 20000 * 15000 and st["value"] > 0
+    assert st["parity"]["all_ranks_equal"] and st["parity"]["gpu_equals_cpu"], st["parity"]
+    assert sum(st["bins_of_one_pass"].values()) == 20000
+    rl = out["realistic_lists"]
+    assert rl["traffic_source"].startswith("measured in this run"), rl["traffic_source"]
+    assert rl["traffic"] > 0 and rl["parity"]["gpu_equals_cpu"]
+    assert out["roofline"]["traffic_source"].startswith("measured in this run")

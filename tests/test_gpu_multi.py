@@ -39,7 +39,7 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
         assert st["devices"] == [0, 0, 0] and st["table_bytes_total"] == st["table_bytes"]   # three rings on one device share its table
         for i in range(3):              # every replica on its own (the pipeline is idle)
             part = multi._part(i)
-            assert part.stats() == multi._part(0).stats()
+            assert part.stats() == multi._part(0).stats()   # (one shared table)
             assert np.array_equal(part.classify_batch(bases, offs), want)
         # queued: twelve batches submitted before the first wait (depth 9 + one waiting per ring), ASCII and
         # packed ahead alike, waited for out of order
@@ -67,45 +67,64 @@ def test_replicated_tables_answer_alike(gpu, orc, tmp_path):
         assert lib.tbk_classifier_create_multi(a._h, b._h, bad, 0, out) == _lib.TBK_ERR_INVALID
 
 
-@pytest.mark.parametrize("layout", ["key", "entry", "short"])
-def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, monkeypatch, layout):
-    """(In each of the table layouts: a replica of short keys carries the overflow table behind its lines.)
-    TBK_FORCE_REPLICA=1: every further ring on device 0 gets a full copy of the table made by the calls a second
-    GPU's replica is made by (tbk_classifier_replicate: hipMemcpyPeer) - the code of an 8-GPU node's table fan-out,
-    executed on the one GPU there is.  Three tables in three places, every one of them classifies like the oracle,
-    alone and behind the pipeline's queue; without the switch the rings share one table."""
-    from trio_binning_amd import kmers
-    from trio_binning_amd._lib import check, lib
+# what two tables of the same lists must share whichever way the second was made; which key of a crowded bucket lies behind a
+# front, and whether two neighbouring runs meet in one entry, depends on the order the racing inserts arrive in
+GEOMETRY = ("entry_layout", "wide_entries", "short_keys", "full_keys", "shared_keys", "front_layout", "distinct_a", "distinct_b", "n_buckets", "table_bytes",
+            "minimizer_w", "minimizer_m", "span_offset", "sampling_t")
 
-    v, fa, fb = _lists(tmp_path)
+
+def geometry(stats):
+    return {name: stats[name] for name in GEOMETRY}
+
+
+@pytest.mark.parametrize("how", ["built", "copied"])
+@pytest.mark.parametrize("layout", ["key", "entry", "wide", "short", "full"])
+def test_forced_replicas_are_real_tables_and_answer_alike(gpu, orc, tmp_path, monkeypatch, layout, how):
+    """TBK_FORCE_REPLICA=1: every further ring on device 0 gets a table of its own, made by the code that makes a second GPU's -
+    the fan-out of an 8-GPU node, executed on the one GPU there is.  `built` (the default): every replica gets the lists' keys and
+    builds the table again, all replicas at once on their own host threads, in the layout and geometry the first build decided
+    on (tbk_classifier_create_multi_opts; c/kmers.c:185-229 builds once and :245-268 only reads, so tables built independently
+    from the same lines answer alike); `copied` (TBK_REPLICA_COPY=1): the finished table is copied, asynchronously.  In each
+    layout (a replica of short keys carries the overflow table behind its lines): three tables in three places with one
+    geometry, every one of them classifies like the oracle, alone and behind the pipeline's queue, every one was asked for
+    every list line when the layout merges keys (or TBK_VERIFY_BUILD=1 says so); without the switch the rings share one table."""
+    from trio_binning_amd import kmers
+
+    v, fa, fb = _lists(tmp_path, 31 if layout in ("wide", "full") else 21)
     a, b = kmers.HashSet.from_file(fa, 0), kmers.HashSet.from_file(fb, 0)
     oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
     bases, offs = kmers.pack_reads(v["reads"])
     want = orc.count_batch(bases, offs, oa, ob)
+    n_lines = len(v["list_a"]) + len(v["list_b"])
 
-    def table_ids(multi):
-        out = []
-        for i in range(len(multi.devices)):
-            tid, rep = C.c_uint64(), C.c_int()
-            check(lib.tbk_classifier_table_id(multi._part(i)._h, C.byref(tid), C.byref(rep)))
-            out.append((tid.value, rep.value))
-        return out
-
-    monkeypatch.delenv("TBK_FORCE_REPLICA", raising=False)
-    for var, val in {"key": {"TBK_ENTRY": "0", "TBK_SHORT": "0"}, "entry": {"TBK_ENTRY": "1"}, "short": {"TBK_SHORT": "1"}}[layout].items():
+    for var in ("TBK_FORCE_REPLICA", "TBK_REPLICA_COPY", "TBK_VERIFY_BUILD"):
+        monkeypatch.delenv(var, raising=False)
+    env = {"key": {"TBK_ENTRY": "0", "TBK_SHORT": "0", "TBK_FULL": "0"}, "entry": {"TBK_ENTRY": "1"}, "wide": {"TBK_ENTRY": "1", "TBK_ENTRY_WIDE": "1"},
+           "short": {"TBK_SHORT": "1"}, "full": {"TBK_FULL": "1"}}[layout]
+    for var, val in env.items():
         monkeypatch.setenv(var, val)
+    merging = layout in ("entry", "wide")
     with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
-        ids = table_ids(multi)
+        ids = [multi._part(i).table_id() for i in range(3)]
         assert len({t for t, _ in ids}) == 1 and all(r == 0 for _, r in ids)
         st = multi._part(0).stats()
-        assert st["entry_layout"] == (layout == "entry") and st["short_keys"] == (layout == "short"), st
+        assert st["entry_layout"] == merging and st["wide_entries"] == (layout == "wide") and st["short_keys"] == (layout == "short") and st["full_keys"] == (layout == "full"), st
+        # the shared table was asked for every list line once; the rings that share it say so too
+        assert [multi._part(i).verified()["lines"] for i in range(3)] == [n_lines if merging else 0] * 3
     monkeypatch.setenv("TBK_FORCE_REPLICA", "1")
+    if how == "copied":
+        monkeypatch.setenv("TBK_REPLICA_COPY", "1")
+    if layout == "short":
+        monkeypatch.setenv("TBK_VERIFY_BUILD", "1")   # (every layout on request)
     with kmers.MultiClassifier(a, b, [0, 0, 0]) as multi:
-        ids = table_ids(multi)
-        assert len({t for t, _ in ids}) == 3 and sorted(r for _, r in ids) == [0, 1, 1], ids
+        ids = [multi._part(i).table_id() for i in range(3)]
+        assert len({t for t, _ in ids}) == 3 and sorted(r for _, r in ids) == ([0, 2, 2] if how == "built" else [0, 1, 1]), ids
         for i in range(3):
-            assert multi._part(i).stats() == multi._part(0).stats()
-            assert np.array_equal(multi._part(i).classify_batch(bases, offs), want), i
+            part = multi._part(i)
+            assert geometry(part.stats()) == geometry(multi._part(0).stats())
+            assert part.verified()["lines"] == (n_lines if merging or layout == "short" else 0), (i, part.verified())
+            assert np.array_equal(part.classify_batch(bases, offs), want), i
+            assert part.verify(a, b)["bad_lines"] == 0
         cuts = [0, 7, 30, 31, 64, 100, 149, len(v["reads"])]
         tickets = []
         for i, (lo, hi) in enumerate(zip(cuts, cuts[1:])):
@@ -114,6 +133,10 @@ def test_forced_replicas_are_real_copies_and_answer_alike(gpu, orc, tmp_path, mo
         for lo, hi, t in tickets:
             assert np.array_equal(multi.wait(t), want[lo:hi]), (lo, hi)
         assert sum(multi.dealt) == len(tickets), multi.dealt   # (which ring takes a batch is a race between the feeders; every replica has answered by itself above)
+    monkeypatch.setenv("TBK_VERIFY_BUILD", "0")
+    with kmers.MultiClassifier(a, b, [0, 0]) as multi:
+        assert [multi._part(i).verified()["lines"] for i in range(2)] == [0, 0]
+        assert np.array_equal(multi._part(1).classify_batch(bases, offs), want)
 
 
 def test_device_numa_node_and_feeder_binding(gpu, tmp_path):

@@ -38,6 +38,7 @@ K, N_LIST = 21, 300_000_000   # the headline configuration (used by the counter 
 CONFIGS = {
     "configs1_2x100M_k21": dict(k=21, n=100_000_000, R=8192, L=15_000, lists="uniform", m_gt_16=False, sample=256),
     "configs2_2x300M_k21": dict(k=21, n=300_000_000, R=16_384, L=15_000, lists="uniform", m_gt_16=False, sample=256),
+    "configs2_haplotype_lists_k21": dict(k=21, n=300_000_000, R=8_192, L=15_000, lists="haplotypes", m_gt_16=False, sample=128),
     "configs4_2x1B_k31": dict(k=31, n=1_000_000_000, R=2_048, L=100_000, lists="uniform", m_gt_16=True, sample=96),
     "configs4_haplotype_lists_k31": dict(k=31, n=1_000_000_000, R=1_024, L=100_000, lists="haplotypes", m_gt_16=True, sample=64),
 }
@@ -302,6 +303,74 @@ def test_second_build_is_identical(big):
     rec = full_membership_sweep(again, a, b, a.device_keys, b.device_keys, cfg["n"], cfg["n"], cfg["k"], device=0,
                                 uniform_seed=KEY_SEED if cfg["lists"] == "uniform" else None, legs=("members",))
     assert rec["ok"], rec
+
+
+def test_replicas_built_on_every_device_at_once(big):
+    """The table fan-out of an N-GPU node at BASELINE's sizes, on the one GPU there is (tbk_options.force_replica): beside the
+    first table, three replicas BUILT from the lists' keys in the first one's geometry, on three host threads at once (the
+    default), and three COPIED (replica_copy = 1).  On one device the three builds share its atomics and the copies its HBM, so
+    the wall here is the sum - what is asserted is what does not depend on that: one geometry, the answers of the first table on
+    every replica, every replica asked for every list line where the layout merges keys (entries, wide entries: the default)
+    and on request (verify_build = 1, here for the rest).  The seconds go to gpurun_out/fanout_<config>.json
+    (profiles/r06/).  The reference builds a table once and only reads it afterwards (c/kmers.c:185-229, 245-268)."""
+    import json
+    import os
+    import time
+
+    from test_gpu_multi import geometry
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    cls, bases, offs, counts, cfg, _ = big
+    a, b = cfg["lists_ab"]
+    st = cls.stats()
+    free_mem = kmers.device_mem_info(0)[0]
+    replicas = 3
+    # (the fixture's table and the lists are there already) four tables, the lists' standalone tables while the expectations are
+    # worked out (32 B per line), the expectations, the sweep's buffers
+    need = (replicas + 1) * st["table_bytes"] + 2 * cfg["n"] * 33 + (8 << 30)
+    if need > free_mem:
+        pytest.skip(f"{replicas + 1} tables of {st['table_bytes'] / 1e9:.0f} GB beside the fixture's do not fit what is free on the device ({free_mem / 1e9:.0f} GB)")
+    merging = st["entry_layout"]
+    n_lines = 2 * cfg["n"]
+    rec = {"config": cfg["name"], "keys_per_list": cfg["n"], "k": cfg["k"], "layout": {name: st[name] for name in ("entry_layout", "wide_entries", "short_keys", "full_keys")},
+           "table_bytes": st["table_bytes"], "replicas": replicas}
+    t0 = time.perf_counter()
+    with kmers.Classifier(a, b, options=kmers.Options(verify_build=0)) as one:
+        rec["one_build_s"] = time.perf_counter() - t0
+        assert geometry(one.stats()) == geometry(st)
+    for how in ("built", "copied"):
+        for verify in (0, -1 if merging else 1):
+            opts = kmers.Options(force_replica=1, replica_copy=int(how == "copied"), verify_build=verify, build_timing=1)
+            devices = (C.c_int * (replicas + 1))(*([0] * (replicas + 1)))
+            handles = (C.c_void_p * (replicas + 1))()
+            for _ in range(200):   # (the previous leg's four tables are back with the device: handing 134 GB back takes the driver seconds)
+                if kmers.device_mem_info(0)[0] >= free_mem - (1 << 30):
+                    break
+                time.sleep(0.1)
+            t0 = time.perf_counter()
+            check(lib.tbk_classifier_create_multi_opts(a._h, b._h, devices, replicas + 1, C.byref(opts.c), handles))   # (the fan-out alone: no pipeline around it)
+            wall = time.perf_counter() - t0
+            parts = [kmers.Classifier(a, b, _handle=h) for h in handles]
+            try:
+                ids = [part.table_id() for part in parts]
+                assert len({t for t, _ in ids}) == replicas + 1 and sorted(r for _, r in ids) == [0] + [2 if how == "built" else 1] * replicas, ids
+                ver = [part.verified() for part in parts]
+                assert [v["lines"] for v in ver] == [n_lines if verify else 0] * (replicas + 1), ver
+                for i, part in enumerate(parts):
+                    assert geometry(part.stats()) == geometry(st), (i, part.stats(), st)
+                    assert np.array_equal(part.classify_batch(bases, offs), counts), (how, i)
+                rec[f"{how}_verify{int(verify != 0)}_s"] = wall
+                if verify:
+                    rec[f"{how}_verify_s_per_table"] = [round(v["seconds"], 3) for v in ver]
+            finally:
+                for part in parts:
+                    part.close()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", f"fanout_{cfg['name']}.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    # the replicas' builds skip the trial layouts the first build went through; on ONE device they queue behind each other
+    assert rec["built_verify0_s"] < (replicas + 1.5) * rec["one_build_s"] + 2.0, rec
 
 
 def test_counter_properties_at_scale(gpu):

@@ -165,6 +165,8 @@ if hasattr(lib, "tbk_classifier_sweep_keys"):  # (variant builds of tools/build_
     _sig("tbk_classifier_sweep_keys", C.c_int, _vp, _vp, _u64, C.c_int, C.c_uint32, C.c_int, _vp, _u64, _u64p)
     if hasattr(lib, "tbk_classifier_verify"):
         _sig("tbk_classifier_verify", C.c_int, _vp, _vp, _vp, _u64p)
+    if hasattr(lib, "tbk_classifier_verified"):
+        _sig("tbk_classifier_verified", C.c_int, _vp, _u64p, C.POINTER(C.c_double))
 _sig("tbk_host_threads", C.c_int)
 _sig("tbk_counter_create", C.c_int, C.c_int, _u64, C.c_int, C.POINTER(_vp))
 _sig("tbk_counter_destroy", None, _vp)
@@ -211,7 +213,7 @@ class tbk_options(C.Structure):
                 ("memory_budget_bytes", C.c_uint64), ("table_align", C.c_uint64), ("short_line_cap", C.c_uint32), ("probe_max_blocks", C.c_int32),
                 ("packed_h2d", C.c_int32), ("slice_bases", C.c_uint64), ("build_timing", C.c_int32), ("force_replica", C.c_int32),
                 ("ring_streams", C.c_int32), ("copy_priority", C.c_int32), ("h2d_streams", C.c_int32), ("zero_copy", C.c_int32),
-                ("full_keys", C.c_int32), ("full_load", C.c_double)]
+                ("full_keys", C.c_int32), ("full_load", C.c_double), ("replica_copy", C.c_int32), ("verify_build", C.c_int32)]
 
 
 HAS_OPTIONS = hasattr(lib, "tbk_classifier_create_opts")  # (variant builds of tools/build_variant.sh may predate round 5)

@@ -80,14 +80,13 @@ def make_classifier(haplotype_a_kmers, haplotype_b_kmers):
     taken back in input order - the library's ``tbk_pipeline``, also when that is a single device."""
     # (how the table is built is an argument of the library - kmers.Options; the command line has no flags for it, as the
     # reference has none, so the TBK_* variables of the environment are its fallback: Options.from_env)
-    classifier = kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, kmers.visible_devices(), options=kmers.Options.from_env())
-    if os.environ.get("TBK_VERIFY_BUILD", "") not in ("", "0"):
-        # every line of both lists through the finished table, against the lists' standalone tables of verbatim keys
-        # (the reference stores every line and finds every stored canonical key: c/kmers.c:112-122, 245-268)
-        rec = classifier._part(0).verify(haplotype_a_kmers, haplotype_b_kmers)
-        print("tbk-verify " + str(rec), file=sys.stderr)
-        if rec["bad_lines"]:
-            raise SystemExit(f"classify-by-kmers: the built table answers {rec['bad_lines']} list lines wrongly (first: line {rec['first_bad']}): not using it")
+    # A table built by inserts that merge keys (entries, wide entries) is asked for every line of both lists before the library
+    # hands it out, on every device (tbk_options.verify_build; c/kmers.c:112-122 stores every line): a wrong table fails here.
+    # TBK_VERIFY_BUILD=1 extends that to every layout, =0 switches it off.
+    options = kmers.Options.from_env() if _lib.HAS_OPTIONS else None
+    classifier = kmers.MultiClassifier(haplotype_a_kmers, haplotype_b_kmers, kmers.visible_devices(), options=options)
+    if os.environ.get("TBK_VERIFY_BUILD", "") not in ("", "0") or os.environ.get("TBK_STATS", "") not in ("", "0"):
+        print("tbk-verify " + str([classifier._part(i).verified() for i in range(len(classifier.devices))]), file=sys.stderr)
     return classifier
 
 

@@ -122,6 +122,7 @@ extern "C" void tbk_options_init(tbk_options *o) {
     o->packed_h2d = 1;
     o->slice_bases = (uint64_t)384 << 20;
     o->h2d_streams = 1;
+    o->verify_build = -1;
 }
 
 extern "C" int tbk_options_from_env(tbk_options *o) {
@@ -143,6 +144,7 @@ extern "C" int tbk_options_from_env(tbk_options *o) {
     inum("TBK_PROBE_MAX_BLOCKS", o->probe_max_blocks); inum("TBK_PACKED_H2D", o->packed_h2d); inum("TBK_BUILD_TIMING", o->build_timing);
     inum("TBK_FORCE_REPLICA", o->force_replica); inum("TBK_RING_STREAMS", o->ring_streams); inum("TBK_COPY_PRIORITY", o->copy_priority);
     inum("TBK_H2D_STREAMS", o->h2d_streams); inum("TBK_ZERO_COPY", o->zero_copy);
+    inum("TBK_REPLICA_COPY", o->replica_copy); tri("TBK_VERIFY_BUILD", o->verify_build);
     return TBK_OK;
 }
 
@@ -320,6 +322,16 @@ struct tbk_table {
     TbkTableView view() const { return TbkTableView{d_slots, n_buckets, 8, 0, TbkMz{0, 0, 0, 0}, 0}; }
 };
 
+// What a build of the paired table reads of a list: its packed keys on the CURRENT device.  A tbk_table on its own device, or
+// the copy of its keys a replica's build has brought to another device (tbk_classifier_create_multi_opts).
+struct ListRef {
+    const uint64_t *d_keys;
+    uint64_t num_lines;
+    ListRef(const tbk_table *t) : d_keys(t->d_keys), num_lines(t->num_lines) {}
+    ListRef(const uint64_t *keys, uint64_t n) : d_keys(keys), num_lines(n) {}
+    const ListRef *operator->() const { return this; }
+};
+
 static constexpr int RING = 3;
 static constexpr int TIMING_POOL = 4096;  // events kept for kernel timing before they are folded into sums
 
@@ -400,12 +412,14 @@ struct tbk_classifier {
     uint64_t distinct_a = 0, distinct_b = 0;
     uint64_t shared = 0;         // hapB list lines left out of the table because hapA holds their key
     TbkMz mz{0, 0, 0};           // how a key picks its bucket (minimizer span or plain hash)
-    int replica_copies = 0;      // 1: this classifier's table is a copy made by tbk_classifier_replicate (hipMemcpyPeer), 0: built here or shared
+    int replica_copies = 0;      // 0: built here first, or shared; 1: a copy of another classifier's finished table (peer copy); 2: built again here from the lists in the first one's geometry
     int layout_builds = 0;       // times the paired table was built (2: the lists clustered under mod-sampling)
     uint64_t past_half = 0;      // keys that found their own half of their home line full
     uint64_t behind_front = 0;   // keys that are not among the first four slots of their list in their home line (entry layouts: entries behind the line's 32-byte front - four narrow entries, two wide ones; short and full keys: keys behind the front's seven / three)
     uint64_t entries_a = 0, entries_b = 0;  // entry layout (TBK_FLAG_ENTRY): slots the lists' keys take (a run of overlapping keys is one entry)
     uint32_t guests = 0;         // TBK_FLAG_GUESTS (k < 32: a full half's surplus sits, tagged, in the other half of its line before it leaves the line) | TBK_FLAG_FRONT (tbk_common.h)
+    uint64_t verified_lines = 0; // list lines looked up again in the finished table (tbk_options.verify_build), all answered as the lists say
+    double verify_s = 0;
     uint32_t over_mask = 0;      // short keys (TBK_FLAG_SHORT): the overflow table behind the lines has over_mask + 1 slots of 8 bytes
     uint64_t table_bytes() const { return (uint64_t)n_buckets * 2 * TBK_BUCKET_BYTES + ((guests & TBK_FLAG_SHORT) ? ((uint64_t)over_mask + 1) * 8 : 0); }
     TbkPairView pair() const { return TbkPairView{d_pair, n_buckets, mz, guests, over_mask}; }
@@ -1150,9 +1164,11 @@ static int classifier_streams(tbk_classifier *c, const tbk_classifier *same_devi
 // give_up_past != 0: a build whose only purpose may be to find out whether the lists cluster - when hapA's list alone has sent
 // more keys than that past their halves (or more than give_up_behind behind their fronts) the answer is known, the table is dropped and *gave_up set (hapB's inserts, which
 // look every key up in hapA's crowded half first, are the slow part of such a build).
-static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, double load, uint64_t *past, uint64_t give_up_past = 0, bool *gave_up = nullptr,
-                            uint64_t give_up_behind = 0) {
-    c->n_buckets = buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES, c->opt.table_load, c->opt.memory_budget_bytes);
+// pinned_buckets != 0: the table of another device's classifier is built again here, with that one's number of lines.
+static int build_pair_table(tbk_classifier *c, ListRef a, ListRef b, double load, uint64_t *past, uint64_t give_up_past = 0, bool *gave_up = nullptr,
+                            uint64_t give_up_behind = 0, uint32_t pinned_buckets = 0) {
+    c->n_buckets = pinned_buckets ? pinned_buckets
+                                  : buckets_for(std::max(a->num_lines, b->num_lines), c->mz.w > 1 ? load : 0.25, 2 * TBK_BUCKET_BYTES, c->opt.table_load, c->opt.memory_budget_bytes);
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = c->alloc_pair(bytes);
     if (e == hipSuccess) e = hipMemset(c->d_pair, 0xFF, bytes);
@@ -1194,7 +1210,7 @@ static int build_pair_table(tbk_classifier *c, const tbk_table *a, const tbk_tab
 // hapB's minus the keys hapA holds (tbk_entry_insert_kernel looks them up in hapA's finished half).
 // (give_up_behind != 0, full keys: a build that may only show that the lists cluster stops after hapA's list when that alone has put
 // more keys than that behind the fronts - *gave_up)
-static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets, uint64_t give_up_behind = 0, bool *gave_up = nullptr) {
+static int build_entry_table(tbk_classifier *c, ListRef a, ListRef b, uint32_t n_buckets, uint64_t give_up_behind = 0, bool *gave_up = nullptr) {
     c->n_buckets = n_buckets;
     const size_t bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES;
     hipError_t e = c->alloc_pair(bytes);
@@ -1206,7 +1222,7 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
     for (int list = 0; list < 2 && e == hipSuccess; list++) {
-        const tbk_table *t = list ? b : a;
+        const ListRef t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
         if (e == hipSuccess) e = (c->guests & TBK_FLAG_FULL)
                                      ? tbk_launch_full_insert(c->d_pair, c->n_buckets, list ? 8u : 0u, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed, 0u, nullptr)
@@ -1235,7 +1251,7 @@ static int build_entry_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
 
 // The paired table of short keys (tbk_common.h "short keys"): n_buckets lines of 32 words, EMPTY = 0, and behind them the
 // overflow table (over_slots 64-bit slots, all ones = empty); hapA's list first, then hapB's minus the keys hapA holds.
-static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_table *b, uint32_t n_buckets, uint32_t over_slots) {
+static int build_short_table(tbk_classifier *c, ListRef a, ListRef b, uint32_t n_buckets, uint32_t over_slots) {
     c->n_buckets = n_buckets;
     c->over_mask = over_slots - 1;
     const size_t line_bytes = (size_t)c->n_buckets * 2 * TBK_BUCKET_BYTES, bytes = line_bytes + (size_t)over_slots * 8;
@@ -1249,7 +1265,7 @@ static int build_short_table(tbk_classifier *c, const tbk_table *a, const tbk_ta
     if (e == hipSuccess) e = hipMalloc((void **)&d_failed, sizeof(int));
     if (e == hipSuccess) e = hipMemset(d_failed, 0, sizeof(int));
     for (int list = 0; list < 2 && e == hipSuccess; list++) {
-        const tbk_table *t = list ? b : a;
+        const ListRef t = list ? b : a;
         e = hipMemset(d_cnt, 0, sizeof cnt[0]);
         if (e == hipSuccess) e = tbk_launch_short_insert(c->d_pair, c->n_buckets, c->over_mask, (uint32_t)list, c->mz, c->k, t->d_keys, t->num_lines, list, d_cnt, d_failed,
                                                               c->opt.short_line_cap ? c->opt.short_line_cap : 32u, nullptr);  // (short_line_cap: tests fill the overflow table)
@@ -1276,7 +1292,7 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     return tbk_classifier_create_opts(a, b, nullptr, out);
 }
 
-extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b, const tbk_options *options, tbk_classifier **out) {
+static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_options *options, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!a || !b) return fail(TBK_ERR_INVALID, "table is NULL");
@@ -1607,13 +1623,73 @@ extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b
     return TBK_OK;
 }
 
-// ---- one classifier per device (SURVEY 8e: tables replicated, reads sharded, no collective) ----
-extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out) {
-    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (!src) return fail(TBK_ERR_INVALID, "classifier is NULL");
-    int rc = use_device(device);
+// ---- every build looked at again (tbk_options.verify_build) ----
+// The reference stores every list line (c/kmers.c:112-122) and finds every stored canonical key (:245-268).  The entry layouts
+// MERGE keys while thousands of threads insert at once - narrow entries OR window bits into a word others are ORing into, wide
+// entries guard two words with a lock made of relaxed agent-scope atomics (tbk_kernels.hip: tbk_wentry_insert_kernel; the
+// formally sufficient acquire / release costs 25 s per 2e9 keys in L2 write-backs) - and a key lost or misfiled there leaves
+// no trace in any counter.  So a table built that way is asked for every line of both lists before it is handed out, by
+// default (-1); verify_build = 1 does so for every layout, 0 never.  2 x 3e8 keys: under a second.
+extern "C" int tbk_verify_expectations_(tbk_table *a, tbk_table *b, void *d_expect);
+extern "C" int tbk_classifier_verify_expect_(tbk_classifier *c, const void *d_keys_a, uint64_t na, const void *d_keys_b, uint64_t nb, int k, const void *d_expect,
+                                             uint64_t out[5]);
+
+static bool verify_wanted(const tbk_classifier *c) {
+    return c->opt.verify_build > 0 || (c->opt.verify_build < 0 && (c->guests & TBK_FLAG_ENTRY) != 0);
+}
+
+// what the lists say of their own lines, one byte per line (hapA's first), on the lists' device; the standalone tables this
+// needs are dropped again when they were built for it (32 B per key: 64 GB at 2 x 1e9)
+static int list_expectations(const tbk_table *a, const tbk_table *b, uint8_t **d_expect) {
+    *d_expect = nullptr;
+    int rc = use_device(a->device);
     if (rc) return rc;
+    tbk_table *ta = const_cast<tbk_table *>(a), *tb = const_cast<tbk_table *>(b);
+    const bool had_a = ta->hashed, had_b = tb->hashed;
+    HIP_TRY(hipMalloc((void **)d_expect, a->num_lines + b->num_lines + 8));
+    rc = tbk_verify_expectations_(ta, tb, *d_expect);
+    auto drop = [](tbk_table *t) { if (t->d_slots) (void)hipFree(t->d_slots); t->d_slots = nullptr; t->hashed = false; };
+    if (!had_a) drop(ta);
+    if (!had_b && tb != ta) drop(tb);
+    if (rc) { (void)hipFree(*d_expect); *d_expect = nullptr; }
+    return rc;
+}
+
+// c's table asked for every list line (the keys and the expectations where c lives)
+static int verify_table(tbk_classifier *c, const uint64_t *ka, uint64_t na, const uint64_t *kb, uint64_t nb, const uint8_t *d_expect) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t r[5];
+    int rc = tbk_classifier_verify_expect_(c, ka, na, kb, nb, c->k, d_expect, r);
+    if (rc) return rc;
+    c->verify_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (c->opt.build_timing) fprintf(stderr, "tbk build: device %d, %llu list lines looked up again: %llu wrong  %7.3f s\n", c->device, (unsigned long long)r[0], (unsigned long long)r[3], c->verify_s);
+    if (r[3]) return fail(TBK_ERR_HIP, "the table built on device %d answers %llu of %llu list lines wrongly (first: line %llu): not using it", c->device,
+                          (unsigned long long)r[3], (unsigned long long)r[0], (unsigned long long)r[4]);
+    c->verified_lines = r[0];
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_create_opts(const tbk_table *a, const tbk_table *b, const tbk_options *options, tbk_classifier **out) {
+    int rc = classifier_build(a, b, options, out);
+    if (rc || !verify_wanted(*out)) return rc;
+    uint8_t *d_expect = nullptr;
+    rc = list_expectations(a, b, &d_expect);
+    if (!rc) rc = verify_table(*out, a->d_keys, a->num_lines, b->d_keys, b->num_lines, d_expect);
+    if (d_expect) (void)hipFree(d_expect);
+    if (rc) { const std::string msg = g_err; tbk_classifier_destroy(*out); *out = nullptr; g_err = msg; }
+    return rc;
+}
+
+extern "C" int tbk_classifier_verified(const tbk_classifier *c, uint64_t *lines, double *seconds) {
+    if (!c) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    if (lines) *lines = c->verified_lines;
+    if (seconds) *seconds = c->verify_s;
+    return TBK_OK;
+}
+
+// ---- one classifier per device (SURVEY 8e: tables replicated, reads sharded, no collective) ----
+// A replica's classifier: everything of `src` but the table and the streams.
+static tbk_classifier *replica_shell(const tbk_classifier *src, int device) {
     tbk_classifier *c = new tbk_classifier();
     c->device = device;
     c->k = src->k;
@@ -1628,36 +1704,134 @@ extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, t
     c->layout_builds = src->layout_builds; c->past_half = src->past_half; c->behind_front = src->behind_front;
     c->entries_a = src->entries_a; c->entries_b = src->entries_b;
     c->over_mask = src->over_mask;
+    return c;
+}
+
+static void enable_peer(int device, int other) {  // (the current device is `device`)
+    int can = 0;
+    if (device != other && hipDeviceCanAccessPeer(&can, device, other) == hipSuccess && can) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(other, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+    (void)hipGetLastError();
+}
+
+// `bytes` from `src` on src_device to `dst` on the current device `device`, asynchronously on `stream` (a stream of the
+// destination: eight destinations' copies leave one source over seven xGMI links at once instead of queueing behind each other)
+static hipError_t copy_from_device(void *dst, int device, const void *src, int src_device, size_t bytes, hipStream_t stream) {
+    if (!bytes) return hipSuccess;
+    if (device == src_device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    return hipMemcpyPeerAsync(dst, device, src, src_device, bytes, stream);
+}
+
+// The finished table of `src`, copied (TBK_REPLICA_COPY=1, tbk_classifier_replicate, and the fallback of a replica whose
+// build from the lists could not be made).  56 to 100 bytes per key cross xGMI.
+static int replica_by_copy(const tbk_classifier *src, int device, tbk_classifier *c) {
     const size_t bytes = (size_t)c->table_bytes();
+    hipError_t e = c->alloc_pair(bytes);
+    hipStream_t stream = nullptr;
+    if (e == hipSuccess) {
+        // the finished table travels device to device (xGMI when the two are peers; the runtime
+        // stages through the host otherwise) - once, outside any timed region
+        enable_peer(device, src->device);
+        e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = copy_from_device(c->d_pair, device, src->d_pair, src->device, bytes, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (stream) (void)hipStreamDestroy(stream);
+        c->replica_copies = 1;
+    }
+    if (e != hipSuccess) {
+        c->free_pair();
+        (void)hipGetLastError();
+        return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "replicating the paired table (%zu bytes) to device %d: %s", bytes, device,
+                    hipGetErrorString(e));
+    }
+    return TBK_OK;
+}
+
+// The table of `src` built AGAIN on `device` from the two lists, in the layout and geometry `src` decided on (layout flags, span,
+// lines, overflow slots are pinned; no trial builds).  The lists' keys - 8 bytes per key, where the finished table is 56 to 100 -
+// are what crosses xGMI when the lists live on another device.  c/kmers.c:185-229 builds a table once and :245-268 only reads it
+// afterwards, so a replica built independently answers like the first as long as it holds the same keys: the counts the build
+// reports (distinct keys per list, keys both lists hold) are compared with src's.
+// *keys_a / *keys_b: where the lists' keys lie on `device` afterwards (the lists' own memory when that is their device; else
+// copies the caller frees: *own_a, *own_b) - the verification reads them once more.
+static int replica_by_build(const tbk_classifier *src, const tbk_table *a, const tbk_table *b, int device, tbk_classifier *c, const uint64_t **keys_a,
+                            const uint64_t **keys_b, uint64_t **own_a, uint64_t **own_b) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t *d_a = nullptr, *d_b = nullptr;
+    *keys_a = *keys_b = nullptr; *own_a = *own_b = nullptr;
+    const uint64_t *ka = a->d_keys, *kb = b->d_keys;
+    double copy_s = 0;
+    if (device != a->device) {
+        enable_peer(device, a->device);
+        hipStream_t stream = nullptr;
+        hipError_t e = hipMalloc((void **)&d_a, std::max<size_t>(8, a->num_lines * 8));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_b, std::max<size_t>(8, b->num_lines * 8));
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = copy_from_device(d_a, device, a->d_keys, a->device, a->num_lines * 8, stream);
+        if (e == hipSuccess) e = copy_from_device(d_b, device, b->d_keys, b->device, b->num_lines * 8, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (e != hipSuccess) {
+            if (d_a) (void)hipFree(d_a);
+            if (d_b) (void)hipFree(d_b);
+            (void)hipGetLastError();
+            return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "the lists' keys (%llu bytes) to device %d: %s",
+                        (unsigned long long)((a->num_lines + b->num_lines) * 8), device, hipGetErrorString(e));
+        }
+        ka = d_a; kb = d_b;
+        copy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    const ListRef la(ka, a->num_lines), lb(kb, b->num_lines);
+    int rc;
+    if (src->guests & TBK_FLAG_SHORT) rc = build_short_table(c, la, lb, src->n_buckets, src->over_mask + 1);
+    else if (src->guests & (TBK_FLAG_ENTRY | TBK_FLAG_FULL)) rc = build_entry_table(c, la, lb, src->n_buckets);
+    else {
+        uint64_t past = 0;
+        rc = build_pair_table(c, la, lb, 0.08, &past, 0, nullptr, 0, src->n_buckets);
+    }
+    if (!rc && (c->distinct_a != src->distinct_a || c->distinct_b != src->distinct_b || c->shared != src->shared)) {
+        c->free_pair();
+        rc = fail(TBK_ERR_HIP, "the table built on device %d holds %llu + %llu keys (%llu in both lists), the one on device %d %llu + %llu (%llu)", device,
+                    (unsigned long long)c->distinct_a, (unsigned long long)c->distinct_b, (unsigned long long)c->shared, src->device,
+                    (unsigned long long)src->distinct_a, (unsigned long long)src->distinct_b, (unsigned long long)src->shared);
+    }
+    if (rc) {
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        return rc;
+    }
+    *keys_a = ka; *keys_b = kb; *own_a = d_a; *own_b = d_b;
+    c->replica_copies = 2;
+    c->layout_builds = 1;
+    if (src->opt.build_timing) {
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "tbk build: replica on device %d from the lists  %7.3f s (the lists' keys: %.3f s)  %u lines, %llu + %llu keys\n", device,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), copy_s, c->n_buckets, (unsigned long long)c->distinct_a, (unsigned long long)c->distinct_b);
+    }
+    return TBK_OK;
+}
+
+extern "C" int tbk_classifier_replicate(const tbk_classifier *src, int device, tbk_classifier **out) {
+    if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!src) return fail(TBK_ERR_INVALID, "classifier is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    tbk_classifier *c = replica_shell(src, device);
     // TBK_FORCE_REPLICA=1: a ring on the device that holds the table gets a full replica of its own all the same,
-    // made by the very calls a second GPU's replica is made by (peer query, hipMemcpyPeer) - how a one-GPU box
+    // made by the very calls a second GPU's replica is made by (peer query, peer copy) - how a one-GPU box
     // executes and checks the replica path of an 8-GPU node (tests/test_gpu_multi.py).
     const bool force_replica = src->opt.force_replica != 0;
     if (device == src->device && src->pair_owner && !force_replica) {
         // another stream ring on the device that holds the table already: the table is read-only, so it is shared
         c->d_pair = src->d_pair;
         c->pair_owner = src->pair_owner;
+        c->replica_copies = 0;
     } else {
-        hipError_t e = c->alloc_pair(bytes);
-        if (e == hipSuccess) {
-            // the finished table travels device to device (xGMI when the two are peers; the runtime
-            // stages through the host otherwise) - once, outside any timed region
-            int can = 0;
-            if (device != src->device && hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
-                const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);
-                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            }
-            (void)hipGetLastError();
-            e = hipMemcpyPeer(c->d_pair, device, src->d_pair, src->device, bytes);
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            c->replica_copies = 1;
-        }
-        if (e != hipSuccess) {
-            c->free_pair();
-            delete c;
-            return fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "replicating the paired table (%zu bytes) to device %d: %s", bytes, device,
-                        hipGetErrorString(e));
-        }
+        rc = replica_by_copy(src, device, c);
+        if (rc) { delete c; return rc; }
         c->own_pair();
     }
     rc = classifier_streams(c, src->opt.ring_streams != 0 ? nullptr : src);  // (TBK_RING_STREAMS=1: streams of its own, the measurement above)
@@ -1670,6 +1844,12 @@ extern "C" int tbk_classifier_create_multi(const tbk_table *a, const tbk_table *
     return tbk_classifier_create_multi_opts(a, b, devices, n_devices, nullptr, out);
 }
 
+// The fan-out.  The lists are hashed once on their own device, which decides the layout (short keys, entries, ... and the
+// table's geometry); every OTHER device then gets the lists' keys (8 B per key over its own xGMI link) and builds the same
+// table itself - one host thread per device, all at once.  Until round 5 the finished table (56-100 B per key) was copied to
+// one device after another by a blocking hipMemcpyPeer out of the first: seven times 33 GB at configs[2], 102-128 GB at
+// configs[4].  tbk_options.replica_copy = 1 keeps the copy (now asynchronous, per destination), and a device whose build
+// fails (no room for the lists beside the table) falls back to it.  Further entries of a device that has a table share it.
 extern "C" int tbk_classifier_create_multi_opts(const tbk_table *a, const tbk_table *b, const int *devices, int n_devices, const tbk_options *options,
                                                 tbk_classifier **out) {
     if (!out || !devices || n_devices < 1) return fail(TBK_ERR_INVALID, "devices/out is NULL or n_devices < 1");
@@ -1678,16 +1858,111 @@ extern "C" int tbk_classifier_create_multi_opts(const tbk_table *a, const tbk_ta
     if (hipGetDeviceCount(&n_visible) != hipSuccess || n_visible <= 0) return fail(TBK_ERR_NO_DEVICE, "no HIP device visible; libtbk_hip has no CPU fallback");
     for (int i = 0; i < n_devices; i++)
         if (devices[i] < 0 || devices[i] >= n_visible) return fail(TBK_ERR_INVALID, "device %d out of range (0..%d)", devices[i], n_visible - 1);
-    // hash the two lists once, on the device that holds them; every other entry gets a copy of the
-    // finished table (identical bytes, hence identical lookups)
     tbk_classifier *first = nullptr;
-    int rc = tbk_classifier_create_opts(a, b, options, &first);
+    int rc = classifier_build(a, b, options, &first);
     if (rc) return rc;
-    bool placed = false;
-    for (int i = 0; i < n_devices && !rc; i++) {
-        if (!placed && devices[i] == first->device) { out[i] = first; placed = true; continue; }
-        rc = tbk_classifier_replicate(first, devices[i], &out[i]);
+    // (tbk_options.verify_build: what the lists say of their own lines is worked out once, where the lists are; every table made
+    // below - the first, the ones built again from the lists, copies - is asked for all of them on its own device)
+    uint8_t *d_expect = nullptr;
+    const bool verify = verify_wanted(first);
+    if (verify) {
+        rc = list_expectations(a, b, &d_expect);
+        if (!rc) rc = verify_table(first, a->d_keys, a->num_lines, b->d_keys, b->num_lines, d_expect);
+        if (rc) { const std::string msg = g_err; if (d_expect) { (void)hipSetDevice(a->device); (void)hipFree(d_expect); } tbk_classifier_destroy(first); g_err = msg; return rc; }
     }
+    const bool force_replica = first->opt.force_replica != 0, by_copy = first->opt.replica_copy != 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    // who makes a table (a "leader": the first entry of a device other than the lists', or with force_replica every entry)
+    // and who shares one (leader_of[i] = the entry whose table entry i shares; -1 = first's)
+    std::vector<int> leader_of(n_devices, -2);
+    std::vector<int> leaders;
+    bool placed = false;
+    for (int i = 0; i < n_devices; i++) {
+        if (!placed && devices[i] == first->device) { out[i] = first; placed = true; leader_of[i] = i; continue; }
+        if (!force_replica) {
+            if (devices[i] == first->device) { leader_of[i] = -1; continue; }
+            int l = -2;
+            for (int j : leaders) if (devices[j] == devices[i]) { l = j; break; }
+            if (l >= 0) { leader_of[i] = l; continue; }
+        }
+        leader_of[i] = i;
+        leaders.push_back(i);
+    }
+    std::vector<int> rcs(n_devices, TBK_OK);
+    std::vector<std::string> errs(n_devices);
+    auto make = [&](int i) {
+        const int device = devices[i];
+        int r = use_device(device);
+        tbk_classifier *c = nullptr;
+        const uint64_t *ka = nullptr, *kb = nullptr;
+        uint64_t *own_a = nullptr, *own_b = nullptr;
+        if (!r) {
+            c = replica_shell(first, device);
+            r = by_copy ? TBK_ERR_HIP : replica_by_build(first, a, b, device, c, &ka, &kb, &own_a, &own_b);
+            if (r && !by_copy && first->opt.build_timing) fprintf(stderr, "tbk build: replica on device %d from the lists failed (%s): copying the table\n", device, g_err.c_str());
+            if (r) {
+                delete c;
+                c = replica_shell(first, device);
+                r = replica_by_copy(first, device, c);
+            }
+            if (!r) {
+                c->own_pair();
+                r = classifier_streams(c, first->opt.ring_streams != 0 ? nullptr : first);
+            } else { delete c; c = nullptr; }
+            if (!r && verify) {
+                // the keys (a copy made for the build, the lists' own on their device, or - behind a copied table - fetched now) and
+                // the expectations, on this device
+                uint8_t *d_exp = d_expect;
+                uint8_t *own_exp = nullptr;
+                hipError_t e = hipSuccess;
+                const uint64_t na = a->num_lines, nb = b->num_lines;
+                if (device != a->device) {
+                    enable_peer(device, a->device);
+                    hipStream_t stream = nullptr;
+                    e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+                    if (e == hipSuccess) e = hipMalloc((void **)&own_exp, na + nb + 8);
+                    if (e == hipSuccess) e = copy_from_device(own_exp, device, d_expect, a->device, na + nb, stream);
+                    if (e == hipSuccess && !ka) {
+                        e = hipMalloc((void **)&own_a, std::max<size_t>(8, na * 8));
+                        if (e == hipSuccess) e = hipMalloc((void **)&own_b, std::max<size_t>(8, nb * 8));
+                        if (e == hipSuccess) e = copy_from_device(own_a, device, a->d_keys, a->device, na * 8, stream);
+                        if (e == hipSuccess) e = copy_from_device(own_b, device, b->d_keys, b->device, nb * 8, stream);
+                        ka = own_a; kb = own_b;
+                    }
+                    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                    if (stream) (void)hipStreamDestroy(stream);
+                    d_exp = own_exp;
+                } else if (!ka) { ka = a->d_keys; kb = b->d_keys; }
+                if (e != hipSuccess) { (void)hipGetLastError(); r = fail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "the lists' keys to device %d for verification: %s", device, hipGetErrorString(e)); }
+                if (!r) r = verify_table(c, ka, na, kb, nb, d_exp);
+                if (own_exp) (void)hipFree(own_exp);
+            }
+            if (own_a) (void)hipFree(own_a);
+            if (own_b) (void)hipFree(own_b);
+            if (r && c) { const std::string msg = g_err; tbk_classifier_destroy(c); c = nullptr; g_err = msg; }
+        }
+        out[i] = c;
+        rcs[i] = r;
+        if (r) errs[i] = g_err;
+    };
+    if (leaders.size() == 1) make(leaders[0]);
+    else if (!leaders.empty()) {
+        std::vector<std::thread> threads;
+        for (int i : leaders) threads.emplace_back(make, i);
+        for (auto &t : threads) t.join();
+        (void)hipSetDevice(first->device);
+    }
+    for (int i : leaders) if (rcs[i] && !rc) { rc = rcs[i]; g_err = errs[i]; }
+    if (d_expect) { (void)hipSetDevice(a->device); (void)hipFree(d_expect); (void)hipSetDevice(first->device); }
+    for (int i = 0; i < n_devices && !rc; i++) {
+        if (out[i]) continue;
+        const tbk_classifier *src = leader_of[i] < 0 ? first : out[leader_of[i]];
+        rc = tbk_classifier_replicate(src, devices[i], &out[i]);  // (the device has the table: shared)
+        if (!rc) { out[i]->verified_lines = src->verified_lines; out[i]->verify_s = src->verify_s; }
+    }
+    if (!rc && first->opt.build_timing && !leaders.empty())
+        fprintf(stderr, "tbk build: %zu replica(s) %s, all at once: %7.3f s\n", leaders.size(), by_copy ? "copied" : "built from the lists",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     if (rc) {
         const std::string msg = g_err;
         for (int i = 0; i < n_devices; i++) { if (out[i] && out[i] != first) tbk_classifier_destroy(out[i]); out[i] = nullptr; }

@@ -185,6 +185,45 @@ extern "C" int tbk_classifier_sweep_keys(tbk_classifier *c, const void *d_keys, 
 // be checked by in the field - a concurrent build (CAS on slots, the wide entries' per-piece lock) leaves no other trace of a
 // lost or misfiled key.  Chunks of 2^24 keys; out = {lines checked, keys counted for hapA, for hapB, lines that differ, the first
 // such line (hapA's lines first, then hapB's; all ones: none)}.  Under a second at 2 x 3e8 keys.
+// Two halves, so that a replica on ANOTHER device (which has the lists' keys but not their standalone tables) is checked too:
+// the expectations - one byte per list line, hapA's lines first - are written once on the lists' device ...
+extern "C" int tbk_verify_expectations_(tbk_table *a, tbk_table *b, void *d_expect) {
+    if (!a || !b || !d_expect) return vfail(TBK_ERR_INVALID, "NULL argument");
+    if (tbk_table_k(a) != tbk_table_k(b) || tbk_table_device(a) != tbk_table_device(b)) return vfail(TBK_ERR_INVALID, "the lists differ in k or device");
+    const uint64_t chunk = (uint64_t)1 << 24;
+    uint64_t base = 0;
+    int rc = TBK_OK;
+    for (tbk_table *t : {a, b}) {
+        const uint64_t n = tbk_table_num_kmers(t);
+        const uint64_t *d_keys = (const uint64_t *)tbk_table_device_keys(t);
+        for (uint64_t first = 0; first < n && !rc; first += chunk)
+            rc = tbk_sweep_expectation_device(a, b, d_keys + first, std::min(chunk, n - first), (uint8_t *)d_expect + base + first);
+        base += n;
+    }
+    return rc;
+}
+
+// ... and the classifier answers for the keys where IT lives (d_keys_a / _b and d_expect on the classifier's device).
+extern "C" int tbk_classifier_verify_expect_(tbk_classifier *c, const void *d_keys_a, uint64_t na, const void *d_keys_b, uint64_t nb, int k, const void *d_expect,
+                                             uint64_t out[5]) {
+    if (!c || !out || !d_expect) return vfail(TBK_ERR_INVALID, "NULL argument");
+    out[0] = out[1] = out[2] = out[3] = 0; out[4] = ~0ull;
+    const uint64_t chunk = (uint64_t)1 << 24;
+    uint64_t base = 0;
+    int rc = TBK_OK;
+    for (int list = 0; list < 2 && !rc; list++) {
+        const uint64_t n = list ? nb : na;
+        const uint64_t *d_keys = (const uint64_t *)(list ? d_keys_b : d_keys_a);
+        uint64_t r[4];
+        if (n) rc = tbk_classifier_sweep_keys(c, d_keys, n, k, 1, 0, (const uint8_t *)d_expect + base, chunk, r);
+        if (rc || !n) { base += n; continue; }
+        out[0] += n; out[1] += r[0]; out[2] += r[1]; out[3] += r[2];
+        if (out[4] == ~0ull && r[3] != ~0ull) out[4] = base + r[3];
+        base += n;
+    }
+    return rc;
+}
+
 extern "C" int tbk_classifier_verify(tbk_classifier *c, tbk_table *a, tbk_table *b, uint64_t out[5]) {
     if (!c || !a || !b || !out) return vfail(TBK_ERR_INVALID, "NULL argument");
     const int k = tbk_table_k(a);
@@ -193,25 +232,11 @@ extern "C" int tbk_classifier_verify(tbk_classifier *c, tbk_table *a, tbk_table 
     int rc = on_device(tbk_classifier_device(c));
     if (rc) return rc;
     out[0] = out[1] = out[2] = out[3] = 0; out[4] = ~0ull;
-    const uint64_t chunk = (uint64_t)1 << 24;
+    const uint64_t na = tbk_table_num_kmers(a), nb = tbk_table_num_kmers(b);
     uint8_t *d_expect = nullptr;
-    V_TRY(hipMalloc((void **)&d_expect, chunk));
-    uint64_t base = 0;
-    for (tbk_table *t : {a, b}) {
-        const uint64_t n = tbk_table_num_kmers(t);
-        const uint64_t *d_keys = (const uint64_t *)tbk_table_device_keys(t);
-        for (uint64_t first = 0; first < n && !rc; first += chunk) {
-            const uint64_t cn = std::min(chunk, n - first);
-            uint64_t r[4];
-            rc = tbk_sweep_expectation_device(a, b, d_keys + first, cn, d_expect);
-            if (!rc) rc = tbk_classifier_sweep_keys(c, d_keys + first, cn, k, 1, 0, d_expect, chunk, r);
-            if (rc) break;
-            out[0] += cn; out[1] += r[0]; out[2] += r[1]; out[3] += r[2];
-            if (out[4] == ~0ull && r[3] != ~0ull) out[4] = base + first + r[3];
-        }
-        base += n;
-        if (rc) break;
-    }
+    V_TRY(hipMalloc((void **)&d_expect, na + nb + 8));
+    rc = tbk_verify_expectations_(a, b, d_expect);
+    if (!rc) rc = tbk_classifier_verify_expect_(c, tbk_table_device_keys(a), na, tbk_table_device_keys(b), nb, k, d_expect, out);
     (void)hipFree(d_expect);
     return rc;
 }

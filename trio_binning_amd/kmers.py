@@ -345,6 +345,8 @@ class Options:
 
 def _options_ptr(options):
     """ctypes pointer for the *_opts calls: the given Options, or - none given - the TBK_* environment's (the fallback)"""
+    if not _lib.HAS_OPTIONS:
+        return None
     if options is None:
         options = Options.from_env()
     return C.byref(options.c)
@@ -396,6 +398,24 @@ class Classifier:
         return {"entry_layout": ent.value in (1, 2), "wide_entries": ent.value == 2, "short_keys": ent.value == 3, "full_keys": ent.value == 4, "entries_a": ea.value, "entries_b": eb.value, "shared_keys": sh.value, "layout_builds": nb_.value, "keys_past_half": past.value, "front_layout": bool(front.value), "keys_behind_front": behind.value, "distinct_a": da.value, "distinct_b": db.value, "n_buckets": nb.value, "table_bytes": by.value,
                 "minimizer_w": w.value, "minimizer_m": m.value, "span_offset": o.value,
                 "sampling_t": lib.tbk_classifier_sampling_t(self._h)}
+
+    def verified(self) -> dict:
+        """What the constructor's own check did (``tbk_options.verify_build``: by default every table built by inserts that
+        merge keys - entries, wide entries - is asked for every line of both lists before it is handed out, on every device):
+        {"lines": list lines looked up again (0: not checked), "seconds"}.  A table that answers a line wrongly is never
+        returned - the constructor fails."""
+        lines, sec = C.c_uint64(), C.c_double()
+        if not hasattr(lib, "tbk_classifier_verified"):
+            return {"lines": 0, "seconds": 0.0}
+        check(lib.tbk_classifier_verified(self._h, C.byref(lines), C.byref(sec)))
+        return {"lines": lines.value, "seconds": sec.value}
+
+    def table_id(self) -> tuple:
+        """(where the table lies - equal ids share one table -, how it was made: 0 built first or shared, 1 a copy of a finished
+        table, 2 built again on this device from the lists in the first one's geometry)"""
+        tid, rep = C.c_uint64(), C.c_int()
+        check(lib.tbk_classifier_table_id(self._h, C.byref(tid), C.byref(rep)))
+        return tid.value, rep.value
 
     def verify(self, kmers_hap_a: Optional[HashSet] = None, kmers_hap_b: Optional[HashSet] = None) -> dict:
         """Every line of both lists through the finished table, against the lists' standalone tables of verbatim keys
