@@ -134,6 +134,11 @@ int tbk_table_contains(tbk_table *t, const uint64_t *keys, uint64_t n, uint8_t *
  * hapA's window length with hapB's packing there, c/kmers.c:251-253,278-290). */
 int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *hap_a,
                             const tbk_table *hap_b, int *count_a, int *count_b);
+/* The same call on a classifier of the caller's (tbk_count_kmers_in_read keeps one for the last pair of lists it saw).  The
+ * reference's driver calls count_kmers_in_read once per read (classify_by_kmers.py:99-102); a call here is one memcpy into
+ * pinned memory, ONE kernel launch that reads the read over PCIe, 8 bytes back and one stream synchronisation (reads of up
+ * to 8 Mi bases; longer ones go through tbk_classify_batch). */
+int tbk_classifier_count_read(tbk_classifier *c, const char *read, int64_t len, int *count_a, int *count_b);
 
 /* Batch path (what the per-read Python loop classify_by_kmers.py:99-102 becomes).  Creating
  * the classifier builds the two open-addressing tables in HBM on the lists' device: 64-bit

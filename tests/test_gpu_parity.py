@@ -102,6 +102,48 @@ def test_golden_edge_vectors(gpu, tmp_path):
         assert got.tolist() == case["counts"], case["name"]
 
 
+@pytest.mark.parametrize("layout,k", [("auto", 5), ("keys", 21), ("entries", 21), ("short_keys", 21), ("full_keys", 31), ("wide_entries", 31), ("auto", 32)])
+def test_one_read_per_call_equals_the_oracle(gpu, orc, tmp_path, layout, k):
+    """count_kmers_in_read (c/kmers.c:270-299) called the way the reference's driver calls it - once per read,
+    classify_by_kmers.py:99-102 - takes a path of its own (tbk_host.cpp count_small: the read is read by the single-read
+    kernel from pinned host memory, the counters run on between calls): every read of the golden vector, reads shorter than
+    k, of exactly k bases, with bytes outside ACGT, a read long enough to make the path's buffer grow and one beyond its
+    limit (the batch path), in an order that mixes them - each count equal to the oracle's."""
+    from trio_binning_amd import kmers
+
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == k)
+    fa = _write(tmp_path, "a.txt", "".join(x + "\n" for x in v["list_a"]))
+    fb = _write(tmp_path, "b.txt", "".join(x + "\n" for x in v["list_b"]))
+    oa, ob = orc.table_from_file(fa), orc.table_from_file(fb)
+    a, b = kmers.HashSet.from_file(fa), kmers.HashSet.from_file(fb)
+    rng = np.random.default_rng(77 + k)
+    keys = v["list_a"] + v["list_b"]
+    long_read = "".join("ACGT"[c] for c in rng.integers(0, 4, 1_600_000))
+    for pos in range(1000, 1_590_000, 50_021):
+        long_read = long_read[:pos] + keys[pos % len(keys)] + long_read[pos + k:]
+    huge = long_read * 6                       # 9.6 Mb: beyond the one-launch path's 8 Mi bases
+    reads = list(v["reads"]) + ["", "A", keys[0][: k - 1], keys[0], _rc(keys[1]), keys[2] + "N" + keys[3], "acgt" * 20 + keys[4], long_read, keys[5] * 3, huge, v["reads"][0]]
+    order = rng.permutation(len(reads))
+    bases, offs = _pack([reads[i] for i in order])
+    want = orc.count_batch(bases, offs, oa, ob)
+    with kmers.Classifier(a, b, options=kmers.Options.layout(layout)) as cls:
+        st = cls.stats()
+        assert {"keys": not (st["entry_layout"] or st["short_keys"] or st["full_keys"]), "entries": st["entry_layout"] and not st["wide_entries"], "wide_entries": st["wide_entries"],
+                "short_keys": st["short_keys"], "full_keys": st["full_keys"], "auto": True}[layout], st
+        for j, i in enumerate(order):
+            assert list(cls.count_read(reads[i])) == want[j].tolist(), (j, i, len(reads[i]))
+        # interleaved with batches on the same classifier: the running counters are the one-read path's own
+        assert np.array_equal(cls.classify_batch(bases, offs), want)
+        assert list(cls.count_read(reads[0])) == want[list(order).index(0)].tolist()
+    for j, i in enumerate(order[:60]):      # (the reference-named entry point: its cached classifier is built with the defaults)
+        assert list(kmers.count_kmers_in_read(reads[i], a, b)) == want[j].tolist(), (j, i, len(reads[i]))
+    assert want.sum() > 100
+    # the same list again after the lists changed places: the cached classifier follows the arguments
+    want_ba = orc.count_batch(bases, offs, ob, oa)
+    for j, i in enumerate(order[:40]):
+        assert list(kmers.count_kmers_in_read(reads[i], b, a)) == want_ba[j].tolist(), (j, i)
+
+
 # ---- seeded random inputs against the oracle ----------------------------------------------------
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 15, 16, 17, 21, 27, 31, 32])
 def test_random_vs_oracle(gpu, orc, tmp_path, k):

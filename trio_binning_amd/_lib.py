@@ -81,6 +81,8 @@ _sig("tbk_table_bytes", _u64, _vp)
 _sig("tbk_table_contains", C.c_int, _vp, _vp, _u64, _vp)
 _sig("tbk_count_kmers_in_read", C.c_int, C.c_char_p, C.c_int64, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_create", C.c_int, _vp, _vp, C.POINTER(_vp))
+if hasattr(lib, "tbk_classifier_count_read"):
+    _sig("tbk_classifier_count_read", C.c_int, _vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int))
 _sig("tbk_classifier_destroy", None, _vp)
 _sig("tbk_classifier_create_multi", C.c_int, _vp, _vp, C.POINTER(C.c_int), C.c_int, C.POINTER(_vp))
 _sig("tbk_classifier_replicate", C.c_int, _vp, C.c_int, C.POINTER(_vp))

@@ -43,7 +43,7 @@ extern "C" hipError_t tbk_launch_full_insert(uint64_t *, uint32_t, uint32_t, Tbk
 extern "C" hipError_t tbk_launch_probe_index(const uint64_t *, uint64_t, uint64_t, int32_t *, uint32_t *, uint64_t, int, hipStream_t);
 extern "C" int tbk_probe_has_two_read_kernel(TbkMz);
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *, const uint32_t *, const uint16_t *, const uint64_t *, uint64_t, uint64_t, TbkPairView, int,
-                                             int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, int, hipEvent_t, hipStream_t);
+                                             int32_t *, uint32_t *, uint64_t, uint64_t, uint64_t, int, int, hipEvent_t, hipStream_t, int);
 extern "C" hipError_t tbk_launch_scatter_bad(const uint32_t *, const uint16_t *, uint64_t, uint16_t *, uint64_t, int, hipStream_t);
 extern "C" uint64_t tbk_packed_chunks(uint64_t total_bases);
 extern "C" uint64_t tbk_probe_passes(uint64_t total);
@@ -449,6 +449,24 @@ struct tbk_classifier {
     double timed_ms = 0.0;         // whole probe: index + both kernels
     double timed_single_ms = 0.0;  // the single-read probe kernel alone
     int fold_timing();
+    // One read per call (tbk_count_kmers_in_read: the reference's own loop, classify_by_kmers.py:99-102, through the literal drop-in).
+    // The read is copied into `small_h` (pinned, mapped into the device's address space) and the single-read kernel reads it
+    // THERE, over PCIe - [offsets: 2 x u64 | pad to 64 B | bases]; the pass index of a one-read batch is all zeros and lives in
+    // `small_scratch`, written once; the two counters in `small_d_counts` are never cleared - they run on, and the host takes the
+    // difference to the previous call's (mod 2^32).  A call is one memcpy on the host, ONE kernel launch, one 8-byte copy back,
+    // one stream synchronisation: 105 us -> what INTEGRATION.md C records.
+    uint8_t *small_h = nullptr;
+    uint32_t *small_h_counts = nullptr, small_last[2] = {0, 0};
+    int32_t *small_d_counts = nullptr;
+    uint32_t *small_scratch = nullptr;
+    uint64_t small_cap = 0, small_pass_cap = 0;
+    void small_free() {
+        if (small_h) (void)hipHostFree(small_h);
+        if (small_h_counts) (void)hipHostFree(small_h_counts);
+        if (small_d_counts) (void)hipFree(small_d_counts);
+        if (small_scratch) (void)hipFree(small_scratch);
+        small_h = nullptr; small_h_counts = nullptr; small_d_counts = nullptr; small_scratch = nullptr; small_cap = small_pass_cap = 0;
+    }
 };
 
 // ---- library ---------------------------------------------------------------------------
@@ -2124,6 +2142,7 @@ extern "C" void tbk_classifier_destroy(tbk_classifier *c) {
         for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
         c->pair_owner.reset();  // (the table itself goes with its last user)
         if (c->d_pass_read) (void)hipFree(c->d_pass_read);
+        c->small_free();
         for (const Slot &s : c->ring) if (s.busy && c->streams) c->streams->in_flight--;
         c->streams.reset();  // (the streams go with their last ring)
     }
@@ -2199,7 +2218,7 @@ static int launch_probe_timed(tbk_classifier *c, const uint8_t *d_bases, const u
         if (slices[j].arrived) HIP_TRY(hipStreamWaitEvent(c->compute, slices[j].arrived, 0));
         if (ev) HIP_TRY(hipEventRecord(ev[2 + 3 * j], c->compute));  // (behind the wait: the slice's own time starts when its bases are there)
         HIP_TRY(tbk_launch_probe_range(d_bases, d_codes, d_bad16, d_offsets, n_reads, total, c->pair(), c->k, d_counts, c->d_pass_read, c->cap_passes,
-                                       slices[j].pass_lo, slices[j].pass_hi, c->max_blocks, c->opt.two_read_kernel != 0, ev ? ev[3 + 3 * j] : nullptr, c->compute));
+                                       slices[j].pass_lo, slices[j].pass_hi, c->max_blocks, c->opt.two_read_kernel != 0, ev ? ev[3 + 3 * j] : nullptr, c->compute, 0));
         if (ev) HIP_TRY(hipEventRecord(ev[4 + 3 * j], c->compute));
     }
     c->last_passes = passes;
@@ -2670,6 +2689,48 @@ static void drop_cached_classifier(const tbk_table *t) {
     }
 }
 
+// One read, one launch (tbk_classifier: small_*).  Reads of up to SMALL_READ_MAX bases; longer ones take the batch path.
+static constexpr uint64_t SMALL_READ_MAX = (uint64_t)8 << 20;
+
+static int count_small(tbk_classifier *c, const char *read, uint64_t len, int *count_a, int *count_b) {
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    if (len > c->small_cap) {
+        c->small_free();
+        const uint64_t cap = std::max<uint64_t>((uint64_t)1 << 20, len + len / 2);
+        const uint64_t pass_cap = (tbk_probe_passes(cap) + 2) & ~1ull;
+        hipError_t e = hipHostMalloc((void **)&c->small_h, 64 + cap + 4096, hipHostMallocPortable | hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->small_h_counts, 64, hipHostMallocPortable);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->small_d_counts, 64);
+        if (e == hipSuccess) e = hipMemset(c->small_d_counts, 0, 64);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->small_scratch, (4 * pass_cap + 16) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(c->small_scratch, 0, (4 * pass_cap + 16) * sizeof(uint32_t));  // every pass starts in read 0; no multi-read, no two-read pass
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { (void)hipGetLastError(); c->small_free(); return TBK_ERR_STATE; }
+        memset(c->small_h, 0, 64 + cap + 4096);
+        c->small_cap = cap; c->small_pass_cap = pass_cap;
+        c->small_last[0] = c->small_last[1] = 0;
+    }
+    uint64_t *offsets = (uint64_t *)c->small_h;
+    uint8_t *bases = c->small_h + 64;
+    offsets[0] = 0; offsets[1] = len;
+    memcpy(bases, read, len);
+    std::lock_guard<std::mutex> together(c->streams->enqueue);
+    hipError_t e = tbk_launch_probe_range(bases, nullptr, nullptr, offsets, 1, len, c->pair(), c->k, c->small_d_counts, c->small_scratch, c->small_pass_cap, 0,
+                                          tbk_probe_passes(len), c->max_blocks, 0, nullptr, c->compute, 1);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->small_h_counts, c->small_d_counts, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->compute);
+    if (e != hipSuccess) {
+        c->small_free();  // (the running counters are no longer known)
+        return fail(TBK_ERR_HIP, "tbk_count_kmers_in_read: %s", hipGetErrorString(e));
+    }
+    const uint32_t now_a = c->small_h_counts[0], now_b = c->small_h_counts[1];
+    *count_a = (int)(uint32_t)(now_a - c->small_last[0]);
+    *count_b = (int)(uint32_t)(now_b - c->small_last[1]);
+    c->small_last[0] = now_a; c->small_last[1] = now_b;
+    return TBK_OK;
+}
+
 extern "C" int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_table *a, const tbk_table *b,
                                        int *count_a, int *count_b) {
     if (!read || !a || !b || !count_a || !count_b) return fail(TBK_ERR_INVALID, "NULL argument");
@@ -2681,9 +2742,21 @@ extern "C" int tbk_count_kmers_in_read(const char *read, int64_t len, const tbk_
         if (rc) return rc;
         g_cached_a = a; g_cached_b = b;
     }
+    return tbk_classifier_count_read(g_cached, read, len, count_a, count_b);
+}
+
+// The same on a classifier of the caller's (one caller at a time per classifier, like every entry point that takes one).
+extern "C" int tbk_classifier_count_read(tbk_classifier *c, const char *read, int64_t len, int *count_a, int *count_b) {
+    if (!c || !read || !count_a || !count_b) return fail(TBK_ERR_INVALID, "NULL argument");
+    if (len < 0) len = (int64_t)strlen(read);
+    if (len < c->k) { *count_a = *count_b = 0; return TBK_OK; }  // c/kmers.c:287: no window
+    if ((uint64_t)len <= SMALL_READ_MAX) {
+        const int rc = count_small(c, read, (uint64_t)len, count_a, count_b);
+        if (rc != TBK_ERR_STATE) return rc;  // (TBK_ERR_STATE: the fast path could not be set up - the batch path below)
+    }
     uint64_t offsets[2] = {0, (uint64_t)len};
     int32_t counts[2] = {0, 0};
-    int rc = tbk_classify_batch(g_cached, (const uint8_t *)read, offsets, 1, counts);
+    int rc = tbk_classify_batch(c, (const uint8_t *)read, offsets, 1, counts);
     if (rc) return rc;
     *count_a = counts[0];
     *count_b = counts[1];

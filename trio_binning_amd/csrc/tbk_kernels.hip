@@ -2314,7 +2314,9 @@ extern "C" hipError_t tbk_launch_probe_index(const uint64_t *d_offsets, uint64_t
 
 extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint32_t *d_codes, const uint16_t *d_bad16, const uint64_t *d_offsets,
                                              uint64_t n_reads, uint64_t total, TbkPairView t, int k, int32_t *d_counts, uint32_t *d_scratch,
-                                             uint64_t pass_cap, uint64_t pass_lo, uint64_t pass_hi, int max_blocks, int use_two, hipEvent_t between, hipStream_t stream) {
+                                             uint64_t pass_cap, uint64_t pass_lo, uint64_t pass_hi, int max_blocks, int use_two, hipEvent_t between, hipStream_t stream,
+                                             int only_single) {
+    // only_single != 0: the single-read kernel alone (a batch of ONE read has no pass that touches two: tbk_count_kmers_in_read's path)
     if (total == 0 || n_reads == 0 || pass_hi <= pass_lo) return hipSuccess;
     ProbeArgs p;
     fill_args(p, d_bases, d_codes, d_bad16, d_offsets, n_reads, total, t, k, d_counts, d_scratch, pass_cap);
@@ -2347,6 +2349,7 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     hipError_t e = hipSuccess;
     for (int which = 2; which >= 0; which--) {  // 2: multi-read passes, 1: two-read passes, 0: single-read passes (timed by itself: `between`)
         if (which == 1 && blocks_two == 0) continue;
+        if (which != 0 && only_single) continue;
         // the event in front of the single-read kernel: the host times it by itself (tbk_kernel_timing_read2)
         if (which == 0 && between != nullptr) { e = hipEventRecord(between, stream); if (e != hipSuccess) return e; }
 #define TBK_LAUNCH(N, M, S, F) do { if (which == 2) hipLaunchKernelGGL((tbk_probe_kernel<N, M, S, F, true>), grid_multi, block, 0, stream, p); \

@@ -436,6 +436,14 @@ class Classifier:
     def classify_reads(self, seqs: Sequence[str]) -> np.ndarray:
         return self.classify_batch(*pack_reads(seqs))
 
+    def count_read(self, read: str) -> Tuple[int, int]:
+        """One read, one kernel launch (``tbk_classifier_count_read``): what ``count_kmers_in_read`` - the reference's per-read
+        call, kmers.py:125-154 - does on its cached classifier."""
+        raw = read.encode("utf-8")
+        ca, cb = C.c_int(), C.c_int()
+        check(lib.tbk_classifier_count_read(self._h, raw, len(raw), C.byref(ca), C.byref(cb)))
+        return ca.value, cb.value
+
     def submit(self, bases: np.ndarray, offsets: np.ndarray) -> int:
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
