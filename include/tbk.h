@@ -363,6 +363,7 @@ int tbk_pipeline_create_test_(int n_rings, int ring_depth, tbk_pipeline_test_sub
 typedef struct tbk_run_stats {
     uint64_t reads, bases, batches;
     double read_s, gpu_wait_s, write_s, total_s;  /* busy seconds of the reader / waiting for tickets / of the writer; wall */
+    int32_t gzip_encoder, reserved_;              /* who coded the bins' gzip members: 0 nobody (plain bins), 1 the host, 2 the device */
 } tbk_run_stats;
 int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64_t num_kmers_a, uint64_t num_kmers_b, const char *out_a,
                       const char *out_b, const char *out_u, int gzip_output, int gzip_level, int tsv_fd, uint64_t batch_bases,
@@ -442,6 +443,16 @@ int tbk_fastx_batch_view(const tbk_fastx_batch *b, uint64_t *n_reads, const uint
 int tbk_bin_writer_open(const char *path_a, const char *path_b, const char *path_u, int gzip_output,
                         int level, int threads, tbk_bin_writer **out);
 /* bins[i] in {'A','B','U'} for every record of the batch; records keep input order per bin. */
+/* gzip output: code the members on `device` (csrc/tbk_gdeflate.hip: per-block Huffman coding as kernels, the members' CRC-32s summed
+ * on the host meanwhile, one writer thread per bin) instead of on the host's threads.  Right after tbk_bin_writer_open.  A no-op for
+ * plain output, level 0, TBK_GZIP_ENCODER=cpu / zlib.  tbk_bin_writer_encoder: 1 when the device codes, 0 when the host does.
+ * The decompressed bytes are the same either way (seq.py:27-42,132-134). */
+int tbk_bin_writer_use_device(tbk_bin_writer *w, int device);
+/* The same encoder by itself: n_members pieces of text (back to back in `text`, member_len[i] bytes each) -> as many gzip members,
+ * back to back in dst (member_out_len[i] bytes each; *need = bytes used, or needed when cap is too small: TBK_ERR_NOMEM). */
+int tbk_gzip_members_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, char *dst, uint64_t cap,
+                            uint64_t *member_out_len, uint64_t *need);
+int tbk_bin_writer_encoder(const tbk_bin_writer *w);
 int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins);
 int tbk_bin_writer_close(tbk_bin_writer *w);
 /* The writer's own encoder for gzip members whose bytes do not come in runs (FASTQ of long reads:

@@ -37,6 +37,9 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--gz-input", action="store_true",
                 help="also feed the reads as .fastq.gz, the way the reference's own CLI test and README do (tests/test_classify_by_kmers.py:19-36, seq.py:86-92): "
                      "once as ONE ordinary gzip member (a single DEFLATE chain: the reader's guessing inflater) and once as bgzf blocks, bins plain")
+ap.add_argument("--gz-both", action="store_true",
+                help="with --gz-input: every gzip'ed input also with gzip'ed bins - the reference's DEFAULT mode (seq.py:86-92 reads .gz through gzip.open, "
+                     "classify_by_kmers.py:86-92 writes .gz unless --no-gzip-output): both ends compressed, sharing the host's CPUs")
 ap.add_argument("--qual", choices=["const", "hifi"], default="const", help="quality strings: one symbol, or HiFi-like (60 %% at the cap, the rest spread: what a real .fastq.gz inflates like)")
 ap.add_argument("--gz-level", type=int, default=6)
 ap.add_argument("--gz-env", default="", help="further runs of the gzip'ed inputs under these environments, ';'-separated (e.g. TBK_PINFLATE_SPAN=4194304;TBK_PINFLATE_SPAN=8388608)")
@@ -224,7 +227,7 @@ for key in ("TBK_LIST_CACHE", "TBK_LIST_GPU_PARSE"):
     os.environ.pop(key, None)
 
 # ---- the command line ---------------------------------------------------------------------------------
-env = dict(os.environ, PYTHONPATH=ROOT, TBK_STATS="1")
+env = dict(os.environ, PYTHONPATH=ROOT, TBK_STATS="1", TBK_WRITE_TIMING="1")
 runs = [(mode, cache) for mode in a.modes.split(",") for cache in ("text_lists", "cached_lists")]
 if a.devices:
     runs.append(("plain", "devices_" + a.devices.replace(",", "_")))
@@ -259,14 +262,18 @@ for mode, cache in runs:
             "wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
             "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None,
             "before_the_loop_s": round(dt - stages.get("loop_s", 0), 2), "bins": bins, "write_timing": wt[-1] if wt else None, "loop_timing": lt[-1] if lt else None,
+            "gpu_gzip": next((l for l in p.stderr.decode().splitlines() if l.startswith("tbk-gpu-gzip ")), None),
             "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages
 # ---- gzip'ed reads in, plain bins out ---------------------------------------------------------------------
-gz_runs = [(label, path, "") for label, path in gz_inputs.items()]
-gz_runs += [(label, path, e) for e in a.gz_env.split(";") if e for label, path in gz_inputs.items()]
-for label, path, extra in gz_runs:
-    label = label + ("" if not extra else "_" + extra.replace("=", "_"))
+gz_runs = [(label, path, "", False) for label, path in gz_inputs.items()]
+gz_runs += [(label, path, e, False) for e in a.gz_env.split(";") if e for label, path in gz_inputs.items()]
+if a.gz_both:
+    gz_runs += [(label, path, "", True) for label, path in gz_inputs.items()]
+    gz_runs += [(label, path, e, True) for e in a.gz_env.split(";") if e for label, path in gz_inputs.items()]
+for label, path, extra, gz_out in gz_runs:
+    label = label + ("_gz_bins" if gz_out else "") + ("" if not extra else "_" + extra.replace("=", "_"))
     out = os.path.join(out_root, "gz_" + label)
     os.makedirs(out)
     tsv = os.path.join(out, "stdout.tsv")
@@ -274,7 +281,7 @@ for label, path, extra in gz_runs:
     with open(tsv, "wb") as so:
         p = subprocess.run([sys.executable, "-m", "trio_binning_amd.classify_by_kmers", path, paths[0], paths[1],
                             "--haplotype-a-out-prefix", os.path.join(out, "hapA"), "--haplotype-b-out-prefix", os.path.join(out, "hapB"),
-                            "--unclassified-out-prefix", os.path.join(out, "unc"), "--no-gzip-output"],
+                            "--unclassified-out-prefix", os.path.join(out, "unc")] + ([] if gz_out else ["--no-gzip-output"]),
                            env=dict(env, TBK_PINFLATE_TIMING="1", **dict(kv.split("=", 1) for kv in extra.split(",") if kv)), stdout=so, stderr=subprocess.PIPE)
     dt = time.time() - t
     err = p.stderr.decode()
@@ -304,7 +311,9 @@ for label, path, extra in gz_runs:
             bins[b] = bins.get(b, 0) + 1
     res["gz_" + label] = {"wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
                           "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None, "inflate": inflate, "bins": bins,
-                          "text_GB_per_s_in_the_loop": round(res["fastq_GB"] / stages["loop_s"], 2) if stages.get("loop_s") else None}
+                          "text_GB_per_s_in_the_loop": round(res["fastq_GB"] / stages["loop_s"], 2) if stages.get("loop_s") else None,
+                          "bins_written_as": "gzip members" if gz_out else "plain text", "gpu_gzip": next((l for l in err.splitlines() if l.startswith("tbk-gpu-gzip ")), None),
+                          "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
     shutil.rmtree(out, ignore_errors=True)
     os.sync()
 if not a.keep:

@@ -45,6 +45,7 @@
 #include "../../include/tbk.h"
 #include "tbk_inflate.h"
 #include "tbk_pack.h"
+#include "tbk_gdeflate.h"
 
 uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp: zlib's crc32() by carry-less multiplication
 
@@ -1587,10 +1588,20 @@ extern "C" int tbk_format_tsv(const tbk_fastx_batch *b, const char *bins, const 
 struct TextBuf {
     char *p = nullptr;
     size_t n = 0, cap = 0;
-    ~TextBuf() { free(p); }
+    bool pinned = false;  // hipHostMalloc'ed: what the GPU gzip encoder copies its text from (set before the first grow_to)
+    ~TextBuf() { release(); }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
     bool grow_to(size_t need) {
         if (need <= cap) return true;
         size_t c = std::max(need + need / 4, (size_t)1 << 20);
+        if (pinned) {
+            char *q = nullptr;
+            if (hipHostMalloc((void **)&q, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (n) memcpy(q, p, n);
+            if (p) (void)hipHostFree(p);
+            p = q; cap = c;
+            return true;
+        }
         char *q = (char *)realloc(p, c);
         if (!q) return false;
         p = q; cap = c;
@@ -1608,6 +1619,44 @@ struct BinFile {
     TextBuf text;           // records not yet written
 };
 
+// One thread per bin that writes finished gzip members to the bin's file while the writer thread is already gathering the next
+// batch (the GPU encoder's path: the members come back from the device two batches later).
+struct IoLane {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<const char *, size_t>> q;
+    bool busy = false, stop = false;
+    int fd = -1;
+    std::string err;
+    uint64_t written = 0;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) { if (stop) return; continue; }
+            auto [p, n] = q.front();
+            q.pop_front();
+            busy = true;
+            lk.unlock();
+            std::string e;
+            while (n) {
+                const ssize_t k = ::write(fd, p, n);
+                if (k < 0) { if (errno == EINTR) continue; e = std::string("write: ") + strerror(errno); break; }
+                p += k; n -= (size_t)k; written += (uint64_t)k;
+            }
+            lk.lock();
+            if (!e.empty() && err.empty()) err = e;
+            busy = false;
+            cv.notify_all();
+        }
+    }
+    void start(int fd_) { fd = fd_; th = std::thread([this] { run(); }); }
+    void put(const char *p, size_t n) { { std::lock_guard<std::mutex> lk(mu); q.emplace_back(p, n); } cv.notify_all(); }
+    void idle() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return q.empty() && !busy; }); }
+    void end() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
+
 struct tbk_bin_writer {
     BinFile bin[3];  // A, B, U
     bool gz = false;
@@ -1615,6 +1664,11 @@ struct tbk_bin_writer {
     int threads = 1;
     size_t chunk = (size_t)1 << 20;  // text per gzip member: small enough that one batch keeps every host thread busy
     std::string err;
+    // the GPU gzip encoder (tbk_gdeflate.hip; tbk_bin_writer_use_device): members coded on the device, written by a thread per bin
+    tbk_gdeflate *gpu = nullptr;
+    IoLane lane[3];
+    bool lanes_on = false;
+    double gpu_submit_s = 0, gpu_crc_s = 0, gpu_text_wait_s = 0, gpu_collect_s = 0, gpu_io_wait_s = 0, fill_s = 0;
 };
 
 static bool write_all(int fd, const char *p, size_t n, std::string &err) {
@@ -1674,6 +1728,84 @@ static bool deflate_member(const char *src, size_t n, int level, std::vector<cha
 
 struct Piece { int bin; const char *src; size_t n; std::vector<char> out; bool ok = true; };
 
+static inline double wall_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// finished members to their bins' files: each bin's are handed to its lane in order (the lanes of the three bins run side by side)
+static int hand_to_lanes(tbk_bin_writer *w, const std::vector<tbk_gdeflate_out> &outs) {
+    const double t0 = wall_now();
+    for (IoLane &l : w->lane) l.idle();  // (the bytes handed over last time are on their way to being reused)
+    w->gpu_io_wait_s += wall_now() - t0;
+    for (IoLane &l : w->lane) if (!l.err.empty()) return ffail(TBK_ERR_IO, "%s", l.err.c_str());
+    for (size_t i = 0; i < outs.size();) {
+        size_t k = i;
+        size_t n = outs[i].n;
+        while (k + 1 < outs.size() && outs[k + 1].tag == outs[i].tag && outs[k + 1].data == outs[k].data + outs[k].n) { k++; n += outs[k].n; }
+        w->lane[outs[i].tag].put(outs[i].data, n);
+        w->bin[outs[i].tag].file_off += n;
+        i = k + 1;
+    }
+    return TBK_OK;
+}
+
+// The gzip members of this flush coded on the device (tbk_gdeflate.hip).  Three jobs deep: this flush's text goes to the
+// device and is coded while the host sums the members' CRC-32s; the previous flush's members travel home; the one before
+// that is handed to the bins' writer threads.  The text buffers are free again when this returns.
+static int flush_bins_gpu(tbk_bin_writer *w, bool final, std::vector<Piece> &pieces, const size_t keep[3]) {
+    std::vector<tbk_gdeflate_out> outs;
+    int rc = TBK_OK;
+    if (!pieces.empty()) {
+        double t0 = wall_now();
+        std::vector<tbk_gdeflate_member> members;
+        members.reserve(pieces.size());
+        for (const Piece &pc : pieces) members.push_back(tbk_gdeflate_member{pc.src, pc.n, pc.bin});
+        rc = tbk_gdeflate_submit(w->gpu, members.data(), members.size());
+        if (rc) return rc;
+        w->gpu_submit_s += wall_now() - t0;
+        t0 = wall_now();
+        static const bool host_crc = getenv("TBK_GZIP_CRC") && strcmp(getenv("TBK_GZIP_CRC"), "host") == 0;  // (default: the device sums them too)
+        if (host_crc) {
+            std::atomic<size_t> next{0};
+            std::vector<uint32_t> crc(pieces.size());
+            auto work = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < pieces.size();) crc[i] = tbk_crc32(0, (const uint8_t *)pieces[i].src, pieces[i].n);
+            };
+            const int nt = (int)std::min<size_t>((size_t)w->threads, pieces.size());
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+            for (size_t i = 0; i < pieces.size(); i++) tbk_gdeflate_set_crc(w->gpu, i, crc[i]);
+        }
+        w->gpu_crc_s += wall_now() - t0;
+        t0 = wall_now();
+        rc = tbk_gdeflate_text_done(w->gpu);
+        if (rc) return rc;
+        w->gpu_text_wait_s += wall_now() - t0;
+        t0 = wall_now();
+        rc = tbk_gdeflate_collect(w->gpu, false, outs);
+        w->gpu_collect_s += wall_now() - t0;
+        if (rc) return rc;
+        if (!outs.empty()) { rc = hand_to_lanes(w, outs); if (rc) return rc; }
+    }
+    if (final) {
+        while (tbk_gdeflate_in_flight(w->gpu) > 0) {
+            const double t0 = wall_now();
+            rc = tbk_gdeflate_collect(w->gpu, true, outs);
+            w->gpu_collect_s += wall_now() - t0;
+            if (rc) return rc;
+            if (!outs.empty()) { rc = hand_to_lanes(w, outs); if (rc) return rc; }
+        }
+        for (IoLane &l : w->lane) l.idle();
+        for (IoLane &l : w->lane) if (!l.err.empty()) return ffail(TBK_ERR_IO, "%s", l.err.c_str());
+    }
+    for (int b = 0; b < 3; b++) {
+        BinFile &f = w->bin[b];
+        if (keep[b] && keep[b] != f.text.size()) memmove(f.text.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
+        f.text.n = keep[b];
+    }
+    return TBK_OK;
+}
+
 static int flush_bins(tbk_bin_writer *w, bool final) {
     // cut every bin's pending text into pieces (whole chunks; everything when final)
     std::vector<Piece> pieces;
@@ -1687,6 +1819,7 @@ static int flush_bins(tbk_bin_writer *w, bool final) {
         if (final && n > off) { pieces.push_back(Piece{b, f.text.data() + off, n - off, {}, true}); off = n; }
         keep[b] = n - off;
     }
+    if (w->gz && w->gpu) return flush_bins_gpu(w, final, pieces, keep);
     if (w->gz && !pieces.empty()) {
         std::atomic<size_t> next{0};
         auto work = [&]() {
@@ -1928,17 +2061,53 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         }
     };
     {
+        const double t0 = wall_now();
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; t++) pool.emplace_back(fill, t);
         fill(0);
         for (std::thread &th : pool) th.join();
+        w->fill_s += wall_now() - t0;
     }
     return flush_bins(w, false);
 }
 
+// The gzip members from here on are coded on `device` (tbk_gdeflate.hip) instead of on the host's threads: call it right after
+// tbk_bin_writer_open (gzip output; before the first write).  TBK_GZIP_ENCODER=cpu / zlib keeps the host encoders.
+extern "C" int tbk_bin_writer_use_device(tbk_bin_writer *w, int device) {
+    if (!w) return ffail(TBK_ERR_INVALID, "NULL argument");
+    if (!w->gz || w->gpu) return TBK_OK;
+    const char *enc = getenv("TBK_GZIP_ENCODER");
+    if ((enc && (strcmp(enc, "cpu") == 0 || strcmp(enc, "zlib") == 0)) || getenv("TBK_GZIP_STRATEGY") || w->level == 0) return TBK_OK;
+    for (int b = 0; b < 3; b++) if (w->bin[b].text.size()) return ffail(TBK_ERR_STATE, "tbk_bin_writer_use_device after the first write");
+    // (two prefixes naming one file: the lanes would interleave their writes where the reference's handles do not)
+    for (int b = 0; b < 3; b++) if (!w->bin[b].positional) return TBK_OK;
+    int rc = tbk_gdeflate_create(device, &w->gpu);
+    if (rc) return rc;
+    for (int b = 0; b < 3; b++) { w->bin[b].text.release(); w->bin[b].text.pinned = true; w->lane[b].start(w->bin[b].fd); }
+    w->lanes_on = true;
+    return TBK_OK;
+}
+
+extern "C" int tbk_bin_writer_encoder(const tbk_bin_writer *w) { return w && w->gpu ? 1 : 0; }
+
 extern "C" int tbk_bin_writer_close(tbk_bin_writer *w) {
     if (!w) return TBK_OK;
     int rc = flush_bins(w, true);
+    if (w->lanes_on) {
+        for (IoLane &l : w->lane) { l.idle(); l.end(); if (!l.err.empty() && !rc) rc = ffail(TBK_ERR_IO, "%s", l.err.c_str()); }
+        w->lanes_on = false;
+    }
+    if (w->gpu) {
+        if (getenv("TBK_WRITE_TIMING")) {
+            uint64_t tb = 0, mb = 0, nb = 0, nm = 0;
+            tbk_gdeflate_stats(w->gpu, &tb, &mb, &nb, &nm);
+            fprintf(stderr, "tbk-gpu-gzip %.3f GB of text in %llu members / %llu blocks -> %.3f GB; writer thread: gather %.3f s, submit %.3f s, crc %.3f s, waiting for the text's copy %.3f s, "
+                            "collect %.3f s, waiting for the bins' writers %.3f s\n", (double)tb / 1e9, (unsigned long long)nm, (unsigned long long)nb, (double)mb / 1e9, w->fill_s, w->gpu_submit_s,
+                    w->gpu_crc_s, w->gpu_text_wait_s, w->gpu_collect_s, w->gpu_io_wait_s);
+        }
+        tbk_gdeflate_destroy(w->gpu);
+        w->gpu = nullptr;
+    }
     if (w->gz) {
         // an empty bin is still a valid (empty) gzip file, as gzip.open(...).close() leaves it
         for (int b = 0; b < 3; b++) {

@@ -1,0 +1,948 @@
+// tbk_gdeflate.hip — the gzip members of the bin writer, entropy-coded on the GPU.
+//
+// The reference writes its three bins through gzip.open unless --no-gzip-output (seq.py:132-134,
+// classify_by_kmers.py:86-92): the DEFAULT mode compresses everything it writes.  tbk_deflate.cpp does that on the host
+// the way FASTQ text wants it - no LZ77 (four-symbol noise and per-base qualities have nothing to match in 32 KiB), a
+// byte histogram per line-aligned block, a canonical Huffman code, the dynamic-block header, the literals; runs of one
+// byte as matches at distance 1 - and 16 CPUs do 9 GB/s of it, which is what a run with gzip'ed bins waited for while
+// 256 CUs idled.  This file is the same coder as three kernels:
+//
+//   gd_encode_kernel   one workgroup (256 threads) per BLOCK of text (<= 32 KiB, cut at a line end by the host): the
+//                      histogram by LDS atomics, the Huffman tree (rank sort over all threads, the two-queue merge on
+//                      one lane), canonical codes, the RFC 1951 3.2.7 header, then every thread codes its own
+//                      contiguous stretch of the block at the bit offset a block-wide scan gives it; the block is
+//                      assembled in LDS (ds_or) and leaves for its slot in HBM in whole words.  A block ends with its
+//                      end-of-block code and an EMPTY STORED block (00 00 FF FF behind the next byte boundary - what
+//                      zlib's Z_SYNC_FLUSH writes), so every block starts on a byte and blocks are coded
+//                      independently.  A block that would not shrink is written as a stored block.
+//   gd_scan_kernel     one workgroup: where every block's bytes go in the dense output (gzip header in front of a
+//                      member's first block, final empty block + CRC-32 + ISIZE behind its last).
+//   gd_gather_kernel   one workgroup per block: slot -> dense output, and the members' framing bytes.
+//
+// The host (this file's tbk_gdeflate_*) cuts blocks, moves text in and members out through pinned memory on a stream of
+// its own, three jobs deep (a job's text goes in while the previous job's members come out and the one before is
+// written to the files), and fills in each member's CRC-32, which it sums (tbk_crc.cpp: PCLMULQDQ) while the device
+// codes.  HBM roofline: the kernels read the text twice and write ~0.45 of it twice: ~3 B of HBM traffic per byte
+// of text; PCIe carries 1 B in and ~0.45 B out per byte.  Any inflater reads the result; the decompressed bytes are
+// what went in (tests/test_gpu_deflate.py: zlib on every member).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tbk.h"
+#include "tbk_gdeflate.h"
+
+extern "C" void tbk_set_error_(int, const char *msg);
+
+namespace {
+
+constexpr int GD_T = 256;                      // threads per workgroup
+constexpr uint32_t GD_MAX_BLOCK = 16384;       // bytes of text per block (the LDS image of a coded block sets how many workgroups a CU holds: 16 KiB -> five)
+constexpr uint32_t GD_HDR_WORDS = 160;         // a dynamic block's header: 17 bits, 19 x 3, at most 287 code-length tokens of at most 7 + 7 bits: under 520 bytes
+constexpr uint32_t GD_NSYM = 288;              // literal/length alphabet (286 used)
+
+struct GdBlock {
+    uint64_t text_off;   // of the block's first byte in the job's text on the device
+    uint64_t slot_off;   // of the block's slot in the slot buffer
+    uint32_t n;          // bytes of text
+    uint32_t member;     // which member it belongs to
+    uint32_t flags;      // 1: first block of its member, 2: last
+    uint32_t member_n;   // bytes of text of the whole member (ISIZE)
+    uint64_t member_off; // of the member's first byte in the job's text (the CRC: how many bytes of the member follow a stretch)
+};
+
+// CRC-32 (the gzip polynomial, bit-reflected) of a concatenation from its parts' CRCs: crc(A || B) = crc(A) * x^(8 |B|) mod P + crc(B)
+// (zlib's crc32_combine, in its multmodp / x2nmodp form).  Every lane sums its own stretch of a block with the byte table and
+// multiplies the sum by x^(8 * bytes of the MEMBER behind the stretch); the member's CRC is the XOR of all of that (atomicXor per block).
+constexpr uint32_t GD_POLY = 0xedb88320u;
+__host__ __device__ inline uint32_t gd_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ GD_POLY : b >> 1;
+    }
+    return p;
+}
+struct GdX2n { uint32_t v[32]; };  // v[k] = x^(2^k) mod P
+__host__ __device__ inline uint32_t gd_x2nmodp(const GdX2n &tab, uint64_t n, unsigned k) {  // x^(n * 2^k) mod P
+    uint32_t p = 1u << 31;
+    while (n) { if (n & 1u) p = gd_multmodp(tab.v[k & 31u], p); n >>= 1; k++; }
+    return p;
+}
+inline GdX2n gd_x2n_table() {
+    GdX2n t;
+    uint32_t p = 1u << 30;  // x^1
+    t.v[0] = p;
+    for (int k = 1; k < 32; k++) t.v[k] = p = gd_multmodp(p, p);
+    return t;
+}
+
+__host__ __device__ inline uint64_t gd_slot_bytes(uint32_t n) { return ((uint64_t)n + n / 8 + 1024 + 15) & ~(uint64_t)15; }
+
+__device__ const uint16_t gd_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t gd_len_bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+
+// length symbol index (0..28) of a match length 3..258 (RFC 1951 3.2.5)
+__device__ inline int gd_len_code(uint32_t len) {
+    if (len == 258) return 28;
+    int c = 27;
+    while (gd_len_base[c] > len) c--;
+    return c;
+}
+
+// The block's text in LDS: 256 stretches of `segw` words, one per lane, each padded to an ODD number of words so that the lanes'
+// byte reads (lane t reads its own stretch front to back) fall into different banks.  The text is fetched from HBM once, in
+// whole coalesced words; until round 6's first profile every lane read its stretch byte by byte from global memory, four times
+// over - 64 cache lines per wave instruction, 130 k cycles of L1 per block: the kernel ran at the L1's pace (2.8 ms per 134 MB).
+constexpr uint32_t GD_SEGW_MAX = ((GD_MAX_BLOCK + 3 + 3) / 4 + GD_T - 1) / GD_T;   // 17 words
+constexpr uint32_t GD_TEXT_WORDS = GD_T * (GD_SEGW_MAX | 1u);
+
+struct Lds {
+    uint32_t text[GD_TEXT_WORDS];
+    uint32_t hdr[GD_HDR_WORDS];   // the block header's bits (the codes go straight to the slot)
+    uint32_t freq[GD_NSYM];
+    uint32_t w[2 * GD_NSYM];
+    uint16_t parent[2 * GD_NSYM];
+    uint16_t order[GD_NSYM];
+    uint16_t code[GD_NSYM];
+    uint8_t len[GD_NSYM];
+    uint8_t depth[2 * GD_NSYM];
+    uint32_t bl_count[16], next_code[16];
+    // the code-length code (19 symbols) and the header's token list
+    uint32_t clfreq[19];
+    uint8_t cllen[19];
+    uint16_t clcode[19];
+    uint8_t cl_sym[GD_NSYM + 2], cl_extra[GD_NSYM + 2];
+    uint32_t wave_sum[GD_T / 64];
+    uint32_t m, deepest, same, header_bits, total_bits, stored;
+};
+
+// Code lengths (<= limit) for the symbols with freq > 0 among freq[0 .. nsym): every thread takes part.  At least two
+// symbols have freq > 0.  The tree of tbk_deflate.cpp's huffman_lengths: leaves sorted by (freq, symbol), two-queue merge,
+// frequencies halved (never to zero) while the tree is deeper than the limit.
+__device__ void gd_huffman(Lds &s, uint32_t *freq, int nsym, int limit, uint8_t *len) {
+    const int t = threadIdx.x;
+    for (;;) {
+        if (t == 0) s.m = 0;
+        __syncthreads();
+        for (int a = t; a < nsym; a += GD_T) {
+            const uint32_t f = freq[a];
+            len[a] = 0;
+            if (!f) continue;
+            uint32_t r = 0;
+            for (int b = 0; b < nsym; b++) { const uint32_t g = freq[b]; r += (g != 0 && (g < f || (g == f && b < a))) ? 1u : 0u; }
+            s.order[r] = (uint16_t)a;
+            atomicAdd(&s.m, 1u);
+        }
+        __syncthreads();
+        const int m = (int)s.m;
+        if (t == 0) {
+            for (int i = 0; i < m; i++) s.w[i] = freq[s.order[i]];
+            int leaf = 0, inner = m, next = m;
+            while (next < 2 * m - 1) {
+                int pick[2];
+                for (int q = 0; q < 2; q++) {
+                    if (leaf < m && (inner >= next || s.w[leaf] <= s.w[inner])) pick[q] = leaf++;
+                    else pick[q] = inner++;
+                }
+                s.w[next] = s.w[pick[0]] + s.w[pick[1]];
+                s.parent[pick[0]] = s.parent[pick[1]] = (uint16_t)next;
+                next++;
+            }
+            s.depth[2 * m - 2] = 0;
+            uint32_t deepest = 0;
+            for (int i = 2 * m - 3; i >= 0; i--) {
+                const uint32_t d = (uint32_t)s.depth[s.parent[i]] + 1u;
+                s.depth[i] = (uint8_t)(d > 255u ? 255u : d);
+                if (i < m && d > deepest) deepest = d;
+            }
+            s.deepest = deepest;
+        }
+        __syncthreads();
+        if ((int)s.deepest <= limit) {
+            for (int i = t; i < m; i += GD_T) len[s.order[i]] = s.depth[i];
+            __syncthreads();
+            return;
+        }
+        for (int a = t; a < nsym; a += GD_T) if (freq[a]) freq[a] = (freq[a] + 1) / 2;
+        __syncthreads();
+    }
+}
+
+// canonical codes of the lengths, bit-reversed (DEFLATE packs a Huffman code from its most significant bit)
+__device__ void gd_codes(Lds &s, const uint8_t *len, int nsym, uint16_t *code) {
+    const int t = threadIdx.x;
+    if (t < 16) s.bl_count[t] = 0;
+    __syncthreads();
+    for (int a = t; a < nsym; a += GD_T) if (len[a]) atomicAdd(&s.bl_count[len[a]], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t c = 0;
+        s.bl_count[0] = 0;
+        for (int l = 1; l <= 15; l++) { c = (c + s.bl_count[l - 1]) << 1; s.next_code[l] = c; }
+    }
+    __syncthreads();
+    for (int a = t; a < nsym; a += GD_T) {
+        const int l = len[a];
+        if (!l) { code[a] = 0; continue; }
+        uint32_t rank = 0;
+        for (int b = 0; b < a; b++) rank += len[b] == l ? 1u : 0u;
+        const uint32_t v = s.next_code[l] + rank;
+        code[a] = (uint16_t)(__brev(v) >> (32 - l));
+    }
+    __syncthreads();
+}
+
+// One lane's bit writer.  LDS (the header, assembled before it is known whether the block is coded at all): every word by ds_or.
+// GLOBAL (the codes, straight into the block's slot in HBM, which the job zeroed): a lane's stretch of bits is contiguous, so only
+// its first and last word are shared with its neighbours - those go in by atomicOr, the words between by plain stores.
+template <bool GLOBAL>
+struct BitOutT {
+    uint32_t *out;
+    uint64_t acc;
+    uint32_t word;   // index of the word acc's bit 0 belongs to
+    int n;           // bits in acc
+    bool first;      // the next word to leave is the stretch's first (it may hold a neighbour's bits)
+    __device__ BitOutT(uint32_t *o, uint32_t bitpos) : out(o), acc(0), word(bitpos >> 5), n((int)(bitpos & 31u)), first(true) {}
+    __device__ inline void put(uint32_t bits, int len) {
+        acc |= (uint64_t)bits << n;
+        n += len;
+        if (n >= 32) {
+            if (!GLOBAL || first) atomicOr(&out[word], (uint32_t)acc);
+            else out[word] = (uint32_t)acc;
+            first = false;
+            acc >>= 32; n -= 32; word++;
+        }
+    }
+    __device__ inline void finish() { if (n > 0 && (uint32_t)acc) atomicOr(&out[word], (uint32_t)acc); }
+};
+using BitOut = BitOutT<true>;
+using BitOutLds = BitOutT<false>;
+
+// The tokens of the stretch [lo, hi) of a block: literals, and - where the block is coded with runs - matches at
+// distance 1.  A run never crosses a lane's stretch (<= 128 bytes, so a match is <= 128 long); a stretch that begins
+// inside its predecessor's run continues it with a match of its own.  MODE 0: count symbols into freq; 1: sum the code
+// bits; 2: write the codes.
+template <int MODE>
+// (src[i] is valid for lo <= i < hi: the lane's stretch in LDS; `prev` is the byte in front of it, -1 at the block's start)
+__device__ inline void gd_tokens(Lds &s, const uint8_t *src, int prev, uint32_t lo, uint32_t hi, bool runs, uint32_t &bits, BitOut *bo) {
+    auto lit = [&](uint32_t v) {
+        if (MODE == 0) atomicAdd(&s.freq[v], 1u);
+        else if (MODE == 1) bits += s.len[v];
+        else bo->put(s.code[v], s.len[v]);
+    };
+    auto match = [&](uint32_t len) {
+        const int c = gd_len_code(len);
+        const uint32_t sym = 257u + (uint32_t)c;
+        if (MODE == 0) atomicAdd(&s.freq[sym], 1u);
+        else if (MODE == 1) bits += (uint32_t)s.len[sym] + gd_len_bits[c] + 1u;
+        else {
+            bo->put(s.code[sym], s.len[sym]);
+            bo->put(((len - gd_len_base[c]) & 0x1Fu), gd_len_bits[c] + 1);  // the extra bits, then the one-bit distance code (0)
+        }
+    };
+    if (!runs) {
+        for (uint32_t i = lo; i < hi; i++) lit(src[i]);
+        return;
+    }
+    uint32_t i = lo;
+    if (i < hi && (int)src[i] == prev) {
+        const uint8_t v = src[i];
+        uint32_t run = 1;
+        while (i + run < hi && src[i + run] == v) run++;
+        if (run >= 3) match(run);
+        else for (uint32_t r = 0; r < run; r++) lit(v);
+        i += run;
+    }
+    while (i < hi) {
+        const uint8_t v = src[i];
+        uint32_t run = 1;
+        while (i + run < hi && src[i + run] == v) run++;
+        lit(v);
+        const uint32_t left = run - 1;
+        if (left >= 3) match(left);
+        else for (uint32_t r = 0; r < left; r++) lit(v);
+        i += run;
+    }
+}
+
+__device__ inline uint32_t gd_block_exclusive_scan(uint32_t *wave_sum, uint32_t v, uint32_t &total) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    uint32_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, all = 0;
+    for (int wv = 0; wv < GD_T / 64; wv++) { if (wv < wave) base += wave_sum[wv]; all += wave_sum[wv]; }
+    total = all;
+    __syncthreads();
+    return base + inc - v;
+}
+
+// One bit per byte of the job's text: is it a line end.  (A thread per 32 bytes; the text buffer is padded to a multiple of 32.)
+__global__ void __launch_bounds__(GD_T)
+gd_newline_kernel(const uint8_t *__restrict__ text, uint64_t n_words, uint32_t *__restrict__ bitmap) {
+    const uint64_t wi = (uint64_t)blockIdx.x * GD_T + threadIdx.x;
+    if (wi >= n_words) return;
+    const uint4 *p = reinterpret_cast<const uint4 *>(text + wi * 32);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint4 v = p[h];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = w[j] ^ 0x0A0A0A0Au;                                    // a zero byte where the text has '\n'
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);  // 0x80 in every zero byte
+            const uint32_t four = ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+            bits |= four << (h * 16 + j * 4);
+        }
+    }
+    bitmap[wi] = bits;
+}
+
+// position of the first line end in text[start, start + count) relative to start, or -1: the whole WAVE looks, 64 words of the
+// bitmap (2 KiB of text) per load and four loads in flight, and every lane returns the same answer
+__device__ inline int64_t gd_find_nl(const uint32_t *__restrict__ bitmap, uint64_t start, uint64_t count) {
+    if (!count) return -1;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t end = start + count, w0 = start >> 5, w_end = (end + 31) >> 5;
+    for (uint64_t base = w0; base < w_end; base += 256) {
+        uint32_t wv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t wi = base + (uint64_t)q * 64 + lane;
+            wv[q] = wi < w_end ? bitmap[wi] : 0u;
+            if (wi == w0) wv[q] &= 0xFFFFFFFFu << (start & 31u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t hit = __builtin_amdgcn_ballot_w64(wv[q] != 0);
+            if (hit) {
+                const int f = __builtin_ctzll(hit);
+                const uint32_t word = (uint32_t)__shfl((int)wv[q], f, 64);
+                const uint64_t pos = ((base + (uint64_t)q * 64 + (uint64_t)f) << 5) + (uint64_t)(__ffs((int)word) - 1);
+                return pos < end ? (int64_t)(pos - start) : -1;
+            }
+        }
+    }
+    return -1;
+}
+
+struct GdMember {
+    uint64_t text_off;    // of the member's first byte in the job's text
+    uint64_t slot_off;    // of its first block's slot
+    uint32_t n;           // bytes of text
+    uint32_t first_block; // its entries in the block table: [first_block, first_block + n / 8192 + 1)
+};
+
+// The blocks of every member (one WAVE per member: a block starts where the one before it ended, members do not wait for each
+// other): tbk_deflate.cpp's rule with 32 KiB as the most.  Long lines (the second line of a block runs past 2 KiB): a block ends
+// at the first line end past 8 KiB, so that the bases of a long read and its qualities get codes of their own; short lines:
+// blocks of 32 KiB.  Entries of the table a member does not use keep n = 0.
+__global__ void __launch_bounds__(64)
+gd_cut_kernel(const GdMember *__restrict__ members, uint32_t n_members, const uint32_t *__restrict__ bitmap, GdBlock *__restrict__ blocks) {
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    if (j >= n_members) return;
+    const GdMember mb = members[j];
+    const uint32_t cap = mb.n / 8192 + 1;
+    uint32_t k = 0;
+    uint64_t slot = mb.slot_off;
+    for (uint64_t off = 0; off < mb.n;) {
+        uint64_t m = mb.n - off;
+        const uint64_t at = mb.text_off + off;
+        const int64_t first = gd_find_nl(bitmap, at, m < 2048 ? m : 2048);
+        const uint64_t used = first >= 0 ? (uint64_t)first + 1 : m;
+        const bool short_lines = first >= 0 && (used == m || gd_find_nl(bitmap, at + used, (m - used) < 2048 ? (m - used) : 2048) >= 0);
+        const uint64_t least = short_lines ? GD_MAX_BLOCK : 8192, most = GD_MAX_BLOCK;
+        if (m > least) {
+            const uint64_t span = (m < most ? m : most) - least;
+            const int64_t nl = gd_find_nl(bitmap, at + least, span);
+            m = nl >= 0 ? least + (uint64_t)nl + 1 : least + span;
+        }
+        if (lane == 0) blocks[mb.first_block + k] = GdBlock{at, slot, (uint32_t)m, j, (k == 0 ? 1u : 0u) | (off + m == mb.n ? 2u : 0u), mb.n, mb.text_off};
+        slot += gd_slot_bytes((uint32_t)m);
+        k++;
+        off += m;
+    }
+    for (uint32_t u = k + lane; u < cap; u += 64) blocks[mb.first_block + u] = GdBlock{0, 0, 0, j, 0, mb.n, mb.text_off};
+}
+
+// The members' CRC-32s: a lane per 64-byte chunk counted from the member's END (so that chunk c has exactly 64 c bytes behind it),
+// slicing-by-4 over the chunk's aligned words, times x^(8 * 64 c) mod P from two tables of 128 (c = c0 + 128 c1; longer members
+// go on with gd_x2nmodp), XOR over the wave, one atomicXor per wave.
+struct GdCrcTabs { uint32_t lo[128], hi[128]; };   // lo[j] = x^(512 j), hi[j] = x^(512 * 128 j)  mod P
+
+__global__ void __launch_bounds__(GD_T)
+gd_crc_kernel(const uint8_t *__restrict__ text, const GdMember *__restrict__ members, const GdCrcTabs *__restrict__ tabs, GdX2n x2n,
+              uint32_t *__restrict__ member_crc) {
+    __shared__ uint32_t T[4][256];
+    const int t = threadIdx.x;
+    {
+        uint32_t c = (uint32_t)t;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ GD_POLY : c >> 1;
+        T[0][t] = c;
+    }
+    __syncthreads();
+    for (int k = 1; k < 4; k++) { T[k][t] = (T[k - 1][t] >> 8) ^ T[0][T[k - 1][t] & 0xFFu]; __syncthreads(); }
+    const GdMember mb = members[blockIdx.y];
+    const uint64_t n_chunks = ((uint64_t)mb.n + 63) / 64;
+    const uint64_t c = (uint64_t)blockIdx.x * GD_T + t;
+    uint32_t part = 0;
+    if (c < n_chunks) {
+        const uint64_t end = (uint64_t)mb.n - c * 64, begin = end > 64 ? end - 64 : 0;   // the member's bytes [begin, end)
+        const uint8_t *p = text + mb.text_off + begin;
+        uint32_t len = (uint32_t)(end - begin), crc = 0xFFFFFFFFu;
+        while (len && ((uintptr_t)p & 3u)) { crc = T[0][(crc ^ *p++) & 0xFFu] ^ (crc >> 8); len--; }
+        for (; len >= 4; len -= 4, p += 4) {
+            const uint32_t x = crc ^ *reinterpret_cast<const uint32_t *>(p);
+            crc = T[3][x & 0xFFu] ^ T[2][(x >> 8) & 0xFFu] ^ T[1][(x >> 16) & 0xFFu] ^ T[0][x >> 24];
+        }
+        while (len) { crc = T[0][(crc ^ *p++) & 0xFFu] ^ (crc >> 8); len--; }
+        uint32_t mult = gd_multmodp(tabs->lo[c & 127u], tabs->hi[(c >> 7) & 127u]);
+        if (c >> 14) mult = gd_multmodp(mult, gd_x2nmodp(x2n, c >> 14, 3 + 6 + 14));
+        part = gd_multmodp(mult, ~crc);
+    }
+    for (int d = 32; d >= 1; d >>= 1) part ^= (uint32_t)__shfl_xor((int)part, d, 64);
+    if ((t & 63) == 0 && part) atomicXor(&member_crc[blockIdx.y], part);
+}
+
+#ifdef GD_PHASES
+__device__ unsigned long long gd_phase[16];
+#define GD_MARK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&gd_phase[k], now_ - mark_); mark_ = now_; } } while (0)
+#else
+#define GD_MARK(k) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(GD_T)
+gd_encode_kernel(const uint8_t *__restrict__ text, const GdBlock *__restrict__ blocks, uint8_t *__restrict__ slots, uint32_t *__restrict__ sizes) {
+    __shared__ Lds s;
+    const int t = threadIdx.x;
+    const GdBlock b = blocks[blockIdx.x];
+    if (b.n == 0) { if (t == 0) sizes[blockIdx.x] = 0; return; }  // an entry its member did not need
+#ifdef GD_PHASES
+    unsigned long long mark_ = clock64();
+#endif
+    const uint8_t *gsrc = text + b.text_off;
+    uint8_t *slot = slots + b.slot_off;
+    const uint32_t n = b.n;
+    // the text into LDS: the aligned words that cover it, `shift` bytes of the first one in front of the block
+    const uint32_t shift = (uint32_t)(b.text_off & 3u), nw = (n + shift + 3) / 4;
+    const uint32_t segw = (nw + GD_T - 1) / GD_T, stride = segw | 1u;
+    {
+        const uint32_t *g32 = reinterpret_cast<const uint32_t *>(text + (b.text_off & ~(uint64_t)3));
+        for (uint32_t w = t; w < nw; w += GD_T) { const uint32_t owner = w / segw; s.text[owner * stride + (w - owner * segw)] = g32[w]; }
+    }
+    // lane t's stretch: the bytes of its words that belong to the block
+    const uint32_t w_lo = (uint32_t)t * segw * 4, w_hi = w_lo + segw * 4;
+    const uint32_t lo = w_lo > shift ? min(n, w_lo - shift) : 0u, hi = w_hi > shift ? min(n, w_hi - shift) : 0u;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(s.text) + (size_t)t * stride * 4 + shift - w_lo;   // src[i], lo <= i < hi (wraps below lo: never read there)
+
+    for (uint32_t i = t; i < GD_HDR_WORDS; i += GD_T) s.hdr[i] = 0;
+    for (uint32_t i = t; i < GD_NSYM; i += GD_T) s.freq[i] = 0;
+    if (t == 0) { s.same = 0; s.stored = 0; }
+    __syncthreads();
+    GD_MARK(0);  // text staged, LDS cleared
+    // bytes that repeat their predecessor: uniform random bases do a quarter of the time and runs of four or more cover
+    // 1.6 % of them - nothing to gain; past 40 % there are real runs (constant or binned qualities, homopolymers)
+    // (the byte in front of the stretch is the last byte of the lane before: its stretch is full when this one is not empty)
+    const int prev = lo > 0 && lo < hi ? (int)reinterpret_cast<const uint8_t *>(s.text)[(size_t)(t - 1) * stride * 4 + segw * 4 - 1] : -1;
+    uint32_t same = 0;
+    int before = prev;
+    for (uint32_t i = lo; i < hi; i++) {
+        const int v = (int)src[i];
+        same += v == before ? 1u : 0u;
+        before = v;
+    }
+    if (same) atomicAdd(&s.same, same);
+    __syncthreads();
+    GD_MARK(1);  // same-as-predecessor pass
+    const bool runs = (uint64_t)s.same * 5 > (uint64_t)n * 2;
+    uint32_t bits = 0;
+    gd_tokens<0>(s, src, prev, lo, hi, runs, bits, nullptr);
+    if (t == 0) atomicAdd(&s.freq[256], 1u);  // end of block
+    __syncthreads();
+    int nlit = 257;
+    if (runs) { nlit = 286; while (nlit > 257 && s.freq[nlit - 1] == 0) nlit--; }
+    GD_MARK(2);  // histogram
+    gd_huffman(s, s.freq, nlit, 15, s.len);
+    GD_MARK(3);  // tree
+    gd_codes(s, s.len, nlit, s.code);
+    GD_MARK(4);  // codes
+
+    // ---- the block header (one lane): RFC 1951 3.2.7 ----
+    if (t == 0) {
+        // the code lengths as code-length symbols: lengths as they are, runs of zeros as 17 (3-10) / 18 (11-138)
+        const int total = nlit + 1;  // + the one distance code: one bit where matches are used, none where not
+        auto length_at = [&](int k) -> int { return k < nlit ? (int)s.len[k] : (runs ? 1 : 0); };
+        int ncl = 0;
+        for (int k = 0; k < 19; k++) s.clfreq[k] = 0;
+        for (int k = 0; k < total;) {
+            const int l = length_at(k);
+            if (l != 0) { s.cl_sym[ncl] = (uint8_t)l; s.cl_extra[ncl] = 0; ncl++; s.clfreq[l]++; k++; continue; }
+            int run = 1;
+            while (k + run < total && length_at(k + run) == 0) run++;
+            int left = run;
+            while (left >= 11) { const int r = left < 138 ? left : 138; s.cl_sym[ncl] = 18; s.cl_extra[ncl] = (uint8_t)(r - 11); ncl++; s.clfreq[18]++; left -= r; }
+            if (left >= 3) { s.cl_sym[ncl] = 17; s.cl_extra[ncl] = (uint8_t)(left - 3); ncl++; s.clfreq[17]++; left = 0; }
+            while (left-- > 0) { s.cl_sym[ncl] = 0; s.cl_extra[ncl] = 0; ncl++; s.clfreq[0]++; }
+            k += run;
+        }
+        int distinct = 0;
+        for (int k = 0; k < 19; k++) distinct += s.clfreq[k] != 0;
+        if (distinct < 2) s.clfreq[s.clfreq[0] ? 1 : 0]++;  // a code needs two symbols to be complete
+        s.header_bits = (uint32_t)ncl;  // (the number of tokens, until the header is written and its length takes the slot)
+    }
+    __syncthreads();
+    const int ncl = (int)s.header_bits;
+    gd_huffman(s, s.clfreq, 19, 7, s.cllen);
+    gd_codes(s, s.cllen, 19, s.clcode);
+    if (t == 0) {
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        int hclen = 19;
+        while (hclen > 4 && s.cllen[order[hclen - 1]] == 0) hclen--;
+        BitOutLds bo(s.hdr, 0);
+        bo.put(0u, 1);                        // not the final block: the member ends with an empty stored block of its own
+        bo.put(2u, 2);                        // dynamic Huffman codes
+        bo.put((uint32_t)(nlit - 257), 5);    // HLIT
+        bo.put(0u, 5);                        // HDIST: 1 distance code
+        bo.put((uint32_t)(hclen - 4), 4);
+        for (int k = 0; k < hclen; k++) bo.put(s.cllen[order[k]], 3);
+        for (int k = 0; k < ncl; k++) {
+            const int sym = s.cl_sym[k];
+            bo.put(s.clcode[sym], s.cllen[sym]);
+            if (sym == 17) bo.put(s.cl_extra[k], 3);
+            else if (sym == 18) bo.put(s.cl_extra[k], 7);
+        }
+        s.header_bits = bo.word * 32u + (uint32_t)bo.n;
+        bo.finish();
+    }
+    __syncthreads();
+
+    GD_MARK(5);  // header (token list, code-length code, bits)
+    // ---- where every lane's codes go; does the block shrink at all ----
+    bits = 0;
+    gd_tokens<1>(s, src, prev, lo, hi, runs, bits, nullptr);
+    uint32_t total_bits = 0;
+    const uint32_t my_bit = gd_block_exclusive_scan(s.wave_sum, bits, total_bits);
+    GD_MARK(6);  // bit counting + scan
+    const uint32_t end_bits = s.header_bits + total_bits + s.len[256];   // behind the end-of-block code
+    const uint32_t coded_bytes = (end_bits + 3 + 7) / 8 + 4;             // + the empty stored block: 3 header bits, pad, 00 00 FF FF
+    if (coded_bytes >= n + 5) {
+        // a stored block (starts on a byte, ends on a byte): 00, LEN, ~LEN, the bytes
+        if (t == 0) {
+            slot[0] = 0; slot[1] = (uint8_t)(n & 0xFF); slot[2] = (uint8_t)(n >> 8); slot[3] = (uint8_t)(~n & 0xFF); slot[4] = (uint8_t)((~n >> 8) & 0xFF);
+            sizes[blockIdx.x] = n + 5;
+        }
+        for (uint32_t i = t; i < n; i += GD_T) slot[5 + i] = gsrc[i];
+        return;
+    }
+    uint32_t *slot32 = reinterpret_cast<uint32_t *>(slot);  // (slots start on 16 bytes and are zero: the job's memset)
+    {
+        // the header's words: whole ones by plain stores, the last (it shares its word with lane 0's first codes) by OR
+        const uint32_t whole = s.header_bits / 32;
+        for (uint32_t i = t; i < whole; i += GD_T) slot32[i] = s.hdr[i];
+        if (t == 0 && (s.header_bits & 31u)) atomicOr(&slot32[whole], s.hdr[whole]);
+        BitOut bo(slot32, s.header_bits + my_bit);
+        gd_tokens<2>(s, src, prev, lo, hi, runs, bits, &bo);
+        bo.finish();
+    }
+    if (t == 0) {
+        BitOut bo(slot32, s.header_bits + total_bits);
+        bo.put(s.code[256], s.len[256]);
+        bo.finish();
+        // the empty stored block: BFINAL = 0, BTYPE = 00, zero bits up to the byte, LEN = 0, NLEN = FFFF
+        const uint32_t at = (end_bits + 3 + 7) / 8;  // first byte of LEN
+        atomicOr(&slot32[(at + 2) >> 2], 0xFFu << (((at + 2) & 3u) * 8));
+        atomicOr(&slot32[(at + 3) >> 2], 0xFFu << (((at + 3) & 3u) * 8));
+        sizes[blockIdx.x] = coded_bytes;
+    }
+    GD_MARK(7);  // codes out
+}
+
+// dense[] = for every member: 10 bytes of gzip header, its blocks back to back, the final empty stored block (5 bytes),
+// CRC-32 and ISIZE (8 bytes).  offsets[b]: where block b's bytes start; member_end[j]: where member j ends.
+__global__ void __launch_bounds__(GD_T)
+gd_scan_kernel(const GdBlock *__restrict__ blocks, const uint32_t *__restrict__ sizes, uint32_t n_blocks, uint64_t *__restrict__ offsets,
+               uint64_t *__restrict__ member_end, uint32_t n_members) {
+    __shared__ uint32_t wave_sum[GD_T / 64];
+    __shared__ uint64_t carry;
+    __shared__ uint32_t used;
+    const int t = threadIdx.x;
+    if (t == 0) { carry = 0; used = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += GD_T) {
+        const uint32_t i = base + t;
+        uint32_t v = 0, flags = 0;
+        if (i < n_blocks && blocks[i].n) { flags = blocks[i].flags; v = sizes[i] + ((flags & 1u) ? 10u : 0u) + ((flags & 2u) ? 13u : 0u); }
+        uint32_t total = 0;
+        const uint32_t ex = gd_block_exclusive_scan(wave_sum, v, total);
+        const uint64_t start = carry + ex;
+        if (i < n_blocks && v) {
+            atomicAdd(&used, 1u);
+            offsets[i] = start + ((flags & 1u) ? 10u : 0u);
+            if (flags & 2u) member_end[blocks[i].member] = start + v;
+        }
+        __syncthreads();
+        if (t == 0) carry += total;
+        __syncthreads();
+    }
+    if (t == 0) member_end[n_members] = used;  // (behind the members' ends: how many blocks the job came to)
+}
+
+__global__ void __launch_bounds__(GD_T)
+gd_gather_kernel(const GdBlock *__restrict__ blocks, const uint32_t *__restrict__ sizes, const uint64_t *__restrict__ offsets, const uint8_t *__restrict__ slots,
+                 uint8_t *__restrict__ dense) {
+    const int t = threadIdx.x;
+    const GdBlock b = blocks[blockIdx.x];
+    if (b.n == 0) return;
+    const uint32_t size = sizes[blockIdx.x];
+    const uint8_t *src = slots + b.slot_off;
+    uint8_t *dst = dense + offsets[blockIdx.x];
+    // (the slot starts on 16 bytes, the destination anywhere: words where it happens to be aligned, bytes where not)
+    if ((((uintptr_t)dst) & 3u) == 0) {
+        const uint32_t words = size / 4;
+        for (uint32_t i = t; i < words; i += GD_T) reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(src)[i];
+        for (uint32_t i = words * 4 + t; i < size; i += GD_T) dst[i] = src[i];
+    } else {
+        for (uint32_t i = t; i < size; i += GD_T) dst[i] = src[i];
+    }
+    if ((b.flags & 1u) && t < 10) {
+        const uint8_t head[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+        dst[(int)t - 10] = head[t];
+    }
+    if ((b.flags & 2u) && t < 13) {
+        // BFINAL = 1, BTYPE = 00 (one byte with the padding), LEN = 0, NLEN = FFFF; the CRC-32 is the host's; ISIZE
+        const uint8_t tail[13] = {0x01, 0x00, 0x00, 0xff, 0xff, 0, 0, 0, 0, (uint8_t)(b.member_n & 0xFF), (uint8_t)((b.member_n >> 8) & 0xFF),
+                                  (uint8_t)((b.member_n >> 16) & 0xFF), (uint8_t)((b.member_n >> 24) & 0xFF)};
+        dst[size + t] = tail[t];
+    }
+}
+
+int gfail(int code, const char *what, hipError_t e) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "GPU gzip encoder: %s: %s", what, hipGetErrorString(e));
+    tbk_set_error_(code, buf);
+    (void)hipGetLastError();
+    return code;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = n + n / 4 + 4096;
+        const hipError_t e = hipMalloc(&p, c);
+        if (e == hipSuccess) cap = c;
+        return e;
+    }
+    void drop() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t need(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t c = n + n / 4 + 4096;
+        const hipError_t e = hipHostMalloc(&p, c, hipHostMallocPortable);
+        if (e == hipSuccess) cap = c;
+        return e;
+    }
+    void drop() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct Job {
+    int state = 0;  // 0 free, 1 coding (text in, kernels, the members' ends on their way home), 2 the members on their way home
+    DevBuf d_text, d_bitmap, d_members, d_blocks, d_slots, d_sizes, d_offsets, d_member_end, d_dense;  // (d_member_end: the members' ends, the block count, then the members' CRCs)
+    PinBuf h_members, h_member_end, h_dense;
+    hipEvent_t text_in = nullptr, meta_home = nullptr, dense_home = nullptr;
+    std::vector<int> tags;          // per member: the caller's tag (the bin)
+    std::vector<uint32_t> crc;      // per member, when the caller has summed it itself (tbk_gdeflate_set_crc); else the device's is used
+    std::vector<uint8_t> crc_set;
+    std::vector<uint64_t> text_len; // per member
+    uint64_t dense_bytes = 0;
+    void drop() {
+        d_text.drop(); d_bitmap.drop(); d_members.drop(); d_blocks.drop(); d_slots.drop(); d_sizes.drop(); d_offsets.drop(); d_member_end.drop(); d_dense.drop();
+        h_members.drop(); h_member_end.drop(); h_dense.drop();
+        if (text_in) (void)hipEventDestroy(text_in);
+        if (meta_home) (void)hipEventDestroy(meta_home);
+        if (dense_home) (void)hipEventDestroy(dense_home);
+    }
+};
+
+}  // namespace
+
+struct tbk_gdeflate {
+    int device = 0;
+    // kernels; the text's way in; the members' way out - three streams, so that a job's text arrives and the previous job's members
+    // leave while the kernels of the one between them run
+    hipStream_t stream = nullptr, stream_in = nullptr, stream_out = nullptr;
+    GdX2n x2n = gd_x2n_table();
+    GdCrcTabs *d_crc_tabs = nullptr;
+    Job jobs[3];
+    uint64_t submitted = 0;  // jobs so far; job k lives in jobs[k % 3]
+    uint64_t collected = 0;
+    // totals (tbk_gdeflate_stats)
+    uint64_t text_bytes = 0, member_bytes = 0, blocks = 0, members = 0;
+};
+
+int tbk_gdeflate_create(int device, tbk_gdeflate **out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); tbk_set_error_(TBK_ERR_NO_DEVICE, "GPU gzip encoder: no such device"); return TBK_ERR_NO_DEVICE; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    tbk_gdeflate *g = new tbk_gdeflate();
+    g->device = device;
+    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_out, hipStreamNonBlocking);
+    for (Job &j : g->jobs) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&j.text_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&j.meta_home, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&j.dense_home, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) {
+        GdCrcTabs tabs;
+        for (uint32_t j = 0; j < 128; j++) { tabs.lo[j] = gd_x2nmodp(g->x2n, j, 3 + 6); tabs.hi[j] = gd_x2nmodp(g->x2n, j, 3 + 6 + 7); }
+        e = hipMalloc((void **)&g->d_crc_tabs, sizeof tabs);
+        if (e == hipSuccess) e = hipMemcpy(g->d_crc_tabs, &tabs, sizeof tabs, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { tbk_gdeflate_destroy(g); return gfail(TBK_ERR_HIP, "setup", e); }
+    *out = g;
+    return TBK_OK;
+}
+
+void tbk_gdeflate_destroy(tbk_gdeflate *g) {
+    if (!g) return;
+    if (hipSetDevice(g->device) == hipSuccess) {
+        if (g->stream) (void)hipStreamSynchronize(g->stream);
+        if (g->stream_in) { (void)hipStreamSynchronize(g->stream_in); (void)hipStreamDestroy(g->stream_in); }
+        if (g->stream_out) { (void)hipStreamSynchronize(g->stream_out); (void)hipStreamDestroy(g->stream_out); }
+        for (Job &j : g->jobs) j.drop();
+        if (g->d_crc_tabs) (void)hipFree(g->d_crc_tabs);
+        if (g->stream) (void)hipStreamDestroy(g->stream);
+    }
+    delete g;
+}
+
+int tbk_gdeflate_submit(tbk_gdeflate *g, const tbk_gdeflate_member *members, size_t n_members) {
+    if (!g || (n_members && !members)) { tbk_set_error_(TBK_ERR_INVALID, "GPU gzip encoder: NULL argument"); return TBK_ERR_INVALID; }
+    Job &j = g->jobs[g->submitted % 3];
+    if (j.state != 0) { tbk_set_error_(TBK_ERR_STATE, "GPU gzip encoder: three jobs in flight; collect first"); return TBK_ERR_STATE; }
+    hipError_t e = hipSetDevice(g->device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    j.tags.clear(); j.crc.assign(n_members, 0); j.crc_set.assign(n_members, 0); j.text_len.clear();
+    // The host never reads the text (it is 30 GB a run): where the line ends are is found on the device (gd_newline_kernel), the
+    // blocks are cut there (gd_cut_kernel).  Here: only what follows from the members' lengths - where a member's text, its
+    // entries of the block table (as many as it could need: a block is 8 KiB or more, but for a member's last) and its slots begin.
+    uint64_t text_total = 0, slot_total = 0, nb = 0;
+    e = j.h_members.need((n_members + 1) * sizeof(GdMember));
+    if (e != hipSuccess) return gfail(TBK_ERR_NOMEM, "buffers", e);
+    GdMember *hm = (GdMember *)j.h_members.p;
+    for (size_t i = 0; i < n_members; i++) {
+        if (members[i].n > 0xFFFFFFF0ull) { tbk_set_error_(TBK_ERR_INVALID, "GPU gzip encoder: a member of 4 GiB or more"); return TBK_ERR_INVALID; }
+        j.tags.push_back(members[i].tag);
+        j.text_len.push_back(members[i].n);
+        const uint64_t entries = members[i].n / 8192 + 1;
+        hm[i] = GdMember{text_total, slot_total, (uint32_t)members[i].n, (uint32_t)nb};
+        text_total += members[i].n;
+        slot_total += (((uint64_t)members[i].n + members[i].n / 8 + 15) & ~(uint64_t)15) + entries * 1040;
+        nb += entries;
+    }
+    if (n_members > 65535) { tbk_set_error_(TBK_ERR_INVALID, "GPU gzip encoder: more than 65535 members in one job"); return TBK_ERR_INVALID; }
+    if (nb > 0x7FFFFFF0ull) { tbk_set_error_(TBK_ERR_INVALID, "GPU gzip encoder: too much text in one job"); return TBK_ERR_INVALID; }
+    const uint64_t n_words = (text_total + 31) / 32;
+    const uint64_t dense_cap = slot_total + 23 * (uint64_t)n_members + 64;
+    e = j.d_text.need(n_words * 32 + 64);
+    if (e == hipSuccess) e = j.d_bitmap.need((n_words + 2) * 4);
+    if (e == hipSuccess) e = j.d_members.need((n_members + 1) * sizeof(GdMember));
+    if (e == hipSuccess) e = j.d_blocks.need((nb + 1) * sizeof(GdBlock));
+    if (e == hipSuccess) e = j.d_slots.need(slot_total + 64);
+    if (e == hipSuccess) e = j.d_sizes.need((nb + 1) * 4);
+    if (e == hipSuccess) e = j.d_offsets.need((nb + 1) * 8);
+    if (e == hipSuccess) e = j.d_member_end.need((n_members + 1) * 8 + (n_members + 1) * 4);
+    if (e == hipSuccess) e = j.d_dense.need(dense_cap);
+    if (e == hipSuccess) e = j.h_member_end.need((n_members + 1) * 8 + (n_members + 1) * 4);
+    if (e == hipSuccess) e = j.h_dense.need(dense_cap);
+    if (e != hipSuccess) return gfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "buffers", e);
+    // the text: members that lie back to back in the caller's memory (a bin's pieces do) go in one copy
+    uint64_t at = 0;
+    for (size_t i = 0; i < n_members && e == hipSuccess;) {
+        size_t k = i;
+        uint64_t run = members[i].n;
+        while (k + 1 < n_members && members[k + 1].src == members[k].src + members[k].n) { k++; run += members[k].n; }
+        if (run) e = hipMemcpyAsync((uint8_t *)j.d_text.p + at, members[i].src, run, hipMemcpyHostToDevice, g->stream_in);
+        at += run;
+        i = k + 1;
+    }
+    if (e == hipSuccess && (text_total & 31)) e = hipMemsetAsync((uint8_t *)j.d_text.p + text_total, 0, 32 - (text_total & 31), g->stream_in);  // (the bitmap's last word reads whole)
+    if (e == hipSuccess && n_members) e = hipMemcpyAsync(j.d_members.p, j.h_members.p, n_members * sizeof(GdMember), hipMemcpyHostToDevice, g->stream_in);
+    if (e == hipSuccess) e = hipEventRecord(j.text_in, g->stream_in);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, j.text_in, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(j.d_member_end.p, 0, (n_members + 1) * 12, g->stream);
+    if (e == hipSuccess && slot_total) e = hipMemsetAsync(j.d_slots.p, 0, slot_total, g->stream);  // (the codes are ORed and stored into zeroed slots)
+    if (e == hipSuccess && text_total) {
+        hipLaunchKernelGGL(gd_newline_kernel, dim3((unsigned)((n_words + GD_T - 1) / GD_T)), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p, n_words, (uint32_t *)j.d_bitmap.p);
+        hipLaunchKernelGGL(gd_cut_kernel, dim3((unsigned)n_members), dim3(64), 0, g->stream, (const GdMember *)j.d_members.p, (uint32_t)n_members,
+                           (const uint32_t *)j.d_bitmap.p, (GdBlock *)j.d_blocks.p);
+        uint64_t longest = 0;
+        for (size_t i = 0; i < n_members; i++) longest = std::max<uint64_t>(longest, members[i].n);
+        hipLaunchKernelGGL(gd_crc_kernel, dim3((unsigned)(((longest + 63) / 64 + GD_T - 1) / GD_T), (unsigned)n_members), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p,
+                           (const GdMember *)j.d_members.p, (const GdCrcTabs *)g->d_crc_tabs, g->x2n, (uint32_t *)((uint64_t *)j.d_member_end.p + n_members + 1));
+        hipLaunchKernelGGL(gd_encode_kernel, dim3((unsigned)nb), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p, (const GdBlock *)j.d_blocks.p, (uint8_t *)j.d_slots.p,
+                           (uint32_t *)j.d_sizes.p);
+        hipLaunchKernelGGL(gd_scan_kernel, dim3(1), dim3(GD_T), 0, g->stream, (const GdBlock *)j.d_blocks.p, (const uint32_t *)j.d_sizes.p, (uint32_t)nb, (uint64_t *)j.d_offsets.p,
+                           (uint64_t *)j.d_member_end.p, (uint32_t)n_members);
+        hipLaunchKernelGGL(gd_gather_kernel, dim3((unsigned)nb), dim3(GD_T), 0, g->stream, (const GdBlock *)j.d_blocks.p, (const uint32_t *)j.d_sizes.p,
+                           (const uint64_t *)j.d_offsets.p, (const uint8_t *)j.d_slots.p, (uint8_t *)j.d_dense.p);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(j.h_member_end.p, j.d_member_end.p, (n_members + 1) * 12, hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipEventRecord(j.meta_home, g->stream);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "submit", e);
+    j.state = 1;
+    g->submitted++;
+    g->text_bytes += text_total; g->members += n_members;
+    return TBK_OK;
+}
+
+int tbk_gdeflate_text_done(tbk_gdeflate *g) {
+    if (!g || g->submitted == 0) return TBK_OK;
+    Job &j = g->jobs[(g->submitted - 1) % 3];
+    const hipError_t e = hipEventSynchronize(j.text_in);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "waiting for the text's copy", e);
+    return TBK_OK;
+}
+
+void tbk_gdeflate_set_crc(tbk_gdeflate *g, size_t member, uint32_t crc) {
+    if (!g || g->submitted == 0) return;
+    Job &j = g->jobs[(g->submitted - 1) % 3];
+    if (member < j.crc.size()) { j.crc[member] = crc; j.crc_set[member] = 1; }
+}
+
+// Moves the pipeline on: the job before the newest starts its members' journey home; the oldest job in flight (if it has
+// come that far, or `drain`) is handed out.  *out: its members in order - (tag, bytes, length) - valid until the next call.
+int tbk_gdeflate_collect(tbk_gdeflate *g, bool drain, std::vector<tbk_gdeflate_out> &out) {
+    out.clear();
+    if (!g) return TBK_OK;
+    hipError_t e = hipSetDevice(g->device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    // stage B: every job whose coding has been submitted and whose successor exists (or drain) sends its members home
+    for (uint64_t k = g->collected; k < g->submitted; k++) {
+        Job &j = g->jobs[k % 3];
+        if (j.state != 1) continue;
+        if (!drain && k + 1 >= g->submitted) break;  // the newest job: its kernels have only just been queued
+        e = hipEventSynchronize(j.meta_home);
+        if (e != hipSuccess) return gfail(TBK_ERR_HIP, "waiting for a job", e);
+        const size_t nm = j.tags.size();
+        const uint64_t *ends = (const uint64_t *)j.h_member_end.p;
+        g->blocks += ends[nm];
+        uint64_t total = 0;
+        // empty members have no block: their bytes are put in by the host below, behind the device's
+        for (size_t i = 0; i < nm; i++) if (j.text_len[i]) total = std::max<uint64_t>(total, ends[i]);
+        j.dense_bytes = total;
+        if (total) e = hipMemcpyAsync(j.h_dense.p, j.d_dense.p, total, hipMemcpyDeviceToHost, g->stream_out);  // (the job's kernels are done: meta_home)
+        if (e == hipSuccess) e = hipEventRecord(j.dense_home, g->stream_out);
+        if (e != hipSuccess) return gfail(TBK_ERR_HIP, "fetching the members", e);
+        j.state = 2;
+    }
+    // stage C: the oldest job, when its members are home (or drain)
+    if (g->collected < g->submitted) {
+        Job &j = g->jobs[g->collected % 3];
+        if (j.state == 2 && (drain || g->collected + 2 < g->submitted || hipEventQuery(j.dense_home) == hipSuccess)) {
+            e = hipEventSynchronize(j.dense_home);
+            if (e != hipSuccess) return gfail(TBK_ERR_HIP, "waiting for the members", e);
+            const size_t nm = j.tags.size();
+            const uint64_t *ends = (const uint64_t *)j.h_member_end.p;
+            uint8_t *dense = (uint8_t *)j.h_dense.p;
+            uint64_t start = 0, spare = j.dense_bytes;
+            for (size_t i = 0; i < nm; i++) {
+                if (j.text_len[i] == 0) {
+                    // an empty member (an empty bin's file is a valid gzip file, as gzip.open(...).close() leaves it)
+                    static const uint8_t empty[23] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff, 0x01, 0x00, 0x00, 0xff, 0xff, 0, 0, 0, 0, 0, 0, 0, 0};
+                    memcpy(dense + spare, empty, 23);
+                    out.push_back(tbk_gdeflate_out{j.tags[i], (const char *)dense + spare, 23});
+                    spare += 23;
+                    g->member_bytes += 23;
+                    continue;
+                }
+                const uint64_t end = ends[i];
+                const uint32_t *dev_crc = (const uint32_t *)(ends + nm + 1);  // what the encode kernel summed (gd_multmodp)
+                const uint32_t crc = j.crc_set[i] ? j.crc[i] : dev_crc[i];
+                memcpy(dense + end - 8, &crc, 4);
+                out.push_back(tbk_gdeflate_out{j.tags[i], (const char *)dense + start, (size_t)(end - start)});
+                g->member_bytes += end - start;
+                start = end;
+            }
+            j.state = 0;
+            g->collected++;
+        }
+    }
+    return TBK_OK;
+}
+
+int tbk_gdeflate_in_flight(const tbk_gdeflate *g) { return g ? (int)(g->submitted - g->collected) : 0; }
+
+void tbk_gdeflate_stats(const tbk_gdeflate *g, uint64_t *text_bytes, uint64_t *member_bytes, uint64_t *blocks, uint64_t *members) {
+    if (text_bytes) *text_bytes = g ? g->text_bytes : 0;
+    if (member_bytes) *member_bytes = g ? g->member_bytes : 0;
+    if (blocks) *blocks = g ? g->blocks : 0;
+    if (members) *members = g ? g->members : 0;
+}
+
+uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp
+
+// C-ABI (include/tbk.h): n_members pieces of text -> as many gzip members, coded on `device`, one job, synchronously.  text holds the
+// members back to back (member_len[i] bytes each); the members are written back to back into dst and member_out_len[i] says how long
+// each one is.  *need = bytes of dst used (or needed, when cap is too small: TBK_ERR_NOMEM).  What tests and tools call; the bin writer
+// drives the same encoder three jobs deep.
+extern "C" int tbk_gzip_members_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, char *dst, uint64_t cap, uint64_t *member_out_len,
+                                       uint64_t *need) {
+    if ((n_members && (!member_len || !member_out_len)) || !need) { tbk_set_error_(TBK_ERR_INVALID, "tbk_gzip_members_device: NULL argument"); return TBK_ERR_INVALID; }
+    tbk_gdeflate *g = nullptr;
+    int rc = tbk_gdeflate_create(device, &g);
+    if (rc) return rc;
+    std::vector<tbk_gdeflate_member> members;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < n_members; i++) { members.push_back(tbk_gdeflate_member{text + off, (size_t)member_len[i], 0}); off += member_len[i]; }
+    rc = tbk_gdeflate_submit(g, members.data(), members.size());
+    if (!rc) {
+        rc = tbk_gdeflate_text_done(g);  // (the members' CRC-32s are the device's)
+    }
+    std::vector<tbk_gdeflate_out> outs;
+    uint64_t used = 0, at = 0;
+    while (!rc && tbk_gdeflate_in_flight(g) > 0) {
+        rc = tbk_gdeflate_collect(g, true, outs);
+        for (const tbk_gdeflate_out &o : outs) {
+            if (dst && used + o.n <= cap) memcpy(dst + used, o.data, o.n);
+            if (at < n_members) member_out_len[at++] = o.n;
+            used += o.n;
+        }
+    }
+    tbk_gdeflate_destroy(g);
+    if (rc) return rc;
+    *need = used;
+    if (used > cap || (!dst && used)) { tbk_set_error_(TBK_ERR_NOMEM, "tbk_gzip_members_device: dst too small"); return TBK_ERR_NOMEM; }
+    return TBK_OK;
+}
+
+#ifdef GD_PHASES
+extern "C" int tbk_gdeflate_phases_(unsigned long long out[16]) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(gd_phase), 16 * sizeof(unsigned long long));
+    unsigned long long z[16] = {0};
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(gd_phase), z, sizeof z);
+    return e == hipSuccess ? 0 : -5;
+}
+#endif

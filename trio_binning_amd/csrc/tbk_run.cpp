@@ -99,6 +99,17 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     tbk_bin_writer *writer = nullptr;
     rc = tbk_bin_writer_open(out_a, out_b, out_u, gzip_output, gzip_level, 0, &writer);
     if (rc) { tbk_fastx_close(reader); return rc; }
+    if (gzip_output) {
+        // the bins' gzip members are coded on the (first) device of the pipeline - it is idle 95 % of an end-to-end run - unless
+        // TBK_GZIP_ENCODER says cpu / zlib (a test pipeline of stub rings has no device: the host's encoder)
+        tbk_classifier *c0 = tbk_pipeline_classifier(p, 0);
+        if (c0) {
+            rc = tbk_bin_writer_use_device(writer, tbk_classifier_device(c0));
+            if (rc) { tbk_bin_writer_close(writer); tbk_fastx_close(reader); return rc; }
+        }
+    }
+
+    st.gzip_encoder = !gzip_output ? 0 : tbk_bin_writer_encoder(writer) ? 2 : 1;
 
     // batches kept submitted: the rings' slots plus one waiting per ring (what the pipeline admits), so that a feeder
     // whose ring has just got room finds its next batch queued already

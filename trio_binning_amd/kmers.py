@@ -741,13 +741,15 @@ class MultiClassifier:
 
         class Stats(C.Structure):
             _fields_ = [("reads", C.c_uint64), ("bases", C.c_uint64), ("batches", C.c_uint64), ("read_s", C.c_double),
-                        ("gpu_wait_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double)]
+                        ("gpu_wait_s", C.c_double), ("write_s", C.c_double), ("total_s", C.c_double), ("gzip_encoder", C.c_int32), ("_pad", C.c_int32)]
 
         st = Stats()
         a, b, u = [os.fsencode(n) for n in out_names]
         check(lib.tbk_classify_file(self._h, os.fsencode(reads_path), num_kmers_a, num_kmers_b, a, b, u, int(bool(gzip_output)), gzip_level,
                                     tsv_fd, batch_bases, batch_reads, C.byref(st)))
-        return {name: getattr(st, name) for name, _ in Stats._fields_}
+        out = {name: getattr(st, name) for name, _ in Stats._fields_ if name != "_pad"}
+        out["gzip_encoder"] = {0: None, 1: "host", 2: "device"}.get(st.gzip_encoder)   # who coded the bins' gzip members
+        return out
 
     def sync(self) -> None:
         pass  # every ticket that was waited for is complete; there is nothing else in flight to wait for

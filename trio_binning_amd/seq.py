@@ -318,7 +318,9 @@ class BinWriter:
     ``open_outfiles`` + ``Read.print``); gzip members are deflated in parallel."""
 
     def __init__(self, haplotype_a_prefix: str, haplotype_b_prefix: str, unclassified_prefix: str,
-                 outfile_extension: str, gzip_output: bool, level: int = -1, threads: int = 0):
+                 outfile_extension: str, gzip_output: bool, level: int = -1, threads: int = 0, device: Optional[int] = None):
+        """``device``: code the gzip members on that GPU (``tbk_bin_writer_use_device``: what ``classify-by-kmers`` does by itself);
+        None: on the host's threads.  ``gpu_encoder`` says which it is."""
         import ctypes as C
         import os
 
@@ -328,6 +330,9 @@ class BinWriter:
         h = C.c_void_p()
         check(lib.tbk_bin_writer_open(*[os.fsencode(n) for n in self.names], int(gzip_output), level, threads, C.byref(h)))
         self._h = h
+        if device is not None:
+            check(lib.tbk_bin_writer_use_device(h, device))
+        self.gpu_encoder = bool(lib.tbk_bin_writer_encoder(h)) if hasattr(lib, "tbk_bin_writer_encoder") else False
 
     def write(self, batch: Batch, bins: bytes) -> None:
         from ._lib import check, lib
@@ -359,3 +364,25 @@ def format_tsv(batch: Batch, bins: bytes, score_a, score_b) -> str:
     buf = C.create_string_buffer(need.value + 1)
     check(lib.tbk_format_tsv(batch._h, bins, score_a.ctypes.data, score_b.ctypes.data, buf, need.value + 1, C.byref(need)))
     return buf.raw[: need.value].decode()
+
+
+def gzip_members_device(pieces, device: int = 0):
+    """Each of ``pieces`` (bytes) as one gzip member, coded on the GPU (``tbk_gzip_members_device``: the bin writer's encoder by
+    itself).  Returns the members as a list of bytes; ``gzip.decompress`` of each gives the piece back."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    text = b"".join(pieces)
+    n = len(pieces)
+    lens = (C.c_uint64 * max(1, n))(*[len(p) for p in pieces])
+    out_lens = (C.c_uint64 * max(1, n))()
+    need = C.c_uint64()
+    cap = len(text) + len(text) // 8 + 1100 * (len(text) // 8192 + 1) + 64 * n + 1024
+    buf = C.create_string_buffer(cap)
+    check(lib.tbk_gzip_members_device(device, text, lens, n, buf, cap, out_lens, C.byref(need)))
+    out, at = [], 0
+    for i in range(n):
+        out.append(C.string_at(C.addressof(buf) + at, out_lens[i]))
+        at += out_lens[i]
+    return out
