@@ -537,7 +537,7 @@ int tbk_synth_hap_reads_ragged_device(int device, uint64_t seed, uint64_t genome
  * when odd; keys_per_read = 1: one read of k bases per key (multi-read passes); P > 1: P keys to a read with an 'N' between
  * neighbours, so that a read counts exactly its member keys (single-read and two-read passes) - chunk_keys at a time (0: 2^25),
  * classifies every chunk through tbk_classify_device and compares the counts on the device with what they must be:
- * expect = 1: every key counts (1, 0); 2: (0, 1); 0: (0, 0); or per key from d_expect (uint8, same codes; keys_per_read = 1).
+ * expect = 1: every key counts (1, 0); 2: (0, 1); 0: (0, 0); or per key from d_expect (uint8, same codes: a read of P keys must count how many of its keys say 1 and how many 2).
  * out[0], out[1] = the sums of the hapA / hapB counts; out[2] = reads that differ from their expectation; out[3] = the index
  * of the first such read (all ones: none).
  * tbk_sweep_expectation_device writes d_expect for arbitrary keys from the two lists' STANDALONE tables (verbatim 64-bit

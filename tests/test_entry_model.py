@@ -64,3 +64,24 @@ def test_short_key_geometry_limits(short_model):
     for args in (("21", "6", "1", "65535"), ("23", "6", "1", "1000000"), ("31", "6", "1", "1000000000")):
         r = subprocess.run([short_model, *args], capture_output=True, text=True)
         assert r.returncode == 0 and "no short keys" in r.stdout, r.stdout
+
+
+@pytest.fixture(scope="module")
+def full_model(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("full_model") / "full_model")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "native", "full_model.cpp")], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("k,w,per_line", [(31, 8, 2.0), (31, 8, 6.0), (29, 8, 12.0), (27, 7, 4.0), (25, 6, 3.0), (23, 6, 10.0), (21, 6, 2.0)])
+def test_full_key_model_equals_set_membership(full_model, k, w, per_line):
+    """Full keys (tbk_common.h): sequential inserts into 16-slot lines with the summary in slot 3, keys sent on by
+    tbk_next_bucket; tbk_full_lookup_one(..., as_window = 0 and 1) must both equal set membership - at crowded loads too (up to
+    twelve keys per line asked for: lines fill and keys walk), list keys through every tied position, near misses that share
+    a line with them, windows of both strands."""
+    for seed in (1, 2):
+        r = subprocess.run([full_model, str(k), str(w), str(seed), str(per_line)], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert r.stdout.startswith("full ") and "mismatches 0" in r.stdout and "as_window disagreements 0" in r.stdout, r.stdout
+        if per_line >= 6:
+            assert " 0 walks past a line" not in r.stdout, r.stdout

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -1310,6 +1311,17 @@ extern "C" int tbk_classifier_create(const tbk_table *a, const tbk_table *b, tbk
     return tbk_classifier_create_opts(a, b, nullptr, out);
 }
 
+// What fraction of uniformly hashed keys lies behind a front of `front` keys when a line gets Poisson(lambda) of them:
+// E[max(0, X - front)] / lambda.  The full-key layout's tests for "these lists cluster" are set against it (a memory-capped
+// table runs at up to six keys per line, where a uniform list already has a third of its keys behind the three-key front).
+static double poisson_behind(double lambda, int front) {
+    if (lambda <= 0) return 0;
+    double p = exp(-lambda), cdf_part = 0, mean_part = 0;  // P(X = x); sum over x <= front of P(x) and of x P(x)
+    for (int x = 0; x <= front; x++) { cdf_part += p; mean_part += x * p; p *= lambda / (x + 1); }
+    // E[max(0, X - front)] = (lambda - mean_part) - front * (1 - cdf_part)
+    return std::max(0.0, ((lambda - mean_part) - front * (1.0 - cdf_part)) / lambda);
+}
+
 static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_options *options, tbk_classifier **out) {
     if (!out) return fail(TBK_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -1510,6 +1522,7 @@ static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_op
     // well over half there) go on to the key layout's test and to entries.  full_keys = 0: never, 1: whatever the lists look like.
     const double full_pin = o.full_keys;
     double sample_behind = -1;  // what the bucket sample of a full-key attempt found behind the fronts (-1: none was taken)
+    bool full_clustered = false;  // a full-key attempt (its sample, or its build) has shown the lists to cluster: on to entries without the key layout's test build
     auto try_full_layout = [&](bool forced) -> bool {
         if (pin == 0 || w_pin == 0 || c->k > 31 || c->k < 17) return false;
         if (!forced && o.table_load > 0) return false;  // (the key layouts' load is pinned: the key layouts are meant)
@@ -1547,10 +1560,12 @@ static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_op
             if (d_failed) (void)hipFree(d_failed);
             if (e != hipSuccess) { (void)hipGetLastError(); return false; }
             const double f = (double)cnt[3] / (double)std::max<unsigned long long>(1, cnt[2]);
-            if (build_timing) fprintf(stderr, "tbk build: full keys, a sixteenth of the buckets: %llu of %llu slots behind a front (%.1f %%)\n", cnt[3], cnt[2], 100.0 * f);
+            // (hapA's list alone at this table's load: what a uniform list would show, times 2.5 - never below the option's own figure)
+            const double sample_limit = std::max(4.0 * o.behind_front, 2.5 * poisson_behind((double)a->num_lines / (double)nb, 3));
+            if (build_timing) fprintf(stderr, "tbk build: full keys, a sixteenth of the buckets: %llu of %llu slots behind a front (%.1f %%; clustered from %.1f %%)\n", cnt[3], cnt[2], 100.0 * f, 100.0 * sample_limit);
             t_last = std::chrono::steady_clock::now();
-            if (f > 4.0 * o.behind_front) {
-                sample_behind = f;  // (the lists cluster: the caller goes on to entries without the key layout's test build)
+            if (f > sample_limit) {
+                sample_behind = f; full_clustered = true;  // (the lists cluster: the caller goes on to entries without the key layout's test build)
                 return false;
             }
         }
@@ -1561,13 +1576,20 @@ static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_op
         c->free_pair();
         bool gave_up = false;
         // (hapA's list alone, at half the load: a uniform list has 2 % of its keys behind a front then, a clustered one a third: given up at 20 %)
-        const uint64_t give_up = forced ? 0 : (uint64_t)(2.0 * o.behind_front * (double)(a->num_lines + b->num_lines)) + 1;
+        const double lam = (double)(a->num_lines + b->num_lines) / (double)nb, lam_a = (double)a->num_lines / (double)nb;
+        const double built_limit = std::max(6.0 * o.behind_front, 2.5 * poisson_behind(lam, 3));
+        // (given up after hapA's list when that alone - at its own load - is 2.5 times past a uniform list's expectation, never below the option's figure)
+        const uint64_t give_up = forced ? 0 : (uint64_t)(std::max(2.0 * o.behind_front * (double)(a->num_lines + b->num_lines), 2.5 * poisson_behind(lam_a, 3) * (double)a->num_lines)) + 1;
         const int brc = build_entry_table(c, a, b, (uint32_t)nb, give_up, &gave_up);
         lap(gave_up ? "full keys (given up after hapA's list)" : "full keys", false);
         bool built = brc == TBK_OK && !gave_up;
         if (built) c->layout_builds++;
         const double n_keys = (double)std::max<uint64_t>(1, c->distinct_a + c->distinct_b);
-        if (built && !forced && (double)c->behind_front / n_keys > 6.0 * o.behind_front) built = false;  // the lists cluster
+        if (built && !forced && (double)c->behind_front / n_keys > built_limit) {  // the lists cluster
+            sample_behind = std::max(sample_behind, (double)c->behind_front / n_keys);  // (measured: the caller need not build the key layout to find out)
+            full_clustered = true;
+            built = false;
+        }
         if (!built) { c->free_pair(); c->mz = keep_mz; c->guests = keep_flags; c->entries_a = c->entries_b = 0; return false; }
         return true;
     };
@@ -1599,7 +1621,7 @@ static int classifier_build(const tbk_table *a, const tbk_table *b, const tbk_op
     // the keys behind an 8-slot front; haplotype-shaped lists: 16 %, uniform ones 1.5 %) skip the key layout's test -
     // building a front-first key table of clustered lists only to measure them takes 2 s at 2 x 3e8 keys, ten times a
     // build of entries - and go to entries at once; lists that do not merge come back here.
-    if ((short_behind > o.plainly_clustered || sample_behind > 4.0 * o.behind_front) && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
+    if ((short_behind > o.plainly_clustered || full_clustered) && entry_pin != 0 && front_pin < 0 && try_entry_layout(false)) {
         c->layout_builds++;
         lap("(kept)", true);
         c->own_pair();

@@ -2334,6 +2334,9 @@ extern "C" hipError_t tbk_launch_probe_range(const uint8_t *d_bases, const uint3
     const bool wide = (t.guests & TBK_FLAG_WIDE) != 0, shortk = (t.guests & TBK_FLAG_SHORT) != 0, fullk = (t.guests & TBK_FLAG_FULL) != 0;
     const bool span3 = (entry || shortk) && t.mz.t > 0 && t.mz.t == t.mz.m - 2 * t.mz.w;
     if ((entry || shortk) && t.mz.t > 0 && !span3 && t.mz.t != t.mz.m - t.mz.w) return hipErrorInvalidValue;
+    // (the single-read entry kernel of LW = 3, W = 6 ranks t-mers through a 256-entry table in LDS: 4^t entries, t = 4, tags of 5 bits -
+    // what tbk_mz_span3 gives at w = 6 today (m = 16); a view with another t must not reach that instantiation)
+    if (TBK_TMER_LUT && span3 && t.mz.w == 6 && t.mz.t != 4) return hipErrorInvalidValue;
     if (shortk) {
         TbkShortGeom g;
         if (!tbk_short_geom(k, t.mz, t.n_buckets, &g) || t.n_buckets > 0x3FFFFFFFu) return hipErrorInvalidValue;

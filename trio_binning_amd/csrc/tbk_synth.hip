@@ -318,7 +318,7 @@ tbk_canonical_keys_kernel(const uint64_t *__restrict__ keys, uint64_t n, int k, 
 }
 
 // counts[r] against what read r must count: its n_k keys (per_read, fewer in the last read) times (1, 0) / (0, 1) / (0, 0)
-// for expect = 1 / 2 / 0, or per key from d_expect (per_read = 1).  out: [0] sum of hapA counts, [1] of hapB counts,
+// for expect = 1 / 2 / 0, or per key from d_expect (a read of per_read keys must count how many of ITS keys say 1 and 2).  out: [0] sum of hapA counts, [1] of hapB counts,
 // [2] reads that differ, [3] the first of them (first + r; all ones: none).
 __global__ void __launch_bounds__(256)
 tbk_counts_check_kernel(const int32_t *__restrict__ counts, uint64_t first, uint64_t n_reads, uint32_t per_read, uint64_t n_keys, int expect,
@@ -327,9 +327,14 @@ tbk_counts_check_kernel(const int32_t *__restrict__ counts, uint64_t first, uint
     unsigned long long a = 0, b = 0, bad = 0;
     if (r < n_reads) {
         const uint64_t nk = r + 1 < n_reads ? per_read : n_keys - r * per_read;
-        const int e = d_expect ? (int)d_expect[r] : expect;
         a = (unsigned long long)counts[2 * r]; b = (unsigned long long)counts[2 * r + 1];
-        bad = (a != (e == 1 ? nk : 0) || b != (e == 2 ? nk : 0)) ? 1 : 0;
+        unsigned long long want_a = expect == 1 ? nk : 0, want_b = expect == 2 ? nk : 0;
+        if (d_expect) {  // per key: the read's keys are d_expect[r * per_read .. + nk) - 1 counts for hapA, 2 for hapB
+            want_a = want_b = 0;
+            const uint8_t *e = d_expect + r * per_read;
+            for (uint64_t i = 0; i < nk; i++) { want_a += e[i] == 1; want_b += e[i] == 2; }
+        }
+        bad = (a != want_a || b != want_b) ? 1 : 0;
         if (bad) atomicMin(&out[3], (unsigned long long)(first + r));
     }
     // wave sums, one atomic per wave and counter

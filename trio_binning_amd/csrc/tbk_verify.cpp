@@ -141,7 +141,6 @@ extern "C" int tbk_classifier_sweep_keys(tbk_classifier *c, const void *d_keys, 
                                          uint64_t chunk_keys, uint64_t out[4]) {
     if (!c || !out || (n && !d_keys)) return vfail(TBK_ERR_INVALID, "NULL argument");
     if (keys_per_read < 1 || expect < 0 || expect > 2 || k < 1 || k > 32) return vfail(TBK_ERR_INVALID, "bad sweep parameters");
-    if (d_expect && keys_per_read != 1) return vfail(TBK_ERR_INVALID, "per-key expectations need keys_per_read = 1");
     out[0] = out[1] = out[2] = 0; out[3] = ~0ull;
     int rc = on_device(tbk_classifier_device(c));
     if (rc || !n) return rc;

@@ -85,13 +85,20 @@ def full_membership_sweep(cls, list_a, list_b, d_keys_a, d_keys_b, n_a, n_b, k, 
             if shared == 0:
                 leg("members_hapB_long_reads", n_b, lambda: _sweep(cls, d_keys_b, n_b, k, LONG_READ_KEYS, 2), 0, n_b)
             else:
+                # hapB keys that hapA's list holds count for hapA: every long read must count exactly what ITS 512 keys say (per-key
+                # expectations from the lists' standalone tables, summed per read on the device) - no allowance by count
                 def b_long():
-                    r = _sweep(cls, d_keys_b, n_b, k, LONG_READ_KEYS, 2)
-                    r["note"] = f"{shared} hapB keys are hapA's too: reads holding one differ from (0, {LONG_READ_KEYS}) by design; the sums decide"
-                    r["bad_reads_allowed"] = r["bad_reads"]
-                    if r["bad_reads"] <= shared:
-                        r["bad_reads"] = 0
-                    return r
+                    tot = {"sum_a": 0, "sum_b": 0, "bad_reads": 0, "first_bad": None}
+                    step = max(LONG_READ_KEYS, chunk // LONG_READ_KEYS * LONG_READ_KEYS)   # whole reads per chunk
+                    for first in range(0, n_b, step):
+                        cn = min(step, n_b - first)
+                        check(lib.tbk_sweep_expectation_device(list_a._h, list_b._h, C.c_void_p(d_keys_b + 8 * first), cn, C.c_void_p(d_exp)))
+                        r = _sweep(cls, d_keys_b + 8 * first, cn, k, LONG_READ_KEYS, 0, d_exp)
+                        tot["sum_a"] += r["sum_a"]; tot["sum_b"] += r["sum_b"]; tot["bad_reads"] += r["bad_reads"]
+                        if tot["first_bad"] is None and r["first_bad"] is not None:
+                            tot["first_bad"] = first // LONG_READ_KEYS + r["first_bad"]
+                    tot["note"] = f"{shared} hapB keys are hapA's too: every read is checked against what its own {LONG_READ_KEYS} keys say"
+                    return tot
                 leg("members_hapB_long_reads", n_b, b_long, shared, n_b - shared)
         if "non_members" in legs:
             n_non = max(n_a, n_b)
