@@ -1617,6 +1617,8 @@ struct BinFile {
     bool positional = false;  // a regular file no other bin names: slices may go out with pwrite from several threads;
                               // anything else (FIFO, /dev/stdout, two prefixes naming one file) gets sequential write()
     TextBuf text;           // records not yet written
+    TextBuf alt;            // the GPU encoder's second buffer: `text` and `alt` change places at every flush, so that the next batch is gathered
+                            // while the device is still fetching this one's text
 };
 
 // One thread per bin that writes finished gzip members to the bin's file while the writer thread is already gathering the next
@@ -1753,6 +1755,7 @@ static int hand_to_lanes(tbk_bin_writer *w, const std::vector<tbk_gdeflate_out> 
 static int flush_bins_gpu(tbk_bin_writer *w, bool final, std::vector<Piece> &pieces, const size_t keep[3]) {
     std::vector<tbk_gdeflate_out> outs;
     int rc = TBK_OK;
+    bool swapped = false;
     if (!pieces.empty()) {
         double t0 = wall_now();
         std::vector<tbk_gdeflate_member> members;
@@ -1778,9 +1781,20 @@ static int flush_bins_gpu(tbk_bin_writer *w, bool final, std::vector<Piece> &pie
         }
         w->gpu_crc_s += wall_now() - t0;
         t0 = wall_now();
-        rc = tbk_gdeflate_text_done(w->gpu);
+        // the text of THIS flush stays where it is until the device has fetched it; what is left over moves to the other buffer
+        // (whose own text - the flush before this one's - must have left: it has, long ago) and the two change places
+        rc = tbk_gdeflate_text_done(w->gpu, 1);
         if (rc) return rc;
         w->gpu_text_wait_s += wall_now() - t0;
+        for (int b = 0; b < 3; b++) {
+            BinFile &f = w->bin[b];
+            f.alt.pinned = true;
+            if (!f.alt.grow_to(std::max<size_t>(keep[b], 1))) return ffail(TBK_ERR_NOMEM, "out of memory buffering a bin");
+            if (keep[b]) memcpy(f.alt.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
+            f.alt.n = keep[b];
+            std::swap(f.text.p, f.alt.p); std::swap(f.text.n, f.alt.n); std::swap(f.text.cap, f.alt.cap);
+        }
+        swapped = true;
         t0 = wall_now();
         rc = tbk_gdeflate_collect(w->gpu, false, outs);
         w->gpu_collect_s += wall_now() - t0;
@@ -1798,11 +1812,12 @@ static int flush_bins_gpu(tbk_bin_writer *w, bool final, std::vector<Piece> &pie
         for (IoLane &l : w->lane) l.idle();
         for (IoLane &l : w->lane) if (!l.err.empty()) return ffail(TBK_ERR_IO, "%s", l.err.c_str());
     }
-    for (int b = 0; b < 3; b++) {
-        BinFile &f = w->bin[b];
-        if (keep[b] && keep[b] != f.text.size()) memmove(f.text.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
-        f.text.n = keep[b];
-    }
+    if (!swapped)
+        for (int b = 0; b < 3; b++) {
+            BinFile &f = w->bin[b];
+            if (keep[b] && keep[b] != f.text.size()) memmove(f.text.data(), f.text.data() + f.text.size() - keep[b], keep[b]);
+            f.text.n = keep[b];
+        }
     return TBK_OK;
 }
 
@@ -2044,7 +2059,8 @@ extern "C" int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b,
         if (!w->bin[k].text.grow_to((size_t)at[k])) return ffail(TBK_ERR_NOMEM, "out of memory buffering a bin");
         w->bin[k].text.n = (size_t)at[k];
     }
-    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)w->threads, total / ((uint64_t)4 << 20)));
+    // (the device codes the members: the gather is all the host does with the text, and the reader's threads want the CPUs - six copy 134 MB in 5 ms)
+    const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(w->gpu ? std::min(w->threads, 6) : w->threads), total / ((uint64_t)4 << 20)));
     auto fill = [&](int t) {
         auto cut = [&](int u) -> size_t {
             if (u <= 0) return 0;

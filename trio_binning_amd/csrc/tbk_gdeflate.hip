@@ -818,9 +818,10 @@ int tbk_gdeflate_submit(tbk_gdeflate *g, const tbk_gdeflate_member *members, siz
     return TBK_OK;
 }
 
-int tbk_gdeflate_text_done(tbk_gdeflate *g) {
-    if (!g || g->submitted == 0) return TBK_OK;
-    Job &j = g->jobs[(g->submitted - 1) % 3];
+// back = 0: the newest job's text has left the caller's buffers; 1: the one before it; ...
+int tbk_gdeflate_text_done(tbk_gdeflate *g, int back) {
+    if (!g || g->submitted <= (uint64_t)back) return TBK_OK;
+    Job &j = g->jobs[(g->submitted - 1 - (uint64_t)back) % 3];
     const hipError_t e = hipEventSynchronize(j.text_in);
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "waiting for the text's copy", e);
     return TBK_OK;
@@ -919,7 +920,7 @@ extern "C" int tbk_gzip_members_device(int device, const char *text, const uint6
     for (uint64_t i = 0; i < n_members; i++) { members.push_back(tbk_gdeflate_member{text + off, (size_t)member_len[i], 0}); off += member_len[i]; }
     rc = tbk_gdeflate_submit(g, members.data(), members.size());
     if (!rc) {
-        rc = tbk_gdeflate_text_done(g);  // (the members' CRC-32s are the device's)
+        rc = tbk_gdeflate_text_done(g, 0);  // (the members' CRC-32s are the device's)
     }
     std::vector<tbk_gdeflate_out> outs;
     uint64_t used = 0, at = 0;
