@@ -118,83 +118,130 @@ struct Lds {
     uint32_t clfreq[19];
     uint8_t cllen[19];
     uint16_t clcode[19];
-    uint8_t cl_sym[GD_NSYM + 2], cl_extra[GD_NSYM + 2];
     uint32_t wave_sum[GD_T / 64];
+    uint16_t hop[2 * GD_NSYM], dep[2 * GD_NSYM];   // pointer jumping over the tree: an ancestor of the node, and how many levels above
+    uint16_t wcnt[5][16];                           // symbols per code length in each group of 64 symbols (canonical codes by ballot)
+    unsigned long long nzmask[5];                   // which symbols have a code (the header's run-length pass walks the set bits)
     uint32_t m, deepest, same, header_bits, total_bits, stored;
 };
 
-// Code lengths (<= limit) for the symbols with freq > 0 among freq[0 .. nsym): every thread takes part.  At least two
-// symbols have freq > 0.  The tree of tbk_deflate.cpp's huffman_lengths: leaves sorted by (freq, symbol), two-queue merge,
-// frequencies halved (never to zero) while the tree is deeper than the limit.
+// Code lengths (<= limit) for the symbols with freq > 0 among freq[0 .. nsym): every thread takes part.  At least two symbols have
+// freq > 0.  Leaves sorted by (freq, symbol) - a rank sort over all lanes; the two-queue merge on one lane (inherently serial: m - 1
+// steps, the queues' heads kept in registers); depths by pointer jumping over all lanes (log2 m rounds instead of 2m dependent LDS
+// reads on one lane).  A tree deeper than the limit is not rebuilt: its over-long leaves are set to the limit and the Kraft sum
+// is brought back to one by moving leaves one level down, one unit per move (zlib's gen_bitlen does the same), then the lengths
+// are handed out again in order of frequency.
 __device__ void gd_huffman(Lds &s, uint32_t *freq, int nsym, int limit, uint8_t *len) {
     const int t = threadIdx.x;
-    for (;;) {
-        if (t == 0) s.m = 0;
-        __syncthreads();
-        for (int a = t; a < nsym; a += GD_T) {
-            const uint32_t f = freq[a];
-            len[a] = 0;
-            if (!f) continue;
-            uint32_t r = 0;
-            for (int b = 0; b < nsym; b++) { const uint32_t g = freq[b]; r += (g != 0 && (g < f || (g == f && b < a))) ? 1u : 0u; }
-            s.order[r] = (uint16_t)a;
-            atomicAdd(&s.m, 1u);
-        }
-        __syncthreads();
-        const int m = (int)s.m;
-        if (t == 0) {
-            for (int i = 0; i < m; i++) s.w[i] = freq[s.order[i]];
-            int leaf = 0, inner = m, next = m;
-            while (next < 2 * m - 1) {
-                int pick[2];
-                for (int q = 0; q < 2; q++) {
-                    if (leaf < m && (inner >= next || s.w[leaf] <= s.w[inner])) pick[q] = leaf++;
-                    else pick[q] = inner++;
-                }
-                s.w[next] = s.w[pick[0]] + s.w[pick[1]];
-                s.parent[pick[0]] = s.parent[pick[1]] = (uint16_t)next;
-                next++;
+    if (t == 0) s.m = 0;
+    __syncthreads();
+    for (int a = t; a < nsym; a += GD_T) {
+        const uint32_t f = freq[a];
+        len[a] = 0;
+        if (!f) continue;
+        uint32_t r = 0;
+        for (int b = 0; b < nsym; b++) { const uint32_t g = freq[b]; r += (g != 0 && (g < f || (g == f && b < a))) ? 1u : 0u; }
+        s.order[r] = (uint16_t)a;
+        atomicAdd(&s.m, 1u);
+    }
+    __syncthreads();
+    const int m = (int)s.m, nodes = 2 * m - 1;
+    for (int i = t; i < m; i += GD_T) s.w[i] = freq[s.order[i]];
+    __syncthreads();
+    if (t == 0) {
+        int leaf = 0, inner = m, next = m;
+        uint32_t wl = s.w[0], wi = 0xFFFFFFFFu;   // the queues' heads (all ones: empty)
+        while (next < nodes) {
+            uint32_t sum = 0;
+            int pick[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (wl <= wi) { pick[q] = leaf++; sum += wl; wl = leaf < m ? s.w[leaf] : 0xFFFFFFFFu; }
+                else { pick[q] = inner++; sum += wi; wi = inner < next ? s.w[inner] : 0xFFFFFFFFu; }
             }
-            s.depth[2 * m - 2] = 0;
-            uint32_t deepest = 0;
-            for (int i = 2 * m - 3; i >= 0; i--) {
-                const uint32_t d = (uint32_t)s.depth[s.parent[i]] + 1u;
-                s.depth[i] = (uint8_t)(d > 255u ? 255u : d);
-                if (i < m && d > deepest) deepest = d;
-            }
-            s.deepest = deepest;
+            s.w[next] = sum;
+            s.parent[pick[0]] = s.parent[pick[1]] = (uint16_t)next;
+            if (inner == next) wi = sum;   // the inner queue was empty: the new node is its head
+            next++;
         }
+    }
+    __syncthreads();
+    // depth of every node: hop = an ancestor, dep = levels up to it; both double until every hop is the root
+    const int root = nodes - 1;
+    for (int i = t; i < nodes; i += GD_T) { s.hop[i] = (uint16_t)(i == root ? root : s.parent[i]); s.dep[i] = (uint16_t)(i == root ? 0 : 1); }
+    __syncthreads();
+    for (int span = 1; span < m; span <<= 1) {
+        uint16_t nh[3], nd[3];
+        int c = 0;
+        for (int i = t; i < nodes; i += GD_T, c++) { const int h = s.hop[i]; nh[c] = s.hop[h]; nd[c] = (uint16_t)(s.dep[i] + s.dep[h]); }
         __syncthreads();
-        if ((int)s.deepest <= limit) {
-            for (int i = t; i < m; i += GD_T) len[s.order[i]] = s.depth[i];
-            __syncthreads();
-            return;
-        }
-        for (int a = t; a < nsym; a += GD_T) if (freq[a]) freq[a] = (freq[a] + 1) / 2;
+        c = 0;
+        for (int i = t; i < nodes; i += GD_T, c++) { s.hop[i] = nh[c]; s.dep[i] = nd[c]; }
         __syncthreads();
     }
+    if ((int)s.dep[0] <= limit) {   // (leaf 0 is the rarest symbol: no leaf lies deeper)
+        for (int i = t; i < m; i += GD_T) len[s.order[i]] = (uint8_t)s.dep[i];
+        __syncthreads();
+        return;
+    }
+    if (t < 16) s.bl_count[t] = 0;
+    if (t == 0) s.deepest = 0;
+    __syncthreads();
+    for (int i = t; i < m; i += GD_T) {
+        const int d = (int)s.dep[i] < limit ? (int)s.dep[i] : limit;
+        atomicAdd(&s.bl_count[d], 1u);
+        atomicAdd(&s.deepest, 1u << (limit - d));   // the Kraft sum in units of 2^-limit
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (uint32_t excess = s.deepest - (1u << limit); excess > 0; excess--) {
+            int bits = limit - 1;
+            while (s.bl_count[bits] == 0) bits--;
+            s.bl_count[bits]--; s.bl_count[bits + 1] += 2; s.bl_count[limit]--;   // one leaf a level down, beside a leaf that comes up from the limit
+        }
+        int idx = 0;
+        for (int bits = limit; bits >= 1; bits--)
+            for (uint32_t c = s.bl_count[bits]; c > 0; c--) len[s.order[idx++]] = (uint8_t)bits;   // the rarest symbols get the longest codes
+    }
+    __syncthreads();
 }
 
-// canonical codes of the lengths, bit-reversed (DEFLATE packs a Huffman code from its most significant bit)
+// canonical codes of the lengths, bit-reversed (DEFLATE packs a Huffman code from its most significant bit).  A symbol's code is
+// the first code of its length plus the number of smaller symbols of that length: counted by wave ballots (fifteen per group of
+// 64 symbols), not by every lane scanning the symbols below it.  Leaves s.bl_count[1 .. 15] = symbols per length.
 __device__ void gd_codes(Lds &s, const uint8_t *len, int nsym, uint16_t *code) {
-    const int t = threadIdx.x;
-    if (t < 16) s.bl_count[t] = 0;
+    const int t = threadIdx.x, lane = t & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int l[2], rank[2] = {0, 0};
+    for (int r = 0; r < 2; r++) {
+        const int a = r * GD_T + t, group = r == 0 ? (t >> 6) : 4;
+        l[r] = a < nsym ? (int)len[a] : 0;
+        if (r == 1 && t >= 64) break;   // (symbols 256 .. 287: the first wave's second turn)
+        for (int L = 1; L <= 15; L++) {
+            const unsigned long long mk = __builtin_amdgcn_ballot_w64(l[r] == L);
+            if (l[r] == L) rank[r] = __popcll(mk & below);
+            if (lane == 0) s.wcnt[group][L] = (uint16_t)__popcll(mk);
+        }
+    }
     __syncthreads();
-    for (int a = t; a < nsym; a += GD_T) if (len[a]) atomicAdd(&s.bl_count[len[a]], 1u);
+    if (t < 16) {
+        uint32_t run = 0;
+        for (int g = 0; g < 5; g++) { const uint32_t c = t ? s.wcnt[g][t] : 0; s.wcnt[g][t] = (uint16_t)run; run += c; }   // -> symbols of this length in earlier groups
+        s.bl_count[t] = run;
+    }
     __syncthreads();
     if (t == 0) {
         uint32_t c = 0;
         s.bl_count[0] = 0;
-        for (int l = 1; l <= 15; l++) { c = (c + s.bl_count[l - 1]) << 1; s.next_code[l] = c; }
+        for (int L = 1; L <= 15; L++) { c = (c + s.bl_count[L - 1]) << 1; s.next_code[L] = c; }
     }
     __syncthreads();
-    for (int a = t; a < nsym; a += GD_T) {
-        const int l = len[a];
-        if (!l) { code[a] = 0; continue; }
-        uint32_t rank = 0;
-        for (int b = 0; b < a; b++) rank += len[b] == l ? 1u : 0u;
-        const uint32_t v = s.next_code[l] + rank;
-        code[a] = (uint16_t)(__brev(v) >> (32 - l));
+    for (int r = 0; r < 2; r++) {
+        const int a = r * GD_T + t, group = r == 0 ? (t >> 6) : 4;
+        if (a >= nsym || (r == 1 && t >= 64)) break;
+        if (!l[r]) { code[a] = 0; continue; }
+        const uint32_t v = s.next_code[l[r]] + s.wcnt[group][l[r]] + (uint32_t)rank[r];
+        code[a] = (uint16_t)(__brev(v) >> (32 - l[r]));
     }
     __syncthreads();
 }
@@ -476,31 +523,48 @@ gd_encode_kernel(const uint8_t *__restrict__ text, const GdBlock *__restrict__ b
     gd_codes(s, s.len, nlit, s.code);
     GD_MARK(4);  // codes
 
-    // ---- the block header (one lane): RFC 1951 3.2.7 ----
-    if (t == 0) {
-        // the code lengths as code-length symbols: lengths as they are, runs of zeros as 17 (3-10) / 18 (11-138)
-        const int total = nlit + 1;  // + the one distance code: one bit where matches are used, none where not
-        auto length_at = [&](int k) -> int { return k < nlit ? (int)s.len[k] : (runs ? 1 : 0); };
-        int ncl = 0;
-        for (int k = 0; k < 19; k++) s.clfreq[k] = 0;
-        for (int k = 0; k < total;) {
-            const int l = length_at(k);
-            if (l != 0) { s.cl_sym[ncl] = (uint8_t)l; s.cl_extra[ncl] = 0; ncl++; s.clfreq[l]++; k++; continue; }
-            int run = 1;
-            while (k + run < total && length_at(k + run) == 0) run++;
-            int left = run;
-            while (left >= 11) { const int r = left < 138 ? left : 138; s.cl_sym[ncl] = 18; s.cl_extra[ncl] = (uint8_t)(r - 11); ncl++; s.clfreq[18]++; left -= r; }
-            if (left >= 3) { s.cl_sym[ncl] = 17; s.cl_extra[ncl] = (uint8_t)(left - 3); ncl++; s.clfreq[17]++; left = 0; }
-            while (left-- > 0) { s.cl_sym[ncl] = 0; s.cl_extra[ncl] = 0; ncl++; s.clfreq[0]++; }
-            k += run;
+    // ---- the block header: RFC 1951 3.2.7 ----
+    // The code lengths go out as code-length symbols: lengths as they are, runs of zeros as 17 (3-10) / 18 (11-138).  Which symbols
+    // have a code is a bit mask (wave ballots); one lane walks its set bits - as many steps as there are symbols in use, not 258 -
+    // once to count the zero-run symbols (the lengths' own counts are gd_codes' bl_count) and once to write.
+    {
+        const int lane = t & 63;
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(t < nlit && s.len[t] != 0);
+        if (lane == 0) s.nzmask[t >> 6] = mk;
+        if (t < 64) {
+            const int a = GD_T + t;
+            const unsigned long long mk2 = __builtin_amdgcn_ballot_w64((a < nlit && s.len[a] != 0) || (a == nlit && runs));   // (the one distance code: a bit where matches are used)
+            if (lane == 0) s.nzmask[4] = mk2;
         }
+    }
+    __syncthreads();
+    const int total = nlit + 1;  // + the one distance code
+    // f(zero run before the symbol, the symbol or -1 for the end) over the symbols that have a code, in order
+    auto walk = [&](auto &&on_zeros, auto &&on_length) {
+        int prev = -1;
+        for (int wv = 0; wv < 5; wv++) {
+            unsigned long long mk = s.nzmask[wv];
+            while (mk) {
+                const int a = wv * 64 + __builtin_ctzll(mk);
+                mk &= mk - 1;
+                if (a - prev - 1 > 0) on_zeros(a - prev - 1);
+                on_length(a);
+                prev = a;
+            }
+        }
+        if (total - prev - 1 > 0) on_zeros(total - prev - 1);
+    };
+    if (t == 0) {
+        uint32_t c0 = 0, c17 = 0, c18 = 0;
+        walk([&](int z) { while (z >= 11) { const int r = z < 138 ? z : 138; c18++; z -= r; } if (z >= 3) { c17++; z = 0; } c0 += (uint32_t)z; }, [&](int) {});
+        for (int k = 1; k <= 15; k++) s.clfreq[k] = s.bl_count[k];
+        if (runs) s.clfreq[1]++;   // the distance code's length
+        s.clfreq[0] = c0; s.clfreq[16] = 0; s.clfreq[17] = c17; s.clfreq[18] = c18;
         int distinct = 0;
         for (int k = 0; k < 19; k++) distinct += s.clfreq[k] != 0;
         if (distinct < 2) s.clfreq[s.clfreq[0] ? 1 : 0]++;  // a code needs two symbols to be complete
-        s.header_bits = (uint32_t)ncl;  // (the number of tokens, until the header is written and its length takes the slot)
     }
     __syncthreads();
-    const int ncl = (int)s.header_bits;
     gd_huffman(s, s.clfreq, 19, 7, s.cllen);
     gd_codes(s, s.cllen, 19, s.clcode);
     if (t == 0) {
@@ -514,12 +578,13 @@ gd_encode_kernel(const uint8_t *__restrict__ text, const GdBlock *__restrict__ b
         bo.put(0u, 5);                        // HDIST: 1 distance code
         bo.put((uint32_t)(hclen - 4), 4);
         for (int k = 0; k < hclen; k++) bo.put(s.cllen[order[k]], 3);
-        for (int k = 0; k < ncl; k++) {
-            const int sym = s.cl_sym[k];
-            bo.put(s.clcode[sym], s.cllen[sym]);
-            if (sym == 17) bo.put(s.cl_extra[k], 3);
-            else if (sym == 18) bo.put(s.cl_extra[k], 7);
-        }
+        const uint32_t z_code = s.clcode[0], z_len = s.cllen[0], c17 = s.clcode[17], l17 = s.cllen[17], c18 = s.clcode[18], l18 = s.cllen[18];
+        walk([&](int z) {
+                 while (z >= 11) { const int r = z < 138 ? z : 138; bo.put(c18, (int)l18); bo.put((uint32_t)(r - 11), 7); z -= r; }
+                 if (z >= 3) { bo.put(c17, (int)l17); bo.put((uint32_t)(z - 3), 3); z = 0; }
+                 for (; z > 0; z--) bo.put(z_code, (int)z_len);
+             },
+             [&](int a) { const int L = a < nlit ? (int)s.len[a] : 1; bo.put(s.clcode[L], s.cllen[L]); });
         s.header_bits = bo.word * 32u + (uint32_t)bo.n;
         bo.finish();
     }
