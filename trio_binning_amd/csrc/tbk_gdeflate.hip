@@ -256,19 +256,68 @@ struct BitOutT {
     uint32_t word;   // index of the word acc's bit 0 belongs to
     int n;           // bits in acc
     bool first;      // the next word to leave is the stretch's first (it may hold a neighbour's bits)
+    // CAPTURE: the stretch's first and last word are not written but kept - (head_w, head_v), (tail_w, tail_v) - for gd_merge_edges
+    bool capture = false, has_head = false, has_tail = false;
+    uint32_t head_w = 0, head_v = 0, tail_w = 0, tail_v = 0;
     __device__ BitOutT(uint32_t *o, uint32_t bitpos) : out(o), acc(0), word(bitpos >> 5), n((int)(bitpos & 31u)), first(true) {}
     __device__ inline void put(uint32_t bits, int len) {
         acc |= (uint64_t)bits << n;
         n += len;
         if (n >= 32) {
-            if (!GLOBAL || first) atomicOr(&out[word], (uint32_t)acc);
+            if (GLOBAL && first && capture) { head_w = word; head_v = (uint32_t)acc; has_head = true; }
+            else if (!GLOBAL || first) atomicOr(&out[word], (uint32_t)acc);
             else out[word] = (uint32_t)acc;
             first = false;
             acc >>= 32; n -= 32; word++;
         }
     }
-    __device__ inline void finish() { if (n > 0 && (uint32_t)acc) atomicOr(&out[word], (uint32_t)acc); }
+    __device__ inline void finish() {
+        if (n <= 0) return;
+        if (!(GLOBAL && capture) && !(uint32_t)acc) return;   // (a captured border is kept even when its bits are all zero: the lanes' chain of borders must not break)
+        if (GLOBAL && capture) {
+            if (first) { head_w = word; head_v = (uint32_t)acc; has_head = true; }   // the whole stretch lies in one word
+            else { tail_w = word; tail_v = (uint32_t)acc; has_tail = true; }
+        } else atomicOr(&out[word], (uint32_t)acc);
+    }
 };
+
+// The words at the borders of the lanes' stretches, merged in the wave's registers instead of by atomics at the memory side (where
+// gfx950 performs device-scope atomics: 700 of them per block wrote 3.6 times the coded bytes).  A lane has a HEAD (its bits in
+// the first word it touches) and, when its stretch goes on past that word, a TAIL (its bits in the last).  The heads of the lanes
+// that begin in one word are ORed by a segmented suffix scan; the word is written ONCE - by the lane whose tail it is, else by the
+// first lane that begins in it - with a plain store.  Only the words a wave shares with its neighbours (its first lane's head
+// group, a tail nobody in the wave continues) still go in by atomicOr: a handful per block.
+__device__ inline void gd_merge_edges(uint32_t *out, const BitOutT<true> &bo) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t hw = bo.has_head ? bo.head_w : 0xFFFF0000u + (uint32_t)lane;   // (no head: a key nobody shares)
+    uint32_t S = bo.has_head ? bo.head_v : 0u;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_down((int)S, d, 64), k = (uint32_t)__shfl_down((int)hw, d, 64);
+        if (lane + d < 64 && k == hw) S |= o;
+    }
+    const uint32_t prev_hw = (uint32_t)__shfl_up((int)hw, 1, 64);
+    const bool leader = bo.has_head && (lane == 0 || prev_hw != hw);
+    const uint32_t tw = bo.has_tail ? bo.tail_w : 0xFFFE0000u + (uint32_t)lane;
+    const uint32_t prev_tw = (uint32_t)__shfl_up((int)tw, 1, 64);
+    const uint32_t next_hw = (uint32_t)__shfl_down((int)hw, 1, 64), next_S = (uint32_t)__shfl_down((int)S, 1, 64);
+    const int next_leader = __shfl_down((int)leader, 1, 64);
+    // A word is written EITHER by one plain store OR by atomics only - a plain store sits in this XCD's L2 until it is written back,
+    // an atomic is performed at the memory side, and the write-back would bury it.  The words this wave may share with its
+    // neighbours - where its first lane begins, where its last lane begins and ends - are the atomic ones.
+    const uint32_t hw0 = (uint32_t)__shfl((int)hw, 0, 64), hw63 = (uint32_t)__shfl((int)hw, 63, 64), tw63 = (uint32_t)__shfl((int)tw, 63, 64);
+    auto shared = [&](uint32_t w) { return w == hw0 || w == hw63 || w == tw63; };
+    if (bo.has_tail) {
+        const bool with_heads = lane < 63 && next_leader && next_hw == tw;   // the heads that begin in my tail's word travel with it
+        const uint32_t v = bo.tail_v | (with_heads ? next_S : 0u);
+        if (with_heads && !shared(tw)) out[tw] = v;
+        else atomicOr(&out[tw], v);
+    }
+    if (leader && !(lane > 0 && prev_tw == hw)) {   // (else: the lane before has written this word with its tail)
+        if (shared(hw)) atomicOr(&out[hw], S);
+        else out[hw] = S;                            // the word begins with this lane's bits
+    }
+}
+
 using BitOut = BitOutT<true>;
 using BitOutLds = BitOutT<false>;
 
@@ -615,19 +664,22 @@ gd_encode_kernel(const uint8_t *__restrict__ text, const GdBlock *__restrict__ b
         for (uint32_t i = t; i < whole; i += GD_T) slot32[i] = s.hdr[i];
         if (t == 0 && (s.header_bits & 31u)) atomicOr(&slot32[whole], s.hdr[whole]);
         BitOut bo(slot32, s.header_bits + my_bit);
+        bo.capture = true;
         gd_tokens<2>(s, src, prev, lo, hi, runs, bits, &bo);
+        if (lo < hi && hi == n) {
+            // the lane with the block's last bytes goes on: the end-of-block code, then the empty stored block - BFINAL = 0, BTYPE = 00,
+            // zero bits up to the byte, LEN = 0, NLEN = FFFF - so that these bits are part of ITS stretch (no second writer in its words)
+            bo.put(s.code[256], s.len[256]);
+            bo.put(0u, 3);
+            const uint32_t at_bit = bo.word * 32u + (uint32_t)bo.n;
+            bo.put(0u, (int)((8u - (at_bit & 7u)) & 7u));
+            bo.put(0u, 16);
+            bo.put(0xFFFFu, 16);
+        }
         bo.finish();
+        gd_merge_edges(slot32, bo);
     }
-    if (t == 0) {
-        BitOut bo(slot32, s.header_bits + total_bits);
-        bo.put(s.code[256], s.len[256]);
-        bo.finish();
-        // the empty stored block: BFINAL = 0, BTYPE = 00, zero bits up to the byte, LEN = 0, NLEN = FFFF
-        const uint32_t at = (end_bits + 3 + 7) / 8;  // first byte of LEN
-        atomicOr(&slot32[(at + 2) >> 2], 0xFFu << (((at + 2) & 3u) * 8));
-        atomicOr(&slot32[(at + 3) >> 2], 0xFFu << (((at + 3) & 3u) * 8));
-        sizes[blockIdx.x] = coded_bytes;
-    }
+    if (t == 0) sizes[blockIdx.x] = coded_bytes;
     GD_MARK(7);  // codes out
 }
 
