@@ -293,12 +293,19 @@ def test_second_build_is_identical(big):
     cls.close()
     big.cls = again = kmers.Classifier(a, b)
     st2 = again.stats()
-    # which key of a crowded bucket ends up behind the front depends on the order of arrival; so does, in the entry layouts, whether
-    # two keys of neighbouring runs that agree where they overlap meet in one entry or open two (2e8 entries: seen to differ by one)
+    # What is the same by construction: the keys stored (distinct_a/_b, shared_keys), the table's geometry, every answer (below, and
+    # the constructor's own verification of every list line).  What is NOT, by construction: which key of a crowded bucket ends up
+    # behind the front (order of arrival), and - entry layouts - HOW MANY entries the keys make.  An entry is a greedy merge: a key
+    # joins the first entry of its m-mer whose flanks agree with its own, entries only gain bits, and a key that agrees with two
+    # entries which do not agree with each other joins whichever it meets first; thousands of threads insert at once, so the
+    # partition of the keys into entries - not the set of keys - differs from build to build (seen: 2e-5 of 7.7e7 narrow entries,
+    # one of 2e8 wide ones).  Membership is a property of the keys, and that is what is compared.
     racy = ("keys_behind_front", "keys_past_half", "entries_a", "entries_b")
     assert {k_: v for k_, v in st2.items() if k_ not in racy} == {k_: v for k_, v in st.items() if k_ not in racy}, (st, st2)
     for name in ("entries_a", "entries_b"):
-        assert abs(st2.get(name, 0) - st.get(name, 0)) <= 1e-5 * max(1, st.get(name, 0)), (name, st, st2)
+        assert abs(st2.get(name, 0) - st.get(name, 0)) <= 1e-3 * max(1, st.get(name, 0)), (name, st, st2)
+    if st["entry_layout"]:
+        assert again.verified()["lines"] == a.num_kmers + b.num_kmers   # (every list line answered by the second build too)
     assert np.array_equal(again.classify_batch(bases, offs), counts)
     rec = full_membership_sweep(again, a, b, a.device_keys, b.device_keys, cfg["n"], cfg["n"], cfg["k"], device=0,
                                 uniform_seed=KEY_SEED if cfg["lists"] == "uniform" else None, legs=("members",))
