@@ -452,6 +452,11 @@ int tbk_bin_writer_use_device(tbk_bin_writer *w, int device);
  * back to back in dst (member_out_len[i] bytes each; *need = bytes used, or needed when cap is too small: TBK_ERR_NOMEM). */
 int tbk_gzip_members_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, char *dst, uint64_t cap,
                             uint64_t *member_out_len, uint64_t *need);
+/* The encoder timed by itself (tools/measure_gdeflate.py): `reps` jobs of these members (text in pinned host memory: tbk_host_alloc)
+ * through the three-deep ring - *pipelined_s per job, the link included - and one job's kernels between HIP events on their own
+ * stream - *kernels_s; *out_bytes = bytes of members a job makes. */
+int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s,
+                          double *kernels_s, uint64_t *out_bytes);
 int tbk_bin_writer_encoder(const tbk_bin_writer *w);
 int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins);
 int tbk_bin_writer_close(tbk_bin_writer *w);

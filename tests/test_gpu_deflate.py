@@ -151,3 +151,45 @@ def test_cli_bins_through_either_encoder(gpu, capsys, tmp_path, monkeypatch, enc
     for fn, digest in v["cli_bins"].items():
         assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
     assert ('"gzip_encoder": "%s"' % ("device" if encoder == "gpu" else "host")) in err, err[-600:]
+
+
+def test_bin_writer_on_the_device_equals_the_python_writer(gpu, tmp_path):
+    """seq.BinWriter(..., device=0): the three bins' gzip members coded on the GPU, many small batches (the job ring turns over, the
+    bins' text changes buffers at every flush, members of 1 MiB are cut across batches), FASTQ and FASTA records mixed - the
+    decompressed bins equal what the Python mirror of seq.py:27-42,98-136 writes; an empty bin is a valid empty gzip file."""
+    import random
+
+    from trio_binning_amd import seq
+
+    rng = random.Random(19)
+    recs = []
+    for i in range(6000):
+        n = rng.randrange(0, 2500)
+        s = "".join(rng.choice("ACGT") for _ in range(n))
+        kind = rng.random()
+        q = None if kind < 0.3 else ("" if kind < 0.35 else "".join(rng.choice("!#5I~") for _ in range(n)))
+        recs.append(seq.Read(f"read{i}/x", s, q))
+    src = tmp_path / "in.fq"
+    with open(src, "w") as fh:
+        for r in recs:
+            r.print(file=fh)
+    for trial, letters in enumerate(("ABU", "AB")):   # (second trial: the unclassified bin stays empty)
+        bins_all = "".join(rng.choice(letters) for _ in recs)
+        outs = seq.open_outfiles(str(tmp_path / f"pa{trial}"), str(tmp_path / f"pb{trial}"), str(tmp_path / f"pu{trial}"), ".fq", True)
+        parsed = list(seq.open_fastx_read(str(src)))
+        for r, b in zip(parsed, bins_all):
+            r.print(file=outs["ABU".index(b)])
+        for fh in outs:
+            fh.close()
+        w = seq.BinWriter(str(tmp_path / f"na{trial}"), str(tmp_path / f"nb{trial}"), str(tmp_path / f"nu{trial}"), ".fq", True, device=0)
+        assert w.gpu_encoder
+        got_n = 0
+        with seq.BatchReader(str(src)) as r:
+            b = seq.Batch()
+            while r.next_batch(b, 200_000, 0):
+                w.write(b, bins_all[got_n:got_n + b.n_reads].encode())
+                got_n += b.n_reads
+        w.close()
+        assert got_n == len(parsed)
+        for py_name, nat_name in zip(seq.output_names(str(tmp_path / f"pa{trial}"), str(tmp_path / f"pb{trial}"), str(tmp_path / f"pu{trial}"), ".fq", True), w.names):
+            assert gzip.open(nat_name, "rb").read() == gzip.open(py_name, "rb").read(), nat_name

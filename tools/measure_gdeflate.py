@@ -22,6 +22,7 @@ ap.add_argument("--mb", type=int, default=134)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--qual", default="hifi")
 ap.add_argument("--read-len", type=int, default=15000)
+ap.add_argument("--bench", type=int, default=0, help="N > 0: also time N jobs through the encoder's ring (tbk_gzip_bench_device) and the host encoder beside it")
 a = ap.parse_args()
 from trio_binning_amd import seq  # noqa: E402
 
@@ -47,5 +48,48 @@ for r in range(a.reps):
     times.append(time.perf_counter() - t0)
 ok = all(zlib.decompressobj(31).decompress(m) == p for m, p in zip(members, pieces))
 out = sum(len(m) for m in members)
-print(json.dumps({"text_MB": round(len(text) / 1e6, 1), "members": len(pieces), "out_MB": round(out / 1e6, 1), "ratio": round(out / len(text), 4),
-                  "call_s": [round(t, 4) for t in times], "text_GB_per_s_best_call": round(len(text) / min(times) / 1e9, 2), "members_inflate_to_their_text": ok}))
+rec = {"text_MB": round(len(text) / 1e6, 1), "members": len(pieces), "out_MB": round(out / 1e6, 1), "ratio": round(out / len(text), 4),
+       "call_s": [round(t, 4) for t in times], "members_inflate_to_their_text": ok}
+if a.bench:
+    # the encoder's own line: the ring in its steady state from pinned memory (what the bin writer drives), one job's kernels between
+    # HIP events, the host's encoder (tbk_deflate.cpp, the same coder) on every usable thread beside it
+    import ctypes as C
+    import threading
+
+    from trio_binning_amd import kmers
+    from trio_binning_amd._lib import check, lib
+
+    pinned = kmers.pinned_empty((len(text),), np.uint8)
+    pinned[:] = np.frombuffer(text, dtype=np.uint8)
+    lens = (C.c_uint64 * len(pieces))(*[len(p) for p in pieces])
+    ps, ks, ob = C.c_double(), C.c_double(), C.c_uint64()
+    check(lib.tbk_gzip_bench_device(0, C.c_void_p(pinned.ctypes.data), lens, len(pieces), a.bench, C.byref(ps), C.byref(ks), C.byref(ob)))
+    threads = kmers.host_threads()
+    cap = 2 * (1 << 20) + 4096
+
+    def host_worker(idx, stop_at, done):
+        buf = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        while time.perf_counter() < stop_at:
+            p = pieces[idx % len(pieces)]
+            lib.tbk_gzip_member(p, len(p), buf, cap, C.byref(n))
+            done[idx % threads] += len(p)
+            idx += threads
+    done = [0] * threads
+    t0 = time.perf_counter()
+    pool = [threading.Thread(target=host_worker, args=(i, t0 + 3.0, done)) for i in range(threads)]
+    for t in pool: t.start()
+    for t in pool: t.join()
+    host_s = time.perf_counter() - t0
+    alg = len(text) + ob.value   # the text read once, the members written once
+    rec["bench"] = {
+        "metric": "GB/s of FASTQ text into gzip members (the bins of classify-by-kmers' default mode, seq.py:132-134)", "unit": "GB/s", "dtype": "u8",
+        "value": round(len(text) / ps.value / 1e9, 2), "what": f"{a.bench} jobs of {len(pieces)} members of 1 MiB through the three-deep ring from pinned host memory: H2D, kernels, D2H overlapped",
+        "kernels_only_GB_per_s": round(len(text) / ks.value / 1e9, 2), "kernels_ms_per_job": round(ks.value * 1e3, 3), "pipelined_ms_per_job": round(ps.value * 1e3, 3),
+        "roofline": {"bound": "pcie", "achieved": round(len(text) / ps.value / 1e9, 2), "peak": 55.0, "unit": "GB/s of text over the link (H2D; the members go back on the other direction)",
+                     "frac": round(len(text) / ps.value / 1e9 / 55.0, 3),
+                     "hbm": {"algorithmic_bytes_per_job": alg, "kernels_ms": round(ks.value * 1e3, 3), "achieved_GB_per_s": round(alg / ks.value / 1e9, 1), "peak": 8000.0,
+                             "frac": round(alg / ks.value / 1e9 / 8000.0, 4), "traffic": "profiles/r06/gdeflate_pmc.json: 138 MB read + 53 MB written by gd_encode_kernel per 134 MB job (1.05 x algorithmic)"}},
+        "cpu_baseline": {"value": round(sum(done) / host_s / 1e9, 2), "unit": "GB/s", "cores": threads, "kind": "port", "sample": f"the library's host encoder (tbk_deflate.cpp: the same coder) on {threads} threads for 3 s over the same members"},
+    }
+print(json.dumps(rec))

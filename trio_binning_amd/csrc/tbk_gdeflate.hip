@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -1064,3 +1065,83 @@ extern "C" int tbk_gdeflate_phases_(unsigned long long out[16]) {
     return e == hipSuccess ? 0 : -5;
 }
 #endif
+
+// C-ABI (include/tbk.h): the encoder timed by itself.  `reps` jobs of the same members (text in PINNED host memory, as the bin writer
+// holds it) go through the three-deep ring - text in, kernels, members out, overlapped - and *pipelined_s is the wall time per job in
+// the steady state (link included); *kernels_s the kernels' own time per job (HIP events around one job's kernels on an idle
+// device).  *out_bytes: bytes of members one job makes.
+extern "C" int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s, double *kernels_s,
+                                     uint64_t *out_bytes) {
+    if (!text || !member_len || !n_members || reps < 4 || !pipelined_s || !kernels_s || !out_bytes) { tbk_set_error_(TBK_ERR_INVALID, "tbk_gzip_bench_device: bad argument"); return TBK_ERR_INVALID; }
+    tbk_gdeflate *g = nullptr;
+    int rc = tbk_gdeflate_create(device, &g);
+    if (rc) return rc;
+    std::vector<tbk_gdeflate_member> members;
+    uint64_t off = 0;
+    for (uint64_t i = 0; i < n_members; i++) { members.push_back(tbk_gdeflate_member{text + off, (size_t)member_len[i], 0}); off += member_len[i]; }
+    std::vector<tbk_gdeflate_out> outs;
+    // warm-up: three jobs (every slot's buffers exist), drained
+    for (int i = 0; i < 3 && !rc; i++) { rc = tbk_gdeflate_submit(g, members.data(), members.size()); if (!rc) rc = tbk_gdeflate_collect(g, false, outs); }
+    while (!rc && tbk_gdeflate_in_flight(g) > 0) rc = tbk_gdeflate_collect(g, true, outs);
+    uint64_t bytes = 0;
+    for (const tbk_gdeflate_out &o : outs) bytes += o.n;
+    // one job alone, its kernels between two events
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0;
+    if (!rc) {
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        // (the kernels wait for the text's event: bracket them by recording behind the text's arrival and behind the last kernel)
+        if (e == hipSuccess) { rc = tbk_gdeflate_submit(g, members.data(), members.size()); }
+        if (e != hipSuccess) rc = gfail(TBK_ERR_HIP, "bench", e);
+        while (!rc && tbk_gdeflate_in_flight(g) > 0) rc = tbk_gdeflate_collect(g, true, outs);
+        // timed again with the text already resident: the same job's kernels re-launched are what the events bracket
+        if (!rc) {
+            Job &j = g->jobs[(g->submitted - 1) % 3];
+            const size_t nm = members.size();
+            uint64_t nb = 0, longest = 0, text_total = 0, slot_total = 0;
+            for (size_t i = 0; i < nm; i++) {
+                const uint64_t entries = members[i].n / 8192 + 1;
+                nb += entries; longest = std::max<uint64_t>(longest, members[i].n); text_total += members[i].n;
+                slot_total += (((uint64_t)members[i].n + members[i].n / 8 + 15) & ~(uint64_t)15) + entries * 1040;
+            }
+            const uint64_t n_words = (text_total + 31) / 32;
+            (void)hipEventRecord(e0, g->stream);
+            (void)hipMemsetAsync(j.d_member_end.p, 0, (nm + 1) * 12, g->stream);
+            (void)hipMemsetAsync(j.d_slots.p, 0, slot_total, g->stream);
+            hipLaunchKernelGGL(gd_newline_kernel, dim3((unsigned)((n_words + GD_T - 1) / GD_T)), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p, n_words, (uint32_t *)j.d_bitmap.p);
+            hipLaunchKernelGGL(gd_cut_kernel, dim3((unsigned)nm), dim3(64), 0, g->stream, (const GdMember *)j.d_members.p, (uint32_t)nm, (const uint32_t *)j.d_bitmap.p, (GdBlock *)j.d_blocks.p);
+            hipLaunchKernelGGL(gd_crc_kernel, dim3((unsigned)(((longest + 63) / 64 + GD_T - 1) / GD_T), (unsigned)nm), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p,
+                               (const GdMember *)j.d_members.p, (const GdCrcTabs *)g->d_crc_tabs, g->x2n, (uint32_t *)((uint64_t *)j.d_member_end.p + nm + 1));
+            hipLaunchKernelGGL(gd_encode_kernel, dim3((unsigned)nb), dim3(GD_T), 0, g->stream, (const uint8_t *)j.d_text.p, (const GdBlock *)j.d_blocks.p, (uint8_t *)j.d_slots.p, (uint32_t *)j.d_sizes.p);
+            hipLaunchKernelGGL(gd_scan_kernel, dim3(1), dim3(GD_T), 0, g->stream, (const GdBlock *)j.d_blocks.p, (const uint32_t *)j.d_sizes.p, (uint32_t)nb, (uint64_t *)j.d_offsets.p,
+                               (uint64_t *)j.d_member_end.p, (uint32_t)nm);
+            hipLaunchKernelGGL(gd_gather_kernel, dim3((unsigned)nb), dim3(GD_T), 0, g->stream, (const GdBlock *)j.d_blocks.p, (const uint32_t *)j.d_sizes.p, (const uint64_t *)j.d_offsets.p,
+                               (const uint8_t *)j.d_slots.p, (uint8_t *)j.d_dense.p);
+            (void)hipEventRecord(e1, g->stream);
+            hipError_t e2 = hipEventSynchronize(e1);
+            if (e2 == hipSuccess) e2 = hipEventElapsedTime(&ms, e0, e1);
+            if (e2 != hipSuccess) rc = gfail(TBK_ERR_HIP, "bench events", e2);
+        }
+    }
+    // the ring in its steady state
+    double wall = 0;
+    if (!rc) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps && !rc; i++) {
+            rc = tbk_gdeflate_submit(g, members.data(), members.size());
+            if (!rc) rc = tbk_gdeflate_collect(g, false, outs);
+        }
+        while (!rc && tbk_gdeflate_in_flight(g) > 0) rc = tbk_gdeflate_collect(g, true, outs);
+        wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    tbk_gdeflate_destroy(g);
+    if (rc) return rc;
+    *pipelined_s = wall / reps;
+    *kernels_s = ms * 1e-3;
+    *out_bytes = bytes;
+    return TBK_OK;
+}
