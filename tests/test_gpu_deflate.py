@@ -70,7 +70,7 @@ def test_members_inflate_to_their_text(gpu):
     assert len(members[10]) < len(pieces[10]) + 5 * (len(pieces[10]) // 8192 + 2) + 64   # noise does not grow beyond the stored blocks' headers
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TBK_DEFLATE_FUZZ_SEEDS", "6"))))   # (a soak run: TBK_DEFLATE_FUZZ_SEEDS=400)
 def test_fuzz_against_zlib(gpu, seed):
     from trio_binning_amd import seq
 
