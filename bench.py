@@ -1046,6 +1046,11 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     # ---- the same stage fed differently (rank 0, N = 1) ----------------------------------------------
     if rank == 0 and world == 1 and not args.no_streaming and not ragged:
         out["pipeline_variants"] = pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batches[0], L)
+    if rank == 0 and world == 1 and not args.no_streaming and not ragged and not hap and hasattr(lib, "tbk_gzip_bench_device"):
+        try:
+            out["bins_gzip_encoder"] = gzip_encoder_leg(np, kmers, lib, check, dev, par_bases, par_offs)
+        except Exception as e:  # (a side record: it must not cost the bench line)
+            print(f"bench: bins_gzip_encoder leg failed: {e}", file=sys.stderr)
 
     if args.calibrate and rank == 0:
         out["calibration"] = calibrate(lib, check, dev, stats["table_bytes"])
@@ -1061,6 +1066,43 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
     hap_a.close()
     hap_b.close()
     return out
+
+
+def gzip_encoder_leg(np, kmers, lib, check, dev, par_bases, par_offs):
+    """What follows the classify stage in the reference's default mode: the three bins written through gzip (seq.py:132-134,
+    classify_by_kmers.py:86-92).  The bin writer codes its members on the device (csrc/tbk_gdeflate.hip); this leg times that encoder
+    by itself on the parity reads as FASTQ text with HiFi-like qualities, cut into members of 1 MiB as the writer cuts them:
+    the three-deep ring from pinned memory (GB/s of text, against the 55 GB/s the link brings) and one job's kernels between HIP
+    events.  Every member's round trip through zlib is tests/test_gpu_deflate.py's business, not this leg's."""
+    rng = np.random.default_rng(0x5EED0006)
+    n_reads = min(len(par_offs) - 1, 4096)
+    lens = np.diff(par_offs[: n_reads + 1]).astype(np.int64)
+    total = int(lens.sum())
+    qual = np.clip(rng.normal(60, 15, total), 2, 93).astype(np.uint8)
+    qual[rng.random(total) < 0.6] = 93
+    qual += 33
+    pieces = []
+    for r in range(n_reads):
+        lo, hi = int(par_offs[r]), int(par_offs[r + 1])
+        pieces += [b"@read%09d c\n" % r, par_bases[lo:hi].tobytes(), b"\n+\n", qual[lo:hi].tobytes(), b"\n"]
+    text = b"".join(pieces)
+    member = 1 << 20
+    n_members = (len(text) + member - 1) // member
+    pinned = kmers.pinned_empty((len(text),), np.uint8)
+    pinned[:] = np.frombuffer(text, dtype=np.uint8)
+    mlens = (C.c_uint64 * n_members)(*[min(member, len(text) - i * member) for i in range(n_members)])
+    ps, ks, ob = C.c_double(), C.c_double(), C.c_uint64()
+    check(lib.tbk_gzip_bench_device(dev, C.c_void_p(pinned.ctypes.data), mlens, n_members, 24, C.byref(ps), C.byref(ks), C.byref(ob)))
+    link = 55.0
+    return {
+        "what": "the bins' gzip members coded on the device (the reference's default output, seq.py:132-134): the parity reads as FASTQ text with HiFi-like "
+                f"qualities, {n_members} members of 1 MiB per job, 24 jobs through the three-deep ring from pinned host memory",
+        "text_MB_per_job": round(len(text) / 1e6, 1), "members_MB_per_job": round(ob.value / 1e6, 1), "ratio": round(ob.value / len(text), 4),
+        "text_GB_per_s": round(len(text) / ps.value / 1e9, 2), "gbases_per_s_equivalent": round(total / ps.value / 1e9, 2),
+        "kernels_only_text_GB_per_s": round(len(text) / ks.value / 1e9, 2), "kernels_ms_per_job": round(ks.value * 1e3, 3),
+        "roofline": {"bound": "pcie", "achieved": round(len(text) / ps.value / 1e9, 2), "peak": link, "unit": "GB/s of text over the link", "frac": round(len(text) / ps.value / 1e9 / link, 3),
+                     "hbm_frac_of_the_kernels": round((len(text) + ob.value) / ks.value / 1e9 / HBM_PEAK_GBPS, 4)},
+    }
 
 
 def pipeline_variants(args, np, kmers, lib, check, dev, pipe, par_bases, par_offs, par_counts, batch0, L):

@@ -58,7 +58,7 @@ def test_sub_records_of_the_default_line():
     """The two sub-records the default N = 1 run adds, at test size: `strong_90gbp` (BASELINE configs[2]'s literal set: one pass
     per step over every distinct batch of a fixed read set, with its own parity against the oracle) and `realistic_lists`
     (haplotype-shaped lists) with its `traffic` measured by a counter pass of its own - the headline's treatment."""
-    base = [a for a in SMALL if a not in ("--no-realistic", "--no-strong-leg", "--no-cpu-baseline")]
+    base = [a for a in SMALL if a not in ("--no-realistic", "--no-strong-leg", "--no-cpu-baseline", "--no-streaming")]
     out = run_bench(["--live-pmc", "on", "--no-sweep", "--strong-reads", "20000", "--strong-leg-timed-s", "0", "--realistic-timed-s", "0", "--cpu-seconds", "0.5"], base)
     st = out["strong_90gbp"]
     assert st["reads"] == 20000 and st["distinct_batches"] == 3 and st["bases"] == 20000 * 15000 and st["value"] > 0
@@ -68,3 +68,5 @@ def test_sub_records_of_the_default_line():
     assert rl["traffic_source"].startswith("measured in this run"), rl["traffic_source"]
     assert rl["traffic"] > 0 and rl["parity"]["gpu_equals_cpu"]
     assert out["roofline"]["traffic_source"].startswith("measured in this run")
+    enc = out["bins_gzip_encoder"]   # the default line's record of the GPU gzip encoder behind the bins
+    assert enc["text_GB_per_s"] > 1 and 0.2 < enc["ratio"] < 0.6 and enc["roofline"]["bound"] == "pcie"
