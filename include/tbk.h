@@ -455,6 +455,11 @@ int tbk_gzip_members_device(int device, const char *text, const uint64_t *member
 /* The encoder timed by itself (tools/measure_gdeflate.py): `reps` jobs of these members (text in pinned host memory: tbk_host_alloc)
  * through the three-deep ring - *pipelined_s per job, the link included - and one job's kernels between HIP events on their own
  * stream - *kernels_s; *out_bytes = bytes of members a job makes. */
+/* The other direction (csrc/tbk_gdeflate.hip, second half): a bgzf file - the chain of independent <= 64 KiB gzip members that bgzip and
+ * htslib write, which the reference reads through gzip.open like any .gz (seq.py:86-92) - inflated on `device`, one wave per block, every
+ * block's CRC-32 checked there.  data / size: the file's bytes (or a run of whole blocks); *text_len: bytes of text.  The reader
+ * (tbk_fastx_set_device) drives the same inflater three windows deep. */
+int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint8_t *dst, uint64_t cap, uint64_t *text_len);
 int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s,
                           double *kernels_s, uint64_t *out_bytes);
 int tbk_bin_writer_encoder(const tbk_bin_writer *w);

@@ -1,0 +1,115 @@
+"""The GPU inflater of the reader's bgzf path (csrc/tbk_gdeflate.hip, second half) against zlib: the text of a bgzf file - what the
+reference gets through gzip.open (seq.py:86-92) - must come out byte for byte, whatever deflate blocks its members hold (dynamic and
+fixed Huffman codes, stored blocks, matches that overlap themselves, codes longer than the look-up tables' index), and a member that
+is damaged must be refused, not returned."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EOF_BLOCK = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def bgzf(text: bytes, level=6, block=60000, strategy=zlib.Z_DEFAULT_STRATEGY, eof=True) -> bytes:
+    out = bytearray()
+    for i in range(0, len(text), block):
+        blk = text[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        body = c.compress(blk) + c.flush()
+        assert 18 + len(body) + 8 <= 65536
+        out += struct.pack("<BBBBIBBHBBHH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6, 66, 67, 2, 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk))
+    return bytes(out) + (EOF_BLOCK if eof else b"")
+
+
+def fastq(rng, n_reads, L, qual="hifi"):
+    recs = []
+    for i in range(n_reads):
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].tobytes()
+        if qual == "const":
+            q = b"I" * L
+        else:
+            qv = np.clip(rng.normal(60, 15, L), 2, 93).astype(np.uint8)
+            qv[rng.random(L) < 0.6] = 93
+            q = (qv + 33).tobytes()
+        recs.append(b"@read%d c\n" % i + seq + b"\n+\n" + q + b"\n")
+    return b"".join(recs)
+
+
+def test_bgzf_text_equals_zlibs(gpu):
+    from trio_binning_amd import seq
+
+    rng = np.random.default_rng(3)
+    texts = {
+        "hifi": fastq(rng, 60, 15000),
+        "const": fastq(rng, 60, 15000, "const"),                        # runs: matches at distance 1 that overlap themselves
+        "short reads": fastq(rng, 5000, 150),
+        "noise": rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes(),   # incompressible: zlib stores
+        "skewed": rng.choice(np.arange(200, dtype=np.uint8), size=400_000, p=(lambda w: w / w.sum())(1.5 ** -np.arange(200))).tobytes(),   # codes up to 15 bits: past the tables' index
+        "periodic": (b"ACGTTGCA" * 7 + b"\n") * 8000,                     # long matches, small distances
+        "one byte": b"x",
+        "empty": b"",
+    }
+    for name, text in texts.items():
+        for level, strategy, block in ((6, zlib.Z_DEFAULT_STRATEGY, 60000), (1, zlib.Z_DEFAULT_STRATEGY, 60000), (9, zlib.Z_DEFAULT_STRATEGY, 65280), (6, zlib.Z_FIXED, 30000),
+                                       (0, zlib.Z_DEFAULT_STRATEGY, 50000), (6, zlib.Z_HUFFMAN_ONLY, 60000), (6, zlib.Z_RLE, 4000)):
+            data = bgzf(text, level, block, strategy)
+            assert gzip.decompress(data) == text
+            assert seq.bgzf_inflate_device(data) == text, (name, level, strategy, block)
+    # members separated by zero padding, no end-of-file block, an end-of-file block in the middle
+    a, b = bgzf(texts["hifi"][:200_000], eof=False), bgzf(texts["const"][:100_000])
+    assert seq.bgzf_inflate_device(a + b"\0" * 7 + EOF_BLOCK + b) == texts["hifi"][:200_000] + texts["const"][:100_000]
+    assert seq.bgzf_inflate_device(EOF_BLOCK) == b""
+
+
+def test_damaged_members_are_refused(gpu):
+    from trio_binning_amd import seq
+    from trio_binning_amd._lib import TbkError
+
+    rng = np.random.default_rng(4)
+    text = fastq(rng, 20, 15000)
+    data = bytearray(bgzf(text))
+    for where in (40, 3000, len(data) // 2, len(data) - 60):   # a flipped bit in a member's deflate stream: it fails to decode or fails its CRC-32
+        bad = bytearray(data)
+        bad[where] ^= 0x10
+        with pytest.raises((TbkError, ValueError, IOError)):
+            seq.bgzf_inflate_device(bytes(bad))
+    wrong_crc = bytearray(data)
+    wrong_crc[data.index(b"\x1f\x8b", 100) - 8] ^= 1           # the first member's CRC-32
+    with pytest.raises((TbkError, ValueError, IOError)):
+        seq.bgzf_inflate_device(bytes(wrong_crc))
+    with pytest.raises((TbkError, ValueError, IOError)):
+        seq.bgzf_inflate_device(bytes(data[: len(data) // 2]))   # cut inside a member
+    with pytest.raises((TbkError, ValueError, IOError)):
+        seq.bgzf_inflate_device(gzip.compress(text))             # an ordinary gzip member is not bgzf
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_against_zlib(gpu, seed):
+    from trio_binning_amd import seq
+
+    rng = np.random.default_rng(500 + seed)
+    parts, want = [], []
+    for _ in range(40):
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(1, 400_000))
+        if kind == 0:
+            t = fastq(rng, max(1, n // 30000), 15000, ["hifi", "const"][int(rng.integers(0, 2))])
+        elif kind == 1:
+            alphabet = rng.integers(0, 256, int(rng.integers(1, 60)), dtype=np.uint8)
+            t = alphabet[rng.integers(0, alphabet.size, n)].tobytes()
+        elif kind == 2:
+            runs = rng.integers(1, 700, max(1, n // 200))
+            t = np.repeat(rng.integers(0, 256, runs.size, dtype=np.uint8), runs).tobytes()
+        elif kind == 3:
+            unit = rng.integers(65, 91, int(rng.integers(1, 300)), dtype=np.uint8).tobytes()
+            t = (unit * (n // len(unit) + 1))[:n]
+        else:
+            t = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        parts.append(bgzf(t, int(rng.integers(0, 10)), int(rng.integers(1000, 65281)),
+                          [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED][int(rng.integers(0, 5))], eof=bool(rng.integers(0, 2))))
+        want.append(t)
+    assert seq.bgzf_inflate_device(b"".join(parts)) == b"".join(want)

@@ -20,3 +20,13 @@ int tbk_gdeflate_text_done(tbk_gdeflate *g, int back = 0);   // back: how many j
 int tbk_gdeflate_collect(tbk_gdeflate *g, bool drain, std::vector<tbk_gdeflate_out> &out);
 int tbk_gdeflate_in_flight(const tbk_gdeflate *g);
 void tbk_gdeflate_stats(const tbk_gdeflate *g, uint64_t *text_bytes, uint64_t *member_bytes, uint64_t *blocks, uint64_t *members);
+
+// ---- the other direction: bgzf blocks inflated on the device (tbk_gdeflate.hip, second half) -------------------------------------------
+struct tbk_ginflate;
+struct tbk_ginflate_block { uint64_t in_off; uint32_t in_len, out_len, crc; uint32_t pad_; };   // a raw deflate stream in the window's input; its text's length and CRC-32 (the bgzf trailer's)
+constexpr int TBK_GINFLATE_SLOTS = 3;
+int tbk_ginflate_create(int device, tbk_ginflate **out);
+void tbk_ginflate_destroy(tbk_ginflate *g);
+uint8_t *tbk_ginflate_input(tbk_ginflate *g, int slot, size_t bytes);
+int tbk_ginflate_submit(tbk_ginflate *g, int slot, size_t in_bytes, const tbk_ginflate_block *blocks, size_t n_blocks, size_t head);
+int tbk_ginflate_wait(tbk_ginflate *g, int slot, uint8_t **out_base, size_t *text_bytes, uint32_t *bad);

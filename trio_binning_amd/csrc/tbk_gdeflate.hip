@@ -1021,6 +1021,379 @@ void tbk_gdeflate_stats(const tbk_gdeflate *g, uint64_t *text_bytes, uint64_t *m
     if (members) *members = g ? g->members : 0;
 }
 
+
+// =====================================================================================================================================
+// The other direction: bgzf input inflated on the GPU (tbk_ginflate_*; the reader's bgzf path, tbk_fastx.cpp).
+// =====================================================================================================================================
+// A .fastq.gz written by bgzip / htslib is a chain of independent gzip members of at most 64 KiB of text (the BC extra field says how
+// long each one is): the reference reads it through gzip.open like any other (seq.py:86-92), this reader inflated its blocks side by
+// side on the host's threads - 6.5 GB/s of text on 16 of them, what a run from bgzf input waited for.  Here ONE WAVE inflates a block,
+// nine thousand blocks at a time.  The decoder is written uniformly - every lane runs the same control flow on the same values, which
+// the compiler keeps in scalar registers; the Huffman tables of the current deflate block live in LDS (built by the wave: canonical
+// order by one lane, the 10-bit / 9-bit look-up tables by all); a literal is one store (every lane writes the same byte to the same
+// place: no lane mask to set up); a match is copied by the lanes side by side (dst[i] = src[i mod dist]).  22-25 GB/s of text
+// (tools/ginflate_gate.hip: the measurement this was built on).  Every block's CRC-32 is summed on the device (gd_crc_kernel) and compared
+// with its trailer's; a block that does not decode, or whose CRC differs, is counted and the caller told.
+constexpr int GI_FAST_BITS = 10, GI_DFAST_BITS = 9;
+constexpr int GI_WAVES = 4;
+
+// a fast-table entry: bits 0..3 code length (0: not a short code), 4..7 extra bits, 8: literal, 9: end of block, 16..31 the literal, the
+// match length's base or the distance's base
+struct GiTables {
+    uint32_t fast[1 << GI_FAST_BITS];
+    uint32_t dfast[1 << GI_DFAST_BITS];
+    uint16_t lsym[288], dsym[32];     // symbols in canonical order
+    uint16_t lcount[16], dcount[16];
+    uint8_t len[320];
+};
+
+__device__ const uint16_t GI_LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ const uint8_t GI_LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ const uint16_t GI_DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ const uint8_t GI_DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ const uint8_t GI_CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// the bit reader: 64 bits in a register pair, refilled from the (read-only) input by 8-byte loads at byte granularity
+struct GiBits {
+    const uint8_t *p;      // next byte not yet in the buffer
+    const uint8_t *end;
+    uint64_t buf;
+    int cnt;
+    __device__ void init(const uint8_t *b, const uint8_t *e) { p = b; end = e; buf = 0; cnt = 0; }
+    __device__ inline void refill() {
+        // (reads up to 8 bytes past the block's end: the input buffer is padded)
+        uint64_t w;
+        memcpy(&w, p, 8);
+        buf |= w << cnt;
+        p += (63 - cnt) >> 3;
+        cnt |= 56;
+    }
+    __device__ inline uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1ull)); }
+    __device__ inline void drop(int n) { buf >>= n; cnt -= n; }
+    __device__ inline uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+
+// canonical order and counts of a code (one lane; n <= 288), then the fast table by all lanes.  kind 0: literal/length code, 1: distance
+// code, 2: the code-length code (entry = the symbol in bits 16.., length in bits 0..3)
+__device__ void gi_build(const uint8_t *len, int n, uint16_t *count, uint16_t *symbol, uint32_t *fast, int fast_bits, int kind, int lane) {
+    if (lane == 0) {
+        for (int l = 0; l < 16; l++) count[l] = 0;
+        for (int s = 0; s < n; s++) count[len[s]]++;
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int l = 1; l < 15; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+        for (int s = 0; s < n; s++) if (len[s]) symbol[offs[len[s]]++] = (uint16_t)s;
+    }
+    for (int i = lane; i < (1 << fast_bits); i += 64) fast[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int total = 0;
+    for (int l = 1; l < 16; l++) total += count[l];
+    for (int i = lane; i < total; i += 64) {
+        int L = 1, first = 0, index = 0;
+        while (i >= index + count[L]) { index += count[L]; first = (first + count[L]) << 1; L++; }
+        if (L > fast_bits) continue;
+        const uint32_t code = (uint32_t)(first + (i - index));
+        const uint32_t rev = __brev(code) >> (32 - L);
+        const uint32_t sym = symbol[i];
+        uint32_t e = (uint32_t)L;
+        if (kind == 2) e |= sym << 16;
+        else if (kind == 1) e |= sym < 30 ? ((uint32_t)GI_DEXT[sym] << 4) | ((uint32_t)GI_DBASE[sym] << 16) : 0xFFFF0000u;
+        else if (sym < 256) e |= 0x100u | (sym << 16);
+        else if (sym == 256) e |= 0x200u;
+        else e |= sym - 257 < 29 ? ((uint32_t)GI_LEXT[sym - 257] << 4) | ((uint32_t)GI_LBASE[sym - 257] << 16) : 0xFFFF0000u;
+        for (uint32_t j = rev; j < (1u << fast_bits); j += 1u << L) fast[j] = e;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// one symbol bit by bit along the canonical order (puff.c's decode): codes longer than the fast table's index
+__device__ inline int gi_decode_slow(GiBits &b, const uint16_t *count, const uint16_t *symbol) {
+    int code = 0, first = 0, index = 0;
+    for (int L = 1; L <= 15; L++) {
+        code |= (int)b.take(1);
+        const int c = count[L];
+        if (code - c < first) return symbol[index + (code - first)];
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+// the same entry the fast table would have held
+__device__ inline uint32_t gi_entry_slow(GiBits &b, const uint16_t *count, const uint16_t *symbol, int kind) {
+    const int sym = gi_decode_slow(b, count, symbol);
+    if (sym < 0) return 0xFFFF0000u;
+    if (kind == 2) return (uint32_t)sym << 16;
+    if (kind == 1) return sym < 30 ? ((uint32_t)GI_DEXT[sym] << 4) | ((uint32_t)GI_DBASE[sym] << 16) : 0xFFFF0000u;
+    if (sym < 256) return 0x100u | ((uint32_t)sym << 16);
+    if (sym == 256) return 0x200u;
+    return sym - 257 < 29 ? ((uint32_t)GI_LEXT[sym - 257] << 4) | ((uint32_t)GI_LBASE[sym - 257] << 16) : 0xFFFF0000u;
+}
+__device__ inline uint32_t gi_lookup(GiBits &b, const uint32_t *fast, int fast_bits, const uint16_t *count, const uint16_t *symbol, int kind) {
+    const uint32_t e = fast[b.peek(fast_bits)];
+    if (e & 15u) { b.drop((int)(e & 15u)); return e; }
+    return gi_entry_slow(b, count, symbol, kind);
+}
+
+__global__ void __launch_bounds__(64 * GI_WAVES)
+gi_inflate_kernel(const uint8_t *__restrict__ in, const tbk_ginflate_block *__restrict__ blks, const uint64_t *__restrict__ out_offs, uint32_t n_blks, uint8_t *__restrict__ out,
+                  uint32_t *__restrict__ bad) {
+    __shared__ GiTables tabs[GI_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bi = blockIdx.x * GI_WAVES + wave;
+    if (bi >= n_blks) return;
+    GiTables &T = tabs[wave];
+    const tbk_ginflate_block blk = blks[bi];
+    if (blk.out_len == 0) return;   // (the end-of-file marker: a final empty block, nothing to write)
+    GiBits b;
+    b.init(in + blk.in_off, in + blk.in_off + blk.in_len);
+    uint8_t *dst = out + out_offs[bi];
+    uint32_t pos = 0;
+    bool fail = false;
+    for (bool last = false; !last && !fail;) {
+        b.refill();
+        last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {  // stored
+            b.drop(b.cnt & 7);
+            // un-read the whole bytes still in the buffer
+            b.p -= b.cnt >> 3; b.buf = 0; b.cnt = 0;
+            if (b.p + 4 > b.end) { fail = true; break; }
+            const uint32_t n = b.p[0] | ((uint32_t)b.p[1] << 8);
+            b.p += 4;
+            if (b.p + n > b.end || pos + n > blk.out_len) { fail = true; break; }
+            for (uint32_t i = lane; i < n; i += 64) dst[pos + i] = b.p[i];
+            pos += n; b.p += n;
+            continue;
+        }
+        if (type == 3) { fail = true; break; }
+        int nlit = 288, ndist = 30;
+        if (type == 1) {
+            for (int i = lane; i < 288; i += 64) T.len[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            if (lane < 30) T.len[288 + lane] = 5;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            nlit = (int)b.take(5) + 257; ndist = (int)b.take(5) + 1;
+            const int ncl = (int)b.take(4) + 4;
+            // the code-length code: lengths into T.len[0..19), its tables into the dist tables' space (built before those)
+            if (lane < 19) T.len[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int i = 0; i < ncl; i++) { if (b.cnt < 3) b.refill(); const uint32_t v = b.take(3); if (lane == 0) T.len[GI_CLORD[i]] = (uint8_t)v; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            gi_build(T.len, 19, T.dcount, T.dsym, T.dfast, 7, 2, lane);
+            uint8_t prev = 0;
+            int i = 0;
+            const int want = nlit + ndist;
+            while (i < want && !fail) {
+                b.refill();
+                const uint32_t e = gi_lookup(b, T.dfast, 7, T.dcount, T.dsym, 2);
+                const int sym = (int)(e >> 16);
+                if (sym > 18) { fail = true; break; }
+                if (sym < 16) { if (lane == 0) T.len[i] = (uint8_t)sym; prev = (uint8_t)sym; i++; continue; }
+                int rep; uint8_t val = 0;
+                if (sym == 16) { val = prev; rep = 3 + (int)b.take(2); }
+                else if (sym == 17) rep = 3 + (int)b.take(3);
+                else rep = 11 + (int)b.take(7);
+                if (i + rep > want) { fail = true; break; }
+                for (int r = lane; r < rep; r += 64) T.len[i + r] = val;
+                i += rep; prev = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (fail) break;
+        }
+        gi_build(T.len, nlit, T.lcount, T.lsym, T.fast, GI_FAST_BITS, 0, lane);
+        gi_build(T.len + nlit, ndist, T.dcount, T.dsym, T.dfast, GI_DFAST_BITS, 1, lane);
+        // ---- the symbols ----
+        for (;;) {
+            if (b.cnt < 32) { if (b.p > b.end + 8) { fail = true; break; } b.refill(); }   // (a corrupt stream must not walk out of its input)
+            uint32_t e = gi_lookup(b, T.fast, GI_FAST_BITS, T.lcount, T.lsym, 0);
+            if (e & 0x100u) {   // a literal: every lane stores the same byte to the same place (no lane mask to set up)
+                if (pos >= blk.out_len) { fail = true; break; }
+                dst[pos++] = (uint8_t)(e >> 16);
+                continue;
+            }
+            if (e & 0x200u) break;   // end of block
+            if ((e >> 16) == 0xFFFFu) { fail = true; break; }
+            if (b.cnt < 32) b.refill();
+            const uint32_t len = (e >> 16) + b.take((int)((e >> 4) & 15u));
+            const uint32_t d = gi_lookup(b, T.dfast, GI_DFAST_BITS, T.dcount, T.dsym, 1);
+            if ((d >> 16) == 0xFFFFu) { fail = true; break; }
+            if (b.cnt < 16) b.refill();
+            const uint32_t dist = (d >> 16) + b.take((int)((d >> 4) & 15u));
+            if (dist > pos || pos + len > blk.out_len) { fail = true; break; }
+            // the lanes copy side by side; a match that overlaps itself repeats its first `dist` bytes
+            const uint8_t *src = dst + pos - dist;
+            if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[pos + i] = src[i]; }
+            else { for (uint32_t i = lane; i < len; i += 64) dst[pos + i] = src[i % dist]; }
+            pos += len;
+        }
+    }
+    if ((fail || pos != blk.out_len) && lane == 0) atomicAdd(bad, 1u);
+}
+
+
+// expected CRC-32s against the ones summed from the inflated text
+__global__ void __launch_bounds__(GD_T)
+gi_check_kernel(const tbk_ginflate_block *__restrict__ blks, const uint32_t *__restrict__ crc, uint32_t n_blks, uint32_t *__restrict__ bad) {
+    const uint32_t i = blockIdx.x * GD_T + threadIdx.x;
+    if (i < n_blks && blks[i].out_len && crc[i] != blks[i].crc) atomicAdd(bad + 1, 1u);
+}
+
+namespace {
+struct GiSlot {
+    PinBuf h_in, h_out, h_blocks, h_members, h_offs, h_bad;
+    DevBuf d_in, d_out, d_blocks, d_members, d_offs, d_crc, d_bad;
+    hipEvent_t done = nullptr;
+    size_t out_bytes = 0;
+    bool busy = false;
+    void drop() {
+        h_in.drop(); h_out.drop(); h_blocks.drop(); h_members.drop(); h_offs.drop(); h_bad.drop();
+        d_in.drop(); d_out.drop(); d_blocks.drop(); d_members.drop(); d_offs.drop(); d_crc.drop(); d_bad.drop();
+        if (done) (void)hipEventDestroy(done);
+    }
+};
+}  // namespace
+
+struct tbk_ginflate {
+    int device = 0;
+    hipStream_t stream = nullptr, stream_in = nullptr, stream_out = nullptr;
+    hipEvent_t in_done = nullptr, k_done = nullptr;
+    GdX2n x2n = gd_x2n_table();
+    GdCrcTabs *d_crc_tabs = nullptr;
+    GiSlot slots[TBK_GINFLATE_SLOTS];
+    uint64_t blocks = 0, text_bytes = 0;
+};
+
+int tbk_ginflate_create(int device, tbk_ginflate **out) {
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); tbk_set_error_(TBK_ERR_NO_DEVICE, "GPU inflater: no such device"); return TBK_ERR_NO_DEVICE; }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    tbk_ginflate *g = new tbk_ginflate();
+    g->device = device;
+    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_out, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->in_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->k_done, hipEventDisableTiming);
+    for (GiSlot &s : g->slots) if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        GdCrcTabs tabs;
+        for (uint32_t j = 0; j < 128; j++) { tabs.lo[j] = gd_x2nmodp(g->x2n, j, 3 + 6); tabs.hi[j] = gd_x2nmodp(g->x2n, j, 3 + 6 + 7); }
+        e = hipMalloc((void **)&g->d_crc_tabs, sizeof tabs);
+        if (e == hipSuccess) e = hipMemcpy(g->d_crc_tabs, &tabs, sizeof tabs, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { tbk_ginflate_destroy(g); return gfail(TBK_ERR_HIP, "GPU inflater setup", e); }
+    *out = g;
+    return TBK_OK;
+}
+
+void tbk_ginflate_destroy(tbk_ginflate *g) {
+    if (!g) return;
+    if (hipSetDevice(g->device) == hipSuccess) {
+        for (hipStream_t s : {g->stream, g->stream_in, g->stream_out}) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+        for (GiSlot &s : g->slots) s.drop();
+        if (g->in_done) (void)hipEventDestroy(g->in_done);
+        if (g->k_done) (void)hipEventDestroy(g->k_done);
+        if (g->d_crc_tabs) (void)hipFree(g->d_crc_tabs);
+    }
+    delete g;
+}
+
+// The slot's pinned buffer for `bytes` of deflated input (the caller copies the window's blocks into it, back to back or as they lie in
+// the file), or NULL.
+uint8_t *tbk_ginflate_input(tbk_ginflate *g, int slot, size_t bytes) {
+    if (!g || slot < 0 || slot >= TBK_GINFLATE_SLOTS || hipSetDevice(g->device) != hipSuccess) return nullptr;
+    GiSlot &s = g->slots[slot];
+    if (s.h_in.need(bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (uint8_t *)s.h_in.p;
+}
+
+// Queue a window: blocks[i] = where block i's raw deflate stream lies in the slot's input (in_off, in_len), how much text it makes and
+// the CRC-32 its trailer names.  The text of the blocks lies back to back in the slot's output, `head` bytes into it (room in front for
+// what the parser has left of the window before).  Asynchronous: tbk_ginflate_wait collects.
+int tbk_ginflate_submit(tbk_ginflate *g, int slot, size_t in_bytes, const tbk_ginflate_block *blocks, size_t n_blocks, size_t head) {
+    if (!g || slot < 0 || slot >= TBK_GINFLATE_SLOTS || !blocks || !n_blocks) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: bad argument"); return TBK_ERR_INVALID; }
+    hipError_t e = hipSetDevice(g->device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    GiSlot &s = g->slots[slot];
+    if (s.busy) { tbk_set_error_(TBK_ERR_STATE, "GPU inflater: the slot is in flight"); return TBK_ERR_STATE; }
+    if (n_blocks > 0x7FFFFFF0ull / 1) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: too many blocks"); return TBK_ERR_INVALID; }
+    uint64_t out_total = 0;
+    e = s.h_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
+    if (e == hipSuccess) e = s.h_members.need((n_blocks + 1) * sizeof(GdMember));
+    if (e == hipSuccess) e = s.h_offs.need((n_blocks + 1) * 8);
+    if (e == hipSuccess) e = s.h_bad.need(64);
+    if (e != hipSuccess) return gfail(TBK_ERR_NOMEM, "GPU inflater buffers", e);
+    memcpy(s.h_blocks.p, blocks, n_blocks * sizeof(tbk_ginflate_block));
+    GdMember *hm = (GdMember *)s.h_members.p;
+    uint64_t *offs = (uint64_t *)s.h_offs.p;
+    uint32_t longest = 0;
+    for (size_t i = 0; i < n_blocks; i++) {
+        if (blocks[i].out_len > 65536u || (uint64_t)blocks[i].in_off + blocks[i].in_len > in_bytes) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: a block outside its window"); return TBK_ERR_INVALID; }
+        offs[i] = out_total;
+        hm[i] = GdMember{out_total, 0, blocks[i].out_len, 0};
+        longest = std::max(longest, blocks[i].out_len);
+        out_total += blocks[i].out_len;
+    }
+    s.out_bytes = out_total;
+    e = s.d_in.need(in_bytes + 64);
+    if (e == hipSuccess) e = s.d_out.need(out_total + 64);
+    if (e == hipSuccess) e = s.d_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
+    if (e == hipSuccess) e = s.d_members.need((n_blocks + 1) * sizeof(GdMember));
+    if (e == hipSuccess) e = s.d_offs.need((n_blocks + 1) * 8);
+    if (e == hipSuccess) e = s.d_crc.need((n_blocks + 1) * 4);
+    if (e == hipSuccess) e = s.d_bad.need(64);
+    if (e == hipSuccess) e = s.h_out.need(head + out_total + 64);
+    if (e != hipSuccess) return gfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "GPU inflater buffers", e);
+    e = hipMemcpyAsync(s.d_in.p, s.h_in.p, in_bytes, hipMemcpyHostToDevice, g->stream_in);
+    if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)s.d_in.p + in_bytes, 0, 64, g->stream_in);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.d_blocks.p, s.h_blocks.p, n_blocks * sizeof(tbk_ginflate_block), hipMemcpyHostToDevice, g->stream_in);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.d_members.p, s.h_members.p, n_blocks * sizeof(GdMember), hipMemcpyHostToDevice, g->stream_in);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.d_offs.p, s.h_offs.p, n_blocks * 8, hipMemcpyHostToDevice, g->stream_in);
+    if (e == hipSuccess) e = hipEventRecord(g->in_done, g->stream_in);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->in_done, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_bad.p, 0, 64, g->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(s.d_crc.p, 0, (n_blocks + 1) * 4, g->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(gi_inflate_kernel, dim3((unsigned)((n_blocks + GI_WAVES - 1) / GI_WAVES)), dim3(64 * GI_WAVES), 0, g->stream, (const uint8_t *)s.d_in.p,
+                           (const tbk_ginflate_block *)s.d_blocks.p, (const uint64_t *)s.d_offs.p, (uint32_t)n_blocks, (uint8_t *)s.d_out.p, (uint32_t *)s.d_bad.p);
+        // the blocks' CRC-32s: gd_crc_kernel over (block = member); blockIdx.y is limited to 65535: in turns
+        for (size_t first = 0; first < n_blocks; first += 65535) {
+            const size_t nb = std::min<size_t>(65535, n_blocks - first);
+            hipLaunchKernelGGL(gd_crc_kernel, dim3((unsigned)std::max<uint64_t>(1, (((uint64_t)longest + 63) / 64 + GD_T - 1) / GD_T), (unsigned)nb), dim3(GD_T), 0, g->stream, (const uint8_t *)s.d_out.p,
+                               (const GdMember *)s.d_members.p + first, (const GdCrcTabs *)g->d_crc_tabs, g->x2n, (uint32_t *)s.d_crc.p + first);
+        }
+        hipLaunchKernelGGL(gi_check_kernel, dim3((unsigned)((n_blocks + GD_T - 1) / GD_T)), dim3(GD_T), 0, g->stream, (const tbk_ginflate_block *)s.d_blocks.p, (const uint32_t *)s.d_crc.p,
+                           (uint32_t)n_blocks, (uint32_t *)s.d_bad.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(g->k_done, g->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream_out, g->k_done, 0);
+    if (e == hipSuccess && out_total) e = hipMemcpyAsync((uint8_t *)s.h_out.p + head, s.d_out.p, out_total, hipMemcpyDeviceToHost, g->stream_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.h_bad.p, s.d_bad.p, 8, hipMemcpyDeviceToHost, g->stream_out);
+    if (e == hipSuccess) e = hipEventRecord(s.done, g->stream_out);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "GPU inflater submit", e);
+    s.busy = true;
+    g->blocks += n_blocks; g->text_bytes += out_total;
+    return TBK_OK;
+}
+
+// The window's text (`head` bytes into the slot's pinned output; valid until the slot's next tbk_ginflate_input); *bad = blocks that did
+// not decode to their length + blocks whose CRC-32 differs from their trailer's.
+int tbk_ginflate_wait(tbk_ginflate *g, int slot, uint8_t **out_base, size_t *text_bytes, uint32_t *bad) {
+    if (!g || slot < 0 || slot >= TBK_GINFLATE_SLOTS) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: bad argument"); return TBK_ERR_INVALID; }
+    GiSlot &s = g->slots[slot];
+    if (!s.busy) { tbk_set_error_(TBK_ERR_STATE, "GPU inflater: nothing in flight in the slot"); return TBK_ERR_STATE; }
+    const hipError_t e = hipEventSynchronize(s.done);
+    s.busy = false;
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "GPU inflater wait", e);
+    const uint32_t *b = (const uint32_t *)s.h_bad.p;
+    if (out_base) *out_base = (uint8_t *)s.h_out.p;
+    if (text_bytes) *text_bytes = s.out_bytes;
+    if (bad) *bad = b[0] + b[1];
+    return TBK_OK;
+}
+
 uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp
 
 // C-ABI (include/tbk.h): n_members pieces of text -> as many gzip members, coded on `device`, one job, synchronously.  text holds the
@@ -1144,4 +1517,48 @@ extern "C" int tbk_gzip_bench_device(int device, const char *text, const uint64_
     *kernels_s = ms * 1e-3;
     *out_bytes = bytes;
     return TBK_OK;
+}
+
+// C-ABI (include/tbk.h): a whole bgzf file (or a run of its blocks) in host memory -> its text, inflated on `device`, one window,
+// synchronously.  What tests and tools call; the reader drives the same inflater three windows deep.  *text_len = bytes of text (also
+// when dst is too small: TBK_ERR_NOMEM); bytes that are not a bgzf block (an ordinary gzip member, garbage) end the run with
+// TBK_ERR_FORMAT; a block that does not decode or fails its CRC-32: TBK_ERR_FORMAT too.
+extern "C" int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint8_t *dst, uint64_t cap, uint64_t *text_len) {
+    if ((!data && size) || !text_len) { tbk_set_error_(TBK_ERR_INVALID, "tbk_bgzf_inflate_device: NULL argument"); return TBK_ERR_INVALID; }
+    *text_len = 0;
+    std::vector<tbk_ginflate_block> blocks;
+    uint64_t p = 0, out_total = 0;
+    while (p < size) {
+        if (data[p] == 0 && !blocks.empty()) { p++; continue; }   // zero padding between members (Python's gzip skips it too)
+        if (size - p < 18 || data[p] != 0x1f || data[p + 1] != 0x8b || data[p + 2] != 8 || !(data[p + 3] & 4)) { tbk_set_error_(TBK_ERR_FORMAT, "not a BGZF block"); return TBK_ERR_FORMAT; }
+        const uint64_t xlen = data[p + 10] | ((uint64_t)data[p + 11] << 8);
+        if (xlen < 6 || data[p + 12] != 'B' || data[p + 13] != 'C' || data[p + 14] != 2 || data[p + 15] != 0) { tbk_set_error_(TBK_ERR_FORMAT, "not a BGZF block"); return TBK_ERR_FORMAT; }
+        const uint64_t bs = ((uint64_t)data[p + 16] | ((uint64_t)data[p + 17] << 8)) + 1, hdr = 12 + xlen;
+        if (bs < 26 || hdr + 8 > bs || p + bs > size) { tbk_set_error_(TBK_ERR_FORMAT, "corrupt BGZF block"); return TBK_ERR_FORMAT; }
+        const uint8_t *b = data + p;
+        const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
+        const uint32_t isize = (uint32_t)b[bs - 4] | ((uint32_t)b[bs - 3] << 8) | ((uint32_t)b[bs - 2] << 16) | ((uint32_t)b[bs - 1] << 24);
+        if (isize > (1u << 16)) { tbk_set_error_(TBK_ERR_FORMAT, "corrupt BGZF block"); return TBK_ERR_FORMAT; }
+        blocks.push_back(tbk_ginflate_block{p + hdr, (uint32_t)(bs - hdr - 8), isize, crc, 0});
+        out_total += isize;
+        p += bs;
+    }
+    *text_len = out_total;
+    if (blocks.empty()) return TBK_OK;
+    tbk_ginflate *g = nullptr;
+    int rc = tbk_ginflate_create(device, &g);
+    if (rc) return rc;
+    uint8_t *in = tbk_ginflate_input(g, 0, (size_t)size);
+    if (!in) { tbk_ginflate_destroy(g); tbk_set_error_(TBK_ERR_NOMEM, "GPU inflater: no pinned memory for the input"); return TBK_ERR_NOMEM; }
+    memcpy(in, data, (size_t)size);
+    rc = tbk_ginflate_submit(g, 0, (size_t)size, blocks.data(), blocks.size(), 0);
+    uint8_t *text = nullptr;
+    size_t n = 0;
+    uint32_t bad = 0;
+    if (!rc) rc = tbk_ginflate_wait(g, 0, &text, &n, &bad);
+    if (!rc && bad) { tbk_set_error_(TBK_ERR_FORMAT, "inflate: corrupt BGZF block"); rc = TBK_ERR_FORMAT; }
+    if (!rc && (n > cap || !dst)) { if (n) { tbk_set_error_(TBK_ERR_NOMEM, "tbk_bgzf_inflate_device: dst too small"); rc = TBK_ERR_NOMEM; } }
+    if (!rc && n) memcpy(dst, text, n);
+    tbk_ginflate_destroy(g);
+    return rc;
 }

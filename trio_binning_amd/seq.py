@@ -386,3 +386,19 @@ def gzip_members_device(pieces, device: int = 0):
         out.append(C.string_at(C.addressof(buf) + at, out_lens[i]))
         at += out_lens[i]
     return out
+
+
+def bgzf_inflate_device(data: bytes, device: int = 0) -> bytes:
+    """The text of a bgzf file (bytes), inflated on the GPU (``tbk_bgzf_inflate_device``: the reader's bgzf path by itself)."""
+    import ctypes as C
+
+    from ._lib import check, lib
+
+    n = C.c_uint64()
+    status = lib.tbk_bgzf_inflate_device(device, data, len(data), None, 0, C.byref(n))
+    if n.value == 0:
+        check(status)
+        return b""
+    buf = C.create_string_buffer(n.value)
+    check(lib.tbk_bgzf_inflate_device(device, data, len(data), buf, n.value, C.byref(n)))
+    return C.string_at(C.addressof(buf), n.value)
