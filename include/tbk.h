@@ -411,6 +411,11 @@ int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, 
  * nobody reads the batch a second time.  tbk_fastx_batch_packed hands the arrays out (*codes = NULL when the
  * batch carries none); they stay valid until the batch is refilled or destroyed. */
 int tbk_fastx_set_packing(tbk_fastx_reader *r, int on);
+/* BGZF input (bgzip / htslib: independent gzip members of <= 64 KiB, which the reference reads through gzip.open like any .gz,
+ * seq.py:86-92) inflated on `device` - csrc/tbk_gdeflate.hip: one wave per block, CRC-32s checked there - instead of on the host's
+ * threads.  Before the first read; other inputs are read as before.  tbk_fastx_inflates_on_device: 1 when that is what happens. */
+int tbk_fastx_set_device(tbk_fastx_reader *r, int device);
+int tbk_fastx_inflates_on_device(const tbk_fastx_reader *r);
 int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, const uint32_t **exc_chunk, const uint16_t **exc_mask,
                            uint64_t *n_exc);
 /* on != 0 (and packing on): batches taken from a plain FASTQ file by the chunk-parallel scan do not copy their

@@ -113,3 +113,68 @@ def test_fuzz_against_zlib(gpu, seed):
                           [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED][int(rng.integers(0, 5))], eof=bool(rng.integers(0, 2))))
         want.append(t)
     assert seq.bgzf_inflate_device(b"".join(parts)) == b"".join(want)
+
+
+def test_reader_and_cli_from_bgzf_on_the_device(gpu, capfd, tmp_path, monkeypatch):
+    """The reader's BGZF path on the GPU (tbk_fastx_set_device): the records of a .fastq.gz written as BGZF come out as from the
+    plain file, over many small windows (TBK_BGZF_GPU_WINDOW: the three-slot ring turns over, windows end between blocks, the
+    end-of-file block is a window of its own), with an ordinary gzip member behind the blocks (the host path takes over there);
+    and classify-by-kmers on it writes the reference's recorded TSV and bins."""
+    import hashlib
+    from unittest.mock import patch
+
+    import trio_binning_amd.classify_by_kmers as cbk
+    from conftest import load_golden
+    from trio_binning_amd import seq
+
+    rng = np.random.default_rng(8)
+    text = fastq(rng, 300, 4000)
+    plain = tmp_path / "r.fastq"
+    plain.write_bytes(text)
+
+    def records(path, **kw):
+        out = []
+        with seq.BatchReader(str(path), **kw) as r:
+            on_device = r.inflates_on_device
+            b = seq.Batch()
+            while r.next_batch(b, 200_000, 0):
+                out += [(x.name, x.seq, x.qual) for x in b.reads()]
+        return out, on_device
+
+    want, _ = records(plain)
+    assert len(want) == 300
+    monkeypatch.setenv("TBK_BGZF_GPU_WINDOW", "70000")
+    for name, data in (("blocks", bgzf(text, 6, 20000)), ("no_eof", bgzf(text, 1, 65280, eof=False)),
+                       ("member_behind", bgzf(text[:1_000_000], 6, 30000, eof=False) + gzip.compress(text[1_000_000:]))):
+        path = tmp_path / f"{name}.fastq.gz"
+        path.write_bytes(data)
+        got, on_device = records(path, device=0)
+        assert on_device and got == want, name
+        got_cpu, on_device = records(path)
+        assert not on_device and got_cpu == want, name
+    # a damaged block: the run fails, it does not go on with wrong text
+    bad = bytearray(bgzf(text, 6, 20000))
+    bad[len(bad) // 2] ^= 0x20
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises(Exception):
+        records(tmp_path / "bad.fastq.gz", device=0)
+
+    # the command line: the reference's recorded output from a BGZF copy of the golden reads
+    v = next(x for x in load_golden("diff_vectors.json") if x["k"] == 21)
+    fa, fb = tmp_path / "la.txt", tmp_path / "lb.txt"
+    fa.write_text("".join(x + "\n" for x in v["list_a"]))
+    fb.write_text("".join(x + "\n" for x in v["list_b"]))
+    fq = tmp_path / "reads21.fa.gz"
+    fq.write_bytes(bgzf("".join(f">r{i} some comment\n{s}\n" for i, s in enumerate(v["reads"])).encode(), 6, 3000))
+    monkeypatch.setenv("TBK_BGZF_GPU_WINDOW", "8000")
+    monkeypatch.setenv("TBK_WRITE_TIMING", "1")
+    od = tmp_path / "out"
+    od.mkdir()
+    with patch("sys.argv", ["classify-by-kmers", str(fq), str(fa), str(fb), "--haplotype-a-out-prefix", str(od / "hapA"),
+                            "--haplotype-b-out-prefix", str(od / "hapB"), "--unclassified-out-prefix", str(od / "unclassified")]):
+        cbk.main()
+    out, err = capfd.readouterr()
+    assert out == v["cli_stdout"]
+    for fn, digest in v["cli_bins"].items():
+        assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
+    assert "tbk-gpu-bgzf" in err and " 0 windows" not in err, err[-500:]

@@ -202,6 +202,9 @@ if hasattr(lib, "tbk_gzip_members_device"):
     _sig("tbk_bin_writer_use_device", C.c_int, _vp, C.c_int)
     _sig("tbk_bin_writer_encoder", C.c_int, _vp)
     _sig("tbk_gzip_members_device", C.c_int, C.c_int, C.c_char_p, _u64p, _u64, C.c_char_p, _u64, _u64p, _u64p)
+    if hasattr(lib, "tbk_fastx_set_device"):
+        _sig("tbk_fastx_set_device", C.c_int, _vp, C.c_int)
+        _sig("tbk_fastx_inflates_on_device", C.c_int, _vp)
     if hasattr(lib, "tbk_bgzf_inflate_device"):
         _sig("tbk_bgzf_inflate_device", C.c_int, C.c_int, C.c_char_p, _u64, C.c_char_p, _u64, _u64p)
     if hasattr(lib, "tbk_gzip_bench_device"):

@@ -114,6 +114,12 @@ struct LineSource {
     // by side.  Same bytes as the sequential path; taken while every member at hand is such a block.
     bool bgzf = false;
     bool bgzf_seen = false;  // a BGZF member has been read: zero padding may follow it (Python's GzipFile skips it)
+    // BGZF blocks inflated on the GPU (tbk_fastx_set_device; csrc/tbk_gdeflate.hip, second half): one wave per block, windows of
+    // 256 MB of the file three deep.  -1: on the host's threads.
+    int gpu_device = -1;
+    bool gpu_slot_free[TBK_GINFLATE_SLOTS] = {true, true, true};
+    uint64_t gpu_windows = 0, gpu_blocks = 0;
+    double gpu_stage_s = 0, gpu_wait_s = 0;
     int threads = 1;
     // Ordinary gzip streams go through the library's own DEFLATE decoder (tbk_inflate.h) on the
     // memory-mapped file: about twice zlib's speed on FASTQ, and that stream is what a run on .gz
@@ -187,7 +193,9 @@ struct LineSource {
     // output in front of the write position), and hands the text over in chunks: inflating and
     // parsing then overlap instead of taking turns.
     // A chunk owns the buffer it was inflated into: [ up to 32 KiB of the text before it | new text ].
-    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; };
+    // (ext / slot: the text lies in a pinned output buffer of the GPU inflater instead of `data`; the slot is the inflater's again once
+    // the parser has taken the text over)
+    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; const uint8_t *ext = nullptr; int slot = -1; };
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -227,6 +235,127 @@ struct LineSource {
             c.off = 0; c.len = text_len; c.last = at_end;
             push(std::move(c));
             if (at_end) return;
+        }
+    }
+    // The blocks of the mapped file from byte `from` on, as many as lie within `span_want` bytes: their deflate streams (relative to
+    // `from`), text lengths and CRC-32s.  *span = bytes of whole blocks (and padding) walked.  Returns -1 for a corrupt block.
+    int bgzf_scan(size_t from, size_t span_want, std::vector<tbk_ginflate_block> &blks, size_t *span, size_t *out_total) {
+        const uint8_t *zbase = map + from;
+        const size_t avail = map_size - from;
+        size_t p = 0;
+        *out_total = 0;
+        while (p < avail && p < span_want) {
+            if (bgzf_seen && zbase[p] == 0) { p++; continue; }  // zero padding between members
+            const size_t bs = bgzf_block_size(zbase + p, avail - p);
+            if (bs == 0) break;                                  // not a BGZF block (an ordinary member, or the file is cut off)
+            if (bs < 26) { err = "corrupt BGZF block"; return -1; }
+            if (p + bs > avail) break;
+            const uint8_t *b = zbase + p;
+            const size_t xlen = b[10] | ((size_t)b[11] << 8), hdr = 12 + xlen;
+            if (hdr + 8 > bs) { err = "corrupt BGZF block"; return -1; }
+            const uint32_t crc = (uint32_t)b[bs - 8] | ((uint32_t)b[bs - 7] << 8) | ((uint32_t)b[bs - 6] << 16) | ((uint32_t)b[bs - 5] << 24);
+            const uint32_t isize = (uint32_t)b[bs - 4] | ((uint32_t)b[bs - 3] << 8) | ((uint32_t)b[bs - 2] << 16) | ((uint32_t)b[bs - 1] << 24);
+            if (isize > (1u << 16)) { err = "corrupt BGZF block"; return -1; }
+            blks.push_back(tbk_ginflate_block{(uint64_t)(p + hdr), (uint32_t)(bs - hdr - 8), isize, crc, 0});
+            *out_total += isize;
+            p += bs;
+            bgzf_seen = true;
+        }
+        *span = p;
+        return 0;
+    }
+    // BGZF on the GPU: windows of the mapped file (TBK_BGZF_GPU_WINDOW bytes, default 256 MB: ~9000 blocks, one wave each - what fills
+    // the chip) are copied into the inflater's pinned input by a few threads, inflated and CRC-checked on the device, and their text
+    // comes back into pinned memory, from where the parser takes it.  Three windows deep: one is staged while one is on the device and
+    // one is with the parser.  Anything that is not a BGZF block (an ordinary member behind the blocks), and any failure to set the
+    // inflater up, hands over to the host path exactly where bgzf_loop would be.
+    void bgzf_loop_gpu() {
+        tbk_ginflate *g = nullptr;
+        if (tbk_ginflate_create(gpu_device, &g) != TBK_OK) { bgzf_loop(); return; }
+        struct Guard {
+            tbk_ginflate *g; LineSource *me;
+            ~Guard() {
+                tbk_ginflate_destroy(g);
+                if (getenv("TBK_PINFLATE_TIMING") || getenv("TBK_WRITE_TIMING"))
+                    fprintf(stderr, "tbk-gpu-bgzf %llu windows, %llu blocks inflated on device %d; the worker: staging %.3f s, waiting for the device %.3f s\n",
+                            (unsigned long long)me->gpu_windows, (unsigned long long)me->gpu_blocks, me->gpu_device, me->gpu_stage_s, me->gpu_wait_s);
+            }
+        } guard{g, this};
+        const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)256 << 20));
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        int in_flight = -1;   // the slot whose window is on the device
+        bool flight_last = false;
+        auto fail_with = [&](const std::string &msg) { Chunk c; c.err = msg; c.last = true; push(std::move(c)); };
+        // the window in flight -> the parser
+        auto collect = [&]() -> bool {
+            if (in_flight < 0) return true;
+            uint8_t *base = nullptr;
+            size_t n = 0;
+            uint32_t bad = 0;
+            const double t0 = now();
+            const int rc = tbk_ginflate_wait(g, in_flight, &base, &n, &bad);
+            gpu_wait_s += now() - t0;
+            if (rc) { fail_with(std::string("inflate: ") + tbk_last_error()); return false; }
+            if (bad) { fail_with("inflate: corrupt BGZF block"); return false; }
+            Chunk c;
+            c.ext = base; c.off = 0; c.len = n; c.slot = in_flight; c.last = flight_last;
+            in_flight = -1;
+            push(std::move(c));
+            return true;
+        };
+        int next_slot = 0;
+        for (;;) {
+            { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
+            std::vector<tbk_ginflate_block> blks;
+            size_t span = 0, out_total = 0;
+            if (bgzf_scan(bgzf_map_pos, window, blks, &span, &out_total) < 0) { if (!collect()) return; fail_with(err); return; }
+            const bool at_end = bgzf_map_pos + span >= map_size;
+            if (blks.empty()) {
+                if (!collect()) return;
+                if (at_end) { Chunk c; c.last = true; push(std::move(c)); return; }
+                if (span > 0) { bgzf_map_pos += span; continue; }   // only padding: drop it and look again
+                if (map_size - bgzf_map_pos >= 18 && bgzf_block_size(map + bgzf_map_pos, map_size - bgzf_map_pos) == 0) {
+                    // an ordinary gzip member follows: the sequential path reads the file itself, from here (as bgzf_window hands over)
+                    if (lseek(fd, (off_t)bgzf_map_pos, SEEK_SET) < 0) { fail_with(std::string("lseek: ") + strerror(errno)); return; }
+                    zin_pos = zin_end = 0; raw_eof = false;
+                    Chunk c; c.fallback = true; push(std::move(c));
+                    return;
+                }
+                fail_with("truncated gzip file");
+                return;
+            }
+            if (out_total == 0) { bgzf_map_pos += span; if (at_end) { if (!collect()) return; Chunk c; c.last = true; push(std::move(c)); return; } continue; }   // only empty blocks (the end-of-file marker)
+            // a slot the parser has given back
+            const int slot = next_slot;
+            next_slot = (next_slot + 1) % TBK_GINFLATE_SLOTS;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || gpu_slot_free[slot]; });
+                if (stop) return;
+                gpu_slot_free[slot] = false;
+            }
+            const double t0 = now();
+            uint8_t *in = tbk_ginflate_input(g, slot, span);
+            if (!in) { if (!collect()) return; fail_with("inflate: no pinned memory for a BGZF window"); return; }
+            {
+                const int nt = std::min(4, std::max(1, threads));
+                std::vector<std::thread> pool;
+                const uint8_t *from = map + bgzf_map_pos;
+                for (int t = 0; t < nt; t++) {
+                    const size_t lo = span * (size_t)t / nt, hi = span * (size_t)(t + 1) / nt;
+                    pool.emplace_back([=] { memcpy(in + lo, from + lo, hi - lo); });
+                }
+                for (std::thread &th : pool) th.join();
+                (void)madvise((void *)(((uintptr_t)from + 4095) & ~(uintptr_t)4095), span > 8192 ? span - 8192 : 0, MADV_DONTNEED);   // (read once)
+            }
+            gpu_stage_s += now() - t0;
+            if (tbk_ginflate_submit(g, slot, span, blks.data(), blks.size(), 0) != TBK_OK) { const std::string m = std::string("inflate: ") + tbk_last_error(); if (!collect()) return; fail_with(m); return; }
+            gpu_windows++; gpu_blocks += blks.size();
+            // the window before this one has had this one's staging time on the device: hand it on
+            if (!collect()) return;
+            in_flight = slot; flight_last = at_end;
+            bgzf_map_pos += span;
+            if (at_end) { (void)collect(); return; }
         }
     }
     void inflate_loop() {
@@ -460,7 +589,7 @@ struct LineSource {
     }
     // own decoder: returns like refill()
     bool refill_fast() {
-        if (!started) { started = true; worker = std::thread([this] { if (bgzf) bgzf_loop(); else if (guessing()) pinflate_loop(); else inflate_loop(); }); }
+        if (!started) { started = true; worker = std::thread([this] { if (bgzf && gpu_device >= 0 && map) bgzf_loop_gpu(); else if (bgzf) bgzf_loop(); else if (guessing()) pinflate_loop(); else inflate_loop(); }); }
         Chunk c;
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -481,8 +610,27 @@ struct LineSource {
             if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
             if (buf.size() - end < c.len) buf.resize(end + c.len + ((size_t)1 << 20));
         }
-        if (c.len) memcpy(buf.data() + end, c.data.data() + c.off, c.len);
+        if (c.len) {
+            const uint8_t *from = (c.ext ? c.ext : c.data.data()) + c.off;
+            // (a GPU window is half a gigabyte of text: a few threads copy it)
+            const int nt = c.len >= ((size_t)64 << 20) ? std::min(4, std::max(1, threads)) : 1;
+            if (nt == 1) memcpy(buf.data() + end, from, c.len);
+            else {
+                std::vector<std::thread> pool;
+                uint8_t *to = buf.data() + end;
+                for (int t = 0; t < nt; t++) {
+                    const size_t lo = c.len * (size_t)t / nt, hi = c.len * (size_t)(t + 1) / nt;
+                    pool.emplace_back([=] { memcpy(to + lo, from + lo, hi - lo); });
+                }
+                for (std::thread &th : pool) th.join();
+            }
+        }
         end += c.len;
+        if (c.slot >= 0) {
+            std::lock_guard<std::mutex> lk(mu);
+            gpu_slot_free[c.slot] = true;
+            cv.notify_all();
+        }
         if (c.last) text_eof = true;
         if (!c.data.empty()) {
             std::lock_guard<std::mutex> lk(mu);
@@ -1313,6 +1461,19 @@ extern "C" int tbk_fastx_set_packing(tbk_fastx_reader *r, int on) {
     r->packing = on != 0;
     return TBK_OK;
 }
+
+// BGZF input from here on is inflated on `device` (before the first tbk_fastx_next; a file that is not BGZF, or not mapped, is read as
+// before).  TBK_BGZF_INFLATE=cpu keeps the host's threads.
+extern "C" int tbk_fastx_set_device(tbk_fastx_reader *r, int device) {
+    if (!r) return ffail(TBK_ERR_INVALID, "NULL argument");
+    const char *how = getenv("TBK_BGZF_INFLATE");
+    if (how && strcmp(how, "cpu") == 0) return TBK_OK;
+    if (r->src.started) return ffail(TBK_ERR_STATE, "tbk_fastx_set_device after the first read");
+    r->src.gpu_device = device;
+    return TBK_OK;
+}
+// 1 when the reader's BGZF blocks are (being) inflated on a device
+extern "C" int tbk_fastx_inflates_on_device(const tbk_fastx_reader *r) { return r && r->src.bgzf && r->src.gpu_device >= 0 && r->src.map ? 1 : 0; }
 
 extern "C" int tbk_fastx_set_borrowing(tbk_fastx_reader *r, int on) {
     if (!r) return ffail(TBK_ERR_INVALID, "NULL argument");

@@ -96,6 +96,11 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     // (TBK_BORROW=0: copied into the batch's arrays first, as the Python-level reader does)
     const char *borrow_env = getenv("TBK_BORROW");
     (void)tbk_fastx_set_borrowing(reader, tbk_pipeline_takes_packed_(p) && !(borrow_env && *borrow_env == '0'));
+    {
+        // BGZF input is inflated on the (first) device of the pipeline, which is idle most of an end-to-end run (stub rings have none)
+        tbk_classifier *c0 = tbk_pipeline_classifier(p, 0);
+        if (c0) (void)tbk_fastx_set_device(reader, tbk_classifier_device(c0));
+    }
     tbk_bin_writer *writer = nullptr;
     rc = tbk_bin_writer_open(out_a, out_b, out_u, gzip_output, gzip_level, 0, &writer);
     if (rc) { tbk_fastx_close(reader); return rc; }

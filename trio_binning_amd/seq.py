@@ -268,7 +268,9 @@ class BatchReader:
     """Native FASTA/FASTQ(.gz) reader: ``next_batch(batch, max_bases, max_reads)`` fills a
     ``Batch`` and returns the number of records (0 at end of input)."""
 
-    def __init__(self, filename: str, packing: bool = False, borrowing: bool = False):
+    def __init__(self, filename: str, packing: bool = False, borrowing: bool = False, device: Optional[int] = None):
+        """``device``: BGZF input is inflated on that GPU (``tbk_fastx_set_device``: what ``classify-by-kmers`` does by itself);
+        None: on the host's threads.  ``inflates_on_device`` says which it is."""
         import ctypes as C
         import os
 
@@ -277,6 +279,9 @@ class BatchReader:
         h = C.c_void_p()
         check(lib.tbk_fastx_open(os.fsencode(filename), C.byref(h)))
         self._h = h
+        if device is not None:
+            check(lib.tbk_fastx_set_device(h, device))
+        self.inflates_on_device = bool(lib.tbk_fastx_inflates_on_device(h)) if hasattr(lib, "tbk_fastx_inflates_on_device") else False
         if packing:  # batches also carry the packed transfer form of their bases (Batch.packed_pointers)
             check(lib.tbk_fastx_set_packing(h, 1))
         if borrowing:  # batches of a plain FASTQ file leave their records in the reader's mapping (what the native loop does):
