@@ -37,6 +37,7 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--gz-input", action="store_true",
                 help="also feed the reads as .fastq.gz, the way the reference's own CLI test and README do (tests/test_classify_by_kmers.py:19-36, seq.py:86-92): "
                      "once as ONE ordinary gzip member (a single DEFLATE chain: the reader's guessing inflater) and once as bgzf blocks, bins plain")
+ap.add_argument("--gz-kinds", default="one_gzip_member,bgzf", help="which of the gzip'ed inputs to run")
 ap.add_argument("--gz-both", action="store_true",
                 help="with --gz-input: every gzip'ed input also with gzip'ed bins - the reference's DEFAULT mode (seq.py:86-92 reads .gz through gzip.open, "
                      "classify_by_kmers.py:86-92 writes .gz unless --no-gzip-output): both ends compressed, sharing the host's CPUs")
@@ -267,6 +268,7 @@ for mode, cache in runs:
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages
 # ---- gzip'ed reads in, plain bins out ---------------------------------------------------------------------
+gz_inputs = {label: path for label, path in gz_inputs.items() if label in a.gz_kinds.split(",")}
 gz_runs = [(label, path, "", False) for label, path in gz_inputs.items()]
 gz_runs += [(label, path, e, False) for e in a.gz_env.split(";") if e for label, path in gz_inputs.items()]
 if a.gz_both:
@@ -312,6 +314,7 @@ for label, path, extra, gz_out in gz_runs:
     res["gz_" + label] = {"wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
                           "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None, "inflate": inflate, "bins": bins,
                           "text_GB_per_s_in_the_loop": round(res["fastq_GB"] / stages["loop_s"], 2) if stages.get("loop_s") else None,
+                          "tbk_lines": [l for l in err.splitlines() if l.startswith(("tbk-gpu", "tbk-write", "tbk-loop"))],
                           "bins_written_as": "gzip members" if gz_out else "plain text", "gpu_gzip": next((l for l in err.splitlines() if l.startswith("tbk-gpu-gzip ")), None),
                           "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
     shutil.rmtree(out, ignore_errors=True)

@@ -107,6 +107,12 @@ struct LineSource {
     size_t zin_pos = 0, zin_end = 0;
     std::vector<uint8_t> buf;  // decoded text window
     size_t pos = 0, end = 0;
+    // Where the text at hand lies: `buf`, or - a window the GPU inflater has written - that window's pinned buffer itself, with what
+    // the parser had left of the window before copied in front of it (`view`; the slot `held` is the inflater's again when the next
+    // window has been taken).  pos and end count from text().
+    uint8_t *view = nullptr;
+    int held = -1;
+    const uint8_t *text() const { return view ? view : buf.data(); }
     bool skip_lf = false;      // previous line ended in '\r' at the window edge: swallow a leading '\n'
     std::string err;
     // BGZF (bgzip) files are gzip files whose members are independent blocks of <= 64 KiB that
@@ -120,6 +126,7 @@ struct LineSource {
     bool gpu_slot_free[TBK_GINFLATE_SLOTS] = {true, true, true};
     uint64_t gpu_windows = 0, gpu_blocks = 0;
     double gpu_stage_s = 0, gpu_wait_s = 0;
+    uint64_t gpu_in_place = 0, gpu_copied = 0;   // windows parsed where the device wrote them / copied into `buf` (more left over than the room in front)
     int threads = 1;
     // Ordinary gzip streams go through the library's own DEFLATE decoder (tbk_inflate.h) on the
     // memory-mapped file: about twice zlib's speed on FASTQ, and that stream is what a run on .gz
@@ -195,7 +202,7 @@ struct LineSource {
     // A chunk owns the buffer it was inflated into: [ up to 32 KiB of the text before it | new text ].
     // (ext / slot: the text lies in a pinned output buffer of the GPU inflater instead of `data`; the slot is the inflater's again once
     // the parser has taken the text over)
-    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; const uint8_t *ext = nullptr; int slot = -1; };
+    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; uint8_t *ext = nullptr; size_t room = 0; int slot = -1; };
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -275,13 +282,25 @@ struct LineSource {
         struct Guard {
             tbk_ginflate *g; LineSource *me;
             ~Guard() {
+                {   // the windows still with the parser lie in the inflater's pinned buffers: it goes when the last of them has been taken over
+                    std::unique_lock<std::mutex> lk(me->mu);
+                    me->cv.wait(lk, [&] {
+                        if (me->stop) return true;
+                        for (bool f : me->gpu_slot_free) if (!f) return false;
+                        return true;
+                    });
+                }
                 tbk_ginflate_destroy(g);
                 if (getenv("TBK_PINFLATE_TIMING") || getenv("TBK_WRITE_TIMING"))
-                    fprintf(stderr, "tbk-gpu-bgzf %llu windows, %llu blocks inflated on device %d; the worker: staging %.3f s, waiting for the device %.3f s\n",
-                            (unsigned long long)me->gpu_windows, (unsigned long long)me->gpu_blocks, me->gpu_device, me->gpu_stage_s, me->gpu_wait_s);
+                    fprintf(stderr, "tbk-gpu-bgzf %llu windows, %llu blocks inflated on device %d (%llu parsed in place, %llu copied); the worker: staging %.3f s, waiting for the device %.3f s\n",
+                            (unsigned long long)me->gpu_windows, (unsigned long long)me->gpu_blocks, me->gpu_device, (unsigned long long)me->gpu_in_place, (unsigned long long)me->gpu_copied,
+                            me->gpu_stage_s, me->gpu_wait_s);
             }
         } guard{g, this};
         const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)256 << 20));
+        // room in front of a window's text for what the parser has left of the window before (it asks for more when less than a batch's
+        // worth, at most 64 MiB and a record, is at hand): the window is then parsed where it lies.  0 = every window is copied.
+        const size_t head_room = env_size("TBK_BGZF_GPU_ROOM", (size_t)96 << 20);
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         int in_flight = -1;   // the slot whose window is on the device
         bool flight_last = false;
@@ -298,7 +317,7 @@ struct LineSource {
             if (rc) { fail_with(std::string("inflate: ") + tbk_last_error()); return false; }
             if (bad) { fail_with("inflate: corrupt BGZF block"); return false; }
             Chunk c;
-            c.ext = base; c.off = 0; c.len = n; c.slot = in_flight; c.last = flight_last;
+            c.ext = base + head_room; c.room = head_room; c.off = 0; c.len = n; c.slot = in_flight; c.last = flight_last;
             in_flight = -1;
             push(std::move(c));
             return true;
@@ -349,7 +368,7 @@ struct LineSource {
                 (void)madvise((void *)(((uintptr_t)from + 4095) & ~(uintptr_t)4095), span > 8192 ? span - 8192 : 0, MADV_DONTNEED);   // (read once)
             }
             gpu_stage_s += now() - t0;
-            if (tbk_ginflate_submit(g, slot, span, blks.data(), blks.size(), 0) != TBK_OK) { const std::string m = std::string("inflate: ") + tbk_last_error(); if (!collect()) return; fail_with(m); return; }
+            if (tbk_ginflate_submit(g, slot, span, blks.data(), blks.size(), head_room) != TBK_OK) { const std::string m = std::string("inflate: ") + tbk_last_error(); if (!collect()) return; fail_with(m); return; }
             gpu_windows++; gpu_blocks += blks.size();
             // the window before this one has had this one's staging time on the device: hand it on
             if (!collect()) return;
@@ -587,6 +606,14 @@ struct LineSource {
             tail.swap(next_tail);
         }
     }
+    void give_back_held() {
+        view = nullptr;
+        if (held < 0) return;
+        std::lock_guard<std::mutex> lk(mu);
+        gpu_slot_free[held] = true;
+        held = -1;
+        cv.notify_all();
+    }
     // own decoder: returns like refill()
     bool refill_fast() {
         if (!started) { started = true; worker = std::thread([this] { if (bgzf && gpu_device >= 0 && map) bgzf_loop_gpu(); else if (bgzf) bgzf_loop(); else if (guessing()) pinflate_loop(); else inflate_loop(); }); }
@@ -599,6 +626,25 @@ struct LineSource {
             cv.notify_all();
         }
         if (!c.err.empty()) { err = c.err; return false; }
+        if (c.ext && c.slot >= 0 && end - pos <= c.room) {
+            // a window of the GPU inflater, and room in front of it for what is left of the text at hand: parsed where it lies
+            const size_t left = end - pos;
+            uint8_t *start = c.ext - left;
+            if (left) memcpy(start, text() + pos, left);
+            give_back_held();
+            view = start; held = c.slot; pos = 0; end = left + c.len;
+            gpu_in_place++;
+            if (c.last) text_eof = true;
+            return true;
+        }
+        if (view) {  // back into `buf` with what is left
+            const size_t left = end - pos;
+            if (buf.size() < left) buf.resize(left + ((size_t)1 << 20));
+            if (left) memcpy(buf.data(), view + pos, left);
+            give_back_held();
+            pos = 0; end = left;
+        }
+        if (c.ext) gpu_copied++;
         if (c.fallback) {  // the worker met an ordinary gzip member and has left: zlib goes on from zin[zin_pos..)
             if (worker.joinable()) worker.join();
             started = false; bgzf = false; threaded = false;
@@ -837,10 +883,10 @@ struct LineSource {
                     if (!refill()) return -1;
                     continue;
                 }
-                if (buf[pos] == '\n') pos++;
+                if (text()[pos] == '\n') pos++;
                 skip_lf = false;
             }
-            const uint8_t *base = buf.data();
+            const uint8_t *base = text();
             size_t i = pos;
             // scan for '\n' or '\r'
             while (i < end) {
@@ -1432,10 +1478,10 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
         while (!src.text_eof && src.end - src.pos < want)
             if (!src.refill()) return ffail(TBK_ERR_IO, "%s", src.err.c_str());
         if (src.pos == src.end) return TBK_OK;  // nothing left: the machine will say so
-        if (src.buf[src.pos] != '@') { sc.inflated = false; return TBK_OK; }
+        if (src.text()[src.pos] != '@') { sc.inflated = false; return TBK_OK; }
         size_t new_pos = src.pos;
         bool leave = false;
-        const int rc = regular_window(sc, src.buf.data(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave);
+        const int rc = regular_window(sc, src.text(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave);
         if (rc) return rc;
         if (b->n_reads() > have_reads) {
             src.pos = new_pos;
@@ -1445,7 +1491,7 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
         }
         // the record at src.pos: cut off by the end of the text at hand (read on: only then is a longer window worth
         // another scan), or not regular whatever follows (the machine's, at once)
-        if (!src.text_eof && src.end - src.pos < ((size_t)64 << 20) && regular_record_cut_off(src.buf.data(), src.end, src.pos)) {
+        if (!src.text_eof && src.end - src.pos < ((size_t)64 << 20) && regular_record_cut_off(src.text(), src.end, src.pos)) {
             at_least = src.end - src.pos + ((size_t)8 << 20);
             continue;
         }
