@@ -158,6 +158,22 @@ def test_reader_and_cli_from_bgzf_on_the_device(gpu, capfd, tmp_path, monkeypatc
             got, on_device = records(path, device=0)
             assert on_device and got == want, (name, room)
         monkeypatch.delenv("TBK_BGZF_GPU_ROOM", raising=False)
+        # borrowing (what the native loop asks for): a batch's records stay in the inflater's window, which stays out of the ring until the
+        # last batch that refers to it is refilled or destroyed - kept here beyond the ring's five windows, and beyond the reader
+        with seq.BatchReader(str(path), packing=True, borrowing=True, device=0) as r:
+            kept, got, borrowed = [], [], 0
+            while True:
+                b = seq.Batch()
+                if not r.next_batch(b, 200_000, 0):
+                    break
+                borrowed += b.borrowed
+                if len(kept) < 4:
+                    kept.append(b)
+                else:
+                    got += [(x.name, x.seq, x.qual) for x in b.reads()]
+        assert borrowed >= (0 if name == "member_behind" else 4), (name, borrowed)   # (the first batch of member_behind reads on into the ordinary member: copied)
+        assert [(x.name, x.seq, x.qual) for b in kept for x in b.reads()] + got == want, name   # (the reader is closed)
+        del kept
         got_cpu, on_device = records(path)
         assert not on_device and got_cpu == want, name
     # a damaged block: the run fails, it does not go on with wrong text

@@ -314,7 +314,7 @@ for label, path, extra, gz_out in gz_runs:
     res["gz_" + label] = {"wall_s": round(dt, 2), "gbases_per_s_wall": round(R * L / 1e9 / dt, 3), "stages": stages,
                           "classify_loop_gbases_per_s": round(R * L / 1e9 / stages["loop_s"], 3) if stages.get("loop_s") else None, "inflate": inflate, "bins": bins,
                           "text_GB_per_s_in_the_loop": round(res["fastq_GB"] / stages["loop_s"], 2) if stages.get("loop_s") else None,
-                          "tbk_lines": [l for l in err.splitlines() if l.startswith(("tbk-gpu", "tbk-write", "tbk-loop"))],
+                          "tbk_lines": [l for l in err.splitlines() if l.startswith(("tbk-gpu", "tbk-write", "tbk-loop", "tbk-read"))],
                           "bins_written_as": "gzip members" if gz_out else "plain text", "gpu_gzip": next((l for l in err.splitlines() if l.startswith("tbk-gpu-gzip ")), None),
                           "out_GB": round(sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) / 1e9, 2)}
     shutil.rmtree(out, ignore_errors=True)

@@ -96,6 +96,30 @@ __attribute__((target("avx2"))) static uint32_t resolve_symbols_avx2(const uint1
 // =======================================================================================
 // line source: plain or gzip file -> lines with universal-newline semantics
 // =======================================================================================
+// The GPU inflater's windows (bgzf_loop_gpu): the inflater and which of its slots are out.  A slot's text lies in pinned memory of the
+// inflater's; it is out while the parser reads it, while it waits in the queue, and while a batch whose records were left in it
+// (borrowed, as from a plain file's mapping) is alive.  Every holder has a WindowHold; the slot is the inflater's again with the last
+// of them, and the inflater itself goes with the last reference to this object - a batch may outlive its reader.
+struct GpuWindows {
+    std::mutex mu;
+    std::condition_variable cv;
+    tbk_ginflate *g = nullptr;
+    bool slot_free[TBK_GINFLATE_SLOTS];
+    bool abandoned = false;   // the reader is being closed: the worker must not wait for a slot
+    GpuWindows() { for (bool &f : slot_free) f = true; }
+    GpuWindows(const GpuWindows &) = delete;
+    GpuWindows &operator=(const GpuWindows &) = delete;
+    ~GpuWindows() { if (g) tbk_ginflate_destroy(g); }
+};
+struct WindowHold {
+    std::shared_ptr<GpuWindows> w;
+    int slot;
+    WindowHold(std::shared_ptr<GpuWindows> w_, int slot_) : w(std::move(w_)), slot(slot_) {}
+    WindowHold(const WindowHold &) = delete;
+    WindowHold &operator=(const WindowHold &) = delete;
+    ~WindowHold() { { std::lock_guard<std::mutex> lk(w->mu); w->slot_free[slot] = true; } w->cv.notify_all(); }
+};
+
 struct LineSource {
     int fd = -1;
     bool gz = false;
@@ -108,10 +132,11 @@ struct LineSource {
     std::vector<uint8_t> buf;  // decoded text window
     size_t pos = 0, end = 0;
     // Where the text at hand lies: `buf`, or - a window the GPU inflater has written - that window's pinned buffer itself, with what
-    // the parser had left of the window before copied in front of it (`view`; the slot `held` is the inflater's again when the next
-    // window has been taken).  pos and end count from text().
+    // the parser had left of the window before copied in front of it (`view`; `held` keeps the window's slot out until the next
+    // window has been taken, and the batches whose records stay in the window share it).  pos and end count from text().
     uint8_t *view = nullptr;
-    int held = -1;
+    std::shared_ptr<WindowHold> held;
+    std::shared_ptr<GpuWindows> windows;
     const uint8_t *text() const { return view ? view : buf.data(); }
     bool skip_lf = false;      // previous line ended in '\r' at the window edge: swallow a leading '\n'
     std::string err;
@@ -123,9 +148,9 @@ struct LineSource {
     // BGZF blocks inflated on the GPU (tbk_fastx_set_device; csrc/tbk_gdeflate.hip, second half): one wave per block, windows of
     // 256 MB of the file three deep.  -1: on the host's threads.
     int gpu_device = -1;
-    bool gpu_slot_free[TBK_GINFLATE_SLOTS] = {true, true, true};
     uint64_t gpu_windows = 0, gpu_blocks = 0;
-    double gpu_stage_s = 0, gpu_wait_s = 0;
+    double gpu_stage_s = 0, gpu_wait_s = 0, gpu_slot_wait_s = 0;
+    double chunk_wait_s = 0, left_copy_s = 0; uint64_t left_bytes = 0;   // the parser's side: waiting for a window, copying what it had left in front of it
     uint64_t gpu_in_place = 0, gpu_copied = 0;   // windows parsed where the device wrote them / copied into `buf` (more left over than the room in front)
     int threads = 1;
     // Ordinary gzip streams go through the library's own DEFLATE decoder (tbk_inflate.h) on the
@@ -202,7 +227,7 @@ struct LineSource {
     // A chunk owns the buffer it was inflated into: [ up to 32 KiB of the text before it | new text ].
     // (ext / slot: the text lies in a pinned output buffer of the GPU inflater instead of `data`; the slot is the inflater's again once
     // the parser has taken the text over)
-    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; uint8_t *ext = nullptr; size_t room = 0; int slot = -1; };
+    struct Chunk { std::vector<uint8_t> data; size_t off = 0, len = 0; bool last = false, fallback = false; std::string err; uint8_t *ext = nullptr; size_t room = 0; std::shared_ptr<WindowHold> hold; };
     std::thread worker;
     std::mutex mu;
     std::condition_variable cv;
@@ -279,24 +304,9 @@ struct LineSource {
     void bgzf_loop_gpu() {
         tbk_ginflate *g = nullptr;
         if (tbk_ginflate_create(gpu_device, &g) != TBK_OK) { bgzf_loop(); return; }
-        struct Guard {
-            tbk_ginflate *g; LineSource *me;
-            ~Guard() {
-                {   // the windows still with the parser lie in the inflater's pinned buffers: it goes when the last of them has been taken over
-                    std::unique_lock<std::mutex> lk(me->mu);
-                    me->cv.wait(lk, [&] {
-                        if (me->stop) return true;
-                        for (bool f : me->gpu_slot_free) if (!f) return false;
-                        return true;
-                    });
-                }
-                tbk_ginflate_destroy(g);
-                if (getenv("TBK_PINFLATE_TIMING") || getenv("TBK_WRITE_TIMING"))
-                    fprintf(stderr, "tbk-gpu-bgzf %llu windows, %llu blocks inflated on device %d (%llu parsed in place, %llu copied); the worker: staging %.3f s, waiting for the device %.3f s\n",
-                            (unsigned long long)me->gpu_windows, (unsigned long long)me->gpu_blocks, me->gpu_device, (unsigned long long)me->gpu_in_place, (unsigned long long)me->gpu_copied,
-                            me->gpu_stage_s, me->gpu_wait_s);
-            }
-        } guard{g, this};
+        std::shared_ptr<GpuWindows> w = std::make_shared<GpuWindows>();
+        w->g = g;   // (goes with the last window that is out, not with this thread)
+        { std::lock_guard<std::mutex> lk(mu); windows = w; }
         const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)256 << 20));
         // room in front of a window's text for what the parser has left of the window before (it asks for more when less than a batch's
         // worth, at most 64 MiB and a record, is at hand): the window is then parsed where it lies.  0 = every window is copied.
@@ -317,12 +327,11 @@ struct LineSource {
             if (rc) { fail_with(std::string("inflate: ") + tbk_last_error()); return false; }
             if (bad) { fail_with("inflate: corrupt BGZF block"); return false; }
             Chunk c;
-            c.ext = base + head_room; c.room = head_room; c.off = 0; c.len = n; c.slot = in_flight; c.last = flight_last;
+            c.ext = base + head_room; c.room = head_room; c.off = 0; c.len = n; c.hold = std::make_shared<WindowHold>(w, in_flight); c.last = flight_last;
             in_flight = -1;
             push(std::move(c));
             return true;
         };
-        int next_slot = 0;
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
             std::vector<tbk_ginflate_block> blks;
@@ -344,14 +353,19 @@ struct LineSource {
                 return;
             }
             if (out_total == 0) { bgzf_map_pos += span; if (at_end) { if (!collect()) return; Chunk c; c.last = true; push(std::move(c)); return; } continue; }   // only empty blocks (the end-of-file marker)
-            // a slot the parser has given back
-            const int slot = next_slot;
-            next_slot = (next_slot + 1) % TBK_GINFLATE_SLOTS;
+            // a slot nobody holds any more
+            int slot = -1;
             {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || gpu_slot_free[slot]; });
-                if (stop) return;
-                gpu_slot_free[slot] = false;
+                const double t0 = now();
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [&] {
+                    if (w->abandoned) return true;
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && i != in_flight) { slot = i; return true; }
+                    return false;
+                });
+                if (slot < 0) return;
+                w->slot_free[slot] = false;
+                gpu_slot_wait_s += now() - t0;
             }
             const double t0 = now();
             uint8_t *in = tbk_ginflate_input(g, slot, span);
@@ -606,33 +620,28 @@ struct LineSource {
             tail.swap(next_tail);
         }
     }
-    void give_back_held() {
-        view = nullptr;
-        if (held < 0) return;
-        std::lock_guard<std::mutex> lk(mu);
-        gpu_slot_free[held] = true;
-        held = -1;
-        cv.notify_all();
-    }
     // own decoder: returns like refill()
     bool refill_fast() {
         if (!started) { started = true; worker = std::thread([this] { if (bgzf && gpu_device >= 0 && map) bgzf_loop_gpu(); else if (bgzf) bgzf_loop(); else if (guessing()) pinflate_loop(); else inflate_loop(); }); }
         Chunk c;
         {
+            const auto t0 = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return !ready.empty(); });
+            chunk_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             c = std::move(ready.front());
             ready.pop_front();
             cv.notify_all();
         }
         if (!c.err.empty()) { err = c.err; return false; }
-        if (c.ext && c.slot >= 0 && end - pos <= c.room) {
+        if (c.ext && c.hold && end - pos <= c.room) {
             // a window of the GPU inflater, and room in front of it for what is left of the text at hand: parsed where it lies
             const size_t left = end - pos;
             uint8_t *start = c.ext - left;
+            const auto t0 = std::chrono::steady_clock::now();
             if (left) memcpy(start, text() + pos, left);
-            give_back_held();
-            view = start; held = c.slot; pos = 0; end = left + c.len;
+            left_copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); left_bytes += left;
+            view = start; held = std::move(c.hold); pos = 0; end = left + c.len;   // (the window before this one is the inflater's again, or its batches')
             gpu_in_place++;
             if (c.last) text_eof = true;
             return true;
@@ -641,7 +650,7 @@ struct LineSource {
             const size_t left = end - pos;
             if (buf.size() < left) buf.resize(left + ((size_t)1 << 20));
             if (left) memcpy(buf.data(), view + pos, left);
-            give_back_held();
+            view = nullptr; held.reset();
             pos = 0; end = left;
         }
         if (c.ext) gpu_copied++;
@@ -672,11 +681,7 @@ struct LineSource {
             }
         }
         end += c.len;
-        if (c.slot >= 0) {
-            std::lock_guard<std::mutex> lk(mu);
-            gpu_slot_free[c.slot] = true;
-            cv.notify_all();
-        }
+        c.hold.reset();   // (copied: the window is the inflater's again)
         if (c.last) text_eof = true;
         if (!c.data.empty()) {
             std::lock_guard<std::mutex> lk(mu);
@@ -803,11 +808,20 @@ struct LineSource {
     ~LineSource() { close_all(); }
     void close_all() {
         if (started) {
-            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            std::shared_ptr<GpuWindows> w;
+            { std::lock_guard<std::mutex> lk(mu); stop = true; w = windows; }
             cv.notify_all();
+            if (w) { { std::lock_guard<std::mutex> lk(w->mu); w->abandoned = true; } w->cv.notify_all(); }
             if (worker.joinable()) worker.join();
             started = false;
+            ready.clear();   // (windows still queued go back)
+            if (gpu_windows && (getenv("TBK_PINFLATE_TIMING") || getenv("TBK_WRITE_TIMING")))
+                fprintf(stderr, "tbk-gpu-bgzf %llu windows, %llu blocks inflated on device %d (%llu parsed in place, %llu copied); the worker: staging %.3f s, waiting for the device %.3f s, "
+                        "for a free window %.3f s; the parser: waiting for a window %.3f s, copying %.1f MB it had left in front of the next %.3f s\n",
+                        (unsigned long long)gpu_windows, (unsigned long long)gpu_blocks, gpu_device, (unsigned long long)gpu_in_place, (unsigned long long)gpu_copied,
+                        gpu_stage_s, gpu_wait_s, gpu_slot_wait_s, chunk_wait_s, left_bytes / 1e6, left_copy_s);
         }
+        view = nullptr; held.reset(); windows.reset();
         if (map) { munmap((void *)map, map_size); map = nullptr; }
         if (zs_live) { inflateEnd(&zs); zs_live = false; }
         if (fd >= 0) { ::close(fd); fd = -1; }
@@ -966,7 +980,8 @@ struct tbk_fastx_batch {
     bool borrowed = false;
     const uint8_t *text = nullptr;
     std::vector<FastqRec> recs;
-    std::shared_ptr<FastxMapping> hold;  // keeps `text` mapped while this batch refers to it
+    std::shared_ptr<void> hold;  // keeps `text` where it is while this batch refers to it: the reader's mapping of the file, or a window of the GPU inflater
+    bool text_mapped = false;    // `text` is the file's mapping (its pages are let go when the batch is refilled)
 
     ~tbk_fastx_batch() {
         release();
@@ -1013,7 +1028,7 @@ struct tbk_fastx_batch {
         has_qual.clear(); n_bases = 0; rec_seq0 = rec_qual0 = 0;
         fused = want_packed; packed_ok = false;
         exc.clear(); exc_chunk.clear(); exc_mask.clear();
-        borrowed = false; text = nullptr; recs.clear(); hold.reset();
+        borrowed = false; text = nullptr; recs.clear(); hold.reset(); text_mapped = false;
     }
     void begin(const uint8_t *name, size_t n) {
         names.insert(names.end(), name, name + n);
@@ -1450,7 +1465,7 @@ static int regular_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_ba
     bool leave = false;
     const int rc = regular_window(sc, sc.map, sc.size, sc.pos, b, max_bases, max_reads, &new_pos, &leave, r->borrowing);
     if (rc) return rc;
-    if (b->borrowed) b->hold = r->mapping;
+    if (b->borrowed) { b->hold = r->mapping; b->text_mapped = true; }
     if (b->n_reads() == 0 || leave) sc.active = false;
     sc.pos = new_pos;
     return TBK_OK;
@@ -1481,12 +1496,16 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
         if (src.text()[src.pos] != '@') { sc.inflated = false; return TBK_OK; }
         size_t new_pos = src.pos;
         bool leave = false;
-        const int rc = regular_window(sc, src.text(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave);
+        // a window of the GPU inflater is parsed where it lies: like a plain file's mapping, it can keep the records of a batch (the batch
+        // then ends with the window at the latest: what the next window brings goes into the next batch)
+        const int rc = regular_window(sc, src.text(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave, r->borrowing && src.view && src.held);
         if (rc) return rc;
         if (b->n_reads() > have_reads) {
             src.pos = new_pos;
             at_least = 0;
+            if (b->borrowed) b->hold = src.held;
             if (leave && src.text_eof) { sc.inflated = false; return TBK_OK; }
+            if (b->borrowed) return TBK_OK;
             continue;
         }
         // the record at src.pos: cut off by the end of the text at hand (read on: only then is a longer window worth
@@ -1516,6 +1535,10 @@ extern "C" int tbk_fastx_set_device(tbk_fastx_reader *r, int device) {
     if (how && strcmp(how, "cpu") == 0) return TBK_OK;
     if (r->src.started) return ffail(TBK_ERR_STATE, "tbk_fastx_set_device after the first read");
     r->src.gpu_device = device;
+    // the host's threads do not inflate now: the chunk-parallel scan has them (TBK_INFLATED_SCAN=0 keeps the sequential machine), and
+    // the windows it scans can keep a batch's records (tbk_fastx_set_borrowing)
+    const char *scan_env = getenv("TBK_FASTQ_SCAN"), *inflated_env = getenv("TBK_INFLATED_SCAN");
+    if (r->src.bgzf && r->src.map && !(scan_env && *scan_env == '0') && !(inflated_env && *inflated_env == '0')) r->scan.inflated = true;
     return TBK_OK;
 }
 // 1 when the reader's BGZF blocks are (being) inflated on a device
@@ -1595,7 +1618,7 @@ extern "C" int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t *
 // let go here, on the reader's thread, a batch at a time - left to tbk_fastx_close (or to the process's exit) the
 // 30 GB mapping of a BASELINE-sized input costs 0.3-1 s of tear-down behind the last record.
 static void release_borrowed(tbk_fastx_batch *b) {
-    if (!b->borrowed || !b->text || b->recs.empty()) return;
+    if (!b->borrowed || !b->text_mapped || !b->text || b->recs.empty()) return;
     const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
     const uintptr_t lo = ((uintptr_t)(b->text + b->recs.front().head) + page - 1) / page * page;  // whole pages inside the batch's text only
     const uintptr_t hi = (uintptr_t)(b->text + b->recs.back().end) / page * page;

@@ -1270,7 +1270,12 @@ int tbk_ginflate_create(int device, tbk_ginflate **out) {
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
     tbk_ginflate *g = new tbk_ginflate();
     g->device = device;
-    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    // the lowest priority there is: a window's kernel runs for tens of milliseconds, and the classifier's and the bins' encoder's short
+    // kernels (default priority) must not queue behind it - their waves take the slots this one's waves leave (TBK_BGZF_GPU_PRIORITY=0: default)
+    int least = 0, greatest = 0;
+    const char *prio = getenv("TBK_BGZF_GPU_PRIORITY");
+    if (!(prio && prio[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    e = least ? hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_out, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->in_done, hipEventDisableTiming);

@@ -140,13 +140,17 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     };
 
     double read_s = 0, write_s = 0, gpu_wait_s = 0, setup_s = since(t_start), close_s = 0;
+    double reader_idle_s = 0, writer_idle_s = 0, feed_idle_s = 0, submit_s = 0;   // (each thread's wait for its queue; TBK_WRITE_TIMING prints them)
     const bool write_timing = getenv("TBK_WRITE_TIMING") != nullptr;  // the writer's ms per batch, in tenths of the run, to stderr
     std::vector<double> per_batch_ms;
     std::thread reader_thread, writer_thread;
     if (!rc) {
         reader_thread = std::thread([&] {
             Item *it = nullptr;
-            while (!failure.any() && free_q.get(it)) {
+            for (;;) {
+                const auto t_idle = Clock::now();
+                if (failure.any() || !free_q.get(it)) break;
+                reader_idle_s += since(t_idle);
                 const auto t = Clock::now();
                 const int r = tbk_fastx_next(reader, it->batch, batch_bases, batch_reads);
                 read_s += since(t);
@@ -165,7 +169,10 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
             Item *it = nullptr;
             std::vector<double> sa, sb;
             std::vector<char> bins, tsv;
-            while (done_q.get(it)) {
+            for (;;) {
+                const auto t_idle = Clock::now();
+                if (!done_q.get(it)) break;
+                writer_idle_s += since(t_idle);
                 if (!failure.any()) {
                     const auto t = Clock::now();
                     const uint64_t n = it->n_reads;
@@ -200,9 +207,13 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
             }
         };
         Item *it = nullptr;
-        while (filled_q.get(it)) {
+        for (;;) {
+            const auto t_idle = Clock::now();
+            if (!filled_q.get(it)) break;
+            feed_idle_s += since(t_idle);
             if (failure.any()) { free_q.put(it); continue; }
             drain((size_t)depth - 1);
+            const auto t_submit = Clock::now();
             const uint32_t *codes = nullptr, *exc_chunk = nullptr;
             const uint16_t *exc_mask = nullptr;
             const uint8_t *bases = nullptr;
@@ -218,6 +229,7 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
             if (r) { failure.set(r, tbk_last_error()); free_q.put(it); continue; }
             st.reads += it->n_reads; st.bases += it->n_bases; st.batches++;
             flying.emplace_back(tk, it);
+            submit_s += since(t_submit);
         }
         drain(0);
         done_q.close();
@@ -248,6 +260,9 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
         if (it.counts) { if (it.counts_pinned) tbk_host_free(it.counts); else free(it.counts); }
     }
     close_s = since(t_close);
+    if (write_timing)
+        fprintf(stderr, "tbk-loop-waits the reader waited %.3f s for a free batch, this thread %.3f s for a read one (and spent %.3f s submitting), the writer %.3f s for a classified one; "
+                "%d batches circulate, %d of them submitted\n", reader_idle_s, feed_idle_s, submit_s, writer_idle_s, n_items, depth);
     if (write_timing)
         fprintf(stderr, "tbk-loop-timing opening the reader, the writer and the batches %.3f s; closing them %.3f s (writer %.3f, reader %.3f, batches %.3f)\n", setup_s, close_s,
                 close_writer_s, close_reader_s, close_s - close_writer_s - close_reader_s);
