@@ -38,6 +38,7 @@ ap.add_argument("--gz-input", action="store_true",
                 help="also feed the reads as .fastq.gz, the way the reference's own CLI test and README do (tests/test_classify_by_kmers.py:19-36, seq.py:86-92): "
                      "once as ONE ordinary gzip member (a single DEFLATE chain: the reader's guessing inflater) and once as bgzf blocks, bins plain")
 ap.add_argument("--gz-kinds", default="one_gzip_member,bgzf", help="which of the gzip'ed inputs to run")
+ap.add_argument("--gz-trace", default="", help="a directory: the bgzf run once more under rocprofv3 --kernel-trace, its per-dispatch CSV kept there (when which kernels ran beside which)")
 ap.add_argument("--gz-both", action="store_true",
                 help="with --gz-input: every gzip'ed input also with gzip'ed bins - the reference's DEFAULT mode (seq.py:86-92 reads .gz through gzip.open, "
                      "classify_by_kmers.py:86-92 writes .gz unless --no-gzip-output): both ends compressed, sharing the host's CPUs")
@@ -268,6 +269,16 @@ for mode, cache in runs:
         shutil.rmtree(out, ignore_errors=True)
         os.sync()  # the next run does not inherit this one's dirty pages
 # ---- gzip'ed reads in, plain bins out ---------------------------------------------------------------------
+if a.gz_trace and "bgzf" in gz_inputs:
+    out = os.path.join(out_root, "gz_trace")
+    os.makedirs(out)
+    os.makedirs(a.gz_trace, exist_ok=True)
+    with open(os.path.join(out, "stdout.tsv"), "wb") as so:
+        p = subprocess.run(["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", a.gz_trace, "-o", "bgzf", "--", sys.executable, "-m", "trio_binning_amd.classify_by_kmers",
+                            gz_inputs["bgzf"], paths[0], paths[1], "--haplotype-a-out-prefix", os.path.join(out, "hapA"), "--haplotype-b-out-prefix", os.path.join(out, "hapB"),
+                            "--unclassified-out-prefix", os.path.join(out, "unc"), "--no-gzip-output"], env=dict(env, TMPDIR="/tmp"), stdout=so, stderr=subprocess.PIPE, cwd="/tmp")
+    res["gz_trace"] = {"rc": p.returncode, "stderr_tail": p.stderr.decode()[-600:]}
+    shutil.rmtree(out, ignore_errors=True)
 gz_inputs = {label: path for label, path in gz_inputs.items() if label in a.gz_kinds.split(",")}
 gz_runs = [(label, path, "", False) for label, path in gz_inputs.items()]
 gz_runs += [(label, path, e, False) for e in a.gz_env.split(";") if e for label, path in gz_inputs.items()]

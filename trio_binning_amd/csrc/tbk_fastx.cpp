@@ -105,8 +105,9 @@ struct GpuWindows {
     std::condition_variable cv;
     tbk_ginflate *g = nullptr;
     bool slot_free[TBK_GINFLATE_SLOTS];
+    bool slot_sized[TBK_GINFLATE_SLOTS];   // its buffers have been sized (by the worker itself: the first one used; by its helper: the others)
     bool abandoned = false;   // the reader is being closed: the worker must not wait for a slot
-    GpuWindows() { for (bool &f : slot_free) f = true; }
+    GpuWindows() { for (bool &f : slot_free) f = true; for (bool &f : slot_sized) f = false; }
     GpuWindows(const GpuWindows &) = delete;
     GpuWindows &operator=(const GpuWindows &) = delete;
     ~GpuWindows() { if (g) tbk_ginflate_destroy(g); }
@@ -307,7 +308,7 @@ struct LineSource {
         std::shared_ptr<GpuWindows> w = std::make_shared<GpuWindows>();
         w->g = g;   // (goes with the last window that is out, not with this thread)
         { std::lock_guard<std::mutex> lk(mu); windows = w; }
-        const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)256 << 20));
+        const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)128 << 20));
         // room in front of a window's text for what the parser has left of the window before (it asks for more when less than a batch's
         // worth, at most 64 MiB and a record, is at hand): the window is then parsed where it lies.  0 = every window is copied.
         const size_t head_room = env_size("TBK_BGZF_GPU_ROOM", (size_t)96 << 20);
@@ -332,6 +333,11 @@ struct LineSource {
             push(std::move(c));
             return true;
         };
+        // the slots' buffers are sized for the first window and a quarter more (what the first window's own buffers get), those of the
+        // slots behind the first by a helper thread while the first window is on its way: a tenth of a second each, not in a row in front
+        std::thread sizer;
+        struct JoinSizer { std::thread &t; ~JoinSizer() { if (t.joinable()) t.join(); } } join_sizer{sizer};
+        bool first_window = true;
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
             std::vector<tbk_ginflate_block> blks;
@@ -360,12 +366,26 @@ struct LineSource {
                 std::unique_lock<std::mutex> lk(w->mu);
                 w->cv.wait(lk, [&] {
                     if (w->abandoned) return true;
-                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && i != in_flight) { slot = i; return true; }
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && i != in_flight && (first_window || w->slot_sized[i])) { slot = i; return true; }
                     return false;
                 });
                 if (slot < 0) return;
                 w->slot_free[slot] = false;
                 gpu_slot_wait_s += now() - t0;
+            }
+            if (first_window) {
+                first_window = false;
+                { std::lock_guard<std::mutex> lk(w->mu); w->slot_sized[slot] = true; }
+                const size_t in_b = span + span / 4, n_b = blks.size() + blks.size() / 4, out_b = head_room + out_total + out_total / 4;
+                sizer = std::thread([w, g, slot, in_b, n_b, out_b] {
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) {
+                        if (i == slot) continue;
+                        { std::lock_guard<std::mutex> lk(w->mu); if (w->abandoned) return; }
+                        (void)tbk_ginflate_reserve(g, i, in_b, n_b, out_b);   // (a failure shows when the slot is used)
+                        { std::lock_guard<std::mutex> lk(w->mu); w->slot_sized[i] = true; }
+                        w->cv.notify_all();
+                    }
+                });
             }
             const double t0 = now();
             uint8_t *in = tbk_ginflate_input(g, slot, span);

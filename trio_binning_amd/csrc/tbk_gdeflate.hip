@@ -1138,17 +1138,28 @@ gi_inflate_kernel(const uint8_t *__restrict__ in, const tbk_ginflate_block *__re
                   uint32_t *__restrict__ bad) {
     __shared__ GiTables tabs[GI_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t bi = blockIdx.x * GI_WAVES + wave;
-    if (bi >= n_blks) return;
     GiTables &T = tabs[wave];
+    // The grid is as many waves as the launch wants resident (tbk_ginflate_submit), not one per block: a wave takes the next block off a
+    // counter (bad[2], zeroed with the other two) until there is none.  A grid of one wave per block - ten thousand for a window - sits in
+    // the dispatcher for most of the kernel's 30 ms, and the kernels of every other stream on the device (the classifier's, the bins'
+    // encoder's) wait behind it: measured, not one of them ran beside such a kernel (EXPERIMENTS.md, round 6).
+  for (;;) {
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(bad + 2, 1u);
+    const uint32_t bi = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+    if (bi >= n_blks) break;
     const tbk_ginflate_block blk = blks[bi];
-    if (blk.out_len == 0) return;   // (the end-of-file marker: a final empty block, nothing to write)
+    if (blk.out_len == 0) continue;   // (the end-of-file marker: a final empty block, nothing to write)
     GiBits b;
     b.init(in + blk.in_off, in + blk.in_off + blk.in_len);
     uint8_t *dst = out + out_offs[bi];
     uint32_t pos = 0;
     bool fail = false;
+    // (every step below writes a byte or uses up input bits; the count of steps a damaged stream can take is bounded all the same)
+    uint32_t fuel = blk.out_len + 8u * blk.in_len + 1024u;
     for (bool last = false; !last && !fail;) {
+        if (fuel < 8u) { fail = true; break; }
+        fuel -= 8u;   // (a deflate block is at least ten bits of input, and its end-of-block symbol one more step)
         b.refill();
         last = b.take(1) != 0;
         const uint32_t type = b.take(2);
@@ -1204,6 +1215,7 @@ gi_inflate_kernel(const uint8_t *__restrict__ in, const tbk_ginflate_block *__re
         // ---- the symbols ----
         for (;;) {
             if (b.cnt < 32) { if (b.p > b.end + 8) { fail = true; break; } b.refill(); }   // (a corrupt stream must not walk out of its input)
+            if (fuel-- == 0u) { fail = true; break; }
             uint32_t e = gi_lookup(b, T.fast, GI_FAST_BITS, T.lcount, T.lsym, 0);
             if (e & 0x100u) {   // a literal: every lane stores the same byte to the same place (no lane mask to set up)
                 if (pos >= blk.out_len) { fail = true; break; }
@@ -1226,7 +1238,11 @@ gi_inflate_kernel(const uint8_t *__restrict__ in, const tbk_ginflate_block *__re
             pos += len;
         }
     }
-    if ((fail || pos != blk.out_len) && lane == 0) atomicAdd(bad, 1u);
+    if (fail || pos != blk.out_len) {   // the window is refused as a whole: this wave is done
+        if (lane == 0) atomicAdd(bad, 1u);
+        break;
+    }
+  }
 }
 
 
@@ -1260,6 +1276,7 @@ struct tbk_ginflate {
     GdCrcTabs *d_crc_tabs = nullptr;
     GiSlot slots[TBK_GINFLATE_SLOTS];
     uint64_t blocks = 0, text_bytes = 0;
+    int cus = 256, resident_wgs = 5;   // the inflate kernel's grid: workgroups (of GI_WAVES waves, 28 KB of LDS) per compute unit
 };
 
 int tbk_ginflate_create(int device, tbk_ginflate **out) {
@@ -1270,12 +1287,11 @@ int tbk_ginflate_create(int device, tbk_ginflate **out) {
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
     tbk_ginflate *g = new tbk_ginflate();
     g->device = device;
-    // the lowest priority there is: a window's kernel runs for tens of milliseconds, and the classifier's and the bins' encoder's short
-    // kernels (default priority) must not queue behind it - their waves take the slots this one's waves leave (TBK_BGZF_GPU_PRIORITY=0: default)
-    int least = 0, greatest = 0;
-    const char *prio = getenv("TBK_BGZF_GPU_PRIORITY");
-    if (!(prio && prio[0] == '0') && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    e = least ? hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, least) : hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) g->cus = prop.multiProcessorCount;
+    // (five such workgroups fill a compute unit's LDS: 5120 waves, one round for a window of 128 MB of the file)
+    if (const char *v = getenv("TBK_BGZF_GPU_WGS")) g->resident_wgs = std::max(1, std::min(8, atoi(v)));
+    e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_out, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->in_done, hipEventDisableTiming);
@@ -1311,6 +1327,31 @@ uint8_t *tbk_ginflate_input(tbk_ginflate *g, int slot, size_t bytes) {
     GiSlot &s = g->slots[slot];
     if (s.h_in.need(bytes + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return (uint8_t *)s.h_in.p;
+}
+
+// Size a slot's buffers ahead of its first window (a gigabyte of pinned and device memory takes the runtime a tenth of a second: the
+// reader's worker has another thread do this for the slots behind the first while the first window is on its way).  Not while the
+// slot is in use.
+int tbk_ginflate_reserve(tbk_ginflate *g, int slot, size_t in_bytes, size_t n_blocks, size_t out_bytes) {
+    if (!g || slot < 0 || slot >= TBK_GINFLATE_SLOTS) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: bad argument"); return TBK_ERR_INVALID; }
+    hipError_t e = hipSetDevice(g->device);
+    if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
+    GiSlot &s = g->slots[slot];
+    e = s.h_in.need(in_bytes + 64);
+    if (e == hipSuccess) e = s.h_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
+    if (e == hipSuccess) e = s.h_members.need((n_blocks + 1) * sizeof(GdMember));
+    if (e == hipSuccess) e = s.h_offs.need((n_blocks + 1) * 8);
+    if (e == hipSuccess) e = s.h_bad.need(64);
+    if (e == hipSuccess) e = s.h_out.need(out_bytes + 64);
+    if (e == hipSuccess) e = s.d_in.need(in_bytes + 64);
+    if (e == hipSuccess) e = s.d_out.need(out_bytes + 64);
+    if (e == hipSuccess) e = s.d_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
+    if (e == hipSuccess) e = s.d_members.need((n_blocks + 1) * sizeof(GdMember));
+    if (e == hipSuccess) e = s.d_offs.need((n_blocks + 1) * 8);
+    if (e == hipSuccess) e = s.d_crc.need((n_blocks + 1) * 4);
+    if (e == hipSuccess) e = s.d_bad.need(64);
+    if (e != hipSuccess) return gfail(e == hipErrorOutOfMemory ? TBK_ERR_NOMEM : TBK_ERR_HIP, "GPU inflater buffers", e);
+    return TBK_OK;
 }
 
 // Queue a window: blocks[i] = where block i's raw deflate stream lies in the slot's input (in_off, in_len), how much text it makes and
@@ -1360,8 +1401,10 @@ int tbk_ginflate_submit(tbk_ginflate *g, int slot, size_t in_bytes, const tbk_gi
     if (e == hipSuccess) e = hipMemsetAsync(s.d_bad.p, 0, 64, g->stream);
     if (e == hipSuccess) e = hipMemsetAsync(s.d_crc.p, 0, (n_blocks + 1) * 4, g->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(gi_inflate_kernel, dim3((unsigned)((n_blocks + GI_WAVES - 1) / GI_WAVES)), dim3(64 * GI_WAVES), 0, g->stream, (const uint8_t *)s.d_in.p,
-                           (const tbk_ginflate_block *)s.d_blocks.p, (const uint64_t *)s.d_offs.p, (uint32_t)n_blocks, (uint8_t *)s.d_out.p, (uint32_t *)s.d_bad.p);
+        // g->resident_wgs workgroups per compute unit, each wave of them working through blocks (see the kernel)
+        const size_t wgs = std::min<size_t>((n_blocks + GI_WAVES - 1) / GI_WAVES, (size_t)g->cus * (size_t)g->resident_wgs);
+        hipLaunchKernelGGL(gi_inflate_kernel, dim3((unsigned)wgs), dim3(64 * GI_WAVES), 0, g->stream, (const uint8_t *)s.d_in.p, (const tbk_ginflate_block *)s.d_blocks.p,
+                           (const uint64_t *)s.d_offs.p, (uint32_t)n_blocks, (uint8_t *)s.d_out.p, (uint32_t *)s.d_bad.p);
         // the blocks' CRC-32s: gd_crc_kernel over (block = member); blockIdx.y is limited to 65535: in turns
         for (size_t first = 0; first < n_blocks; first += 65535) {
             const size_t nb = std::min<size_t>(65535, n_blocks - first);

@@ -2,11 +2,11 @@
 //
 // Replaces the body of classify_by_kmers.main (classify_by_kmers.py:80-117): for every read of the input,
 // count_kmers_in_read, the two scores, the bin, the record written to that bin and a TSV line on stdout.
-// The reference does that one read at a time in Python; here three stages run side by side on batches:
+// The reference does that one read at a time in Python; here the stages run side by side on batches:
 //     reader thread    tbk_fastx_next: the next batch of records into pinned memory, its bases packed
 //                      into the transfer format on the way (tbk_fastx_set_packing);
-//     calling thread   tbk_pipeline_submit_packed / _wait: up to `depth` batches in flight on the
-//                      device(s), taken back in input order;
+//     calling thread   tbk_pipeline_submit_packed: up to `depth` batches in flight on the device(s);
+//     collector thread tbk_pipeline_wait: the batches taken back in input order, as soon as they are classified;
 //     writer thread    tbk_score_and_bin, tbk_bin_writer_write, tbk_format_tsv -> tsv_fd, in input order.
 // Batches circulate through a fixed set of buffers (depth + 3), so memory is bounded and nothing is
 // allocated per batch.  Output bytes are those of the Python mirror's loop, which are those of the
@@ -140,7 +140,7 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     };
 
     double read_s = 0, write_s = 0, gpu_wait_s = 0, setup_s = since(t_start), close_s = 0;
-    double reader_idle_s = 0, writer_idle_s = 0, feed_idle_s = 0, submit_s = 0;   // (each thread's wait for its queue; TBK_WRITE_TIMING prints them)
+    double reader_idle_s = 0, writer_idle_s = 0, feed_idle_s = 0, submit_s = 0, collect_s = 0;   // (each thread's wait for its queue; TBK_WRITE_TIMING prints them)
     const bool write_timing = getenv("TBK_WRITE_TIMING") != nullptr;  // the writer's ms per batch, in tenths of the run, to stderr
     std::vector<double> per_batch_ms;
     std::thread reader_thread, writer_thread;
@@ -193,26 +193,38 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
             }
         });
 
-        // this thread: keep the device(s) fed, take the batches back in input order
-        std::deque<std::pair<uint64_t, Item *>> flying;
-        auto drain = [&](size_t keep) {
-            while (flying.size() > keep) {
-                auto [tk, it] = flying.front();
-                flying.pop_front();
+        // this thread keeps the device(s) fed; a collector takes the batches back in input order and hands them to the writer the moment
+        // they are classified (a reader that delivers in bursts - windows of inflated text - must not find its batches parked behind a
+        // submit loop that waits for the next one to be read)
+        Chan<std::pair<uint64_t, Item *>> flying_q;
+        std::mutex fly_mu;
+        std::condition_variable fly_cv;
+        int in_flight = 0;
+        std::thread collector([&] {
+            std::pair<uint64_t, Item *> f;
+            while (flying_q.get(f)) {
                 const auto t = Clock::now();
-                const int r = tbk_pipeline_wait(p, tk, nullptr);
-                gpu_wait_s += since(t);
+                const int r = tbk_pipeline_wait(p, f.first, nullptr);
+                collect_s += since(t);
                 if (r) failure.set(r, tbk_last_error());
-                done_q.put(it);
+                done_q.put(f.second);
+                { std::lock_guard<std::mutex> lk(fly_mu); in_flight--; }
+                fly_cv.notify_all();
             }
-        };
+        });
         Item *it = nullptr;
         for (;;) {
             const auto t_idle = Clock::now();
             if (!filled_q.get(it)) break;
             feed_idle_s += since(t_idle);
             if (failure.any()) { free_q.put(it); continue; }
-            drain((size_t)depth - 1);
+            {   // as many submitted as the pipeline admits
+                const auto t = Clock::now();
+                std::unique_lock<std::mutex> lk(fly_mu);
+                fly_cv.wait(lk, [&] { return in_flight < depth; });
+                in_flight++;
+                gpu_wait_s += since(t);
+            }
             const auto t_submit = Clock::now();
             const uint32_t *codes = nullptr, *exc_chunk = nullptr;
             const uint16_t *exc_mask = nullptr;
@@ -226,12 +238,18 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
                 if (codes) r = tbk_pipeline_submit_packed(p, codes, exc_chunk, exc_mask, n_exc, off, it->n_reads, it->counts, &tk);
                 else r = tbk_pipeline_submit(p, bases, off, it->n_reads, it->counts, &tk);
             }
-            if (r) { failure.set(r, tbk_last_error()); free_q.put(it); continue; }
+            if (r) {
+                failure.set(r, tbk_last_error());
+                free_q.put(it);
+                { std::lock_guard<std::mutex> lk(fly_mu); in_flight--; }
+                continue;
+            }
             st.reads += it->n_reads; st.bases += it->n_bases; st.batches++;
-            flying.emplace_back(tk, it);
+            flying_q.put({tk, it});
             submit_s += since(t_submit);
         }
-        drain(0);
+        flying_q.close();
+        collector.join();
         done_q.close();
         writer_thread.join();
         free_q.close();
@@ -261,8 +279,9 @@ extern "C" int tbk_classify_file(tbk_pipeline *p, const char *reads_path, uint64
     }
     close_s = since(t_close);
     if (write_timing)
-        fprintf(stderr, "tbk-loop-waits the reader waited %.3f s for a free batch, this thread %.3f s for a read one (and spent %.3f s submitting), the writer %.3f s for a classified one; "
-                "%d batches circulate, %d of them submitted\n", reader_idle_s, feed_idle_s, submit_s, writer_idle_s, n_items, depth);
+        fprintf(stderr, "tbk-loop-waits the reader waited %.3f s for a free batch, this thread %.3f s for a read one and %.3f s for room in the rings (and spent %.3f s submitting), the collector "
+                "%.3f s for the oldest batch submitted, the writer %.3f s for a classified one; %d batches circulate, %d of them submitted\n", reader_idle_s, feed_idle_s, gpu_wait_s, submit_s,
+                collect_s, writer_idle_s, n_items, depth);
     if (write_timing)
         fprintf(stderr, "tbk-loop-timing opening the reader, the writer and the batches %.3f s; closing them %.3f s (writer %.3f, reader %.3f, batches %.3f)\n", setup_s, close_s,
                 close_writer_s, close_reader_s, close_s - close_writer_s - close_reader_s);
