@@ -313,26 +313,54 @@ struct LineSource {
         // worth, at most 64 MiB and a record, is at hand): the window is then parsed where it lies.  0 = every window is copied.
         const size_t head_room = env_size("TBK_BGZF_GPU_ROOM", (size_t)96 << 20);
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        int in_flight = -1;   // the slot whose window is on the device
-        bool flight_last = false;
         auto fail_with = [&](const std::string &msg) { Chunk c; c.err = msg; c.last = true; push(std::move(c)); };
-        // the window in flight -> the parser
-        auto collect = [&]() -> bool {
-            if (in_flight < 0) return true;
-            uint8_t *base = nullptr;
-            size_t n = 0;
-            uint32_t bad = 0;
-            const double t0 = now();
-            const int rc = tbk_ginflate_wait(g, in_flight, &base, &n, &bad);
-            gpu_wait_s += now() - t0;
-            if (rc) { fail_with(std::string("inflate: ") + tbk_last_error()); return false; }
-            if (bad) { fail_with("inflate: corrupt BGZF block"); return false; }
-            Chunk c;
-            c.ext = base + head_room; c.room = head_room; c.off = 0; c.len = n; c.hold = std::make_shared<WindowHold>(w, in_flight); c.last = flight_last;
-            in_flight = -1;
-            push(std::move(c));
-            return true;
+        // The windows on the device, oldest first, and the thread that takes them home: it waits for a window's kernels, copies its text
+        // into the slot's pinned output and hands it to the parser, while this thread stages the next window.
+        struct Flight { int slot; bool last; };
+        std::deque<Flight> flights;
+        std::mutex fl_mu;
+        std::condition_variable fl_cv;
+        bool no_more = false, collector_failed = false;
+        std::thread collector([&] {
+            for (;;) {
+                Flight f;
+                {
+                    std::unique_lock<std::mutex> lk(fl_mu);
+                    fl_cv.wait(lk, [&] { return no_more || !flights.empty(); });
+                    if (flights.empty()) return;
+                    f = flights.front();
+                }
+                uint8_t *base = nullptr;
+                size_t n = 0;
+                uint32_t bad = 0;
+                const double t0 = now();
+                const int rc = tbk_ginflate_wait(g, f.slot, &base, &n, &bad);
+                gpu_wait_s += now() - t0;
+                bool ok = true;
+                if (rc) { fail_with(std::string("inflate: ") + tbk_last_error()); ok = false; }
+                else if (bad) { fail_with("inflate: corrupt BGZF block"); ok = false; }
+                else {
+                    Chunk c;
+                    c.ext = base + head_room; c.room = head_room; c.off = 0; c.len = n; c.hold = std::make_shared<WindowHold>(w, f.slot); c.last = f.last;
+                    push(std::move(c));
+                }
+                {
+                    std::lock_guard<std::mutex> lk(fl_mu);
+                    flights.pop_front();
+                    if (!ok) collector_failed = true;
+                }
+                fl_cv.notify_all();
+                if (!ok) return;
+            }
+        });
+        // every window submitted has gone to the parser (true), or the collector has reported an error of its own (false)
+        auto drain = [&]() -> bool {
+            { std::lock_guard<std::mutex> lk(fl_mu); no_more = true; }
+            fl_cv.notify_all();
+            if (collector.joinable()) collector.join();
+            return !collector_failed;
         };
+        struct JoinCollector { decltype(drain) &d; ~JoinCollector() { (void)d(); } } join_collector{drain};
         // the slots' buffers are sized for the first window and a quarter more (what the first window's own buffers get), those of the
         // slots behind the first by a helper thread while the first window is on its way: a tenth of a second each, not in a row in front
         std::thread sizer;
@@ -340,14 +368,15 @@ struct LineSource {
         bool first_window = true;
         for (;;) {
             { std::lock_guard<std::mutex> lk(mu); if (stop) return; }
+            { std::lock_guard<std::mutex> lk(fl_mu); if (collector_failed) return; }
             std::vector<tbk_ginflate_block> blks;
             size_t span = 0, out_total = 0;
-            if (bgzf_scan(bgzf_map_pos, window, blks, &span, &out_total) < 0) { if (!collect()) return; fail_with(err); return; }
+            if (bgzf_scan(bgzf_map_pos, window, blks, &span, &out_total) < 0) { if (drain()) fail_with(err); return; }
             const bool at_end = bgzf_map_pos + span >= map_size;
             if (blks.empty()) {
-                if (!collect()) return;
+                if (!at_end && span > 0) { bgzf_map_pos += span; continue; }   // only padding: drop it and look again
+                if (!drain()) return;
                 if (at_end) { Chunk c; c.last = true; push(std::move(c)); return; }
-                if (span > 0) { bgzf_map_pos += span; continue; }   // only padding: drop it and look again
                 if (map_size - bgzf_map_pos >= 18 && bgzf_block_size(map + bgzf_map_pos, map_size - bgzf_map_pos) == 0) {
                     // an ordinary gzip member follows: the sequential path reads the file itself, from here (as bgzf_window hands over)
                     if (lseek(fd, (off_t)bgzf_map_pos, SEEK_SET) < 0) { fail_with(std::string("lseek: ") + strerror(errno)); return; }
@@ -358,7 +387,11 @@ struct LineSource {
                 fail_with("truncated gzip file");
                 return;
             }
-            if (out_total == 0) { bgzf_map_pos += span; if (at_end) { if (!collect()) return; Chunk c; c.last = true; push(std::move(c)); return; } continue; }   // only empty blocks (the end-of-file marker)
+            if (out_total == 0) {   // only empty blocks (the end-of-file marker)
+                bgzf_map_pos += span;
+                if (at_end) { if (drain()) { Chunk c; c.last = true; push(std::move(c)); } return; }
+                continue;
+            }
             // a slot nobody holds any more
             int slot = -1;
             {
@@ -366,7 +399,7 @@ struct LineSource {
                 std::unique_lock<std::mutex> lk(w->mu);
                 w->cv.wait(lk, [&] {
                     if (w->abandoned) return true;
-                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && i != in_flight && (first_window || w->slot_sized[i])) { slot = i; return true; }
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && (first_window || w->slot_sized[i])) { slot = i; return true; }
                     return false;
                 });
                 if (slot < 0) return;
@@ -389,7 +422,7 @@ struct LineSource {
             }
             const double t0 = now();
             uint8_t *in = tbk_ginflate_input(g, slot, span);
-            if (!in) { if (!collect()) return; fail_with("inflate: no pinned memory for a BGZF window"); return; }
+            if (!in) { if (drain()) fail_with("inflate: no pinned memory for a BGZF window"); return; }
             {
                 const int nt = std::min(4, std::max(1, threads));
                 std::vector<std::thread> pool;
@@ -402,13 +435,12 @@ struct LineSource {
                 (void)madvise((void *)(((uintptr_t)from + 4095) & ~(uintptr_t)4095), span > 8192 ? span - 8192 : 0, MADV_DONTNEED);   // (read once)
             }
             gpu_stage_s += now() - t0;
-            if (tbk_ginflate_submit(g, slot, span, blks.data(), blks.size(), head_room) != TBK_OK) { const std::string m = std::string("inflate: ") + tbk_last_error(); if (!collect()) return; fail_with(m); return; }
+            if (tbk_ginflate_submit(g, slot, span, blks.data(), blks.size(), head_room) != TBK_OK) { const std::string m = std::string("inflate: ") + tbk_last_error(); if (drain()) fail_with(m); return; }
             gpu_windows++; gpu_blocks += blks.size();
-            // the window before this one has had this one's staging time on the device: hand it on
-            if (!collect()) return;
-            in_flight = slot; flight_last = at_end;
+            { std::lock_guard<std::mutex> lk(fl_mu); flights.push_back(Flight{slot, at_end}); }
+            fl_cv.notify_all();
             bgzf_map_pos += span;
-            if (at_end) { (void)collect(); return; }
+            if (at_end) { (void)drain(); return; }
         }
     }
     void inflate_loop() {

@@ -1111,8 +1111,8 @@ __device__ inline int gi_decode_slow(GiBits &b, const uint16_t *count, const uin
     int code = 0, first = 0, index = 0;
     for (int L = 1; L <= 15; L++) {
         code |= (int)b.take(1);
-        const int c = count[L];
-        if (code - c < first) return symbol[index + (code - first)];
+        const int c = __builtin_amdgcn_readfirstlane((int)count[L]);
+        if (code - c < first) return __builtin_amdgcn_readfirstlane((int)symbol[index + (code - first)]);
         index += c; first += c; first <<= 1; code <<= 1;
     }
     return -1;
@@ -1128,7 +1128,7 @@ __device__ inline uint32_t gi_entry_slow(GiBits &b, const uint16_t *count, const
     return sym - 257 < 29 ? ((uint32_t)GI_LEXT[sym - 257] << 4) | ((uint32_t)GI_LBASE[sym - 257] << 16) : 0xFFFF0000u;
 }
 __device__ inline uint32_t gi_lookup(GiBits &b, const uint32_t *fast, int fast_bits, const uint16_t *count, const uint16_t *symbol, int kind) {
-    const uint32_t e = fast[b.peek(fast_bits)];
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)fast[b.peek(fast_bits)]);
     if (e & 15u) { b.drop((int)(e & 15u)); return e; }
     return gi_entry_slow(b, count, symbol, kind);
 }
@@ -1137,7 +1137,9 @@ __global__ void __launch_bounds__(64 * GI_WAVES)
 gi_inflate_kernel(const uint8_t *__restrict__ in, const tbk_ginflate_block *__restrict__ blks, const uint64_t *__restrict__ out_offs, uint32_t n_blks, uint8_t *__restrict__ out,
                   uint32_t *__restrict__ bad) {
     __shared__ GiTables tabs[GI_WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all 64 lanes, and with it everything read through the
+    // wave's tables and block - the whole state of the decoder - would live in vector registers: measured, 20 % slower)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     GiTables &T = tabs[wave];
     // The grid is as many waves as the launch wants resident (tbk_ginflate_submit), not one per block: a wave takes the next block off a
     // counter (bad[2], zeroed with the other two) until there is none.  A grid of one wave per block - ten thousand for a window - sits in
@@ -1257,8 +1259,8 @@ namespace {
 struct GiSlot {
     PinBuf h_in, h_out, h_blocks, h_members, h_offs, h_bad;
     DevBuf d_in, d_out, d_blocks, d_members, d_offs, d_crc, d_bad;
-    hipEvent_t done = nullptr;
-    size_t out_bytes = 0;
+    hipEvent_t done = nullptr;   // the window's kernels
+    size_t out_bytes = 0, head = 0;
     bool busy = false;
     void drop() {
         h_in.drop(); h_out.drop(); h_blocks.drop(); h_members.drop(); h_offs.drop(); h_bad.drop();
@@ -1415,12 +1417,13 @@ int tbk_ginflate_submit(tbk_ginflate *g, int slot, size_t in_bytes, const tbk_gi
                            (uint32_t)n_blocks, (uint32_t *)s.d_bad.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipEventRecord(g->k_done, g->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream_out, g->k_done, 0);
-    if (e == hipSuccess && out_total) e = hipMemcpyAsync((uint8_t *)s.h_out.p + head, s.d_out.p, out_total, hipMemcpyDeviceToHost, g->stream_out);
-    if (e == hipSuccess) e = hipMemcpyAsync(s.h_bad.p, s.d_bad.p, 8, hipMemcpyDeviceToHost, g->stream_out);
-    if (e == hipSuccess) e = hipEventRecord(s.done, g->stream_out);
+    // The text's copy home is NOT queued here behind the kernels' event: a copy that waits sits at the head of the copy engine's queue,
+    // and every copy queued after it - the classifier's batches, the bins' encoder's text - waits with it for the 16 ms of this window's
+    // kernel and the copy itself (measured: the classifier's kernels started 11 ms after an inflate kernel's end, to the tenth of a
+    // millisecond, never earlier).  tbk_ginflate_wait queues it when the kernels are done.
+    if (e == hipSuccess) e = hipEventRecord(s.done, g->stream);
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "GPU inflater submit", e);
+    s.head = head;
     s.busy = true;
     g->blocks += n_blocks; g->text_bytes += out_total;
     return TBK_OK;
@@ -1432,7 +1435,11 @@ int tbk_ginflate_wait(tbk_ginflate *g, int slot, uint8_t **out_base, size_t *tex
     if (!g || slot < 0 || slot >= TBK_GINFLATE_SLOTS) { tbk_set_error_(TBK_ERR_INVALID, "GPU inflater: bad argument"); return TBK_ERR_INVALID; }
     GiSlot &s = g->slots[slot];
     if (!s.busy) { tbk_set_error_(TBK_ERR_STATE, "GPU inflater: nothing in flight in the slot"); return TBK_ERR_STATE; }
-    const hipError_t e = hipEventSynchronize(s.done);
+    hipError_t e = hipSetDevice(g->device);
+    if (e == hipSuccess) e = hipEventSynchronize(s.done);
+    if (e == hipSuccess && s.out_bytes) e = hipMemcpyAsync((uint8_t *)s.h_out.p + s.head, s.d_out.p, s.out_bytes, hipMemcpyDeviceToHost, g->stream_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(s.h_bad.p, s.d_bad.p, 8, hipMemcpyDeviceToHost, g->stream_out);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream_out);
     s.busy = false;
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "GPU inflater wait", e);
     const uint32_t *b = (const uint32_t *)s.h_bad.p;
