@@ -437,6 +437,223 @@ ginflate_kernel2(const uint8_t *__restrict__ in, uint64_t in_total, const Blk *_
     if ((fail || pos != blk.out_len) && lane == 0) atomicAdd(bad, 1);
 }
 
+
+// ---- the third decoder: the second one laid out for the instruction cache and the scalar unit ------------------------------------------
+// Everything that is not the way from one symbol to the next is a function of its own (table builds, the canonical walk for long codes,
+// a chunk of input into LDS, a group of matches resolved): the loop that runs 18 000 times per block is a few dozen instructions.
+__device__ __noinline__ void build_nl(const uint8_t *len, int n, uint16_t *count, uint16_t *symbol, uint32_t *fast, int fast_bits, int kind, int lane) {
+    build(len, n, count, symbol, fast, fast_bits, kind, lane);
+}
+// the code at the low end of `bits` (15 of them are enough) walked along the canonical order: symbol << 8 | length, or ~0u
+__device__ __noinline__ uint32_t slow_code(uint32_t bits, const uint16_t *count, const uint16_t *symbol) {
+    int code = 0, first = 0, index = 0;
+    for (int L = 1; L <= 15; L++) {
+        code |= (int)(bits & 1u);
+        bits >>= 1;
+        const int c = __builtin_amdgcn_readfirstlane((int)count[L]);
+        if (code - c < first) return ((uint32_t)__builtin_amdgcn_readfirstlane((int)symbol[index + (code - first)]) << 8) | (uint32_t)L;
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return ~0u;
+}
+__device__ __noinline__ uint32_t entry_of(uint32_t sym, int kind) {
+    if (kind == 1) return sym < 30 ? ((uint32_t)DEXT[sym] << 4) | ((uint32_t)DBASE[sym] << 16) : 0xFFFF0000u;
+    if (sym < 256) return 0x100u | (sym << 16);
+    if (sym == 256) return 0x200u;
+    return sym - 257 < 29 ? ((uint32_t)LEXT[sym - 257] << 4) | ((uint32_t)LBASE[sym - 257] << 16) : 0xFFFF0000u;
+}
+__device__ __noinline__ void load_chunk_nl(const uint32_t *g, uint32_t *lds, uint32_t ndw, uint32_t c, int lane) {
+    const uint32_t base = c * 128u;
+    uint32_t a = base + (uint32_t)lane, bq = base + 64u + (uint32_t)lane;
+    a = a < ndw ? a : ndw - 1; bq = bq < ndw ? bq : ndw - 1;
+    const uint32_t x = g[a], y = g[bq];
+    lds[(base & 255u) + (uint32_t)lane] = x;
+    lds[(base & 255u) + 64u + (uint32_t)lane] = y;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+__device__ __noinline__ void resolve_nl(uint8_t *dst, uint32_t tok_pos, uint32_t tok_len, uint32_t tok_dist, uint32_t ntok, int lane) {
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok_pos);
+    const bool active = (uint32_t)lane < ntok;
+    const uint32_t src = tok_pos - tok_dist;
+    const bool later = active && (src + tok_len > p0 || tok_len > SHORT_MATCH);
+    if (active && !later) {
+        uint8_t v[SHORT_MATCH];
+#pragma unroll
+        for (uint32_t j = 0; j < SHORT_MATCH; j++) v[j] = j < tok_len ? dst[src + j] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t j = 0; j < SHORT_MATCH; j++) if (j < tok_len) dst[tok_pos + j] = v[j];
+    }
+    uint64_t todo = __ballot(later);
+    while (todo) {
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)tok_pos, k), len = (uint32_t)__builtin_amdgcn_readlane((int)tok_len, k),
+                       dist = (uint32_t)__builtin_amdgcn_readlane((int)tok_dist, k);
+        const uint8_t *s = dst + p - dist;
+        if (dist >= len) { for (uint32_t i = lane; i < len; i += 64) dst[p + i] = s[i]; }
+        else if (dist == 1) { const uint8_t c = s[0]; for (uint32_t i = lane; i < len; i += 64) dst[p + i] = c; }
+        else { for (uint32_t i = lane; i < len; i += 64) dst[p + i] = s[i % dist]; }
+    }
+}
+
+struct Bits3 {
+    const uint32_t *g;
+    uint32_t *lds;
+    uint32_t ndw, iw;
+    uint64_t buf;
+    int cnt;
+    int lane;
+    __device__ inline void seek(uint32_t q) {
+        iw = q >> 2;
+        load_chunk_nl(g, lds, ndw, iw >> 7, lane);
+        load_chunk_nl(g, lds, ndw, (iw >> 7) + 1, lane);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[iw & 255u]);
+        const uint32_t sh = 8u * (q & 3u);
+        buf = (uint64_t)(w >> sh);
+        cnt = 32 - (int)sh;
+        iw++;
+        if ((iw & 127u) == 0) load_chunk_nl(g, lds, ndw, (iw >> 7) + 1, lane);
+    }
+    __device__ inline uint32_t byte_pos() const { return iw * 4u - (uint32_t)(cnt >> 3); }
+    __device__ inline void refill() {
+        if (cnt <= 32) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[iw & 255u]);
+            buf |= (uint64_t)w << cnt;
+            cnt += 32;
+            iw++;
+            if ((iw & 127u) == 0) load_chunk_nl(g, lds, ndw, (iw >> 7) + 1, lane);
+        }
+    }
+    __device__ inline uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+    __device__ inline void drop(int n) { buf >>= n; cnt -= n; }
+    __device__ inline uint32_t take(int n) { const uint32_t v = peek(n); drop(n); return v; }
+};
+// a table entry for the code at hand: the fast table's, or the long way round
+__device__ inline uint32_t lookup3(Bits3 &b, const uint32_t *fast, int fast_bits, const uint16_t *count, const uint16_t *symbol, int kind) {
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)fast[b.peek(fast_bits)]);
+    if (__builtin_expect((e & 15u) != 0, 1)) { b.drop((int)(e & 15u)); return e; }
+    // (what a function returns is "different in every lane" to the compiler unless it is told otherwise)
+    const uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)slow_code((uint32_t)b.buf & 0x7FFFu, count, symbol));
+    if (sc == ~0u) return 0xFFFF0000u;
+    b.drop((int)(sc & 255u));
+    return kind == 2 ? (sc >> 8) << 16 : (uint32_t)__builtin_amdgcn_readfirstlane((int)entry_of(sc >> 8, kind));
+}
+
+__global__ void __launch_bounds__(64 * WAVES_PER_BLOCK)
+ginflate_kernel3(const uint8_t *__restrict__ in, uint64_t in_total, const Blk *__restrict__ blks, uint32_t n_blks, uint8_t *__restrict__ out, int *__restrict__ bad) {
+    __shared__ Tables2 tabs[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t bi = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (bi >= n_blks) return;
+    Tables &T = tabs[wave].t;
+    const Blk blk = blks[bi];
+    Bits3 b;
+    const uint64_t start = blk.in_off & ~3ull;
+    b.g = (const uint32_t *)(in + start);
+    b.lds = tabs[wave].inbuf;
+    b.ndw = (uint32_t)((in_total - start) >> 2);
+    b.lane = lane;
+    b.seek((uint32_t)(blk.in_off - start));
+    const uint32_t in_end = (uint32_t)(blk.in_off - start) + blk.in_len;
+    uint8_t *dst = out + blk.out_off;
+    uint32_t pos = 0;
+    bool fail = false;
+    uint64_t lit_acc = 0;
+    uint32_t lit_n = 0, lit_pos = 0;
+    uint32_t ntok = 0, tok_pos = 0, tok_len = 0, tok_dist = 0;
+#define FLUSH_LITS() do { if (lit_n) { if ((uint32_t)lane < lit_n) dst[lit_pos + lane] = (uint8_t)(lit_acc >> (8 * lane)); lit_n = 0; lit_acc = 0; } } while (0)
+#define RESOLVE() do { FLUSH_LITS(); if (ntok) { resolve_nl(dst, tok_pos, tok_len, tok_dist, ntok, lane); ntok = 0; } } while (0)
+    for (bool last = false; !last && !fail;) {
+        b.refill();
+        last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 0) {  // stored
+            RESOLVE();
+            b.drop(b.cnt & 7);
+            b.refill();
+            const uint32_t n = b.take(16);
+            b.refill();
+            (void)b.take(16);
+            const uint32_t q = b.byte_pos();
+            if (q + n > in_end || pos + n > blk.out_len) { fail = true; break; }
+            const uint8_t *s = (const uint8_t *)b.g + q;
+            for (uint32_t i = lane; i < n; i += 64) dst[pos + i] = s[i];
+            pos += n;
+            b.seek(q + n);
+            continue;
+        }
+        if (type == 3) { fail = true; break; }
+        int nlit = 288, ndist = 30;
+        if (type == 1) {
+            for (int i = lane; i < 288; i += 64) T.len[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+            if (lane < 30) T.len[288 + lane] = 5;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            nlit = (int)b.take(5) + 257; ndist = (int)b.take(5) + 1;
+            const int ncl = (int)b.take(4) + 4;
+            if (lane < 19) T.len[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int i = 0; i < ncl; i++) { b.refill(); const uint32_t v = b.take(3); if (lane == 0) T.len[CLORD[i]] = (uint8_t)v; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            build_nl(T.len, 19, T.dcount, T.dsym, T.dfast, 7, 2, lane);
+            uint8_t prev = 0;
+            int i = 0;
+            const int want = nlit + ndist;
+            while (i < want && !fail) {
+                b.refill();
+                const uint32_t e = lookup3(b, T.dfast, 7, T.dcount, T.dsym, 2);
+                const int sym = (int)(e >> 16);
+                if (sym > 18) { fail = true; break; }
+                if (sym < 16) { if (lane == 0) T.len[i] = (uint8_t)sym; prev = (uint8_t)sym; i++; continue; }
+                int rep; uint8_t val = 0;
+                if (sym == 16) { val = prev; rep = 3 + (int)b.take(2); }
+                else if (sym == 17) rep = 3 + (int)b.take(3);
+                else rep = 11 + (int)b.take(7);
+                if (i + rep > want) { fail = true; break; }
+                for (int r = lane; r < rep; r += 64) T.len[i + r] = val;
+                i += rep; prev = val;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (fail) break;
+        }
+        build_nl(T.len, nlit, T.lcount, T.lsym, T.fast, FAST_BITS, 0, lane);
+        build_nl(T.len + nlit, ndist, T.dcount, T.dsym, T.dfast, DFAST_BITS, 1, lane);
+        // ---- the symbols ----
+        const uint32_t out_len = blk.out_len;
+        for (;;) {
+            b.refill();
+            const uint32_t e = lookup3(b, T.fast, FAST_BITS, T.lcount, T.lsym, 0);
+            if (e & 0x100u) {
+                if (lit_n == 0) lit_pos = pos;
+                lit_acc |= (uint64_t)(e >> 16) << (8 * lit_n);
+                lit_n++; pos++;
+                if (lit_n == 8) { if (pos > out_len) { fail = true; break; } FLUSH_LITS(); }
+                continue;
+            }
+            if (e & 0x200u) break;   // end of block
+            if ((e >> 16) == 0xFFFFu || b.byte_pos() > in_end + 8) { fail = true; break; }
+            b.refill();
+            const uint32_t len = (e >> 16) + b.take((int)((e >> 4) & 15u));
+            const uint32_t d = lookup3(b, T.dfast, DFAST_BITS, T.dcount, T.dsym, 1);
+            if ((d >> 16) == 0xFFFFu) { fail = true; break; }
+            b.refill();
+            const uint32_t dist = (d >> 16) + b.take((int)((d >> 4) & 15u));
+            if (dist > pos || pos + len > out_len) { fail = true; break; }
+            FLUSH_LITS();
+            if ((uint32_t)lane == ntok) { tok_pos = pos; tok_len = len; tok_dist = dist; }
+            ntok++;
+            pos += len;
+            if (ntok == 64) { resolve_nl(dst, tok_pos, tok_len, tok_dist, ntok, lane); ntok = 0; }
+        }
+        if (pos > out_len) fail = true;
+    }
+    if (fail) { lit_n = 0; ntok = 0; }
+    RESOLVE();
+    if ((fail || pos != blk.out_len) && lane == 0) atomicAdd(bad, 1);
+#undef FLUSH_LITS
+#undef RESOLVE
+}
+
 int main(int argc, char **argv) {
     const size_t mb = argc > 1 ? (size_t)atol(argv[1]) : 512;
     const int level = argc > 2 ? atoi(argv[2]) : 4;
@@ -494,11 +711,12 @@ int main(int argc, char **argv) {
     unsigned long long *d_stats;
     CHECK(hipMalloc(&d_stats, 32));
     CHECK(hipMemset(d_stats, 0, 32));
-    for (int rep = 0; rep < 9; rep++) {
+    for (int rep = 0; rep < 12; rep++) {
         const int mode = rep / 3;
         CHECK(hipMemset(d_out, 0, text.size()));
         CHECK(hipEventRecord(e0));
         if (mode == 0) hipLaunchKernelGGL(ginflate_kernel<0>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, nullptr, d_in, d_blks, (uint32_t)blks.size(), d_out, d_bad, rep == 0 ? d_stats : nullptr);
+        else if (mode == 3) hipLaunchKernelGGL(ginflate_kernel3, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, nullptr, d_in, (uint64_t)comp.size(), d_blks, (uint32_t)blks.size(), d_out, d_bad);
         else if (mode == 2) hipLaunchKernelGGL(ginflate_kernel2, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, nullptr, d_in, (uint64_t)comp.size(), d_blks, (uint32_t)blks.size(), d_out, d_bad);
         else hipLaunchKernelGGL(ginflate_kernel<1>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), 0, nullptr, d_in, d_blks, (uint32_t)blks.size(), d_out, d_bad, (unsigned long long *)nullptr);
         CHECK(hipEventRecord(e1));
