@@ -106,6 +106,7 @@ struct GpuWindows {
     tbk_ginflate *g = nullptr;
     bool slot_free[TBK_GINFLATE_SLOTS];
     bool slot_sized[TBK_GINFLATE_SLOTS];   // its buffers have been sized (by the worker itself: the first one used; by its helper: the others)
+    bool sizing_done = false;              // the helper has gone through the slots (one it could not size ends it: the ring is as deep as it got)
     bool abandoned = false;   // the reader is being closed: the worker must not wait for a slot
     GpuWindows() { for (bool &f : slot_free) f = true; for (bool &f : slot_sized) f = false; }
     GpuWindows(const GpuWindows &) = delete;
@@ -139,6 +140,15 @@ struct LineSource {
     std::shared_ptr<WindowHold> held;
     std::shared_ptr<GpuWindows> windows;
     const uint8_t *text() const { return view ? view : buf.data(); }
+    // May a batch leave its records in the window at hand?  Only while two more windows are free: the ring must turn over whatever
+    // the batches' owner does with them (a caller who keeps every batch would otherwise stop the reader for good).
+    bool window_can_lend() {
+        if (!view || !held || !windows) return false;
+        std::lock_guard<std::mutex> lk(windows->mu);
+        int free_now = 0;
+        for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) free_now += windows->slot_sized[i] && windows->slot_free[i];
+        return free_now >= 2;
+    }
     bool skip_lf = false;      // previous line ended in '\r' at the window edge: swallow a leading '\n'
     std::string err;
     // BGZF (bgzip) files are gzip files whose members are independent blocks of <= 64 KiB that
@@ -399,25 +409,47 @@ struct LineSource {
                 std::unique_lock<std::mutex> lk(w->mu);
                 w->cv.wait(lk, [&] {
                     if (w->abandoned) return true;
-                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) if (w->slot_free[i] && (first_window || w->slot_sized[i])) { slot = i; return true; }
-                    return false;
+                    int sized = 0;
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) {
+                        sized += w->slot_sized[i];
+                        if (slot < 0 && w->slot_free[i] && (first_window || w->slot_sized[i])) slot = i;
+                    }
+                    if (slot >= 0) return true;
+                    return !first_window && w->sizing_done && sized < 2;   // (one window cannot turn over: the parser keeps it until the next arrives)
                 });
-                if (slot < 0) return;
+                if (slot < 0) {
+                    if (!w->abandoned) { lk.unlock(); if (drain()) fail_with("inflate: no pinned memory for two BGZF windows (TBK_BGZF_INFLATE=cpu inflates on the host)"); }
+                    return;
+                }
                 w->slot_free[slot] = false;
                 gpu_slot_wait_s += now() - t0;
             }
             if (first_window) {
                 first_window = false;
-                { std::lock_guard<std::mutex> lk(w->mu); w->slot_sized[slot] = true; }
                 const size_t in_b = span + span / 4, n_b = blks.size() + blks.size() / 4, out_b = head_room + out_total + out_total / 4;
-                sizer = std::thread([w, g, slot, in_b, n_b, out_b] {
-                    for (int i = 0; i < TBK_GINFLATE_SLOTS; i++) {
+                const char *limit = getenv("TBK_BGZF_GPU_SLOTS");   // (tests: as if the memory for more windows than this were not there)
+                const int max_slots = limit ? atoi(limit) : TBK_GINFLATE_SLOTS;
+                if (max_slots < 2 || tbk_ginflate_reserve(g, slot, in_b, n_b, out_b) != TBK_OK) {
+                    // not even one window's buffers: the host's threads inflate, from this very block on
+                    { std::lock_guard<std::mutex> lk(w->mu); w->slot_free[slot] = true; }
+                    (void)drain();
+                    gpu_device = -1;
+                    bgzf_loop();
+                    return;
+                }
+                { std::lock_guard<std::mutex> lk(w->mu); w->slot_sized[slot] = true; }
+                sizer = std::thread([w, g, slot, in_b, n_b, out_b, max_slots] {
+                    int have = 1;
+                    for (int i = 0; i < TBK_GINFLATE_SLOTS && have < max_slots; i++) {
                         if (i == slot) continue;
-                        { std::lock_guard<std::mutex> lk(w->mu); if (w->abandoned) return; }
-                        (void)tbk_ginflate_reserve(g, i, in_b, n_b, out_b);   // (a failure shows when the slot is used)
+                        { std::lock_guard<std::mutex> lk(w->mu); if (w->abandoned) break; }
+                        if (tbk_ginflate_reserve(g, i, in_b, n_b, out_b) != TBK_OK) break;
                         { std::lock_guard<std::mutex> lk(w->mu); w->slot_sized[i] = true; }
                         w->cv.notify_all();
+                        have++;
                     }
+                    { std::lock_guard<std::mutex> lk(w->mu); w->sizing_done = true; }
+                    w->cv.notify_all();
                 });
             }
             const double t0 = now();
@@ -1550,7 +1582,7 @@ static int regular_next_inflated(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64
         bool leave = false;
         // a window of the GPU inflater is parsed where it lies: like a plain file's mapping, it can keep the records of a batch (the batch
         // then ends with the window at the latest: what the next window brings goes into the next batch)
-        const int rc = regular_window(sc, src.text(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave, r->borrowing && src.view && src.held);
+        const int rc = regular_window(sc, src.text(), src.end, src.pos, b, max_bases - have_bases, max_reads - have_reads, &new_pos, &leave, r->borrowing && src.window_can_lend());
         if (rc) return rc;
         if (b->n_reads() > have_reads) {
             src.pos = new_pos;
