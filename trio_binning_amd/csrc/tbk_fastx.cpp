@@ -157,7 +157,7 @@ struct LineSource {
     bool bgzf = false;
     bool bgzf_seen = false;  // a BGZF member has been read: zero padding may follow it (Python's GzipFile skips it)
     // BGZF blocks inflated on the GPU (tbk_fastx_set_device; csrc/tbk_gdeflate.hip, second half): one wave per block, windows of
-    // 256 MB of the file three deep.  -1: on the host's threads.
+    // 96 MB of the file four deep.  -1: on the host's threads.
     int gpu_device = -1;
     uint64_t gpu_windows = 0, gpu_blocks = 0;
     double gpu_stage_s = 0, gpu_wait_s = 0, gpu_slot_wait_s = 0;
@@ -307,21 +307,23 @@ struct LineSource {
         *span = p;
         return 0;
     }
-    // BGZF on the GPU: windows of the mapped file (TBK_BGZF_GPU_WINDOW bytes, default 256 MB: ~9000 blocks, one wave each - what fills
-    // the chip) are copied into the inflater's pinned input by a few threads, inflated and CRC-checked on the device, and their text
-    // comes back into pinned memory, from where the parser takes it.  Three windows deep: one is staged while one is on the device and
-    // one is with the parser.  Anything that is not a BGZF block (an ordinary member behind the blocks), and any failure to set the
-    // inflater up, hands over to the host path exactly where bgzf_loop would be.
+    // BGZF on the GPU: windows of the mapped file (TBK_BGZF_GPU_WINDOW bytes, default 96 MB: ~3800 blocks, one wave each) are copied
+    // into the inflater's pinned input by a few threads, inflated and CRC-checked on the device, and their text comes back into pinned
+    // memory, where the parser reads it.  Four windows deep (TBK_GINFLATE_SLOTS): one is staged while one is on the device, one is with
+    // the parser and one more with it or with batches that left their records in it.  Measured at configs[1] scale (Gbases/s end to
+    // end): 256 MB x 5: 3.2, 128 MB x 8: 3.6-3.9, x 5: 4.0-4.2, x 4: 4.3-4.5, 96 MB x 4: 4.5 - the pinned memory costs a tenth of a
+    // second per 600 MB to get and as much to give back.  Anything that is not a BGZF block (an ordinary member behind the blocks),
+    // and any failure to set the inflater up, hands over to the host path exactly where bgzf_loop would be.
     void bgzf_loop_gpu() {
         tbk_ginflate *g = nullptr;
         if (tbk_ginflate_create(gpu_device, &g) != TBK_OK) { bgzf_loop(); return; }
         std::shared_ptr<GpuWindows> w = std::make_shared<GpuWindows>();
         w->g = g;   // (goes with the last window that is out, not with this thread)
         { std::lock_guard<std::mutex> lk(mu); windows = w; }
-        const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)128 << 20));
+        const size_t window = std::max<size_t>((size_t)1 << 16, env_size("TBK_BGZF_GPU_WINDOW", (size_t)96 << 20));
         // room in front of a window's text for what the parser has left of the window before (it asks for more when less than a batch's
         // worth, at most 64 MiB and a record, is at hand): the window is then parsed where it lies.  0 = every window is copied.
-        const size_t head_room = env_size("TBK_BGZF_GPU_ROOM", (size_t)96 << 20);
+        const size_t head_room = env_size("TBK_BGZF_GPU_ROOM", (size_t)72 << 20);
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         auto fail_with = [&](const std::string &msg) { Chunk c; c.err = msg; c.last = true; push(std::move(c)); };
         // The windows on the device, oldest first, and the thread that takes them home: it waits for a window's kernels, copies its text
@@ -426,7 +428,7 @@ struct LineSource {
             }
             if (first_window) {
                 first_window = false;
-                const size_t in_b = span + span / 4, n_b = blks.size() + blks.size() / 4, out_b = head_room + out_total + out_total / 4;
+                const size_t in_b = span + span / 10, n_b = blks.size() + blks.size() / 4, out_b = head_room + out_total + out_total / 10;   // (windows are cut to one size: a tenth of slack; a window that needs more grows its buffers)
                 const char *limit = getenv("TBK_BGZF_GPU_SLOTS");   // (tests: as if the memory for more windows than this were not there)
                 const int max_slots = limit ? atoi(limit) : TBK_GINFLATE_SLOTS;
                 if (max_slots < 2 || tbk_ginflate_reserve(g, slot, in_b, n_b, out_b) != TBK_OK) {

@@ -24,7 +24,7 @@ void tbk_gdeflate_stats(const tbk_gdeflate *g, uint64_t *text_bytes, uint64_t *m
 // ---- the other direction: bgzf blocks inflated on the device (tbk_gdeflate.hip, second half) -------------------------------------------
 struct tbk_ginflate;
 struct tbk_ginflate_block { uint64_t in_off; uint32_t in_len, out_len, crc; uint32_t pad_; };   // a raw deflate stream in the window's input; its text's length and CRC-32 (the bgzf trailer's)
-constexpr int TBK_GINFLATE_SLOTS = 8;   // one being staged, one on the device, one with the parser, the rest with the batches whose records stay in them
+constexpr int TBK_GINFLATE_SLOTS = 4;   // one being staged, one on the device, one with the parser, one more (measured at configs[1] scale: 8 -> 3.9, 5 -> 4.2, 4 -> 4.4 Gbases/s: their pinned memory costs more to get and to give back than lending it to the batches saves)
 int tbk_ginflate_create(int device, tbk_ginflate **out);
 void tbk_ginflate_destroy(tbk_ginflate *g);
 uint8_t *tbk_ginflate_input(tbk_ginflate *g, int slot, size_t bytes);

@@ -754,11 +754,11 @@ int gfail(int code, const char *what, hipError_t e) {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    hipError_t need(size_t n) {
+    hipError_t need(size_t n, bool exact = false) {   // (exact: the caller has put its slack into n already)
         if (n <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr; cap = 0;
-        const size_t c = n + n / 4 + 4096;
+        const size_t c = exact ? n + 4096 : n + n / 4 + 4096;
         const hipError_t e = hipMalloc(&p, c);
         if (e == hipSuccess) cap = c;
         return e;
@@ -768,11 +768,11 @@ struct DevBuf {
 struct PinBuf {
     void *p = nullptr;
     size_t cap = 0;
-    hipError_t need(size_t n) {
+    hipError_t need(size_t n, bool exact = false) {
         if (n <= cap) return hipSuccess;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        const size_t c = n + n / 4 + 4096;
+        const size_t c = exact ? n + 4096 : n + n / 4 + 4096;
         const hipError_t e = hipHostMalloc(&p, c, hipHostMallocPortable);
         if (e == hipSuccess) cap = c;
         return e;
@@ -1339,14 +1339,14 @@ int tbk_ginflate_reserve(tbk_ginflate *g, int slot, size_t in_bytes, size_t n_bl
     hipError_t e = hipSetDevice(g->device);
     if (e != hipSuccess) return gfail(TBK_ERR_HIP, "hipSetDevice", e);
     GiSlot &s = g->slots[slot];
-    e = s.h_in.need(in_bytes + 64);
+    e = s.h_in.need(in_bytes + 64, true);
     if (e == hipSuccess) e = s.h_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
     if (e == hipSuccess) e = s.h_members.need((n_blocks + 1) * sizeof(GdMember));
     if (e == hipSuccess) e = s.h_offs.need((n_blocks + 1) * 8);
     if (e == hipSuccess) e = s.h_bad.need(64);
-    if (e == hipSuccess) e = s.h_out.need(out_bytes + 64);
-    if (e == hipSuccess) e = s.d_in.need(in_bytes + 64);
-    if (e == hipSuccess) e = s.d_out.need(out_bytes + 64);
+    if (e == hipSuccess) e = s.h_out.need(out_bytes + 64, true);
+    if (e == hipSuccess) e = s.d_in.need(in_bytes + 64, true);
+    if (e == hipSuccess) e = s.d_out.need(out_bytes + 64, true);
     if (e == hipSuccess) e = s.d_blocks.need(n_blocks * sizeof(tbk_ginflate_block));
     if (e == hipSuccess) e = s.d_members.need((n_blocks + 1) * sizeof(GdMember));
     if (e == hipSuccess) e = s.d_offs.need((n_blocks + 1) * 8);
