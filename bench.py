@@ -1051,6 +1051,11 @@ def run_classify(args, np, kmers, lib, check, _lib, dev, dist, world, rank, plac
             out["bins_gzip_encoder"] = gzip_encoder_leg(np, kmers, lib, check, dev, par_bases, par_offs)
         except Exception as e:  # (a side record: it must not cost the bench line)
             print(f"bench: bins_gzip_encoder leg failed: {e}", file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_streaming and not ragged and not hap and hasattr(lib, "tbk_bgzf_bench_device"):
+        try:
+            out["input_bgzf_inflater"] = bgzf_inflater_leg(np, lib, check, dev, par_bases, par_offs)
+        except Exception as e:
+            print(f"bench: input_bgzf_inflater leg failed: {e}", file=sys.stderr)
 
     if args.calibrate and rank == 0:
         out["calibration"] = calibrate(lib, check, dev, stats["table_bytes"])
@@ -1102,6 +1107,52 @@ def gzip_encoder_leg(np, kmers, lib, check, dev, par_bases, par_offs):
         "kernels_only_text_GB_per_s": round(len(text) / ks.value / 1e9, 2), "kernels_ms_per_job": round(ks.value * 1e3, 3),
         "roofline": {"bound": "pcie", "achieved": round(len(text) / ps.value / 1e9, 2), "peak": link, "unit": "GB/s of text over the link", "frac": round(len(text) / ps.value / 1e9 / link, 3),
                      "hbm_frac_of_the_kernels": round((len(text) + ob.value) / ks.value / 1e9 / HBM_PEAK_GBPS, 4)},
+    }
+
+
+def bgzf_inflater_leg(np, lib, check, dev, par_bases, par_offs):
+    """What precedes the classify stage when the reads come as .fastq.gz written by bgzip / htslib (the reference reads any .gz through
+    gzip.open, seq.py:86-92): the reader inflates the file's blocks on the device (csrc/tbk_gdeflate.hip, second half).  This leg times
+    that inflater by itself on one window: the parity reads as FASTQ text with HiFi-like qualities, cut into 60 000-byte blocks and
+    deflated by zlib at level 6 (what bgzip writes) - the window's kernels between HIP events (input resident; every block's CRC-32
+    checked on the device in the timed region) and the ring as the reader drives it, staging copy and both link crossings included."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    rng = np.random.default_rng(0x5EED0007)
+    n_par = len(par_offs) - 1
+    n_reads = 2 * min(n_par, 4096)   # (the parity reads twice, with qualities of their own: about the 3 800 blocks of one of the reader's windows)
+    pieces, total = [], 0
+    for r in range(n_reads):
+        lo, hi = int(par_offs[r % n_par]), int(par_offs[r % n_par + 1])
+        q = np.clip(rng.normal(60, 15, hi - lo), 2, 93).astype(np.uint8)
+        q[rng.random(hi - lo) < 0.6] = 93
+        pieces += [b"@read%09d c\n" % r, par_bases[lo:hi].tobytes(), b"\n+\n", (q + 33).tobytes(), b"\n"]
+        total += hi - lo
+    text = b"".join(pieces)
+
+    def block(i):
+        blk = text[i:i + 60000]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(blk) + c.flush()
+        return struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, 18 + len(body) + 8 - 1) + body + struct.pack("<II", zlib.crc32(blk) & 0xFFFFFFFF, len(blk))
+
+    with ThreadPoolExecutor(os.cpu_count() or 4) as pool:   # (zlib releases the GIL)
+        data = b"".join(pool.map(block, range(0, len(text), 60000)))
+    n_blocks = (len(text) + 59999) // 60000
+    rs, ks, tb = C.c_double(), C.c_double(), C.c_uint64()
+    check(lib.tbk_bgzf_bench_device(dev, data, len(data), 12, C.byref(rs), C.byref(ks), C.byref(tb)))
+    assert tb.value == len(text)
+    return {
+        "what": "bgzf input inflated on the device (what the reader does with a .fastq.gz of bgzf blocks before the classify stage): the parity reads as FASTQ text with "
+                f"HiFi-like qualities, {n_blocks} blocks of 60 000 bytes deflated by zlib at level 6, one wave per block, every block's CRC-32 checked on the device",
+        "text_MB_per_window": round(len(text) / 1e6, 1), "deflated_MB_per_window": round(len(data) / 1e6, 1), "ratio": round(len(data) / len(text), 4), "blocks": n_blocks,
+        "kernels_only_text_GB_per_s": round(len(text) / ks.value / 1e9, 2), "kernels_ms_per_window": round(ks.value * 1e3, 3),
+        "ring_text_GB_per_s": round(len(text) / rs.value / 1e9, 2), "gbases_per_s_equivalent": round(total / rs.value / 1e9, 2),
+        "bound": "the kernel's scalar instructions: 56 per symbol against a SIMD's one scalar issue per four cycles (profiles/r06/ginflate_gate_pmc.json); its bytes "
+                 f"(read {round(len(data) / len(text), 2)} + write 1 per byte of text) would allow {round(HBM_PEAK_GBPS / (1 + len(data) / len(text)) / 1e3, 1)} TB/s",
+        "hbm_frac_of_the_kernels": round((len(text) + len(data)) / ks.value / 1e9 / HBM_PEAK_GBPS, 4),
     }
 
 

@@ -463,8 +463,12 @@ int tbk_gzip_members_device(int device, const char *text, const uint64_t *member
 /* The other direction (csrc/tbk_gdeflate.hip, second half): a bgzf file - the chain of independent <= 64 KiB gzip members that bgzip and
  * htslib write, which the reference reads through gzip.open like any .gz (seq.py:86-92) - inflated on `device`, one wave per block, every
  * block's CRC-32 checked there.  data / size: the file's bytes (or a run of whole blocks); *text_len: bytes of text.  The reader
- * (tbk_fastx_set_device) drives the same inflater three windows deep. */
+ * (tbk_fastx_set_device) drives the same inflater four windows deep. */
 int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint8_t *dst, uint64_t cap, uint64_t *text_len);
+/* The inflater timed by itself (bench.py's `input_bgzf_inflater`): one window of bgzf blocks, `reps` times - *kernels_s per window with the
+ * input resident (HIP events around inflate, CRC-32 and check), *ring_s per window through the ring as the reader drives it (staging
+ * copy, copy in, kernels, text home; two windows in flight); *text_bytes: a window's text. */
+int tbk_bgzf_bench_device(int device, const uint8_t *data, uint64_t size, int reps, double *ring_s, double *kernels_s, uint64_t *text_bytes);
 int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s,
                           double *kernels_s, uint64_t *out_bytes);
 int tbk_bin_writer_encoder(const tbk_bin_writer *w);

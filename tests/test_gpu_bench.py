@@ -70,3 +70,5 @@ def test_sub_records_of_the_default_line():
     assert out["roofline"]["traffic_source"].startswith("measured in this run")
     enc = out["bins_gzip_encoder"]   # the default line's record of the GPU gzip encoder behind the bins
     assert enc["text_GB_per_s"] > 1 and 0.2 < enc["ratio"] < 0.6 and enc["roofline"]["bound"] == "pcie"
+    inf = out["input_bgzf_inflater"]   # and of the GPU inflater in front of the reader (every block's CRC-32 checked in the timed region)
+    assert inf["kernels_only_text_GB_per_s"] > 1 and inf["ring_text_GB_per_s"] > 0.5 and 0.2 < inf["ratio"] < 0.6 and inf["blocks"] > 10

@@ -207,6 +207,8 @@ if hasattr(lib, "tbk_gzip_members_device"):
         _sig("tbk_fastx_inflates_on_device", C.c_int, _vp)
     if hasattr(lib, "tbk_bgzf_inflate_device"):
         _sig("tbk_bgzf_inflate_device", C.c_int, C.c_int, C.c_char_p, _u64, C.c_char_p, _u64, _u64p)
+    if hasattr(lib, "tbk_bgzf_bench_device"):
+        _sig("tbk_bgzf_bench_device", C.c_int, C.c_int, C.c_char_p, _u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _u64p)
     if hasattr(lib, "tbk_gzip_bench_device"):
         _sig("tbk_gzip_bench_device", C.c_int, C.c_int, _vp, _u64p, _u64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _u64p)
 _sig("tbk_gzip_member", C.c_int, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t))

@@ -1574,14 +1574,12 @@ extern "C" int tbk_gzip_bench_device(int device, const char *text, const uint64_
     return TBK_OK;
 }
 
+// the blocks of a bgzf file in memory (tbk_bgzf_inflate_device, tbk_bgzf_bench_device)
 // C-ABI (include/tbk.h): a whole bgzf file (or a run of its blocks) in host memory -> its text, inflated on `device`, one window,
-// synchronously.  What tests and tools call; the reader drives the same inflater three windows deep.  *text_len = bytes of text (also
+// synchronously.  What tests and tools call; the reader drives the same inflater four windows deep.  *text_len = bytes of text (also
 // when dst is too small: TBK_ERR_NOMEM); bytes that are not a bgzf block (an ordinary gzip member, garbage) end the run with
 // TBK_ERR_FORMAT; a block that does not decode or fails its CRC-32: TBK_ERR_FORMAT too.
-extern "C" int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint8_t *dst, uint64_t cap, uint64_t *text_len) {
-    if ((!data && size) || !text_len) { tbk_set_error_(TBK_ERR_INVALID, "tbk_bgzf_inflate_device: NULL argument"); return TBK_ERR_INVALID; }
-    *text_len = 0;
-    std::vector<tbk_ginflate_block> blocks;
+static int bgzf_blocks_of(const uint8_t *data, uint64_t size, std::vector<tbk_ginflate_block> &blocks, uint64_t *out_total_p) {
     uint64_t p = 0, out_total = 0;
     while (p < size) {
         if (data[p] == 0 && !blocks.empty()) { p++; continue; }   // zero padding between members (Python's gzip skips it too)
@@ -1598,6 +1596,16 @@ extern "C" int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t
         out_total += isize;
         p += bs;
     }
+    *out_total_p = out_total;
+    return TBK_OK;
+}
+
+extern "C" int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint8_t *dst, uint64_t cap, uint64_t *text_len) {
+    if ((!data && size) || !text_len) { tbk_set_error_(TBK_ERR_INVALID, "tbk_bgzf_inflate_device: NULL argument"); return TBK_ERR_INVALID; }
+    *text_len = 0;
+    std::vector<tbk_ginflate_block> blocks;
+    uint64_t out_total = 0;
+    { const int rc0 = bgzf_blocks_of(data, size, blocks, &out_total); if (rc0) return rc0; }
     *text_len = out_total;
     if (blocks.empty()) return TBK_OK;
     tbk_ginflate *g = nullptr;
@@ -1614,6 +1622,90 @@ extern "C" int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t
     if (!rc && bad) { tbk_set_error_(TBK_ERR_FORMAT, "inflate: corrupt BGZF block"); rc = TBK_ERR_FORMAT; }
     if (!rc && (n > cap || !dst)) { if (n) { tbk_set_error_(TBK_ERR_NOMEM, "tbk_bgzf_inflate_device: dst too small"); rc = TBK_ERR_NOMEM; } }
     if (!rc && n) memcpy(dst, text, n);
+    tbk_ginflate_destroy(g);
+    return rc;
+}
+
+// C-ABI (include/tbk.h; bench.py's `input_bgzf_inflater` record): the inflater by itself on one window of bgzf blocks in host memory.
+// *kernels_s: the window's kernels (inflate, CRC-32, check) between two HIP events, the input resident, mean of `reps` launches;
+// *ring_s: wall time per window of `reps` windows through the ring as the reader drives it (staging copy into pinned memory, copy in,
+// kernels, text home, two windows in flight).  Every window's text is checked against its blocks' CRC-32s on the device.
+extern "C" int tbk_bgzf_bench_device(int device, const uint8_t *data, uint64_t size, int reps, double *ring_s, double *kernels_s, uint64_t *text_bytes) {
+    if (!data || !size || reps < 2 || !ring_s || !kernels_s || !text_bytes) { tbk_set_error_(TBK_ERR_INVALID, "tbk_bgzf_bench_device: bad argument"); return TBK_ERR_INVALID; }
+    std::vector<tbk_ginflate_block> blocks;
+    uint64_t out_total = 0;
+    int rc = bgzf_blocks_of(data, size, blocks, &out_total);
+    if (rc) return rc;
+    if (blocks.empty() || !out_total) { tbk_set_error_(TBK_ERR_INVALID, "tbk_bgzf_bench_device: no blocks"); return TBK_ERR_INVALID; }
+    *text_bytes = out_total;
+    tbk_ginflate *g = nullptr;
+    rc = tbk_ginflate_create(device, &g);
+    if (rc) return rc;
+    uint8_t *text = nullptr;
+    size_t n = 0;
+    uint32_t bad = 0;
+    auto window = [&](int slot) -> int {
+        uint8_t *in = tbk_ginflate_input(g, slot, (size_t)size);
+        if (!in) { tbk_set_error_(TBK_ERR_NOMEM, "GPU inflater: no pinned memory for the input"); return TBK_ERR_NOMEM; }
+        memcpy(in, data, (size_t)size);
+        return tbk_ginflate_submit(g, slot, (size_t)size, blocks.data(), blocks.size(), 0);
+    };
+    auto home = [&](int slot) -> int {
+        int r = tbk_ginflate_wait(g, slot, &text, &n, &bad);
+        if (!r && (bad || n != out_total)) { tbk_set_error_(TBK_ERR_FORMAT, "inflate: corrupt BGZF block"); r = TBK_ERR_FORMAT; }
+        return r;
+    };
+    // both slots' buffers exist
+    for (int slot = 0; slot < 2 && !rc; slot++) { rc = window(slot); if (!rc) rc = home(slot); }
+    // the kernels alone: slot 0's input is on the device
+    if (!rc) {
+        GiSlot &s = g->slots[0];
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        uint32_t longest = 0;
+        for (const tbk_ginflate_block &b : blocks) longest = std::max(longest, b.out_len);
+        const size_t nb = blocks.size();
+        const size_t wgs = std::min<size_t>((nb + GI_WAVES - 1) / GI_WAVES, (size_t)g->cus * (size_t)g->resident_wgs);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, g->stream);
+        for (int i = 0; i < reps && e == hipSuccess; i++) {
+            e = hipMemsetAsync(s.d_bad.p, 0, 64, g->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(s.d_crc.p, 0, (nb + 1) * 4, g->stream);
+            hipLaunchKernelGGL(gi_inflate_kernel, dim3((unsigned)wgs), dim3(64 * GI_WAVES), 0, g->stream, (const uint8_t *)s.d_in.p, (const tbk_ginflate_block *)s.d_blocks.p,
+                               (const uint64_t *)s.d_offs.p, (uint32_t)nb, (uint8_t *)s.d_out.p, (uint32_t *)s.d_bad.p);
+            for (size_t first = 0; first < nb; first += 65535) {
+                const size_t part = std::min<size_t>(65535, nb - first);
+                hipLaunchKernelGGL(gd_crc_kernel, dim3((unsigned)std::max<uint64_t>(1, (((uint64_t)longest + 63) / 64 + GD_T - 1) / GD_T), (unsigned)part), dim3(GD_T), 0, g->stream,
+                                   (const uint8_t *)s.d_out.p, (const GdMember *)s.d_members.p + first, (const GdCrcTabs *)g->d_crc_tabs, g->x2n, (uint32_t *)s.d_crc.p + first);
+            }
+            hipLaunchKernelGGL(gi_check_kernel, dim3((unsigned)((nb + GD_T - 1) / GD_T)), dim3(GD_T), 0, g->stream, (const tbk_ginflate_block *)s.d_blocks.p, (const uint32_t *)s.d_crc.p,
+                               (uint32_t)nb, (uint32_t *)s.d_bad.p);
+            if (e == hipSuccess) e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, g->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        uint32_t h_bad[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpy(h_bad, s.d_bad.p, 8, hipMemcpyDeviceToHost);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (e != hipSuccess) rc = gfail(TBK_ERR_HIP, "bench events", e);
+        else if (h_bad[0] + h_bad[1]) { tbk_set_error_(TBK_ERR_FORMAT, "inflate: corrupt BGZF block"); rc = TBK_ERR_FORMAT; }
+        *kernels_s = (double)ms * 1e-3 / reps;
+    }
+    // the ring: window i + 1 staged and queued while window i is on the device
+    if (!rc) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = window(0);
+        for (int i = 1; i < reps && !rc; i++) {
+            rc = window(i & 1);
+            if (!rc) rc = home((i - 1) & 1);
+        }
+        if (!rc) rc = home((reps - 1) & 1);
+        *ring_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
     tbk_ginflate_destroy(g);
     return rc;
 }
