@@ -413,7 +413,10 @@ int tbk_fastx_next(tbk_fastx_reader *r, tbk_fastx_batch *b, uint64_t max_bases, 
 int tbk_fastx_set_packing(tbk_fastx_reader *r, int on);
 /* BGZF input (bgzip / htslib: independent gzip members of <= 64 KiB, which the reference reads through gzip.open like any .gz,
  * seq.py:86-92) inflated on `device` - csrc/tbk_gdeflate.hip: one wave per block, CRC-32s checked there - instead of on the host's
- * threads.  Before the first read; other inputs are read as before.  tbk_fastx_inflates_on_device: 1 when that is what happens. */
+ * threads.  Before the first read; other inputs are read as before.  tbk_fastx_inflates_on_device: 1 when that is what happens.  The text
+ * arrives in windows of pinned memory, four deep; the chunk-parallel scan reads it there, and with tbk_fastx_set_borrowing a batch may
+ * leave its records in a window (while two more are free) - it keeps the window, and the inflater's memory, alive until it is refilled
+ * or destroyed.  When the pinned memory for two windows cannot be had, the host's threads inflate after all. */
 int tbk_fastx_set_device(tbk_fastx_reader *r, int device);
 int tbk_fastx_inflates_on_device(const tbk_fastx_reader *r);
 int tbk_fastx_batch_packed(const tbk_fastx_batch *b, const uint32_t **codes, const uint32_t **exc_chunk, const uint16_t **exc_mask,
@@ -460,6 +463,8 @@ int tbk_gzip_members_device(int device, const char *text, const uint64_t *member
 /* The encoder timed by itself (tools/measure_gdeflate.py): `reps` jobs of these members (text in pinned host memory: tbk_host_alloc)
  * through the three-deep ring - *pipelined_s per job, the link included - and one job's kernels between HIP events on their own
  * stream - *kernels_s; *out_bytes = bytes of members a job makes. */
+int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s,
+                          double *kernels_s, uint64_t *out_bytes);
 /* The other direction (csrc/tbk_gdeflate.hip, second half): a bgzf file - the chain of independent <= 64 KiB gzip members that bgzip and
  * htslib write, which the reference reads through gzip.open like any .gz (seq.py:86-92) - inflated on `device`, one wave per block, every
  * block's CRC-32 checked there.  data / size: the file's bytes (or a run of whole blocks); *text_len: bytes of text.  The reader
@@ -469,8 +474,6 @@ int tbk_bgzf_inflate_device(int device, const uint8_t *data, uint64_t size, uint
  * input resident (HIP events around inflate, CRC-32 and check), *ring_s per window through the ring as the reader drives it (staging
  * copy, copy in, kernels, text home; two windows in flight); *text_bytes: a window's text. */
 int tbk_bgzf_bench_device(int device, const uint8_t *data, uint64_t size, int reps, double *ring_s, double *kernels_s, uint64_t *text_bytes);
-int tbk_gzip_bench_device(int device, const char *text, const uint64_t *member_len, uint64_t n_members, int reps, double *pipelined_s,
-                          double *kernels_s, uint64_t *out_bytes);
 int tbk_bin_writer_encoder(const tbk_bin_writer *w);
 int tbk_bin_writer_write(tbk_bin_writer *w, const tbk_fastx_batch *b, const char *bins);
 int tbk_bin_writer_close(tbk_bin_writer *w);
