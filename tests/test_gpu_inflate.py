@@ -200,13 +200,17 @@ def test_reader_and_cli_from_bgzf_on_the_device(gpu, capfd, tmp_path, monkeypatc
     fq.write_bytes(bgzf("".join(f">r{i} some comment\n{s}\n" for i, s in enumerate(v["reads"])).encode(), 6, 3000))
     monkeypatch.setenv("TBK_BGZF_GPU_WINDOW", "8000")
     monkeypatch.setenv("TBK_WRITE_TIMING", "1")
-    od = tmp_path / "out"
-    od.mkdir()
-    with patch("sys.argv", ["classify-by-kmers", str(fq), str(fa), str(fb), "--haplotype-a-out-prefix", str(od / "hapA"),
-                            "--haplotype-b-out-prefix", str(od / "hapB"), "--unclassified-out-prefix", str(od / "unclassified")]):
-        cbk.main()
-    out, err = capfd.readouterr()
-    assert out == v["cli_stdout"]
-    for fn, digest in v["cli_bins"].items():
-        assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, fn
-    assert "tbk-gpu-bgzf" in err and " 0 windows" not in err, err[-500:]
+    monkeypatch.setattr(cbk, "_BATCH_BASES", 3000)
+    monkeypatch.setattr(cbk, "_BATCH_READS", 20)
+    for devices in ("0", "0,0"):   # (two rings on the device beside the inflater and the bins' encoder)
+        monkeypatch.setenv("TBK_DEVICES", devices)
+        od = tmp_path / ("out" + devices.replace(",", "_"))
+        od.mkdir()
+        with patch("sys.argv", ["classify-by-kmers", str(fq), str(fa), str(fb), "--haplotype-a-out-prefix", str(od / "hapA"),
+                                "--haplotype-b-out-prefix", str(od / "hapB"), "--unclassified-out-prefix", str(od / "unclassified")]):
+            cbk.main()
+        out, err = capfd.readouterr()
+        assert out == v["cli_stdout"], devices
+        for fn, digest in v["cli_bins"].items():
+            assert hashlib.sha256(gzip.open(od / fn, "rb").read()).hexdigest() == digest, (fn, devices)
+        assert "tbk-gpu-bgzf" in err and " 0 windows" not in err, err[-500:]
