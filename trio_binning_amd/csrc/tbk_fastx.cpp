@@ -50,6 +50,8 @@
 uint32_t tbk_crc32(uint32_t crc, const uint8_t *p, size_t n);  // tbk_crc.cpp: zlib's crc32() by carry-less multiplication
 
 extern "C" void tbk_set_error_(int code, const char *msg);  // tbk_host.cpp
+extern "C" void *tbk_pin_alloc_(size_t bytes);              // tbk_host.cpp: pinned staging memory (huge pages registered with the runtime)
+extern "C" void tbk_pin_free_(void *p);
 
 static int ffail(int code, const char *fmt, ...) {
     char buf[512];
@@ -1037,7 +1039,7 @@ struct FastxMapping {
 };
 
 struct tbk_fastx_batch {
-    uint8_t *bases = nullptr;  // pinned (hipHostMalloc) when a device is present, else malloc
+    uint8_t *bases = nullptr;  // pinned (tbk_pin_alloc_) when a device is present, else malloc
     size_t bases_cap = 0;
     bool pinned = false;
     std::vector<uint64_t> base_off{0};
@@ -1071,10 +1073,10 @@ struct tbk_fastx_batch {
 
     ~tbk_fastx_batch() {
         release();
-        if (codes) { if (codes_pinned) (void)hipHostFree(codes); else free(codes); }
+        if (codes) { if (codes_pinned) tbk_pin_free_(codes); else free(codes); }
     }
     void release() {  // the bases buffer (reserve_bases replaces it when it grows)
-        if (bases) { if (pinned) (void)hipHostFree(bases); else free(bases); }
+        if (bases) { if (pinned) tbk_pin_free_(bases); else free(bases); }
         bases = nullptr; bases_cap = 0;
     }
     bool reserve_codes(size_t need_chunks) {
@@ -1082,16 +1084,16 @@ struct tbk_fastx_batch {
         const size_t cap = std::max<size_t>(need_chunks + need_chunks / 2, (size_t)1 << 18);
         uint32_t *nc = nullptr;
         bool np = false;
-        if (pinned && hipHostMalloc((void **)&nc, cap * sizeof(uint32_t), hipHostMallocPortable) == hipSuccess) np = true;
-        else { (void)hipGetLastError(); nc = (uint32_t *)malloc(cap * sizeof(uint32_t)); }
+        if (pinned && (nc = (uint32_t *)tbk_pin_alloc_(cap * sizeof(uint32_t))) != nullptr) np = true;
+        else nc = (uint32_t *)malloc(cap * sizeof(uint32_t));
         if (!nc) return false;
         if (codes && codes_cap) memcpy(nc, codes, codes_cap * sizeof(uint32_t));
-        if (codes) { if (codes_pinned) (void)hipHostFree(codes); else free(codes); }
+        if (codes) { if (codes_pinned) tbk_pin_free_(codes); else free(codes); }
         codes = nc; codes_cap = cap; codes_pinned = np;
         return true;
     }
     // Pinned when a device is there (the batch then goes to the GPU without a staging copy).
-    // Pinning is tried once per process: a failing hipHostMalloc (no device) is slow.
+    // Pinning is tried once per process: a failing attempt (no device) is slow.
     bool reserve_bases(size_t need) {
         if (need <= bases_cap) return true;
         static std::atomic<int> pin_state{0};  // 0 unknown, 1 works, -1 does not
@@ -1099,8 +1101,8 @@ struct tbk_fastx_batch {
         uint8_t *nb = nullptr;
         bool np = false;
         if (pin_state.load() >= 0) {
-            if (hipHostMalloc((void **)&nb, cap, hipHostMallocPortable) == hipSuccess) { np = true; pin_state.store(1); }
-            else { (void)hipGetLastError(); nb = nullptr; pin_state.store(-1); }
+            if ((nb = (uint8_t *)tbk_pin_alloc_(cap)) != nullptr) { np = true; pin_state.store(1); }
+            else pin_state.store(-1);
         }
         if (!nb) nb = (uint8_t *)malloc(cap);
         if (!nb) return false;
@@ -1904,17 +1906,17 @@ extern "C" int tbk_format_tsv(const tbk_fastx_batch *b, const char *bins, const 
 struct TextBuf {
     char *p = nullptr;
     size_t n = 0, cap = 0;
-    bool pinned = false;  // hipHostMalloc'ed: what the GPU gzip encoder copies its text from (set before the first grow_to)
+    bool pinned = false;  // pinned (tbk_pin_alloc_): what the GPU gzip encoder copies its text from (set before the first grow_to)
     ~TextBuf() { release(); }
-    void release() { if (p) { if (pinned) (void)hipHostFree(p); else free(p); } p = nullptr; cap = 0; }
+    void release() { if (p) { if (pinned) tbk_pin_free_(p); else free(p); } p = nullptr; cap = 0; }
     bool grow_to(size_t need) {
         if (need <= cap) return true;
         size_t c = std::max(need + need / 4, (size_t)1 << 20);
         if (pinned) {
-            char *q = nullptr;
-            if (hipHostMalloc((void **)&q, c, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return false; }
+            char *q = (char *)tbk_pin_alloc_(c);
+            if (!q) return false;
             if (n) memcpy(q, p, n);
-            if (p) (void)hipHostFree(p);
+            if (p) tbk_pin_free_(p);
             p = q; cap = c;
             return true;
         }

@@ -751,6 +751,9 @@ int gfail(int code, const char *what, hipError_t e) {
     return code;
 }
 
+extern "C" void *tbk_pin_alloc_(size_t bytes);   // tbk_host.cpp
+extern "C" void tbk_pin_free_(void *p);
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -770,14 +773,15 @@ struct PinBuf {
     size_t cap = 0;
     hipError_t need(size_t n, bool exact = false) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
+        if (p) tbk_pin_free_(p);
         p = nullptr; cap = 0;
         const size_t c = exact ? n + 4096 : n + n / 4 + 4096;
-        const hipError_t e = hipHostMalloc(&p, c, hipHostMallocPortable);
-        if (e == hipSuccess) cap = c;
-        return e;
+        p = tbk_pin_alloc_(c);   // (huge pages registered with the runtime: a third of hipHostMalloc's cost, tbk_host.cpp)
+        if (!p) return hipErrorOutOfMemory;
+        cap = c;
+        return hipSuccess;
     }
-    void drop() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void drop() { if (p) tbk_pin_free_(p); p = nullptr; cap = 0; }
 };
 
 struct Job {

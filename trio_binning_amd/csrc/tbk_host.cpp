@@ -2593,6 +2593,54 @@ extern "C" void *tbk_host_alloc(size_t bytes) {
 }
 extern "C" void tbk_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
+// Pinned staging memory for the big streaming buffers (the reader's GPU windows, the bin writer's text, the batches): transparent huge
+// pages mapped by the process itself and registered with the runtime, instead of hipHostMalloc.  Measured on the pool's boxes
+// (tools/pin_cost.hip, 432 MB): hipHostMalloc 65-88 ms + hipHostFree 47-78 ms; mmap + MADV_HUGEPAGE + touch 27 ms, hipHostRegister
+// 1.5 ms, unregister + munmap 17 ms - and the same 57 GB/s both ways over the link.  A run that holds 2-3 GB of such buffers used to
+// spend half a second getting them and giving them back.  Used only as the source or target of hipMemcpyAsync (no kernel reads it
+// through a device pointer).  Where mapping or registering fails, and under TBK_PINNED=malloc: hipHostMalloc.
+namespace {
+struct PinnedMap { void *map; size_t len; bool registered; };
+std::mutex pinned_mu;
+std::vector<std::pair<void *, PinnedMap>> pinned_maps;   // (a handful of live buffers: a vector does)
+}  // namespace
+
+extern "C" void *tbk_pin_alloc_(size_t bytes) {
+    if (!bytes) bytes = 1;
+    static const bool plain = [] { const char *e = getenv("TBK_PINNED"); return e && strcmp(e, "malloc") == 0; }();
+    constexpr size_t HUGE = (size_t)2 << 20;
+    if (!plain && bytes >= HUGE) {
+        const size_t len = (bytes + HUGE - 1) & ~(HUGE - 1);
+        void *m = mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m != MAP_FAILED) {
+            uint8_t *a = (uint8_t *)(((uintptr_t)m + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+            (void)madvise(a, len, MADV_HUGEPAGE);
+            for (size_t off = 0; off < len; off += 4096) a[off] = 0;   // (the pages exist before they are pinned: faulted in here, two megabytes at a time)
+            if (hipHostRegister(a, len, hipHostRegisterPortable) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(pinned_mu);
+                pinned_maps.emplace_back((void *)a, PinnedMap{m, len + HUGE, true});
+                return a;
+            }
+            (void)hipGetLastError();
+            munmap(m, len + HUGE);
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void tbk_pin_free_(void *p) {
+    if (!p) return;
+    PinnedMap pm{nullptr, 0, false};
+    {
+        std::lock_guard<std::mutex> lk(pinned_mu);
+        for (size_t i = 0; i < pinned_maps.size(); i++)
+            if (pinned_maps[i].first == p) { pm = pinned_maps[i].second; pinned_maps[i] = pinned_maps.back(); pinned_maps.pop_back(); break; }
+    }
+    if (pm.registered) { (void)hipHostUnregister(p); munmap(pm.map, pm.len); return; }
+    (void)hipHostFree(p);
+}
+
 extern "C" int tbk_classify_device(tbk_classifier *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                                    uint64_t total_bases, void *d_counts) {
     if (!c || (n_reads && (!d_offsets || !d_counts)) || (total_bases && !d_bases)) return fail(TBK_ERR_INVALID, "NULL argument");
