@@ -831,12 +831,14 @@ static bool par_pread(int fd, uint8_t *dst, size_t n, size_t off, uint64_t *sum6
 // The staging buffers outlive a list: the command line loads two lists one after the other, and pinning 2 x 128 MB
 // again for the second costs a third of its 0.18 s.  They are kept until a classifier is made of the lists
 // (tbk_classifier_create lets them go) or another size is asked for.
+extern "C" void *tbk_pin_alloc_(size_t bytes);
+extern "C" void tbk_pin_free_(void *p);
 struct ListStaging {
     std::mutex mu;
     uint8_t *h[2] = {nullptr, nullptr};
     size_t bytes = 0;
     void release_locked() {
-        for (uint8_t *&b : h) { if (b) (void)hipHostFree(b); b = nullptr; }
+        for (uint8_t *&b : h) { if (b) tbk_pin_free_(b); b = nullptr; }
         bytes = 0;
     }
 };
@@ -858,7 +860,7 @@ static int staged_file_upload(int fd, size_t file_off, size_t bytes, size_t piec
     hipError_t e = hipSuccess;
     if (g_list_staging.bytes != piece_bytes) g_list_staging.release_locked();
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        if (!g_list_staging.h[i]) e = hipHostMalloc((void **)&g_list_staging.h[i], piece_bytes, hipHostMallocPortable);
+        if (!g_list_staging.h[i] && !(g_list_staging.h[i] = (uint8_t *)tbk_pin_alloc_(piece_bytes))) e = hipErrorOutOfMemory;   // (huge pages, registered: below)
         h[i] = g_list_staging.h[i];
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
     }
