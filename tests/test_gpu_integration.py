@@ -42,6 +42,11 @@ def test_integration_snippet_runs_the_reference_kats(gpu, letter, capfd, tmp_pat
         for kmer, value in kat["kmer_to_int"]:
             assert ns["kmer_to_int"](kmer) == value
         for kmer, value in kat["reverse_complement"]:
+            # (the reference's binding, kmers.py:89-93, lets the C function write into a `bytes` object; for a k-mer of ONE base that
+            # object is CPython's shared b"x", and every b"x" of the process reads "G" from then on - found when a later test compared one.
+            # The one-base vector is the oracle's business, tests/test_oracle_golden.py; here it would poison the interpreter.)
+            if len(kmer) == 1:
+                continue
             assert ns["reverse_complement"](kmer) == value
         with pytest.raises(IOError):
             ns["create_kmer_hash_set"](os.path.join(DATA, "no_such_list.txt"))
