@@ -1032,12 +1032,14 @@ void tbk_gdeflate_stats(const tbk_gdeflate *g, uint64_t *text_bytes, uint64_t *m
 // A .fastq.gz written by bgzip / htslib is a chain of independent gzip members of at most 64 KiB of text (the BC extra field says how
 // long each one is): the reference reads it through gzip.open like any other (seq.py:86-92), this reader inflated its blocks side by
 // side on the host's threads - 6.5 GB/s of text on 16 of them, what a run from bgzf input waited for.  Here ONE WAVE inflates a block,
-// nine thousand blocks at a time.  The decoder is written uniformly - every lane runs the same control flow on the same values, which
-// the compiler keeps in scalar registers; the Huffman tables of the current deflate block live in LDS (built by the wave: canonical
-// order by one lane, the 10-bit / 9-bit look-up tables by all); a literal is one store (every lane writes the same byte to the same
-// place: no lane mask to set up); a match is copied by the lanes side by side (dst[i] = src[i mod dist]).  22-25 GB/s of text
-// (tools/ginflate_gate.hip: the measurement this was built on).  Every block's CRC-32 is summed on the device (gd_crc_kernel) and compared
-// with its trailer's; a block that does not decode, or whose CRC differs, is counted and the caller told.
+// some four thousand blocks to a window.  The decoder is written uniformly - every lane runs the same control flow on the same values,
+// and the values are kept in scalar registers (readfirstlane behind the wave index and behind every LDS read: the compiler cannot
+// know they are uniform); the Huffman tables of the current deflate block live in LDS (built by the wave: canonical order by one
+// lane, the 10-bit / 9-bit look-up tables by all); a literal is one store (every lane writes the same byte to the same place: no lane
+// mask to set up); a match is copied by the lanes side by side (dst[i] = src[i mod dist]).  22-25 GB/s of text, bound by the 56 scalar
+// instructions a symbol costs (tools/ginflate_gate.hip: the measurement this was built on, and three decoders that were not faster).
+// Every block's CRC-32 is summed on the device (gd_crc_kernel) and compared with its trailer's; a block that does not decode, or whose
+// CRC differs, is counted and the caller told.
 constexpr int GI_FAST_BITS = 10, GI_DFAST_BITS = 9;
 constexpr int GI_WAVES = 4;
 
@@ -1277,7 +1279,7 @@ struct GiSlot {
 struct tbk_ginflate {
     int device = 0;
     hipStream_t stream = nullptr, stream_in = nullptr, stream_out = nullptr;
-    hipEvent_t in_done = nullptr, k_done = nullptr;
+    hipEvent_t in_done = nullptr;
     GdX2n x2n = gd_x2n_table();
     GdCrcTabs *d_crc_tabs = nullptr;
     GiSlot slots[TBK_GINFLATE_SLOTS];
@@ -1301,7 +1303,6 @@ int tbk_ginflate_create(int device, tbk_ginflate **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_in, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream_out, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->in_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->k_done, hipEventDisableTiming);
     for (GiSlot &s : g->slots) if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
     if (e == hipSuccess) {
         GdCrcTabs tabs;
@@ -1320,7 +1321,6 @@ void tbk_ginflate_destroy(tbk_ginflate *g) {
         for (hipStream_t s : {g->stream, g->stream_in, g->stream_out}) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
         for (GiSlot &s : g->slots) s.drop();
         if (g->in_done) (void)hipEventDestroy(g->in_done);
-        if (g->k_done) (void)hipEventDestroy(g->k_done);
         if (g->d_crc_tabs) (void)hipFree(g->d_crc_tabs);
     }
     delete g;
