@@ -2617,6 +2617,7 @@ extern "C" void *tbk_pin_alloc_(size_t bytes) {
         if (m != MAP_FAILED) {
             uint8_t *a = (uint8_t *)(((uintptr_t)m + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
             (void)madvise(a, len, MADV_HUGEPAGE);
+            (void)madvise(a, len, MADV_DONTFORK);   // (a child - subprocess.run in the caller - must not share pages the device copies into: no copy-on-write under a transfer)
             for (size_t off = 0; off < len; off += 4096) a[off] = 0;   // (the pages exist before they are pinned: faulted in here, two megabytes at a time)
             if (hipHostRegister(a, len, hipHostRegisterPortable) == hipSuccess) {
                 std::lock_guard<std::mutex> lk(pinned_mu);
